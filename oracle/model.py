@@ -1,0 +1,359 @@
+"""
+oracle/model.py -- TEST INFRASTRUCTURE ONLY.
+
+Functional CPU (torch fp32) restatement of the reference's ObjectDetector (VGG16 trunk,
+`gtbox` and `refinerels` eval paths) and RelModel / LinearizedContext forward, written over a
+plain state-dict whose keys are the reference's own, so a product model's
+``state_dict()`` can be fed in unchanged.
+
+  trunk / heads        lib/object_detector.py:78-138, :300-303, :623-633
+  RPN head             lib/object_detector.py:488-612
+  context ordering     lib/rel_model.py:31-61, :139-169; lib/pytorch_misc.py:278-287, :365-384
+  LinearizedContext    lib/rel_model.py:171-296
+  RelModel.forward     lib/rel_model.py:403-547
+  union features       lib/get_union_boxes.py:15-93
+  FrequencyBias        lib/sparse_targets.py:32-37
+  filter_dets          lib/surgery.py:21-59
+
+Third-party arithmetic (conv, GEMM, softmax, BN) comes from today's PyTorch CPU kernels; the
+reference pinned PyTorch 0.3/cuDNN for it (README.md:21) and ships no vectors -> tolerance 1e-4.
+
+Randomness is *injected*: every dropout / sampling site draws from the ``HostRNG`` passed in,
+in the reference's call order, so the HIP path can reproduce the exact masks.
+"""
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from . import boxes as B
+from . import lstm as L
+from . import native
+
+VGG_CONVS = (0, 2, 5, 7, 10, 12, 14, 17, 19, 21, 24, 26, 28)
+VGG_POOLS_AFTER = (2, 7, 14, 21)
+BATCHNORM_MOMENTUM = 0.01
+
+
+class HostRNG(object):
+    """Seeded host-side source of dropout masks (numpy MT19937), consumed in call order."""
+
+    def __init__(self, seed):
+        self.rs = np.random.RandomState(seed)
+
+    def keep_mask(self, shape, keep_prob):
+        """float32 {0,1} mask with P(1)=keep_prob."""
+        return torch.from_numpy((self.rs.random_sample(tuple(shape)) < keep_prob).astype(np.float32))
+
+
+def dropout(x, p, training, rng):
+    if not training or p == 0.0:
+        return x
+    return x * rng.keep_mask(x.shape, 1.0 - p) / (1.0 - p)
+
+
+# --------------------------------------------------------------------------- trunk + heads
+def vgg_features(sd, x, prefix='detector.features.'):
+    for idx in VGG_CONVS:
+        x = F.relu(F.conv2d(x, sd[prefix + '%d.weight' % idx], sd[prefix + '%d.bias' % idx], padding=1))
+        if idx in VGG_POOLS_AFTER:
+            x = F.max_pool2d(x, 2, 2)
+    return x
+
+
+class _RoIAlignFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, feat, rois, ph, pw, scale):
+        ctx.save_for_backward(rois)
+        ctx.meta = (tuple(feat.shape), scale)
+        return torch.from_numpy(native.roi_align_fwd(feat.detach().numpy(), rois.numpy(), ph, pw, scale))
+
+    @staticmethod
+    def backward(ctx, g):
+        (rois,) = ctx.saved_tensors
+        shape, scale = ctx.meta
+        return torch.from_numpy(native.roi_align_bwd(g.contiguous().numpy(), rois.numpy(), shape, scale)), \
+            None, None, None, None
+
+
+def roi_align(feat, rois, ph=7, pw=7, spatial_scale=1.0 / 16):
+    return _RoIAlignFn.apply(feat, rois.detach(), ph, pw, spatial_scale)
+
+
+def vgg_classifier(sd, x, prefix, training, rng, use_dropout=True, use_relu=True):
+    """load_vgg(...).classifier (object_detector.py:623-633): fc6,ReLU,Dropout,fc7[,ReLU[,Dropout]]"""
+    x = F.relu(F.linear(x, sd[prefix + '0.weight'], sd[prefix + '0.bias']))
+    x = dropout(x, 0.5, training, rng)
+    x = F.linear(x, sd[prefix + '3.weight'], sd[prefix + '3.bias'])
+    if use_relu:
+        x = F.relu(x)
+        if use_dropout:
+            x = dropout(x, 0.5, training, rng)
+    return x
+
+
+def rpn_head(sd, fmap, prefix='detector.rpn_head.'):
+    """RPNHead.forward (object_detector.py:521-531) -> [B,h,w,A,6]"""
+    x = F.conv2d(fmap, sd[prefix + 'conv.0.weight'], sd[prefix + 'conv.0.bias'], padding=1)
+    x = F.relu6(x)
+    x = F.conv2d(x, sd[prefix + 'conv.2.weight'], sd[prefix + 'conv.2.bias'])
+    b, nc, h, w = x.shape
+    x = x.view(b, nc, -1).transpose(1, 2).contiguous().view(b, h, w, nc)
+    return x.view(b, h, w, nc // 6, 6)
+
+
+def detector_forward(sd, cfg, x, im_sizes, image_offset, gt_boxes, gt_classes, training, rng,
+                     rel_labels=None):
+    """
+    ObjectDetector.forward for mode 'gtbox' (sgcls / predcls) and eval 'refinerels' (sgdet).
+    Returns a dict with the Result fields the RelModel reads.
+    `rel_labels`: the sampled relation rows (host sampler output) for gtbox training.
+    """
+    fmap = vgg_features(sd, x)
+    res = {'fmap': fmap}
+    if cfg['mode'] in ('sgcls', 'predcls'):
+        im_inds = gt_classes[:, 0] - image_offset
+        rois = torch.cat((im_inds.float()[:, None], gt_boxes), 1)
+        obj_fmap = vgg_classifier(sd, roi_align(fmap, rois).view(rois.size(0), -1),
+                                  'detector.roi_fmap.', training, rng)
+        od_obj_dists = F.linear(obj_fmap, sd['detector.score_fc.weight'], sd['detector.score_fc.bias'])
+        res.update(im_inds=rois[:, 0].long() + image_offset, rm_obj_dists=od_obj_dists,
+                   od_obj_dists=od_obj_dists, rm_box_priors=rois[:, 1:], rm_obj_labels=gt_classes[:, 1],
+                   rel_labels=rel_labels, boxes_all=None, obj_fmap=obj_fmap)
+        return res
+    # sgdet eval: RPN -> proposals -> RoI head -> per-class NMS
+    assert not training, "oracle covers sgdet eval only"
+    feats = rpn_head(sd, fmap)
+    rois = B.roi_proposals(feats, sd['detector.rpn_head.anchors'], im_sizes, nms_thresh=0.7,
+                           pre_nms_topn=6000, post_nms_topn=1000)
+    obj_fmap = vgg_classifier(sd, roi_align(fmap, rois).view(rois.size(0), -1),
+                              'detector.roi_fmap.', training, rng)
+    od_obj_dists = F.linear(obj_fmap, sd['detector.score_fc.weight'], sd['detector.score_fc.bias'])
+    od_box_deltas = F.linear(obj_fmap, sd['detector.bbox_fc.weight'], sd['detector.bbox_fc.bias']).view(
+        -1, od_obj_dists.size(1), 4)
+    out = B.nms_boxes(od_obj_dists, rois, od_box_deltas, im_sizes, max_per_img=cfg.get('max_per_img', 64),
+                      thresh=cfg.get('thresh', 0.01))
+    if out is None:
+        return None
+    nms_inds, nms_scores, nms_preds, nms_boxes_assign, nms_boxes, nms_imgs = out
+    res.update(im_inds=nms_imgs + image_offset, rm_obj_dists=od_obj_dists[nms_inds],
+               od_obj_dists=od_obj_dists, rm_box_priors=nms_boxes[:, 0], rm_obj_labels=None,
+               rel_labels=None, boxes_all=nms_boxes, obj_fmap=obj_fmap[nms_inds], rois=rois,
+               nms_inds=nms_inds, obj_scores=nms_scores, obj_preds=nms_preds)
+    return res
+
+
+# --------------------------------------------------------------------------- context ordering
+def transpose_packed_sequence_inds(lengths):
+    """lib/pytorch_misc.py:365-384"""
+    new_inds, new_lens = [], []
+    cum_add = np.cumsum([0] + list(lengths))
+    max_len = lengths[0]
+    length_pointer = len(lengths) - 1
+    for i in range(max_len):
+        while length_pointer > 0 and lengths[length_pointer] <= i:
+            length_pointer -= 1
+        new_inds.append(cum_add[:(length_pointer + 1)].copy())
+        cum_add[:(length_pointer + 1)] += 1
+        new_lens.append(length_pointer + 1)
+    return np.concatenate(new_inds, 0), new_lens
+
+
+def sort_by_score(im_inds, scores):
+    """lib/rel_model.py:31-61 (descending sort with (value desc, index asc) tie rule)"""
+    num_im = int(im_inds[-1]) + 1
+    rois_per_image = scores.new_zeros(num_im)
+    lengths = []
+    for i, s, e in B.enumerate_by_image(im_inds.numpy()):
+        rois_per_image[i] = 2 * (s - e) * num_im + i
+        lengths.append(e - s)
+    lengths = sorted(lengths, reverse=True)
+    inds, ls_transposed = transpose_packed_sequence_inds(lengths)
+    inds = torch.from_numpy(np.asarray(inds, dtype=np.int64))
+    roi_order = scores - 2 * rois_per_image[im_inds]
+    _, perm = torch.sort(roi_order, dim=0, descending=True, stable=True)
+    perm = perm[inds]
+    _, inv_perm = torch.sort(perm)
+    return perm, inv_perm, ls_transposed
+
+
+def sort_rois(order, batch_idx, confidence, box_priors):
+    """LinearizedContext.sort_rois (rel_model.py:139-162); 'random' is not reproducible -> unsupported."""
+    cxcywh = B.center_size(box_priors)
+    if order == 'size':
+        sizes = cxcywh[:, 2] * cxcywh[:, 3]
+        scores = sizes / (sizes.max() + 1)
+    elif order == 'confidence':
+        scores = confidence
+    elif order == 'leftright':
+        centers = cxcywh[:, 0]
+        scores = centers / (centers.max() + 1)
+    else:
+        raise ValueError(order)
+    return sort_by_score(batch_idx, scores)
+
+
+def _lstm_mask(rng, L_, Bsz, H, p, training):
+    """alternating_highway_lstm.py:279-287: bernoulli(1-p)/(1-p) in train, ones in eval."""
+    if not training:
+        return torch.ones(L_, Bsz, H)
+    return rng.keep_mask((L_, Bsz, H), 1.0 - p) / (1.0 - p)
+
+
+def context_forward(sd, cfg, obj_fmaps, obj_logits, im_inds, obj_labels, box_priors, boxes_per_cls,
+                    training, rng, prefix='context.'):
+    """LinearizedContext.forward (rel_model.py:236-296) for nl_obj > 0 and nl_edge > 0."""
+    H = cfg['hidden_dim']
+    num_classes = sd[prefix + 'obj_embed.weight'].shape[0]
+    obj_embed = F.softmax(obj_logits, dim=1) @ sd[prefix + 'obj_embed.weight']
+    cs = B.center_size(box_priors)
+    pe = F.batch_norm(cs, sd[prefix + 'pos_embed.0.running_mean'], sd[prefix + 'pos_embed.0.running_var'],
+                      sd[prefix + 'pos_embed.0.weight'], sd[prefix + 'pos_embed.0.bias'],
+                      training=training, momentum=BATCHNORM_MOMENTUM / 10.0, eps=1e-5)
+    pe = F.relu(F.linear(pe, sd[prefix + 'pos_embed.1.weight'], sd[prefix + 'pos_embed.1.bias']))
+    pos_embed = dropout(pe, 0.1, training, rng)
+    obj_pre_rep = torch.cat((obj_fmaps, obj_embed, pos_embed), 1)
+
+    # ---- obj_ctx (rel_model.py:197-234)
+    confidence = F.softmax(obj_logits, dim=1).detach()[:, 1:].max(1)[0]
+    perm, inv_perm, ls_transposed = sort_rois(cfg['order'], im_inds, confidence, box_priors)
+    obj_inp_rep = obj_pre_rep[perm].contiguous()
+    mask = _lstm_mask(rng, cfg['nl_obj'], int(ls_transposed[0]), H, cfg['rec_dropout'], training)
+    encoder_rep = L.alternating_highway_lstm(obj_inp_rep, ls_transposed, sd[prefix + 'obj_ctx_rnn.weight'],
+                                             sd[prefix + 'obj_ctx_rnn.bias'], H, cfg['nl_obj'], training, mask)
+    if cfg['mode'] != 'predcls':
+        dec_in = torch.cat((obj_inp_rep, encoder_rep), 1) if cfg['pass_in_obj_feats_to_decoder'] else encoder_rep
+        dec_p = {k[len(prefix + 'decoder_rnn.'):]: v for k, v in sd.items() if k.startswith(prefix + 'decoder_rnn.')}
+        dmask = None
+        if cfg['rec_dropout'] > 0.0:
+            # decoder_rnn.py:13-37 -- drawn in eval mode too (it is simply not applied there)
+            dmask = rng.keep_mask((int(ls_transposed[0]), H), 1.0 - cfg['rec_dropout']) / (1.0 - cfg['rec_dropout'])
+        obj_dists2, obj_preds = L.decoder_forward(
+            dec_p, dec_in, ls_transposed, H, training,
+            labels=obj_labels[perm] if obj_labels is not None else None,
+            boxes_for_nms=boxes_per_cls[perm] if boxes_per_cls is not None else None,
+            dropout_mask=dmask)
+        obj_preds = obj_preds[inv_perm]
+        obj_dists2 = obj_dists2[inv_perm]
+    else:
+        obj_preds = obj_labels
+        obj_dists2 = torch.full((obj_preds.size(0), num_classes), -1000.0)
+        obj_dists2[torch.arange(obj_preds.size(0)), obj_preds] = 1000.0
+    obj_ctx = encoder_rep[inv_perm]
+
+    # ---- edge_ctx (rel_model.py:171-195)
+    edge_in_feats = torch.cat((obj_fmaps, obj_ctx), 1) if cfg['pass_in_obj_feats_to_edge'] else obj_ctx
+    obj_embed2 = sd[prefix + 'obj_embed2.weight'][obj_preds]
+    inp_feats = torch.cat((obj_embed2, edge_in_feats), 1)
+    d2 = obj_dists2.detach()
+    confidence = F.softmax(d2, dim=1).view(-1)[obj_preds + torch.arange(obj_preds.size(0)) * num_classes]
+    perm, inv_perm, ls_transposed = sort_rois(cfg['order'], im_inds, confidence, box_priors)
+    mask = _lstm_mask(rng, cfg['nl_edge'], int(ls_transposed[0]), H, cfg['rec_dropout'], training)
+    edge_reps = L.alternating_highway_lstm(inp_feats[perm], ls_transposed, sd[prefix + 'edge_ctx_rnn.weight'],
+                                           sd[prefix + 'edge_ctx_rnn.bias'], H, cfg['nl_edge'], training, mask)
+    edge_ctx = edge_reps[inv_perm]
+    return obj_dists2, obj_preds, edge_ctx
+
+
+# --------------------------------------------------------------------------- union features
+def union_boxes_feats(sd, fmap, rois, union_inds, training, prefix='union_boxes.', pooling_size=7):
+    """UnionBoxesAndFeats.forward (get_union_boxes.py:42-53); updates BN running stats in `sd`."""
+    im_inds = rois[:, 0][union_inds[:, 0]]
+    union_rois = torch.cat((im_inds[:, None],
+                            torch.min(rois[:, 1:3][union_inds[:, 0]], rois[:, 1:3][union_inds[:, 1]]),
+                            torch.max(rois[:, 3:5][union_inds[:, 0]], rois[:, 3:5][union_inds[:, 1]])), 1)
+    union_pools = roi_align(fmap, union_rois, pooling_size, pooling_size, 1.0 / 16)
+    pair_rois = torch.cat((rois[:, 1:][union_inds[:, 0]], rois[:, 1:][union_inds[:, 1]]), 1).numpy()
+    rects = torch.from_numpy(native.draw_union_boxes(pair_rois, pooling_size * 4 - 1) - np.float32(0.5))
+    x = F.conv2d(rects, sd[prefix + 'conv.0.weight'], sd[prefix + 'conv.0.bias'], stride=2, padding=3)
+    x = F.relu(x)
+    x = F.batch_norm(x, sd[prefix + 'conv.2.running_mean'], sd[prefix + 'conv.2.running_var'],
+                     sd[prefix + 'conv.2.weight'], sd[prefix + 'conv.2.bias'], training=training,
+                     momentum=BATCHNORM_MOMENTUM, eps=1e-5)
+    x = F.max_pool2d(x, kernel_size=3, stride=2, padding=1)
+    x = F.conv2d(x, sd[prefix + 'conv.4.weight'], sd[prefix + 'conv.4.bias'], stride=1, padding=1)
+    x = F.relu(x)
+    x = F.batch_norm(x, sd[prefix + 'conv.6.running_mean'], sd[prefix + 'conv.6.running_var'],
+                     sd[prefix + 'conv.6.weight'], sd[prefix + 'conv.6.bias'], training=training,
+                     momentum=BATCHNORM_MOMENTUM, eps=1e-5)
+    return union_pools + x
+
+
+def get_rel_inds(cfg, rel_labels, im_inds, box_priors, training):
+    """RelModel.get_rel_inds (rel_model.py:416-437)"""
+    if training:
+        return rel_labels[:, :3].clone()
+    rel_cands = im_inds[:, None] == im_inds[None]
+    rel_cands.view(-1)[torch.arange(im_inds.size(0)) * (im_inds.size(0) + 1)] = False
+    if cfg['mode'] == 'sgdet' and cfg.get('require_overlap', True):
+        rel_cands = rel_cands & (B.bbox_overlaps(box_priors, box_priors) > 0)
+    rel_cands = rel_cands.nonzero()
+    if rel_cands.numel() == 0:
+        rel_cands = im_inds.new_zeros(1, 2)
+    return torch.cat((im_inds[rel_cands[:, 0]][:, None], rel_cands), 1)
+
+
+def filter_dets(boxes, obj_scores, obj_classes, rel_inds, pred_scores):
+    """lib/surgery.py:21-59 (stable descending sort)"""
+    obj_scores0 = obj_scores[rel_inds[:, 0]]
+    obj_scores1 = obj_scores[rel_inds[:, 1]]
+    pred_scores_max, _ = pred_scores[:, 1:].max(1)
+    rel_scores_argmaxed = pred_scores_max * obj_scores0 * obj_scores1
+    _, rel_scores_idx = torch.sort(rel_scores_argmaxed.view(-1), dim=0, descending=True, stable=True)
+    return (boxes.numpy(), obj_classes.numpy(), obj_scores.numpy(), rel_inds[rel_scores_idx].numpy(),
+            pred_scores[rel_scores_idx].numpy())
+
+
+def relmodel_forward(sd, cfg, x, im_sizes, image_offset, gt_boxes, gt_classes, training, rng,
+                     rel_labels=None):
+    """
+    RelModel.forward (rel_model.py:450-547).  `sd` maps the reference's state-dict keys to CPU
+    fp32 tensors (BN running stats are updated in place in training mode, as nn.BatchNorm does).
+    Training returns a dict of Result fields; eval returns the filter_dets 5-tuple.
+    """
+    with torch.no_grad():   # train_rels.py:50-52 freezes the detector; rel_model.py:491 detaches fmap
+        det = detector_forward(sd, cfg, x, im_sizes, image_offset, gt_boxes, gt_classes, training, rng,
+                               rel_labels)
+    if det is None:
+        return None
+    im_inds = det['im_inds'] - image_offset
+    boxes = det['rm_box_priors']
+    rel_inds = get_rel_inds(cfg, det['rel_labels'], im_inds, boxes, training)
+    rois = torch.cat((im_inds[:, None].float(), boxes), 1)
+    fmap = det['fmap'].detach()
+    obj_fmap = vgg_classifier(sd, roi_align(fmap, rois).view(rois.size(0), -1), 'roi_fmap_obj.', training, rng)
+    use_labels = training or cfg['mode'] == 'predcls'
+    rm_obj_dists, obj_preds, edge_ctx = context_forward(
+        sd, cfg, obj_fmap, det['rm_obj_dists'].detach(), im_inds,
+        det['rm_obj_labels'] if use_labels else None, boxes, det['boxes_all'], training, rng)
+    P = cfg['pooling_dim']
+    edge_rep = F.linear(edge_ctx, sd['post_lstm.weight'], sd['post_lstm.bias']).view(-1, 2, P)
+    subj_rep, obj_rep = edge_rep[:, 0], edge_rep[:, 1]
+    prod_rep = subj_rep[rel_inds[:, 1]] * obj_rep[rel_inds[:, 2]]
+    if cfg.get('use_vision', True):
+        ub = union_boxes_feats(sd, fmap, rois, rel_inds[:, 1:], training)
+        vr = vgg_classifier(sd, ub.view(ub.size(0), -1), 'roi_fmap.1.', training, rng,
+                            use_dropout=False, use_relu=False)
+        if cfg['limit_vision']:
+            prod_rep = torch.cat((prod_rep[:, :2048] * vr[:, :2048], prod_rep[:, 2048:]), 1)
+        else:
+            prod_rep = prod_rep * vr
+    if cfg['use_tanh']:
+        prod_rep = torch.tanh(prod_rep)
+    rel_dists = F.linear(prod_rep, sd['rel_compress.weight'], sd['rel_compress.bias'])
+    if cfg['use_bias']:
+        num_objs = sd['context.obj_embed.weight'].shape[0]
+        rel_dists = rel_dists + sd['freq_bias.obj_baseline.weight'][
+            obj_preds[rel_inds[:, 1]] * num_objs + obj_preds[rel_inds[:, 2]]]
+    if training:
+        return dict(rm_obj_dists=rm_obj_dists, rm_obj_labels=det['rm_obj_labels'], rel_dists=rel_dists,
+                    rel_labels=det['rel_labels'], obj_preds=obj_preds, obj_fmap=obj_fmap,
+                    od_obj_dists=det['od_obj_dists'], fmap=fmap, rel_inds=rel_inds)
+    num_classes = rm_obj_dists.size(1)
+    twod_inds = torch.arange(obj_preds.size(0)) * num_classes + obj_preds
+    obj_scores = F.softmax(rm_obj_dists, dim=1).view(-1)[twod_inds]
+    if cfg['mode'] == 'sgdet':
+        bboxes = det['boxes_all'].view(-1, 4)[twod_inds].view(det['boxes_all'].size(0), 4)
+    else:
+        bboxes = det['rm_box_priors']
+    rel_rep = F.softmax(rel_dists, dim=1)
+    return filter_dets(bboxes, obj_scores, obj_preds, rel_inds[:, 1:], rel_rep)
