@@ -1,0 +1,176 @@
+/*
+ * motifs_hip.h -- C ABI of libmotifs_hip.so, the MI355X (gfx950) implementation of the
+ * neural-motifs per-image hot path.
+ *
+ * Conventions (SURVEY.md §8b "what the C-ABI replacement must export"):
+ *   - plain pointers and sizes only; every pointer is DEVICE memory unless the name ends in _host
+ *   - the caller owns every buffer, including outputs and workspaces (sizes from mh_*_ws_bytes)
+ *   - `stream` is a hipStream_t passed as void*; nothing here synchronises the device or the stream
+ *   - return value: 0 = ok, otherwise a hipError_t (>0) or MH_EINVAL (-1) for bad arguments;
+ *     nothing calls exit()
+ *   - the device is whatever the caller made current (hipSetDevice); entry points are reentrant
+ *
+ * Each entry point cites the reference interface it replaces (paths under the reference repo).
+ */
+#ifndef MOTIFS_HIP_H
+#define MOTIFS_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MH_OK 0
+#define MH_EINVAL (-1)
+
+/* epilogue flags for GEMM / conv */
+#define MH_EPI_NONE 0
+#define MH_EPI_RELU 1
+#define MH_EPI_RELU6 2
+
+int mh_version(void);
+/* name of the last kernel-launch error on this thread (for diagnostics), or "" */
+const char *mh_last_error(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * NMS.  Replaces `int nms_apply(THIntTensor* keep, THCudaTensor* boxes_sorted, float thresh)`
+ * (lib/fpn/nms/src/nms_cuda.h:1, nms_kernel.cu:88-132).  Fully on device: a 64x64-tile wavefront
+ * bitmask IoU kernel followed by a single-wave sweep; no D2H copy, no hipMalloc.
+ *   boxes_sorted [n,4] fp32 xyxy, sorted by descending score
+ *   keep         [n]   int32 out: kept positions (into the sorted list), ascending
+ *   num_keep     [1]   int32 out
+ *   workspace    >= mh_nms_ws_bytes(n)
+ * mh_nms_batched runs `nseg` independent problems (one per (image,class) segment): segment s covers
+ * boxes [seg_offsets[s], seg_offsets[s+1]); keep/num_keep are per segment (keep uses the same
+ * offsets, positions are segment-relative).  max_seg = largest segment length (host value).
+ * ------------------------------------------------------------------------------------------- */
+size_t mh_nms_ws_bytes(int n);
+int mh_nms(const float *boxes_sorted, int n, float thresh, int *keep, int *num_keep,
+           void *workspace, size_t ws_bytes, void *stream);
+size_t mh_nms_batched_ws_bytes(int total_boxes, int nseg, int max_seg);
+int mh_nms_batched(const float *boxes_sorted, const int *seg_offsets, int nseg, int total_boxes,
+                   int max_seg, float thresh, int *keep, int *num_keep, void *workspace,
+                   size_t ws_bytes, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * RoIAlign (single-sample bilinear crop).  Replaces roi_align_forward_cuda / roi_align_backward_cuda
+ * (lib/fpn/roi_align/src/roi_align_cuda.h:1-6) INCLUDING the roi normalisation the Python wrapper
+ * did (functions/roi_align.py:17-32): rois are passed un-normalised, [n,5] = (im, x1,y1,x2,y2).
+ *   feat_layout 0: feat is NCHW [B,C,H,W] (the reference layout)
+ *   feat_layout 1: feat is NHWC [B,H,W,C] (the trunk's internal layout; coalesced over C)
+ *   out [n,C,ph,pw] always (the layout fc6 expects).  Rows whose image index is out of range are
+ *   zero-filled.  The backward is deterministic (gather formulation, no atomics) and OVERWRITES
+ *   grad_feat (same layout flag).
+ * ------------------------------------------------------------------------------------------- */
+int mh_roi_align_fwd(const float *feat, int B, int C, int H, int W, int feat_layout,
+                     const float *rois, int n, int ph, int pw, float spatial_scale, float *out,
+                     void *stream);
+int mh_roi_align_bwd(const float *grad_out, int B, int C, int H, int W, int feat_layout,
+                     const float *rois, int n, int ph, int pw, float spatial_scale,
+                     float *grad_feat, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Union-box mask rasteriser.  Replaces the Cython `draw_union_boxes(bbox_pairs[N,8], pooling_size)`
+ * (lib/draw_rectangles/draw_rectangles.pyx:12-67) and the host round trip around it
+ * (lib/get_union_boxes.py:47-50).  out = mask + offset (the caller passes -0.5f, get_union_boxes.py:49).
+ *   channels_last 0: out [n,2,P,P]   1: out [n,P,P,2]
+ * ------------------------------------------------------------------------------------------- */
+int mh_draw_union_boxes(const float *box_pairs, int n, int P, float offset, int channels_last,
+                        float *out, void *stream);
+
+/* fp32 pairwise IoU, torch semantics of lib/fpn/box_utils.py:85-131: out[a,b] */
+int mh_bbox_overlaps(const float *boxes_a, int na, const float *boxes_b, int nb, float *out,
+                     void *stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * FP32 GEMM on MFMA (v_mfma_f32_32x32x2_f32; exact fp32 fma chain).  Replaces the cuBLAS / nn.Linear
+ * calls on the path (lib/object_detector.py:80-104, lib/rel_model.py:367-390,
+ * highway_lstm_kernel.cu:441-465).  Row-major:
+ *     C[M,N] = epi( opA(A)[M,K] * opB(B)[K,N] + bias[N] )   (+ C if accumulate)
+ *   transA 0: A stored [M,K] (lda)   1: A stored [K,M]
+ *   transB 0: B stored [K,N] (ldb)   1: B stored [N,K]     (nn.Linear weight -> transB=1)
+ *   bias may be NULL.  splitk <= 0 lets the library choose; >1 needs workspace >= mh_gemm_ws_bytes.
+ * ------------------------------------------------------------------------------------------- */
+size_t mh_gemm_ws_bytes(int M, int N, int K, int splitk);
+int mh_gemm_auto_splitk(int M, int N, int K);
+int mh_gemm_f32(int transA, int transB, int M, int N, int K, const float *A, int lda,
+                const float *B, int ldb, float *C, int ldc, const float *bias, int epilogue,
+                int accumulate, int splitk, void *workspace, size_t ws_bytes, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Convolution stack, NHWC internal layout (cuDNN replacement; lib/object_detector.py:110-118,
+ * :503-508, lib/get_union_boxes.py:31-39).
+ *   mh_conv3x3_nhwc: 3x3, stride 1, pad 1 implicit GEMM on MFMA, fused bias + ReLU/ReLU6.
+ *       in [B,H,W,Cin] (Cin % 16 == 0), wt [9][Cin][Cout] (tap-major, see mh_conv3x3_pack_weight),
+ *       out [B,H,W,Cout] (Cout % 4 == 0)
+ *   mh_conv3x3_pack_weight: w [Cout,Cin,3,3] (API layout) -> wt [9][Cin][Cout];
+ *       flip_transpose=1 produces the dgrad weights (taps mirrored, Cin/Cout swapped: wt [9][Cout][Cin])
+ *   mh_conv_first_nchw: the 3->Cout stem reading the NCHW image directly, writing NHWC; bias+ReLU
+ *   mh_maxpool2x2_nhwc: 2x2/2 max pool (floor), NHWC
+ *   mh_im2col_nhwc: generic patch matrix out[B*Ho*Wo, ldo] with column (ky*kw+kx)*C + c
+ *   mh_col2im... not needed on this path (the only im2col conv takes an input without gradient)
+ *   mh_nchw_to_nhwc / mh_nhwc_to_nchw: layout converters
+ * ------------------------------------------------------------------------------------------- */
+int mh_conv3x3_pack_weight(const float *w, int Cout, int Cin, int flip_transpose, float *wt,
+                           void *stream);
+int mh_conv3x3_nhwc(const float *in, int B, int H, int W, int Cin, const float *wt, int Cout,
+                    const float *bias, int epilogue, float *out, void *stream);
+int mh_conv_first_nchw(const float *in_nchw, int B, int Cin, int H, int W, const float *w /*[Cout,Cin,3,3]*/,
+                       int Cout, const float *bias, int epilogue, float *out_nhwc, void *stream);
+int mh_maxpool2x2_nhwc(const float *in, int B, int H, int W, int C, float *out, void *stream);
+int mh_im2col_nhwc(const float *in, int B, int H, int W, int C, int kh, int kw, int stride, int pad,
+                   float *out, int ldo, void *stream);
+int mh_nchw_to_nhwc(const float *in, int B, int C, int H, int W, float *out, void *stream);
+int mh_nhwc_to_nchw(const float *in, int B, int C, int H, int W, float *out, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Stacked alternating-direction highway LSTM.  Replaces highway_lstm_forward_cuda /
+ * highway_lstm_backward_cuda (lib/lstm/highway_lstm_cuda/src/highway_lstm_cuda.h:1-14) with the same
+ * caller-owned buffer set, minus tmp_i/tmp_h (superseded by the workspace) and plus an explicit stream.
+ *   x        [T,B,in]  zero padded, sequences sorted by decreasing length
+ *   lengths_host [B]   int32, HOST memory (as in the reference)
+ *   h_data, c_data [L,T+1,B,H]  zero-filled by the caller (slot 0 = initial state)
+ *   weight   flat: per layer Wx[in_l,6H] then Wh[H,5H];  bias flat [L,5H]
+ *   dropout  [L,B,H]  (scaled keep mask, shared over time)
+ *   gates    [L,T,B,6H] written when is_training (may be NULL otherwise)
+ * The input projection x_t*Wx is hoisted out of the time loop into one MFMA GEMM per layer; the
+ * recurrent part is one fused GEMV+gate kernel per (layer,t).
+ * Backward: out_grad [T,B,H]; outputs x_grad [T,B,in] (overwritten), weight_grad / bias_grad
+ * (ACCUMULATED into, caller zero-fills) when do_weight_grad.
+ * ------------------------------------------------------------------------------------------- */
+size_t mh_hwlstm_fwd_ws_bytes(int in_size, int H, int B, int L, int T);
+int mh_hwlstm_fwd(int in_size, int H, int B, int L, int T, const float *x,
+                  const int *lengths_host, float *h_data, float *c_data, const float *weight,
+                  const float *bias, const float *dropout, float *gates, int is_training,
+                  void *workspace, size_t ws_bytes, void *stream);
+size_t mh_hwlstm_bwd_ws_bytes(int in_size, int H, int B, int L, int T);
+int mh_hwlstm_bwd(int in_size, int H, int B, int L, int T, const float *out_grad,
+                  const int *lengths_host, const float *x, const float *h_data,
+                  const float *c_data, const float *weight, const float *gates,
+                  const float *dropout, float *x_grad, float *weight_grad, float *bias_grad,
+                  int do_weight_grad, void *workspace, size_t ws_bytes, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * One fused highway-LSTM cell step for the label decoder (lib/lstm/decoder_rnn.py:96-131):
+ *   pre_i [n,6H] = input projection INCLUDING its bias (hoisted GEMM + embedding-table gather)
+ *   h_prev, c_prev [n,H];  wh_t [5H,H] = state_linearity.weight (nn.Linear layout, K contiguous)
+ *   bias_h [5H];  dropout [n,H] or NULL;  outputs h_out, c_out [n,H]; gates_out [n,6H] or NULL
+ * and its backward (d_h, d_c_out -> gate grads [n,6H], d_c_in [n,H]); the recurrent dgrad/wgrad
+ * GEMMs are issued by the caller through mh_gemm_f32 / mh_gemv_rows.
+ * ------------------------------------------------------------------------------------------- */
+int mh_hwlstm_cell_fwd(int n, int H, const float *pre_i, const float *h_prev, const float *c_prev,
+                       const float *wh_t, const float *bias_h, const float *dropout,
+                       float *h_out, float *c_out, float *gates_out, void *stream);
+int mh_hwlstm_cell_bwd(int n, int H, const float *d_h, const float *d_c_out, const float *c_prev,
+                       const float *c_out, const float *gates, const float *dropout,
+                       float *d_gates /*[n,6H]*/, float *d_c_in, void *stream);
+/* out[n,R] = v[n,K] * Wt[R,K]^T (+bias[R]); n <= 64 small-batch GEMV, one wave per output row */
+int mh_gemv_rows(int n, int R, int K, const float *v, int ldv, const float *wt, int ldw,
+                 const float *bias, float *out, int ldo, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MOTIFS_HIP_H */

@@ -1,0 +1,55 @@
+#!/usr/bin/env python3
+"""Build libmotifs_hip.so for gfx950 with hipcc (cross-compiles without a GPU).
+
+    python neural-motifs_amd/csrc/build.py [--force] [--verbose]
+
+exact_ops.hip is compiled with -ffp-contract=off (bit-exact NMS / RoIAlign / rasteriser, mirroring
+oracle/native_ops.c); the MFMA files use the default contraction.  The shared object is written next to the
+sources (in-tree, git-ignored) so that it travels to the GPU box with the repo snapshot.
+"""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SO = os.path.join(HERE, 'libmotifs_hip.so')
+ARCH = 'gfx950'
+EXACT = ('exact_ops.hip',)
+SOURCES = ('exact_ops.hip', 'gemm.hip', 'conv.hip', 'lstm.hip')
+HEADERS = ('common.h', 'mfma_tile.h', os.path.join('..', '..', 'include', 'motifs_hip.h'))
+HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=False):
+    hdrs = [os.path.join(HERE, h) for h in HEADERS]
+    objs = []
+    for src in SOURCES:
+        s = os.path.join(HERE, src)
+        o = os.path.join(HERE, src.replace('.hip', '.o'))
+        objs.append(o)
+        if force or _stale(o, [s] + hdrs + [os.path.abspath(__file__)]):
+            cmd = [HIPCC, '--offload-arch=' + ARCH, '-O3', '-std=c++17', '-fPIC', '-c', s, '-o', o,
+                   '-Wall', '-Wno-unused-function']
+            if src in EXACT:
+                cmd += ['-ffp-contract=off']
+            if verbose:
+                cmd += ['-Rpass-analysis=kernel-resource-usage']
+                print(' '.join(cmd))
+            subprocess.check_call(cmd)
+    if force or _stale(SO, objs):
+        cmd = [HIPCC, '--offload-arch=' + ARCH, '-shared', '-fPIC', '-o', SO] + objs
+        if verbose:
+            print(' '.join(cmd))
+        subprocess.check_call(cmd)
+    return SO
+
+
+if __name__ == '__main__':
+    print(build(force='--force' in sys.argv, verbose='--verbose' in sys.argv))

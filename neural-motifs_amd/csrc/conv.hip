@@ -1,0 +1,348 @@
+// conv.hip -- the convolution stack in NHWC on the gfx950 matrix cores.
+//
+// conv3x3 (stride 1, pad 1) is an implicit GEMM on the 128x128x16 FP32 MFMA tile engine (mfma_tile.h):
+//   M = B*H*W output pixels (NHWC row = pixel, so the GEMM's K-contiguous A rows are pixel channel vectors),
+//   N = Cout, K = 9 taps x Cin.  For each tap the A row of pixel (b,y,x) is the channel vector of pixel
+//   (b,y+dy-1,x+dx-1) or zeros outside the image: the halo is a predicate on the row pointer, no im2col buffer.
+//   B = packed weights [9][Cin][Cout] ("MC": Cout contiguous).  Epilogue fuses bias + ReLU/ReLU6.
+// The same kernel computes dgrad when given flip-transposed weights (mh_conv3x3_pack_weight).
+#include <algorithm>
+
+#include "mfma_tile.h"
+
+namespace mh {
+
+struct ConvArgs {
+    const float *in;
+    int B, H, W, Cin;
+    const float *wt;  // [9][Cin][Cout]
+    int Cout;
+    const float *bias;
+    int epilogue;
+    float *out;
+    int tiles_m, tiles_n;
+};
+
+__device__ __forceinline__ float conv_epi(float v, int epilogue)
+{
+    if (epilogue == MH_EPI_RELU) return fmaxf(v, 0.f);
+    if (epilogue == MH_EPI_RELU6) return fminf(fmaxf(v, 0.f), 6.f);
+    return v;
+}
+
+template <int BM, int BN>
+__global__ __launch_bounds__(kThreads, 2) void conv3x3_nhwc_kernel(const ConvArgs p)
+{
+    constexpr int LDA = TileGeom<BM>::ld, LDB = TileGeom<BN>::ld;
+    constexpr int FA = TileGeom<BM>::floats, FB = TileGeom<BN>::floats;
+    __shared__ __attribute__((aligned(16))) float lds[2 * (FA + FB)];
+    auto As = [&](int buf) -> float * { return lds + buf * (FA + FB); };
+    auto Bs = [&](int buf) -> float * { return lds + buf * (FA + FB) + FA; };
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int wm, wn;
+    wave_origin<BM, BN>(wave, wm, wn);
+    const int ntiles = p.tiles_m * p.tiles_n;
+    const int t = xcd_remap(blockIdx.x, ntiles);
+    // consecutive tiles walk over Cout first: they share the same input pixels (A panel) in L2
+    const long long m0 = (long long)(t / p.tiles_n) * BM;
+    const int n0 = (t % p.tiles_n) * BN;
+    const long long Mtot = (long long)p.B * p.H * p.W;
+
+    // this thread's A row (fixed for the whole K loop): decode the pixel once
+    const long long pix = m0 + (tid % BM);
+    const bool row_ok = pix < Mtot;
+    int py = 0, px = 0;
+    if (row_ok) {
+        const int rem = (int)(pix % ((long long)p.H * p.W));
+        py = rem / p.W;
+        px = rem % p.W;
+    }
+    const float *in_row = p.in + (size_t)(row_ok ? pix : 0) * p.Cin;
+
+    const int kt_per_tap = p.Cin / kBK;
+    const int total_kt = 9 * kt_per_tap;
+
+    auto load_tiles = [&](Stage<BM> &sa, Stage<BN> &sb, int kt) {
+        const int tap = kt / kt_per_tap;
+        const int c0 = (kt - tap * kt_per_tap) * kBK;
+        const int dy = tap / 3 - 1, dx = tap % 3 - 1;
+        const bool ok = row_ok && (unsigned)(py + dy) < (unsigned)p.H && (unsigned)(px + dx) < (unsigned)p.W;
+        const float *ap = in_row + ((long long)dy * p.W + dx) * p.Cin + c0;
+        auto a_row = [&](int) -> const float * { return ok ? ap : nullptr; };
+        load_kc<BM, true>(sa, a_row, 0, kBK, true, tid, p.in);
+        const float *wtap = p.wt + ((size_t)tap * p.Cin + c0) * p.Cout;
+        auto b_row = [&](int k) -> const float * { return wtap + (size_t)k * p.Cout; };
+        load_mc<BN, true>(sb, b_row, 0, n0, p.Cout, true, tid, p.wt);
+    };
+    auto store_tiles = [&](const Stage<BM> &sa, const Stage<BN> &sb, int buf) {
+        store_kc<BM>(sa, As(buf), tid);
+        store_mc<BN>(sb, Bs(buf), tid);
+    };
+
+    Acc acc;
+    acc_zero(acc);
+    Stage<BM> sa;
+    Stage<BN> sb;
+    load_tiles(sa, sb, 0);
+    store_tiles(sa, sb, 0);
+    __syncthreads();
+    for (int kt = 0; kt < total_kt; ++kt) {
+        const int cur = kt & 1;
+        const bool more = (kt + 1 < total_kt);
+        if (more) load_tiles(sa, sb, kt + 1);
+        mma_ktile<LDA, LDB>(As(cur), Bs(cur), wm, wn, lane, acc);
+        if (more) store_tiles(sa, sb, cur ^ 1);
+        __syncthreads();
+    }
+
+    acc_foreach_pair(acc, wm, wn, lane, [&](int r, int c, float v0, float v1) {
+        const long long row = m0 + r;
+        const int col = n0 + c;
+        if (row >= Mtot || col >= p.Cout) return;   // Cout % 4 == 0 -> col+1 is valid whenever col is
+        if (p.bias) { v0 += p.bias[col]; v1 += p.bias[col + 1]; }
+        v0 = conv_epi(v0, p.epilogue);
+        v1 = conv_epi(v1, p.epilogue);
+        *reinterpret_cast<float2 *>(p.out + (size_t)row * p.Cout + col) = make_float2(v0, v1);
+    });
+}
+
+// w [Cout,Cin,3,3] -> wt [9][Cin][Cout]; flip_transpose: wt[(2-ky)*3+(2-kx)][co][ci] = w[co][ci][ky][kx]
+__global__ void pack_weight_kernel(const float *__restrict__ w, int Cout, int Cin, int flip_transpose,
+                                   float *__restrict__ wt)
+{
+    const long long total = (long long)Cout * Cin * 9;
+    for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total;
+         idx += (long long)blockDim.x * gridDim.x) {
+        // idx enumerates the OUTPUT so writes are coalesced
+        if (!flip_transpose) {
+            const int co = idx % Cout;
+            const int ci = (idx / Cout) % Cin;
+            const int tap = idx / ((long long)Cout * Cin);
+            wt[idx] = w[((size_t)co * Cin + ci) * 9 + tap];
+        } else {
+            const int ci = idx % Cin;
+            const int co = (idx / Cin) % Cout;
+            const int tap = idx / ((long long)Cout * Cin);
+            wt[idx] = w[((size_t)co * Cin + ci) * 9 + (8 - tap)];
+        }
+    }
+}
+
+// Stem conv: NCHW image (Cin small, e.g. 3) -> NHWC, bias + activation.  Direct VALU kernel: the layer is
+// bandwidth-bound (1.2 GFLOP vs 90 MB written per 592x592 image).  One thread = one pixel x 16 output channels;
+// the 16 channel-groups of a pixel sit in adjacent lanes, so stores are 64-B runs forming full lines and the
+// (re-)loads of the 27 inputs hit L1.  Weights are staged in LDS as [tap*Cin][Cout].
+constexpr int kStemCo = 16;
+__global__ __launch_bounds__(256) void conv_first_kernel(const float *__restrict__ in, int B, int Cin, int H, int W,
+                                                         const float *__restrict__ w, int Cout,
+                                                         const float *__restrict__ bias, int epilogue,
+                                                         float *__restrict__ out)
+{
+    extern __shared__ __attribute__((aligned(16))) float wl[];  // [9*Cin][Cout] + bias[Cout]
+    const int K = 9 * Cin;
+    for (int i = threadIdx.x; i < K * Cout; i += blockDim.x) {
+        const int co = i % Cout, k = i / Cout;       // k = tap*Cin + ci
+        const int tap = k / Cin, ci = k % Cin;
+        wl[i] = w[((size_t)co * Cin + ci) * 9 + tap];
+    }
+    for (int i = threadIdx.x; i < Cout; i += blockDim.x) wl[K * Cout + i] = bias ? bias[i] : 0.f;
+    __syncthreads();
+    const int groups = Cout / kStemCo;
+    const long long total = (long long)B * H * W * groups;
+    for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total;
+         idx += (long long)blockDim.x * gridDim.x) {
+        const int grp = idx % groups;
+        const long long pix = idx / groups;
+        const int x = pix % W;
+        const int y = (pix / W) % H;
+        const int b = pix / ((long long)W * H);
+        float acc[kStemCo];
+#pragma unroll
+        for (int j = 0; j < kStemCo; ++j) acc[j] = wl[K * Cout + grp * kStemCo + j];
+        for (int ci = 0; ci < Cin; ++ci) {
+            const float *plane = in + ((size_t)b * Cin + ci) * H * W;
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                const int yy = y + tap / 3 - 1, xx = x + tap % 3 - 1;
+                float v = 0.f;
+                if ((unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W) v = plane[(size_t)yy * W + xx];
+                const float *wr = wl + (tap * Cin + ci) * Cout + grp * kStemCo;
+#pragma unroll
+                for (int j = 0; j < kStemCo; ++j) acc[j] = fmaf(v, wr[j], acc[j]);
+            }
+        }
+        float *o = out + (size_t)pix * Cout + grp * kStemCo;
+#pragma unroll
+        for (int j = 0; j < kStemCo; j += 4) {
+            float4 v = make_float4(conv_epi(acc[j], epilogue), conv_epi(acc[j + 1], epilogue),
+                                   conv_epi(acc[j + 2], epilogue), conv_epi(acc[j + 3], epilogue));
+            *reinterpret_cast<float4 *>(o + j) = v;
+        }
+    }
+}
+
+// 2x2 stride-2 max pool, NHWC, float4 over channels (C % 4 == 0)
+__global__ void maxpool2x2_nhwc_kernel(const float4 *__restrict__ in, int B, int H, int W, int C4,
+                                       float4 *__restrict__ out)
+{
+    const int Ho = H / 2, Wo = W / 2;
+    const long long total = (long long)B * Ho * Wo * C4;
+    for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total;
+         idx += (long long)blockDim.x * gridDim.x) {
+        const int c = idx % C4;
+        long long t = idx / C4;
+        const int xo = t % Wo; t /= Wo;
+        const int yo = t % Ho;
+        const int b = t / Ho;
+        const float4 *p = in + (((size_t)b * H + 2 * yo) * W + 2 * xo) * C4 + c;
+        const float4 a = p[0], bq = p[C4], cq = p[(size_t)W * C4], d = p[(size_t)W * C4 + C4];
+        float4 m;
+        m.x = fmaxf(fmaxf(a.x, bq.x), fmaxf(cq.x, d.x));
+        m.y = fmaxf(fmaxf(a.y, bq.y), fmaxf(cq.y, d.y));
+        m.z = fmaxf(fmaxf(a.z, bq.z), fmaxf(cq.z, d.z));
+        m.w = fmaxf(fmaxf(a.w, bq.w), fmaxf(cq.w, d.w));
+        out[idx] = m;
+    }
+}
+
+// generic NHWC patch matrix: out[(b,yo,xo)][(ky*kw+kx)*C + c]; columns >= kh*kw*C (padding up to ldo) are zeroed
+__global__ void im2col_nhwc_kernel(const float *__restrict__ in, int B, int H, int W, int C, int kh, int kw,
+                                   int stride, int pad, int Ho, int Wo, float *__restrict__ out, int ldo)
+{
+    const long long total = (long long)B * Ho * Wo * ldo;
+    const int Kc = kh * kw * C;
+    for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total;
+         idx += (long long)blockDim.x * gridDim.x) {
+        const int col = idx % ldo;
+        const long long row = idx / ldo;
+        float v = 0.f;
+        if (col < Kc) {
+            const int c = col % C;
+            const int tap = col / C;
+            const int ky = tap / kw, kx = tap % kw;
+            const int xo = row % Wo;
+            const int yo = (row / Wo) % Ho;
+            const int b = row / ((long long)Wo * Ho);
+            const int y = yo * stride - pad + ky, x = xo * stride - pad + kx;
+            if ((unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W) v = in[(((size_t)b * H + y) * W + x) * C + c];
+        }
+        out[idx] = v;
+    }
+}
+
+// [B,C,H*W] <-> [B,H*W,C] through a 32x32 LDS tile
+__global__ __launch_bounds__(256) void transpose_kernel(const float *__restrict__ in, int rows, int cols,
+                                                        float *__restrict__ out)
+{
+    __shared__ float tile[32][33];
+    const int b = blockIdx.z;
+    const float *src = in + (size_t)b * rows * cols;
+    float *dst = out + (size_t)b * rows * cols;
+    const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+    for (int j = ty; j < 32; j += 8)
+        if (r0 + j < rows && c0 + tx < cols) tile[j][tx] = src[(size_t)(r0 + j) * cols + c0 + tx];
+    __syncthreads();
+    for (int j = ty; j < 32; j += 8)
+        if (c0 + j < cols && r0 + tx < rows) dst[(size_t)(c0 + j) * rows + r0 + tx] = tile[tx][j];
+}
+
+}  // namespace mh
+
+using namespace mh;
+
+extern "C" {
+
+int mh_conv3x3_pack_weight(const float *w, int Cout, int Cin, int flip_transpose, float *wt, void *stream)
+{
+    MH_REQUIRE(w && wt && Cout > 0 && Cin > 0);
+    const long long total = (long long)Cout * Cin * 9;
+    const int blocks = (int)std::min<long long>((total + 255) / 256, 4096);
+    hipLaunchKernelGGL(pack_weight_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), w, Cout, Cin, flip_transpose,
+                       wt);
+    return check_launch("pack_weight_kernel");
+}
+
+int mh_conv3x3_nhwc(const float *in, int B, int H, int W, int Cin, const float *wt, int Cout, const float *bias,
+                    int epilogue, float *out, void *stream)
+{
+    MH_REQUIRE(in && wt && out && B > 0 && H > 0 && W > 0);
+    MH_REQUIRE(Cin > 0 && Cin % kBK == 0 && Cout > 0 && Cout % 4 == 0);
+    MH_REQUIRE(((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(wt) | reinterpret_cast<uintptr_t>(out)) & 15) == 0);
+    ConvArgs p;
+    p.in = in; p.B = B; p.H = H; p.W = W; p.Cin = Cin; p.wt = wt; p.Cout = Cout; p.bias = bias;
+    p.epilogue = epilogue; p.out = out;
+    const long long M = (long long)B * H * W;
+    const bool narrow = (Cout <= 64);
+    const int bm = narrow ? 256 : 128, bn = narrow ? 64 : 128;
+    p.tiles_m = (int)((M + bm - 1) / bm);
+    p.tiles_n = ceil_div(Cout, bn);
+    const long long ntiles = (long long)p.tiles_m * p.tiles_n;
+    MH_REQUIRE(ntiles < (1LL << 31));
+    if (narrow)
+        hipLaunchKernelGGL((conv3x3_nhwc_kernel<256, 64>), dim3((unsigned)ntiles), dim3(kThreads), 0, as_stream(stream), p);
+    else
+        hipLaunchKernelGGL((conv3x3_nhwc_kernel<128, 128>), dim3((unsigned)ntiles), dim3(kThreads), 0, as_stream(stream), p);
+    return check_launch("conv3x3_nhwc_kernel");
+}
+
+int mh_conv_first_nchw(const float *in_nchw, int B, int Cin, int H, int W, const float *w, int Cout,
+                       const float *bias, int epilogue, float *out_nhwc, void *stream)
+{
+    MH_REQUIRE(in_nchw && w && out_nhwc && B > 0 && Cin > 0 && H > 0 && W > 0);
+    MH_REQUIRE(Cout > 0 && Cout % kStemCo == 0);
+    MH_REQUIRE((reinterpret_cast<uintptr_t>(out_nhwc) & 15) == 0);
+    const size_t lds = ((size_t)9 * Cin * Cout + Cout) * sizeof(float);
+    MH_REQUIRE(lds <= 64 * 1024);
+    const long long total = (long long)B * H * W * (Cout / kStemCo);
+    const int blocks = (int)std::min<long long>((total + 255) / 256, 256 * 8);
+    hipLaunchKernelGGL(conv_first_kernel, dim3(blocks), dim3(256), lds, as_stream(stream), in_nchw, B, Cin, H, W, w,
+                       Cout, bias, epilogue, out_nhwc);
+    return check_launch("conv_first_kernel");
+}
+
+int mh_maxpool2x2_nhwc(const float *in, int B, int H, int W, int C, float *out, void *stream)
+{
+    MH_REQUIRE(in && out && B > 0 && H >= 2 && W >= 2 && C > 0 && C % 4 == 0);
+    MH_REQUIRE(((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(out)) & 15) == 0);
+    const long long total = (long long)B * (H / 2) * (W / 2) * (C / 4);
+    const int blocks = (int)std::min<long long>((total + 255) / 256, 256 * 8);
+    hipLaunchKernelGGL(maxpool2x2_nhwc_kernel, dim3(blocks), dim3(256), 0, as_stream(stream),
+                       reinterpret_cast<const float4 *>(in), B, H, W, C / 4, reinterpret_cast<float4 *>(out));
+    return check_launch("maxpool2x2_nhwc_kernel");
+}
+
+int mh_im2col_nhwc(const float *in, int B, int H, int W, int C, int kh, int kw, int stride, int pad, float *out,
+                   int ldo, void *stream)
+{
+    MH_REQUIRE(in && out && B > 0 && H > 0 && W > 0 && C > 0 && kh > 0 && kw > 0 && stride > 0 && pad >= 0);
+    MH_REQUIRE(ldo >= kh * kw * C);
+    const int Ho = (H + 2 * pad - kh) / stride + 1, Wo = (W + 2 * pad - kw) / stride + 1;
+    MH_REQUIRE(Ho > 0 && Wo > 0);
+    const long long total = (long long)B * Ho * Wo * ldo;
+    const int blocks = (int)std::min<long long>((total + 255) / 256, 256 * 16);
+    hipLaunchKernelGGL(im2col_nhwc_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), in, B, H, W, C, kh, kw,
+                       stride, pad, Ho, Wo, out, ldo);
+    return check_launch("im2col_nhwc_kernel");
+}
+
+static int launch_transpose(const float *in, int B, int rows, int cols, float *out, void *stream)
+{
+    MH_REQUIRE(in && out && B > 0 && rows > 0 && cols > 0 && B <= 65535);
+    MH_REQUIRE(ceil_div(rows, 32) <= 65535);
+    hipLaunchKernelGGL(transpose_kernel, dim3(ceil_div(cols, 32), ceil_div(rows, 32), B), dim3(256), 0,
+                       as_stream(stream), in, rows, cols, out);
+    return check_launch("transpose_kernel");
+}
+
+int mh_nchw_to_nhwc(const float *in, int B, int C, int H, int W, float *out, void *stream)
+{
+    return launch_transpose(in, B, C, H * W, out, stream);
+}
+
+int mh_nhwc_to_nchw(const float *in, int B, int C, int H, int W, float *out, void *stream)
+{
+    return launch_transpose(in, B, H * W, C, out, stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,508 @@
+// exact_ops.hip -- the operators whose results must be BIT-EXACT against the CPU oracle:
+// NMS keep lists, RoIAlign (border tests decide zero fill), union-box masks, fp32 IoU.
+// This file is compiled with -ffp-contract=off (see build.py): every fp32 expression is evaluated
+// exactly as written, one IEEE rounding per operation, like oracle/native_ops.c.
+//
+// gfx950 notes: wavefront = 64, so one wave covers a whole 64-box NMS tile and the per-row
+// suppression words are native 64-bit lane values; cross-lane traffic uses readlane/ballot, not LDS.
+#include <algorithm>
+
+#include "common.h"
+
+namespace mh {
+
+static thread_local char g_err[256] = "";
+void set_last_error(const char *what, hipError_t e)
+{
+    snprintf(g_err, sizeof(g_err), "%s: %s", what, hipGetErrorString(e));
+}
+
+// =====================================================================================
+// NMS
+// =====================================================================================
+// IoU with the +1 pixel convention, same operation order as the reference's devIoU
+// (lib/fpn/nms/src/cuda/nms_kernel.cu:23-31).
+__device__ __forceinline__ float iou_p1(const float4 a, const float4 b)
+{
+    float left = fmaxf(a.x, b.x), right = fminf(a.z, b.z);
+    float top = fmaxf(a.y, b.y), bottom = fminf(a.w, b.w);
+    float width = fmaxf(right - left + 1, 0.f), height = fmaxf(bottom - top + 1, 0.f);
+    float interS = width * height;
+    float Sa = (a.z - a.x + 1) * (a.w - a.y + 1);
+    float Sb = (b.z - b.x + 1) * (b.w - b.y + 1);
+    return interS / (Sa + Sb - interS);
+}
+
+// One wave per 64x64 tile of the (row box, column box) IoU matrix; only tiles on or above the
+// diagonal are needed by the sweep.  Lane i owns row box i and produces its 64-bit word.
+// grid = (col_blocks, row_blocks, nseg).  mask row stride = cb_stride words.
+__global__ __launch_bounds__(64) void nms_mask_kernel(const float4 *__restrict__ boxes,
+                                                      const int *__restrict__ seg_offsets, int n_single,
+                                                      float thresh, unsigned long long *__restrict__ mask,
+                                                      int cb_stride)
+{
+    const int seg = blockIdx.z;
+    const int base = seg_offsets ? seg_offsets[seg] : 0;
+    const int n = seg_offsets ? seg_offsets[seg + 1] - base : n_single;
+    const int row_blk = blockIdx.y, col_blk = blockIdx.x;
+    if (col_blk < row_blk) return;
+    if (row_blk * 64 >= n || col_blk * 64 >= n) return;
+    const int lane = threadIdx.x;
+    const int col_size = min(n - col_blk * 64, 64);
+    const int row = row_blk * 64 + lane;
+
+    // the 64 column boxes live one per lane; lane j's box is broadcast with readlane
+    float4 cbox = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (lane < col_size) cbox = boxes[base + col_blk * 64 + lane];
+    float4 rbox = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (row < n) rbox = boxes[base + row];
+
+    unsigned long long t = 0;
+    const int start = (row_blk == col_blk) ? lane + 1 : 0;
+    for (int j = 0; j < col_size; ++j) {
+        float4 cb;
+        cb.x = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, cbox.x), j));
+        cb.y = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, cbox.y), j));
+        cb.z = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, cbox.z), j));
+        cb.w = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, cbox.w), j));
+        if (j >= start && iou_p1(rbox, cb) > thresh) t |= 1ULL << j;
+    }
+    if (row < n) mask[(size_t)(base + row) * cb_stride + col_blk] = t;
+}
+
+// Sequential greedy sweep, one 256-thread block per segment.  Wave 0 resolves one 64-box block-row
+// at a time from the diagonal words (uniform loop + readlane broadcast), then the whole block ORs
+// the kept rows' words into the running `removed` bitmap (LDS).
+__global__ __launch_bounds__(256) void nms_sweep_kernel(const unsigned long long *__restrict__ mask,
+                                                        const int *__restrict__ seg_offsets, int n_single,
+                                                        int cb_stride, int *__restrict__ keep,
+                                                        int *__restrict__ num_keep)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned long long smem[];  // [cb_stride] removed + 2 words
+    const int seg = blockIdx.x;
+    const int base = seg_offsets ? seg_offsets[seg] : 0;
+    const int n = seg_offsets ? seg_offsets[seg + 1] - base : n_single;
+    const int col_blocks = (n + 63) / 64;
+    unsigned long long *removed = smem;
+    unsigned long long *kept_word = smem + cb_stride;  // [0] = kept bits of the current block-row
+    const int tid = threadIdx.x;
+    for (int j = tid; j < col_blocks; j += blockDim.x) removed[j] = 0ULL;
+    __syncthreads();
+
+    int total = 0;  // meaningful in wave 0 only (uniform)
+    for (int r = 0; r < col_blocks; ++r) {
+        const int rows = min(n - r * 64, 64);
+        if (tid < 64) {
+            const int lane = tid;
+            unsigned long long diag = 0ULL;
+            if (lane < rows) diag = mask[(size_t)(base + r * 64 + lane) * cb_stride + r];
+            unsigned long long alive = ~removed[r];
+            if (rows < 64) alive &= (1ULL << rows) - 1ULL;
+            unsigned long long kept = 0ULL;
+            const unsigned dlo = (unsigned)diag, dhi = (unsigned)(diag >> 32);
+            for (int i = 0; i < rows; ++i) {  // uniform trip count
+                if ((alive >> i) & 1ULL) {
+                    kept |= 1ULL << i;
+                    unsigned lo = __builtin_amdgcn_readlane(dlo, i);
+                    unsigned hi = __builtin_amdgcn_readlane(dhi, i);
+                    alive &= ~(((unsigned long long)hi << 32) | lo);
+                }
+            }
+            if ((kept >> lane) & 1ULL) {
+                int rank = __popcll(kept & ((1ULL << lane) - 1ULL));
+                keep[base + total + rank] = r * 64 + lane;
+            }
+            total += __popcll(kept);
+            if (lane == 0) kept_word[0] = kept;
+        }
+        __syncthreads();
+        const unsigned long long kept = kept_word[0];
+        // removed[j] |= OR_{i kept} mask[r*64+i][j]   for j > r  (j == r is already final)
+        for (int j = r + 1 + tid; j < col_blocks; j += blockDim.x) {
+            unsigned long long acc = 0ULL;
+            unsigned long long bits = kept;
+            while (bits) {
+                int i = __ffsll((long long)bits) - 1;
+                bits &= bits - 1;
+                acc |= mask[(size_t)(base + r * 64 + i) * cb_stride + j];
+            }
+            removed[j] |= acc;
+        }
+        __syncthreads();
+    }
+    if (tid == 0) num_keep[seg] = total;
+}
+
+// =====================================================================================
+// RoIAlign
+// =====================================================================================
+struct RoiGeom {
+    int b_in;
+    float x1, y1, x2, y2;  // normalised
+};
+
+// The Python wrapper's normalisation (lib/fpn/roi_align/functions/roi_align.py:25-32): the divisor
+// (H-1)/spatial_scale is computed in double on the host and rounded to fp32 (passed in as inv args).
+__device__ __forceinline__ RoiGeom load_roi(const float *rois, int n, float width, float height)
+{
+    RoiGeom g;
+    const float *r = rois + 5 * n;
+    g.b_in = (int)r[0];
+    g.x1 = r[1] / width;
+    g.y1 = r[2] / height;
+    g.x2 = r[3] / width;
+    g.y2 = r[4] / height;
+    return g;
+}
+
+struct Sample {
+    int top, bottom, left, right;  // -1 in `top` marks "outside -> extrapolation value 0"
+    float y_lerp, x_lerp;
+};
+
+// lib/fpn/roi_align/src/cuda/roi_align_kernel.cu:36-66, same expression order.
+__device__ __forceinline__ Sample make_sample(const RoiGeom &g, int y, int x, int H, int W, int ph, int pw)
+{
+    Sample s;
+    s.top = -1;
+    s.bottom = s.left = s.right = 0;
+    s.y_lerp = s.x_lerp = 0.f;
+    const float height_scale = (ph > 1) ? (g.y2 - g.y1) * (H - 1) / (ph - 1) : 0;
+    const float width_scale = (pw > 1) ? (g.x2 - g.x1) * (W - 1) / (pw - 1) : 0;
+    const float in_y = (ph > 1) ? g.y1 * (H - 1) + y * height_scale
+                                : (float)(0.5 * (g.y1 + g.y2) * (H - 1));
+    if (in_y < 0 || in_y > H - 1) return s;
+    const float in_x = (pw > 1) ? g.x1 * (W - 1) + x * width_scale
+                                : (float)(0.5 * (g.x1 + g.x2) * (W - 1));
+    if (in_x < 0 || in_x > W - 1) return s;
+    s.top = (int)floorf(in_y);
+    s.bottom = (int)ceilf(in_y);
+    s.y_lerp = in_y - s.top;
+    s.left = (int)floorf(in_x);
+    s.right = (int)ceilf(in_x);
+    s.x_lerp = in_x - s.left;
+    return s;
+}
+
+__device__ __forceinline__ float bilerp(float tl, float tr, float bl, float br, const Sample &s)
+{
+    const float top = tl + (tr - tl) * s.x_lerp;
+    const float bottom = bl + (br - bl) * s.x_lerp;
+    return top + (bottom - top) * s.y_lerp;
+}
+
+// NCHW features: one thread per output element (x fastest), the reference's own decomposition.
+__global__ void roi_align_fwd_nchw(const float *__restrict__ feat, const float *__restrict__ rois, int n_rois,
+                                   int B, int C, int H, int W, int ph, int pw, float width, float height,
+                                   float *__restrict__ out)
+{
+    const long long total = (long long)n_rois * C * ph * pw;
+    for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total;
+         idx += (long long)blockDim.x * gridDim.x) {
+        long long t = idx;
+        const int x = t % pw; t /= pw;
+        const int y = t % ph; t /= ph;
+        const int d = t % C;
+        const int n = t / C;
+        const RoiGeom g = load_roi(rois, n, width, height);
+        float v = 0.f;
+        if (g.b_in >= 0 && g.b_in < B) {
+            const Sample s = make_sample(g, y, x, H, W, ph, pw);
+            if (s.top >= 0) {
+                const float *plane = feat + ((size_t)g.b_in * C + d) * H * W;
+                v = bilerp(plane[s.top * W + s.left], plane[s.top * W + s.right],
+                           plane[s.bottom * W + s.left], plane[s.bottom * W + s.right], s);
+            }
+        }
+        out[idx] = v;
+    }
+}
+
+// NHWC features: block = (roi, 64-channel chunk).  Reads are 256-B coalesced over channels; the
+// [64][ph*pw] result tile is transposed through LDS so the [n][c][y][x] output run (64*49 floats,
+// contiguous) is written with coalesced stores.
+constexpr int kRoiCh = 64;
+__global__ __launch_bounds__(256) void roi_align_fwd_nhwc(const float *__restrict__ feat,
+                                                          const float *__restrict__ rois, int B, int C, int H,
+                                                          int W, int ph, int pw, float width, float height,
+                                                          float *__restrict__ out)
+{
+    extern __shared__ __attribute__((aligned(16))) float lds[];  // [bins] samples (6 words) + tile
+    const int n = blockIdx.x;
+    const int c0 = blockIdx.y * kRoiCh;
+    const int bins = ph * pw;
+    Sample *samp = reinterpret_cast<Sample *>(lds);
+    float *tile = lds + bins * (sizeof(Sample) / sizeof(float));  // [kRoiCh][bins+1]
+    const int tstride = bins + 1;
+    const RoiGeom g = load_roi(rois, n, width, height);
+    const bool valid_im = (g.b_in >= 0 && g.b_in < B);
+    for (int b = threadIdx.x; b < bins; b += blockDim.x) samp[b] = make_sample(g, b / pw, b % pw, H, W, ph, pw);
+    __syncthreads();
+    const int c = threadIdx.x % kRoiCh;
+    const int grp = threadIdx.x / kRoiCh;
+    const int ngrp = blockDim.x / kRoiCh;
+    const bool cvalid = (c0 + c) < C;
+    const float *img = feat + (size_t)(valid_im ? g.b_in : 0) * H * W * C + c0 + c;
+    for (int b = grp; b < bins; b += ngrp) {
+        const Sample s = samp[b];
+        float v = 0.f;
+        if (valid_im && cvalid && s.top >= 0) {
+            const float tl = img[((size_t)s.top * W + s.left) * C];
+            const float tr = img[((size_t)s.top * W + s.right) * C];
+            const float bl = img[((size_t)s.bottom * W + s.left) * C];
+            const float br = img[((size_t)s.bottom * W + s.right) * C];
+            v = bilerp(tl, tr, bl, br, s);
+        }
+        tile[c * tstride + b] = v;
+    }
+    __syncthreads();
+    const int nch = min(kRoiCh, C - c0);
+    float *dst = out + ((size_t)n * C + c0) * bins;
+    for (int i = threadIdx.x; i < nch * bins; i += blockDim.x) dst[i] = tile[(i / bins) * tstride + (i % bins)];
+}
+
+// Backward: the reference scatters with atomicAdd (roi_align_kernel.cu:103-170); same here.
+// layout 0 = NCHW, 1 = NHWC for grad_feat.
+__global__ void roi_align_bwd_kernel(const float *__restrict__ grad_out, const float *__restrict__ rois,
+                                     int n_rois, int B, int C, int H, int W, int ph, int pw, float width,
+                                     float height, int layout, float *__restrict__ grad_feat)
+{
+    const long long total = (long long)n_rois * C * ph * pw;
+    for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total;
+         idx += (long long)blockDim.x * gridDim.x) {
+        long long t = idx;
+        const int x = t % pw; t /= pw;
+        const int y = t % ph; t /= ph;
+        const int d = t % C;
+        const int n = t / C;
+        const RoiGeom g = load_roi(rois, n, width, height);
+        if (g.b_in < 0 || g.b_in >= B) continue;
+        const Sample s = make_sample(g, y, x, H, W, ph, pw);
+        if (s.top < 0) continue;
+        const float go = grad_out[idx];
+        const float dtop = (1 - s.y_lerp) * go;
+        const float dbottom = s.y_lerp * go;
+        auto at = [&](int yy, int xx) -> float * {
+            return layout == 0 ? grad_feat + (((size_t)g.b_in * C + d) * H + yy) * W + xx
+                               : grad_feat + (((size_t)g.b_in * H + yy) * W + xx) * C + d;
+        };
+        atomicAdd(at(s.top, s.left), (1 - s.x_lerp) * dtop);
+        atomicAdd(at(s.top, s.right), s.x_lerp * dtop);
+        atomicAdd(at(s.bottom, s.left), (1 - s.x_lerp) * dbottom);
+        atomicAdd(at(s.bottom, s.right), s.x_lerp * dbottom);
+    }
+}
+
+// =====================================================================================
+// union-box mask rasteriser (lib/draw_rectangles/draw_rectangles.pyx:41-66)
+// =====================================================================================
+__device__ __forceinline__ float clamp01(float x)
+{
+    float t = (0.f > x) ? 0.f : x;   // same comparisons as the generated C (no NaN handling)
+    return (1.f < t) ? 1.f : t;
+}
+
+// one block per box pair; separable: 2*P x- and 2*P y-contributions in LDS, then P*P*2 outputs
+__global__ __launch_bounds__(128) void draw_union_boxes_kernel(const float *__restrict__ pairs, int P,
+                                                               float offset, int channels_last,
+                                                               float *__restrict__ out)
+{
+    extern __shared__ __attribute__((aligned(16))) float contrib[];  // xc[2][P], yc[2][P]
+    const int n = blockIdx.x;
+    const float *bp = pairs + 8 * (size_t)n;
+    const float x1_union = fminf(bp[0], bp[4]);
+    const float y1_union = fminf(bp[1], bp[5]);
+    const float x2_union = fmaxf(bp[2], bp[6]);
+    const float y2_union = fmaxf(bp[3], bp[7]);
+    const float w = x2_union - x1_union;
+    const float h = y2_union - y1_union;
+    const float Pf = (float)(unsigned)P;
+    for (int t = threadIdx.x; t < 4 * P; t += blockDim.x) {
+        const int which = t / (2 * P);  // 0: x, 1: y
+        const int i = (t / P) & 1;
+        const int k = t % P;
+        float lo, hi;
+        if (which == 0) {
+            lo = (bp[0 + 4 * i] - x1_union) * Pf / w;
+            hi = (bp[2 + 4 * i] - x1_union) * Pf / w;
+        } else {
+            lo = (bp[1 + 4 * i] - y1_union) * Pf / h;
+            hi = (bp[3 + 4 * i] - y1_union) * Pf / h;
+        }
+        contrib[t] = clamp01((float)(unsigned)(k + 1) - lo) * clamp01(hi - (float)(unsigned)k);
+    }
+    __syncthreads();
+    const float *xc = contrib, *yc = contrib + 2 * P;
+    const int per = 2 * P * P;
+    float *dst = out + (size_t)n * per;
+    for (int t = threadIdx.x; t < per; t += blockDim.x) {
+        int i, j, k;
+        if (channels_last) { i = t % 2; k = (t / 2) % P; j = t / (2 * P); }
+        else { k = t % P; j = (t / P) % P; i = t / (P * P); }
+        dst[t] = xc[i * P + k] * yc[i * P + j] + offset;
+    }
+}
+
+// =====================================================================================
+// fp32 pairwise IoU (torch semantics of lib/fpn/box_utils.py:85-131)
+// =====================================================================================
+__global__ void bbox_overlaps_kernel(const float4 *__restrict__ a, int na, const float4 *__restrict__ b, int nb,
+                                     float *__restrict__ out)
+{
+    const long long total = (long long)na * nb;
+    for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total;
+         idx += (long long)blockDim.x * gridDim.x) {
+        const float4 p = a[idx / nb], q = b[idx % nb];
+        const float iw = fmaxf(fminf(p.z, q.z) - fmaxf(p.x, q.x) + 1.0f, 0.f);
+        const float ih = fmaxf(fminf(p.w, q.w) - fmaxf(p.y, q.y) + 1.0f, 0.f);
+        const float inter = iw * ih;
+        const float area_a = (p.z - p.x + 1.0f) * (p.w - p.y + 1.0f);
+        const float area_b = (q.z - q.x + 1.0f) * (q.w - q.y + 1.0f);
+        out[idx] = inter / (area_a + area_b - inter);
+    }
+}
+
+}  // namespace mh
+
+using namespace mh;
+
+// =====================================================================================
+// C ABI
+// =====================================================================================
+extern "C" {
+
+int mh_version(void) { return 100; }
+const char *mh_last_error(void) { return mh::g_err; }
+
+size_t mh_nms_ws_bytes(int n)
+{
+    const size_t cb = (size_t)(n + 63) / 64;
+    return align_up((size_t)(n > 0 ? n : 1) * (cb ? cb : 1) * sizeof(unsigned long long), 256);
+}
+
+int mh_nms(const float *boxes_sorted, int n, float thresh, int *keep, int *num_keep, void *workspace,
+           size_t ws_bytes, void *stream)
+{
+    MH_REQUIRE(n >= 0 && keep && num_keep);
+    hipStream_t st = as_stream(stream);
+    if (n == 0) return (int)hipMemsetAsync(num_keep, 0, sizeof(int), st);
+    MH_REQUIRE(boxes_sorted && workspace && ws_bytes >= mh_nms_ws_bytes(n));
+    MH_REQUIRE((reinterpret_cast<uintptr_t>(boxes_sorted) & 15) == 0);
+    const int cb = (n + 63) / 64;
+    auto *mask = reinterpret_cast<unsigned long long *>(workspace);
+    hipLaunchKernelGGL(nms_mask_kernel, dim3(cb, cb, 1), dim3(64), 0, st,
+                       reinterpret_cast<const float4 *>(boxes_sorted), (const int *)nullptr, n, thresh, mask, cb);
+    int rc = check_launch("nms_mask_kernel");
+    if (rc) return rc;
+    hipLaunchKernelGGL(nms_sweep_kernel, dim3(1), dim3(256), (size_t)(cb + 2) * 8, st, mask, (const int *)nullptr, n,
+                       cb, keep, num_keep);
+    return check_launch("nms_sweep_kernel");
+}
+
+size_t mh_nms_batched_ws_bytes(int total_boxes, int nseg, int max_seg)
+{
+    (void)nseg;
+    const size_t cb = (size_t)(max_seg + 63) / 64;
+    return align_up((size_t)(total_boxes > 0 ? total_boxes : 1) * (cb ? cb : 1) * sizeof(unsigned long long), 256);
+}
+
+int mh_nms_batched(const float *boxes_sorted, const int *seg_offsets, int nseg, int total_boxes, int max_seg,
+                   float thresh, int *keep, int *num_keep, void *workspace, size_t ws_bytes, void *stream)
+{
+    MH_REQUIRE(nseg >= 0 && total_boxes >= 0 && max_seg >= 0);
+    if (nseg == 0) return MH_OK;
+    hipStream_t st = as_stream(stream);
+    MH_REQUIRE(seg_offsets && keep && num_keep);
+    if (max_seg == 0 || total_boxes == 0) return (int)hipMemsetAsync(num_keep, 0, sizeof(int) * nseg, st);
+    MH_REQUIRE(boxes_sorted && workspace && ws_bytes >= mh_nms_batched_ws_bytes(total_boxes, nseg, max_seg));
+    MH_REQUIRE((reinterpret_cast<uintptr_t>(boxes_sorted) & 15) == 0);
+    MH_REQUIRE(nseg <= 65535);
+    const int cb = (max_seg + 63) / 64;
+    auto *mask = reinterpret_cast<unsigned long long *>(workspace);
+    hipLaunchKernelGGL(nms_mask_kernel, dim3(cb, cb, nseg), dim3(64), 0, st,
+                       reinterpret_cast<const float4 *>(boxes_sorted), seg_offsets, 0, thresh, mask, cb);
+    int rc = check_launch("nms_mask_kernel(batched)");
+    if (rc) return rc;
+    hipLaunchKernelGGL(nms_sweep_kernel, dim3(nseg), dim3(256), (size_t)(cb + 2) * 8, st, mask, seg_offsets, 0, cb,
+                       keep, num_keep);
+    return check_launch("nms_sweep_kernel(batched)");
+}
+
+static void roi_norm(int H, int W, float spatial_scale, float *width, float *height)
+{
+    // Python: height = (data_height - 1) / self.spatial_scale  in double, then fp32 tensor /= scalar
+    *height = (float)((double)(H - 1) / (double)spatial_scale);
+    *width = (float)((double)(W - 1) / (double)spatial_scale);
+}
+
+int mh_roi_align_fwd(const float *feat, int B, int C, int H, int W, int feat_layout, const float *rois, int n,
+                     int ph, int pw, float spatial_scale, float *out, void *stream)
+{
+    MH_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0 && ph > 0 && pw > 0 && n >= 0);
+    MH_REQUIRE(feat_layout == 0 || feat_layout == 1);
+    if (n == 0) return MH_OK;
+    MH_REQUIRE(feat && rois && out);
+    float width, height;
+    roi_norm(H, W, spatial_scale, &width, &height);
+    hipStream_t st = as_stream(stream);
+    if (feat_layout == 0) {
+        const long long total = (long long)n * C * ph * pw;
+        const int blocks = (int)std::min<long long>((total + 255) / 256, 256 * 32);
+        hipLaunchKernelGGL(roi_align_fwd_nchw, dim3(blocks), dim3(256), 0, st, feat, rois, n, B, C, H, W, ph, pw,
+                           width, height, out);
+        return check_launch("roi_align_fwd_nchw");
+    }
+    const int bins = ph * pw;
+    const size_t lds = (size_t)bins * sizeof(Sample) + (size_t)kRoiCh * (bins + 1) * sizeof(float);
+    MH_REQUIRE(lds <= 64 * 1024);
+    MH_REQUIRE(ceil_div(C, kRoiCh) <= 65535);
+    hipLaunchKernelGGL(roi_align_fwd_nhwc, dim3(n, ceil_div(C, kRoiCh)), dim3(256), lds, st, feat, rois, B, C, H, W,
+                       ph, pw, width, height, out);
+    return check_launch("roi_align_fwd_nhwc");
+}
+
+int mh_roi_align_bwd(const float *grad_out, int B, int C, int H, int W, int feat_layout, const float *rois, int n,
+                     int ph, int pw, float spatial_scale, float *grad_feat, void *stream)
+{
+    MH_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0 && ph > 0 && pw > 0 && n >= 0 && grad_feat);
+    MH_REQUIRE(feat_layout == 0 || feat_layout == 1);
+    hipStream_t st = as_stream(stream);
+    hipError_t e = hipMemsetAsync(grad_feat, 0, sizeof(float) * (size_t)B * C * H * W, st);
+    if (e != hipSuccess) return (int)e;
+    if (n == 0) return MH_OK;
+    MH_REQUIRE(grad_out && rois);
+    float width, height;
+    roi_norm(H, W, spatial_scale, &width, &height);
+    const long long total = (long long)n * C * ph * pw;
+    const int blocks = (int)std::min<long long>((total + 255) / 256, 256 * 32);
+    hipLaunchKernelGGL(roi_align_bwd_kernel, dim3(blocks), dim3(256), 0, st, grad_out, rois, n, B, C, H, W, ph, pw,
+                       width, height, feat_layout, grad_feat);
+    return check_launch("roi_align_bwd_kernel");
+}
+
+int mh_draw_union_boxes(const float *box_pairs, int n, int P, float offset, int channels_last, float *out,
+                        void *stream)
+{
+    MH_REQUIRE(n >= 0 && P > 0 && P <= 1024);
+    if (n == 0) return MH_OK;
+    MH_REQUIRE(box_pairs && out);
+    hipLaunchKernelGGL(draw_union_boxes_kernel, dim3(n), dim3(128), (size_t)4 * P * sizeof(float), as_stream(stream),
+                       box_pairs, P, offset, channels_last, out);
+    return check_launch("draw_union_boxes_kernel");
+}
+
+int mh_bbox_overlaps(const float *boxes_a, int na, const float *boxes_b, int nb, float *out, void *stream)
+{
+    MH_REQUIRE(na >= 0 && nb >= 0);
+    if (na == 0 || nb == 0) return MH_OK;
+    MH_REQUIRE(boxes_a && boxes_b && out);
+    MH_REQUIRE(((reinterpret_cast<uintptr_t>(boxes_a) | reinterpret_cast<uintptr_t>(boxes_b)) & 15) == 0);
+    const long long total = (long long)na * nb;
+    const int blocks = (int)std::min<long long>((total + 255) / 256, 256 * 16);
+    hipLaunchKernelGGL(bbox_overlaps_kernel, dim3(blocks), dim3(256), 0, as_stream(stream),
+                       reinterpret_cast<const float4 *>(boxes_a), na, reinterpret_cast<const float4 *>(boxes_b), nb,
+                       out);
+    return check_launch("bbox_overlaps_kernel");
+}
+
+}  // extern "C"

@@ -1,0 +1,233 @@
+// gemm.hip -- FP32 GEMM on the gfx950 matrix cores (v_mfma_f32_32x32x2_f32) for every nn.Linear-shaped
+// contraction on the path (fc6/fc7 x3, score/bbox heads, LSTM input projections, post_lstm, rel_compress and
+// their dgrad/wgrad).  Block tile 128x128x16, LDS double-buffered with register prefetch (one barrier per
+// k-tile), optional split-K with a fused bias/activation reduction.  See mfma_tile.h for the tile engine.
+#include <algorithm>
+
+#include "mfma_tile.h"
+
+namespace mh {
+
+struct GemmArgs {
+    int M, N, K;
+    const float *A;
+    int lda;
+    const float *B;
+    int ldb;
+    float *C;
+    int ldc;
+    const float *bias;
+    int epilogue, accumulate;
+    int splitk, ktiles_per_split;
+    float *partial;  // [splitk][M][N] when splitk > 1
+    int vecA, vecB, vecC;
+    int tiles_m, tiles_n;
+};
+
+__device__ __forceinline__ float apply_epi(float v, int epilogue)
+{
+    if (epilogue == MH_EPI_RELU) return fmaxf(v, 0.f);
+    if (epilogue == MH_EPI_RELU6) return fminf(fmaxf(v, 0.f), 6.f);
+    return v;
+}
+
+template <bool TA, bool TB, int BM, int BN, bool FAST>
+__global__ __launch_bounds__(kThreads, 2) void gemm_kernel(const GemmArgs p)
+{
+    constexpr int LDA = TileGeom<BM>::ld, LDB = TileGeom<BN>::ld;
+    constexpr int FA = TileGeom<BM>::floats, FB = TileGeom<BN>::floats;
+    __shared__ __attribute__((aligned(16))) float lds[2 * (FA + FB)];
+    auto As = [&](int buf) -> float * { return lds + buf * (FA + FB); };
+    auto Bs = [&](int buf) -> float * { return lds + buf * (FA + FB) + FA; };
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int wm, wn;
+    wave_origin<BM, BN>(wave, wm, wn);
+    const int ntiles = p.tiles_m * p.tiles_n;
+    const int t = xcd_remap(blockIdx.x, ntiles);
+    const int m0 = (t / p.tiles_n) * BM, n0 = (t % p.tiles_n) * BN;
+    const int z = blockIdx.y;
+    const int total_kt = (p.K + kBK - 1) / kBK;
+    const int kt_begin = z * p.ktiles_per_split;
+    const int kt_end = min(total_kt, kt_begin + p.ktiles_per_split);
+
+    auto a_row = [&](int r) -> const float * {  // KC: r = tile row ; MC: r = k
+        if (TA) return (r < p.K) ? p.A + (size_t)r * p.lda : nullptr;
+        return (m0 + r < p.M) ? p.A + (size_t)(m0 + r) * p.lda : nullptr;
+    };
+    auto b_row = [&](int r) -> const float * {
+        if (TB) return (n0 + r < p.N) ? p.B + (size_t)(n0 + r) * p.ldb : nullptr;
+        return (r < p.K) ? p.B + (size_t)r * p.ldb : nullptr;
+    };
+    auto load_tiles = [&](Stage<BM> &sa, Stage<BN> &sb, int kt) {
+        const int k0 = kt * kBK;
+        if (TA) load_mc<BM, FAST>(sa, a_row, k0, m0, p.M, p.vecA != 0, tid, p.A);
+        else load_kc<BM, FAST>(sa, a_row, k0, p.K, p.vecA != 0, tid, p.A);
+        if (TB) load_kc<BN, FAST>(sb, b_row, k0, p.K, p.vecB != 0, tid, p.B);
+        else load_mc<BN, FAST>(sb, b_row, k0, n0, p.N, p.vecB != 0, tid, p.B);
+    };
+    auto store_tiles = [&](const Stage<BM> &sa, const Stage<BN> &sb, int buf) {
+        if (TA) store_mc<BM>(sa, As(buf), tid); else store_kc<BM>(sa, As(buf), tid);
+        if (TB) store_kc<BN>(sb, Bs(buf), tid); else store_mc<BN>(sb, Bs(buf), tid);
+    };
+
+    Acc acc;
+    acc_zero(acc);
+    Stage<BM> sa;
+    Stage<BN> sb;
+    if (kt_begin < kt_end) {
+        load_tiles(sa, sb, kt_begin);
+        store_tiles(sa, sb, 0);
+    }
+    __syncthreads();
+    for (int kt = kt_begin; kt < kt_end; ++kt) {
+        const int cur = (kt - kt_begin) & 1;
+        const bool more = (kt + 1 < kt_end);
+        if (more) load_tiles(sa, sb, kt + 1);
+        mma_ktile<LDA, LDB>(As(cur), Bs(cur), wm, wn, lane, acc);
+        if (more) store_tiles(sa, sb, cur ^ 1);
+        __syncthreads();
+    }
+
+    if (p.splitk > 1) {
+        float *dst = p.partial + (size_t)z * p.M * p.N;
+        const bool vec = (p.N % 2) == 0;
+        acc_foreach_pair(acc, wm, wn, lane, [&](int r, int c, float v0, float v1) {
+            const int row = m0 + r, col = n0 + c;
+            if (row >= p.M || col >= p.N) return;
+            float *q = dst + (size_t)row * p.N + col;
+            if (vec && col + 1 < p.N) *reinterpret_cast<float2 *>(q) = make_float2(v0, v1);
+            else { q[0] = v0; if (col + 1 < p.N) q[1] = v1; }
+        });
+        return;
+    }
+    acc_foreach_pair(acc, wm, wn, lane, [&](int r, int c, float v0, float v1) {
+        const int row = m0 + r, col = n0 + c;
+        if (row >= p.M || col >= p.N) return;
+        const bool has1 = (col + 1 < p.N);
+        if (p.bias) { v0 += p.bias[col]; if (has1) v1 += p.bias[col + 1]; }
+        v0 = apply_epi(v0, p.epilogue);
+        v1 = apply_epi(v1, p.epilogue);
+        float *q = p.C + (size_t)row * p.ldc + col;
+        if (p.accumulate) { v0 += q[0]; if (has1) v1 += q[1]; }
+        if (p.vecC && has1) *reinterpret_cast<float2 *>(q) = make_float2(v0, v1);
+        else { q[0] = v0; if (has1) q[1] = v1; }
+    });
+}
+
+// C = epi(sum_z partial[z] + bias) (+ C)
+__global__ void splitk_reduce_kernel(const float *__restrict__ partial, int splitk, int M, int N, float *__restrict__ C,
+                                     int ldc, const float *__restrict__ bias, int epilogue, int accumulate)
+{
+    const long long total = (long long)M * N;
+    const size_t plane = (size_t)M * N;
+    for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total;
+         idx += (long long)blockDim.x * gridDim.x) {
+        const int row = idx / N, col = idx % N;
+        float v = 0.f;
+        for (int z = 0; z < splitk; ++z) v += partial[z * plane + idx];
+        if (bias) v += bias[col];
+        v = apply_epi(v, epilogue);
+        float *q = C + (size_t)row * ldc + col;
+        if (accumulate) v += *q;
+        *q = v;
+    }
+}
+
+static int choose_splitk(int M, int N, int K)
+{
+    const int bm = (N <= 64) ? 256 : 128, bn = (N <= 64) ? 64 : 128;
+    const long long tiles = (long long)ceil_div(M, bm) * ceil_div(N, bn);
+    const int ktiles = ceil_div(K, kBK);
+    if (tiles >= 1024 || ktiles < 16) return 1;
+    static const int cand[] = {1, 2, 3, 4, 6, 8, 12, 16, 24, 32};
+    double best = 1e30;
+    int best_s = 1;
+    for (int s : cand) {
+        if (s > 1 && ktiles / s < 8) break;
+        const double rounds = (double)((tiles * s + 255) / 256);
+        // time ~ rounds / s block-times, plus the partial write+read traffic relative to the MFMA work
+        const double cost = rounds / s * (1.0 + 0.02 * (s - 1)) + (s > 1 ? 0.25 * s * 128.0 / K : 0.0);
+        if (cost < best - 1e-9) { best = cost; best_s = s; }
+    }
+    return best_s;
+}
+
+}  // namespace mh
+
+using namespace mh;
+
+extern "C" {
+
+int mh_gemm_auto_splitk(int M, int N, int K) { return (M > 0 && N > 0 && K > 0) ? choose_splitk(M, N, K) : 1; }
+
+size_t mh_gemm_ws_bytes(int M, int N, int K, int splitk)
+{
+    if (M <= 0 || N <= 0 || K <= 0) return 0;
+    if (splitk <= 0) splitk = choose_splitk(M, N, K);
+    if (splitk <= 1) return 0;
+    return align_up((size_t)splitk * M * N * sizeof(float), 256);
+}
+
+int mh_gemm_f32(int transA, int transB, int M, int N, int K, const float *A, int lda, const float *B, int ldb,
+                float *C, int ldc, const float *bias, int epilogue, int accumulate, int splitk, void *workspace,
+                size_t ws_bytes, void *stream)
+{
+    MH_REQUIRE(M >= 0 && N >= 0 && K >= 0);
+    if (M == 0 || N == 0) return MH_OK;
+    MH_REQUIRE(A && B && C && K > 0);
+    MH_REQUIRE(lda >= (transA ? M : K) && ldb >= (transB ? K : N) && ldc >= N);
+    MH_REQUIRE(epilogue >= MH_EPI_NONE && epilogue <= MH_EPI_RELU6);
+    if (splitk <= 0) splitk = choose_splitk(M, N, K);
+    const int total_kt = ceil_div(K, kBK);
+    splitk = std::min(splitk, total_kt);
+    if (splitk > 1 && (workspace == nullptr || ws_bytes < (size_t)splitk * M * N * sizeof(float))) splitk = 1;
+    GemmArgs p;
+    p.M = M; p.N = N; p.K = K;
+    p.A = A; p.lda = lda; p.B = B; p.ldb = ldb; p.C = C; p.ldc = ldc;
+    p.bias = bias; p.epilogue = epilogue; p.accumulate = accumulate;
+    p.ktiles_per_split = ceil_div(total_kt, splitk);
+    splitk = ceil_div(total_kt, p.ktiles_per_split);  // drop empty tail splits
+    p.splitk = splitk;
+    p.partial = reinterpret_cast<float *>(workspace);
+    auto al16 = [](const void *q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+    p.vecA = al16(A) && (lda % 4 == 0);
+    p.vecB = al16(B) && (ldb % 4 == 0);
+    p.vecC = ((reinterpret_cast<uintptr_t>(C) & 7) == 0) && (ldc % 2 == 0);
+    const bool narrow = (N <= 64);
+    p.tiles_m = ceil_div(M, narrow ? 256 : 128);
+    p.tiles_n = ceil_div(N, narrow ? 64 : 128);
+    const long long ntiles = (long long)p.tiles_m * p.tiles_n;
+    MH_REQUIRE(ntiles < (1LL << 31) && splitk <= 65535);
+    hipStream_t st = as_stream(stream);
+    dim3 grid((unsigned)ntiles, (unsigned)splitk);
+    // FAST: both operands 16-B aligned and their contiguous extents multiples of 4 (see load4_guarded)
+    const bool fast = p.vecA && p.vecB && ((transA ? M : K) % 4 == 0) && ((transB ? K : N) % 4 == 0);
+#define MH_LAUNCH_GEMM2(TA_, TB_, F_)                                                                           \
+    do {                                                                                                        \
+        if (narrow) hipLaunchKernelGGL((gemm_kernel<TA_, TB_, 256, 64, F_>), grid, dim3(kThreads), 0, st, p);    \
+        else hipLaunchKernelGGL((gemm_kernel<TA_, TB_, 128, 128, F_>), grid, dim3(kThreads), 0, st, p);          \
+    } while (0)
+#define MH_LAUNCH_GEMM(TA_, TB_)                          \
+    do {                                                  \
+        if (fast) MH_LAUNCH_GEMM2(TA_, TB_, true);        \
+        else MH_LAUNCH_GEMM2(TA_, TB_, false);            \
+    } while (0)
+    if (!transA && !transB) MH_LAUNCH_GEMM(false, false);
+    else if (!transA && transB) MH_LAUNCH_GEMM(false, true);
+    else if (transA && !transB) MH_LAUNCH_GEMM(true, false);
+    else MH_LAUNCH_GEMM(true, true);
+#undef MH_LAUNCH_GEMM
+#undef MH_LAUNCH_GEMM2
+    int rc = check_launch("gemm_kernel");
+    if (rc) return rc;
+    if (splitk > 1) {
+        const long long total = (long long)M * N;
+        const int blocks = (int)std::min<long long>((total + 255) / 256, 256 * 16);
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, p.partial, splitk, M, N, C, ldc, bias,
+                           epilogue, accumulate);
+        rc = check_launch("splitk_reduce_kernel");
+    }
+    return rc;
+}
+
+}  // extern "C"

@@ -1,0 +1,525 @@
+// lstm.hip -- stacked alternating-direction highway LSTM (lib/lstm/highway_lstm_cuda) for gfx950.
+//
+// Restructuring vs the reference host loop (highway_lstm_kernel.cu:377-496 / :162-375):
+//   * the input projection x_t*Wx does not depend on the recurrence -> ONE MFMA GEMM per layer over all T*B rows
+//     (mh_gemm_f32) instead of T tiny cuBLAS calls; likewise dX, dWx, dWh in the backward are single GEMMs over
+//     the stored per-step gate gradients.
+//   * the serial part of a step is a small-batch GEMV (n <= B rows against Wh) fused with the gate math: one
+//     launch per (layer, t), no device synchronisation, no side streams.  A wave owns 4 hidden units, 16 lanes
+//     split K for each; the n right-hand sides sit in LDS; partial sums are reduced with 4 xor-shuffles.
+//   * sigmoid / cell expressions keep the reference's operation order (elementWise_fp :108-160), including the
+//     double-precision `(1. - r)` term.
+#include <algorithm>
+
+#include "common.h"
+
+namespace mh {
+
+constexpr int kNB = 8;        // right-hand sides (batch rows) processed per pass
+constexpr int kKChunk = 512;  // K staged in LDS per pass
+
+__device__ __forceinline__ float sigmoidf_ref(float x) { return 1.f / (1.f + expf(-x)); }
+
+// Accumulate, for NR rows of `w` (row r at w + r*ldw, K contiguous) and `n` vectors in LDS (vs[b*kKChunk + k]),
+// the partial dot products of this lane's k-slice: lane kq of 16 takes float4 q = kq, kq+16, ...
+template <int NR>
+__device__ __forceinline__ void dot_rows_chunk(const float *const (&wrow)[NR], const float *vs, int kc, int kq,
+                                               bool vec, float (&acc)[NR][kNB])
+{
+    for (int k = 4 * kq; k < kc; k += 64) {
+        float4 w[NR];
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            if (vec && k + 3 < kc) {
+                w[r] = *reinterpret_cast<const float4 *>(wrow[r] + k);
+            } else {
+                w[r].x = (k + 0 < kc) ? wrow[r][k + 0] : 0.f;
+                w[r].y = (k + 1 < kc) ? wrow[r][k + 1] : 0.f;
+                w[r].z = (k + 2 < kc) ? wrow[r][k + 2] : 0.f;
+                w[r].w = (k + 3 < kc) ? wrow[r][k + 3] : 0.f;
+            }
+        }
+#pragma unroll
+        for (int b = 0; b < kNB; ++b) {
+            const float4 h = *reinterpret_cast<const float4 *>(vs + b * kKChunk + k);  // zero padded
+#pragma unroll
+            for (int r = 0; r < NR; ++r) {
+                acc[r][b] = fmaf(w[r].x, h.x, acc[r][b]);
+                acc[r][b] = fmaf(w[r].y, h.y, acc[r][b]);
+                acc[r][b] = fmaf(w[r].z, h.z, acc[r][b]);
+                acc[r][b] = fmaf(w[r].w, h.w, acc[r][b]);
+            }
+        }
+    }
+}
+
+// stage v[b0..b0+kNB)[k0..k0+kc) into LDS (zero padded to kNB x kKChunk)
+__device__ __forceinline__ void stage_vectors(const float *v, int ldv, int n, int b0, int k0, int kc, float *vs)
+{
+    for (int i = threadIdx.x; i < kNB * kKChunk; i += blockDim.x) {
+        const int b = i / kKChunk, k = i % kKChunk;
+        vs[i] = (b0 + b < n && k < kc) ? v[(size_t)(b0 + b) * ldv + k0 + k] : 0.f;
+    }
+}
+
+template <int NR>
+__device__ __forceinline__ void reduce16(float (&acc)[NR][kNB])
+{
+#pragma unroll
+    for (int r = 0; r < NR; ++r)
+#pragma unroll
+        for (int b = 0; b < kNB; ++b) {
+            float v = acc[r][b];
+            v += __shfl_xor(v, 1);
+            v += __shfl_xor(v, 2);
+            v += __shfl_xor(v, 4);
+            v += __shfl_xor(v, 8);
+            acc[r][b] = v;
+        }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// out[b][r] = sum_k v[b][k] * wt[r][k] (+ bias[r]);  one wave per block, 4 rows per wave.
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void gemv_rows_kernel(int n, int R, int K, const float *__restrict__ v, int ldv,
+                                                       const float *__restrict__ wt, int ldw,
+                                                       const float *__restrict__ bias, float *__restrict__ out,
+                                                       int ldo, int vec)
+{
+    __shared__ __attribute__((aligned(16))) float vs[kNB * kKChunk];
+    const int lane = threadIdx.x, kq = lane & 15, ru = lane >> 4;
+    const int row = blockIdx.x * 4 + ru;
+    const bool row_ok = row < R;
+    for (int b0 = 0; b0 < n; b0 += kNB) {
+        float acc[1][kNB];
+#pragma unroll
+        for (int b = 0; b < kNB; ++b) acc[0][b] = 0.f;
+        for (int k0 = 0; k0 < K; k0 += kKChunk) {
+            const int kc = min(kKChunk, K - k0);
+            __syncthreads();
+            stage_vectors(v, ldv, n, b0, k0, kc, vs);
+            __syncthreads();
+            if (row_ok) {
+                const float *const wrow[1] = {wt + (size_t)row * ldw + k0};
+                dot_rows_chunk<1>(wrow, vs, kc, kq, vec != 0, acc);
+            }
+        }
+        reduce16<1>(acc);
+        if (row_ok) {
+#pragma unroll
+            for (int b = 0; b < kNB; ++b)
+                if (kq == b && b0 + b < n) out[(size_t)(b0 + b) * ldo + row] = acc[0][b] + (bias ? bias[row] : 0.f);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Fused highway-LSTM cell step (elementWise_fp + the recurrent Sgemm of highway_lstm_kernel.cu:453-485).
+//   pre_i [n,6H] (ld_i)  : x_t*Wx (+ input bias for the decoder)
+//   wh_t  [5H,H]         : recurrent weights, K(=H)-contiguous rows, row = gate*H + unit
+//   bias  [5H] or NULL
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void hw_cell_fwd_kernel(int n, int H, const float *__restrict__ pre_i, int ld_i,
+                                                         const float *__restrict__ h_prev,
+                                                         const float *__restrict__ c_prev,
+                                                         const float *__restrict__ wh_t,
+                                                         const float *__restrict__ bias,
+                                                         const float *__restrict__ dropout,
+                                                         float *__restrict__ h_out, float *__restrict__ c_out,
+                                                         float *__restrict__ gates_out, int vec)
+{
+    __shared__ __attribute__((aligned(16))) float vs[kNB * kKChunk];
+    const int lane = threadIdx.x, kq = lane & 15, ul = lane >> 4;
+    const int u = blockIdx.x * 4 + ul;
+    const bool u_ok = u < H;
+    for (int b0 = 0; b0 < n; b0 += kNB) {
+        float acc[5][kNB];
+#pragma unroll
+        for (int g = 0; g < 5; ++g)
+#pragma unroll
+            for (int b = 0; b < kNB; ++b) acc[g][b] = 0.f;
+        for (int k0 = 0; k0 < H; k0 += kKChunk) {
+            const int kc = min(kKChunk, H - k0);
+            __syncthreads();
+            stage_vectors(h_prev, H, n, b0, k0, kc, vs);
+            __syncthreads();
+            if (u_ok) {
+                const float *const wrow[5] = {wh_t + ((size_t)0 * H + u) * H + k0, wh_t + ((size_t)1 * H + u) * H + k0,
+                                              wh_t + ((size_t)2 * H + u) * H + k0, wh_t + ((size_t)3 * H + u) * H + k0,
+                                              wh_t + ((size_t)4 * H + u) * H + k0};
+                dot_rows_chunk<5>(wrow, vs, kc, kq, vec != 0, acc);
+            }
+        }
+        reduce16<5>(acc);
+        // lane kq == b finalises (row b0+b, unit u)
+        float th[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int b = 0; b < kNB; ++b)
+            if (kq == b) {
+#pragma unroll
+                for (int g = 0; g < 5; ++g) th[g] = acc[g][b];
+            }
+        const int row = b0 + kq;
+        if (u_ok && kq < kNB && row < n) {
+            const float *pi = pre_i + (size_t)row * ld_i + u;
+            float g[5];
+#pragma unroll
+            for (int k = 0; k < 5; ++k) {
+                g[k] = pi[(size_t)k * H] + th[k];               // tmp_i + tmp_h
+                if (bias) g[k] += bias[k * H + u];              // += bias
+            }
+            const float in_gate = sigmoidf_ref(g[0]);
+            const float forget_gate = sigmoidf_ref(g[1]);
+            const float act_gate = tanhf(g[2]);
+            const float out_gate = sigmoidf_ref(g[3]);
+            const float r_gate = sigmoidf_ref(g[4]);
+            const float lin_gate = pi[(size_t)5 * H];
+            const size_t o = (size_t)row * H + u;
+            float val = (forget_gate * c_prev[o]) + (in_gate * act_gate);
+            c_out[o] = val;
+            val = out_gate * tanhf(val);
+            val = (float)((double)(val * r_gate) + (1. - (double)r_gate) * (double)lin_gate);
+            if (dropout) val = val * dropout[o];
+            h_out[o] = val;
+            if (gates_out) {
+                float *go = gates_out + (size_t)row * 6 * H + u;
+                go[0] = in_gate;
+                go[(size_t)1 * H] = forget_gate;
+                go[(size_t)2 * H] = act_gate;
+                go[(size_t)3 * H] = out_gate;
+                go[(size_t)4 * H] = r_gate;
+                go[(size_t)5 * H] = lin_gate;
+            }
+        }
+    }
+}
+
+// elementWise_bp (highway_lstm_kernel.cu:46-104): d_h = (out_grad + h_rec_grad) * dropout ...
+// d_gates [n,6H]: gates 0..4 are both the input- and the state-projection gradients, gate 5 = d_lin.
+__global__ void hw_cell_bwd_kernel(int n, int H, const float *__restrict__ d_out, const float *__restrict__ d_h_rec,
+                                   const float *__restrict__ d_c_out, const float *__restrict__ c_prev,
+                                   const float *__restrict__ c_out, const float *__restrict__ gates,
+                                   const float *__restrict__ dropout, float *__restrict__ d_gates,
+                                   float *__restrict__ d_c_in)
+{
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n * H) return;
+    const int b = idx / H, u = idx % H;
+    const float *gp = gates + (size_t)b * 6 * H + u;
+    float d_h = d_out[idx] + (d_h_rec ? d_h_rec[idx] : 0.f);
+    if (dropout) d_h = d_h * dropout[idx];
+    const float in_gate = gp[0], forget_gate = gp[(size_t)H], act_gate = gp[(size_t)2 * H];
+    const float out_gate = gp[(size_t)3 * H], r_gate = gp[(size_t)4 * H], lin_gate = gp[(size_t)5 * H];
+    const float tc = tanhf(c_out[idx]);
+    const float d_o = d_h * r_gate;
+    const float d_c = d_o * out_gate * (1.f - tc * tc) + (d_c_out ? d_c_out[idx] : 0.f);
+    const float h_prime = out_gate * tc;
+    float *dg = d_gates + (size_t)b * 6 * H + u;
+    dg[0] = d_c * act_gate * in_gate * (1.f - in_gate);
+    dg[(size_t)H] = d_c * c_prev[idx] * forget_gate * (1.f - forget_gate);
+    dg[(size_t)2 * H] = d_c * in_gate * (1.f - act_gate * act_gate);
+    dg[(size_t)3 * H] = d_o * tc * out_gate * (1.f - out_gate);
+    dg[(size_t)4 * H] = d_h * (h_prime - lin_gate) * r_gate * (1.f - r_gate);
+    dg[(size_t)5 * H] = d_h * (1 - r_gate);
+    d_c_in[idx] = forget_gate * d_c;
+}
+
+// out[c] += sum_r in[r][c]   (bias gradient; the reference uses Sgemv with a ones vector, :342-355)
+__global__ void colsum_accum_kernel(const float *__restrict__ in, int rows, int cols, int ld, float *__restrict__ out)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= cols) return;
+    float s = 0.f;
+    for (int r = 0; r < rows; ++r) s += in[(size_t)r * ld + c];
+    out[c] += s;
+}
+
+// [rows, cols] -> [cols, rows]
+__global__ __launch_bounds__(256) void transpose2d_kernel(const float *__restrict__ src, int rows, int cols,
+                                                          float *__restrict__ dst)
+{
+    __shared__ float tile[32][33];
+    const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int j = ty; j < 32; j += 8)
+        if (r0 + j < rows && c0 + tx < cols) tile[j][tx] = src[(size_t)(r0 + j) * cols + c0 + tx];
+    __syncthreads();
+    for (int j = ty; j < 32; j += 8)
+        if (c0 + j < cols && r0 + tx < rows) dst[(size_t)(c0 + j) * rows + r0 + tx] = tile[tx][j];
+}
+
+struct LayerOffsets {
+    size_t wx, wh;
+    int in_size;
+};
+
+static LayerOffsets layer_offsets(int in_size, int H, int layer)
+{
+    // alternating_highway_lstm.py:213-229: per layer Wx[in_l,6H] then Wh[H,5H]
+    LayerOffsets o;
+    size_t w = 0;
+    int ins = in_size;
+    for (int l = 0; l <= layer; ++l) {
+        ins = (l == 0) ? in_size : H;
+        o.wx = w;
+        o.wh = w + (size_t)6 * H * ins;
+        w = o.wh + (size_t)5 * H * H;
+    }
+    o.in_size = ins;
+    return o;
+}
+
+static bool al16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+static int launch_cell_fwd(int n, int H, const float *pre_i, int ld_i, const float *h_prev, const float *c_prev,
+                           const float *wh_t, const float *bias, const float *dropout, float *h_out, float *c_out,
+                           float *gates_out, hipStream_t st)
+{
+    const int vec = al16(wh_t) && (H % 4 == 0);
+    hipLaunchKernelGGL(hw_cell_fwd_kernel, dim3(ceil_div(H, 4)), dim3(64), 0, st, n, H, pre_i, ld_i, h_prev, c_prev,
+                       wh_t, bias, dropout, h_out, c_out, gates_out, vec);
+    return check_launch("hw_cell_fwd_kernel");
+}
+
+static int launch_gemv_rows(int n, int R, int K, const float *v, int ldv, const float *wt, int ldw, const float *bias,
+                            float *out, int ldo, hipStream_t st)
+{
+    const int vec = al16(wt) && (ldw % 4 == 0);
+    hipLaunchKernelGGL(gemv_rows_kernel, dim3(ceil_div(R, 4)), dim3(64), 0, st, n, R, K, v, ldv, wt, ldw, bias, out,
+                       ldo, vec);
+    return check_launch("gemv_rows_kernel");
+}
+
+// (t, numCovered) in the order the reference visits the timesteps (highway_lstm_kernel.cu:410-424)
+static void covered_schedule(const int *lengths, int T, int B, bool forward_dir, int *ts, int *ns)
+{
+    if (forward_dir) {
+        int n = B;
+        for (int t = 0; t < T; ++t) {
+            while (n > 0 && lengths[n - 1] <= t) --n;
+            ts[t] = t;
+            ns[t] = n;
+        }
+    } else {
+        int n = 0;
+        for (int i = 0, t = T - 1; t >= 0; --t, ++i) {
+            while (n < B && lengths[n] > t) ++n;
+            ts[i] = t;
+            ns[i] = n;
+        }
+    }
+}
+
+}  // namespace mh
+
+using namespace mh;
+
+#define MH_TRY(expr)          \
+    do {                      \
+        int rc__ = (expr);    \
+        if (rc__) return rc__; \
+    } while (0)
+
+extern "C" {
+
+int mh_gemv_rows(int n, int R, int K, const float *v, int ldv, const float *wt, int ldw, const float *bias, float *out,
+                 int ldo, void *stream)
+{
+    MH_REQUIRE(n >= 0 && R >= 0 && K > 0);
+    if (n == 0 || R == 0) return MH_OK;
+    MH_REQUIRE(v && wt && out && ldv >= K && ldw >= K && ldo >= R);
+    return launch_gemv_rows(n, R, K, v, ldv, wt, ldw, bias, out, ldo, as_stream(stream));
+}
+
+int mh_hwlstm_cell_fwd(int n, int H, const float *pre_i, const float *h_prev, const float *c_prev, const float *wh_t,
+                       const float *bias_h, const float *dropout, float *h_out, float *c_out, float *gates_out,
+                       void *stream)
+{
+    MH_REQUIRE(n >= 0 && H > 0);
+    if (n == 0) return MH_OK;
+    MH_REQUIRE(pre_i && h_prev && c_prev && wh_t && h_out && c_out);
+    return launch_cell_fwd(n, H, pre_i, 6 * H, h_prev, c_prev, wh_t, bias_h, dropout, h_out, c_out, gates_out,
+                           as_stream(stream));
+}
+
+int mh_hwlstm_cell_bwd(int n, int H, const float *d_h, const float *d_c_out, const float *c_prev, const float *c_out,
+                       const float *gates, const float *dropout, float *d_gates, float *d_c_in, void *stream)
+{
+    MH_REQUIRE(n >= 0 && H > 0);
+    if (n == 0) return MH_OK;
+    MH_REQUIRE(d_h && c_prev && c_out && gates && d_gates && d_c_in);
+    hipLaunchKernelGGL(hw_cell_bwd_kernel, dim3(ceil_div(n * H, 256)), dim3(256), 0, as_stream(stream), n, H, d_h,
+                       (const float *)nullptr, d_c_out, c_prev, c_out, gates, dropout, d_gates, d_c_in);
+    return check_launch("hw_cell_bwd_kernel");
+}
+
+// workspace layout (forward): tmp_i_all [T*B,6H] | wh_t [5H,H] | gemm split-K scratch
+size_t mh_hwlstm_fwd_ws_bytes(int in_size, int H, int B, int L, int T)
+{
+    (void)L;
+    size_t s = align_up((size_t)T * B * 6 * H * sizeof(float), 256) + align_up((size_t)5 * H * H * sizeof(float), 256);
+    s += std::max(mh_gemm_ws_bytes(T * B, 6 * H, in_size, 0), mh_gemm_ws_bytes(T * B, 6 * H, H, 0));
+    return s + 256;
+}
+
+int mh_hwlstm_fwd(int in_size, int H, int B, int L, int T, const float *x, const int *lengths_host, float *h_data,
+                  float *c_data, const float *weight, const float *bias, const float *dropout, float *gates,
+                  int is_training, void *workspace, size_t ws_bytes, void *stream)
+{
+    MH_REQUIRE(in_size > 0 && H > 0 && B > 0 && L > 0 && T > 0);
+    MH_REQUIRE(x && lengths_host && h_data && c_data && weight && bias && dropout && workspace);
+    MH_REQUIRE(!is_training || gates);
+    MH_REQUIRE(ws_bytes >= mh_hwlstm_fwd_ws_bytes(in_size, H, B, L, T));
+    MH_REQUIRE(T <= 4096);
+    for (int b = 0; b < B; ++b) {
+        MH_REQUIRE(lengths_host[b] >= 1 && lengths_host[b] <= T);
+        MH_REQUIRE(b == 0 || lengths_host[b] <= lengths_host[b - 1]);
+    }
+    MH_REQUIRE(lengths_host[0] == T);
+    hipStream_t st = as_stream(stream);
+    char *ws = reinterpret_cast<char *>(workspace);
+    float *tmp_i = reinterpret_cast<float *>(ws);
+    ws += align_up((size_t)T * B * 6 * H * sizeof(float), 256);
+    float *wh_t = reinterpret_cast<float *>(ws);
+    ws += align_up((size_t)5 * H * H * sizeof(float), 256);
+    void *gws = ws;
+    const size_t gws_bytes = ws_bytes - (size_t)(ws - reinterpret_cast<char *>(workspace));
+    const size_t numEl = (size_t)B * H;
+    int ts[4096], ns[4096];
+
+    for (int layer = 0; layer < L; ++layer) {
+        const LayerOffsets o = layer_offsets(in_size, H, layer);
+        const bool fwd_dir = (layer % 2 == 0);
+        const float *inp = (layer == 0) ? x : h_data + ((size_t)(layer - 1) * (T + 1) + 1) * numEl;
+        // tmp_i[T*B, 6H] = inp[T*B, in] * Wx[in, 6H]
+        MH_TRY(mh_gemm_f32(0, 0, T * B, 6 * H, o.in_size, inp, o.in_size, weight + o.wx, 6 * H, tmp_i, 6 * H, nullptr,
+                           MH_EPI_NONE, 0, 0, gws, gws_bytes, stream));
+        // wh_t[5H,H] = Wh[H,5H]^T so that every output column's K weights are contiguous
+        hipLaunchKernelGGL(transpose2d_kernel, dim3(ceil_div(5 * H, 32), ceil_div(H, 32)), dim3(256), 0, st,
+                           weight + o.wh, H, 5 * H, wh_t);
+        MH_TRY(check_launch("transpose2d_kernel"));
+        covered_schedule(lengths_host, T, B, fwd_dir, ts, ns);
+        float *hl = h_data + (size_t)layer * (T + 1) * numEl;
+        float *cl = c_data + (size_t)layer * (T + 1) * numEl;
+        for (int i = 0; i < T; ++i) {
+            const int t = ts[i], n = ns[i];
+            if (n == 0) continue;
+            const int prev = fwd_dir ? t : (t + 2) % (T + 1);
+            MH_TRY(launch_cell_fwd(n, H, tmp_i + (size_t)t * B * 6 * H, 6 * H, hl + (size_t)prev * numEl,
+                                   cl + (size_t)prev * numEl, wh_t, bias + (size_t)5 * H * layer,
+                                   dropout + (size_t)layer * numEl, hl + (size_t)(t + 1) * numEl,
+                                   cl + (size_t)(t + 1) * numEl,
+                                   is_training ? gates + ((size_t)layer * T + t) * 6 * numEl : nullptr, st));
+        }
+    }
+    return MH_OK;
+}
+
+// workspace layout (backward): d_gates_all [T*B,6H] | h_grad [T+1,B,H] | c_grad [T+1,B,H] | below_grad x2 [T,B,H]
+//                              | gemm split-K scratch
+size_t mh_hwlstm_bwd_ws_bytes(int in_size, int H, int B, int L, int T)
+{
+    (void)L;
+    const size_t numEl = (size_t)B * H;
+    size_t s = align_up((size_t)T * B * 6 * H * sizeof(float), 256);
+    s += 2 * align_up((size_t)(T + 1) * numEl * sizeof(float), 256);
+    s += 2 * align_up((size_t)T * numEl * sizeof(float), 256);
+    size_t g = 0;
+    const int ins[2] = {in_size, H};
+    for (int i = 0; i < 2; ++i) {
+        g = std::max(g, mh_gemm_ws_bytes(T * B, ins[i], 6 * H, 0));
+        g = std::max(g, mh_gemm_ws_bytes(ins[i], 6 * H, T * B, 0));
+    }
+    g = std::max(g, mh_gemm_ws_bytes(H, 5 * H, T * B, 0));
+    return s + g + 256;
+}
+
+int mh_hwlstm_bwd(int in_size, int H, int B, int L, int T, const float *out_grad, const int *lengths_host,
+                  const float *x, const float *h_data, const float *c_data, const float *weight, const float *gates,
+                  const float *dropout, float *x_grad, float *weight_grad, float *bias_grad, int do_weight_grad,
+                  void *workspace, size_t ws_bytes, void *stream)
+{
+    MH_REQUIRE(in_size > 0 && H > 0 && B > 0 && L > 0 && T > 0 && T <= 4096);
+    MH_REQUIRE(out_grad && lengths_host && x && h_data && c_data && weight && gates && dropout && x_grad && workspace);
+    MH_REQUIRE(!do_weight_grad || (weight_grad && bias_grad));
+    MH_REQUIRE(ws_bytes >= mh_hwlstm_bwd_ws_bytes(in_size, H, B, L, T));
+    for (int b = 0; b < B; ++b) {
+        MH_REQUIRE(lengths_host[b] >= 1 && lengths_host[b] <= T);
+        MH_REQUIRE(b == 0 || lengths_host[b] <= lengths_host[b - 1]);
+    }
+    hipStream_t st = as_stream(stream);
+    const size_t numEl = (size_t)B * H;
+    char *ws = reinterpret_cast<char *>(workspace);
+    float *dg_all = reinterpret_cast<float *>(ws);
+    ws += align_up((size_t)T * B * 6 * H * sizeof(float), 256);
+    float *h_grad = reinterpret_cast<float *>(ws);
+    ws += align_up((size_t)(T + 1) * numEl * sizeof(float), 256);
+    float *c_grad = reinterpret_cast<float *>(ws);
+    ws += align_up((size_t)(T + 1) * numEl * sizeof(float), 256);
+    float *below[2];
+    below[0] = reinterpret_cast<float *>(ws);
+    ws += align_up((size_t)T * numEl * sizeof(float), 256);
+    below[1] = reinterpret_cast<float *>(ws);
+    ws += align_up((size_t)T * numEl * sizeof(float), 256);
+    void *gws = ws;
+    const size_t gws_bytes = ws_bytes - (size_t)(ws - reinterpret_cast<char *>(workspace));
+    int ts[4096], ns[4096];
+
+    const float *grad_in = out_grad;  // gradient arriving at the current layer's outputs [T,B,H]
+    for (int layer = L - 1; layer >= 0; --layer) {
+        const LayerOffsets o = layer_offsets(in_size, H, layer);
+        const bool fwd_dir = (layer % 2 == 0);
+        hipError_t e = hipMemsetAsync(dg_all, 0, (size_t)T * B * 6 * H * sizeof(float), st);
+        if (e == hipSuccess) e = hipMemsetAsync(h_grad, 0, (size_t)(T + 1) * numEl * sizeof(float), st);
+        if (e == hipSuccess) e = hipMemsetAsync(c_grad, 0, (size_t)(T + 1) * numEl * sizeof(float), st);
+        if (e != hipSuccess) return (int)e;
+        const float *hl = h_data + (size_t)layer * (T + 1) * numEl;
+        const float *cl = c_data + (size_t)layer * (T + 1) * numEl;
+        // the backward pass walks time in the opposite order of the forward pass (:199-231)
+        covered_schedule(lengths_host, T, B, !fwd_dir ? true : false, ts, ns);
+        // (for a forward-direction layer the backward visits t = T-1..0 with n growing, which is exactly the
+        //  schedule of a backward-direction forward pass, and vice versa)
+        for (int i = 0; i < T; ++i) {
+            const int t = ts[i], n = ns[i];
+            if (n == 0) continue;
+            const int prev_grad = fwd_dir ? (t + 2) % (T + 1) : t;
+            const int prev = fwd_dir ? t : (t + 2) % (T + 1);
+            float *dg = dg_all + (size_t)t * B * 6 * H;
+            hipLaunchKernelGGL(hw_cell_bwd_kernel, dim3(ceil_div(n * H, 256)), dim3(256), 0, st, n, H,
+                               grad_in + (size_t)t * numEl, h_grad + (size_t)prev_grad * numEl,
+                               c_grad + (size_t)prev_grad * numEl, cl + (size_t)prev * numEl,
+                               cl + (size_t)(t + 1) * numEl, gates + ((size_t)layer * T + t) * 6 * numEl,
+                               dropout + (size_t)layer * numEl, dg, c_grad + (size_t)(t + 1) * numEl);
+            MH_TRY(check_launch("hw_cell_bwd_kernel"));
+            // h_grad[t+1][:n] = dg[:n,:5H] * Wh^T      (Wh [H,5H]: row k is contiguous over the 5H gate columns)
+            MH_TRY(launch_gemv_rows(n, H, 5 * H, dg, 6 * H, weight + o.wh, 5 * H, nullptr,
+                                    h_grad + (size_t)(t + 1) * numEl, H, st));
+        }
+        const float *inp = (layer == 0) ? x : h_data + ((size_t)(layer - 1) * (T + 1) + 1) * numEl;
+        float *inp_grad = (layer == 0) ? x_grad : below[layer & 1];
+        // d(inp)[T*B, in] = dg_all[T*B, 6H] * Wx[in, 6H]^T
+        MH_TRY(mh_gemm_f32(0, 1, T * B, o.in_size, 6 * H, dg_all, 6 * H, weight + o.wx, 6 * H, inp_grad, o.in_size,
+                           nullptr, MH_EPI_NONE, 0, 0, gws, gws_bytes, stream));
+        if (do_weight_grad) {
+            // dWx[in, 6H] += inp[T*B, in]^T * dg_all[T*B, 6H]
+            MH_TRY(mh_gemm_f32(1, 0, o.in_size, 6 * H, T * B, inp, o.in_size, dg_all, 6 * H, weight_grad + o.wx, 6 * H,
+                               nullptr, MH_EPI_NONE, 1, 0, gws, gws_bytes, stream));
+            // dWh[H, 5H] += h_prev^T * dg_all[:, :5H];  h_prev(t) = slot t (forward layers) or slot t+2
+            // (backward layers; t = T-1 reads the all-zero slot 0 and contributes nothing)
+            if (fwd_dir) {
+                MH_TRY(mh_gemm_f32(1, 0, H, 5 * H, T * B, hl, H, dg_all, 6 * H, weight_grad + o.wh, 5 * H, nullptr,
+                                   MH_EPI_NONE, 1, 0, gws, gws_bytes, stream));
+            } else if (T > 1) {
+                MH_TRY(mh_gemm_f32(1, 0, H, 5 * H, (T - 1) * B, hl + 2 * numEl, H, dg_all, 6 * H, weight_grad + o.wh,
+                                   5 * H, nullptr, MH_EPI_NONE, 1, 0, gws, gws_bytes, stream));
+            }
+            hipLaunchKernelGGL(colsum_accum_kernel, dim3(ceil_div(5 * H, 256)), dim3(256), 0, st, dg_all, T * B, 5 * H,
+                               6 * H, bias_grad + (size_t)5 * H * layer);
+            MH_TRY(check_launch("colsum_accum_kernel"));
+        }
+        grad_in = inp_grad;
+    }
+    return MH_OK;
+}
+
+}  // extern "C"

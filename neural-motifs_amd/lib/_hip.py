@@ -1,0 +1,347 @@
+"""
+ctypes binding of libmotifs_hip.so (the C ABI declared in include/motifs_hip.h).
+
+This is the ONLY gateway from Python to the hot-path kernels.  There is no CPU or eager-PyTorch
+fallback: if the shared object is missing, or a tensor is not a contiguous fp32/int32 CUDA(HIP)
+tensor, the call raises.  Build the library with ``python neural-motifs_amd/csrc/build.py``
+(or ``__graft_entry__.build()``).
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+SO_PATH = os.path.join(os.path.dirname(_HERE), 'csrc', 'libmotifs_hip.so')
+
+# every symbol include/motifs_hip.h declares (checked by tests/test_cabi.py against the header)
+SYMBOLS = (
+    'mh_version', 'mh_last_error',
+    'mh_nms_ws_bytes', 'mh_nms', 'mh_nms_batched_ws_bytes', 'mh_nms_batched',
+    'mh_roi_align_fwd', 'mh_roi_align_bwd', 'mh_draw_union_boxes', 'mh_bbox_overlaps',
+    'mh_gemm_ws_bytes', 'mh_gemm_auto_splitk', 'mh_gemm_f32',
+    'mh_conv3x3_pack_weight', 'mh_conv3x3_nhwc', 'mh_conv_first_nchw', 'mh_maxpool2x2_nhwc',
+    'mh_im2col_nhwc', 'mh_nchw_to_nhwc', 'mh_nhwc_to_nchw',
+    'mh_hwlstm_fwd_ws_bytes', 'mh_hwlstm_fwd', 'mh_hwlstm_bwd_ws_bytes', 'mh_hwlstm_bwd',
+    'mh_hwlstm_cell_fwd', 'mh_hwlstm_cell_bwd', 'mh_gemv_rows',
+)
+
+_lib = None
+
+
+class HipKernelError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load the shared object (once).  Raises if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(SO_PATH):
+            raise HipKernelError(
+                'libmotifs_hip.so not found at %s -- build it with '
+                '`python neural-motifs_amd/csrc/build.py`; there is no fallback path' % SO_PATH)
+        L = ctypes.CDLL(SO_PATH)
+        for name in SYMBOLS:
+            getattr(L, name)          # AttributeError if the library is stale
+        L.mh_last_error.restype = ctypes.c_char_p
+        for name in ('mh_nms_ws_bytes', 'mh_nms_batched_ws_bytes', 'mh_gemm_ws_bytes',
+                     'mh_hwlstm_fwd_ws_bytes', 'mh_hwlstm_bwd_ws_bytes'):
+            getattr(L, name).restype = ctypes.c_size_t
+        _lib = L
+    return _lib
+
+
+def _check(rc, what):
+    if rc != 0:
+        msg = lib().mh_last_error()
+        raise HipKernelError('%s failed with status %d: %s' % (what, rc, msg.decode() if msg else ''))
+
+
+def ptr(t):
+    """device pointer of a contiguous CUDA tensor (or NULL for None)"""
+    if t is None:
+        return ctypes.c_void_p(0)
+    if not t.is_cuda:
+        raise HipKernelError('expected a CUDA (HIP) tensor, got a %s tensor: the hot path has no CPU fallback'
+                             % t.device.type)
+    if not t.is_contiguous():
+        raise HipKernelError('tensor must be contiguous')
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def f32(t):
+    if t is not None and t.dtype != torch.float32:
+        raise HipKernelError('expected float32, got %s' % t.dtype)
+    return ptr(t)
+
+
+def i32(t):
+    if t is not None and t.dtype != torch.int32:
+        raise HipKernelError('expected int32, got %s' % t.dtype)
+    return ptr(t)
+
+
+def stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+_ws_cache = {}
+
+
+def workspace(nbytes, device, tag='default'):
+    """Grow-only scratch buffer per (device, tag).  All users are ordered on the current stream."""
+    nbytes = max(int(nbytes), 256)
+    key = (str(device), tag)
+    buf = _ws_cache.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(int(nbytes * 1.25) + 256, dtype=torch.uint8, device=device)
+        _ws_cache[key] = buf
+    return buf
+
+
+c_int = ctypes.c_int
+c_float = ctypes.c_float
+c_size_t = ctypes.c_size_t
+
+
+# ----------------------------------------------------------------------------------------------- GEMM
+def gemm(a, b, trans_a=False, trans_b=False, bias=None, epilogue=0, out=None, accumulate=False, splitk=0):
+    """C = epi(op(a) @ op(b) + bias) on the FP32 MFMA GEMM.  a, b: 2-D fp32 CUDA tensors whose last dim is
+    contiguous (row stride may exceed the width)."""
+    L = lib()
+    for t in (a, b):
+        if t.dim() != 2 or t.stride(1) != 1 or not t.is_cuda or t.dtype != torch.float32:
+            raise HipKernelError('gemm operands must be 2-D fp32 CUDA tensors with unit inner stride')
+    M = a.shape[1] if trans_a else a.shape[0]
+    K = a.shape[0] if trans_a else a.shape[1]
+    Kb = b.shape[1] if trans_b else b.shape[0]
+    N = b.shape[0] if trans_b else b.shape[1]
+    if K != Kb:
+        raise HipKernelError('gemm inner dimensions differ: %d vs %d' % (K, Kb))
+    if out is None:
+        out = torch.empty(M, N, dtype=torch.float32, device=a.device)
+        accumulate = False
+    elif out.shape != (M, N) or out.stride(1) != 1:
+        raise HipKernelError('bad output tensor for gemm')
+    if M == 0 or N == 0:
+        return out
+    if K == 0:
+        if not accumulate:
+            out.zero_()
+        return out
+    if splitk <= 0:
+        splitk = L.mh_gemm_auto_splitk(M, N, K)
+    wsb = L.mh_gemm_ws_bytes(M, N, K, splitk)
+    ws = workspace(wsb, a.device, 'gemm') if wsb else None
+    rc = L.mh_gemm_f32(c_int(int(trans_a)), c_int(int(trans_b)), M, N, K,
+                       ctypes.c_void_p(a.data_ptr()), c_int(a.stride(0)),
+                       ctypes.c_void_p(b.data_ptr()), c_int(b.stride(0)),
+                       ctypes.c_void_p(out.data_ptr()), c_int(out.stride(0)),
+                       f32(bias), c_int(epilogue), c_int(int(accumulate)), c_int(splitk),
+                       ptr(ws), c_size_t(ws.numel() if ws is not None else 0), stream())
+    _check(rc, 'mh_gemm_f32')
+    return out
+
+
+# ----------------------------------------------------------------------------------------------- NMS
+def nms(boxes_sorted, thresh):
+    """boxes_sorted [n,4] fp32 (score-descending).  Returns (keep int32 [n], num_keep int32 [1]) on device."""
+    L = lib()
+    n = boxes_sorted.shape[0]
+    keep = torch.empty(max(n, 1), dtype=torch.int32, device=boxes_sorted.device)
+    num = torch.zeros(1, dtype=torch.int32, device=boxes_sorted.device)
+    ws = workspace(L.mh_nms_ws_bytes(n), boxes_sorted.device, 'nms')
+    rc = L.mh_nms(f32(boxes_sorted), n, c_float(thresh), i32(keep), i32(num), ptr(ws), c_size_t(ws.numel()),
+                  stream())
+    _check(rc, 'mh_nms')
+    return keep, num
+
+
+def nms_batched(boxes_sorted, seg_offsets, max_seg, thresh):
+    """boxes_sorted [total,4]; seg_offsets int32 [nseg+1] (device).  Returns keep [total] (segment-relative
+    positions, packed at each segment's offset) and num_keep [nseg]."""
+    L = lib()
+    total = boxes_sorted.shape[0]
+    nseg = seg_offsets.numel() - 1
+    keep = torch.empty(max(total, 1), dtype=torch.int32, device=boxes_sorted.device)
+    num = torch.zeros(max(nseg, 1), dtype=torch.int32, device=boxes_sorted.device)
+    ws = workspace(L.mh_nms_batched_ws_bytes(total, nseg, max_seg), boxes_sorted.device, 'nms')
+    rc = L.mh_nms_batched(f32(boxes_sorted), i32(seg_offsets), nseg, total, int(max_seg), c_float(thresh),
+                          i32(keep), i32(num), ptr(ws), c_size_t(ws.numel()), stream())
+    _check(rc, 'mh_nms_batched')
+    return keep, num
+
+
+# ----------------------------------------------------------------------------------------------- RoIAlign
+def roi_align_fwd(feat, rois, ph, pw, spatial_scale, nhwc):
+    """feat: [B,C,H,W] (nhwc=False) or [B,H,W,C] (nhwc=True) contiguous.  -> [n,C,ph,pw]"""
+    if nhwc:
+        B, H, W, C = feat.shape
+    else:
+        B, C, H, W = feat.shape
+    n = rois.shape[0]
+    out = torch.empty(n, C, ph, pw, dtype=torch.float32, device=feat.device)
+    rc = lib().mh_roi_align_fwd(f32(feat), B, C, H, W, c_int(int(nhwc)), f32(rois), n, ph, pw,
+                                c_float(spatial_scale), f32(out), stream())
+    _check(rc, 'mh_roi_align_fwd')
+    return out
+
+
+def roi_align_bwd(grad_out, rois, B, C, H, W, spatial_scale, nhwc):
+    n, _, ph, pw = grad_out.shape
+    shape = (B, H, W, C) if nhwc else (B, C, H, W)
+    gf = torch.empty(shape, dtype=torch.float32, device=grad_out.device)
+    rc = lib().mh_roi_align_bwd(f32(grad_out), B, C, H, W, c_int(int(nhwc)), f32(rois), n, ph, pw,
+                                c_float(spatial_scale), f32(gf), stream())
+    _check(rc, 'mh_roi_align_bwd')
+    return gf
+
+
+def draw_union_boxes(box_pairs, P, offset=0.0, channels_last=False):
+    n = box_pairs.shape[0]
+    shape = (n, P, P, 2) if channels_last else (n, 2, P, P)
+    out = torch.empty(shape, dtype=torch.float32, device=box_pairs.device)
+    rc = lib().mh_draw_union_boxes(f32(box_pairs), n, P, c_float(offset), c_int(int(channels_last)), f32(out),
+                                   stream())
+    _check(rc, 'mh_draw_union_boxes')
+    return out
+
+
+def bbox_overlaps(a, b):
+    out = torch.empty(a.shape[0], b.shape[0], dtype=torch.float32, device=a.device)
+    rc = lib().mh_bbox_overlaps(f32(a), a.shape[0], f32(b), b.shape[0], f32(out), stream())
+    _check(rc, 'mh_bbox_overlaps')
+    return out
+
+
+# ----------------------------------------------------------------------------------------------- conv stack
+def conv3x3_pack_weight(w, flip_transpose=False):
+    Cout, Cin = w.shape[0], w.shape[1]
+    wt = torch.empty((9, Cout, Cin) if flip_transpose else (9, Cin, Cout), dtype=torch.float32, device=w.device)
+    rc = lib().mh_conv3x3_pack_weight(f32(w), Cout, Cin, c_int(int(flip_transpose)), f32(wt), stream())
+    _check(rc, 'mh_conv3x3_pack_weight')
+    return wt
+
+
+def conv3x3_nhwc(x, wt, bias, epilogue):
+    """x [B,H,W,Cin], wt [9,Cin,Cout] -> [B,H,W,Cout]"""
+    B, H, W, Cin = x.shape
+    Cout = wt.shape[2]
+    out = torch.empty(B, H, W, Cout, dtype=torch.float32, device=x.device)
+    rc = lib().mh_conv3x3_nhwc(f32(x), B, H, W, Cin, f32(wt), Cout, f32(bias), c_int(epilogue), f32(out), stream())
+    _check(rc, 'mh_conv3x3_nhwc')
+    return out
+
+
+def conv_first_nchw(x, w, bias, epilogue):
+    """x [B,Cin,H,W] NCHW, w [Cout,Cin,3,3] -> NHWC [B,H,W,Cout]"""
+    B, Cin, H, W = x.shape
+    Cout = w.shape[0]
+    out = torch.empty(B, H, W, Cout, dtype=torch.float32, device=x.device)
+    rc = lib().mh_conv_first_nchw(f32(x), B, Cin, H, W, f32(w), Cout, f32(bias), c_int(epilogue), f32(out), stream())
+    _check(rc, 'mh_conv_first_nchw')
+    return out
+
+
+def maxpool2x2_nhwc(x):
+    B, H, W, C = x.shape
+    out = torch.empty(B, H // 2, W // 2, C, dtype=torch.float32, device=x.device)
+    rc = lib().mh_maxpool2x2_nhwc(f32(x), B, H, W, C, f32(out), stream())
+    _check(rc, 'mh_maxpool2x2_nhwc')
+    return out
+
+
+def im2col_nhwc(x, kh, kw, stride, pad, ldo=None):
+    B, H, W, C = x.shape
+    Ho = (H + 2 * pad - kh) // stride + 1
+    Wo = (W + 2 * pad - kw) // stride + 1
+    K = kh * kw * C
+    ldo = K if ldo is None else ldo
+    out = torch.empty(B * Ho * Wo, ldo, dtype=torch.float32, device=x.device)
+    rc = lib().mh_im2col_nhwc(f32(x), B, H, W, C, kh, kw, stride, pad, f32(out), ldo, stream())
+    _check(rc, 'mh_im2col_nhwc')
+    return out, Ho, Wo
+
+
+def nchw_to_nhwc(x):
+    B, C, H, W = x.shape
+    out = torch.empty(B, H, W, C, dtype=torch.float32, device=x.device)
+    _check(lib().mh_nchw_to_nhwc(f32(x), B, C, H, W, f32(out), stream()), 'mh_nchw_to_nhwc')
+    return out
+
+
+def nhwc_to_nchw(x):
+    B, H, W, C = x.shape
+    out = torch.empty(B, C, H, W, dtype=torch.float32, device=x.device)
+    _check(lib().mh_nhwc_to_nchw(f32(x), B, C, H, W, f32(out), stream()), 'mh_nhwc_to_nchw')
+    return out
+
+
+# ----------------------------------------------------------------------------------------------- LSTM
+def _lengths_array(lengths):
+    arr = (ctypes.c_int * len(lengths))(*[int(v) for v in lengths])
+    return arr
+
+
+def hwlstm_fwd(x, lengths, weight, bias, dropout, H, L_, training):
+    """x [T,B,in]; returns (h_data, c_data [L,T+1,B,H], gates [L,T,B,6H] or None)"""
+    T, B, in_size = x.shape
+    dev = x.device
+    h_data = torch.zeros(L_, T + 1, B, H, dtype=torch.float32, device=dev)
+    c_data = torch.zeros(L_, T + 1, B, H, dtype=torch.float32, device=dev)
+    gates = torch.empty(L_, T, B, 6 * H, dtype=torch.float32, device=dev) if training else None
+    wsb = lib().mh_hwlstm_fwd_ws_bytes(in_size, H, B, L_, T)
+    ws = workspace(wsb, dev, 'lstm')
+    rc = lib().mh_hwlstm_fwd(in_size, H, B, L_, T, f32(x), _lengths_array(lengths), f32(h_data), f32(c_data),
+                             f32(weight), f32(bias), f32(dropout), f32(gates), c_int(int(training)),
+                             ptr(ws), c_size_t(ws.numel()), stream())
+    _check(rc, 'mh_hwlstm_fwd')
+    return h_data, c_data, gates
+
+
+def hwlstm_bwd(out_grad, x, lengths, weight, dropout, H, L_, h_data, c_data, gates, need_weight_grad=True):
+    T, B, in_size = x.shape
+    dev = x.device
+    x_grad = torch.empty_like(x)
+    w_grad = torch.zeros_like(weight) if need_weight_grad else None
+    b_grad = torch.zeros(5 * H * L_, dtype=torch.float32, device=dev) if need_weight_grad else None
+    wsb = lib().mh_hwlstm_bwd_ws_bytes(in_size, H, B, L_, T)
+    ws = workspace(wsb, dev, 'lstm')
+    rc = lib().mh_hwlstm_bwd(in_size, H, B, L_, T, f32(out_grad), _lengths_array(lengths), f32(x), f32(h_data),
+                             f32(c_data), f32(weight), f32(gates), f32(dropout), f32(x_grad), f32(w_grad),
+                             f32(b_grad), c_int(int(need_weight_grad)), ptr(ws), c_size_t(ws.numel()), stream())
+    _check(rc, 'mh_hwlstm_bwd')
+    return x_grad, w_grad, b_grad
+
+
+def hwlstm_cell_fwd(pre_i, h_prev, c_prev, wh_t, bias_h, dropout, want_gates):
+    n, H = h_prev.shape
+    h_out = torch.empty_like(h_prev)
+    c_out = torch.empty_like(c_prev)
+    gates = torch.empty(n, 6 * H, dtype=torch.float32, device=h_prev.device) if want_gates else None
+    rc = lib().mh_hwlstm_cell_fwd(n, H, f32(pre_i), f32(h_prev), f32(c_prev), f32(wh_t), f32(bias_h), f32(dropout),
+                                  f32(h_out), f32(c_out), f32(gates), stream())
+    _check(rc, 'mh_hwlstm_cell_fwd')
+    return h_out, c_out, gates
+
+
+def hwlstm_cell_bwd(d_h, d_c_out, c_prev, c_out, gates, dropout):
+    n, H = d_h.shape
+    d_gates = torch.empty(n, 6 * H, dtype=torch.float32, device=d_h.device)
+    d_c_in = torch.empty(n, H, dtype=torch.float32, device=d_h.device)
+    rc = lib().mh_hwlstm_cell_bwd(n, H, f32(d_h), f32(d_c_out), f32(c_prev), f32(c_out), f32(gates), f32(dropout),
+                                  f32(d_gates), f32(d_c_in), stream())
+    _check(rc, 'mh_hwlstm_cell_bwd')
+    return d_gates, d_c_in
+
+
+def gemv_rows(v, wt, bias=None):
+    """out[n,R] = v[n,K] @ wt[R,K]^T (+ bias): small-n GEMV, one wave per 4 output rows"""
+    n, K = v.shape
+    R = wt.shape[0]
+    out = torch.empty(n, R, dtype=torch.float32, device=v.device)
+    rc = lib().mh_gemv_rows(n, R, K, ctypes.c_void_p(v.data_ptr()), c_int(v.stride(0)),
+                            ctypes.c_void_p(wt.data_ptr()), c_int(wt.stride(0)), f32(bias), f32(out), R, stream())
+    _check(rc, 'mh_gemv_rows')
+    return out

@@ -1,0 +1,64 @@
+"""C-ABI checks that need no GPU: the shared object builds/loads and exports exactly the symbols
+include/motifs_hip.h declares; the product path refuses to run without a HIP device."""
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, 'include', 'motifs_hip.h')
+
+
+def _declared_symbols():
+    src = open(HEADER).read()
+    src = re.sub(r'/\*.*?\*/', '', src, flags=re.S)
+    return sorted(set(re.findall(r'\b(mh_[a-z0-9_]+)\s*\(', src)))
+
+
+@pytest.fixture(scope='module')
+def so_path():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location('mh_build', os.path.join(ROOT, 'neural-motifs_amd', 'csrc', 'build.py'))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod.build()
+
+
+def test_header_symbols_are_exported(so_path):
+    lib = ctypes.CDLL(so_path)
+    declared = _declared_symbols()
+    assert len(declared) >= 25
+    for name in declared:
+        assert hasattr(lib, name), 'header declares %s but the library does not export it' % name
+    assert lib.mh_version() >= 100
+
+
+def test_python_binding_lists_every_header_symbol(so_path):
+    from lib import _hip
+    assert sorted(_hip.SYMBOLS) == _declared_symbols()
+    _hip.lib()
+
+
+def test_argument_validation_needs_no_device(so_path):
+    lib = ctypes.CDLL(so_path)
+    lib.mh_last_error.restype = ctypes.c_char_p
+    lib.mh_gemm_ws_bytes.restype = ctypes.c_size_t
+    lib.mh_nms_ws_bytes.restype = ctypes.c_size_t
+    assert lib.mh_gemm_auto_splitk(120, 4096, 25088) >= 2          # 32 tiles: split K to fill 256 CUs
+    assert lib.mh_gemm_auto_splitk(8214, 512, 4608) == 1 or lib.mh_gemm_auto_splitk(8214, 512, 4608) >= 1
+    assert lib.mh_gemm_ws_bytes(120, 4096, 25088, 4) >= 4 * 120 * 4096 * 4
+    assert lib.mh_nms_ws_bytes(6000) >= 6000 * 94 * 8
+    # bad arguments are reported, never abort()/exit()
+    rc = lib.mh_gemm_f32(0, 0, 4, 4, 4, None, 4, None, 4, None, 4, None, 0, 0, 1, None, ctypes.c_size_t(0), None)
+    assert rc == -1 and b'bad argument' in lib.mh_last_error()
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason='checks the no-GPU failure mode')
+def test_hot_path_fails_loudly_without_gpu(so_path):
+    from lib import _hip
+    with pytest.raises(_hip.HipKernelError):
+        _hip.gemm(torch.zeros(4, 4), torch.zeros(4, 4))
+    with pytest.raises(_hip.HipKernelError):
+        _hip.nms(torch.zeros(4, 4), 0.5)

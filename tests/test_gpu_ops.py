@@ -1,0 +1,334 @@
+"""
+GPU parity tests proper: every HIP operator, called through the C ABI (lib/_hip.py -> libmotifs_hip.so),
+against the CPU oracle on the same seeded inputs.
+
+Bars: bit-exact for NMS keep lists, RoIAlign, union-box masks, fp32 IoU (integer / index / border-decision work);
+1e-4 absolute for fp32 GEMM / conv / LSTM arithmetic (BASELINE.json north_star).
+"""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def hip():
+    if not torch.cuda.is_available():
+        pytest.fail('GPU tests need a HIP device (there is no CPU fallback for the hot path)')
+    from lib import _hip
+    _hip.lib()
+    return _hip
+
+
+def dev(a, dtype=torch.float32):
+    return torch.as_tensor(np.ascontiguousarray(a), dtype=dtype).cuda()
+
+
+def rand_boxes(rs, n, hi=591.0):
+    x1 = rs.uniform(0, hi - 20, n)
+    y1 = rs.uniform(0, hi - 20, n)
+    w = rs.uniform(2, 250, n)
+    h = rs.uniform(2, 250, n)
+    return np.stack([x1, y1, np.minimum(x1 + w, hi), np.minimum(y1 + h, hi)], 1).astype(np.float32)
+
+
+# ----------------------------------------------------------------------------------------------- NMS
+@pytest.mark.parametrize('n,thresh', [(0, 0.5), (1, 0.5), (2, 0.3), (63, 0.3), (64, 0.7), (65, 0.5), (129, 0.3),
+                                      (1000, 0.3), (2500, 0.5), (6000, 0.7)])
+def test_nms_bit_exact(hip, n, thresh):
+    from oracle import native
+    rs = np.random.RandomState(100 + n)
+    boxes = rand_boxes(rs, n)
+    if n >= 64:
+        boxes[5] = boxes[3]                 # exact duplicates (IoU == 1)
+        boxes[40:44] = boxes[40] + np.float32(0.5)
+    keep, num = hip.nms(dev(boxes).view(-1, 4), thresh)
+    k = int(num.item())
+    ref = native.nms(boxes, thresh)
+    assert k == len(ref)
+    np.testing.assert_array_equal(keep[:k].cpu().numpy(), ref)
+
+
+def test_nms_thresholds_at_the_boundary(hip):
+    """IoU exactly equal to the threshold must NOT suppress (strict >), as in nms_kernel.cu:61."""
+    from oracle import native
+    boxes = np.array([[0, 0, 9, 9], [0, 5, 9, 14], [100, 100, 119, 119], [100, 110, 119, 129]], np.float32)
+    # IoU(0,1) = 50/150 = 1/3 ; IoU(2,3) = 200/600 = 1/3
+    for thr in (np.float32(1.0) / np.float32(3.0), 0.3333, 0.33334):
+        keep, num = hip.nms(dev(boxes), float(thr))
+        ref = native.nms(boxes, float(thr))
+        np.testing.assert_array_equal(keep[:int(num.item())].cpu().numpy(), ref)
+
+
+def test_nms_batched_matches_per_segment(hip):
+    from oracle import native
+    rs = np.random.RandomState(7)
+    seg_lens = [300, 0, 64, 1, 517, 300]
+    offs = np.concatenate([[0], np.cumsum(seg_lens)]).astype(np.int32)
+    boxes = rand_boxes(rs, int(offs[-1]), hi=300.0)
+    keep, num = hip.nms_batched(dev(boxes).view(-1, 4), dev(offs, torch.int32), max(seg_lens), 0.3)
+    keep, num = keep.cpu().numpy(), num.cpu().numpy()
+    for s, L in enumerate(seg_lens):
+        ref = native.nms(boxes[offs[s]:offs[s + 1]], 0.3)
+        assert num[s] == len(ref)
+        np.testing.assert_array_equal(keep[offs[s]:offs[s] + num[s]], ref)
+
+
+# ----------------------------------------------------------------------------------------------- RoIAlign
+def _rois(rs, n, B):
+    b = rand_boxes(rs, n)
+    b[0] = [0, 0, 591, 591]            # spills over the last row/col -> zero fill
+    b[1] = [575.5, 10, 576.5, 400]     # straddles the x border decision in_x > W-1
+    b[2] = [16, 16, 16, 16]            # degenerate: every bin samples the same point
+    im = rs.randint(0, B, n).astype(np.float32)
+    return np.concatenate([im[:, None], b], 1).astype(np.float32)
+
+
+@pytest.mark.parametrize('C', [7, 64, 512])
+def test_roi_align_fwd_bit_exact(hip, C):
+    from oracle import native
+    rs = np.random.RandomState(C)
+    B = 3
+    feat = rs.randn(B, C, 37, 37).astype(np.float32)
+    rois = _rois(rs, 37, B)
+    rois[5, 0] = 9                      # image index out of range -> zeros
+    ref = native.roi_align_fwd(feat, rois)
+    out_nchw = hip.roi_align_fwd(dev(feat), dev(rois), 7, 7, 1.0 / 16, nhwc=False)
+    np.testing.assert_array_equal(out_nchw.cpu().numpy(), ref)
+    feat_nhwc = dev(feat.transpose(0, 2, 3, 1))
+    out_nhwc = hip.roi_align_fwd(feat_nhwc, dev(rois), 7, 7, 1.0 / 16, nhwc=True)
+    np.testing.assert_array_equal(out_nhwc.cpu().numpy(), ref)
+
+
+def test_roi_align_bwd(hip):
+    from oracle import native
+    rs = np.random.RandomState(5)
+    B, C = 2, 24
+    rois = _rois(rs, 11, B)
+    g = rs.randn(11, C, 7, 7).astype(np.float32)
+    ref = native.roi_align_bwd(g, rois, (B, C, 37, 37))
+    out = hip.roi_align_bwd(dev(g), dev(rois), B, C, 37, 37, 1.0 / 16, nhwc=False)
+    np.testing.assert_allclose(out.cpu().numpy(), ref, atol=1e-5)          # atomic order differs
+    out2 = hip.roi_align_bwd(dev(g), dev(rois), B, C, 37, 37, 1.0 / 16, nhwc=True)
+    np.testing.assert_allclose(out2.permute(0, 3, 1, 2).cpu().numpy(), ref, atol=1e-5)
+
+
+# ----------------------------------------------------------------------------------------------- masks / IoU
+@pytest.mark.parametrize('P', [27, 7])
+def test_draw_union_boxes_matches_reference_golden(hip, golden, P):
+    g = golden('draw_P%d' % P)
+    out = hip.draw_union_boxes(dev(g['pairs']), P)
+    np.testing.assert_array_equal(out.cpu().numpy(), g['masks'])
+    out_cl = hip.draw_union_boxes(dev(g['pairs']), P, offset=-0.5, channels_last=True)
+    np.testing.assert_array_equal(out_cl.permute(0, 3, 1, 2).cpu().numpy(), g['masks'] - np.float32(0.5))
+
+
+def test_draw_union_boxes_random_vs_oracle(hip):
+    from oracle import native
+    rs = np.random.RandomState(1)
+    pairs = np.concatenate([rand_boxes(rs, 700), rand_boxes(rs, 700)], 1)
+    out = hip.draw_union_boxes(dev(pairs), 27)
+    np.testing.assert_array_equal(out.cpu().numpy(), native.draw_union_boxes(pairs, 27))
+
+
+def test_bbox_overlaps_matches_reference_golden(hip, golden):
+    g = golden('box_utils')
+    out = hip.bbox_overlaps(dev(g['boxes']), dev(g['boxes_b']))
+    np.testing.assert_array_equal(out.cpu().numpy(), g['bbox_overlaps'])
+
+
+# ----------------------------------------------------------------------------------------------- GEMM
+GEMM_CASES = [
+    # M, N, K, ta, tb
+    (128, 128, 64, 0, 1), (120, 4096, 1024, 0, 1), (1, 151, 512, 0, 1), (257, 130, 100, 0, 1),
+    (120, 3072, 4424, 0, 0), (37, 51, 4096, 0, 1), (300, 64, 48, 0, 0), (64, 200, 151, 0, 0),
+    (200, 600, 120, 1, 0), (151, 512, 96, 1, 0), (98, 256, 1000, 1, 0), (70, 90, 33, 1, 1), (513, 384, 256, 0, 0),
+]
+
+
+@pytest.mark.parametrize('M,N,K,ta,tb', GEMM_CASES)
+def test_gemm_against_fp64(hip, M, N, K, ta, tb):
+    g = torch.Generator().manual_seed(M * 7 + N * 3 + K)
+    a = torch.randn((K, M) if ta else (M, K), generator=g)
+    b = torch.randn((N, K) if tb else (K, N), generator=g)
+    bias = torch.randn(N, generator=g)
+    ref = ((a.t() if ta else a).double() @ (b.t() if tb else b).double())
+    out = hip.gemm(a.cuda(), b.cuda(), bool(ta), bool(tb))
+    tol = 2e-6 * K ** 0.5 * 4 + 1e-5
+    np.testing.assert_allclose(out.cpu().numpy(), ref.float().numpy(), atol=tol * 8)
+    # asymmetric operands: a transposed C-write would show as O(1) error
+    out2 = hip.gemm(a.cuda(), b.cuda(), bool(ta), bool(tb), bias=bias.cuda(), epilogue=1)
+    np.testing.assert_allclose(out2.cpu().numpy(), torch.relu(ref + bias.double()).float().numpy(), atol=tol * 8)
+    for sk in (2, 5):
+        out3 = hip.gemm(a.cuda(), b.cuda(), bool(ta), bool(tb), bias=bias.cuda(), splitk=sk)
+        np.testing.assert_allclose(out3.cpu().numpy(), (ref + bias.double()).float().numpy(), atol=tol * 8)
+    acc = torch.randn(M, N, generator=g)
+    out4 = acc.clone().cuda()
+    hip.gemm(a.cuda(), b.cuda(), bool(ta), bool(tb), out=out4, accumulate=True)
+    np.testing.assert_allclose(out4.cpu().numpy(), (ref + acc.double()).float().numpy(), atol=tol * 8)
+
+
+def test_gemm_is_an_exact_fp32_fma_chain(hip):
+    """MFMA f32 is a k-ordered fmaf chain: integer-valued operands give exact results."""
+    g = torch.Generator().manual_seed(0)
+    a = torch.randint(-8, 9, (130, 96), generator=g).float()
+    b = torch.randint(-8, 9, (70, 96), generator=g).float()
+    out = hip.gemm(a.cuda(), b.cuda(), False, True)
+    np.testing.assert_array_equal(out.cpu().numpy(), (a.double() @ b.double().t()).float().numpy())
+
+
+def test_gemm_strided_rows(hip):
+    g = torch.Generator().manual_seed(3)
+    big = torch.randn(40, 700, generator=g).cuda()
+    a = big[:, 100:612]                      # lda = 700, K = 512
+    w = torch.randn(96, 512, generator=g).cuda()
+    out = hip.gemm(a, w, False, True)
+    np.testing.assert_allclose(out.cpu().numpy(), (a.cpu().double() @ w.cpu().double().t()).float().numpy(), atol=2e-4)
+
+
+# ----------------------------------------------------------------------------------------------- conv stack
+@pytest.mark.parametrize('B,H,W,Cin,Cout,epi', [(2, 9, 11, 16, 32, 1), (1, 37, 37, 64, 128, 1), (2, 14, 14, 64, 64, 0),
+                                                (1, 20, 23, 128, 120, 2), (3, 7, 7, 256, 512, 1)])
+def test_conv3x3_nhwc(hip, B, H, W, Cin, Cout, epi):
+    g = torch.Generator().manual_seed(Cin + Cout)
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) * (2.0 / (9 * Cin)) ** 0.5
+    b = torch.randn(Cout, generator=g)
+    ref = F.conv2d(x.double(), w.double(), b.double(), padding=1)
+    ref = {0: ref, 1: F.relu(ref), 2: F.relu6(ref)}[epi]
+    wt = hip.conv3x3_pack_weight(w.cuda())
+    out = hip.conv3x3_nhwc(x.permute(0, 2, 3, 1).contiguous().cuda(), wt, b.cuda(), epi)
+    np.testing.assert_allclose(out.permute(0, 3, 1, 2).cpu().numpy(), ref.float().numpy(), atol=1e-4)
+
+
+def test_conv3x3_dgrad_via_flipped_weights(hip):
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(2, 32, 7, 7, generator=g, dtype=torch.float64, requires_grad=True)
+    w = torch.randn(48, 32, 3, 3, generator=g, dtype=torch.float64) * 0.1
+    y = F.conv2d(x, w, padding=1)
+    gy = torch.randn(y.shape, generator=g, dtype=torch.float64)
+    y.backward(gy)
+    wt = hip.conv3x3_pack_weight(w.float().cuda(), flip_transpose=True)        # [9, Cout, Cin]
+    gx = hip.conv3x3_nhwc(gy.float().permute(0, 2, 3, 1).contiguous().cuda(), wt, None, 0)
+    np.testing.assert_allclose(gx.permute(0, 3, 1, 2).cpu().numpy(), x.grad.float().numpy(), atol=1e-4)
+
+
+def test_conv_first_and_pool_and_layouts(hip):
+    g = torch.Generator().manual_seed(2)
+    x = torch.randn(2, 3, 38, 42, generator=g)
+    w = torch.randn(64, 3, 3, 3, generator=g) * 0.2
+    b = torch.randn(64, generator=g)
+    out = hip.conv_first_nchw(x.cuda(), w.cuda(), b.cuda(), 1)
+    ref = F.relu(F.conv2d(x.double(), w.double(), b.double(), padding=1)).float()
+    np.testing.assert_allclose(out.permute(0, 3, 1, 2).cpu().numpy(), ref.numpy(), atol=1e-5)
+    pooled = hip.maxpool2x2_nhwc(out)
+    np.testing.assert_array_equal(pooled.permute(0, 3, 1, 2).cpu().numpy(),
+                                  F.max_pool2d(out.permute(0, 3, 1, 2), 2, 2).cpu().numpy())
+    y = torch.randn(2, 5, 6, 7, generator=g).cuda()
+    np.testing.assert_array_equal(hip.nchw_to_nhwc(y).cpu().numpy(), y.permute(0, 2, 3, 1).contiguous().cpu().numpy())
+    np.testing.assert_array_equal(hip.nhwc_to_nchw(hip.nchw_to_nhwc(y)).cpu().numpy(), y.cpu().numpy())
+
+
+def test_im2col_conv7x7_stride2(hip):
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn(3, 2, 27, 27, generator=g)
+    w = torch.randn(16, 2, 7, 7, generator=g) * 0.1
+    cols, Ho, Wo = hip.im2col_nhwc(x.permute(0, 2, 3, 1).contiguous().cuda(), 7, 7, 2, 3, ldo=100)
+    assert (Ho, Wo) == (14, 14)
+    wmat = torch.zeros(16, 100)
+    wmat[:, :98] = w.permute(0, 2, 3, 1).reshape(16, 98)
+    out = hip.gemm(cols, wmat.cuda(), False, True).view(3, 14, 14, 16).permute(0, 3, 1, 2)
+    ref = F.conv2d(x.double(), w.double(), stride=2, padding=3).float()
+    np.testing.assert_allclose(out.cpu().numpy(), ref.numpy(), atol=1e-4)
+
+
+# ----------------------------------------------------------------------------------------------- LSTM
+def _lstm_problem(lengths, in_size, H, nl, seed, p=0.0):
+    from oracle import lstm as OL
+    g = torch.Generator().manual_seed(seed)
+    lengths = sorted(lengths, reverse=True)
+    T, B = lengths[0], len(lengths)
+    x = torch.randn(T, B, in_size, generator=g)
+    for b, l in enumerate(lengths):
+        x[l:, b] = 0
+    _, wtot = OL.layer_offsets(in_size, H, nl)
+    weight = torch.randn(wtot, generator=g) * (1.0 / in_size ** 0.5)
+    bias = torch.randn(5 * H * nl, generator=g) * 0.1
+    drop = torch.ones(nl, B, H)
+    if p > 0:
+        drop = (torch.rand(nl, B, H, generator=g) > p).float() / (1 - p)
+    return x, lengths, weight, bias, drop
+
+
+@pytest.mark.parametrize('lengths,in_size,H,nl,p', [([5, 3, 3, 1], 24, 16, 1, 0.0), ([6, 6, 2], 40, 32, 2, 0.3),
+                                                     ([4, 2, 1], 20, 8, 3, 0.2), ([7], 12, 20, 4, 0.0),
+                                                     ([20] * 3 + [17, 9, 9, 4, 2, 1, 1], 712, 512, 2, 0.1)])
+def test_hwlstm_fwd_bwd(hip, lengths, in_size, H, nl, p):
+    from oracle import lstm as OL
+    x, lengths, weight, bias, drop = _lstm_problem(lengths, in_size, H, nl, seed=nl + H, p=p)
+    T, B = x.shape[0], x.shape[1]
+    out_ref, h_slots, c_slots, gates = OL.highway_lstm_forward(x, lengths, weight, bias, drop, H, nl, True,
+                                                               return_state=True)
+    h_data, c_data, g = hip.hwlstm_fwd(x.cuda(), lengths, weight.cuda(), bias.cuda(), drop.cuda(), H, nl, True)
+    np.testing.assert_allclose(h_data[-1, 1:].cpu().numpy(), out_ref.numpy(), atol=1e-4)
+    for l in range(nl):
+        np.testing.assert_allclose(c_data[l, 1:].cpu().numpy(), torch.stack(c_slots[l][1:]).numpy(), atol=1e-4)
+    gout = torch.randn(T, B, H, generator=torch.Generator().manual_seed(1))
+    for b, l in enumerate(lengths):
+        gout[l:, b] = 0
+    xg_ref, wg_ref, bg_ref = OL.highway_lstm_backward(gout, x, lengths, weight, drop, H, nl, h_slots, c_slots, gates)
+    xg, wg, bg = hip.hwlstm_bwd(gout.cuda(), x.cuda(), lengths, weight.cuda(), drop.cuda(), H, nl, h_data, c_data, g)
+    np.testing.assert_allclose(xg.cpu().numpy(), xg_ref.numpy(), atol=2e-4)
+    np.testing.assert_allclose(wg.cpu().numpy(), wg_ref.numpy(), atol=5e-4)
+    np.testing.assert_allclose(bg.cpu().numpy(), bg_ref.numpy(), atol=5e-4)
+    # eval mode: same outputs, no gates
+    h2, _, g2 = hip.hwlstm_fwd(x.cuda(), lengths, weight.cuda(), bias.cuda(), drop.cuda(), H, nl, False)
+    assert g2 is None
+    np.testing.assert_array_equal(h2.cpu().numpy(), h_data.cpu().numpy())
+
+
+def test_decoder_cell_and_gemv(hip):
+    from oracle import lstm as OL
+    g = torch.Generator().manual_seed(11)
+    n, H, D = 6, 32, 44
+    p = {'input_linearity.weight': torch.randn(6 * H, D, generator=g) * 0.2,
+         'input_linearity.bias': torch.randn(6 * H, generator=g) * 0.1,
+         'state_linearity.weight': torch.randn(5 * H, H, generator=g) * 0.2,
+         'state_linearity.bias': torch.randn(5 * H, generator=g) * 0.1}
+    x = torch.randn(n, D, generator=g)
+    h0, c0 = torch.randn(n, H, generator=g), torch.randn(n, H, generator=g)
+    mask = (torch.rand(n, H, generator=g) > 0.2).float() / 0.8
+    h_ref, c_ref = OL.decoder_lstm_equations(p, x, h0, c0, H, mask, True)
+    pre_i = hip.gemm(x.cuda(), p['input_linearity.weight'].cuda(), False, True, bias=p['input_linearity.bias'].cuda())
+    h1, c1, gates = hip.hwlstm_cell_fwd(pre_i, h0.cuda(), c0.cuda(), p['state_linearity.weight'].cuda(),
+                                        p['state_linearity.bias'].cuda(), mask.cuda(), True)
+    np.testing.assert_allclose(h1.cpu().numpy(), h_ref.numpy(), atol=1e-5)
+    np.testing.assert_allclose(c1.cpu().numpy(), c_ref.numpy(), atol=1e-5)
+    # cell backward vs autograd of the oracle cell
+    x64 = {k: v.double() for k, v in p.items()}
+    pi = pre_i.cpu().double().requires_grad_()
+    h0d, c0d = h0.double().requires_grad_(), c0.double().requires_grad_()
+    ps = F.linear(h0d, x64['state_linearity.weight'], x64['state_linearity.bias'])
+    ig = torch.sigmoid(pi[:, :H] + ps[:, :H]); fg = torch.sigmoid(pi[:, H:2 * H] + ps[:, H:2 * H])
+    mi = torch.tanh(pi[:, 2 * H:3 * H] + ps[:, 2 * H:3 * H]); og = torch.sigmoid(pi[:, 3 * H:4 * H] + ps[:, 3 * H:4 * H])
+    mem = ig * mi + fg * c0d
+    hg = torch.sigmoid(pi[:, 4 * H:5 * H] + ps[:, 4 * H:5 * H])
+    hout = (hg * (og * torch.tanh(mem)) + (1 - hg) * pi[:, 5 * H:]) * mask.double()
+    dh, dc = torch.randn(n, H, generator=g), torch.randn(n, H, generator=g)
+    (hout * dh.double()).sum().add((mem * dc.double()).sum()).backward()
+    d_gates, d_c_in = hip.hwlstm_cell_bwd(dh.cuda(), dc.cuda(), c0.cuda(), c1, gates, mask.cuda())
+    np.testing.assert_allclose(d_gates.cpu().numpy(), pi.grad.float().numpy(), atol=1e-5)
+    np.testing.assert_allclose(d_c_in.cpu().numpy(), c0d.grad.float().numpy(), atol=1e-5)
+    # small-batch GEMV: recurrent dgrad  d_h_prev = d_gates[:, :5H] @ W_state  (W_state^T rows are K=5H contiguous)
+    wt = p['state_linearity.weight'].t().contiguous().cuda()               # [H, 5H]
+    dhp = hip.gemv_rows(d_gates[:, :5 * H], wt)
+    np.testing.assert_allclose(dhp.cpu().numpy(), h0d.grad.float().numpy(), atol=1e-5)
+    for nn, R, K in [(1, 151, 512), (9, 37, 100), (17, 8, 2560)]:
+        v = torch.randn(nn, K, generator=g)
+        w = torch.randn(R, K, generator=g)
+        bb = torch.randn(R, generator=g)
+        out = hip.gemv_rows(v.cuda(), w.cuda(), bb.cuda())
+        np.testing.assert_allclose(out.cpu().numpy(), (v.double() @ w.double().t() + bb.double()).float().numpy(),
+                                   atol=2e-4)
