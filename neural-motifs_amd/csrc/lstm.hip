@@ -16,99 +16,187 @@
 namespace mh {
 
 constexpr int kNB = 8;        // right-hand sides (batch rows) processed per pass
-constexpr int kKChunk = 512;  // K staged in LDS per pass
+constexpr int kChunk = 512;   // floats of K consumed per block per pipeline stage (4 waves x 16 lanes x 2 float4)
+constexpr int kGemvThreads = 256;
 
 __device__ __forceinline__ float sigmoidf_ref(float x) { return 1.f / (1.f + expf(-x)); }
 
-// Accumulate, for NR rows of `w` (row r at w + r*ldw, K contiguous) and `n` vectors in LDS (vs[b*kKChunk + k]),
-// the partial dot products of this lane's k-slice: lane kq of 16 takes float4 q = kq, kq+16, ...
+// ---------------------------------------------------------------------------------------------------
+// Small-batch GEMV block engine.  A 256-thread block computes, for 4 "units" (one per 16-lane group index
+// grp = lane>>4, identical in all 4 waves) and NR weight rows per unit, the dot products with up to kNB vectors
+//       acc[r][b] = sum_k w_r[k] * v[b][k].
+// K is consumed in chunks of 512 floats: wave w owns floats [128w, 128w+128) of the chunk, lane kq owns the two
+// float4 at 128w + 4kq and 128w + 64 + 4kq.  The n vectors are staged through LDS by all 256 threads (float4),
+// and the NEXT chunk's weight float4s and staging registers are loaded before the current chunk's FMAs, so each
+// pipeline stage costs one (overlapped) memory round trip instead of one per k-step.
+// After the K loop the per-lane partials are reduced over the 16 lanes of a group with xor-shuffles and over the
+// 4 waves through LDS; the block-level totals are returned in `red` ([4 units][NR][kNB], valid after the
+// trailing __syncthreads()).
+// ---------------------------------------------------------------------------------------------------
 template <int NR>
-__device__ __forceinline__ void dot_rows_chunk(const float *const (&wrow)[NR], const float *vs, int kc, int kq,
-                                               bool vec, float (&acc)[NR][kNB])
+struct WRegs {
+    float4 v[NR][2];
+};
+
+template <int NR>
+__device__ __forceinline__ void load_w(WRegs<NR> &w, const float *const (&wrow)[NR], bool ok_rows, bool vec, int k0,
+                                       int K, int wave, int kq)
 {
-    for (int k = 4 * kq; k < kc; k += 64) {
-        float4 w[NR];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int k = k0 + 128 * wave + 64 * h + 4 * kq;
 #pragma unroll
         for (int r = 0; r < NR; ++r) {
-            if (vec && k + 3 < kc) {
-                w[r] = *reinterpret_cast<const float4 *>(wrow[r] + k);
-            } else {
-                w[r].x = (k + 0 < kc) ? wrow[r][k + 0] : 0.f;
-                w[r].y = (k + 1 < kc) ? wrow[r][k + 1] : 0.f;
-                w[r].z = (k + 2 < kc) ? wrow[r][k + 2] : 0.f;
-                w[r].w = (k + 3 < kc) ? wrow[r][k + 3] : 0.f;
+            float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (ok_rows) {
+                if (vec && k + 3 < K) {
+                    x = *reinterpret_cast<const float4 *>(wrow[r] + k);
+                } else {
+                    if (k + 0 < K) x.x = wrow[r][k + 0];
+                    if (k + 1 < K) x.y = wrow[r][k + 1];
+                    if (k + 2 < K) x.z = wrow[r][k + 2];
+                    if (k + 3 < K) x.w = wrow[r][k + 3];
+                }
             }
-        }
-#pragma unroll
-        for (int b = 0; b < kNB; ++b) {
-            const float4 h = *reinterpret_cast<const float4 *>(vs + b * kKChunk + k);  // zero padded
-#pragma unroll
-            for (int r = 0; r < NR; ++r) {
-                acc[r][b] = fmaf(w[r].x, h.x, acc[r][b]);
-                acc[r][b] = fmaf(w[r].y, h.y, acc[r][b]);
-                acc[r][b] = fmaf(w[r].z, h.z, acc[r][b]);
-                acc[r][b] = fmaf(w[r].w, h.w, acc[r][b]);
-            }
+            w.v[r][h] = x;
         }
     }
 }
 
-// stage v[b0..b0+kNB)[k0..k0+kc) into LDS (zero padded to kNB x kKChunk)
-__device__ __forceinline__ void stage_vectors(const float *v, int ldv, int n, int b0, int k0, int kc, float *vs)
+struct VStage {
+    float4 v[4];
+};
+
+// chunk of v: kNB rows x 128 float4; thread t takes f = t + 256 i  ->  (b = f / 128, q = f % 128)
+__device__ __forceinline__ void load_vstage(VStage &s, const float *v, int ldv, bool vec, int n, int b0, int k0, int K,
+                                            int tid)
 {
-    for (int i = threadIdx.x; i < kNB * kKChunk; i += blockDim.x) {
-        const int b = i / kKChunk, k = i % kKChunk;
-        vs[i] = (b0 + b < n && k < kc) ? v[(size_t)(b0 + b) * ldv + k0 + k] : 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int f = tid + kGemvThreads * i;
+        const int b = b0 + (f >> 7), k = k0 + 4 * (f & 127);
+        float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (b < n) {
+            const float *p = v + (size_t)b * ldv;
+            if (vec && k + 3 < K) {
+                x = *reinterpret_cast<const float4 *>(p + k);
+            } else {
+                if (k + 0 < K) x.x = p[k + 0];
+                if (k + 1 < K) x.y = p[k + 1];
+                if (k + 2 < K) x.z = p[k + 2];
+                if (k + 3 < K) x.w = p[k + 3];
+            }
+        }
+        s.v[i] = x;
     }
+}
+
+__device__ __forceinline__ void store_vstage(const VStage &s, float *vs, int tid)
+{
+#pragma unroll
+    for (int i = 0; i < 4; ++i) *reinterpret_cast<float4 *>(vs + 4 * (tid + kGemvThreads * i)) = s.v[i];
 }
 
 template <int NR>
-__device__ __forceinline__ void reduce16(float (&acc)[NR][kNB])
+__device__ __forceinline__ void block_gemv(const float *const (&wrow)[NR], bool ok_rows, bool wvec, const float *v,
+                                           int ldv, bool vvec, int n, int b0, int K, float *vs /*[kNB*kChunk]*/,
+                                           float *red /*[4 waves][4 units][NR][kNB]*/, float (&tot)[NR])
 {
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, grp = lane >> 4, kq = lane & 15;
+    float acc[NR][kNB];
+#pragma unroll
+    for (int r = 0; r < NR; ++r)
+#pragma unroll
+        for (int b = 0; b < kNB; ++b) acc[r][b] = 0.f;
+
+    WRegs<NR> wc, wn;
+    VStage st;
+    load_vstage(st, v, ldv, vvec, n, b0, 0, K, tid);
+    load_w<NR>(wc, wrow, ok_rows, wvec, 0, K, wave, kq);
+    for (int k0 = 0; k0 < K; k0 += kChunk) {
+        __syncthreads();               // previous chunk's LDS reads are done
+        store_vstage(st, vs, tid);
+        __syncthreads();
+        const bool more = (k0 + kChunk < K);
+        if (more) {
+            load_vstage(st, v, ldv, vvec, n, b0, k0 + kChunk, K, tid);
+            load_w<NR>(wn, wrow, ok_rows, wvec, k0 + kChunk, K, wave, kq);
+        }
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const float *vp = vs + 128 * wave + 64 * h + 4 * kq;
+#pragma unroll
+            for (int b = 0; b < kNB; ++b) {
+                const float4 x = *reinterpret_cast<const float4 *>(vp + b * kChunk);
+#pragma unroll
+                for (int r = 0; r < NR; ++r) {
+                    acc[r][b] = fmaf(wc.v[r][h].x, x.x, acc[r][b]);
+                    acc[r][b] = fmaf(wc.v[r][h].y, x.y, acc[r][b]);
+                    acc[r][b] = fmaf(wc.v[r][h].z, x.z, acc[r][b]);
+                    acc[r][b] = fmaf(wc.v[r][h].w, x.w, acc[r][b]);
+                }
+            }
+        }
+        if (more) wc = wn;
+    }
+    // reduce over the 16 lanes of the group, then over the 4 waves (LDS)
 #pragma unroll
     for (int r = 0; r < NR; ++r)
 #pragma unroll
         for (int b = 0; b < kNB; ++b) {
-            float v = acc[r][b];
-            v += __shfl_xor(v, 1);
-            v += __shfl_xor(v, 2);
-            v += __shfl_xor(v, 4);
-            v += __shfl_xor(v, 8);
-            acc[r][b] = v;
+            float x = acc[r][b];
+            x += __shfl_xor(x, 1);
+            x += __shfl_xor(x, 2);
+            x += __shfl_xor(x, 4);
+            x += __shfl_xor(x, 8);
+            acc[r][b] = x;
         }
+    if (kq < kNB) {
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            float x = 0.f;
+#pragma unroll
+            for (int b = 0; b < kNB; ++b)
+                if (kq == b) x = acc[r][b];
+            red[((wave * 4 + grp) * NR + r) * kNB + kq] = x;
+        }
+    }
+    __syncthreads();
+    // thread (grp = t>>3 & 3, b = t&7) of wave 0 gathers the totals for (unit grp, batch b)
+#pragma unroll
+    for (int r = 0; r < NR; ++r) tot[r] = 0.f;
+    if (tid < 4 * kNB) {
+        const int g2 = tid >> 3, b = tid & 7;
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            float x = 0.f;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) x += red[((w * 4 + g2) * NR + r) * kNB + b];
+            tot[r] = x;
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------
-// out[b][r] = sum_k v[b][k] * wt[r][k] (+ bias[r]);  one wave per block, 4 rows per wave.
+// out[b][r] = sum_k v[b][k] * wt[r][k] (+ bias[r]);  4 output rows per block.
 // ---------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void gemv_rows_kernel(int n, int R, int K, const float *__restrict__ v, int ldv,
-                                                       const float *__restrict__ wt, int ldw,
-                                                       const float *__restrict__ bias, float *__restrict__ out,
-                                                       int ldo, int vec)
+__global__ __launch_bounds__(kGemvThreads) void gemv_rows_kernel(int n, int R, int K, const float *__restrict__ v,
+                                                                int ldv, const float *__restrict__ wt, int ldw,
+                                                                const float *__restrict__ bias,
+                                                                float *__restrict__ out, int ldo, int wvec, int vvec)
 {
-    __shared__ __attribute__((aligned(16))) float vs[kNB * kKChunk];
-    const int lane = threadIdx.x, kq = lane & 15, ru = lane >> 4;
-    const int row = blockIdx.x * 4 + ru;
+    __shared__ __attribute__((aligned(16))) float vs[kNB * kChunk];
+    __shared__ float red[4 * 4 * 1 * kNB];
+    const int lane = threadIdx.x & 63, grp = lane >> 4;
+    const int row = blockIdx.x * 4 + grp;
     const bool row_ok = row < R;
+    const float *const wrow[1] = {wt + (size_t)(row_ok ? row : 0) * ldw};
     for (int b0 = 0; b0 < n; b0 += kNB) {
-        float acc[1][kNB];
-#pragma unroll
-        for (int b = 0; b < kNB; ++b) acc[0][b] = 0.f;
-        for (int k0 = 0; k0 < K; k0 += kKChunk) {
-            const int kc = min(kKChunk, K - k0);
-            __syncthreads();
-            stage_vectors(v, ldv, n, b0, k0, kc, vs);
-            __syncthreads();
-            if (row_ok) {
-                const float *const wrow[1] = {wt + (size_t)row * ldw + k0};
-                dot_rows_chunk<1>(wrow, vs, kc, kq, vec != 0, acc);
-            }
-        }
-        reduce16<1>(acc);
-        if (row_ok) {
-#pragma unroll
-            for (int b = 0; b < kNB; ++b)
-                if (kq == b && b0 + b < n) out[(size_t)(b0 + b) * ldo + row] = acc[0][b] + (bias ? bias[row] : 0.f);
+        float tot[1];
+        block_gemv<1>(wrow, row_ok, wvec != 0, v, ldv, vvec != 0, n, b0, K, vs, red, tot);
+        if (threadIdx.x < 4 * kNB) {
+            const int r2 = blockIdx.x * 4 + (threadIdx.x >> 3), b = b0 + (threadIdx.x & 7);
+            if (r2 < R && b < n) out[(size_t)b * ldo + r2] = tot[0] + (bias ? bias[r2] : 0.f);
         }
     }
 }
@@ -118,49 +206,32 @@ __global__ __launch_bounds__(64) void gemv_rows_kernel(int n, int R, int K, cons
 //   pre_i [n,6H] (ld_i)  : x_t*Wx (+ input bias for the decoder)
 //   wh_t  [5H,H]         : recurrent weights, K(=H)-contiguous rows, row = gate*H + unit
 //   bias  [5H] or NULL
+// 4 hidden units per block, 5 gate rows each.
 // ---------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void hw_cell_fwd_kernel(int n, int H, const float *__restrict__ pre_i, int ld_i,
-                                                         const float *__restrict__ h_prev,
-                                                         const float *__restrict__ c_prev,
-                                                         const float *__restrict__ wh_t,
-                                                         const float *__restrict__ bias,
-                                                         const float *__restrict__ dropout,
-                                                         float *__restrict__ h_out, float *__restrict__ c_out,
-                                                         float *__restrict__ gates_out, int vec)
+__global__ __launch_bounds__(kGemvThreads) void hw_cell_fwd_kernel(int n, int H, const float *__restrict__ pre_i,
+                                                                  int ld_i, const float *__restrict__ h_prev,
+                                                                  const float *__restrict__ c_prev,
+                                                                  const float *__restrict__ wh_t,
+                                                                  const float *__restrict__ bias,
+                                                                  const float *__restrict__ dropout,
+                                                                  float *__restrict__ h_out,
+                                                                  float *__restrict__ c_out,
+                                                                  float *__restrict__ gates_out, int wvec, int vvec)
 {
-    __shared__ __attribute__((aligned(16))) float vs[kNB * kKChunk];
-    const int lane = threadIdx.x, kq = lane & 15, ul = lane >> 4;
-    const int u = blockIdx.x * 4 + ul;
-    const bool u_ok = u < H;
+    __shared__ __attribute__((aligned(16))) float vs[kNB * kChunk];
+    __shared__ float red[4 * 4 * 5 * kNB];
+    const int lane = threadIdx.x & 63, grp = lane >> 4;
+    const int ug = blockIdx.x * 4 + grp;
+    const bool u_ok = ug < H;
+    const int us = u_ok ? ug : 0;
+    const float *const wrow[5] = {wh_t + ((size_t)0 * H + us) * H, wh_t + ((size_t)1 * H + us) * H,
+                                  wh_t + ((size_t)2 * H + us) * H, wh_t + ((size_t)3 * H + us) * H,
+                                  wh_t + ((size_t)4 * H + us) * H};
     for (int b0 = 0; b0 < n; b0 += kNB) {
-        float acc[5][kNB];
-#pragma unroll
-        for (int g = 0; g < 5; ++g)
-#pragma unroll
-            for (int b = 0; b < kNB; ++b) acc[g][b] = 0.f;
-        for (int k0 = 0; k0 < H; k0 += kKChunk) {
-            const int kc = min(kKChunk, H - k0);
-            __syncthreads();
-            stage_vectors(h_prev, H, n, b0, k0, kc, vs);
-            __syncthreads();
-            if (u_ok) {
-                const float *const wrow[5] = {wh_t + ((size_t)0 * H + u) * H + k0, wh_t + ((size_t)1 * H + u) * H + k0,
-                                              wh_t + ((size_t)2 * H + u) * H + k0, wh_t + ((size_t)3 * H + u) * H + k0,
-                                              wh_t + ((size_t)4 * H + u) * H + k0};
-                dot_rows_chunk<5>(wrow, vs, kc, kq, vec != 0, acc);
-            }
-        }
-        reduce16<5>(acc);
-        // lane kq == b finalises (row b0+b, unit u)
-        float th[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int b = 0; b < kNB; ++b)
-            if (kq == b) {
-#pragma unroll
-                for (int g = 0; g < 5; ++g) th[g] = acc[g][b];
-            }
-        const int row = b0 + kq;
-        if (u_ok && kq < kNB && row < n) {
+        float th[5];
+        block_gemv<5>(wrow, u_ok, wvec != 0, h_prev, H, vvec != 0, n, b0, H, vs, red, th);
+        const int u = blockIdx.x * 4 + (threadIdx.x >> 3), row = b0 + (threadIdx.x & 7);
+        if (threadIdx.x < 4 * kNB && u < H && row < n) {
             const float *pi = pre_i + (size_t)row * ld_i + u;
             float g[5];
 #pragma unroll
@@ -225,13 +296,17 @@ __global__ void hw_cell_bwd_kernel(int n, int H, const float *__restrict__ d_out
 }
 
 // out[c] += sum_r in[r][c]   (bias gradient; the reference uses Sgemv with a ones vector, :342-355)
-__global__ void colsum_accum_kernel(const float *__restrict__ in, int rows, int cols, int ld, float *__restrict__ out)
+__global__ __launch_bounds__(256) void colsum_accum_kernel(const float *__restrict__ in, int rows, int cols, int ld,
+                                                           float *__restrict__ out)
 {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= cols) return;
+    __shared__ float part[4][64];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), rp = threadIdx.x >> 6;
     float s = 0.f;
-    for (int r = 0; r < rows; ++r) s += in[(size_t)r * ld + c];
-    out[c] += s;
+    if (c < cols)
+        for (int r = rp; r < rows; r += 4) s += in[(size_t)r * ld + c];
+    part[rp][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (rp == 0 && c < cols) out[c] += (part[0][threadIdx.x] + part[1][threadIdx.x]) + (part[2][threadIdx.x] + part[3][threadIdx.x]);
 }
 
 // [rows, cols] -> [cols, rows]
@@ -275,18 +350,20 @@ static int launch_cell_fwd(int n, int H, const float *pre_i, int ld_i, const flo
                            const float *wh_t, const float *bias, const float *dropout, float *h_out, float *c_out,
                            float *gates_out, hipStream_t st)
 {
-    const int vec = al16(wh_t) && (H % 4 == 0);
-    hipLaunchKernelGGL(hw_cell_fwd_kernel, dim3(ceil_div(H, 4)), dim3(64), 0, st, n, H, pre_i, ld_i, h_prev, c_prev,
-                       wh_t, bias, dropout, h_out, c_out, gates_out, vec);
+    const int wvec = al16(wh_t) && (H % 4 == 0);
+    const int vvec = al16(h_prev) && (H % 4 == 0);
+    hipLaunchKernelGGL(hw_cell_fwd_kernel, dim3(ceil_div(H, 4)), dim3(kGemvThreads), 0, st, n, H, pre_i, ld_i, h_prev,
+                       c_prev, wh_t, bias, dropout, h_out, c_out, gates_out, wvec, vvec);
     return check_launch("hw_cell_fwd_kernel");
 }
 
 static int launch_gemv_rows(int n, int R, int K, const float *v, int ldv, const float *wt, int ldw, const float *bias,
                             float *out, int ldo, hipStream_t st)
 {
-    const int vec = al16(wt) && (ldw % 4 == 0);
-    hipLaunchKernelGGL(gemv_rows_kernel, dim3(ceil_div(R, 4)), dim3(64), 0, st, n, R, K, v, ldv, wt, ldw, bias, out,
-                       ldo, vec);
+    const int wvec = al16(wt) && (ldw % 4 == 0);
+    const int vvec = al16(v) && (ldv % 4 == 0);
+    hipLaunchKernelGGL(gemv_rows_kernel, dim3(ceil_div(R, 4)), dim3(kGemvThreads), 0, st, n, R, K, v, ldv, wt, ldw, bias,
+                       out, ldo, wvec, vvec);
     return check_launch("gemv_rows_kernel");
 }
 
@@ -513,7 +590,7 @@ int mh_hwlstm_bwd(int in_size, int H, int B, int L, int T, const float *out_grad
                 MH_TRY(mh_gemm_f32(1, 0, H, 5 * H, (T - 1) * B, hl + 2 * numEl, H, dg_all, 6 * H, weight_grad + o.wh,
                                    5 * H, nullptr, MH_EPI_NONE, 1, 0, gws, gws_bytes, stream));
             }
-            hipLaunchKernelGGL(colsum_accum_kernel, dim3(ceil_div(5 * H, 256)), dim3(256), 0, st, dg_all, T * B, 5 * H,
+            hipLaunchKernelGGL(colsum_accum_kernel, dim3(ceil_div(5 * H, 64)), dim3(256), 0, st, dg_all, T * B, 5 * H,
                                6 * H, bias_grad + (size_t)5 * H * layer);
             MH_TRY(check_launch("colsum_accum_kernel"));
         }
