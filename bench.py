@@ -1,0 +1,197 @@
+#!/usr/bin/env python3
+"""
+bench.py -- headline metric of BASELINE.json: images/sec of a MotifNet-SGCls training step (forward + backward +
+grad-clip + SGD step) on synthetic 592x592 VG-shaped batches, `configs[1]`:
+    SGCls MotifNet (order=leftright, 2-layer highway LSTMs, hidden 512) VGG16, batch 6 per GPU, 20 GT boxes/img.
+
+    python bench.py --gpus N --steps K --warmup W
+For N > 1 launch with torchrun (one rank per GPU, RCCL): every rank trains on its own images (weak scaling), the only
+collective is the gradient all-reduce.  Rank 0 prints ONE JSON line.
+
+Extra objects in the line:
+  roofline     -- the dominant kernel (conv3x3 implicit GEMM on FP32 MFMA): algorithmic FLOPs / HIP-event time of
+                  its launches during the timed steps, against the 157.3 TFLOP/s FP32 MFMA peak.
+  cpu_baseline -- the CPU oracle (oracle/model.py, "port") timed on this host on a bounded sample of the same
+                  workload (1 image, forward+backward), rank 0 at N=1 only.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, 'neural-motifs_amd')):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+PEAK_FP32_MFMA_TFLOPS = 157.3          # /opt/skills/guides/MI355X_MICROARCH.md chip table
+MODEL_KW = dict(hidden_dim=512, pooling_dim=4096, nl_obj=2, nl_edge=2, order='leftright', rec_dropout=0.1,
+                use_bias=True, pass_in_obj_feats_to_decoder=False, pass_in_obj_feats_to_edge=False, use_tanh=False,
+                limit_vision=False)
+BATCH, N_BOXES, N_RELS = 6, 20, 30
+
+
+class ConvMeter(object):
+    """HIP-event timing of every conv3x3 implicit-GEMM launch (on the stream the kernel is launched on) plus its
+    algorithmic FLOPs (2*Cin*Cout*9*B*H*W)."""
+
+    def __init__(self, hip):
+        self.hip, self.orig, self.records, self.enabled = hip, hip.conv3x3_nhwc, [], False
+        hip.conv3x3_nhwc = self
+
+    def __call__(self, x, wt, bias, epilogue):
+        if not self.enabled:
+            return self.orig(x, wt, bias, epilogue)
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        y = self.orig(x, wt, bias, epilogue)
+        e.record()
+        B, H, W, Cin = x.shape
+        self.records.append((s, e, 2.0 * B * H * W * Cin * wt.shape[2] * 9))
+        return y
+
+    def summary(self):
+        torch.cuda.synchronize()
+        ms = sum(s.elapsed_time(e) for s, e, _ in self.records)
+        flops = sum(f for _, _, f in self.records)
+        n = max(len(self.records), 1)
+        return dict(launches=len(self.records), avg_ms=ms / n, flops_per_launch=flops / n,
+                    tflops=(flops / (ms * 1e-3) / 1e12) if ms > 0 else 0.0)
+
+
+def cpu_baseline(ds, model_sd):
+    """oracle forward+backward on ONE image of the same workload (bounded sample), all host threads"""
+    from oracle import model as OM
+    from dataloaders.synthetic import make_blob
+    from lib.fpn.proposal_assignments.proposal_assignments_gtbox import proposal_assignments_gtbox
+    blob = make_blob(ds, [0], is_train=True)
+    a = blob[0]
+    rois = torch.cat((a[4][:, :1].float(), a[3]), 1)
+    _, _, rel_labels = proposal_assignments_gtbox(rois, a[3], a[4], a[5], 0, rs=np.random.RandomState(0))
+    trainable = {k for k in model_sd if not k.startswith('detector.') and model_sd[k].is_floating_point()
+                 and 'running_' not in k and 'num_batches' not in k}
+    params = {k: v.clone().requires_grad_(k in trainable) for k, v in model_sd.items()}
+    cfg = dict(MODEL_KW, mode='sgcls')
+    t0 = time.time()
+    out = OM.relmodel_forward(params, cfg, a[0], a[1], 0, a[3], a[4], True, OM.HostRNG(0), rel_labels=rel_labels)
+    loss = F.cross_entropy(out['rm_obj_dists'], out['rm_obj_labels']) + \
+        F.cross_entropy(out['rel_dists'], out['rel_labels'][:, -1])
+    loss.backward()
+    dt = time.time() - t0
+    return dict(value=1.0 / dt, unit='img/s', cores=torch.get_num_threads(), kind='port',
+                sample='1 image x (fwd+bwd) of the same SGCls step, %d relation rows, %.1f s, no warm-up'
+                       % (rel_labels.shape[0], dt))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=10)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    args = ap.parse_args()
+
+    from lib import dist as D
+    rank, world, local_rank = D.init_from_env()
+    if world != args.gpus:
+        raise SystemExit('--gpus %d but WORLD_SIZE=%d: launch with torchrun --nproc-per-node %d' % (args.gpus, world, args.gpus))
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs a HIP device (no CPU fallback for the hot path)')
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+
+    from dataloaders.synthetic import SyntheticVG, make_blob
+    from lib import _hip
+    from lib.pytorch_misc import clip_grad_norm
+    from lib.rel_model import RelModel
+
+    torch.manual_seed(1234)
+    np.random.seed(1234 + 200 + rank)
+    n_img = BATCH * 4
+    ds = SyntheticVG(num_images=n_img, seed=1234 + 200 + rank, n_boxes=N_BOXES, n_rels=N_RELS)
+    model = RelModel(classes=ds.ind_to_classes, rel_classes=ds.ind_to_predicates, mode='sgcls', num_gpus=1, **MODEL_KW)
+    for _, p in model.detector.named_parameters():           # models/train_rels.py:50-52
+        p.requires_grad = False
+    sd_cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        sd_cpu = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    model.to(dev).train()
+    lr = 1e-3 * world * BATCH                                 # train_rels.py:192
+    fc = [p for n, p in model.named_parameters() if n.startswith('roi_fmap') and p.requires_grad]
+    rest = [p for n, p in model.named_parameters() if not n.startswith('roi_fmap') and p.requires_grad]
+    opt = torch.optim.SGD([{'params': fc, 'lr': lr / 10.0}, {'params': rest}], lr=lr, momentum=0.9, weight_decay=1e-4)
+    buckets = D.GradBuckets([p for p in model.parameters() if p.requires_grad])
+    blobs = [make_blob(ds, range(i * BATCH, (i + 1) * BATCH), is_train=True) for i in range(n_img // BATCH)]
+    for b in blobs:
+        b.scatter()                                           # inputs resident in HBM before the timed region
+    meter = ConvMeter(_hip)
+
+    def step(i):
+        res = model[blobs[i % len(blobs)]]
+        l_obj = F.cross_entropy(res.rm_obj_dists, res.rm_obj_labels)
+        l_rel = F.cross_entropy(res.rel_dists, res.rel_labels[:, -1])
+        if world > 1:
+            w = D.global_row_weights([res.rm_obj_labels.shape[0], res.rel_labels.shape[0]], dev)
+            loss = l_obj * w[0] + l_rel * w[1]
+        else:
+            loss = l_obj + l_rel
+        opt.zero_grad(set_to_none=True)
+        loss.backward()
+        buckets.all_reduce()
+        clip_grad_norm([(n, p) for n, p in model.named_parameters() if p.grad is not None], max_norm=5.0, clip=True)
+        opt.step()
+        return loss
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(i)
+    barrier()
+    meter.enabled = True
+    t0 = time.time()
+    for i in range(args.steps):
+        loss = step(args.warmup + i)
+    barrier()
+    dt = time.time() - t0
+    meter.enabled = False
+    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
+    dt = float(tmax.item())
+
+    if rank == 0:
+        conv = meter.summary()
+        line = {
+            'metric': 'images/sec MotifNet-SGCls fwd+bwd', 'value': world * BATCH * args.steps / dt, 'unit': 'img/s',
+            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * dt / args.steps,
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': 'SGCls MotifNet VGG16 train step (fwd+bwd+clip+SGD), order=leftright, nl_obj=2, '
+                                   'nl_edge=2, hidden 512, batch 6/GPU, 20 GT boxes/img, <=256 rel rows/img, 592x592',
+                       'global_batch': world * BATCH, 'parallelism': 'dp%d' % world, 'final_loss': float(loss.item())},
+            'roofline': {'bound': 'mfma', 'kernel': 'conv3x3_nhwc_kernel (FP32 MFMA implicit GEMM: VGG trunk + union tower)',
+                         'achieved': conv['tflops'], 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
+                         'frac': conv['tflops'] / PEAK_FP32_MFMA_TFLOPS, 'traffic': None,
+                         'launches': conv['launches'], 'avg_launch_ms': conv['avg_ms'],
+                         'flops_per_launch': conv['flops_per_launch']},
+        }
+        if sd_cpu is not None:
+            try:
+                line['cpu_baseline'] = cpu_baseline(ds, sd_cpu)
+            except Exception as ex:                          # the baseline must never take the bench line down
+                line['cpu_baseline'] = {'value': None, 'unit': 'img/s', 'cores': torch.get_num_threads(),
+                                        'kind': 'port', 'sample': 'failed: %r' % (ex,)}
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

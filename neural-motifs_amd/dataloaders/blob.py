@@ -1,0 +1,89 @@
+"""
+Per-step batch container with the reference's interface (dataloaders/blob.py): `append(entry)`, `reduce()`,
+`scatter()`, `blob[gpu] -> (imgs, im_sizes, image_offset, gt_boxes, gt_classes, gt_rels, proposals[, train_anchor_inds])`.
+
+Data parallelism is one process per GPU, so a Blob always describes ONE device's images (`num_gpus == 1`,
+`image_offset == 0`); the ragged torch.nn.parallel scatter of the reference (:148-153) has no counterpart.
+Anchor targets (only consumed by detector pre-training) are not produced: `train_anchor_inds`
+is an empty [0,4] index tensor with the right rank.
+"""
+import numpy as np
+import torch
+
+
+class Blob(object):
+    def __init__(self, mode='det', is_train=False, num_gpus=1, primary_gpu=0, batch_size_per_gpu=3):
+        assert mode in ('det', 'rel')
+        if num_gpus != 1:
+            raise ValueError('one process per GPU: build one Blob(num_gpus=1) per rank')
+        self.mode = mode
+        self.is_train = is_train
+        self.num_gpus = 1
+        self.batch_size_per_gpu = batch_size_per_gpu
+        self.primary_gpu = primary_gpu
+        self.imgs, self.im_sizes = [], []
+        self.gt_boxes, self.gt_classes, self.gt_rels = [], [], []
+        self.proposals = []
+        self.train_anchor_inds = None
+        self.proposal_chunks = None
+
+    @property
+    def is_rel(self):
+        return self.mode == 'rel'
+
+    def append(self, d):
+        """add one image entry (the dict of dataloaders/visual_genome.py:187-197)"""
+        i = len(self.imgs)
+        self.imgs.append(d['img'])
+        h, w, scale = d['img_size']
+        self.im_sizes.append((h, w, scale))
+        self.gt_boxes.append(d['gt_boxes'].astype(np.float32) * d['scale'])
+        self.gt_classes.append(np.column_stack((i * np.ones(d['gt_classes'].shape[0], dtype=np.int64), d['gt_classes'])))
+        if self.is_rel:
+            self.gt_rels.append(np.column_stack((i * np.ones(d['gt_relations'].shape[0], dtype=np.int64),
+                                                 d['gt_relations'])))
+        if 'proposals' in d:
+            self.proposals.append(np.column_stack((i * np.ones(d['proposals'].shape[0], dtype=np.float32),
+                                                   d['scale'] * d['proposals'].astype(np.float32))))
+
+    def reduce(self):
+        if len(self.imgs) != self.batch_size_per_gpu:
+            raise ValueError("Wrong batch size? imgs len {} bsize/gpu {}".format(len(self.imgs), self.batch_size_per_gpu))
+        self.imgs = torch.stack(self.imgs, 0)
+        self.im_sizes = np.stack(self.im_sizes).reshape((1, self.batch_size_per_gpu, 3))
+        if self.is_rel:
+            self.gt_rels = torch.from_numpy(np.concatenate(self.gt_rels, 0)).long()
+        self.gt_boxes = torch.from_numpy(np.concatenate(self.gt_boxes, 0)).float()
+        self.gt_classes = torch.from_numpy(np.concatenate(self.gt_classes, 0)).long()
+        if self.is_train:
+            self.train_anchor_inds = torch.zeros(0, 4, dtype=torch.long)
+        if len(self.proposals) != 0:
+            self.proposals = torch.from_numpy(np.concatenate(self.proposals, 0)).float()
+            self.proposal_chunks = [self.proposals.shape[0]]
+
+    def _to_device(self, x):
+        return x.cuda(self.primary_gpu, non_blocking=True)
+
+    def scatter(self):
+        """move the batch to this process's GPU (asynchronous H2D)"""
+        if isinstance(self.imgs, torch.Tensor) and self.imgs.is_cuda:
+            return
+        self.imgs = self._to_device(self.imgs)
+        self.gt_classes = self._to_device(self.gt_classes)
+        self.gt_boxes = self._to_device(self.gt_boxes)
+        if self.is_rel:
+            self.gt_rels = self._to_device(self.gt_rels)
+        if self.is_train:
+            self.train_anchor_inds = self._to_device(self.train_anchor_inds)
+        if self.proposal_chunks is not None:
+            self.proposals = self._to_device(self.proposals)
+
+    def __getitem__(self, index):
+        if index != 0:
+            raise ValueError("Out of bounds with index {} and 1 gpu per process".format(index))
+        rels = self.gt_rels if self.is_rel else None
+        proposals = self.proposals if self.proposal_chunks is not None else None
+        if self.is_train:
+            return (self.imgs, self.im_sizes[0], 0, self.gt_boxes, self.gt_classes, rels, proposals,
+                    self.train_anchor_inds)
+        return self.imgs, self.im_sizes[0], 0, self.gt_boxes, self.gt_classes, rels, proposals

@@ -1,0 +1,320 @@
+"""
+autograd glue over the HIP kernels (lib/_hip.py): the nn.Module / Function layer that replaces the cuDNN / cuBLAS
+backed nn.Linear and nn.Conv2d calls of the reference on the hot path.
+
+Every op here runs hand-written gfx950 kernels through the C ABI; nothing falls back to rocBLAS/MIOpen or to the
+CPU.  Parameter names and shapes are the reference's (nn.Linear: weight [out,in], bias [out]; conv: weight
+[Cout,Cin,kh,kw]) so checkpoints load unchanged.
+"""
+import math
+
+import torch
+import torch.nn as nn
+
+from lib import _hip
+from lib.rng import dropout as rng_dropout
+
+EPI_NONE, EPI_RELU, EPI_RELU6 = 0, 1, 2
+
+
+def _c(t):
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def _rows2d(t):
+    """2-D view with unit inner stride (row stride may be larger); copies only if it has to"""
+    if t.dim() != 2:
+        raise ValueError('expected a 2-D tensor')
+    return t if t.stride(1) == 1 else t.contiguous()
+
+
+# =========================================================================================== Linear
+class _LinearFn(torch.autograd.Function):
+    """y = act(x @ W^T + b) on the FP32 MFMA GEMM; ReLU fused into the epilogue."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, relu):
+        x2, w2 = _rows2d(x), _rows2d(weight)
+        y = _hip.gemm(x2, w2, False, True, bias=bias, epilogue=EPI_RELU if relu else EPI_NONE)
+        ctx.relu = relu
+        ctx.has_bias = bias is not None
+        ctx.save_for_backward(x2, w2, y if relu else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x2, w2, y = ctx.saved_tensors
+        gy = _rows2d(gy)
+        if ctx.relu:
+            gy = gy * (y > 0).to(gy.dtype)
+        gx = gw = gb = None
+        if ctx.needs_input_grad[0]:
+            gx = _hip.gemm(gy, w2, False, False)              # [M,N] x [N,K]
+        if ctx.needs_input_grad[1]:
+            gw = _hip.gemm(gy, x2, True, False)               # [M,N]^T x [M,K] -> [N,K]
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            gb = gy.sum(0)
+        return gx, gw, gb, None
+
+
+def linear(x, weight, bias=None, relu=False):
+    return _LinearFn.apply(x, weight, bias, relu)
+
+
+class Linear(nn.Module):
+    """Drop-in for nn.Linear (same parameter names / init) running on the HIP GEMM."""
+
+    def __init__(self, in_features, out_features, bias=True):
+        super(Linear, self).__init__()
+        self.in_features, self.out_features = in_features, out_features
+        self.weight = nn.Parameter(torch.empty(out_features, in_features))
+        self.bias = nn.Parameter(torch.empty(out_features)) if bias else None
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        nn.init.kaiming_uniform_(self.weight, a=math.sqrt(5))
+        if self.bias is not None:
+            bound = 1.0 / math.sqrt(self.in_features)
+            nn.init.uniform_(self.bias, -bound, bound)
+
+    def forward(self, x, relu=False):
+        lead = x.shape[:-1]
+        y = linear(x.reshape(-1, x.shape[-1]), self.weight, self.bias, relu)
+        return y.view(*lead, self.out_features)
+
+    def extra_repr(self):
+        return 'in_features=%d, out_features=%d, bias=%s' % (self.in_features, self.out_features, self.bias is not None)
+
+
+class ReLU(nn.Module):
+    """Marker module (keeps the reference's Sequential indices); fused into the preceding Linear/conv when the
+    parent container runs the stack, plain clamp otherwise."""
+
+    def forward(self, x):
+        return torch.clamp_min(x, 0.0)
+
+
+class Dropout(nn.Module):
+    """nn.Dropout whose mask source can be switched to the seeded host stream (lib/rng.py)."""
+
+    def __init__(self, p=0.5):
+        super(Dropout, self).__init__()
+        self.p = p
+
+    def forward(self, x):
+        return rng_dropout(x, self.p, self.training)
+
+
+class FCStack(nn.Sequential):
+    """A VGG-classifier-style Sequential of Linear / ReLU / Dropout children (indices as in torchvision's
+    vgg16.classifier after the reference's deletions, lib/object_detector.py:623-633).  Running the container
+    fuses each Linear with a following ReLU into one GEMM epilogue."""
+
+    def forward(self, x):
+        mods = list(self.children())
+        i = 0
+        while i < len(mods):
+            m = mods[i]
+            if isinstance(m, Linear) and i + 1 < len(mods) and isinstance(mods[i + 1], ReLU):
+                x = m(x, relu=True)
+                i += 2
+            else:
+                x = m(x)
+                i += 1
+        return x
+
+
+class Flattener(nn.Module):
+    def forward(self, x):
+        return x.reshape(x.size(0), -1)
+
+
+# =========================================================================================== conv stack
+class Conv3x3(nn.Module):
+    """3x3 / stride 1 / pad 1 convolution parameters in the API layout [Cout,Cin,3,3]; the packed [9][Cin][Cout]
+    copy the implicit-GEMM kernel reads is cached and refreshed when the weight tensor changes."""
+
+    def __init__(self, cin, cout):
+        super(Conv3x3, self).__init__()
+        self.in_channels, self.out_channels = cin, cout
+        self.weight = nn.Parameter(torch.empty(cout, cin, 3, 3))
+        self.bias = nn.Parameter(torch.zeros(cout))
+        nn.init.kaiming_normal_(self.weight, mode='fan_out', nonlinearity='relu')
+        self._packed = None
+        self._packed_key = None
+
+    def packed_weight(self, flip_transpose=False):
+        key = (self.weight.data_ptr(), self.weight._version, flip_transpose, self.weight.device)
+        if self._packed_key != key:
+            self._packed = _hip.conv3x3_pack_weight(_c(self.weight.detach()), flip_transpose)
+            self._packed_key = key
+        return self._packed
+
+    def forward_nhwc(self, x_nhwc, epilogue=EPI_RELU):
+        if self.in_channels % 16 != 0:
+            raise ValueError('Conv3x3.forward_nhwc needs Cin % 16 == 0 (use the stem kernel for the image layer)')
+        return _hip.conv3x3_nhwc(x_nhwc, self.packed_weight(), self.bias.detach(), epilogue)
+
+    def forward(self, x):
+        """API-compatible NCHW in / NCHW-shaped out (channels_last memory)."""
+        y = self.forward_nhwc(_hip.nchw_to_nhwc(_c(x)) if not _is_nhwc(x) else x.permute(0, 2, 3, 1), EPI_NONE)
+        return y.permute(0, 3, 1, 2)
+
+
+def _is_nhwc(x):
+    """logical NCHW tensor whose memory is NHWC-contiguous"""
+    return x.dim() == 4 and x.permute(0, 2, 3, 1).is_contiguous()
+
+
+class MaxPool2x2(nn.Module):
+    def forward(self, x):
+        return _hip.maxpool2x2_nhwc(_c(x.permute(0, 2, 3, 1))).permute(0, 3, 1, 2)
+
+
+class VGG16Features(nn.Sequential):
+    """torchvision vgg16().features minus the last max-pool (lib/object_detector.py:623-626): same child indices
+    (convs at 0,2,5,7,10,12,14,17,19,21,24,26,28 -> state-dict keys features.N.{weight,bias}).
+
+    forward: NCHW image in; every layer runs in NHWC on the MFMA implicit-GEMM kernel with fused bias+ReLU; the
+    returned feature map is a logical [B,512,H/16,W/16] tensor with channels_last strides (physically NHWC), which
+    RoIAlign consumes coalesced over channels.  The trunk is forward-only here: train_rels freezes the detector
+    (models/train_rels.py:50-52) -- conv backward belongs to the detector-pretraining path."""
+
+    CFG = (64, 64, 'M', 128, 128, 'M', 256, 256, 256, 'M', 512, 512, 512, 'M', 512, 512, 512)
+
+    def __init__(self):
+        layers, cin = [], 3
+        for v in self.CFG:
+            if v == 'M':
+                layers.append(MaxPool2x2())
+            else:
+                layers += [Conv3x3(cin, v), ReLU()]
+                cin = v
+        super(VGG16Features, self).__init__(*layers)
+
+    def forward(self, x):
+        if any(p.requires_grad for p in self.parameters()) and torch.is_grad_enabled():
+            raise NotImplementedError('VGG trunk backward is not built yet (detector pre-training path, '
+                                      'SURVEY.md §8f); freeze the detector as models/train_rels.py does')
+        with torch.no_grad():
+            mods = list(self.children())
+            first = mods[0]
+            y = _hip.conv_first_nchw(_c(x), _c(first.weight), first.bias, EPI_RELU)   # NHWC out
+            i = 2
+            while i < len(mods):
+                m = mods[i]
+                if isinstance(m, Conv3x3):
+                    y = m.forward_nhwc(y, EPI_RELU)
+                    i += 2                      # its ReLU is fused
+                elif isinstance(m, MaxPool2x2):
+                    y = _hip.maxpool2x2_nhwc(y)
+                    i += 1
+                else:
+                    raise RuntimeError('unexpected module in VGG16Features')
+        return y.permute(0, 3, 1, 2)
+
+
+# =========================================================================================== generic conv (im2col)
+class _ConvIm2colFn(torch.autograd.Function):
+    """NHWC convolution as im2col + MFMA GEMM (used for the 2-channel 7x7/2 mask conv, whose K = 98 is too
+    small for the implicit-GEMM kernel).  No input gradient (its input is a constant mask)."""
+
+    @staticmethod
+    def forward(ctx, x_nhwc, weight, bias, kh, kw, stride, pad):
+        B, H, W, C = x_nhwc.shape
+        K = kh * kw * C
+        ldo = (K + 3) // 4 * 4
+        cols, Ho, Wo = _hip.im2col_nhwc(_c(x_nhwc), kh, kw, stride, pad, ldo=ldo)
+        wmat = weight.new_zeros(weight.shape[0], ldo)
+        wmat[:, :K] = weight.permute(0, 2, 3, 1).reshape(weight.shape[0], K)
+        y = _hip.gemm(cols, wmat, False, True, bias=bias)
+        ctx.save_for_backward(cols)
+        ctx.meta = (weight.shape, K)
+        return y.view(B, Ho, Wo, weight.shape[0])
+
+    @staticmethod
+    def backward(ctx, gy):
+        (cols,) = ctx.saved_tensors
+        wshape, K = ctx.meta
+        g2 = _c(gy).view(-1, wshape[0])
+        gw = gb = None
+        if ctx.needs_input_grad[1]:
+            gwm = _hip.gemm(g2, cols, True, False)                       # [Cout, ldo]
+            gw = gwm[:, :K].reshape(wshape[0], wshape[2], wshape[3], wshape[1]).permute(0, 3, 1, 2).contiguous()
+        if ctx.needs_input_grad[2]:
+            gb = g2.sum(0)
+        return None, gw, gb, None, None, None, None
+
+
+class _Conv3x3Fn(torch.autograd.Function):
+    """Trainable NHWC 3x3 conv: forward = implicit GEMM; dgrad = the same kernel on flip-transposed weights;
+    wgrad = im2col(x)^T x dY on the GEMM."""
+
+    @staticmethod
+    def forward(ctx, x_nhwc, weight, bias):
+        x_nhwc = _c(x_nhwc)
+        wt = _hip.conv3x3_pack_weight(_c(weight), False)
+        y = _hip.conv3x3_nhwc(x_nhwc, wt, bias, EPI_NONE)
+        ctx.save_for_backward(x_nhwc, weight)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x_nhwc, weight = ctx.saved_tensors
+        gy = _c(gy)
+        Cout, Cin = weight.shape[0], weight.shape[1]
+        gx = gw = gb = None
+        if ctx.needs_input_grad[0]:
+            wt_t = _hip.conv3x3_pack_weight(_c(weight), True)          # [9][Cout][Cin]
+            gx = _hip.conv3x3_nhwc(gy, wt_t, None, EPI_NONE)
+        if ctx.needs_input_grad[1]:
+            cols, _, _ = _hip.im2col_nhwc(x_nhwc, 3, 3, 1, 1)          # [M, 9*Cin]
+            gwm = _hip.gemm(gy.view(-1, Cout), cols, True, False)      # [Cout, 9*Cin]  (tap-major, then cin)
+            gw = gwm.view(Cout, 3, 3, Cin).permute(0, 3, 1, 2).contiguous()
+        if ctx.needs_input_grad[2]:
+            gb = gy.view(-1, Cout).sum(0)
+        return gx, gw, gb
+
+
+class Conv2dNHWC(nn.Module):
+    """nn.Conv2d-compatible parameters ([Cout,Cin,kh,kw], bias); forward takes / returns NHWC tensors."""
+
+    def __init__(self, cin, cout, kernel_size, stride=1, padding=0):
+        super(Conv2dNHWC, self).__init__()
+        self.cin, self.cout, self.k, self.stride, self.padding = cin, cout, kernel_size, stride, padding
+        self.weight = nn.Parameter(torch.empty(cout, cin, kernel_size, kernel_size))
+        self.bias = nn.Parameter(torch.empty(cout))
+        nn.init.kaiming_uniform_(self.weight, a=math.sqrt(5))
+        bound = 1.0 / math.sqrt(cin * kernel_size * kernel_size)
+        nn.init.uniform_(self.bias, -bound, bound)
+
+    def forward(self, x_nhwc):
+        if self.k == 3 and self.stride == 1 and self.padding == 1 and self.cin % 16 == 0 and self.cout % 4 == 0:
+            return _Conv3x3Fn.apply(x_nhwc, self.weight, self.bias)
+        return _ConvIm2colFn.apply(x_nhwc, self.weight, self.bias, self.k, self.k, self.stride, self.padding)
+
+
+# =========================================================================================== RoIAlign
+class _RoIAlignFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, features, rois, ph, pw, spatial_scale):
+        nhwc = _is_nhwc(features)
+        feat = features.permute(0, 2, 3, 1) if nhwc else _c(features)
+        rois = _c(rois.detach().float())
+        if rois.dim() != 2 or rois.size(1) != 5:
+            raise ValueError('rois must be [n,5] (im, x1, y1, x2, y2)')     # roi_align_cuda.c:19-22 returned 0
+        B, C, H, W = features.shape
+        ctx.meta = (B, C, H, W, spatial_scale, nhwc)
+        ctx.save_for_backward(rois)
+        return _hip.roi_align_fwd(feat, rois, ph, pw, spatial_scale, nhwc)
+
+    @staticmethod
+    def backward(ctx, g):
+        (rois,) = ctx.saved_tensors
+        B, C, H, W, scale, nhwc = ctx.meta
+        gf = _hip.roi_align_bwd(_c(g), rois, B, C, H, W, scale, nhwc)
+        return (gf.permute(0, 3, 1, 2) if nhwc else gf), None, None, None, None
+
+
+def roi_align(features, rois, ph, pw, spatial_scale):
+    return _RoIAlignFn.apply(features, rois, int(ph), int(pw), float(spatial_scale))

@@ -1,0 +1,236 @@
+"""
+Highway-LSTM label decoder (reference lib/lstm/decoder_rnn.py:40-251) on the gfx950 kernels.
+
+Same constructor, parameters (obj_embed [152,100], input_linearity, state_linearity, out) and
+`forward(PackedSequence, labels=None, boxes_for_nms=None) -> (out_dists, out_commitments)`.
+
+How the per-timestep Python loop of the reference is restructured:
+  * x_t = [enc_t || emb(prev_t)], so  input_linearity(x_t) = W_enc enc_t + b  +  W_emb emb(prev_t).
+    The first term is ONE MFMA GEMM over all packed rows; the second is a row gather from the 152 x 6H table
+    E_proj = obj_embed.weight @ W_emb^T (one tiny GEMM per forward).  No per-step input GEMM remains.
+  * the recurrence itself is one fused GEMV+gate kernel per step (mh_hwlstm_cell_fwd) inside a single autograd
+    Function whose backward replays the steps in reverse (mh_hwlstm_cell_bwd + mh_gemv_rows) and computes the
+    recurrent weight gradient with ONE GEMM over all steps.
+  * teacher forcing makes every `prev_t` known up front; when a label is background (0 -> the step's own arg-max
+    is fed back, :205-213) or in eval (greedy, :214-227) a no-grad sequential pass first resolves the fed-back
+    labels, then the differentiable pass runs with them as constants (arg-max has no gradient).
+"""
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+from torch.nn.utils.rnn import PackedSequence
+
+from lib import _hip
+from lib import rng
+from lib.fpn.box_utils import nms_overlaps
+from lib.hip_ops import Linear, linear
+from lib.lstm.highway_lstm_cuda.alternating_highway_lstm import block_orthogonal
+from lib.word_vectors import obj_edge_vectors
+
+
+def get_dropout_mask(dropout_probability, shape, device):
+    """binary keep mask scaled by 1/(1-p) (reference :13-37)"""
+    return rng.keep_mask(shape, 1.0 - dropout_probability, device) / (1.0 - dropout_probability)
+
+
+def _step_bounds(batch_sizes):
+    ends = np.cumsum(batch_sizes)
+    return [(int(e - n), int(e), int(n)) for e, n in zip(ends, batch_sizes)]
+
+
+def _prev_state_rows(batch_sizes):
+    """index of the previous timestep's row for every packed row (-1 for the first timestep)"""
+    idx, start_prev = [], None
+    for s, e, n in _step_bounds(batch_sizes):
+        idx.append(np.full(n, -1, np.int64) if start_prev is None else start_prev + np.arange(n))
+        start_prev = s
+    return np.concatenate(idx)
+
+
+class _DecoderRecurrenceFn(torch.autograd.Function):
+    """h_all [N,H] from pre_i_all [N,6H] (input projection incl. bias and fed-back embedding) over a packed,
+    time-major batch.  state weight is nn.Linear layout [5H,H] == the kernel's K-contiguous wh_t."""
+
+    @staticmethod
+    def forward(ctx, pre_i_all, w_state, b_state, dropout_mask, batch_sizes):
+        N, H = pre_i_all.shape[0], w_state.shape[1]
+        pre_i_all = pre_i_all.contiguous()
+        w_state = w_state.contiguous()
+        h_all = pre_i_all.new_empty(N, H)
+        c_all = pre_i_all.new_empty(N, H)
+        gates_all = pre_i_all.new_empty(N, 6 * H)
+        B = int(batch_sizes[0])
+        zeros = pre_i_all.new_zeros(B, H)
+        h_prev = c_prev = zeros
+        for s, e, n in _step_bounds(batch_sizes):
+            h, c, g = _hip.hwlstm_cell_fwd(pre_i_all[s:e], h_prev[:n].contiguous(), c_prev[:n].contiguous(), w_state,
+                                           b_state, None if dropout_mask is None else dropout_mask[:n].contiguous(),
+                                           True)
+            h_all[s:e], c_all[s:e], gates_all[s:e] = h, c, g
+            h_prev, c_prev = h, c
+        ctx.batch_sizes = [int(v) for v in batch_sizes]
+        ctx.has_mask = dropout_mask is not None
+        ctx.save_for_backward(w_state, h_all, c_all, gates_all, dropout_mask if dropout_mask is not None else zeros)
+        return h_all
+
+    @staticmethod
+    def backward(ctx, dh_all):
+        w_state, h_all, c_all, gates_all, mask = ctx.saved_tensors
+        bs = ctx.batch_sizes
+        N, H = h_all.shape
+        dh_all = dh_all.contiguous()
+        d_pre = dh_all.new_zeros(N, 6 * H)
+        w_state_t = w_state.t().contiguous()              # [H,5H]: row k contiguous over the gate columns
+        steps = _step_bounds(bs)
+        dh_rec = dc_rec = None                             # gradients flowing from step t+1 (first n_{t+1} rows)
+        for t in range(len(steps) - 1, -1, -1):
+            s, e, n = steps[t]
+            d_h = dh_all[s:e].clone()
+            d_c = dh_all.new_zeros(n, H)
+            if dh_rec is not None:
+                m = dh_rec.shape[0]
+                d_h[:m] += dh_rec
+                d_c[:m] = dc_rec
+            if t > 0:
+                ps = steps[t - 1][0]
+                c_prev = c_all[ps:ps + n].contiguous()
+            else:
+                c_prev = dh_all.new_zeros(n, H)
+            dg, dc_in = _hip.hwlstm_cell_bwd(d_h, d_c, c_prev, c_all[s:e].contiguous(), gates_all[s:e].contiguous(),
+                                             mask[:n].contiguous() if ctx.has_mask else None)
+            d_pre[s:e] = dg
+            if t > 0:
+                dh_rec = _hip.gemv_rows(dg[:, :5 * H], w_state_t)
+                dc_rec = dc_in
+        gw = gb = None
+        if ctx.needs_input_grad[1]:
+            prev_rows = _prev_state_rows(bs)
+            valid = torch.from_numpy((prev_rows >= 0)).to(h_all.device)
+            h_prev_all = h_all.index_select(0, torch.from_numpy(np.maximum(prev_rows, 0)).to(h_all.device))
+            h_prev_all = h_prev_all * valid[:, None].to(h_all.dtype)
+            gw = _hip.gemm(d_pre[:, :5 * H], h_prev_all, True, False)         # [5H, H]
+        if ctx.needs_input_grad[2]:
+            gb = d_pre[:, :5 * H].sum(0)
+        return d_pre, gw, gb, None, None
+
+
+class DecoderRNN(torch.nn.Module):
+    def __init__(self, classes, embed_dim, inputs_dim, hidden_dim, recurrent_dropout_probability=0.2,
+                 use_highway=True, use_input_projection_bias=True):
+        super(DecoderRNN, self).__init__()
+        if not use_highway:
+            raise NotImplementedError('only the highway variant is on the path (reference default)')
+        self.classes = classes
+        embed_vecs = obj_edge_vectors(['start'] + self.classes, wv_dim=100)       # [152,100] (reference :56-58)
+        self.obj_embed = nn.Embedding(len(self.classes), embed_dim)
+        self.obj_embed.weight.data = embed_vecs
+        self.hidden_size = hidden_dim
+        self.inputs_dim = inputs_dim
+        self.nms_thresh = 0.3
+        self.recurrent_dropout_probability = recurrent_dropout_probability
+        self.use_highway = use_highway
+        self.input_linearity = Linear(self.input_size, 6 * self.hidden_size, bias=use_input_projection_bias)
+        self.state_linearity = Linear(self.hidden_size, 5 * self.hidden_size, bias=True)
+        self.out = Linear(self.hidden_size, len(self.classes))
+        self.reset_parameters()
+
+    @property
+    def input_size(self):
+        return self.inputs_dim + self.obj_embed.weight.size(1)
+
+    def reset_parameters(self):
+        block_orthogonal(self.input_linearity.weight.data, [self.hidden_size, self.input_size])
+        block_orthogonal(self.state_linearity.weight.data, [self.hidden_size, self.hidden_size])
+        self.state_linearity.bias.data.fill_(0.0)
+        self.state_linearity.bias.data[self.hidden_size:2 * self.hidden_size].fill_(1.0)
+
+    # ------------------------------------------------------------------------------------------
+    def _projections(self, sequence_tensor):
+        D = self.inputs_dim
+        w_in = self.input_linearity.weight
+        enc_proj = linear(sequence_tensor, w_in[:, :D], self.input_linearity.bias)          # [N,6H]
+        emb_proj = linear(self.obj_embed.weight, w_in[:, D:], None)                         # [152,6H]
+        return enc_proj, emb_proj
+
+    def _greedy_feedback(self, enc_proj, emb_proj, batch_sizes, labels, dropout_mask):
+        """Sequential no-grad pass that resolves which label index is fed back at every row
+        (train: the GT label, or the step's non-bg arg-max where the label is 0; eval: the arg-max)."""
+        H = self.hidden_size
+        with torch.no_grad():
+            B = int(batch_sizes[0])
+            h_prev = c_prev = enc_proj.new_zeros(B, H)
+            prev = torch.zeros(B, dtype=torch.long, device=enc_proj.device)      # 'start'
+            fed, commits = [], []
+            w_state, b_state = self.state_linearity.weight.contiguous(), self.state_linearity.bias
+            for s, e, n in _step_bounds(batch_sizes):
+                fed.append(prev[:n])
+                pre_i = enc_proj[s:e] + emb_proj.index_select(0, prev[:n])
+                h, c, _ = _hip.hwlstm_cell_fwd(pre_i.contiguous(), h_prev[:n].contiguous(), c_prev[:n].contiguous(),
+                                               w_state, b_state,
+                                               None if dropout_mask is None else dropout_mask[:n].contiguous(), False)
+                pred = _hip.gemv_rows(h, self.out.weight, self.out.bias)
+                best = pred[:, 1:].max(1)[1] + 1
+                if labels is not None:
+                    lab = labels[s:e].clone()
+                    lab = torch.where(lab == 0, best, lab)
+                else:
+                    lab = best
+                commits.append(lab)
+                prev = lab + 1
+                h_prev, c_prev = h, c
+        return torch.cat(fed, 0), torch.cat(commits, 0)
+
+    def forward(self, inputs, initial_state=None, labels=None, boxes_for_nms=None):
+        if not isinstance(inputs, PackedSequence):
+            raise ValueError('inputs must be PackedSequence but got %s' % (type(inputs)))
+        if initial_state is not None:
+            raise NotImplementedError('initial_state is ignored by the reference too')
+        sequence_tensor = inputs.data
+        batch_sizes = [int(v) for v in inputs.batch_sizes]
+        B = batch_sizes[0]
+        dropout_mask = None
+        if self.recurrent_dropout_probability > 0.0:
+            m = get_dropout_mask(self.recurrent_dropout_probability, (B, self.hidden_size), sequence_tensor.device)
+            dropout_mask = m if self.training else None            # reference :126-130 applies it in train only
+        enc_proj, emb_proj = self._projections(sequence_tensor)
+
+        if self.training:
+            if labels is None:
+                raise ValueError('training needs labels (teacher forcing)')
+            if bool((labels == 0).any()):
+                fed, commits = self._greedy_feedback(enc_proj.detach(), emb_proj.detach(), batch_sizes, labels,
+                                                     dropout_mask)
+            else:
+                # prev label of row r at step t is the label of the same sequence at step t-1
+                prev_rows = torch.from_numpy(_prev_state_rows(batch_sizes)).to(labels.device)
+                fed = torch.where(prev_rows >= 0, labels[prev_rows.clamp(min=0)] + 1, torch.zeros_like(labels))
+                commits = labels.clone()
+        else:
+            for n in batch_sizes:
+                assert n == 1, 'eval decodes one image at a time (reference :215)'
+            fed, commits = self._greedy_feedback(enc_proj.detach(), emb_proj.detach(), batch_sizes, None, None)
+
+        pre_i_all = enc_proj + emb_proj.index_select(0, fed)
+        h_all = _DecoderRecurrenceFn.apply(pre_i_all, self.state_linearity.weight, self.state_linearity.bias,
+                                           dropout_mask, batch_sizes)
+        out_dists = self.out(h_all)
+
+        if boxes_for_nms is not None and not self.training:
+            commits = self._nms_commitments(out_dists, boxes_for_nms)
+        return out_dists, commits
+
+    def _nms_commitments(self, out_dists, boxes_for_nms):
+        """class-wise greedy suppression of the sampled labels in sgdet eval (reference :230-247); host side
+        like the reference (N <= 64 objects)."""
+        is_overlap = nms_overlaps(boxes_for_nms.detach()).view(
+            boxes_for_nms.size(0), boxes_for_nms.size(0), boxes_for_nms.size(1)).cpu().numpy() >= self.nms_thresh
+        sampled = F.softmax(out_dists.detach(), 1).cpu().numpy().copy()
+        sampled[:, 0] = 0
+        commits = np.zeros(out_dists.size(0), dtype=np.int64)
+        for _ in range(commits.shape[0]):
+            box_ind, cls_ind = np.unravel_index(sampled.argmax(), sampled.shape)
+            commits[int(box_ind)] = int(cls_ind)
+            sampled[is_overlap[box_ind, :, cls_ind], cls_ind] = 0.0
+            sampled[box_ind] = -1.0
+        return torch.from_numpy(commits).to(out_dists.device)

@@ -1,0 +1,163 @@
+"""
+Small tensor / numpy helpers with the reference's names (lib/pytorch_misc.py) -- host-side glue on the path:
+index arithmetic for packed sequences, per-image enumeration, gradient clipping, checkpoint restore.
+"""
+import numpy as np
+import torch
+from torch import nn
+
+
+def optimistic_restore(network, state_dict):
+    """copy every same-named, same-shaped tensor; report the rest (reference :14-33). True iff nothing mismatched."""
+    own = network.state_dict()
+    ok = True
+    for name, param in state_dict.items():
+        if name not in own:
+            print("Unexpected key {} in state_dict with size {}".format(name, tuple(param.size())))
+            ok = False
+        elif param.size() == own[name].size():
+            own[name].copy_(param)
+        else:
+            print("Network has {} with size {}, ckpt has {}".format(name, tuple(own[name].size()), tuple(param.size())))
+            ok = False
+    missing = set(own.keys()) - set(state_dict.keys())
+    if missing:
+        print("We couldn't find {}".format(','.join(sorted(missing))))
+        ok = False
+    return ok
+
+
+class Flattener(nn.Module):
+    def forward(self, x):
+        return x.reshape(x.size(0), -1)
+
+
+def arange(base_tensor, n=None):
+    n = base_tensor.size(0) if n is None else n
+    return torch.arange(n, dtype=torch.long, device=base_tensor.device)
+
+
+def to_onehot(vec, num_classes, fill=1000):
+    """[n,num_classes] float tensor with +fill at vec[i] and -fill elsewhere (reference :110-125)"""
+    out = torch.full((vec.size(0), num_classes), -float(fill), dtype=torch.float32, device=vec.device)
+    out[torch.arange(vec.size(0), device=vec.device), vec.long()] = float(fill)
+    return out
+
+
+def gather_nd(x, index):
+    """x [d0..d{n-1}, dim], index [num, n] -> rows x[index[i,0],...,index[i,n-1]]  (reference :255-275)"""
+    nd = x.dim() - 1
+    assert nd > 0 and index.dim() == 2 and index.size(1) == nd
+    flat = index[:, nd - 1].clone()
+    mult = x.size(nd - 1)
+    for col in range(nd - 2, -1, -1):
+        flat += index[:, col] * mult
+        mult *= x.size(col)
+    return x.reshape(-1, x.size(-1))[flat]
+
+
+def enumerate_by_image(im_inds):
+    """yield (image id, start, end) for every run of equal image indices (reference :278-287)"""
+    arr = im_inds.cpu().numpy() if torch.is_tensor(im_inds) else np.asarray(im_inds)
+    if arr.shape[0] == 0:
+        return
+    start, cur = 0, int(arr[0])
+    for i in range(1, arr.shape[0]):
+        if arr[i] != cur:
+            yield cur, start, i
+            start, cur = i, int(arr[i])
+    yield cur, start, arr.shape[0]
+
+
+def diagonal_inds(tensor):
+    assert tensor.dim() >= 2 and tensor.size(0) == tensor.size(1)
+    n = tensor.size(0)
+    return (n + 1) * torch.arange(n, dtype=torch.long, device=tensor.device)
+
+
+def nonintersecting_2d_inds(x):
+    rs = 1 - np.diag(np.ones(x, dtype=np.int32))
+    return np.column_stack(np.where(rs))
+
+
+def intersect_2d(x1, x2):
+    """[m1,m2] bool: row i of x1 equals row j of x2"""
+    if x1.shape[1] != x2.shape[1]:
+        raise ValueError("Input arrays must have same #columns")
+    return (x1[..., None] == x2.T[None, ...]).all(1)
+
+
+def argsort_desc(scores):
+    """indices (one row per element) that sort `scores` descending"""
+    return np.column_stack(np.unravel_index(np.argsort(-scores.ravel()), scores.shape))
+
+
+def unravel_index(index, dims):
+    out, rem = [], index.clone()
+    for d in dims[::-1]:
+        out.append(rem % d)
+        rem = rem // d
+    return torch.stack(out[::-1], 1)
+
+
+def de_chunkize(tensor, chunks):
+    s = 0
+    for c in chunks:
+        yield tensor[s:s + c]
+        s += c
+
+
+def random_choose(tensor, num, rs=np.random):
+    """`num` rows without replacement (numpy RNG like the reference, :347-363); `rs` makes it seedable"""
+    if min(tensor.size(0), num) == tensor.size(0):
+        return tensor
+    idx = rs.choice(tensor.size(0), size=num, replace=False)
+    return tensor[torch.from_numpy(idx).to(tensor.device)].contiguous()
+
+
+def transpose_packed_sequence_inds(lengths):
+    """indices that turn a batch-major concatenation (sequences sorted by decreasing length) into time-major
+    packed order, plus the batch size per timestep (reference :365-384)"""
+    lengths = list(lengths)
+    starts = np.cumsum([0] + lengths[:-1])
+    inds, sizes = [], []
+    alive = len(lengths)
+    for t in range(lengths[0]):
+        while alive > 1 and lengths[alive - 1] <= t:
+            alive -= 1
+        inds.append(starts[:alive] + t)
+        sizes.append(alive)
+    return np.concatenate(inds, 0), sizes
+
+
+def clip_grad_norm(named_parameters, max_norm, clip=False, verbose=False):
+    """global L2 norm over all gradients; scales them in place when `clip` (reference :416-455).
+    One device reduction for the whole list instead of one host sync per parameter."""
+    named_parameters = [(n, p) for n, p in named_parameters if p.grad is not None]
+    max_norm = float(max_norm)
+    if not named_parameters:
+        return 0.0
+    norms = torch.stack([p.grad.detach().norm(2) for _, p in named_parameters])
+    total_norm = float(norms.pow(2).sum().sqrt().item())
+    clip_coef = max_norm / (total_norm + 1e-6)
+    if clip_coef < 1 and clip:
+        for _, p in named_parameters:
+            p.grad.detach().mul_(clip_coef)
+    if verbose:
+        print('---Total norm {:.3f} clip coef {:.3f}-----------------'.format(total_norm, clip_coef))
+        for (name, p), nv in sorted(zip(named_parameters, norms.tolist()), key=lambda x: -x[1]):
+            print("{:<50s}: {:.3f}, ({})".format(name, nv, tuple(p.size())))
+        print('-------------------------------', flush=True)
+    return total_norm
+
+
+def print_para(model):
+    rows, total = [], 0
+    for name, p in model.named_parameters():
+        total += p.numel()
+        if 'bias' not in name.split('.')[-1]:
+            rows.append((name, list(p.size()), p.numel(), p.requires_grad))
+    rows.sort(key=lambda r: -r[2])
+    lines = ["{:<50s}: {:<16s}({:8d}) ({})".format(n, '[{}]'.format(','.join(map(str, s))), k, 'grad' if g else '    ')
+             for n, s, k, g in rows]
+    return '\n {:.1f}M total parameters \n ----- \n \n{}'.format(total / 1e6, '\n'.join(lines))

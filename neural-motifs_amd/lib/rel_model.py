@@ -1,0 +1,345 @@
+"""
+MotifNet relation model -- the reference's `RelModel` / `LinearizedContext` API (lib/rel_model.py:66-560) on the
+gfx950 kernels: object/edge context through the stacked alternating highway LSTM, label decoder, O(N^2) relation
+head (union-box features -> fc6/fc7 on the MFMA GEMM), frequency bias, eval post-processing.
+
+Constructor arguments, forward arguments, Result fields and state-dict keys follow the reference.
+Behaviours kept on purpose (SURVEY.md §7 "quirks"): 'leftright' order is descending centre-x; the "BiLSTM" is
+alternating-direction stacking; limit_vision multiplies only the first 2048 dims; ties in every sort break by index.
+"""
+import math
+
+import numpy as np
+import torch
+import torch.nn as nn
+from torch.nn import functional as F
+from torch.nn.utils.rnn import PackedSequence
+
+from config import BATCHNORM_MOMENTUM
+from lib.fpn.box_utils import bbox_overlaps, center_size
+from lib.fpn.nms.functions.nms import apply_nms
+from lib.fpn.roi_align.functions.roi_align import RoIAlignFunction
+from lib.get_union_boxes import UnionBoxesAndFeats
+from lib.hip_ops import Dropout, Flattener, Linear, ReLU, linear
+from lib.lstm.decoder_rnn import DecoderRNN
+from lib.lstm.highway_lstm_cuda.alternating_highway_lstm import AlternatingHighwayLSTM
+from lib.object_detector import ObjectDetector, gather_res, load_vgg
+from lib.pytorch_misc import transpose_packed_sequence_inds, to_onehot, arange, enumerate_by_image
+from lib.sparse_targets import FrequencyBias
+from lib.surgery import filter_dets
+from lib.word_vectors import obj_edge_vectors
+
+MODES = ('sgdet', 'sgcls', 'predcls')
+
+
+def _sort_by_score(im_inds, scores):
+    """Permutation that orders rois for the LSTMs (reference :31-61): inside an image by descending score, images by
+    decreasing object count, then time-major (TxB packed).  Returns (perm, inv_perm, batch size per timestep)."""
+    num_im = int(im_inds[-1]) + 1
+    im_key = np.zeros(num_im, dtype=np.float32)
+    lengths = []
+    for i, s, e in enumerate_by_image(im_inds):
+        im_key[i] = 2 * (s - e) * num_im + i
+        lengths.append(e - s)
+    lengths = sorted(lengths, reverse=True)
+    inds, ls_transposed = transpose_packed_sequence_inds(lengths)
+    inds = torch.from_numpy(np.asarray(inds, dtype=np.int64)).to(im_inds.device)
+    roi_order = scores - 2 * torch.from_numpy(im_key).to(scores.device)[im_inds]
+    _, perm = torch.sort(roi_order, dim=0, descending=True, stable=True)
+    perm = perm[inds]
+    _, inv_perm = torch.sort(perm)
+    return perm, inv_perm, ls_transposed
+
+
+class LinearizedContext(nn.Module):
+    """object context -> label decoder -> edge context"""
+
+    def __init__(self, classes, rel_classes, mode='sgdet', embed_dim=200, hidden_dim=256, obj_dim=2048, nl_obj=2,
+                 nl_edge=2, dropout_rate=0.2, order='confidence', pass_in_obj_feats_to_decoder=True,
+                 pass_in_obj_feats_to_edge=True):
+        super(LinearizedContext, self).__init__()
+        self.classes = classes
+        self.rel_classes = rel_classes
+        assert mode in MODES
+        self.mode = mode
+        self.nl_obj, self.nl_edge = nl_obj, nl_edge
+        self.embed_dim, self.hidden_dim, self.obj_dim = embed_dim, hidden_dim, obj_dim
+        self.dropout_rate = dropout_rate
+        self.pass_in_obj_feats_to_decoder = pass_in_obj_feats_to_decoder
+        self.pass_in_obj_feats_to_edge = pass_in_obj_feats_to_edge
+        assert order in ('size', 'confidence', 'random', 'leftright')
+        self.order = order
+
+        embed_vecs = obj_edge_vectors(self.classes, wv_dim=self.embed_dim)
+        self.obj_embed = nn.Embedding(self.num_classes, self.embed_dim)
+        self.obj_embed.weight.data = embed_vecs.clone()
+        self.obj_embed2 = nn.Embedding(self.num_classes, self.embed_dim)
+        self.obj_embed2.weight.data = embed_vecs.clone()
+
+        self.pos_embed = nn.Sequential(
+            nn.BatchNorm1d(4, momentum=BATCHNORM_MOMENTUM / 10.0),
+            Linear(4, 128),
+            ReLU(),
+            Dropout(0.1),
+        )
+        if self.nl_obj > 0:
+            self.obj_ctx_rnn = AlternatingHighwayLSTM(input_size=self.obj_dim + self.embed_dim + 128,
+                                                      hidden_size=self.hidden_dim, num_layers=self.nl_obj,
+                                                      recurrent_dropout_probability=dropout_rate)
+            decoder_inputs_dim = self.hidden_dim
+            if self.pass_in_obj_feats_to_decoder:
+                decoder_inputs_dim += self.obj_dim + self.embed_dim
+            self.decoder_rnn = DecoderRNN(self.classes, embed_dim=self.embed_dim, inputs_dim=decoder_inputs_dim,
+                                          hidden_dim=self.hidden_dim, recurrent_dropout_probability=dropout_rate)
+        else:
+            self.decoder_lin = Linear(self.obj_dim + self.embed_dim + 128, self.num_classes)
+        if self.nl_edge > 0:
+            input_dim = self.embed_dim
+            if self.nl_obj > 0:
+                input_dim += self.hidden_dim
+            if self.pass_in_obj_feats_to_edge:
+                input_dim += self.obj_dim
+            self.edge_ctx_rnn = AlternatingHighwayLSTM(input_size=input_dim, hidden_size=self.hidden_dim,
+                                                       num_layers=self.nl_edge,
+                                                       recurrent_dropout_probability=dropout_rate)
+
+    @property
+    def num_classes(self):
+        return len(self.classes)
+
+    @property
+    def num_rels(self):
+        return len(self.rel_classes)
+
+    def sort_rois(self, batch_idx, confidence, box_priors):
+        cxcywh = center_size(box_priors)
+        if self.order == 'size':
+            sizes = cxcywh[:, 2] * cxcywh[:, 3]
+            scores = sizes / (sizes.max() + 1)
+        elif self.order == 'confidence':
+            scores = confidence
+        elif self.order == 'random':
+            scores = torch.from_numpy(np.random.rand(batch_idx.size(0)).astype(np.float32)).to(batch_idx.device)
+        elif self.order == 'leftright':
+            centers = cxcywh[:, 0]
+            scores = centers / (centers.max() + 1)
+        else:
+            raise ValueError("invalid mode {}".format(self.order))
+        return _sort_by_score(batch_idx, scores)
+
+    def edge_ctx(self, obj_feats, obj_dists, im_inds, obj_preds, box_priors=None):
+        obj_embed2 = self.obj_embed2(obj_preds)
+        inp_feats = torch.cat((obj_embed2, obj_feats), 1)
+        confidence = F.softmax(obj_dists, dim=1).detach().view(-1)[obj_preds.detach() + arange(obj_preds) * self.num_classes]
+        perm, inv_perm, ls_transposed = self.sort_rois(im_inds.detach(), confidence, box_priors)
+        edge_input_packed = PackedSequence(inp_feats[perm], torch.tensor(ls_transposed))
+        edge_reps = self.edge_ctx_rnn(edge_input_packed)[0][0]
+        return edge_reps[inv_perm]
+
+    def obj_ctx(self, obj_feats, obj_dists, im_inds, obj_labels=None, box_priors=None, boxes_per_cls=None):
+        confidence = F.softmax(obj_dists, dim=1).detach()[:, 1:].max(1)[0]
+        perm, inv_perm, ls_transposed = self.sort_rois(im_inds.detach(), confidence, box_priors)
+        obj_inp_rep = obj_feats[perm].contiguous()
+        bs = torch.tensor(ls_transposed)
+        encoder_rep = self.obj_ctx_rnn(PackedSequence(obj_inp_rep, bs))[0][0]
+        if self.mode != 'predcls':
+            dec_in = torch.cat((obj_inp_rep, encoder_rep), 1) if self.pass_in_obj_feats_to_decoder else encoder_rep
+            obj_dists, obj_preds = self.decoder_rnn(
+                PackedSequence(dec_in, bs),
+                labels=obj_labels[perm] if obj_labels is not None else None,
+                boxes_for_nms=boxes_per_cls[perm] if boxes_per_cls is not None else None)
+            obj_preds = obj_preds[inv_perm]
+            obj_dists = obj_dists[inv_perm]
+        else:
+            assert obj_labels is not None
+            obj_preds = obj_labels
+            obj_dists = to_onehot(obj_preds.detach(), self.num_classes)
+        return obj_dists, obj_preds, encoder_rep[inv_perm]
+
+    def forward(self, obj_fmaps, obj_logits, im_inds, obj_labels=None, box_priors=None, boxes_per_cls=None):
+        obj_embed = linear(F.softmax(obj_logits, dim=1), self.obj_embed.weight.t())        # probs @ E
+        pos_embed = self.pos_embed(center_size(box_priors))
+        obj_pre_rep = torch.cat((obj_fmaps, obj_embed, pos_embed), 1)
+
+        if self.nl_obj > 0:
+            obj_dists2, obj_preds, obj_ctx = self.obj_ctx(obj_pre_rep, obj_logits, im_inds, obj_labels, box_priors,
+                                                          boxes_per_cls)
+        else:
+            if self.mode == 'predcls':
+                obj_dists2 = to_onehot(obj_labels.detach(), self.num_classes)
+            else:
+                obj_dists2 = self.decoder_lin(obj_pre_rep)
+            if self.mode == 'sgdet' and not self.training:
+                probs = F.softmax(obj_dists2, 1).detach()
+                nms_mask = torch.zeros_like(probs)
+                for c_i in range(1, obj_dists2.size(1)):
+                    keep = apply_nms(probs[:, c_i], boxes_per_cls.detach()[:, c_i], pre_nms_topn=probs.size(0),
+                                     post_nms_topn=probs.size(0), nms_thresh=0.3)
+                    nms_mask[:, c_i][keep] = 1
+                obj_preds = (nms_mask * probs)[:, 1:].max(1)[1] + 1
+            else:
+                obj_preds = obj_labels if obj_labels is not None else obj_dists2[:, 1:].max(1)[1] + 1
+            obj_ctx = obj_pre_rep
+
+        edge_ctx = None
+        if self.nl_edge > 0:
+            edge_ctx = self.edge_ctx(torch.cat((obj_fmaps, obj_ctx), 1) if self.pass_in_obj_feats_to_edge else obj_ctx,
+                                     obj_dists=obj_dists2.detach(), im_inds=im_inds, obj_preds=obj_preds,
+                                     box_priors=box_priors)
+        return obj_dists2, obj_preds, edge_ctx
+
+
+class RelModel(nn.Module):
+    def __init__(self, classes, rel_classes, mode='sgdet', num_gpus=1, use_vision=True, require_overlap_det=True,
+                 embed_dim=200, hidden_dim=256, pooling_dim=2048, nl_obj=1, nl_edge=2, use_resnet=False,
+                 order='confidence', thresh=0.01, use_proposals=False, pass_in_obj_feats_to_decoder=True,
+                 pass_in_obj_feats_to_edge=True, rec_dropout=0.0, use_bias=True, use_tanh=True, limit_vision=True,
+                 max_per_img=64, freq_counts=None):
+        """Arguments as in the reference (lib/rel_model.py:303-308) plus two additions: `max_per_img` (the reference
+        hard-codes 64, :345; BASELINE cfg5 needs 80) and `freq_counts=(fg_matrix, bg_matrix)` to inject the
+        predicate statistics instead of scanning the dataset at construction time."""
+        super(RelModel, self).__init__()
+        self.classes = classes
+        self.rel_classes = rel_classes
+        self.num_gpus = num_gpus
+        assert mode in MODES
+        self.mode = mode
+        if use_resnet:
+            raise NotImplementedError('ResNet-101 variant: not built yet (BASELINE cfg4)')
+        self.pooling_size = 7
+        self.embed_dim = embed_dim
+        self.hidden_dim = hidden_dim
+        self.obj_dim = 4096
+        self.pooling_dim = pooling_dim
+        self.use_bias = use_bias
+        self.use_vision = use_vision
+        self.use_tanh = use_tanh
+        self.limit_vision = limit_vision
+        self.require_overlap = require_overlap_det and self.mode == 'sgdet'
+        self.sampler_rs = None            # optional numpy RandomState for the relation sampler (reproducible runs)
+
+        self.detector = ObjectDetector(
+            classes=classes,
+            mode=('proposals' if use_proposals else 'refinerels') if mode == 'sgdet' else 'gtbox',
+            use_resnet=use_resnet, thresh=thresh, max_per_img=max_per_img)
+
+        self.context = LinearizedContext(self.classes, self.rel_classes, mode=self.mode, embed_dim=self.embed_dim,
+                                         hidden_dim=self.hidden_dim, obj_dim=self.obj_dim, nl_obj=nl_obj,
+                                         nl_edge=nl_edge, dropout_rate=rec_dropout, order=order,
+                                         pass_in_obj_feats_to_decoder=pass_in_obj_feats_to_decoder,
+                                         pass_in_obj_feats_to_edge=pass_in_obj_feats_to_edge)
+
+        self.union_boxes = UnionBoxesAndFeats(pooling_size=self.pooling_size, stride=16, dim=512)
+
+        roi_fmap = [Flattener(),
+                    load_vgg(use_dropout=False, use_relu=False, use_linear=pooling_dim == 4096).classifier]
+        if pooling_dim != 4096:
+            roi_fmap.append(Linear(4096, pooling_dim))
+        self.roi_fmap = nn.Sequential(*roi_fmap)
+        self.roi_fmap_obj = load_vgg().classifier
+
+        self.post_lstm = Linear(self.hidden_dim, self.pooling_dim * 2)
+        self.post_lstm.weight.data.normal_(0, 10.0 * math.sqrt(1.0 / self.hidden_dim))
+        self.post_lstm.bias.data.zero_()
+        if nl_edge == 0:
+            self.post_emb = nn.Embedding(self.num_classes, self.pooling_dim * 2)
+            self.post_emb.weight.data.normal_(0, math.sqrt(1.0))
+        self.rel_compress = Linear(self.pooling_dim, self.num_rels, bias=True)
+        nn.init.xavier_normal_(self.rel_compress.weight, gain=1.0)
+        if self.use_bias:
+            fg, bg = freq_counts if freq_counts is not None else (None, None)
+            self.freq_bias = FrequencyBias(fg_matrix=fg, bg_matrix=bg, num_objs=self.num_classes,
+                                           num_rels=self.num_rels)
+
+    @property
+    def num_classes(self):
+        return len(self.classes)
+
+    @property
+    def num_rels(self):
+        return len(self.rel_classes)
+
+    def visual_rep(self, features, rois, pair_inds):
+        assert pair_inds.size(1) == 2
+        uboxes = self.union_boxes(features, rois, pair_inds)
+        return self.roi_fmap(uboxes)
+
+    def get_rel_inds(self, rel_labels, im_inds, box_priors):
+        """candidate (image, subject, object) rows: the sampled labels in training, every ordered pair of distinct
+        boxes of an image in eval (overlapping ones only for sgdet)"""
+        if self.training:
+            return rel_labels[:, :3].detach().clone()
+        rel_cands = im_inds[:, None] == im_inds[None]
+        rel_cands.fill_diagonal_(False)
+        if self.require_overlap:
+            rel_cands = rel_cands & (bbox_overlaps(box_priors.detach().contiguous(),
+                                                   box_priors.detach().contiguous()) > 0)
+        rel_cands = rel_cands.nonzero()
+        if rel_cands.numel() == 0:
+            rel_cands = im_inds.new_zeros(1, 2)
+        return torch.cat((im_inds[rel_cands[:, 0]][:, None], rel_cands), 1)
+
+    def obj_feature_map(self, features, rois):
+        pooled = RoIAlignFunction(self.pooling_size, self.pooling_size, spatial_scale=1 / 16)(features, rois)
+        return self.roi_fmap_obj(pooled.view(rois.size(0), -1))
+
+    def forward(self, x, im_sizes, image_offset, gt_boxes=None, gt_classes=None, gt_rels=None, proposals=None,
+                train_anchor_inds=None, return_fmap=False):
+        self.detector.sampler_rs = self.sampler_rs
+        result = self.detector(x, im_sizes, image_offset, gt_boxes, gt_classes, gt_rels, proposals,
+                               train_anchor_inds, return_fmap=True)
+        if result.is_none():
+            return ValueError("heck")            # the reference returns (not raises) this, :474-475
+
+        im_inds = result.im_inds - image_offset
+        boxes = result.rm_box_priors
+        if self.training and result.rel_labels is None:
+            raise NotImplementedError('sgdet training needs rel_assignments (SURVEY.md §8 a9): not built yet')
+
+        rel_inds = self.get_rel_inds(result.rel_labels, im_inds, boxes)
+        rois = torch.cat((im_inds[:, None].float(), boxes), 1)
+        fmap = result.fmap.detach()
+        result.obj_fmap = self.obj_feature_map(fmap, rois)
+
+        result.rm_obj_dists, result.obj_preds, edge_ctx = self.context(
+            result.obj_fmap, result.rm_obj_dists.detach(), im_inds,
+            result.rm_obj_labels if self.training or self.mode == 'predcls' else None,
+            boxes.detach(), result.boxes_all)
+
+        edge_rep = self.post_emb(result.obj_preds) if edge_ctx is None else self.post_lstm(edge_ctx)
+        edge_rep = edge_rep.view(edge_rep.size(0), 2, self.pooling_dim)
+        subj_rep, obj_rep = edge_rep[:, 0], edge_rep[:, 1]
+        prod_rep = subj_rep[rel_inds[:, 1]] * obj_rep[rel_inds[:, 2]]
+
+        if self.use_vision:
+            vr = self.visual_rep(fmap, rois, rel_inds[:, 1:])
+            if self.limit_vision:
+                prod_rep = torch.cat((prod_rep[:, :2048] * vr[:, :2048], prod_rep[:, 2048:]), 1)
+            else:
+                prod_rep = prod_rep * vr
+        if self.use_tanh:
+            prod_rep = torch.tanh(prod_rep)
+
+        result.rel_dists = self.rel_compress(prod_rep)
+        if self.use_bias:
+            result.rel_dists = result.rel_dists + self.freq_bias.index_with_labels(torch.stack((
+                result.obj_preds[rel_inds[:, 1]], result.obj_preds[rel_inds[:, 2]]), 1))
+        if self.training:
+            return result
+
+        twod_inds = arange(result.obj_preds) * self.num_classes + result.obj_preds
+        result.obj_scores = F.softmax(result.rm_obj_dists, dim=1).view(-1)[twod_inds]
+        if self.mode == 'sgdet':
+            bboxes = result.boxes_all.view(-1, 4)[twod_inds].view(result.boxes_all.size(0), 4)
+        else:
+            bboxes = result.rm_box_priors
+        rel_rep = F.softmax(result.rel_dists, dim=1)
+        return filter_dets(bboxes, result.obj_scores, result.obj_preds, rel_inds[:, 1:], rel_rep)
+
+    def __getitem__(self, batch):
+        """`detector[blob]` (reference :549-560); one replica per process, see lib/dist.py for the multi-GPU path"""
+        batch.scatter()
+        if self.num_gpus != 1:
+            raise RuntimeError('in-process multi-GPU replication is replaced by one process per GPU: launch with '
+                               'torchrun and keep num_gpus=1 per rank')
+        return self(*batch[0])

@@ -1,0 +1,161 @@
+"""
+TEST-ONLY stand-in for the HIP kernels, so that the product's *host logic* (module wiring, index arithmetic,
+autograd plumbing, samplers, drivers) can be exercised in the GPU-less build container.
+
+`install()` monkey-patches the functions of `lib._hip` with CPU implementations backed by the oracle / plain torch.
+Nothing in the product imports this module; the product itself has no CPU path and raises without a HIP device
+(tests/test_cabi.py::test_hot_path_fails_loudly_without_gpu).  Numerical parity is NOT established here -- that is
+the job of the `-m gpu` tests, which run the real kernels.
+"""
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from oracle import lstm as OL
+from oracle import native
+
+
+_GATES = {}
+
+
+def _np(t):
+    return t.detach().cpu().numpy()
+
+
+def install():
+    from lib import _hip
+    from dataloaders import blob as blob_mod
+
+    def gemm(a, b, trans_a=False, trans_b=False, bias=None, epilogue=0, out=None, accumulate=False, splitk=0):
+        r = (a.t() if trans_a else a) @ (b.t() if trans_b else b)
+        if bias is not None:
+            r = r + bias
+        r = {0: r, 1: F.relu(r), 2: F.relu6(r)}[epilogue]
+        if out is not None:
+            out.copy_(out + r if accumulate else r)
+            return out
+        return r
+
+    def nms(boxes_sorted, thresh):
+        keep = native.nms(_np(boxes_sorted), thresh)
+        k = torch.zeros(max(boxes_sorted.shape[0], 1), dtype=torch.int32)
+        k[:len(keep)] = torch.from_numpy(keep)
+        return k, torch.tensor([len(keep)], dtype=torch.int32)
+
+    def nms_batched(boxes_sorted, seg_offsets, max_seg, thresh):
+        offs = seg_offsets.tolist()
+        keep = torch.zeros(max(boxes_sorted.shape[0], 1), dtype=torch.int32)
+        num = torch.zeros(max(len(offs) - 1, 1), dtype=torch.int32)
+        for s in range(len(offs) - 1):
+            k = native.nms(_np(boxes_sorted[offs[s]:offs[s + 1]]), thresh)
+            keep[offs[s]:offs[s] + len(k)] = torch.from_numpy(k)
+            num[s] = len(k)
+        return keep, num
+
+    def roi_align_fwd(feat, rois, ph, pw, spatial_scale, nhwc):
+        f = feat.permute(0, 3, 1, 2) if nhwc else feat
+        return torch.from_numpy(native.roi_align_fwd(_np(f), _np(rois), ph, pw, spatial_scale))
+
+    def roi_align_bwd(grad_out, rois, B, C, H, W, spatial_scale, nhwc):
+        g = torch.from_numpy(native.roi_align_bwd(_np(grad_out), _np(rois), (B, C, H, W), spatial_scale))
+        return g.permute(0, 2, 3, 1).contiguous() if nhwc else g
+
+    def draw_union_boxes(box_pairs, P, offset=0.0, channels_last=False):
+        m = torch.from_numpy(native.draw_union_boxes(_np(box_pairs), P)) + np.float32(offset)
+        return m.permute(0, 2, 3, 1).contiguous() if channels_last else m
+
+    def bbox_overlaps(a, b):
+        from oracle import boxes as OB
+        return OB.bbox_overlaps(a, b)
+
+    def conv3x3_pack_weight(w, flip_transpose=False):
+        if flip_transpose:
+            return w.flip(2, 3).permute(2, 3, 0, 1).reshape(9, w.shape[0], w.shape[1]).contiguous()
+        return w.permute(2, 3, 1, 0).reshape(9, w.shape[1], w.shape[0]).contiguous()
+
+    def conv3x3_nhwc(x, wt, bias, epilogue):
+        cin, cout = wt.shape[1], wt.shape[2]
+        w = wt.view(3, 3, cin, cout).permute(3, 2, 0, 1)
+        y = F.conv2d(x.permute(0, 3, 1, 2), w, bias, padding=1)
+        y = {0: y, 1: F.relu(y), 2: F.relu6(y)}[epilogue]
+        return y.permute(0, 2, 3, 1).contiguous()
+
+    def conv_first_nchw(x, w, bias, epilogue):
+        y = F.conv2d(x, w, bias, padding=1)
+        y = {0: y, 1: F.relu(y), 2: F.relu6(y)}[epilogue]
+        return y.permute(0, 2, 3, 1).contiguous()
+
+    def maxpool2x2_nhwc(x):
+        return F.max_pool2d(x.permute(0, 3, 1, 2), 2, 2).permute(0, 2, 3, 1).contiguous()
+
+    def im2col_nhwc(x, kh, kw, stride, pad, ldo=None):
+        B, H, W, C = x.shape
+        Ho = (H + 2 * pad - kh) // stride + 1
+        Wo = (W + 2 * pad - kw) // stride + 1
+        cols = F.unfold(x.permute(0, 3, 1, 2), (kh, kw), padding=pad, stride=stride)      # [B, C*kh*kw, L]
+        cols = cols.view(B, C, kh * kw, Ho * Wo).permute(0, 3, 2, 1).reshape(B * Ho * Wo, kh * kw * C)
+        K = kh * kw * C
+        ldo = K if ldo is None else ldo
+        out = x.new_zeros(B * Ho * Wo, ldo)
+        out[:, :K] = cols
+        return out, Ho, Wo
+
+    def nchw_to_nhwc(x):
+        return x.permute(0, 2, 3, 1).contiguous()
+
+    def nhwc_to_nchw(x):
+        return x.permute(0, 3, 1, 2).contiguous()
+
+    def hwlstm_fwd(x, lengths, weight, bias, dropout, H, L_, training):
+        out, h_slots, c_slots, gates = OL.highway_lstm_forward(x, lengths, weight, bias, dropout, H, L_, True,
+                                                               return_state=True)
+        T, B = x.shape[0], x.shape[1]
+        h_data = torch.stack([torch.stack(h_slots[l]) for l in range(L_)]).detach()
+        c_data = torch.stack([torch.stack(c_slots[l]) for l in range(L_)]).detach()
+        if not training:
+            return h_data, c_data, None
+        token = torch.zeros(1)                      # a tensor autograd can save; the python-side gates ride along
+        _GATES[token.data_ptr()] = (token, gates)
+        return h_data, c_data, token
+
+    def hwlstm_bwd(out_grad, x, lengths, weight, dropout, H, L_, h_data, c_data, gates, need_weight_grad=True):
+        h_slots = [[h_data[l, t] for t in range(h_data.shape[1])] for l in range(L_)]
+        c_slots = [[c_data[l, t] for t in range(c_data.shape[1])] for l in range(L_)]
+        gates = _GATES.pop(gates.data_ptr())[1]
+        xg, wg, bg = OL.highway_lstm_backward(out_grad, x, lengths, weight, dropout, H, L_, h_slots, c_slots, gates)
+        return xg, (wg if need_weight_grad else None), (bg if need_weight_grad else None)
+
+    def hwlstm_cell_fwd(pre_i, h_prev, c_prev, wh_t, bias_h, dropout, want_gates):
+        H = h_prev.shape[1]
+        ps = h_prev @ wh_t.t() + (bias_h if bias_h is not None else 0)
+        g = pre_i[:, :5 * H] + ps
+        ig, fg = torch.sigmoid(g[:, :H]), torch.sigmoid(g[:, H:2 * H])
+        ag, og, rg = torch.tanh(g[:, 2 * H:3 * H]), torch.sigmoid(g[:, 3 * H:4 * H]), torch.sigmoid(g[:, 4 * H:5 * H])
+        lin = pre_i[:, 5 * H:]
+        c = fg * c_prev + ig * ag
+        h = rg * (og * torch.tanh(c)) + (1 - rg) * lin
+        if dropout is not None:
+            h = h * dropout
+        return h, c, (torch.cat((ig, fg, ag, og, rg, lin), 1) if want_gates else None)
+
+    def hwlstm_cell_bwd(d_h, d_c_out, c_prev, c_out, gates, dropout):
+        H = d_h.shape[1]
+        ig, fg, ag, og, rg, lin = [gates[:, k * H:(k + 1) * H] for k in range(6)]
+        dh = d_h * dropout if dropout is not None else d_h
+        tc = torch.tanh(c_out)
+        d_o = dh * rg
+        d_c = d_o * og * (1 - tc * tc) + (d_c_out if d_c_out is not None else 0)
+        dg = torch.cat((d_c * ag * ig * (1 - ig), d_c * c_prev * fg * (1 - fg), d_c * ig * (1 - ag * ag),
+                        d_o * tc * og * (1 - og), dh * (og * tc - lin) * rg * (1 - rg), dh * (1 - rg)), 1)
+        return dg, fg * d_c
+
+    def gemv_rows(v, wt, bias=None):
+        r = v @ wt.t()
+        return r + bias if bias is not None else r
+
+    for name, fn in list(locals().items()):
+        if callable(fn) and hasattr(_hip, name) and name not in ('install',):
+            setattr(_hip, name, fn)
+    _hip.lib = lambda: None
+    blob_mod.Blob._to_device = lambda self, x: x
+    return _hip

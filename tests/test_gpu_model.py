@@ -1,0 +1,128 @@
+"""
+End-to-end parity of the HIP path (lib.rel_model.RelModel on the GPU) against the CPU oracle (oracle/model.py) on
+identical seeded inputs, weights, relation samples and dropout masks.
+
+Tolerances (BASELINE.json north_star): integer outputs (predicted labels, relation indices, box indices) exact;
+fp32 logits within 1e-4 -- applied relative to the tensor's largest magnitude, because the reference's own
+initialisation (post_lstm ~ N(0, 10/sqrt(H)), lib/rel_model.py:377-384) makes untrained relation logits O(1e2).
+"""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+CFG = dict(mode='sgcls', hidden_dim=512, pooling_dim=4096, nl_obj=2, nl_edge=2, order='leftright', rec_dropout=0.1,
+           use_bias=True, use_tanh=False, limit_vision=False, pass_in_obj_feats_to_decoder=False,
+           pass_in_obj_feats_to_edge=False)
+
+
+def rel_close(got, ref, rtol=1e-4, what=''):
+    got, ref = np.asarray(got, dtype=np.float64), np.asarray(ref, dtype=np.float64)
+    scale = max(1.0, float(np.abs(ref).max()))
+    err = float(np.abs(got - ref).max())
+    print('%-28s max|ref|=%10.4f  max abs err=%.3e  (%.2e of scale)' % (what, scale, err, err / scale))
+    assert err <= rtol * scale, '%s: max abs err %.3e > %.1e * %.3f' % (what, err, rtol, scale)
+
+
+@pytest.fixture(scope='module')
+def world():
+    if not torch.cuda.is_available():
+        pytest.fail('needs a HIP device')
+    from dataloaders.synthetic import SyntheticVG, make_blob
+    from lib.rel_model import RelModel
+    torch.manual_seed(0)
+    ds = SyntheticVG(num_images=4, seed=11, n_boxes=8, n_rels=10)
+    model = RelModel(classes=ds.ind_to_classes, rel_classes=ds.ind_to_predicates, mode='sgcls', num_gpus=1,
+                     hidden_dim=512, pooling_dim=4096, nl_obj=2, nl_edge=2, order='leftright', rec_dropout=0.1,
+                     use_bias=True, pass_in_obj_feats_to_decoder=False, pass_in_obj_feats_to_edge=False,
+                     use_tanh=False, limit_vision=False)
+    for n, p in model.detector.named_parameters():
+        p.requires_grad = False
+    sd_cpu = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    model.cuda()
+    return ds, model, sd_cpu, make_blob
+
+
+def test_sgcls_train_step_parity(world):
+    from lib import rng
+    from oracle import model as OM
+    ds, model, sd_cpu, make_blob = world
+    sd = {k: v.clone() for k, v in sd_cpu.items()}
+    model.train()
+    blob = make_blob(ds, [0, 1], is_train=True)
+    cpu_args = blob[0]
+    model.sampler_rs = np.random.RandomState(5)
+    rng.use_host_rng(2024)
+    res = model[blob]
+    rng.use_host_rng(None)
+    loss = F.cross_entropy(res.rm_obj_dists, res.rm_obj_labels) + F.cross_entropy(res.rel_dists, res.rel_labels[:, -1])
+    loss.backward()
+
+    trainable = {n for n, p in model.named_parameters() if p.requires_grad}
+    params = {k: v.clone().requires_grad_(k in trainable) for k, v in sd.items()}
+    out = OM.relmodel_forward(params, CFG, cpu_args[0], cpu_args[1], 0, cpu_args[3], cpu_args[4], True,
+                              OM.HostRNG(2024), rel_labels=res.rel_labels.cpu())
+    np.testing.assert_array_equal(res.obj_preds.cpu().numpy(), out['obj_preds'].numpy())
+    rel_close(res.fmap.float().cpu().numpy(), out['fmap'].numpy(), what='trunk feature map')
+    rel_close(res.od_obj_dists.detach().cpu().numpy(), out['od_obj_dists'].numpy(), what='detector logits')
+    rel_close(res.rm_obj_dists.detach().cpu().numpy(), out['rm_obj_dists'].detach().numpy(), what='object logits')
+    rel_close(res.rel_dists.detach().cpu().numpy(), out['rel_dists'].detach().numpy(), what='relation logits')
+    loss_ref = F.cross_entropy(out['rm_obj_dists'], out['rm_obj_labels']) + \
+        F.cross_entropy(out['rel_dists'], out['rel_labels'][:, -1])
+    rel_close(loss.item(), loss_ref.item(), what='loss')
+    loss_ref.backward()
+    checked = 0
+    for name, p in model.named_parameters():
+        if not p.requires_grad:
+            assert p.grad is None
+            continue
+        ref = params[name].grad
+        assert ref is not None and p.grad is not None, name
+        rel_close(p.grad.cpu().numpy(), ref.numpy(), rtol=2e-3, what='grad ' + name[-24:])
+        checked += 1
+    assert checked >= 30
+    for k in ('context.pos_embed.0.running_mean', 'context.pos_embed.0.running_var',
+              'union_boxes.conv.2.running_mean', 'union_boxes.conv.6.running_var'):
+        rel_close(model.state_dict()[k].cpu().numpy(), params[k].detach().numpy(), what=k[-30:])
+
+
+@pytest.mark.parametrize('mode', ['predcls', 'sgcls'])
+def test_eval_tuple_parity_and_recall(world, mode):
+    from config import BOX_SCALE, IM_SCALE
+    from lib.evaluation.sg_eval import BasicSceneGraphEvaluator
+    from oracle import model as OM
+    ds, model, sd_cpu, make_blob = world
+    model.load_state_dict(sd_cpu)
+    model.eval()
+    model.mode = model.context.mode = mode
+    cfg = dict(CFG, mode=mode)
+    recalls = {}
+    for idx in (2, 3):
+        blob = make_blob(ds, [idx], is_train=False)
+        a = blob[0]
+        with torch.no_grad():
+            got = model[blob]
+            ref = OM.relmodel_forward({k: v.clone() for k, v in sd_cpu.items()}, cfg, a[0], a[1], 0, a[3], a[4],
+                                      False, OM.HostRNG(0))
+        np.testing.assert_array_equal(got[0], ref[0])                      # boxes
+        np.testing.assert_array_equal(got[1], ref[1])                      # classes
+        rel_close(got[2], ref[2], what=mode + ' obj scores')
+        # relation rows may swap among near-equal triple scores; compare after aligning on the (subj, obj) pair
+        def by_pair(rels, scores):
+            order = np.lexsort((rels[:, 1], rels[:, 0]))
+            return rels[order], scores[order]
+        r1, s1 = by_pair(got[3], got[4])
+        r2, s2 = by_pair(ref[3], ref[4])
+        np.testing.assert_array_equal(r1, r2)
+        rel_close(s1, s2, what=mode + ' predicate probs')
+        for tag, tup in (('hip', got), ('oracle', ref)):
+            ev = BasicSceneGraphEvaluator.all_modes()
+            ev[mode].evaluate_scene_graph_entry(
+                dict(gt_classes=ds.gt_classes[idx], gt_relations=ds.relationships[idx], gt_boxes=ds.gt_boxes[idx]),
+                dict(pred_boxes=tup[0] * BOX_SCALE / IM_SCALE, pred_classes=tup[1], pred_rel_inds=tup[3],
+                     obj_scores=tup[2], rel_scores=tup[4]))
+            recalls[(tag, idx)] = [ev[mode].result_dict[mode + '_recall'][k][0] for k in (20, 50, 100)]
+        assert np.allclose(recalls[('hip', idx)], recalls[('oracle', idx)], atol=0.1 + 1e-9)   # Recall@K within 0.1
+    model.mode = model.context.mode = 'sgcls'

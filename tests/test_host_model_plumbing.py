@@ -1,0 +1,122 @@
+"""Host-logic test of the product model on CPU through tests/cpu_shim.py (kernels replaced by oracle-backed
+stand-ins): module wiring, state-dict key contract, packed-sequence index arithmetic, sampler, autograd plumbing,
+and agreement of the whole forward with oracle/model.py.  Kernel numerics are covered by the -m gpu tests."""
+import numpy as np
+import pytest
+import torch
+
+
+@pytest.fixture(scope='module')
+def shim():
+    import cpu_shim
+    return cpu_shim.install()
+
+
+@pytest.fixture(scope='module')
+def small_world(shim):
+    from dataloaders.synthetic import SyntheticVG, make_blob
+    from lib.rel_model import RelModel
+    torch.manual_seed(0)
+    ds = SyntheticVG(num_images=4, seed=3, n_boxes=5, n_rels=6, im_size=224)
+    model = RelModel(classes=ds.ind_to_classes, rel_classes=ds.ind_to_predicates, mode='sgcls', num_gpus=1,
+                     hidden_dim=32, pooling_dim=4096, nl_obj=2, nl_edge=2, order='leftright', rec_dropout=0.1,
+                     use_bias=True, pass_in_obj_feats_to_decoder=False, pass_in_obj_feats_to_edge=False,
+                     use_tanh=False, limit_vision=False)
+    for n, p in model.detector.named_parameters():
+        p.requires_grad = False
+    return ds, model, make_blob
+
+
+CFG = dict(mode='sgcls', hidden_dim=32, pooling_dim=4096, nl_obj=2, nl_edge=2, order='leftright', rec_dropout=0.1,
+           use_bias=True, use_tanh=False, limit_vision=False, pass_in_obj_feats_to_decoder=False,
+           pass_in_obj_feats_to_edge=False)
+
+
+def test_state_dict_keys_follow_the_reference(small_world):
+    _, model, _ = small_world
+    keys = set(model.state_dict().keys())
+    expected = ['detector.features.%d.%s' % (i, s) for i in (0, 2, 5, 7, 10, 12, 14, 17, 19, 21, 24, 26, 28)
+                for s in ('weight', 'bias')]
+    expected += ['detector.roi_fmap.0.weight', 'detector.roi_fmap.3.bias', 'detector.score_fc.weight',
+                 'detector.bbox_fc.bias', 'detector.rpn_head.conv.0.weight', 'detector.rpn_head.conv.2.bias',
+                 'detector.rpn_head.anchors', 'context.obj_embed.weight', 'context.obj_embed2.weight',
+                 'context.pos_embed.0.running_mean', 'context.pos_embed.1.weight', 'context.obj_ctx_rnn.weight',
+                 'context.obj_ctx_rnn.bias', 'context.edge_ctx_rnn.weight', 'context.decoder_rnn.obj_embed.weight',
+                 'context.decoder_rnn.input_linearity.weight', 'context.decoder_rnn.state_linearity.bias',
+                 'context.decoder_rnn.out.weight', 'union_boxes.conv.0.weight', 'union_boxes.conv.2.running_var',
+                 'union_boxes.conv.4.bias', 'union_boxes.conv.6.weight', 'roi_fmap.1.0.weight', 'roi_fmap.1.3.bias',
+                 'roi_fmap_obj.0.weight', 'roi_fmap_obj.3.weight', 'post_lstm.weight', 'rel_compress.bias',
+                 'freq_bias.obj_baseline.weight']
+    missing = [k for k in expected if k not in keys]
+    assert not missing, missing
+    sd = model.state_dict()
+    assert tuple(sd['detector.rpn_head.anchors'].shape) == (37, 37, 20, 4)
+    assert tuple(sd['context.decoder_rnn.obj_embed.weight'].shape) == (152, 100)
+    assert tuple(sd['freq_bias.obj_baseline.weight'].shape) == (151 * 151, 51)
+    assert sd['context.obj_ctx_rnn.weight'].dim() == 1
+    assert tuple(sd['detector.rpn_head.conv.2.weight'].shape) == (120, 512, 1, 1)
+    # the handles models/train_rels.py indexes (train_rels.py:87-95)
+    assert model.roi_fmap[1][0].weight.shape == (4096, 25088) and model.roi_fmap[1][3].weight.shape == (4096, 4096)
+    assert model.roi_fmap_obj[0].weight.shape == (4096, 25088) and model.roi_fmap_obj[3].weight.shape == (4096, 4096)
+    assert [n for n, _ in model.named_parameters() if n.startswith('roi_fmap')]
+
+
+def _to_oracle_sd(model):
+    return {k: v.detach().clone() for k, v in model.state_dict().items()}
+
+
+def test_train_forward_backward_matches_oracle_model(small_world):
+    from lib import rng
+    from oracle import model as OM
+    ds, model, make_blob = small_world
+    model.train()
+    blob = make_blob(ds, [0, 1], is_train=True)
+    sd = _to_oracle_sd(model)
+    model.sampler_rs = np.random.RandomState(5)
+    rng.use_host_rng(77)
+    res = model[blob]
+    rng.use_host_rng(None)
+    assert res.rel_labels.shape[1] == 4 and res.rel_dists.shape == (res.rel_labels.shape[0], 51)
+    # rel_labels: sorted by (im, subj, obj), bg rows have predicate 0, fg rows come from the GT
+    rl = res.rel_labels.numpy()
+    key = rl[:, 0] * 100 + rl[:, 1] * 10 + rl[:, 2]
+    assert np.all(np.diff(key) > 0)
+    args = blob[0]
+    out = OM.relmodel_forward(sd, CFG, args[0], args[1], 0, args[3], args[4], True, OM.HostRNG(77),
+                              rel_labels=res.rel_labels)
+    np.testing.assert_allclose(res.rm_obj_dists.detach().numpy(), out['rm_obj_dists'].detach().numpy(), atol=2e-4)
+    np.testing.assert_allclose(res.rel_dists.detach().numpy(), out['rel_dists'].detach().numpy(), atol=2e-3)
+    np.testing.assert_array_equal(res.obj_preds.numpy(), out['obj_preds'].numpy())
+    # BN running statistics were updated identically
+    for k in ('context.pos_embed.0.running_mean', 'union_boxes.conv.2.running_var', 'union_boxes.conv.6.running_mean'):
+        np.testing.assert_allclose(model.state_dict()[k].numpy(), sd[k].numpy(), atol=1e-5)
+    loss = torch.nn.functional.cross_entropy(res.rm_obj_dists, res.rm_obj_labels) + \
+        torch.nn.functional.cross_entropy(res.rel_dists, res.rel_labels[:, -1])
+    loss.backward()
+    grads = {n: p.grad for n, p in model.named_parameters() if p.requires_grad}
+    assert all(g is not None and torch.isfinite(g).all() for g in grads.values()), \
+        [n for n, g in grads.items() if g is None]
+    assert all(p.grad is None for p in model.detector.parameters())
+
+
+def test_eval_tuple_and_recall_pipeline(small_world):
+    from lib.evaluation.sg_eval import BasicSceneGraphEvaluator
+    from config import BOX_SCALE
+    ds, model, make_blob = small_world
+    model.eval()
+    for mode in ('predcls', 'sgcls'):
+        model.mode = model.context.mode = mode
+        ev = BasicSceneGraphEvaluator.all_modes()
+        with torch.no_grad():
+            boxes, objs, obj_scores, rels, pred_scores = model[make_blob(ds, [2], is_train=False)]
+        n = ds.gt_classes[2].shape[0]
+        assert boxes.shape == (n, 4) and rels.shape == (n * (n - 1), 2) and pred_scores.shape == (n * (n - 1), 51)
+        if mode == 'predcls':
+            np.testing.assert_array_equal(objs, ds.gt_classes[2])
+        ev[mode].evaluate_scene_graph_entry(
+            dict(gt_classes=ds.gt_classes[2], gt_relations=ds.relationships[2], gt_boxes=ds.gt_boxes[2]),
+            dict(pred_boxes=boxes * BOX_SCALE / 224, pred_classes=objs, pred_rel_inds=rels, obj_scores=obj_scores,
+                 rel_scores=pred_scores))
+        r = ev[mode].result_dict[mode + '_recall']
+        assert 0.0 <= r[20][0] <= r[50][0] <= r[100][0] <= 1.0
+    model.mode = model.context.mode = 'sgcls'
