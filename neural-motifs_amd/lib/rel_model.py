@@ -334,6 +334,7 @@ class RelModel(nn.Module):
         else:
             bboxes = result.rm_box_priors
         rel_rep = F.softmax(result.rel_dists, dim=1)
+        self.last_eval_result = result            # raw logits of the last eval forward (tests / debugging)
         return filter_dets(bboxes, result.obj_scores, result.obj_preds, rel_inds[:, 1:], rel_rep)
 
     def __getitem__(self, batch):

@@ -356,4 +356,7 @@ def relmodel_forward(sd, cfg, x, im_sizes, image_offset, gt_boxes, gt_classes, t
     else:
         bboxes = det['rm_box_priors']
     rel_rep = F.softmax(rel_dists, dim=1)
-    return filter_dets(bboxes, obj_scores, obj_preds, rel_inds[:, 1:], rel_rep)
+    out = filter_dets(bboxes, obj_scores, obj_preds, rel_inds[:, 1:], rel_rep)
+    if cfg.get('return_logits', False):
+        return out, dict(rel_dists=rel_dists, rm_obj_dists=rm_obj_dists, rel_inds=rel_inds)
+    return out
