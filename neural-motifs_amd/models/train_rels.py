@@ -1,0 +1,173 @@
+"""
+Relation-model training driver -- the flow of the reference's models/train_rels.py (build RelModel, freeze the
+detector, SGD with 1/10 learning rate on the fc layers, loss = CE(objects) + CE(relations), global grad-clip,
+per-epoch checkpoint + Recall@K validation, LR-on-plateau) on the MI355X implementation.
+
+    python models/train_rels.py -m sgcls -model motifnet -order leftright -nl_obj 2 -nl_edge 2 -b 6 -clip 5 \
+        -hidden_dim 512 -pooling_dim 4096 -lr 1e-3 -ngpu 1 -use_bias -nepoch 1 -max_iters 20
+    torchrun --nproc-per-node 8 models/train_rels.py ... -ngpu 8        # one process per GPU, RCCL all-reduce
+"""
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+import numpy as np
+import pandas as pd
+import torch
+from torch import optim
+from torch.nn import functional as F
+from torch.optim.lr_scheduler import ReduceLROnPlateau
+
+from config import ModelConfig, BOX_SCALE, IM_SCALE
+from dataloaders.visual_genome import VGDataLoader, VG
+from lib import dist as D
+from lib.evaluation.sg_eval import BasicSceneGraphEvaluator
+from lib.pytorch_misc import optimistic_restore, clip_grad_norm, print_para
+
+conf = ModelConfig()
+if conf.model != 'motifnet':
+    raise ValueError('only the MotifNet model family is built (rel_model_stanford is out of scope)')
+from lib.rel_model import RelModel
+
+rank, world, local_rank = D.init_from_env()
+if world > 1 and conf.num_gpus != world:
+    raise ValueError('-ngpu {} but WORLD_SIZE={}'.format(conf.num_gpus, world))
+torch.cuda.set_device(local_rank)
+np.random.seed(conf.seed + rank)
+torch.manual_seed(conf.seed)
+
+train, val, _ = VG.splits(num_val_im=conf.val_size, filter_duplicate_rels=True, use_proposals=conf.use_proposals,
+                          filter_non_overlap=conf.mode == 'sgdet', seed=conf.seed)
+train_loader, val_loader = VGDataLoader.splits(train, val, mode='rel', batch_size=conf.batch_size,
+                                               num_workers=conf.num_workers, num_gpus=1, rank=rank, world_size=world)
+
+detector = RelModel(classes=train.ind_to_classes, rel_classes=train.ind_to_predicates, num_gpus=1, mode=conf.mode,
+                    require_overlap_det=True, use_resnet=conf.use_resnet, order=conf.order, nl_edge=conf.nl_edge,
+                    nl_obj=conf.nl_obj, hidden_dim=conf.hidden_dim, use_proposals=conf.use_proposals,
+                    pass_in_obj_feats_to_decoder=conf.pass_in_obj_feats_to_decoder,
+                    pass_in_obj_feats_to_edge=conf.pass_in_obj_feats_to_edge, pooling_dim=conf.pooling_dim,
+                    rec_dropout=conf.rec_dropout, use_bias=conf.use_bias, use_tanh=conf.use_tanh,
+                    limit_vision=conf.limit_vision)
+
+for n, param in detector.detector.named_parameters():      # freeze the detector
+    param.requires_grad = False
+if rank == 0:
+    print(print_para(detector), flush=True)
+
+
+def get_optim(lr):
+    fc_params = [p for n, p in detector.named_parameters() if n.startswith('roi_fmap') and p.requires_grad]
+    non_fc_params = [p for n, p in detector.named_parameters() if not n.startswith('roi_fmap') and p.requires_grad]
+    params = [{'params': fc_params, 'lr': lr / 10.0}, {'params': non_fc_params}]
+    if conf.adam:
+        optimizer = optim.Adam(params, weight_decay=conf.l2, lr=lr, eps=1e-3)
+    else:
+        optimizer = optim.SGD(params, weight_decay=conf.l2, lr=lr, momentum=0.9)
+    scheduler = ReduceLROnPlateau(optimizer, 'max', patience=3, factor=0.1, threshold=0.0001, threshold_mode='abs',
+                                  cooldown=1)
+    return optimizer, scheduler
+
+
+start_epoch = -1
+if conf.ckpt is not None:
+    ckpt = torch.load(conf.ckpt, map_location='cpu')
+    if conf.ckpt.split('-')[-2].split('/')[-1] == 'vgrel':
+        print("Loading EVERYTHING")
+        start_epoch = ckpt['epoch']
+        if not optimistic_restore(detector, ckpt['state_dict']):
+            start_epoch = -1
+    else:                                                     # a detector checkpoint: seed the three fc6/fc7 copies
+        optimistic_restore(detector.detector, ckpt['state_dict'])
+        for dst in (detector.roi_fmap[1], detector.roi_fmap_obj):
+            for idx in (0, 3):
+                dst[idx].weight.data.copy_(ckpt['state_dict']['roi_fmap.%d.weight' % idx])
+                dst[idx].bias.data.copy_(ckpt['state_dict']['roi_fmap.%d.bias' % idx])
+
+detector.cuda()
+buckets = D.GradBuckets([p for p in detector.parameters() if p.requires_grad])
+
+
+def train_batch(b, verbose=False):
+    result = detector[b]
+    l_obj = F.cross_entropy(result.rm_obj_dists, result.rm_obj_labels)
+    l_rel = F.cross_entropy(result.rel_dists, result.rel_labels[:, -1])
+    if world > 1:      # global-mean loss semantics of the single-process reference
+        w = D.global_row_weights([result.rm_obj_labels.shape[0], result.rel_labels.shape[0]], l_obj.device)
+        loss = l_obj * w[0] + l_rel * w[1]
+    else:
+        loss = l_obj + l_rel
+    optimizer.zero_grad(set_to_none=True)
+    loss.backward()
+    buckets.all_reduce()
+    clip_grad_norm([(n, p) for n, p in detector.named_parameters() if p.grad is not None], max_norm=conf.clip,
+                   verbose=verbose and rank == 0, clip=True)
+    optimizer.step()
+    return pd.Series({'class_loss': l_obj.item(), 'rel_loss': l_rel.item(), 'total': (l_obj + l_rel).item()})
+
+
+def train_epoch(epoch_num):
+    detector.train()
+    tr, start = [], time.time()
+    for b, batch in enumerate(train_loader):
+        if conf.max_iters and b >= conf.max_iters:
+            break
+        tr.append(train_batch(batch, verbose=b % (conf.print_interval * 10) == 0))
+        if b % conf.print_interval == 0 and b >= conf.print_interval and rank == 0:
+            mn = pd.concat(tr[-conf.print_interval:], axis=1).mean(1)
+            tpb = (time.time() - start) / conf.print_interval
+            print("\ne{:2d}b{:5d}/{:5d} {:.3f}s/batch, {:.1f}m/epoch".format(epoch_num, b, len(train_loader), tpb,
+                                                                             len(train_loader) * tpb / 60))
+            print(mn)
+            print('-----------', flush=True)
+            start = time.time()
+    return pd.concat(tr, axis=1)
+
+
+def val_batch(batch_num, b, evaluator):
+    det_res = [detector[b]]
+    for i, (boxes_i, objs_i, obj_scores_i, rels_i, pred_scores_i) in enumerate(det_res):
+        gt_entry = {'gt_classes': val.gt_classes[batch_num + i].copy(),
+                    'gt_relations': val.relationships[batch_num + i].copy(),
+                    'gt_boxes': val.gt_boxes[batch_num + i].copy()}
+        assert np.all(objs_i[rels_i[:, 0]] > 0) and np.all(objs_i[rels_i[:, 1]] > 0)
+        pred_entry = {'pred_boxes': boxes_i * BOX_SCALE / IM_SCALE, 'pred_classes': objs_i, 'pred_rel_inds': rels_i,
+                      'obj_scores': obj_scores_i, 'rel_scores': pred_scores_i}
+        evaluator[conf.mode].evaluate_scene_graph_entry(gt_entry, pred_entry)
+
+
+def val_epoch():
+    detector.eval()
+    evaluator = BasicSceneGraphEvaluator.all_modes()
+    with torch.no_grad():
+        for val_b, batch in enumerate(val_loader):
+            val_batch((val_b * world + rank), batch, evaluator)
+    recalls = evaluator[conf.mode].result_dict[conf.mode + '_recall']
+    if world > 1:                                            # every rank evaluated its own images: merge the lists
+        gathered = [None] * world
+        torch.distributed.all_gather_object(gathered, recalls)
+        for k in recalls:
+            recalls[k] = [x for g in gathered for x in g[k]]
+    if rank == 0:
+        evaluator[conf.mode].print_stats()
+    return float(np.mean(recalls[100])) if len(recalls[100]) else 0.0
+
+
+if rank == 0:
+    print("Training starts now!")
+optimizer, scheduler = get_optim(conf.lr * world * conf.batch_size)
+for epoch in range(start_epoch + 1, start_epoch + 1 + conf.num_epochs):
+    rez = train_epoch(epoch)
+    if rank == 0:
+        print("overall{:2d}: ({:.3f})\n{}".format(epoch, rez.mean(1)['total'], rez.mean(1)), flush=True)
+        if conf.save_dir is not None:
+            torch.save({'epoch': epoch, 'state_dict': detector.state_dict()},
+                       os.path.join(conf.save_dir, '{}-{}.tar'.format('vgrel', epoch)))
+    mAp = val_epoch()
+    scheduler.step(mAp)
+    if any(pg['lr'] <= (conf.lr * world * conf.batch_size) / 99.0 for pg in optimizer.param_groups):
+        print("exiting training early", flush=True)
+        break
+if world > 1:
+    torch.distributed.destroy_process_group()
