@@ -39,6 +39,8 @@ def build(force=False, verbose=False):
                    '-Wall', '-Wno-unused-function']
             if src in EXACT:
                 cmd += ['-ffp-contract=off']
+            if os.environ.get('MH_BK'):
+                cmd += ['-DMH_BK=' + os.environ['MH_BK']]
             if verbose:
                 cmd += ['-Rpass-analysis=kernel-resource-usage']
                 print(' '.join(cmd))

@@ -20,14 +20,17 @@
 
 namespace mh {
 
-constexpr int kBK = 16;
+#ifndef MH_BK
+#define MH_BK 16
+#endif
+constexpr int kBK = MH_BK;
 constexpr int kThreads = 256;
 
 template <int WD>
 struct TileGeom {
     static constexpr int ld = WD + 4;             // padded LDS row (floats); keeps 16-B alignment
     static constexpr int floats = kBK * ld;       // one operand tile
-    static constexpr int nv = WD / 64;            // float4 staged per thread
+    static constexpr int nv = WD * kBK / 1024;    // float4 staged per thread (256 threads)
 };
 
 struct Acc {

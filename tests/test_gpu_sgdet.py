@@ -1,0 +1,103 @@
+"""
+SGDet-only stages on the GPU: RPN head, proposal decode + per-image NMS,
+class-specific decode + batched per-class NMS (`filter_det`), and the end-to-end SGDet eval forward.
+
+Index outputs are compared EXACTLY, stage by stage, on identical inputs (the upstream fp32 tensors are produced once
+on the GPU and handed to the CPU oracle): chaining stages across devices would let 1-ulp differences of exp()/conv
+summation order re-rank near-tied scores, which says nothing about the kernels.
+"""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def det():
+    if not torch.cuda.is_available():
+        pytest.fail('needs a HIP device')
+    from dataloaders.synthetic import SyntheticVG, make_blob
+    from lib.rel_model import RelModel
+    torch.manual_seed(3)
+    ds = SyntheticVG(num_images=3, seed=21, n_boxes=10, n_rels=12)
+    model = RelModel(classes=ds.ind_to_classes, rel_classes=ds.ind_to_predicates, mode='sgdet', num_gpus=1,
+                     hidden_dim=256, pooling_dim=4096, nl_obj=2, nl_edge=2, order='confidence', rec_dropout=0.1,
+                     use_bias=True, pass_in_obj_feats_to_decoder=False, pass_in_obj_feats_to_edge=False,
+                     use_tanh=False, limit_vision=False)
+    with torch.no_grad():          # make the random detector confident enough to produce detections
+        model.detector.score_fc.weight.mul_(30.0)
+        model.detector.rpn_head.conv[2].weight.mul_(4.0)
+    sd_cpu = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    model.cuda().eval()
+    return ds, model, sd_cpu, make_blob
+
+
+def test_rpn_head_matches_oracle(det):
+    from oracle import model as OM
+    ds, model, sd, make_blob = det
+    blob = make_blob(ds, [0, 1], is_train=False)
+    with torch.no_grad():
+        fmap = model.detector.feature_map(blob[0][0].cuda())
+        feats = model.detector.rpn_head(fmap)
+        ref = OM.rpn_head(sd, fmap.float().cpu().contiguous())
+    assert tuple(feats.shape) == (2, 37, 37, 20, 6)
+    np.testing.assert_allclose(feats.cpu().numpy(), ref.numpy(), atol=1e-4 * max(1.0, float(ref.abs().max())))
+
+
+def test_proposal_nms_indices_exact(det):
+    from lib.object_detector import filter_roi_proposals
+    from oracle import boxes as OB
+    rs = np.random.RandomState(0)
+    per_im = 37 * 37 * 20
+    x1y1 = rs.uniform(0, 560, (2 * per_im, 2))
+    wh = rs.uniform(1, 300, (2 * per_im, 2))
+    boxes = torch.from_numpy(np.concatenate((x1y1, np.minimum(x1y1 + wh, 591)), 1).astype(np.float32))
+    scores = torch.from_numpy(rs.rand(2 * per_im).astype(np.float32))
+    scores[rs.rand(2 * per_im) < 0.3] = -0.01                    # the reference's "invalid" score: thousands of ties
+    rois = filter_roi_proposals(boxes.cuda(), scores.cuda(), np.array([per_im, per_im]), nms_thresh=0.7,
+                                pre_nms_topn=6000, post_nms_topn=1000)
+    inds, im_per = OB.apply_nms(scores, boxes, pre_nms_topn=6000, post_nms_topn=1000, boxes_per_im=[per_im, per_im],
+                                nms_thresh=0.7)
+    ref = torch.cat((torch.cat([torch.full((n,), float(i)) for i, n in enumerate(im_per)])[:, None], boxes[inds]), 1)
+    np.testing.assert_array_equal(rois.cpu().numpy(), ref.numpy())
+
+
+@pytest.mark.parametrize('dup', [True, False])
+def test_filter_det_indices_exact(det, dup):
+    from lib.object_detector import filter_det
+    from oracle import boxes as OB
+    rs = np.random.RandomState(4)
+    n, C = 700, 151
+    scores = torch.softmax(torch.from_numpy((rs.randn(n, C) * 3).astype(np.float32)), 1)
+    x1y1 = rs.uniform(0, 500, (n, C, 2))
+    boxes = torch.from_numpy(np.concatenate((x1y1, x1y1 + rs.uniform(4, 200, (n, C, 2))), 2).astype(np.float32))
+    got = filter_det(scores.cuda(), boxes.cuda(), start_ind=5, max_per_img=64, thresh=0.01, nms_filter_duplicates=dup)
+    ref = OB.filter_det(scores, boxes, start_ind=5, max_per_img=64, thresh=0.01, nms_filter_duplicates=dup)
+    for g, r in zip(got, ref):
+        np.testing.assert_array_equal(g.cpu().numpy(), r.numpy())
+
+
+def test_sgdet_eval_end_to_end(det):
+    from oracle import model as OM
+    ds, model, sd, make_blob = det
+    cfg = dict(mode='sgdet', hidden_dim=256, pooling_dim=4096, nl_obj=2, nl_edge=2, order='confidence',
+               rec_dropout=0.1, use_bias=True, use_tanh=False, limit_vision=False, pass_in_obj_feats_to_decoder=False,
+               pass_in_obj_feats_to_edge=False, thresh=0.01, max_per_img=64)
+    blob = make_blob(ds, [2], is_train=False)
+    a = blob[0]
+    with torch.no_grad():
+        got = model[blob]
+        ref = OM.relmodel_forward({k: v.clone() for k, v in sd.items()}, cfg, a[0], a[1], 0, a[3], a[4], False,
+                                  OM.HostRNG(0))
+    boxes, objs, obj_scores, rels, pred_scores = got
+    assert boxes.shape[1] == 4 and 1 <= boxes.shape[0] <= 64
+    assert rels.shape[1] == 2 and pred_scores.shape == (rels.shape[0], 51)
+    assert np.all(objs > 0) and np.all(rels[:, 0] != rels[:, 1])
+    assert np.all(boxes[:, 0] <= boxes[:, 2]) and np.all(boxes >= 0) and np.all(boxes <= 591)
+    # cross-device agreement (not required to be exact, see module docstring): most detections coincide
+    rb = ref[0]
+    same = sum(1 for b in boxes if np.any(np.all(np.abs(rb - b[None]) < 1e-2, 1)))
+    print('sgdet e2e: %d detections (oracle %d), %d coincide' % (boxes.shape[0], rb.shape[0], same))
+    assert same >= 0.8 * min(boxes.shape[0], rb.shape[0])
