@@ -39,8 +39,9 @@ def build(force=False, verbose=False):
                    '-Wall', '-Wno-unused-function']
             if src in EXACT:
                 cmd += ['-ffp-contract=off']
-            if os.environ.get('MH_BK'):
-                cmd += ['-DMH_BK=' + os.environ['MH_BK']]
+            for knob in ('MH_BK', 'MH_LDS_PIPE', 'MH_MINW'):
+                if os.environ.get(knob):
+                    cmd += ['-D%s=%s' % (knob, os.environ[knob])]
             if verbose:
                 cmd += ['-Rpass-analysis=kernel-resource-usage']
                 print(' '.join(cmd))

@@ -31,7 +31,7 @@ __device__ __forceinline__ float conv_epi(float v, int epilogue)
 }
 
 template <int BM, int BN>
-__global__ __launch_bounds__(kThreads, 2) void conv3x3_nhwc_kernel(const ConvArgs p)
+__global__ __launch_bounds__(kThreads, MH_MINW) void conv3x3_nhwc_kernel(const ConvArgs p)
 {
     constexpr int LDA = TileGeom<BM>::ld, LDB = TileGeom<BN>::ld;
     constexpr int FA = TileGeom<BM>::floats, FB = TileGeom<BN>::floats;

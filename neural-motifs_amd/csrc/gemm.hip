@@ -32,7 +32,7 @@ __device__ __forceinline__ float apply_epi(float v, int epilogue)
 }
 
 template <bool TA, bool TB, int BM, int BN, bool FAST>
-__global__ __launch_bounds__(kThreads, 2) void gemm_kernel(const GemmArgs p)
+__global__ __launch_bounds__(kThreads, MH_MINW) void gemm_kernel(const GemmArgs p)
 {
     constexpr int LDA = TileGeom<BM>::ld, LDB = TileGeom<BN>::ld;
     constexpr int FA = TileGeom<BM>::floats, FB = TileGeom<BN>::floats;

@@ -23,6 +23,9 @@ namespace mh {
 #ifndef MH_BK
 #define MH_BK 16
 #endif
+#ifndef MH_MINW
+#define MH_MINW 2
+#endif
 constexpr int kBK = MH_BK;
 constexpr int kThreads = 256;
 
@@ -48,22 +51,42 @@ __device__ __forceinline__ void acc_zero(Acc &a)
 }
 
 // One k-tile (kBK deep) of MFMAs for this wave.  wm/wn = wave's row/col offset inside the block tile.
-template <int LDA, int LDB>
-__device__ __forceinline__ void mma_ktile(const float *__restrict__ As, const float *__restrict__ Bs, int wm, int wn,
-                                          int lane, Acc &acc)
+// MFMAs of k-steps [KK0, KK1) of the current k-tile (a k-step = 2 k values = one 32x32x2 MFMA per accumulator).
+// The fragment reads of step kk+1 are issued before the 4 MFMAs of step kk and the order is pinned with
+// sched_group_barrier, so the 4 x 64-cycle MFMA issue of one step covers the LDS latency of the next inside the SAME
+// wave (the compiler otherwise batches [reads, wait, 8 MFMAs] and exposes the LDS latency four times per k-tile).
+template <int LDA, int LDB, int KK0, int KK1>
+__device__ __forceinline__ void mma_ksteps(const float *__restrict__ As, const float *__restrict__ Bs, int wm, int wn,
+                                           int lane, Acc &acc)
 {
     const int i = lane & 31, g = lane >> 5;
     const float *ap = As + g * LDA + wm + 2 * i;
     const float *bp = Bs + g * LDB + wn + 2 * i;
+    float2 a = *reinterpret_cast<const float2 *>(ap + 2 * KK0 * LDA);
+    float2 b = *reinterpret_cast<const float2 *>(bp + 2 * KK0 * LDB);
 #pragma unroll
-    for (int kk = 0; kk < kBK / 2; ++kk) {
-        const float2 a = *reinterpret_cast<const float2 *>(ap + 2 * kk * LDA);
-        const float2 b = *reinterpret_cast<const float2 *>(bp + 2 * kk * LDB);
+    for (int kk = KK0; kk < KK1; ++kk) {
+        float2 an = a, bn = b;
+        if (kk + 1 < KK1) {
+            an = *reinterpret_cast<const float2 *>(ap + 2 * (kk + 1) * LDA);
+            bn = *reinterpret_cast<const float2 *>(bp + 2 * (kk + 1) * LDB);
+        }
         acc.v[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc.v[0][0], 0, 0, 0);
         acc.v[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.y, acc.v[0][1], 0, 0, 0);
         acc.v[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.x, acc.v[1][0], 0, 0, 0);
         acc.v[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc.v[1][1], 0, 0, 0);
+        a = an;
+        b = bn;
+        if (kk + 1 < KK1) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);   // 2 LDS reads (step kk+1)
+        __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);                       // 4 MFMAs   (step kk)
     }
+}
+
+template <int LDA, int LDB>
+__device__ __forceinline__ void mma_ktile(const float *__restrict__ As, const float *__restrict__ Bs, int wm, int wn,
+                                          int lane, Acc &acc)
+{
+    mma_ksteps<LDA, LDB, 0, kBK / 2>(As, Bs, wm, wn, lane, acc);
 }
 
 // Staging registers for one operand k-tile of width WD: WD/64 float4 per thread.
