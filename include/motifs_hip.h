@@ -61,8 +61,9 @@ int mh_nms_batched(const float *boxes_sorted, const int *seg_offsets, int nseg, 
  *   feat_layout 0: feat is NCHW [B,C,H,W] (the reference layout)
  *   feat_layout 1: feat is NHWC [B,H,W,C] (the trunk's internal layout; coalesced over C)
  *   out [n,C,ph,pw] always (the layout fc6 expects).  Rows whose image index is out of range are
- *   zero-filled.  The backward is deterministic (gather formulation, no atomics) and OVERWRITES
- *   grad_feat (same layout flag).
+ *   zero-filled.  The backward OVERWRITES grad_feat (same layout flag); like the reference it scatters
+ *   with fp32 atomicAdd, so its summation order is not reproducible run to run (it is not on the
+ *   train_rels path: the feature map is detached there, lib/rel_model.py:491).
  * ------------------------------------------------------------------------------------------- */
 int mh_roi_align_fwd(const float *feat, int B, int C, int H, int W, int feat_layout,
                      const float *rois, int n, int ph, int pw, float spatial_scale, float *out,
@@ -115,8 +116,10 @@ int mh_gemm_f32(int transA, int transB, int M, int N, int K, const float *A, int
  * ------------------------------------------------------------------------------------------- */
 int mh_conv3x3_pack_weight(const float *w, int Cout, int Cin, int flip_transpose, float *wt,
                            void *stream);
+size_t mh_conv3x3_ws_bytes(int B, int H, int W, int Cin, int Cout);   /* split-K scratch (0 if not split) */
 int mh_conv3x3_nhwc(const float *in, int B, int H, int W, int Cin, const float *wt, int Cout,
-                    const float *bias, int epilogue, float *out, void *stream);
+                    const float *bias, int epilogue, float *out, void *workspace, size_t ws_bytes,
+                    void *stream);
 int mh_conv_first_nchw(const float *in_nchw, int B, int Cin, int H, int W, const float *w /*[Cout,Cin,3,3]*/,
                        int Cout, const float *bias, int epilogue, float *out_nhwc, void *stream);
 int mh_maxpool2x2_nhwc(const float *in, int B, int H, int W, int C, float *out, void *stream);

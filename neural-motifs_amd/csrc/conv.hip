@@ -21,6 +21,8 @@ struct ConvArgs {
     int epilogue;
     float *out;
     int tiles_m, tiles_n;
+    int splitk, ktiles_per_split;
+    float *partial;   // [splitk][M][Cout] when splitk > 1
 };
 
 __device__ __forceinline__ float conv_epi(float v, int epilogue)
@@ -61,6 +63,8 @@ __global__ __launch_bounds__(kThreads, MH_MINW) void conv3x3_nhwc_kernel(const C
 
     const int kt_per_tap = p.Cin / kBK;
     const int total_kt = 9 * kt_per_tap;
+    const int kt_begin = blockIdx.y * p.ktiles_per_split;
+    const int kt_end = min(total_kt, kt_begin + p.ktiles_per_split);
 
     auto load_tiles = [&](Stage<BM> &sa, Stage<BN> &sb, int kt) {
         const int tap = kt / kt_per_tap;
@@ -83,18 +87,28 @@ __global__ __launch_bounds__(kThreads, MH_MINW) void conv3x3_nhwc_kernel(const C
     acc_zero(acc);
     Stage<BM> sa;
     Stage<BN> sb;
-    load_tiles(sa, sb, 0);
+    load_tiles(sa, sb, kt_begin);
     store_tiles(sa, sb, 0);
     __syncthreads();
-    for (int kt = 0; kt < total_kt; ++kt) {
-        const int cur = kt & 1;
-        const bool more = (kt + 1 < total_kt);
+    for (int kt = kt_begin; kt < kt_end; ++kt) {
+        const int cur = (kt - kt_begin) & 1;
+        const bool more = (kt + 1 < kt_end);
         if (more) load_tiles(sa, sb, kt + 1);
         mma_ktile<LDA, LDB>(As(cur), Bs(cur), wm, wn, lane, acc);
         if (more) store_tiles(sa, sb, cur ^ 1);
         __syncthreads();
     }
 
+    if (p.splitk > 1) {
+        float *dst = p.partial + (size_t)blockIdx.y * Mtot * p.Cout;
+        acc_foreach_pair(acc, wm, wn, lane, [&](int r, int c, float v0, float v1) {
+            const long long row = m0 + r;
+            const int col = n0 + c;
+            if (row >= Mtot || col >= p.Cout) return;
+            *reinterpret_cast<float2 *>(dst + (size_t)row * p.Cout + col) = make_float2(v0, v1);
+        });
+        return;
+    }
     acc_foreach_pair(acc, wm, wn, lane, [&](int r, int c, float v0, float v1) {
         const long long row = m0 + r;
         const int col = n0 + c;
@@ -263,8 +277,23 @@ int mh_conv3x3_pack_weight(const float *w, int Cout, int Cin, int flip_transpose
     return check_launch("pack_weight_kernel");
 }
 
+static int conv_splitk(long long M, int Cin, int Cout)
+{
+    const bool narrow = (Cout <= 64);
+    const long long tiles = ((M + (narrow ? 255 : 127)) / (narrow ? 256 : 128)) * ceil_div(Cout, narrow ? 64 : 128);
+    return choose_splitk_tiles(tiles, 9 * (Cin / kBK), (double)M * Cout, 2.0 * 9 * Cin * (double)Cout * M);
+}
+
+size_t mh_conv3x3_ws_bytes(int B, int H, int W, int Cin, int Cout)
+{
+    const long long M = (long long)B * H * W;
+    if (M <= 0 || Cin <= 0 || Cout <= 0 || Cin % kBK != 0) return 0;
+    const int s = conv_splitk(M, Cin, Cout);
+    return s > 1 ? align_up((size_t)s * M * Cout * sizeof(float), 256) : 0;
+}
+
 int mh_conv3x3_nhwc(const float *in, int B, int H, int W, int Cin, const float *wt, int Cout, const float *bias,
-                    int epilogue, float *out, void *stream)
+                    int epilogue, float *out, void *workspace, size_t ws_bytes, void *stream)
 {
     MH_REQUIRE(in && wt && out && B > 0 && H > 0 && W > 0);
     MH_REQUIRE(Cin > 0 && Cin % kBK == 0 && Cout > 0 && Cout % 4 == 0);
@@ -279,11 +308,21 @@ int mh_conv3x3_nhwc(const float *in, int B, int H, int W, int Cin, const float *
     p.tiles_n = ceil_div(Cout, bn);
     const long long ntiles = (long long)p.tiles_m * p.tiles_n;
     MH_REQUIRE(ntiles < (1LL << 31));
+    const int total_kt = 9 * (Cin / kBK);
+    int splitk = conv_splitk(M, Cin, Cout);
+    if (splitk > 1 && (workspace == nullptr || ws_bytes < (size_t)splitk * M * Cout * sizeof(float))) splitk = 1;
+    p.ktiles_per_split = ceil_div(total_kt, splitk);
+    splitk = ceil_div(total_kt, p.ktiles_per_split);
+    p.splitk = splitk;
+    p.partial = reinterpret_cast<float *>(workspace);
+    dim3 grid((unsigned)ntiles, (unsigned)splitk);
     if (narrow)
-        hipLaunchKernelGGL((conv3x3_nhwc_kernel<256, 64>), dim3((unsigned)ntiles), dim3(kThreads), 0, as_stream(stream), p);
+        hipLaunchKernelGGL((conv3x3_nhwc_kernel<256, 64>), grid, dim3(kThreads), 0, as_stream(stream), p);
     else
-        hipLaunchKernelGGL((conv3x3_nhwc_kernel<128, 128>), dim3((unsigned)ntiles), dim3(kThreads), 0, as_stream(stream), p);
-    return check_launch("conv3x3_nhwc_kernel");
+        hipLaunchKernelGGL((conv3x3_nhwc_kernel<128, 128>), grid, dim3(kThreads), 0, as_stream(stream), p);
+    int rc = check_launch("conv3x3_nhwc_kernel");
+    if (rc || splitk == 1) return rc;
+    return launch_splitk_reduce(p.partial, splitk, M, Cout, out, Cout, bias, epilogue, 0, as_stream(stream));
 }
 
 int mh_conv_first_nchw(const float *in_nchw, int B, int Cin, int H, int W, const float *w, int Cout,

@@ -114,6 +114,8 @@ __global__ __launch_bounds__(kThreads, MH_MINW) void gemm_kernel(const GemmArgs 
     });
 }
 
+}  // namespace mh
+namespace mh {
 // C = epi(sum_z partial[z] + bias) (+ C)
 __global__ void splitk_reduce_kernel(const float *__restrict__ partial, int splitk, int M, int N, float *__restrict__ C,
                                      int ldc, const float *__restrict__ bias, int epilogue, int accumulate)
@@ -133,23 +135,45 @@ __global__ void splitk_reduce_kernel(const float *__restrict__ partial, int spli
     }
 }
 
+// Work-distribution model shared by GEMM and conv: `tiles` output tiles of `ktiles` k-steps each are cut into
+// S k-slices.  Blocks are handed to 256 CUs greedily, so the makespan is ceil(tiles*S/256)/S tile-times; a CU that
+// holds fewer than 2 resident blocks cannot hide its barrier/LDS latency (measured ~0.8x); the partial-sum round trip
+// costs S*M*N*8 bytes of HBM traffic against 2*M*N*K flops.
+int choose_splitk_tiles(long long tiles, int ktiles, double out_elems, double flops)
+{
+    if (tiles >= 2048 || ktiles < 16) return 1;
+    static const int cand[] = {1, 2, 3, 4, 5, 6, 7, 8, 10, 12, 14, 16, 20, 24, 28, 32, 40, 48, 56, 64};
+    double best = 1e30;
+    int best_s = 1;
+    for (int s : cand) {
+        if (s > 1 && ktiles / s < 6) break;
+        const double blocks = (double)tiles * s;
+        const double rounds = (double)((tiles * s + 255) / 256);
+        double t_mfma = rounds / s * ((double)tiles > 0 ? 1.0 : 0.0);            // in tile-times
+        if (blocks < 512) t_mfma *= 1.2;                                         // < 2 resident blocks per CU
+        const double tile_time = flops / (double)tiles / (110e12 / 256.0);       // one tile on one CU, seconds
+        const double t_partial = (s > 1) ? (out_elems * 8.0 * s) / 4.0e12 + 4e-6 : 0.0;
+        const double cost = t_mfma * tile_time + t_partial;
+        if (cost < best * 0.97) { best = cost; best_s = s; }
+    }
+    return best_s;
+}
+
 static int choose_splitk(int M, int N, int K)
 {
     const int bm = (N <= 64) ? 256 : 128, bn = (N <= 64) ? 64 : 128;
     const long long tiles = (long long)ceil_div(M, bm) * ceil_div(N, bn);
-    const int ktiles = ceil_div(K, kBK);
-    if (tiles >= 1024 || ktiles < 16) return 1;
-    static const int cand[] = {1, 2, 3, 4, 6, 8, 12, 16, 24, 32};
-    double best = 1e30;
-    int best_s = 1;
-    for (int s : cand) {
-        if (s > 1 && ktiles / s < 8) break;
-        const double rounds = (double)((tiles * s + 255) / 256);
-        // time ~ rounds / s block-times, plus the partial write+read traffic relative to the MFMA work
-        const double cost = rounds / s * (1.0 + 0.02 * (s - 1)) + (s > 1 ? 0.25 * s * 128.0 / K : 0.0);
-        if (cost < best - 1e-9) { best = cost; best_s = s; }
-    }
-    return best_s;
+    return choose_splitk_tiles(tiles, ceil_div(K, kBK), (double)M * N, 2.0 * M * N * K);
+}
+
+int launch_splitk_reduce(const float *partial, int splitk, long long M, int N, float *C, int ldc, const float *bias,
+                         int epilogue, int accumulate, hipStream_t st)
+{
+    const long long total = M * N;
+    const int blocks = (int)std::min<long long>((total + 255) / 256, 256 * 16);
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, partial, splitk, (int)M, N, C, ldc, bias,
+                       epilogue, accumulate);
+    return check_launch("splitk_reduce_kernel");
 }
 
 }  // namespace mh
@@ -179,7 +203,7 @@ int mh_gemm_f32(int transA, int transB, int M, int N, int K, const float *A, int
     MH_REQUIRE(epilogue >= MH_EPI_NONE && epilogue <= MH_EPI_RELU6);
     if (splitk <= 0) splitk = choose_splitk(M, N, K);
     const int total_kt = ceil_div(K, kBK);
-    splitk = std::min(splitk, total_kt);
+    splitk = std::min(std::min(splitk, total_kt), 64);
     if (splitk > 1 && (workspace == nullptr || ws_bytes < (size_t)splitk * M * N * sizeof(float))) splitk = 1;
     GemmArgs p;
     p.M = M; p.N = N; p.K = K;

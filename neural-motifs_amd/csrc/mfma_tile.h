@@ -205,3 +205,10 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblocks)
 }
 
 }  // namespace mh
+
+namespace mh {
+// defined in gemm.hip
+int choose_splitk_tiles(long long tiles, int ktiles, double out_elems, double flops);
+int launch_splitk_reduce(const float *partial, int splitk, long long M, int N, float *C, int ldc, const float *bias,
+                         int epilogue, int accumulate, hipStream_t st);
+}  // namespace mh

@@ -20,7 +20,7 @@ SYMBOLS = (
     'mh_nms_ws_bytes', 'mh_nms', 'mh_nms_batched_ws_bytes', 'mh_nms_batched',
     'mh_roi_align_fwd', 'mh_roi_align_bwd', 'mh_draw_union_boxes', 'mh_bbox_overlaps',
     'mh_gemm_ws_bytes', 'mh_gemm_auto_splitk', 'mh_gemm_f32',
-    'mh_conv3x3_pack_weight', 'mh_conv3x3_nhwc', 'mh_conv_first_nchw', 'mh_maxpool2x2_nhwc',
+    'mh_conv3x3_pack_weight', 'mh_conv3x3_ws_bytes', 'mh_conv3x3_nhwc', 'mh_conv_first_nchw', 'mh_maxpool2x2_nhwc',
     'mh_im2col_nhwc', 'mh_nchw_to_nhwc', 'mh_nhwc_to_nchw',
     'mh_hwlstm_fwd_ws_bytes', 'mh_hwlstm_fwd', 'mh_hwlstm_bwd_ws_bytes', 'mh_hwlstm_bwd',
     'mh_hwlstm_cell_fwd', 'mh_hwlstm_cell_bwd', 'mh_gemv_rows',
@@ -45,7 +45,7 @@ def lib():
         for name in SYMBOLS:
             getattr(L, name)          # AttributeError if the library is stale
         L.mh_last_error.restype = ctypes.c_char_p
-        for name in ('mh_nms_ws_bytes', 'mh_nms_batched_ws_bytes', 'mh_gemm_ws_bytes',
+        for name in ('mh_nms_ws_bytes', 'mh_nms_batched_ws_bytes', 'mh_gemm_ws_bytes', 'mh_conv3x3_ws_bytes',
                      'mh_hwlstm_fwd_ws_bytes', 'mh_hwlstm_bwd_ws_bytes'):
             getattr(L, name).restype = ctypes.c_size_t
         _lib = L
@@ -229,7 +229,10 @@ def conv3x3_nhwc(x, wt, bias, epilogue):
     B, H, W, Cin = x.shape
     Cout = wt.shape[2]
     out = torch.empty(B, H, W, Cout, dtype=torch.float32, device=x.device)
-    rc = lib().mh_conv3x3_nhwc(f32(x), B, H, W, Cin, f32(wt), Cout, f32(bias), c_int(epilogue), f32(out), stream())
+    wsb = lib().mh_conv3x3_ws_bytes(B, H, W, Cin, Cout)
+    ws = workspace(wsb, x.device, 'conv') if wsb else None
+    rc = lib().mh_conv3x3_nhwc(f32(x), B, H, W, Cin, f32(wt), Cout, f32(bias), c_int(epilogue), f32(out),
+                               ptr(ws), c_size_t(ws.numel() if ws is not None else 0), stream())
     _check(rc, 'mh_conv3x3_nhwc')
     return out
 
