@@ -107,7 +107,7 @@ def main():
 
     from dataloaders.synthetic import SyntheticVG, make_blob
     from lib import _hip
-    from lib.pytorch_misc import clip_grad_norm
+    from lib.optim import FusedClipSGD
     from lib.rel_model import RelModel
 
     torch.manual_seed(1234)
@@ -124,7 +124,7 @@ def main():
     lr = 1e-3 * world * BATCH                                 # train_rels.py:192
     fc = [p for n, p in model.named_parameters() if n.startswith('roi_fmap') and p.requires_grad]
     rest = [p for n, p in model.named_parameters() if not n.startswith('roi_fmap') and p.requires_grad]
-    opt = torch.optim.SGD([{'params': fc, 'lr': lr / 10.0}, {'params': rest}], lr=lr, momentum=0.9, weight_decay=1e-4)
+    opt = FusedClipSGD([{'params': fc, 'lr': lr / 10.0}, {'params': rest}], lr=lr, momentum=0.9, weight_decay=1e-4)
     buckets = D.GradBuckets([p for p in model.parameters() if p.requires_grad])
     blobs = [make_blob(ds, range(i * BATCH, (i + 1) * BATCH), is_train=True) for i in range(n_img // BATCH)]
     for b in blobs:
@@ -143,8 +143,7 @@ def main():
         opt.zero_grad(set_to_none=True)
         loss.backward()
         buckets.all_reduce()
-        clip_grad_norm([(n, p) for n, p in model.named_parameters() if p.grad is not None], max_norm=5.0, clip=True)
-        opt.step()
+        opt.step(max_norm=5.0)           # global-norm clip (5.0) + SGD(momentum, wd) in three multi-tensor launches
         return loss
 
     def barrier():

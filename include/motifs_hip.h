@@ -173,6 +173,21 @@ int mh_hwlstm_cell_bwd(int n, int H, const float *d_h, const float *d_c_out, con
 int mh_gemv_rows(int n, int R, int K, const float *v, int ldv, const float *wt, int ldw,
                  const float *bias, float *out, int ldo, void *stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Tail of the training step: global grad-norm clip + SGD(momentum, weight decay) as multi-tensor kernels.
+ * Replaces lib/pytorch_misc.py:416-455 (`clip_grad_norm`: one host sync per parameter) and torch.optim.SGD
+ * (models/train_rels.py:57-72,143-150).
+ *   chunks: device array of 32-byte records {float* p; const float* g; float* buf; int32 n; float lr}, each
+ *           covering at most mh_opt_chunk_elems() consecutive elements of one parameter (built once).
+ *   mh_multi_sumsq  : sumsq_out[0] = sum over all chunks of g^2 (device scalar; partial = nchunks floats scratch)
+ *   mh_multi_sgd_step: g' = g * min(1, max_norm/(sqrt(sumsq)+1e-6)) (skipped when sumsq == NULL or max_norm <= 0);
+ *                      d = g' + wd*p; buf = first_step ? d : momentum*buf + d; p -= lr*buf
+ * ------------------------------------------------------------------------------------------- */
+int mh_opt_chunk_elems(void);
+int mh_multi_sumsq(const void *chunks, int nchunks, float *partial, float *sumsq_out, void *stream);
+int mh_multi_sgd_step(const void *chunks, int nchunks, const float *sumsq, float max_norm, float momentum,
+                      float weight_decay, int first_step, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,140 @@
+// optim.hip -- the tail of the training step (models/train_rels.py:143-150): global gradient-norm clipping
+// (lib/pytorch_misc.py:416-455) and SGD with momentum + weight decay, as multi-tensor kernels.
+//
+// The reference computes one `.norm()` per parameter with a host sync each, then scales every gradient, then runs
+// torch's SGD (several elementwise passes per tensor).  Here:
+//   mh_multi_sumsq   : one launch over a chunk table covering all gradients -> per-chunk partial sums of squares
+//                      (fixed order => deterministic), second tiny launch -> total sum of squares on the DEVICE
+//   mh_multi_sgd_step: one launch; every element does
+//                         g' = g * clip_coef            clip_coef = min(1, max_norm / (sqrt(sumsq) + 1e-6))
+//                         d  = g' + wd * p
+//                         buf = first_step ? d : momentum * buf + d
+//                         p  = p - lr * buf
+//                      reading p,g,buf and writing p,buf once (5 x 4 B per element: HBM-bound), no host round trip.
+// The chunk table (device array of {p, g, buf, n, lr}) is built once by the caller and reused every step.
+#include <algorithm>
+
+#include "common.h"
+
+namespace mh {
+
+struct OptChunk {
+    float *p;
+    const float *g;
+    float *buf;
+    int n;       // elements in this chunk (<= kChunkElems)
+    float lr;
+};
+static_assert(sizeof(OptChunk) == 32, "OptChunk layout is part of the C ABI (4 x 8 bytes)");
+
+constexpr int kChunkElems = 65536;
+
+__global__ __launch_bounds__(256) void multi_sumsq_kernel(const OptChunk *__restrict__ chunks, float *__restrict__ partial)
+{
+    __shared__ float red[256];
+    const OptChunk c = chunks[blockIdx.x];
+    float s = 0.f;
+    const int n4 = c.n >> 2;
+    const bool vec = (reinterpret_cast<uintptr_t>(c.g) & 15) == 0;
+    if (vec) {
+        const float4 *g4 = reinterpret_cast<const float4 *>(c.g);
+        for (int i = threadIdx.x; i < n4; i += 256) {
+            const float4 v = g4[i];
+            s += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+        }
+        for (int i = 4 * n4 + threadIdx.x; i < c.n; i += 256) s += c.g[i] * c.g[i];
+    } else {
+        for (int i = threadIdx.x; i < c.n; i += 256) s += c.g[i] * c.g[i];
+    }
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) partial[blockIdx.x] = red[0];
+}
+
+__global__ __launch_bounds__(256) void sum_partials_kernel(const float *__restrict__ partial, int n, float *__restrict__ out)
+{
+    __shared__ double red[256];
+    double s = 0.0;
+    for (int i = threadIdx.x; i < n; i += 256) s += (double)partial[i];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[0] = (float)red[0];
+}
+
+__global__ __launch_bounds__(256) void multi_sgd_kernel(const OptChunk *__restrict__ chunks,
+                                                        const float *__restrict__ sumsq, float max_norm, float momentum,
+                                                        float weight_decay, int first_step)
+{
+    const OptChunk c = chunks[blockIdx.x];
+    float coef = 1.f;
+    if (sumsq != nullptr && max_norm > 0.f) {
+        const float total_norm = sqrtf(sumsq[0]);
+        const float cc = max_norm / (total_norm + 1e-6f);
+        coef = cc < 1.f ? cc : 1.f;
+    }
+    const bool vec = ((reinterpret_cast<uintptr_t>(c.g) | reinterpret_cast<uintptr_t>(c.p) |
+                       reinterpret_cast<uintptr_t>(c.buf)) & 15) == 0;
+    auto upd = [&](float p, float g, float b, float &pn, float &bn) {
+        const float d = g * coef + weight_decay * p;
+        bn = first_step ? d : momentum * b + d;
+        pn = p - c.lr * bn;
+    };
+    const int n4 = vec ? (c.n >> 2) : 0;
+    float4 *p4 = reinterpret_cast<float4 *>(c.p);
+    const float4 *g4 = reinterpret_cast<const float4 *>(c.g);
+    float4 *b4 = reinterpret_cast<float4 *>(c.buf);
+    for (int i = threadIdx.x; i < n4; i += 256) {
+        float4 p = p4[i], b = b4[i];
+        const float4 g = g4[i];
+        upd(p.x, g.x, b.x, p.x, b.x);
+        upd(p.y, g.y, b.y, p.y, b.y);
+        upd(p.z, g.z, b.z, p.z, b.z);
+        upd(p.w, g.w, b.w, p.w, b.w);
+        p4[i] = p;
+        b4[i] = b;
+    }
+    for (int i = 4 * n4 + threadIdx.x; i < c.n; i += 256) upd(c.p[i], c.g[i], c.buf[i], c.p[i], c.buf[i]);
+}
+
+}  // namespace mh
+
+using namespace mh;
+
+extern "C" {
+
+int mh_opt_chunk_elems(void) { return kChunkElems; }
+
+int mh_multi_sumsq(const void *chunks, int nchunks, float *partial, float *sumsq_out, void *stream)
+{
+    MH_REQUIRE(nchunks >= 0 && sumsq_out);
+    hipStream_t st = as_stream(stream);
+    if (nchunks == 0) return (int)hipMemsetAsync(sumsq_out, 0, sizeof(float), st);
+    MH_REQUIRE(chunks && partial);
+    hipLaunchKernelGGL(multi_sumsq_kernel, dim3(nchunks), dim3(256), 0, st, reinterpret_cast<const OptChunk *>(chunks),
+                       partial);
+    int rc = check_launch("multi_sumsq_kernel");
+    if (rc) return rc;
+    hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, st, partial, nchunks, sumsq_out);
+    return check_launch("sum_partials_kernel");
+}
+
+int mh_multi_sgd_step(const void *chunks, int nchunks, const float *sumsq, float max_norm, float momentum,
+                      float weight_decay, int first_step, void *stream)
+{
+    MH_REQUIRE(nchunks >= 0);
+    if (nchunks == 0) return MH_OK;
+    MH_REQUIRE(chunks);
+    hipLaunchKernelGGL(multi_sgd_kernel, dim3(nchunks), dim3(256), 0, as_stream(stream),
+                       reinterpret_cast<const OptChunk *>(chunks), sumsq, max_norm, momentum, weight_decay, first_step);
+    return check_launch("multi_sgd_kernel");
+}
+
+}  // extern "C"

@@ -24,6 +24,7 @@ SYMBOLS = (
     'mh_im2col_nhwc', 'mh_nchw_to_nhwc', 'mh_nhwc_to_nchw',
     'mh_hwlstm_fwd_ws_bytes', 'mh_hwlstm_fwd', 'mh_hwlstm_bwd_ws_bytes', 'mh_hwlstm_bwd',
     'mh_hwlstm_cell_fwd', 'mh_hwlstm_cell_bwd', 'mh_gemv_rows',
+    'mh_opt_chunk_elems', 'mh_multi_sumsq', 'mh_multi_sgd_step',
 )
 
 _lib = None

@@ -1,0 +1,105 @@
+"""
+Fused tail of the training step on the GPU: global gradient-norm clipping + SGD(momentum, weight decay)
+(reference: lib/pytorch_misc.py:416-455 `clip_grad_norm`, models/train_rels.py:57-72 `get_optim`, :143-150).
+
+`FusedClipSGD` looks like a torch optimizer (param_groups with per-group 'lr', `zero_grad`, `step`, `state_dict`), so
+`ReduceLROnPlateau` keeps working, but one `step(max_norm)` is two multi-tensor launches (norm) + one (update) over a
+chunk table that lives on the device; the norm never travels to the host unless `last_total_norm()` is asked for.
+Gradients must be dense fp32 and present for every parameter of the table (parameters whose .grad is None in a step
+are skipped by rebuilding the table -- this only happens if the set of used parameters changes).
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from lib import _hip
+
+
+class FusedClipSGD(torch.optim.Optimizer):
+    def __init__(self, params, lr, momentum=0.9, weight_decay=0.0):
+        super(FusedClipSGD, self).__init__(params, dict(lr=lr, momentum=momentum, weight_decay=weight_decay))
+        mom = {g['momentum'] for g in self.param_groups}
+        wd = {g['weight_decay'] for g in self.param_groups}
+        if len(mom) != 1 or len(wd) != 1:
+            raise ValueError('FusedClipSGD needs one momentum / weight_decay for all groups (per-group lr is fine)')
+        self._table = None
+        self._table_key = None
+        self._steps = 0
+        self._sumsq = None
+        self._partial = None
+
+    # -- chunk table -----------------------------------------------------------------------------
+    def _build_table(self):
+        """(re)build the device chunk table when any pointer / lr changed (cheap check per step; numpy build)"""
+        chunk = _hip.lib().mh_opt_chunk_elems()
+        key, dev = [], None
+        for group in self.param_groups:
+            for p in group['params']:
+                if p.grad is None:
+                    continue
+                if p.grad.dtype != torch.float32 or not p.grad.is_contiguous() or not p.is_contiguous():
+                    raise _hip.HipKernelError('FusedClipSGD needs contiguous fp32 parameters and gradients')
+                st = self.state[p]
+                if 'momentum_buffer' not in st:
+                    st['momentum_buffer'] = torch.zeros_like(p)
+                    st['fresh'] = True
+                dev = p.device
+                key.append((p.data_ptr(), p.grad.data_ptr(), st['momentum_buffer'].data_ptr(), p.numel(),
+                            float(group['lr'])))
+        key = tuple(key)
+        if key != self._table_key:
+            rec = np.dtype([('p', '<u8'), ('g', '<u8'), ('buf', '<u8'), ('n', '<i4'), ('lr', '<f4')])
+            parts = []
+            for pp, gp, bp, n, lr in key:
+                offs = np.arange(0, n, chunk, dtype=np.uint64)
+                r = np.empty(offs.shape[0], dtype=rec)
+                r['p'], r['g'], r['buf'] = pp + 4 * offs, gp + 4 * offs, bp + 4 * offs
+                r['n'] = np.minimum(chunk, n - offs.astype(np.int64)).astype(np.int32)
+                r['lr'] = lr
+                parts.append(r)
+            table = np.concatenate(parts) if parts else np.empty(0, dtype=rec)
+            self._nchunks = int(table.shape[0])
+            host = torch.from_numpy(table.view(np.uint8).copy())
+            self._table = host.to(dev, non_blocking=False) if dev is not None else host
+            self._table_key = key
+            if dev is not None:
+                self._partial = torch.empty(max(self._nchunks, 1), dtype=torch.float32, device=dev)
+                if self._sumsq is None:
+                    self._sumsq = torch.zeros(1, dtype=torch.float32, device=dev)
+        return self._nchunks
+
+    def last_total_norm(self):
+        """host value of the gradient norm measured by the last step (forces a sync; for logging only)"""
+        return float(self._sumsq.sqrt().item()) if self._sumsq is not None else 0.0
+
+    @torch.no_grad()
+    def step(self, max_norm=0.0, closure=None):
+        n = self._build_table()
+        if n == 0:
+            return None
+        L = _hip.lib()
+        g0 = self.param_groups[0]
+        fresh = all(self.state[p].get('fresh', False) for grp in self.param_groups for p in grp['params']
+                    if p.grad is not None)
+        some_fresh = any(self.state[p].get('fresh', False) for grp in self.param_groups for p in grp['params']
+                         if p.grad is not None)
+        if some_fresh and not fresh:
+            raise _hip.HipKernelError('parameters joined the optimizer after the first step: not supported')
+        stream = _hip.stream()
+        tptr = ctypes.c_void_p(self._table.data_ptr())
+        sumsq_ptr = ctypes.c_void_p(0)
+        if max_norm and max_norm > 0:
+            _hip._check(L.mh_multi_sumsq(tptr, n, _hip.f32(self._partial), _hip.f32(self._sumsq), stream),
+                        'mh_multi_sumsq')
+            sumsq_ptr = _hip.f32(self._sumsq)
+        _hip._check(L.mh_multi_sgd_step(tptr, n, sumsq_ptr, ctypes.c_float(float(max_norm or 0.0)),
+                                        ctypes.c_float(g0['momentum']), ctypes.c_float(g0['weight_decay']),
+                                        ctypes.c_int(1 if fresh else 0), stream), 'mh_multi_sgd_step')
+        if fresh:
+            for grp in self.param_groups:
+                for p in grp['params']:
+                    if p.grad is not None:
+                        self.state[p]['fresh'] = False
+        self._steps += 1
+        return None

@@ -24,6 +24,7 @@ from config import ModelConfig, BOX_SCALE, IM_SCALE
 from dataloaders.visual_genome import VGDataLoader, VG
 from lib import dist as D
 from lib.evaluation.sg_eval import BasicSceneGraphEvaluator
+from lib.optim import FusedClipSGD
 from lib.pytorch_misc import optimistic_restore, clip_grad_norm, print_para
 
 conf = ModelConfig()
@@ -64,7 +65,7 @@ def get_optim(lr):
     if conf.adam:
         optimizer = optim.Adam(params, weight_decay=conf.l2, lr=lr, eps=1e-3)
     else:
-        optimizer = optim.SGD(params, weight_decay=conf.l2, lr=lr, momentum=0.9)
+        optimizer = FusedClipSGD(params, weight_decay=conf.l2, lr=lr, momentum=0.9)      # clip + SGD fused on the GPU
     scheduler = ReduceLROnPlateau(optimizer, 'max', patience=3, factor=0.1, threshold=0.0001, threshold_mode='abs',
                                   cooldown=1)
     return optimizer, scheduler
@@ -101,9 +102,14 @@ def train_batch(b, verbose=False):
     optimizer.zero_grad(set_to_none=True)
     loss.backward()
     buckets.all_reduce()
-    clip_grad_norm([(n, p) for n, p in detector.named_parameters() if p.grad is not None], max_norm=conf.clip,
-                   verbose=verbose and rank == 0, clip=True)
-    optimizer.step()
+    if isinstance(optimizer, FusedClipSGD):
+        optimizer.step(max_norm=conf.clip)
+        if verbose and rank == 0:
+            print('---Total norm {:.3f}'.format(optimizer.last_total_norm()), flush=True)
+    else:
+        clip_grad_norm([(n, p) for n, p in detector.named_parameters() if p.grad is not None], max_norm=conf.clip,
+                       verbose=verbose and rank == 0, clip=True)
+        optimizer.step()
     return pd.Series({'class_loss': l_obj.item(), 'rel_loss': l_rel.item(), 'total': (l_obj + l_rel).item()})
 
 

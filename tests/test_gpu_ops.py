@@ -332,3 +332,37 @@ def test_decoder_cell_and_gemv(hip):
         out = hip.gemv_rows(v.cuda(), w.cuda(), bb.cuda())
         np.testing.assert_allclose(out.cpu().numpy(), (v.double() @ w.double().t() + bb.double()).float().numpy(),
                                    atol=2e-4)
+
+
+# ----------------------------------------------------------------------------------------------- optimiser tail
+def test_fused_clip_sgd_matches_torch(hip):
+    from lib.optim import FusedClipSGD
+    from lib.pytorch_misc import clip_grad_norm
+    g = torch.Generator().manual_seed(5)
+    shapes = [(300, 257), (70001,), (5,), (128, 64, 3, 3), (65536,), (65537,)]
+    ref_p = [torch.randn(s, generator=g).cuda().requires_grad_() for s in shapes]
+    new_p = [p.detach().clone().requires_grad_() for p in ref_p]
+    groups = lambda ps: [{'params': ps[:2], 'lr': 0.01}, {'params': ps[2:]}]
+    ref_opt = torch.optim.SGD(groups(ref_p), lr=0.1, momentum=0.9, weight_decay=1e-4)
+    new_opt = FusedClipSGD(groups(new_p), lr=0.1, momentum=0.9, weight_decay=1e-4)
+    for step in range(4):
+        grads = [torch.randn(s, generator=g).cuda() * (10.0 if step % 2 == 0 else 0.01) for s in shapes]
+        for p, q, gr in zip(ref_p, new_p, grads):
+            p.grad, q.grad = gr.clone(), gr.clone()
+        tn = clip_grad_norm([('p%d' % i, p) for i, p in enumerate(ref_p)], max_norm=5.0, clip=True)
+        ref_opt.step()
+        new_opt.step(max_norm=5.0)
+        assert abs(new_opt.last_total_norm() - tn) <= 1e-4 * tn
+        for p, q in zip(ref_p, new_p):
+            np.testing.assert_allclose(q.detach().cpu().numpy(), p.detach().cpu().numpy(), rtol=2e-5, atol=2e-6)
+    if True:   # lr change through param_groups (what ReduceLROnPlateau does) is honoured
+        for opt in (ref_opt, new_opt):
+            for grp in opt.param_groups:
+                grp['lr'] *= 0.1
+        grads = [torch.randn(s, generator=g).cuda() for s in shapes]
+        for p, q, gr in zip(ref_p, new_p, grads):
+            p.grad, q.grad = gr.clone(), gr.clone()
+        ref_opt.step()
+        new_opt.step(max_norm=0.0)
+        for p, q in zip(ref_p, new_p):
+            np.testing.assert_allclose(q.detach().cpu().numpy(), p.detach().cpu().numpy(), rtol=2e-5, atol=2e-6)
