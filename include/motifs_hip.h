@@ -188,6 +188,30 @@ int mh_multi_sumsq(const void *chunks, int nchunks, float *partial, float *sumsq
 int mh_multi_sgd_step(const void *chunks, int nchunks, const float *sumsq, float max_norm, float momentum,
                       float weight_decay, int first_step, void *stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Fused BatchNorm(train) / ReLU-mask / max-pool kernels of the union-box mask tower (NHWC fp32;
+ * lib/get_union_boxes.py:31-39 Conv->ReLU->BN->MaxPool(3,2,1)->Conv->ReLU->BN, + RoIAligned features).
+ *   mh_bn_stats        : per-channel mean / invstd of x[M,C] (biased var + eps), running stats updated (momentum,
+ *                        unbiased var) when running_mean/var are given -- nn.BatchNorm semantics
+ *   mh_bn_pool_fwd     : z = maxpool3x3/2/pad1( gamma*(x-mean)*invstd + beta ), argmax byte (ky*3+kx) per output
+ *   mh_bn_residual_nchw: out[n,c,p] = residual[n,c,p] + BN(x)[n,p,c]  (x NHWC [N,P,C] -> NCHW, residual may be NULL)
+ *   mh_nchw_to_nhwc_small: [N,C,P] -> [N,P,C]
+ *   mh_bn_bwd          : dx (with the producer's ReLU mask x>0 when relu_mask), dgamma, dbeta from the dense
+ *                        gradient g[N,H,W,C] or, when pooled, from the pooled gradient g[N,H/2,W/2,C] + argmax
+ * ------------------------------------------------------------------------------------------- */
+size_t mh_bn_ws_bytes(long long M, int C);
+int mh_bn_stats(const float *x, long long M, int C, float eps, float momentum, float *mean, float *invstd,
+                float *running_mean, float *running_var, void *workspace, size_t ws_bytes, void *stream);
+int mh_bn_pool_fwd(const float *x, long long N, int H, int W, int C, const float *mean, const float *invstd,
+                   const float *gamma, const float *beta, float *z, unsigned char *argmax, void *stream);
+int mh_bn_residual_nchw(const float *x, long long N, int P, int C, const float *mean, const float *invstd,
+                        const float *gamma, const float *beta, const float *residual_nchw, float *out_nchw,
+                        void *stream);
+int mh_nchw_to_nhwc_small(const float *in_nchw, long long N, int P, int C, float *out_nhwc, void *stream);
+int mh_bn_bwd(const float *x, const float *g, const unsigned char *argmax, long long N, int H, int W, int C,
+              const float *mean, const float *invstd, const float *gamma, int pooled, int relu_mask, float *dx,
+              float *dgamma, float *dbeta, void *workspace, size_t ws_bytes, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,376 @@
+// tower.hip -- fused BatchNorm(train) / ReLU / max-pool kernels for the union-box mask tower
+// (lib/get_union_boxes.py:31-39: Conv7x7/2 -> ReLU -> BN -> MaxPool3x3/2 -> Conv3x3 -> ReLU -> BN, summed with the
+// RoIAligned union features).  All tensors NHWC fp32; the convolutions run on the MFMA kernels with ReLU fused into
+// their epilogues, so these kernels see POST-ReLU activations (the ReLU backward mask is x > 0).
+//
+// Why custom: the framework's channels-last BN kernels move 308 MB at < 1 TB/s and make separate passes for
+// statistics, normalisation, pooling and the residual add.  Here
+//   forward : stats (1 read pass, deterministic two-stage reduction, running stats updated like nn.BatchNorm)
+//             -> apply fused with the 3x3/2 max-pool (first BN) or with the NHWC->NCHW residual add (second BN)
+//   backward: per-channel sums (1 pass; pooled variant gathers through the saved arg-max) -> dx fused with the
+//             ReLU mask.
+// HBM-bound: a few passes over [n*14*14, 256] / [n*7*7, 512].
+#include <algorithm>
+
+#include "common.h"
+
+namespace mh {
+
+constexpr int kRowsPerBlock = 128;
+
+// ---- per-channel partial sums of (x, x^2) or (g, g*xhat): block b covers rows [b*128, b*128+128) ---------------
+// threads: c4 = tid % (C/4) float4 columns, lane-row = tid / (C/4); partial[b][0/1][C]
+template <bool BWD, bool POOL>
+__global__ __launch_bounds__(256) void bn_partial_kernel(const float *__restrict__ x, const float *__restrict__ g,
+                                                         const unsigned char *__restrict__ argmax,
+                                                         const float *__restrict__ mean, const float *__restrict__ invstd,
+                                                         long long M, int C, int H, int W, float *__restrict__ partial)
+{
+    extern __shared__ __attribute__((aligned(16))) float red[];   // [rl][2][C]
+    const int C4 = C >> 2;
+    const int c4 = threadIdx.x % C4, rl = threadIdx.x / C4, nrl = blockDim.x / C4;
+    const long long r0 = (long long)blockIdx.x * kRowsPerBlock;
+    float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0;
+    float4 mu = s0, is = s0;
+    if (BWD) {
+        mu = reinterpret_cast<const float4 *>(mean)[c4];
+        is = reinterpret_cast<const float4 *>(invstd)[c4];
+    }
+    if (rl < nrl) {
+        for (long long r = r0 + rl; r < std::min(M, r0 + kRowsPerBlock); r += nrl) {
+            if (!BWD) {
+                const float4 v = reinterpret_cast<const float4 *>(x + r * C)[c4];
+                s0.x += v.x; s0.y += v.y; s0.z += v.z; s0.w += v.w;
+                s1.x += v.x * v.x; s1.y += v.y * v.y; s1.z += v.z * v.z; s1.w += v.w * v.w;
+            } else {
+                // r indexes the rows of g.  POOL: g is the pooled gradient [n, H/2, W/2, C]; the matching x element is
+                // the arg-max position inside the 3x3/2 window (pad 1) of the [n,H,W,C] input.
+                const float4 gv = reinterpret_cast<const float4 *>(g + r * C)[c4];
+                float4 xv;
+                if (POOL) {
+                    const int Ho = H / 2, Wo = W / 2;
+                    const int ox = (int)(r % Wo), oy = (int)((r / Wo) % Ho);
+                    const long long n = r / ((long long)Wo * Ho);
+                    const uchar4 a = reinterpret_cast<const uchar4 *>(argmax + r * C)[c4];
+                    const unsigned char aa[4] = {a.x, a.y, a.z, a.w};
+                    float xs[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int iy = 2 * oy - 1 + aa[j] / 3, ix = 2 * ox - 1 + aa[j] % 3;
+                        xs[j] = x[((n * H + iy) * W + ix) * C + 4 * c4 + j];
+                    }
+                    xv = make_float4(xs[0], xs[1], xs[2], xs[3]);
+                } else {
+                    xv = reinterpret_cast<const float4 *>(x + r * C)[c4];
+                }
+                s0.x += gv.x; s0.y += gv.y; s0.z += gv.z; s0.w += gv.w;
+                s1.x += gv.x * (xv.x - mu.x) * is.x; s1.y += gv.y * (xv.y - mu.y) * is.y;
+                s1.z += gv.z * (xv.z - mu.z) * is.z; s1.w += gv.w * (xv.w - mu.w) * is.w;
+            }
+        }
+        reinterpret_cast<float4 *>(red + (size_t)(rl * 2 + 0) * C)[c4] = s0;
+        reinterpret_cast<float4 *>(red + (size_t)(rl * 2 + 1) * C)[c4] = s1;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2 * C; i += blockDim.x) {
+        float s = 0.f;
+        for (int q = 0; q < nrl; ++q) s += red[(size_t)q * 2 * C + i];
+        partial[(size_t)blockIdx.x * 2 * C + i] = s;
+    }
+}
+
+// forward finalize: mean, biased var -> invstd; running stats with momentum (unbiased var), like nn.BatchNorm
+__global__ void bn_finalize_fwd_kernel(const float *__restrict__ partial, int nblk, int C, long long M, float eps,
+                                       float momentum, float *__restrict__ mean, float *__restrict__ invstd,
+                                       float *__restrict__ running_mean, float *__restrict__ running_var)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s = 0.0, ss = 0.0;
+    for (int b = 0; b < nblk; ++b) {
+        s += (double)partial[(size_t)b * 2 * C + c];
+        ss += (double)partial[(size_t)b * 2 * C + C + c];
+    }
+    const double mu = s / (double)M;
+    double var = ss / (double)M - mu * mu;
+    if (var < 0.0) var = 0.0;
+    mean[c] = (float)mu;
+    invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+    if (running_mean) {
+        const double unbiased = (M > 1) ? var * (double)M / (double)(M - 1) : var;
+        running_mean[c] = (float)((1.0 - momentum) * running_mean[c] + momentum * mu);
+        running_var[c] = (float)((1.0 - momentum) * running_var[c] + momentum * unbiased);
+    }
+}
+
+// backward finalize: dbeta = sum g, dgamma = sum g*xhat
+__global__ void bn_finalize_bwd_kernel(const float *__restrict__ partial, int nblk, int C, float *__restrict__ dgamma,
+                                       float *__restrict__ dbeta)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s = 0.0, ss = 0.0;
+    for (int b = 0; b < nblk; ++b) {
+        s += (double)partial[(size_t)b * 2 * C + c];
+        ss += (double)partial[(size_t)b * 2 * C + C + c];
+    }
+    dbeta[c] = (float)s;
+    dgamma[c] = (float)ss;
+}
+
+__device__ __forceinline__ float bn_affine(float x, float mu, float is, float ga, float be) { return (x - mu) * is * ga + be; }
+
+// y = BN(x) followed by 3x3 / stride 2 / pad 1 max-pool; x [n,H,W,C] -> z [n,H/2,W/2,C], argmax in 0..8 (ky*3+kx)
+__global__ void bn_pool_fwd_kernel(const float *__restrict__ x, const float *__restrict__ mean,
+                                   const float *__restrict__ invstd, const float *__restrict__ gamma,
+                                   const float *__restrict__ beta, long long N, int H, int W, int C,
+                                   float *__restrict__ z, unsigned char *__restrict__ argmax)
+{
+    const int Ho = H / 2, Wo = W / 2, C4 = C >> 2;
+    const long long total = N * Ho * Wo * C4;
+    for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total;
+         idx += (long long)blockDim.x * gridDim.x) {
+        const int c4 = idx % C4;
+        long long t = idx / C4;
+        const int ox = t % Wo; t /= Wo;
+        const int oy = t % Ho;
+        const long long n = t / Ho;
+        const float4 mu = reinterpret_cast<const float4 *>(mean)[c4], is = reinterpret_cast<const float4 *>(invstd)[c4];
+        const float4 ga = reinterpret_cast<const float4 *>(gamma)[c4], be = reinterpret_cast<const float4 *>(beta)[c4];
+        float best[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+        unsigned char arg[4] = {4, 4, 4, 4};
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+            const int iy = 2 * oy - 1 + k / 3, ix = 2 * ox - 1 + k % 3;
+            if ((unsigned)iy >= (unsigned)H || (unsigned)ix >= (unsigned)W) continue;
+            const float4 v = reinterpret_cast<const float4 *>(x + ((n * H + iy) * W + ix) * C)[c4];
+            const float y[4] = {bn_affine(v.x, mu.x, is.x, ga.x, be.x), bn_affine(v.y, mu.y, is.y, ga.y, be.y),
+                                bn_affine(v.z, mu.z, is.z, ga.z, be.z), bn_affine(v.w, mu.w, is.w, ga.w, be.w)};
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (y[j] > best[j]) { best[j] = y[j]; arg[j] = (unsigned char)k; }     // first maximum wins
+        }
+        reinterpret_cast<float4 *>(z)[idx] = make_float4(best[0], best[1], best[2], best[3]);
+        reinterpret_cast<uchar4 *>(argmax)[idx] = make_uchar4(arg[0], arg[1], arg[2], arg[3]);
+    }
+}
+
+// out[n][c][p] = residual[n][c][p] + BN(x)[n][p][c]   (x NHWC [n,P,C] -> out NCHW [n,C,P]); 32x32 LDS transpose
+__global__ __launch_bounds__(256) void bn_residual_nchw_kernel(const float *__restrict__ x, const float *__restrict__ mean,
+                                                               const float *__restrict__ invstd,
+                                                               const float *__restrict__ gamma,
+                                                               const float *__restrict__ beta,
+                                                               const float *__restrict__ residual, int P, int C,
+                                                               float *__restrict__ out)
+{
+    __shared__ float tile[32][33];
+    const long long n = blockIdx.z;
+    const int c0 = blockIdx.x * 32, p0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const float *xs = x + n * (long long)P * C;
+    for (int j = ty; j < 32; j += 8) {
+        const int p = p0 + j, c = c0 + tx;
+        if (p < P && c < C) tile[j][tx] = bn_affine(xs[(size_t)p * C + c], mean[c], invstd[c], gamma[c], beta[c]);
+    }
+    __syncthreads();
+    for (int j = ty; j < 32; j += 8) {
+        const int c = c0 + j, p = p0 + tx;
+        if (p < P && c < C) {
+            const size_t o = (n * C + c) * (size_t)P + p;
+            out[o] = (residual ? residual[o] : 0.f) + tile[tx][j];
+        }
+    }
+}
+
+// g_nhwc[n][p][c] = g_nchw[n][c][p]
+__global__ __launch_bounds__(256) void nchw_to_nhwc_small_kernel(const float *__restrict__ in, int P, int C,
+                                                                 float *__restrict__ out)
+{
+    __shared__ float tile[32][33];
+    const long long n = blockIdx.z;
+    const int c0 = blockIdx.x * 32, p0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int j = ty; j < 32; j += 8) {
+        const int c = c0 + j, p = p0 + tx;
+        if (p < P && c < C) tile[j][tx] = in[(n * C + c) * (size_t)P + p];
+    }
+    __syncthreads();
+    for (int j = ty; j < 32; j += 8) {
+        const int p = p0 + j, c = c0 + tx;
+        if (p < P && c < C) out[(n * P + p) * (size_t)C + c] = tile[tx][j];
+    }
+}
+
+// dx = gamma*invstd * (dy - (dbeta + xhat*dgamma)/M) * [x > 0]
+// POOL: dy at an input position = sum of the pooled gradients whose window arg-max is this position
+template <bool POOL>
+__global__ void bn_bwd_apply_kernel(const float *__restrict__ x, const float *__restrict__ g,
+                                    const unsigned char *__restrict__ argmax, const float *__restrict__ mean,
+                                    const float *__restrict__ invstd, const float *__restrict__ gamma,
+                                    const float *__restrict__ dgamma, const float *__restrict__ dbeta, long long N, int H,
+                                    int W, int C, int relu_mask, float *__restrict__ dx)
+{
+    const int C4 = C >> 2;
+    const long long total = N * H * W * C4;
+    const float invM = 1.f / (float)(N * H * W);
+    for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total;
+         idx += (long long)blockDim.x * gridDim.x) {
+        const int c4 = idx % C4;
+        long long t = idx / C4;
+        const int ix = t % W; t /= W;
+        const int iy = t % H;
+        const long long n = t / H;
+        const float4 xv = reinterpret_cast<const float4 *>(x)[idx];
+        float dy[4] = {0.f, 0.f, 0.f, 0.f};
+        if (POOL) {
+            const int Ho = H / 2, Wo = W / 2;
+            // windows (oy,ox) with 2*oy-1 <= iy <= 2*oy+1
+            for (int oy = (iy) / 2; oy <= (iy + 1) / 2; ++oy) {
+                if (oy >= Ho) continue;
+                const int ky = iy - (2 * oy - 1);
+                for (int ox = (ix) / 2; ox <= (ix + 1) / 2; ++ox) {
+                    if (ox >= Wo) continue;
+                    const int kx = ix - (2 * ox - 1);
+                    const long long o = ((n * Ho + oy) * Wo + ox) * C4 + c4;
+                    const uchar4 a = reinterpret_cast<const uchar4 *>(argmax)[o];
+                    const float4 gv = reinterpret_cast<const float4 *>(g)[o];
+                    const int k = ky * 3 + kx;
+                    if (a.x == k) dy[0] += gv.x;
+                    if (a.y == k) dy[1] += gv.y;
+                    if (a.z == k) dy[2] += gv.z;
+                    if (a.w == k) dy[3] += gv.w;
+                }
+            }
+        } else {
+            const float4 gv = reinterpret_cast<const float4 *>(g)[idx];
+            dy[0] = gv.x; dy[1] = gv.y; dy[2] = gv.z; dy[3] = gv.w;
+        }
+        const float4 mu = reinterpret_cast<const float4 *>(mean)[c4], is = reinterpret_cast<const float4 *>(invstd)[c4];
+        const float4 ga = reinterpret_cast<const float4 *>(gamma)[c4];
+        const float4 dg = reinterpret_cast<const float4 *>(dgamma)[c4], db = reinterpret_cast<const float4 *>(dbeta)[c4];
+        const float xs[4] = {xv.x, xv.y, xv.z, xv.w}, mus[4] = {mu.x, mu.y, mu.z, mu.w}, iss[4] = {is.x, is.y, is.z, is.w};
+        const float gas[4] = {ga.x, ga.y, ga.z, ga.w}, dgs[4] = {dg.x, dg.y, dg.z, dg.w}, dbs[4] = {db.x, db.y, db.z, db.w};
+        float r[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float xhat = (xs[j] - mus[j]) * iss[j];
+            float v = gas[j] * iss[j] * (dy[j] - (dbs[j] + xhat * dgs[j]) * invM);
+            if (relu_mask && !(xs[j] > 0.f)) v = 0.f;
+            r[j] = v;
+        }
+        reinterpret_cast<float4 *>(dx)[idx] = make_float4(r[0], r[1], r[2], r[3]);
+    }
+}
+
+static int grid_for(long long total) { return (int)std::min<long long>((total + 255) / 256, 256 * 16); }
+
+}  // namespace mh
+
+using namespace mh;
+
+extern "C" {
+
+size_t mh_bn_ws_bytes(long long M, int C)
+{
+    if (M <= 0 || C <= 0) return 0;
+    const long long nblk = (M + kRowsPerBlock - 1) / kRowsPerBlock;
+    return align_up((size_t)nblk * 2 * C * sizeof(float), 256);
+}
+
+static int check_bn_args(long long M, int C)
+{
+    MH_REQUIRE(M > 0 && C > 0 && C % 4 == 0 && C <= 1024 && (C / 4) <= 256);
+    return MH_OK;
+}
+
+// statistics of x [M,C] (NHWC rows): mean, invstd (biased variance, eps); running stats updated when given
+int mh_bn_stats(const float *x, long long M, int C, float eps, float momentum, float *mean, float *invstd,
+                float *running_mean, float *running_var, void *workspace, size_t ws_bytes, void *stream)
+{
+    int rc = check_bn_args(M, C);
+    if (rc) return rc;
+    MH_REQUIRE(x && mean && invstd && workspace && ws_bytes >= mh_bn_ws_bytes(M, C));
+    MH_REQUIRE((running_mean == nullptr) == (running_var == nullptr));
+    hipStream_t st = as_stream(stream);
+    const int nblk = (int)((M + kRowsPerBlock - 1) / kRowsPerBlock);
+    float *partial = reinterpret_cast<float *>(workspace);
+    const int nrl = 256 / (C / 4);
+    hipLaunchKernelGGL((bn_partial_kernel<false, false>), dim3(nblk), dim3(256), (size_t)nrl * 2 * C * sizeof(float), st, x,
+                       (const float *)nullptr, (const unsigned char *)nullptr, (const float *)nullptr,
+                       (const float *)nullptr, M, C, 0, 0, partial);
+    rc = check_launch("bn_partial_kernel<fwd>");
+    if (rc) return rc;
+    hipLaunchKernelGGL(bn_finalize_fwd_kernel, dim3(ceil_div(C, 256)), dim3(256), 0, st, partial, nblk, C, M, eps, momentum,
+                       mean, invstd, running_mean, running_var);
+    return check_launch("bn_finalize_fwd_kernel");
+}
+
+int mh_bn_pool_fwd(const float *x, long long N, int H, int W, int C, const float *mean, const float *invstd,
+                   const float *gamma, const float *beta, float *z, unsigned char *argmax, void *stream)
+{
+    int rc = check_bn_args(N * H * W, C);
+    if (rc) return rc;
+    MH_REQUIRE(x && mean && invstd && gamma && beta && z && argmax && H % 2 == 0 && W % 2 == 0);
+    hipLaunchKernelGGL(bn_pool_fwd_kernel, dim3(grid_for(N * (H / 2) * (W / 2) * (C / 4))), dim3(256), 0, as_stream(stream),
+                       x, mean, invstd, gamma, beta, N, H, W, C, z, argmax);
+    return check_launch("bn_pool_fwd_kernel");
+}
+
+int mh_bn_residual_nchw(const float *x, long long N, int P, int C, const float *mean, const float *invstd,
+                        const float *gamma, const float *beta, const float *residual_nchw, float *out_nchw, void *stream)
+{
+    int rc = check_bn_args(N * P, C);
+    if (rc) return rc;
+    MH_REQUIRE(x && mean && invstd && gamma && beta && out_nchw && P > 0 && N <= 65535);
+    hipLaunchKernelGGL(bn_residual_nchw_kernel, dim3(ceil_div(C, 32), ceil_div(P, 32), (unsigned)N), dim3(256), 0,
+                       as_stream(stream), x, mean, invstd, gamma, beta, residual_nchw, P, C, out_nchw);
+    return check_launch("bn_residual_nchw_kernel");
+}
+
+int mh_nchw_to_nhwc_small(const float *in_nchw, long long N, int P, int C, float *out_nhwc, void *stream)
+{
+    MH_REQUIRE(in_nchw && out_nhwc && N > 0 && N <= 65535 && P > 0 && C > 0);
+    hipLaunchKernelGGL(nchw_to_nhwc_small_kernel, dim3(ceil_div(C, 32), ceil_div(P, 32), (unsigned)N), dim3(256), 0,
+                       as_stream(stream), in_nchw, P, C, out_nhwc);
+    return check_launch("nchw_to_nhwc_small_kernel");
+}
+
+// BN backward (+ ReLU mask of the producer).  pooled != 0: g is the gradient of the POOLED output [N,H/2,W/2,C] and
+// argmax the indices saved by mh_bn_pool_fwd; otherwise g is dense [N,H,W,C].  Outputs dx [N,H,W,C], dgamma, dbeta [C].
+int mh_bn_bwd(const float *x, const float *g, const unsigned char *argmax, long long N, int H, int W, int C,
+              const float *mean, const float *invstd, const float *gamma, int pooled, int relu_mask, float *dx,
+              float *dgamma, float *dbeta, void *workspace, size_t ws_bytes, void *stream)
+{
+    const long long M = N * H * W;
+    int rc = check_bn_args(M, C);
+    if (rc) return rc;
+    MH_REQUIRE(x && g && mean && invstd && gamma && dx && dgamma && dbeta && workspace);
+    MH_REQUIRE(!pooled || (argmax && H % 2 == 0 && W % 2 == 0));
+    const long long Mg = pooled ? N * (H / 2) * (W / 2) : M;
+    MH_REQUIRE(ws_bytes >= mh_bn_ws_bytes(Mg, C));
+    hipStream_t st = as_stream(stream);
+    const int nblk = (int)((Mg + kRowsPerBlock - 1) / kRowsPerBlock);
+    float *partial = reinterpret_cast<float *>(workspace);
+    const int nrl = 256 / (C / 4);
+    const size_t lds = (size_t)nrl * 2 * C * sizeof(float);
+    if (pooled)
+        hipLaunchKernelGGL((bn_partial_kernel<true, true>), dim3(nblk), dim3(256), lds, st, x, g, argmax, mean, invstd, Mg,
+                           C, H, W, partial);
+    else
+        hipLaunchKernelGGL((bn_partial_kernel<true, false>), dim3(nblk), dim3(256), lds, st, x, g, argmax, mean, invstd, Mg,
+                           C, H, W, partial);
+    rc = check_launch("bn_partial_kernel<bwd>");
+    if (rc) return rc;
+    hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3(ceil_div(C, 256)), dim3(256), 0, st, partial, nblk, C, dgamma, dbeta);
+    rc = check_launch("bn_finalize_bwd_kernel");
+    if (rc) return rc;
+    if (pooled)
+        hipLaunchKernelGGL((bn_bwd_apply_kernel<true>), dim3(grid_for(M * (C / 4))), dim3(256), 0, st, x, g, argmax, mean,
+                           invstd, gamma, dgamma, dbeta, N, H, W, C, relu_mask, dx);
+    else
+        hipLaunchKernelGGL((bn_bwd_apply_kernel<false>), dim3(grid_for(M * (C / 4))), dim3(256), 0, st, x, g, argmax, mean,
+                           invstd, gamma, dgamma, dbeta, N, H, W, C, relu_mask, dx);
+    return check_launch("bn_bwd_apply_kernel");
+}
+
+}  // extern "C"

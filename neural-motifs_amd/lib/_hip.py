@@ -25,6 +25,7 @@ SYMBOLS = (
     'mh_hwlstm_fwd_ws_bytes', 'mh_hwlstm_fwd', 'mh_hwlstm_bwd_ws_bytes', 'mh_hwlstm_bwd',
     'mh_hwlstm_cell_fwd', 'mh_hwlstm_cell_bwd', 'mh_gemv_rows',
     'mh_opt_chunk_elems', 'mh_multi_sumsq', 'mh_multi_sgd_step',
+    'mh_bn_ws_bytes', 'mh_bn_stats', 'mh_bn_pool_fwd', 'mh_bn_residual_nchw', 'mh_nchw_to_nhwc_small', 'mh_bn_bwd',
 )
 
 _lib = None
@@ -46,7 +47,7 @@ def lib():
         for name in SYMBOLS:
             getattr(L, name)          # AttributeError if the library is stale
         L.mh_last_error.restype = ctypes.c_char_p
-        for name in ('mh_nms_ws_bytes', 'mh_nms_batched_ws_bytes', 'mh_gemm_ws_bytes', 'mh_conv3x3_ws_bytes',
+        for name in ('mh_nms_ws_bytes', 'mh_nms_batched_ws_bytes', 'mh_gemm_ws_bytes', 'mh_conv3x3_ws_bytes', 'mh_bn_ws_bytes',
                      'mh_hwlstm_fwd_ws_bytes', 'mh_hwlstm_bwd_ws_bytes'):
             getattr(L, name).restype = ctypes.c_size_t
         _lib = L
@@ -349,3 +350,56 @@ def gemv_rows(v, wt, bias=None):
                             ctypes.c_void_p(wt.data_ptr()), c_int(wt.stride(0)), f32(bias), f32(out), R, stream())
     _check(rc, 'mh_gemv_rows')
     return out
+
+
+# ----------------------------------------------------------------------------------------------- BN / pool tower
+c_ll = ctypes.c_longlong
+
+
+def bn_stats(x2d, eps, momentum, running_mean=None, running_var=None):
+    """x2d [M,C] -> (mean, invstd); running stats updated in place when given"""
+    M, C = x2d.shape
+    mean = torch.empty(C, dtype=torch.float32, device=x2d.device)
+    invstd = torch.empty(C, dtype=torch.float32, device=x2d.device)
+    ws = workspace(lib().mh_bn_ws_bytes(c_ll(M), C), x2d.device, 'bn')
+    _check(lib().mh_bn_stats(f32(x2d), c_ll(M), C, c_float(eps), c_float(momentum), f32(mean), f32(invstd),
+                             f32(running_mean), f32(running_var), ptr(ws), c_size_t(ws.numel()), stream()), 'mh_bn_stats')
+    return mean, invstd
+
+
+def bn_pool_fwd(x, mean, invstd, gamma, beta):
+    N, H, W, C = x.shape
+    z = torch.empty(N, H // 2, W // 2, C, dtype=torch.float32, device=x.device)
+    arg = torch.empty(N, H // 2, W // 2, C, dtype=torch.uint8, device=x.device)
+    _check(lib().mh_bn_pool_fwd(f32(x), c_ll(N), H, W, C, f32(mean), f32(invstd), f32(gamma), f32(beta), f32(z),
+                                ptr(arg), stream()), 'mh_bn_pool_fwd')
+    return z, arg
+
+
+def bn_residual_nchw(x, mean, invstd, gamma, beta, residual):
+    N, Hh, Ww, C = x.shape
+    out = torch.empty(N, C, Hh, Ww, dtype=torch.float32, device=x.device)
+    _check(lib().mh_bn_residual_nchw(f32(x), c_ll(N), Hh * Ww, C, f32(mean), f32(invstd), f32(gamma), f32(beta),
+                                     f32(residual), f32(out), stream()), 'mh_bn_residual_nchw')
+    return out
+
+
+def nchw_to_nhwc_small(x):
+    N, C, Hh, Ww = x.shape
+    out = torch.empty(N, Hh, Ww, C, dtype=torch.float32, device=x.device)
+    _check(lib().mh_nchw_to_nhwc_small(f32(x), c_ll(N), Hh * Ww, C, f32(out), stream()), 'mh_nchw_to_nhwc_small')
+    return out
+
+
+def bn_bwd(x, g, argmax, mean, invstd, gamma, relu_mask):
+    """x [N,H,W,C]; g dense [N,H,W,C] (argmax None) or pooled [N,H/2,W/2,C] -> (dx, dgamma, dbeta)"""
+    N, H, W, C = x.shape
+    dx = torch.empty_like(x)
+    dgamma = torch.empty(C, dtype=torch.float32, device=x.device)
+    dbeta = torch.empty(C, dtype=torch.float32, device=x.device)
+    Mg = g.numel() // C
+    ws = workspace(lib().mh_bn_ws_bytes(c_ll(Mg), C), x.device, 'bn')
+    _check(lib().mh_bn_bwd(f32(x), f32(g), ptr(argmax), c_ll(N), H, W, C, f32(mean), f32(invstd), f32(gamma),
+                           c_int(int(argmax is not None)), c_int(int(relu_mask)), f32(dx), f32(dgamma), f32(dbeta),
+                           ptr(ws), c_size_t(ws.numel()), stream()), 'mh_bn_bwd')
+    return dx, dgamma, dbeta

@@ -14,7 +14,8 @@ from torch.nn import functional as F
 from config import BATCHNORM_MOMENTUM
 from lib.draw_rectangles.draw_rectangles import draw_union_boxes
 from lib.fpn.roi_align.functions.roi_align import RoIAlignFunction
-from lib.hip_ops import Conv2dNHWC, ReLU
+from lib import _hip
+from lib.hip_ops import Conv2dNHWC, ReLU, EPI_NONE, EPI_RELU
 
 
 class _ChannelsLastBN(nn.BatchNorm2d):
@@ -29,6 +30,58 @@ class _MaxPoolNHWC(nn.MaxPool2d):
     def forward(self, x_nhwc):
         y = super(_MaxPoolNHWC, self).forward(x_nhwc.permute(0, 3, 1, 2))
         return y.permute(0, 2, 3, 1)
+
+
+class _TowerFn(torch.autograd.Function):
+    """Conv7x7/2+ReLU -> BN -> MaxPool3x3/2 -> Conv3x3+ReLU -> BN -> (+ union features, NCHW out) as ONE autograd
+    node over the fused kernels of csrc/tower.hip (ReLU lives in the conv epilogues; BN statistics / apply / pool /
+    residual add and their backward are single HBM passes)."""
+
+    @staticmethod
+    def forward(ctx, rects, union_pools, w0, b0, g1, be1, w4, b4, g2, be2, bn1, bn2, training):
+        N = rects.shape[0]
+        C0, C1 = w0.shape[0], w4.shape[0]
+        K0 = w0.shape[1] * w0.shape[2] * w0.shape[3]
+        ld0 = (K0 + 3) // 4 * 4
+        cols0, Ho, Wo = _hip.im2col_nhwc(rects.contiguous(), w0.shape[2], w0.shape[3], 2, 3, ldo=ld0)
+        wmat = w0.new_zeros(C0, ld0)
+        wmat[:, :K0] = w0.permute(0, 2, 3, 1).reshape(C0, K0)
+        y0 = _hip.gemm(cols0, wmat, False, True, bias=b0, epilogue=EPI_RELU).view(N, Ho, Wo, C0)
+
+        def stats(x2d, bn):
+            if training:
+                return _hip.bn_stats(x2d, bn.eps, bn.momentum, bn.running_mean, bn.running_var)
+            return bn.running_mean, torch.rsqrt(bn.running_var + bn.eps)
+        mean1, invstd1 = stats(y0.view(-1, C0), bn1)
+        if training:
+            bn1.num_batches_tracked += 1
+            bn2.num_batches_tracked += 1
+        z, arg = _hip.bn_pool_fwd(y0, mean1, invstd1, g1, be1)
+        wt4 = _hip.conv3x3_pack_weight(w4.contiguous(), False)
+        y1 = _hip.conv3x3_nhwc(z, wt4, b4, EPI_RELU)
+        mean2, invstd2 = stats(y1.view(-1, C1), bn2)
+        out = _hip.bn_residual_nchw(y1, mean2, invstd2, g2, be2, union_pools.contiguous())
+        ctx.save_for_backward(cols0, y0, arg, z, y1, mean1, invstd1, mean2, invstd2, w0, w4, g1, g2)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        cols0, y0, arg, z, y1, mean1, invstd1, mean2, invstd2, w0, w4, g1, g2 = ctx.saved_tensors
+        C0, C1 = w0.shape[0], w4.shape[0]
+        K0 = w0.shape[1] * w0.shape[2] * w0.shape[3]
+        g_nhwc = _hip.nchw_to_nhwc_small(dout.contiguous())
+        dx2, dg2, db2 = _hip.bn_bwd(y1, g_nhwc, None, mean2, invstd2, g2, True)          # through BN2 and conv.4's ReLU
+        wt4_t = _hip.conv3x3_pack_weight(w4.contiguous(), True)
+        dz = _hip.conv3x3_nhwc(dx2, wt4_t, None, EPI_NONE)
+        cols4, _, _ = _hip.im2col_nhwc(z, 3, 3, 1, 1)
+        dw4 = _hip.gemm(dx2.view(-1, C1), cols4, True, False).view(C1, 3, 3, w4.shape[1]).permute(0, 3, 1, 2).contiguous()
+        db4 = dx2.view(-1, C1).sum(0)
+        dx1, dg1, db1 = _hip.bn_bwd(y0, dz, arg, mean1, invstd1, g1, True)               # pool + BN1 + conv.0's ReLU
+        dwm = _hip.gemm(dx1.view(-1, C0), cols0, True, False)
+        dw0 = dwm[:, :K0].reshape(C0, w0.shape[2], w0.shape[3], w0.shape[1]).permute(0, 3, 1, 2).contiguous()
+        db0 = dx1.view(-1, C0).sum(0)
+        d_up = dout if ctx.needs_input_grad[1] else None
+        return None, d_up, dw0, db0, dg1, db1, dw4, db4, dg2, db2, None, None, None
 
 
 class UnionBoxesAndFeats(nn.Module):
@@ -56,7 +109,11 @@ class UnionBoxesAndFeats(nn.Module):
             return union_pools.detach()
         pair_rois = torch.cat((rois[:, 1:][union_inds[:, 0]], rois[:, 1:][union_inds[:, 1]]), 1).detach()
         rects = draw_union_boxes(pair_rois, self.pooling_size * 4 - 1, offset=-0.5, channels_last=True)   # [N,27,27,2]
-        tower = self.conv(rects).permute(0, 3, 1, 2)                      # logical NCHW
+        if not self.concat and rects.is_cuda:
+            c = self.conv
+            return _TowerFn.apply(rects, union_pools, c[0].weight, c[0].bias, c[2].weight, c[2].bias, c[4].weight,
+                                  c[4].bias, c[6].weight, c[6].bias, c[2], c[6], self.training)
+        tower = self.conv(rects).permute(0, 3, 1, 2)                      # generic path (logical NCHW)
         if self.concat:
             return torch.cat((union_pools, tower), 1)
         return union_pools + tower
