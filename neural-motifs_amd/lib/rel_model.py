@@ -18,6 +18,7 @@ from torch.nn.utils.rnn import PackedSequence
 from config import BATCHNORM_MOMENTUM
 from lib.fpn.box_utils import bbox_overlaps, center_size
 from lib.fpn.nms.functions.nms import apply_nms
+from lib.fpn.proposal_assignments.rel_assignments import rel_assignments
 from lib.fpn.roi_align.functions.roi_align import RoIAlignFunction
 from lib.get_union_boxes import UnionBoxesAndFeats
 from lib.hip_ops import Dropout, Flattener, Linear, ReLU, linear
@@ -294,7 +295,10 @@ class RelModel(nn.Module):
         im_inds = result.im_inds - image_offset
         boxes = result.rm_box_priors
         if self.training and result.rel_labels is None:
-            raise NotImplementedError('sgdet training needs rel_assignments (SURVEY.md §8 a9): not built yet')
+            assert self.mode == 'sgdet'
+            result.rel_labels = rel_assignments(im_inds.detach(), boxes.detach(), result.rm_obj_labels.detach(),
+                                                gt_boxes.detach(), gt_classes.detach(), gt_rels.detach(), image_offset,
+                                                filter_non_overlap=True, num_sample_per_gt=1, rs=self.sampler_rs)
 
         rel_inds = self.get_rel_inds(result.rel_labels, im_inds, boxes)
         rois = torch.cat((im_inds[:, None].float(), boxes), 1)

@@ -101,3 +101,30 @@ def test_sgdet_eval_end_to_end(det):
     same = sum(1 for b in boxes if np.any(np.all(np.abs(rb - b[None]) < 1e-2, 1)))
     print('sgdet e2e: %d detections (oracle %d), %d coincide' % (boxes.shape[0], rb.shape[0], same))
     assert same >= 0.8 * min(boxes.shape[0], rb.shape[0])
+
+
+def test_sgdet_train_step_runs(det):
+    """SGDet training (rows a8/a9): RPN -> NMS -> detections matched to GT -> rel_assignments -> context (decoder with
+    background labels feeding back its own arg-max) -> losses -> backward."""
+    ds, model, sd, make_blob = det
+    model.train()
+    try:
+        blob = make_blob(ds, [0, 1], is_train=True)
+        model.sampler_rs = np.random.RandomState(2)
+        for _, p in model.detector.named_parameters():
+            p.requires_grad = False
+        res = model[blob]
+        assert res.rel_labels is not None and res.rel_labels.shape[1] == 4
+        n_obj = res.rm_obj_dists.shape[0]
+        assert res.rm_obj_labels.shape == (n_obj,) and res.rel_dists.shape == (res.rel_labels.shape[0], 51)
+        assert int(res.rel_labels[:, 1:3].max()) < n_obj
+        loss = F.cross_entropy(res.rm_obj_dists, res.rm_obj_labels) + F.cross_entropy(res.rel_dists, res.rel_labels[:, -1])
+        loss.backward()
+        assert torch.isfinite(loss)
+        grads = [p.grad for n, p in model.named_parameters() if p.requires_grad]
+        assert all(g is not None and torch.isfinite(g).all() for g in grads)
+        print('sgdet train: %d detections, %d relation rows (%d fg), loss %.3f' % (
+            n_obj, res.rel_labels.shape[0], int((res.rel_labels[:, 3] > 0).sum()), loss.item()))
+    finally:
+        model.eval()
+        model.zero_grad(set_to_none=True)
