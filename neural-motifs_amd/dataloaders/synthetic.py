@@ -20,7 +20,9 @@ class SyntheticVG(torch.utils.data.Dataset):
         rs = np.random.RandomState(seed)
         scale = BOX_SCALE / float(im_size)
         self.gt_boxes, self.gt_classes, self.relationships = [], [], []
-        for _ in range(num_images):
+        box_counts = n_boxes if isinstance(n_boxes, (list, tuple)) else [n_boxes] * num_images
+        for im in range(num_images):
+            n_boxes = int(box_counts[im % len(box_counts)])        # ragged object counts when a list is given
             boxes = np.zeros((0, 4))
             while boxes.shape[0] < n_boxes:                       # integer boxes in image space, de-duplicated
                 x1y1 = rs.uniform(0, im_size - 32, (n_boxes, 2))
