@@ -35,8 +35,7 @@ __device__ __forceinline__ float conv_epi(float v, int epilogue)
 template <int BM, int BN>
 __global__ __launch_bounds__(kThreads, MH_MINW) void conv3x3_nhwc_kernel(const ConvArgs p)
 {
-    constexpr int LDA = TileGeom<BM>::ld, LDB = TileGeom<BN>::ld;
-    constexpr int FA = TileGeom<BM>::floats, FB = TileGeom<BN>::floats;
+    constexpr int FA = TileGeom<BM, true>::floats, FB = TileGeom<BN, false>::floats;   // A: NHWC pixels (WM), B: KM
     __shared__ __attribute__((aligned(16))) float lds[2 * (FA + FB)];
     auto As = [&](int buf) -> float * { return lds + buf * (FA + FB); };
     auto Bs = [&](int buf) -> float * { return lds + buf * (FA + FB) + FA; };
@@ -50,16 +49,20 @@ __global__ __launch_bounds__(kThreads, MH_MINW) void conv3x3_nhwc_kernel(const C
     const int n0 = (t % p.tiles_n) * BN;
     const long long Mtot = (long long)p.B * p.H * p.W;
 
-    // this thread's A row (fixed for the whole K loop): decode the pixel once
-    const long long pix = m0 + (tid % BM);
-    const bool row_ok = pix < Mtot;
-    int py = 0, px = 0;
-    if (row_ok) {
-        const int rem = (int)(pix % ((long long)p.H * p.W));
-        py = rem / p.W;
-        px = rem % p.W;
+    // this thread's A rows (fixed for the whole K loop): float4 f = tid + 256 j belongs to tile row f >> 2
+    constexpr int NVA = TileGeom<BM, true>::nv;
+    bool row_ok[NVA];
+    int py[NVA], px[NVA];
+    const float *in_row[NVA];
+#pragma unroll
+    for (int j = 0; j < NVA; ++j) {
+        const long long pix = m0 + ((tid + kThreads * j) >> 2);
+        row_ok[j] = pix < Mtot;
+        const int rem = (int)((row_ok[j] ? pix : 0) % ((long long)p.H * p.W));
+        py[j] = rem / p.W;
+        px[j] = rem % p.W;
+        in_row[j] = p.in + (size_t)(row_ok[j] ? pix : 0) * p.Cin + 4 * ((tid + kThreads * j) & 3);
     }
-    const float *in_row = p.in + (size_t)(row_ok ? pix : 0) * p.Cin;
 
     const int kt_per_tap = p.Cin / kBK;
     const int total_kt = 9 * kt_per_tap;
@@ -70,17 +73,20 @@ __global__ __launch_bounds__(kThreads, MH_MINW) void conv3x3_nhwc_kernel(const C
         const int tap = kt / kt_per_tap;
         const int c0 = (kt - tap * kt_per_tap) * kBK;
         const int dy = tap / 3 - 1, dx = tap % 3 - 1;
-        const bool ok = row_ok && (unsigned)(py + dy) < (unsigned)p.H && (unsigned)(px + dx) < (unsigned)p.W;
-        const float *ap = in_row + ((long long)dy * p.W + dx) * p.Cin + c0;
-        auto a_row = [&](int) -> const float * { return ok ? ap : nullptr; };
-        load_kc<BM, true>(sa, a_row, 0, kBK, true, tid, p.in);
+        const long long shift = ((long long)dy * p.W + dx) * p.Cin + c0;
+#pragma unroll
+        for (int j = 0; j < NVA; ++j) {
+            const bool ok = row_ok[j] && (unsigned)(py[j] + dy) < (unsigned)p.H && (unsigned)(px[j] + dx) < (unsigned)p.W;
+            const float4 v = *reinterpret_cast<const float4 *>(ok ? in_row[j] + shift : p.in);
+            sa.v[j] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
         const float *wtap = p.wt + ((size_t)tap * p.Cin + c0) * p.Cout;
         auto b_row = [&](int k) -> const float * { return wtap + (size_t)k * p.Cout; };
-        load_mc<BN, true>(sb, b_row, 0, n0, p.Cout, true, tid, p.wt);
+        load_km<BN, true>(sb, b_row, 0, n0, p.Cout, true, tid, p.wt);
     };
     auto store_tiles = [&](const Stage<BM> &sa, const Stage<BN> &sb, int buf) {
-        store_kc<BM>(sa, As(buf), tid);
-        store_mc<BN>(sb, Bs(buf), tid);
+        store_wm<BM>(sa, As(buf), tid);
+        store_km<BN>(sb, Bs(buf), tid);
     };
 
     Acc acc;
@@ -94,14 +100,14 @@ __global__ __launch_bounds__(kThreads, MH_MINW) void conv3x3_nhwc_kernel(const C
         const int cur = (kt - kt_begin) & 1;
         const bool more = (kt + 1 < kt_end);
         if (more) load_tiles(sa, sb, kt + 1);
-        mma_ktile<LDA, LDB>(As(cur), Bs(cur), wm, wn, lane, acc);
+        mma_ktile<true, false, BM, BN>(As(cur), Bs(cur), wm, wn, lane, acc);
         if (more) store_tiles(sa, sb, cur ^ 1);
         __syncthreads();
     }
 
     if (p.splitk > 1) {
         float *dst = p.partial + (size_t)blockIdx.y * Mtot * p.Cout;
-        acc_foreach_pair(acc, wm, wn, lane, [&](int r, int c, float v0, float v1) {
+        acc_foreach_pair<true, false>(acc, wm, wn, lane, [&](int r, int c, int, float v0, float v1) {
             const long long row = m0 + r;
             const int col = n0 + c;
             if (row >= Mtot || col >= p.Cout) return;
@@ -109,7 +115,7 @@ __global__ __launch_bounds__(kThreads, MH_MINW) void conv3x3_nhwc_kernel(const C
         });
         return;
     }
-    acc_foreach_pair(acc, wm, wn, lane, [&](int r, int c, float v0, float v1) {
+    acc_foreach_pair<true, false>(acc, wm, wn, lane, [&](int r, int c, int, float v0, float v1) {
         const long long row = m0 + r;
         const int col = n0 + c;
         if (row >= Mtot || col >= p.Cout) return;   // Cout % 4 == 0 -> col+1 is valid whenever col is

@@ -6,6 +6,13 @@
 
 #include "mfma_tile.h"
 
+#ifndef MH_DBG
+#define MH_DBG 0
+#endif
+#ifndef MH_STAGGER
+#define MH_STAGGER 0
+#endif
+
 namespace mh {
 
 struct GemmArgs {
@@ -34,8 +41,8 @@ __device__ __forceinline__ float apply_epi(float v, int epilogue)
 template <bool TA, bool TB, int BM, int BN, bool FAST>
 __global__ __launch_bounds__(kThreads, MH_MINW) void gemm_kernel(const GemmArgs p)
 {
-    constexpr int LDA = TileGeom<BM>::ld, LDB = TileGeom<BN>::ld;
-    constexpr int FA = TileGeom<BM>::floats, FB = TileGeom<BN>::floats;
+    constexpr bool AWM = !TA, BWM = TB;          // K-contiguous global storage -> width-major LDS tile
+    constexpr int FA = TileGeom<BM, AWM>::floats, FB = TileGeom<BN, BWM>::floats;
     __shared__ __attribute__((aligned(16))) float lds[2 * (FA + FB)];
     auto As = [&](int buf) -> float * { return lds + buf * (FA + FB); };
     auto Bs = [&](int buf) -> float * { return lds + buf * (FA + FB) + FA; };
@@ -50,7 +57,7 @@ __global__ __launch_bounds__(kThreads, MH_MINW) void gemm_kernel(const GemmArgs 
     const int kt_begin = z * p.ktiles_per_split;
     const int kt_end = min(total_kt, kt_begin + p.ktiles_per_split);
 
-    auto a_row = [&](int r) -> const float * {  // KC: r = tile row ; MC: r = k
+    auto a_row = [&](int r) -> const float * {  // WM: r = tile row ; KM: r = k
         if (TA) return (r < p.K) ? p.A + (size_t)r * p.lda : nullptr;
         return (m0 + r < p.M) ? p.A + (size_t)(m0 + r) * p.lda : nullptr;
     };
@@ -60,20 +67,28 @@ __global__ __launch_bounds__(kThreads, MH_MINW) void gemm_kernel(const GemmArgs 
     };
     auto load_tiles = [&](Stage<BM> &sa, Stage<BN> &sb, int kt) {
         const int k0 = kt * kBK;
-        if (TA) load_mc<BM, FAST>(sa, a_row, k0, m0, p.M, p.vecA != 0, tid, p.A);
-        else load_kc<BM, FAST>(sa, a_row, k0, p.K, p.vecA != 0, tid, p.A);
-        if (TB) load_kc<BN, FAST>(sb, b_row, k0, p.K, p.vecB != 0, tid, p.B);
-        else load_mc<BN, FAST>(sb, b_row, k0, n0, p.N, p.vecB != 0, tid, p.B);
+        if (TA) load_km<BM, FAST>(sa, a_row, k0, m0, p.M, p.vecA != 0, tid, p.A);
+        else load_wm<BM, FAST>(sa, a_row, k0, p.K, p.vecA != 0, tid, p.A);
+        if (TB) load_wm<BN, FAST>(sb, b_row, k0, p.K, p.vecB != 0, tid, p.B);
+        else load_km<BN, FAST>(sb, b_row, k0, n0, p.N, p.vecB != 0, tid, p.B);
     };
     auto store_tiles = [&](const Stage<BM> &sa, const Stage<BN> &sb, int buf) {
-        if (TA) store_mc<BM>(sa, As(buf), tid); else store_kc<BM>(sa, As(buf), tid);
-        if (TB) store_kc<BN>(sb, Bs(buf), tid); else store_mc<BN>(sb, Bs(buf), tid);
+        if (TA) store_km<BM>(sa, As(buf), tid); else store_wm<BM>(sa, As(buf), tid);
+        if (TB) store_wm<BN>(sb, Bs(buf), tid); else store_km<BN>(sb, Bs(buf), tid);
     };
 
     Acc acc;
     acc_zero(acc);
     Stage<BM> sa;
     Stage<BN> sb;
+#if MH_STAGGER
+    // co-resident blocks of a CU start in lockstep; offset their phases so that one block's load/LDS-write phase
+    // overlaps another's MFMA phase
+    {
+        const int slot = (blockIdx.x >> 8) & 3;
+        for (int q = 0; q < slot; ++q) __builtin_amdgcn_s_sleep(MH_STAGGER);
+    }
+#endif
     if (kt_begin < kt_end) {
         load_tiles(sa, sb, kt_begin);
         store_tiles(sa, sb, 0);
@@ -82,35 +97,47 @@ __global__ __launch_bounds__(kThreads, MH_MINW) void gemm_kernel(const GemmArgs 
     for (int kt = kt_begin; kt < kt_end; ++kt) {
         const int cur = (kt - kt_begin) & 1;
         const bool more = (kt + 1 < kt_end);
+#if MH_DBG == 1      /* timing experiment: no global loads / LDS writes / barrier in the loop */
+        mma_ktile<AWM, BWM, BM, BN>(As(0), Bs(0), wm, wn, lane, acc);
+#elif MH_DBG == 2    /* timing experiment: loads + writes but no barrier */
         if (more) load_tiles(sa, sb, kt + 1);
-        mma_ktile<LDA, LDB>(As(cur), Bs(cur), wm, wn, lane, acc);
+        mma_ktile<AWM, BWM, BM, BN>(As(cur), Bs(cur), wm, wn, lane, acc);
+        if (more) store_tiles(sa, sb, cur ^ 1);
+#elif MH_DBG == 3    /* timing experiment: global loads only (kept live), no LDS writes, no barrier */
+        if (more) load_tiles(sa, sb, kt + 1);
+        mma_ktile<AWM, BWM, BM, BN>(As(0), Bs(0), wm, wn, lane, acc);
+        asm volatile("" ::"v"(sa.v[0].x), "v"(sb.v[0].x));
+#else
+        if (more) load_tiles(sa, sb, kt + 1);
+        mma_ktile<AWM, BWM, BM, BN>(As(cur), Bs(cur), wm, wn, lane, acc);
         if (more) store_tiles(sa, sb, cur ^ 1);
         __syncthreads();
+#endif
     }
 
     if (p.splitk > 1) {
         float *dst = p.partial + (size_t)z * p.M * p.N;
-        const bool vec = (p.N % 2) == 0;
-        acc_foreach_pair(acc, wm, wn, lane, [&](int r, int c, float v0, float v1) {
-            const int row = m0 + r, col = n0 + c;
-            if (row >= p.M || col >= p.N) return;
-            float *q = dst + (size_t)row * p.N + col;
-            if (vec && col + 1 < p.N) *reinterpret_cast<float2 *>(q) = make_float2(v0, v1);
-            else { q[0] = v0; if (col + 1 < p.N) q[1] = v1; }
+        const bool vec = !BWM && (p.N % 2) == 0;
+        acc_foreach_pair<AWM, BWM>(acc, wm, wn, lane, [&](int r, int c0, int c1, float v0, float v1) {
+            const int row = m0 + r, col0 = n0 + c0, col1 = n0 + c1;
+            if (row >= p.M) return;
+            float *q = dst + (size_t)row * p.N;
+            if (vec && col1 < p.N) *reinterpret_cast<float2 *>(q + col0) = make_float2(v0, v1);
+            else { if (col0 < p.N) q[col0] = v0; if (col1 < p.N) q[col1] = v1; }
         });
         return;
     }
-    acc_foreach_pair(acc, wm, wn, lane, [&](int r, int c, float v0, float v1) {
-        const int row = m0 + r, col = n0 + c;
-        if (row >= p.M || col >= p.N) return;
-        const bool has1 = (col + 1 < p.N);
-        if (p.bias) { v0 += p.bias[col]; if (has1) v1 += p.bias[col + 1]; }
+    acc_foreach_pair<AWM, BWM>(acc, wm, wn, lane, [&](int r, int c0, int c1, float v0, float v1) {
+        const int row = m0 + r, col0 = n0 + c0, col1 = n0 + c1;
+        if (row >= p.M) return;
+        const bool has0 = (col0 < p.N), has1 = (col1 < p.N);
+        if (p.bias) { if (has0) v0 += p.bias[col0]; if (has1) v1 += p.bias[col1]; }
         v0 = apply_epi(v0, p.epilogue);
         v1 = apply_epi(v1, p.epilogue);
-        float *q = p.C + (size_t)row * p.ldc + col;
-        if (p.accumulate) { v0 += q[0]; if (has1) v1 += q[1]; }
-        if (p.vecC && has1) *reinterpret_cast<float2 *>(q) = make_float2(v0, v1);
-        else { q[0] = v0; if (has1) q[1] = v1; }
+        float *q = p.C + (size_t)row * p.ldc;
+        if (p.accumulate) { if (has0) v0 += q[col0]; if (has1) v1 += q[col1]; }
+        if (!BWM && p.vecC && has1) *reinterpret_cast<float2 *>(q + col0) = make_float2(v0, v1);
+        else { if (has0) q[col0] = v0; if (has1) q[col1] = v1; }
     });
 }
 

@@ -5,35 +5,38 @@
 //   128x128 (waves 2x2)  -- the default
 //   256x64  (waves 4x1)  -- for N <= 64 (the 64-channel VGG layer), so no MFMA issues on padding columns
 //
-// LDS layout (both operands "k-major"):  As[k][m], Bs[k][n], row stride = tile width + 4 floats.
-//   * operand register for one MFMA is ONE float per lane: lane l supplies A[i = l&31][k = l>>5].
-//   * the wave's 64 rows are interleaved over its two 32-row MFMA sub-tiles: tile row 2*i+s belongs to sub-tile
-//     s, so a lane fetches BOTH sub-tiles' operands with a single ds_read_b64 (a 32-lane group reads 256
-//     contiguous bytes: conflict-free), and in the epilogue holds two horizontally adjacent outputs -> 8-byte
-//     stores.  Same for B/columns.
-//   * K-contiguous global operands (activations, nn.Linear weights) are transposed while staging: a lane owns
-//     one tile row, loads float4s along k and issues conflict-free ds_write_b32 (consecutive lanes ->
-//     consecutive LDS words).
+// An operand tile lives in LDS in the orientation its GLOBAL storage has, so that staging is always a straight
+// 16-byte copy (global_load_dwordx4 -> ds_write_b128), never a transposing scatter:
+//   * "KM" (k-major, [k][w], row stride w+4): operands stored with the tile's row/column dimension contiguous
+//     (B of y = x*W when W is [K,N]; both operands of a weight gradient).  The wave's 64 rows are interleaved over
+//     its two 32-row MFMA sub-tiles (tile row 2i+s -> sub-tile s), so one ds_read_b64 feeds both sub-tiles.
+//   * "WM" (width-major, [w][k], row stride 16+4): operands stored K-contiguous (activations, nn.Linear weights,
+//     NHWC pixels).  Sub-tile s owns tile rows i+32s; a lane reads 4 consecutive k of its row with one
+//     ds_read_b128 (conflict-free at stride 20: the 16 lanes of a service group cover all 64 banks).
+// The k index of a tile is permuted consistently for both operands: MFMA lane group g = lane>>5 takes
+// k = 8g + step (step = 0..7), which is what makes the WM vector read possible (order of the fp32 summation over k
+// changes, nothing else).
+// Fragment reads are software-pipelined in two phases of 4 k-steps (reads of phase p+1 are issued before the 16
+// MFMAs of phase p; order pinned with sched_group_barrier) so the MFMA issue covers the LDS latency in-wave.
 // Accumulator (C/D) map of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5), r in [0,16).
 #pragma once
 #include "common.h"
 
-namespace mh {
-
-#ifndef MH_BK
-#define MH_BK 16
-#endif
 #ifndef MH_MINW
 #define MH_MINW 2
 #endif
-constexpr int kBK = MH_BK;
-constexpr int kThreads = 256;
 
-template <int WD>
+namespace mh {
+
+constexpr int kBK = 16;
+constexpr int kThreads = 256;
+constexpr int kLdW = kBK + 4;   // WM row stride (floats)
+
+template <int WD, bool WM>
 struct TileGeom {
-    static constexpr int ld = WD + 4;             // padded LDS row (floats); keeps 16-B alignment
-    static constexpr int floats = kBK * ld;       // one operand tile
-    static constexpr int nv = WD * kBK / 1024;    // float4 staged per thread (256 threads)
+    static constexpr int ld = WM ? kLdW : WD + 4;        // LDS row stride (floats); keeps 16-B alignment
+    static constexpr int floats = WM ? WD * kLdW : kBK * (WD + 4);
+    static constexpr int nv = WD * kBK / 1024;            // float4 staged per thread (256 threads)
 };
 
 struct Acc {
@@ -50,54 +53,88 @@ __device__ __forceinline__ void acc_zero(Acc &a)
             for (int r = 0; r < 16; ++r) a.v[i][j][r] = 0.f;
 }
 
-// One k-tile (kBK deep) of MFMAs for this wave.  wm/wn = wave's row/col offset inside the block tile.
-// MFMAs of k-steps [KK0, KK1) of the current k-tile (a k-step = 2 k values = one 32x32x2 MFMA per accumulator).
-// The fragment reads of step kk+1 are issued before the 4 MFMAs of step kk and the order is pinned with
-// sched_group_barrier, so the 4 x 64-cycle MFMA issue of one step covers the LDS latency of the next inside the SAME
-// wave (the compiler otherwise batches [reads, wait, 8 MFMAs] and exposes the LDS latency four times per k-tile).
-template <int LDA, int LDB, int KK0, int KK1>
-__device__ __forceinline__ void mma_ksteps(const float *__restrict__ As, const float *__restrict__ Bs, int wm, int wn,
-                                           int lane, Acc &acc)
+// Per-lane operand fragments of one k-tile.  WM: two float4 per phase of 4 k-steps (sub-tiles s = 0,1);
+// KM: one float2 per k-step (x = sub-tile 0, y = sub-tile 1).
+template <bool WM>
+struct FragBuf;
+template <>
+struct FragBuf<true> {
+    float4 v[2][2];   // [phase parity][sub-tile]
+};
+template <>
+struct FragBuf<false> {
+    float2 v[kBK / 2];   // one register pair per k-step (no reuse inside a k-tile: lets the waits be counted exactly)
+};
+
+// issue the LDS reads that provide k-step `kk`; returns the number of DS instructions issued (compile-time folded)
+template <int WD>
+__device__ __forceinline__ int frag_fetch(FragBuf<true> &f, const float *__restrict__ tile, int w0, int lane, int kk)
 {
-    const int i = lane & 31, g = lane >> 5;
-    const float *ap = As + g * LDA + wm + 2 * i;
-    const float *bp = Bs + g * LDB + wn + 2 * i;
-    float2 a = *reinterpret_cast<const float2 *>(ap + 2 * KK0 * LDA);
-    float2 b = *reinterpret_cast<const float2 *>(bp + 2 * KK0 * LDB);
-#pragma unroll
-    for (int kk = KK0; kk < KK1; ++kk) {
-        float2 an = a, bn = b;
-        if (kk + 1 < KK1) {
-            an = *reinterpret_cast<const float2 *>(ap + 2 * (kk + 1) * LDA);
-            bn = *reinterpret_cast<const float2 *>(bp + 2 * (kk + 1) * LDB);
-        }
-        acc.v[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc.v[0][0], 0, 0, 0);
-        acc.v[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.y, acc.v[0][1], 0, 0, 0);
-        acc.v[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.x, acc.v[1][0], 0, 0, 0);
-        acc.v[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc.v[1][1], 0, 0, 0);
-        a = an;
-        b = bn;
-        if (kk + 1 < KK1) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);   // 2 LDS reads (step kk+1)
-        __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);                       // 4 MFMAs   (step kk)
-    }
+    if (kk % 4 != 0) return 0;
+    const float *p = tile + (w0 + (lane & 31)) * kLdW + 8 * (lane >> 5) + kk;
+    f.v[(kk / 4) & 1][0] = *reinterpret_cast<const float4 *>(p);
+    f.v[(kk / 4) & 1][1] = *reinterpret_cast<const float4 *>(p + 32 * kLdW);
+    return 2;
+}
+template <int WD>
+__device__ __forceinline__ int frag_fetch(FragBuf<false> &f, const float *__restrict__ tile, int w0, int lane, int kk)
+{
+    constexpr int ld = TileGeom<WD, false>::ld;
+    f.v[kk] = *reinterpret_cast<const float2 *>(tile + (8 * (lane >> 5) + kk) * ld + w0 + 2 * (lane & 31));
+    return 1;
+}
+__device__ __forceinline__ float frag_get(const FragBuf<true> &f, int kk, int s)
+{
+    const float4 &x = f.v[(kk / 4) & 1][s];
+    return (kk % 4 == 0) ? x.x : (kk % 4 == 1) ? x.y : (kk % 4 == 2) ? x.z : x.w;
+}
+__device__ __forceinline__ float frag_get(const FragBuf<false> &f, int kk, int s)
+{
+    return s == 0 ? f.v[kk].x : f.v[kk].y;
 }
 
-template <int LDA, int LDB>
+// All MFMAs of one k-tile for this wave.  wm/wn = the wave's row/col origin inside the block tile.
+// The LDS reads for k-step kk+1 are issued before the 4 MFMAs of step kk and the order is pinned with
+// sched_group_barrier, so the 4 x 64-cycle MFMA issue covers the LDS latency inside the SAME wave.
+template <bool AWM, bool BWM, int BM, int BN>
 __device__ __forceinline__ void mma_ktile(const float *__restrict__ As, const float *__restrict__ Bs, int wm, int wn,
                                           int lane, Acc &acc)
 {
-    mma_ksteps<LDA, LDB, 0, kBK / 2>(As, Bs, wm, wn, lane, acc);
+    FragBuf<AWM> a;
+    FragBuf<BWM> b;
+    frag_fetch<BM>(a, As, wm, lane, 0);
+    frag_fetch<BN>(b, Bs, wn, lane, 0);
+    __builtin_amdgcn_sched_group_barrier(0x100, (AWM ? 2 : 1) + (BWM ? 2 : 1), 0);   // the prologue reads form group 0
+#pragma unroll
+    for (int kk = 0; kk < kBK / 2; ++kk) {
+        int nreads = 0;
+        if (kk + 1 < kBK / 2) {
+            nreads += frag_fetch<BM>(a, As, wm, lane, kk + 1);
+            nreads += frag_fetch<BN>(b, Bs, wn, lane, kk + 1);
+        }
+        const float a0 = frag_get(a, kk, 0), a1 = frag_get(a, kk, 1);
+        const float b0 = frag_get(b, kk, 0), b1 = frag_get(b, kk, 1);
+        acc.v[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc.v[0][0], 0, 0, 0);
+        acc.v[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc.v[0][1], 0, 0, 0);
+        acc.v[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc.v[1][0], 0, 0, 0);
+        acc.v[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc.v[1][1], 0, 0, 0);
+        if (nreads == 1) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        if (nreads == 2) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+        if (nreads == 3) __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+        if (nreads == 4) __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+    }
 }
 
 // Staging registers for one operand k-tile of width WD: WD/64 float4 per thread.
 template <int WD>
 struct Stage {
-    float4 v[TileGeom<WD>::nv];
+    float4 v[WD * kBK / 1024];
 };
 
 // FAST = operands are 16-B aligned with the contiguous extent a multiple of 4 (checked on the host): every float4
-// is entirely inside or entirely outside the matrix, so the load is issued UNCONDITIONALLY from a clamped
-// address and zeroed by a select -- no exec-masked branches, the k-tile's loads all stay in flight together.
+// is entirely inside or entirely outside the matrix, so the load is issued from a clamped address and zeroed by a
+// select -- no per-element exec-masked branches, the k-tile's loads all stay in flight together.
 template <bool FAST>
 __device__ __forceinline__ float4 load4_guarded(const float *p, int c, int extent, bool vec, const float *safe)
 {
@@ -116,72 +153,78 @@ __device__ __forceinline__ float4 load4_guarded(const float *p, int c, int exten
     return v;
 }
 
-// ---- "MC" operand: stored k-major in global memory (row = k, contiguous along the tile's m/n dimension).
+// ---- KM operand: global rows are k (contiguous along the tile's w dimension).
 // tile = kBK rows x WD floats; float4 f = tid + 256*j sits at (row f / (WD/4), float4-column f % (WD/4)).
 // row_ptr(k) returns the address of matrix element (k, 0) or nullptr when row k is all-zero / out of range;
 // `col0` = first tile column in the matrix, `ncols` = matrix extent along the contiguous dimension.
 template <int WD, bool FAST, typename RowPtr>
-__device__ __forceinline__ void load_mc(Stage<WD> &s, RowPtr row_ptr, int k0, int col0, int ncols, bool vec, int tid,
+__device__ __forceinline__ void load_km(Stage<WD> &s, RowPtr row_ptr, int k0, int col0, int ncols, bool vec, int tid,
                                         const float *safe)
 {
     constexpr int c4n = WD / 4;
 #pragma unroll
-    for (int j = 0; j < TileGeom<WD>::nv; ++j) {
+    for (int j = 0; j < TileGeom<WD, false>::nv; ++j) {
         const int f = tid + kThreads * j;
         s.v[j] = load4_guarded<FAST>(row_ptr(k0 + f / c4n), col0 + 4 * (f % c4n), ncols, vec, safe);
     }
 }
 
 template <int WD>
-__device__ __forceinline__ void store_mc(const Stage<WD> &s, float *tile, int tid)
+__device__ __forceinline__ void store_km(const Stage<WD> &s, float *tile, int tid)
 {
     constexpr int c4n = WD / 4;
 #pragma unroll
-    for (int j = 0; j < TileGeom<WD>::nv; ++j) {
+    for (int j = 0; j < TileGeom<WD, false>::nv; ++j) {
         const int f = tid + kThreads * j;
-        *reinterpret_cast<float4 *>(tile + (f / c4n) * TileGeom<WD>::ld + 4 * (f % c4n)) = s.v[j];
+        *reinterpret_cast<float4 *>(tile + (f / c4n) * TileGeom<WD, false>::ld + 4 * (f % c4n)) = s.v[j];
     }
 }
 
-// ---- "KC" operand: stored row-major with k contiguous (row = tile row m/n).  Thread t owns tile row t % WD and
-// the 4*nv consecutive k values starting at 4*nv*(t / WD).  row_ptr(r) returns the address of element (r, k = 0)
-// or nullptr when the row is out of range / zero; `kext` = matrix extent along k.
+// ---- WM operand: global rows are the tile's w dimension (k contiguous).  float4 f = tid + 256*j belongs to tile
+// row f / 4, k-quad f % 4: four consecutive lanes read one row's 64 contiguous bytes.
+// row_ptr(r) returns the address of element (r, k = 0) or nullptr when the row is out of range / zero;
+// `kext` = matrix extent along k.
 template <int WD, bool FAST, typename RowPtr>
-__device__ __forceinline__ void load_kc(Stage<WD> &s, RowPtr row_ptr, int k0, int kext, bool vec, int tid,
+__device__ __forceinline__ void load_wm(Stage<WD> &s, RowPtr row_ptr, int k0, int kext, bool vec, int tid,
                                         const float *safe)
 {
-    const float *p = row_ptr(tid % WD);
-    const int k = k0 + 4 * TileGeom<WD>::nv * (tid / WD);
 #pragma unroll
-    for (int j = 0; j < TileGeom<WD>::nv; ++j) s.v[j] = load4_guarded<FAST>(p, k + 4 * j, kext, vec, safe);
+    for (int j = 0; j < TileGeom<WD, true>::nv; ++j) {
+        const int f = tid + kThreads * j;
+        s.v[j] = load4_guarded<FAST>(row_ptr(f >> 2), k0 + 4 * (f & 3), kext, vec, safe);
+    }
 }
 
 template <int WD>
-__device__ __forceinline__ void store_kc(const Stage<WD> &s, float *tile, int tid)
+__device__ __forceinline__ void store_wm(const Stage<WD> &s, float *tile, int tid)
 {
-    constexpr int ld = TileGeom<WD>::ld;
-    float *base = tile + (4 * TileGeom<WD>::nv * (tid / WD)) * ld + (tid % WD);
 #pragma unroll
-    for (int j = 0; j < TileGeom<WD>::nv; ++j) {
-        base[(4 * j + 0) * ld] = s.v[j].x;
-        base[(4 * j + 1) * ld] = s.v[j].y;
-        base[(4 * j + 2) * ld] = s.v[j].z;
-        base[(4 * j + 3) * ld] = s.v[j].w;
+    for (int j = 0; j < TileGeom<WD, true>::nv; ++j) {
+        const int f = tid + kThreads * j;
+        *reinterpret_cast<float4 *>(tile + (f >> 2) * kLdW + 4 * (f & 3)) = s.v[j];
     }
 }
 
-// Epilogue visitor: calls f(row, col, v0, v1) for every pair of horizontally adjacent outputs this lane holds
-// (row/col relative to the block tile; v0 at col, v1 at col+1).
-template <typename F>
+// tile row (or column) held by MFMA index idx (0..31) of sub-tile s, for the two operand layouts
+template <bool WM>
+__device__ __forceinline__ int tile_coord(int idx, int s)
+{
+    return WM ? idx + 32 * s : 2 * idx + s;
+}
+
+// Epilogue visitor: calls f(row, col0, col1, v0, v1) for the two outputs (sub-tile columns sn = 0,1) this lane holds
+// in tile row `row` (all relative to the block tile).  With a KM B operand col1 == col0 + 1 (8-byte stores).
+template <bool AWM, bool BWM, typename F>
 __device__ __forceinline__ void acc_foreach_pair(const Acc &acc, int wm, int wn, int lane, F f)
 {
     const int j = lane & 31, g = lane >> 5;
+    const int c0 = wn + tile_coord<BWM>(j, 0), c1 = wn + tile_coord<BWM>(j, 1);
 #pragma unroll
     for (int sm = 0; sm < 2; ++sm)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int ri = (r & 3) + 8 * (r >> 2) + 4 * g;
-            f(wm + 2 * ri + sm, wn + 2 * j, acc.v[sm][0][r], acc.v[sm][1][r]);
+            f(wm + tile_coord<AWM>(ri, sm), c0, c1, acc.v[sm][0][r], acc.v[sm][1][r]);
         }
 }
 
@@ -204,11 +247,9 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblocks)
     return start + idx;
 }
 
-}  // namespace mh
-
-namespace mh {
 // defined in gemm.hip
 int choose_splitk_tiles(long long tiles, int ktiles, double out_elems, double flops);
 int launch_splitk_reduce(const float *partial, int splitk, long long M, int N, float *C, int ldc, const float *bias,
                          int epilogue, int accumulate, hipStream_t st);
+
 }  // namespace mh
