@@ -94,7 +94,8 @@ _ws_cache = {}
 def workspace(nbytes, device, tag='default'):
     """Grow-only scratch buffer per (device, tag).  All users are ordered on the current stream."""
     nbytes = max(int(nbytes), 256)
-    key = (str(device), tag)
+    # one buffer per (device, purpose, stream): kernels enqueued on different HIP streams may run concurrently
+    key = (str(device), tag, torch.cuda.current_stream().cuda_stream if torch.cuda.is_available() else 0)
     buf = _ws_cache.get(key)
     if buf is None or buf.numel() < nbytes:
         buf = torch.empty(int(nbytes * 1.25) + 256, dtype=torch.uint8, device=device)
