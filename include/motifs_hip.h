@@ -31,6 +31,10 @@ extern "C" {
 #define MH_EPI_RELU6 2
 
 int mh_version(void);
+/* how the fp32 matrix products of mh_gemm_* / mh_conv3x3_* are evaluated in this build:
+ * 6 = bf16x6 (exact 3-way bf16 split of both operands, six bf16 MFMAs, fp32 accumulate; default),
+ * 0 = f32-input MFMA (exact fp32 fma chain), 3 = bf16x3 (2^-17 products; experiments only). */
+int mh_mfma_split(void);
 /* name of the last kernel-launch error on this thread (for diagnostics), or "" */
 const char *mh_last_error(void);
 

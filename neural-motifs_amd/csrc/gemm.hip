@@ -209,6 +209,8 @@ using namespace mh;
 
 extern "C" {
 
+int mh_mfma_split(void) { return MH_MFMA_SPLIT; }
+
 int mh_gemm_auto_splitk(int M, int N, int K) { return (M > 0 && N > 0 && K > 0) ? choose_splitk(M, N, K) : 1; }
 
 size_t mh_gemm_ws_bytes(int M, int N, int K, int splitk)

@@ -1,12 +1,17 @@
-// mfma_tile.h -- the shared FP32 MFMA block-tile engine (gfx950), block tile BM x BN x 16.
+// mfma_tile.h -- the shared fp32 matrix-core block-tile engine (gfx950), block tile BM x BN x 16.
 //
-// One workgroup = 256 threads = 4 waves; each wave owns a 64x64 output tile held as 2x2 accumulators of
-// v_mfma_f32_32x32x2_f32 (16 VGPRs each, exact fp32 fma chain, 64 cycles/SIMD).  Two block shapes are used:
+// One workgroup = 256 threads = 4 waves; each wave owns a 64x64 output tile held as 2x2 32x32 fp32 accumulators
+// (16 VGPRs each).  Two block shapes are used:
 //   128x128 (waves 2x2)  -- the default
 //   256x64  (waves 4x1)  -- for N <= 64 (the 64-channel VGG layer), so no MFMA issues on padding columns
+// Two interchangeable inner loops compute the same fp32 result (selected at build time, MH_MFMA_SPLIT):
+//   6 (default): "bf16x6" -- each fp32 operand is split exactly into three bf16 terms in registers and six
+//      v_mfma_f32_32x32x16_bf16 accumulate the cross terms in fp32 (see below): 6/16 of the matrix-core time of
+//   0: v_mfma_f32_32x32x2_f32, the f32-input MFMA (an exact fp32 fma chain, 64 cycles per 2 k).
+// Measured error against fp64 is the same for both (tools/gemm_accuracy.py).
 //
-// An operand tile lives in LDS in the orientation its GLOBAL storage has, so that staging is always a straight
-// 16-byte copy (global_load_dwordx4 -> ds_write_b128), never a transposing scatter:
+// An operand tile lives in LDS as fp32 in the orientation its GLOBAL storage has, so that staging is always a
+// straight 16-byte copy (global_load_dwordx4 -> ds_write_b128), never a transposing scatter:
 //   * "KM" (k-major, [k][w], row stride w+4): operands stored with the tile's row/column dimension contiguous
 //     (B of y = x*W when W is [K,N]; both operands of a weight gradient).  The wave's 64 rows are interleaved over
 //     its two 32-row MFMA sub-tiles (tile row 2i+s -> sub-tile s), so one ds_read_b64 feeds both sub-tiles.
@@ -14,16 +19,19 @@
 //     NHWC pixels).  Sub-tile s owns tile rows i+32s; a lane reads 4 consecutive k of its row with one
 //     ds_read_b128 (conflict-free at stride 20: the 16 lanes of a service group cover all 64 banks).
 // The k index of a tile is permuted consistently for both operands: MFMA lane group g = lane>>5 takes
-// k = 8g + step (step = 0..7), which is what makes the WM vector read possible (order of the fp32 summation over k
-// changes, nothing else).
-// Fragment reads are software-pipelined in two phases of 4 k-steps (reads of phase p+1 are issued before the 16
-// MFMAs of phase p; order pinned with sched_group_barrier) so the MFMA issue covers the LDS latency in-wave.
+// k = 8g + step (step = 0..7): the f32 loop runs 8 steps of 2 k, the bf16 loop consumes the lane's 8 k at once
+// (order of the fp32 summation over k changes, nothing else).
+// In the f32 loop the LDS reads of step kk+1 are issued before the 4 MFMAs of step kk (order pinned with
+// sched_group_barrier) so the MFMA issue covers the LDS latency in-wave.
 // Accumulator (C/D) map of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5), r in [0,16).
 #pragma once
 #include "common.h"
 
 #ifndef MH_MINW
 #define MH_MINW 2
+#endif
+#ifndef MH_MFMA_SPLIT
+#define MH_MFMA_SPLIT 6   /* 6: bf16x6 split (fp32-accurate, default); 0: f32-input MFMA; 3: bf16x3 (2^-17, tests only) */
 #endif
 
 namespace mh {
@@ -97,7 +105,7 @@ __device__ __forceinline__ float frag_get(const FragBuf<false> &f, int kk, int s
 // The LDS reads for k-step kk+1 are issued before the 4 MFMAs of step kk and the order is pinned with
 // sched_group_barrier, so the 4 x 64-cycle MFMA issue covers the LDS latency inside the SAME wave.
 template <bool AWM, bool BWM, int BM, int BN>
-__device__ __forceinline__ void mma_ktile(const float *__restrict__ As, const float *__restrict__ Bs, int wm, int wn,
+__device__ __forceinline__ void mma_ktile_f32(const float *__restrict__ As, const float *__restrict__ Bs, int wm, int wn,
                                           int lane, Acc &acc)
 {
     FragBuf<AWM> a;
@@ -124,6 +132,115 @@ __device__ __forceinline__ void mma_ktile(const float *__restrict__ As, const fl
         if (nreads == 4) __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
         __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
     }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// FP32-accurate products on the BF16 matrix cores ("bf16x6").
+// gfx950's v_mfma_f32_32x32x16_bf16 retires 16 k per 32 cycles, the f32-input MFMA 2 k per 64 cycles: 16x the rate.
+// An fp32 number splits EXACTLY into three bf16 terms by truncation, a = a1 + a2 + a3 with 8 mantissa bits each
+// (a1 = top 16 bits of a; r = a - a1 is exact; a2 = top 16 bits of r; a3 = r - a2 has <= 8 significant bits), a
+// bf16 x bf16 product is exact in fp32, and the MFMA accumulates in fp32.  Keeping the six cross terms down to
+// 2^-24 relative magnitude,
+//     a*b = a1b1 + (a1b2 + a2b1) + (a1b3 + a3b1 + a2b2) + O(2^-27 |ab|),
+// gives products accurate to fp32 rounding at 6/16 of the f32-MFMA matrix-core time (MH_MFMA_SPLIT == 6); the first
+// three terms alone (== 3) are accurate to 2^-17.  The LDS tiles, staging and epilogue are unchanged: a lane's
+// operand for the K=16 instruction is 8 consecutive k of its row -- exactly the k = 8g + step permutation above.
+// ---------------------------------------------------------------------------------------------------------------
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+
+struct SplitFrag {
+    bf16x8 p[3];   // hi, mid, lo planes of 8 consecutive k
+};
+
+// 8 fp32 -> three bf16x8 planes (exact truncation split)
+__device__ __forceinline__ void split8(const float (&x)[8], SplitFrag &f)
+{
+    unsigned h[8], m[8], l[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const unsigned xb = __builtin_bit_cast(unsigned, x[i]);
+        const unsigned hb = xb & 0xffff0000u;
+        const float r1 = x[i] - __builtin_bit_cast(float, hb);
+        const unsigned r1b = __builtin_bit_cast(unsigned, r1);
+        const unsigned mb = r1b & 0xffff0000u;
+        const float r2 = r1 - __builtin_bit_cast(float, mb);
+        h[i] = hb; m[i] = mb; l[i] = __builtin_bit_cast(unsigned, r2);
+    }
+    unsigned ph[4], pm[4], pl[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {   // element 2i in the low half, 2i+1 in the high half
+        ph[i] = (h[2 * i] >> 16) | (h[2 * i + 1] & 0xffff0000u);
+        pm[i] = (m[2 * i] >> 16) | (m[2 * i + 1] & 0xffff0000u);
+        pl[i] = (l[2 * i] >> 16) | (l[2 * i + 1] & 0xffff0000u);
+    }
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    f.p[0] = __builtin_bit_cast(bf16x8, (u32x4){ph[0], ph[1], ph[2], ph[3]});
+    f.p[1] = __builtin_bit_cast(bf16x8, (u32x4){pm[0], pm[1], pm[2], pm[3]});
+    f.p[2] = __builtin_bit_cast(bf16x8, (u32x4){pl[0], pl[1], pl[2], pl[3]});
+}
+
+// fetch the 8 k-values (k = 8g .. 8g+7) of this lane's row for both sub-tiles and split them
+template <bool WM, int WD>
+__device__ __forceinline__ void fetch_split(SplitFrag (&f)[2], const float *__restrict__ tile, int w0, int lane)
+{
+    const int i = lane & 31, g = lane >> 5;
+    float x[2][8];
+    if (WM) {
+        const float *p = tile + (w0 + i) * kLdW + 8 * g;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const float4 lo = *reinterpret_cast<const float4 *>(p + 32 * s * kLdW);
+            const float4 hi = *reinterpret_cast<const float4 *>(p + 32 * s * kLdW + 4);
+            x[s][0] = lo.x; x[s][1] = lo.y; x[s][2] = lo.z; x[s][3] = lo.w;
+            x[s][4] = hi.x; x[s][5] = hi.y; x[s][6] = hi.z; x[s][7] = hi.w;
+        }
+    } else {
+        constexpr int ld = TileGeom<WD, false>::ld;
+        const float *p = tile + (8 * g) * ld + w0 + 2 * i;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const float2 v = *reinterpret_cast<const float2 *>(p + q * ld);
+            x[0][q] = v.x;
+            x[1][q] = v.y;
+        }
+    }
+    split8(x[0], f[0]);
+    split8(x[1], f[1]);
+}
+
+template <bool AWM, bool BWM, int BM, int BN>
+__device__ __forceinline__ void mma_ktile_split(const float *__restrict__ As, const float *__restrict__ Bs, int wm,
+                                                int wn, int lane, Acc &acc)
+{
+    SplitFrag a[2], b[2];
+    fetch_split<AWM, BM>(a, As, wm, lane);
+    fetch_split<BWM, BN>(b, Bs, wn, lane);
+#pragma unroll
+    for (int sm = 0; sm < 2; ++sm)
+#pragma unroll
+        for (int sn = 0; sn < 2; ++sn) {
+            f32x16 c = acc.v[sm][sn];
+#if MH_MFMA_SPLIT >= 6
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[sm].p[2], b[sn].p[0], c, 0, 0, 0);   // smallest terms first
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[sm].p[0], b[sn].p[2], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[sm].p[1], b[sn].p[1], c, 0, 0, 0);
+#endif
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[sm].p[1], b[sn].p[0], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[sm].p[0], b[sn].p[1], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[sm].p[0], b[sn].p[0], c, 0, 0, 0);
+            acc.v[sm][sn] = c;
+        }
+}
+
+template <bool AWM, bool BWM, int BM, int BN>
+__device__ __forceinline__ void mma_ktile(const float *__restrict__ As, const float *__restrict__ Bs, int wm, int wn,
+                                          int lane, Acc &acc)
+{
+#if MH_MFMA_SPLIT
+    mma_ktile_split<AWM, BWM, BM, BN>(As, Bs, wm, wn, lane, acc);
+#else
+    mma_ktile_f32<AWM, BWM, BM, BN>(As, Bs, wm, wn, lane, acc);
+#endif
 }
 
 // Staging registers for one operand k-tile of width WD: WD/64 float4 per thread.

@@ -16,7 +16,7 @@ SO_PATH = os.path.join(os.path.dirname(_HERE), 'csrc', 'libmotifs_hip.so')
 
 # every symbol include/motifs_hip.h declares (checked by tests/test_cabi.py against the header)
 SYMBOLS = (
-    'mh_version', 'mh_last_error',
+    'mh_version', 'mh_mfma_split', 'mh_last_error',
     'mh_nms_ws_bytes', 'mh_nms', 'mh_nms_batched_ws_bytes', 'mh_nms_batched',
     'mh_roi_align_fwd', 'mh_roi_align_bwd', 'mh_draw_union_boxes', 'mh_bbox_overlaps',
     'mh_gemm_ws_bytes', 'mh_gemm_auto_splitk', 'mh_gemm_f32',

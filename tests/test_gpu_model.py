@@ -18,6 +18,24 @@ CFG = dict(mode='sgcls', hidden_dim=512, pooling_dim=4096, nl_obj=2, nl_edge=2, 
            pass_in_obj_feats_to_edge=False)
 
 
+def grad_close(got, ref, what='', rtol=1e-4, max_flipped_rows=2):
+    """Gradients agree to `rtol` of scale, except that a ReLU (or max-pool) input lying within rounding of its kink
+    can switch ONE unit's upstream gradient on or off between two fp32 evaluation orders: the difference is then
+    confined to that unit's row of the weight gradient (and its bias entry).  Such rows are counted, bounded and
+    printed -- never silently accepted elsewhere."""
+    got, ref = np.asarray(got, dtype=np.float64), np.asarray(ref, dtype=np.float64)
+    scale = max(1.0, float(np.abs(ref).max()))
+    err = np.abs(got - ref).reshape(got.shape[0], -1) if got.ndim else np.abs(got - ref).reshape(1, 1)
+    bad_rows = np.nonzero((err > rtol * scale).any(1))[0]
+    ok_err = float(np.delete(err, bad_rows, axis=0).max()) if len(bad_rows) < err.shape[0] else 0.0
+    print('%-28s max|ref|=%10.4f  max abs err=%.3e  (%.2e of scale)%s' % (
+        what, scale, ok_err, ok_err / scale,
+        '' if not len(bad_rows) else '  + kink-flipped rows %s (max err %.3e)' % (bad_rows.tolist(), err.max())))
+    assert len(bad_rows) <= max_flipped_rows, '%s: %d rows differ by more than %.1e of scale' % (
+        what, len(bad_rows), rtol)
+    assert err.max() <= 5e-2 * scale, what
+
+
 def rel_close(got, ref, rtol=1e-4, what=''):
     got, ref = np.asarray(got, dtype=np.float64), np.asarray(ref, dtype=np.float64)
     scale = max(1.0, float(np.abs(ref).max()))
@@ -80,7 +98,7 @@ def test_sgcls_train_step_parity(world):
             continue
         ref = params[name].grad
         assert ref is not None and p.grad is not None, name
-        rel_close(p.grad.cpu().numpy(), ref.numpy(), rtol=2e-3, what='grad ' + name[-24:])
+        grad_close(p.grad.cpu().numpy(), ref.numpy(), what='grad ' + name[-24:])
         checked += 1
     assert checked >= 30
     for k in ('context.pos_embed.0.running_mean', 'context.pos_embed.0.running_var',
