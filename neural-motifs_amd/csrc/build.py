@@ -39,7 +39,7 @@ def build(force=False, verbose=False):
                    '-Wall', '-Wno-unused-function']
             if src in EXACT:
                 cmd += ['-ffp-contract=off']
-            for knob in ('MH_BK', 'MH_MINW', 'MH_DBG', 'MH_STAGGER', 'MH_MFMA_SPLIT'):
+            for knob in ('MH_MINW', 'MH_MFMA_SPLIT', 'MH_SPLIT_AT_STAGE', 'MH_DBG'):
                 if os.environ.get(knob):
                     cmd += ['-D%s=%s' % (knob, os.environ[knob])]
             if verbose:

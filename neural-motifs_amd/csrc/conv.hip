@@ -8,6 +8,7 @@
 // The same kernel computes dgrad when given flip-transposed weights (mh_conv3x3_pack_weight).
 #include <algorithm>
 
+#include <type_traits>
 #include "mfma_tile.h"
 
 namespace mh {
@@ -36,7 +37,7 @@ template <int BM, int BN>
 __global__ __launch_bounds__(kThreads, MH_MINW) void conv3x3_nhwc_kernel(const ConvArgs p)
 {
     constexpr int FA = TileGeom<BM, true>::floats, FB = TileGeom<BN, false>::floats;   // A: NHWC pixels (WM), B: KM
-    __shared__ __attribute__((aligned(16))) float lds[2 * (FA + FB)];
+    extern __shared__ __attribute__((aligned(16))) float lds[];   // 2 x (FA + FB) floats, see launch_tile_kernel
     auto As = [&](int buf) -> float * { return lds + buf * (FA + FB); };
     auto Bs = [&](int buf) -> float * { return lds + buf * (FA + FB) + FA; };
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -49,19 +50,23 @@ __global__ __launch_bounds__(kThreads, MH_MINW) void conv3x3_nhwc_kernel(const C
     const int n0 = (t % p.tiles_n) * BN;
     const long long Mtot = (long long)p.B * p.H * p.W;
 
-    // this thread's A rows (fixed for the whole K loop): float4 f = tid + 256 j belongs to tile row f >> 2
+    // this thread's A rows (fixed for the whole K loop): float4 f = tid + 256 j belongs to tile row f >> 2.
+    // A is addressed relative to a block origin one halo (W+1 pixels) before the tile's first pixel, so every tap of
+    // every valid pixel has a small non-negative 32-bit offset whatever the size of the input tensor.
     constexpr int NVA = TileGeom<BM, true>::nv;
+    const int halo = (p.W + 1) * p.Cin;
+    const GSrc ga = make_gsrc(p.in + (ptrdiff_t)m0 * p.Cin - halo), gb = make_gsrc(p.wt);
     bool row_ok[NVA];
-    int py[NVA], px[NVA];
-    const float *in_row[NVA];
+    int py[NVA], px[NVA], in_off[NVA];
 #pragma unroll
     for (int j = 0; j < NVA; ++j) {
-        const long long pix = m0 + ((tid + kThreads * j) >> 2);
+        const int r = (tid + kThreads * j) >> 2;
+        const long long pix = m0 + r;
         row_ok[j] = pix < Mtot;
         const int rem = (int)((row_ok[j] ? pix : 0) % ((long long)p.H * p.W));
         py[j] = rem / p.W;
         px[j] = rem % p.W;
-        in_row[j] = p.in + (size_t)(row_ok[j] ? pix : 0) * p.Cin + 4 * ((tid + kThreads * j) & 3);
+        in_off[j] = halo + r * p.Cin + 4 * ((tid + kThreads * j) & 3);
     }
 
     const int kt_per_tap = p.Cin / kBK;
@@ -69,20 +74,21 @@ __global__ __launch_bounds__(kThreads, MH_MINW) void conv3x3_nhwc_kernel(const C
     const int kt_begin = blockIdx.y * p.ktiles_per_split;
     const int kt_end = min(total_kt, kt_begin + p.ktiles_per_split);
 
-    auto load_tiles = [&](Stage<BM> &sa, Stage<BN> &sb, int kt) {
+    // `live` = false: every load becomes a zero-returning out-of-range access (see gemm_kernel)
+    auto load_tiles = [&](Stage<BM> &sa, Stage<BN> &sb, int kt, bool live) {
         const int tap = kt / kt_per_tap;
         const int c0 = (kt - tap * kt_per_tap) * kBK;
         const int dy = tap / 3 - 1, dx = tap % 3 - 1;
-        const long long shift = ((long long)dy * p.W + dx) * p.Cin + c0;
+        const int shift = (dy * p.W + dx) * p.Cin + c0;
 #pragma unroll
         for (int j = 0; j < NVA; ++j) {
-            const bool ok = row_ok[j] && (unsigned)(py[j] + dy) < (unsigned)p.H && (unsigned)(px[j] + dx) < (unsigned)p.W;
-            const float4 v = *reinterpret_cast<const float4 *>(ok ? in_row[j] + shift : p.in);
-            sa.v[j] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+            const bool ok = live && row_ok[j] && (unsigned)(py[j] + dy) < (unsigned)p.H &&
+                            (unsigned)(px[j] + dx) < (unsigned)p.W;
+            sa.v[j] = buffer_load4(ga, ok ? (unsigned)(in_off[j] + shift) * 4u : kOobOffset);
         }
         const float *wtap = p.wt + ((size_t)tap * p.Cin + c0) * p.Cout;
-        auto b_row = [&](int k) -> const float * { return wtap + (size_t)k * p.Cout; };
-        load_km<BN, true>(sb, b_row, 0, n0, p.Cout, true, tid, p.wt);
+        auto b_row = [&](int k) -> const float * { return live ? wtap + (size_t)k * p.Cout : nullptr; };
+        load_km<BN, true>(sb, b_row, 0, n0, p.Cout, true, tid, gb);
     };
     auto store_tiles = [&](const Stage<BM> &sa, const Stage<BN> &sb, int buf) {
         store_wm<BM>(sa, As(buf), tid);
@@ -91,18 +97,29 @@ __global__ __launch_bounds__(kThreads, MH_MINW) void conv3x3_nhwc_kernel(const C
 
     Acc acc;
     acc_zero(acc);
-    Stage<BM> sa;
-    Stage<BN> sb;
-    load_tiles(sa, sb, kt_begin);
-    store_tiles(sa, sb, 0);
+    // prefetch distance 2, branch-free half-steps (see gemm_kernel): tile kt in LDS, tile kt+1 in one register
+    // stage, tile kt+2 in flight; tiles beyond kt_end are zeros
+    Stage<BM> sa0, sa1;
+    Stage<BN> sb0, sb1;
+    load_tiles(sa0, sb0, kt_begin, true);
+    store_tiles(sa0, sb0, 0);
+    load_tiles(sa1, sb1, kt_begin + 1, kt_begin + 1 < kt_end);
     __syncthreads();
-    for (int kt = kt_begin; kt < kt_end; ++kt) {
-        const int cur = (kt - kt_begin) & 1;
-        const bool more = (kt + 1 < kt_end);
-        if (more) load_tiles(sa, sb, kt + 1);
-        mma_ktile<true, false, BM, BN>(As(cur), Bs(cur), wm, wn, lane, acc);
-        if (more) store_tiles(sa, sb, cur ^ 1);
-        __syncthreads();
+    auto step = [&](auto PAR, int kt) {
+        constexpr int cur = decltype(PAR)::value;
+        Stage<BM> &sa_next = cur ? sa0 : sa1, &sa_far = cur ? sa1 : sa0;
+        Stage<BN> &sb_next = cur ? sb0 : sb1, &sb_far = cur ? sb1 : sb0;
+        auto load_far = [&]() { load_tiles(sa_far, sb_far, kt + 2, kt + 2 < kt_end); };
+        auto store_next = [&]() { store_tiles(sa_next, sb_next, cur ^ 1); };
+#if MH_PLANES
+        half_step<BM, BN>(load_far, store_next, As(cur), Bs(cur), wm, wn, lane, acc);
+#else
+        half_step_f32<BM, BN, true, false>(load_far, store_next, As(cur), Bs(cur), wm, wn, lane, acc);
+#endif
+    };
+    for (int kt = kt_begin; kt < kt_end; kt += 2) {
+        step(std::integral_constant<int, 0>{}, kt);
+        step(std::integral_constant<int, 1>{}, kt + 1);
     }
 
     if (p.splitk > 1) {
@@ -304,6 +321,8 @@ int mh_conv3x3_nhwc(const float *in, int B, int H, int W, int Cin, const float *
     MH_REQUIRE(in && wt && out && B > 0 && H > 0 && W > 0);
     MH_REQUIRE(Cin > 0 && Cin % kBK == 0 && Cout > 0 && Cout % 4 == 0);
     MH_REQUIRE(((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(wt) | reinterpret_cast<uintptr_t>(out)) & 15) == 0);
+    // 32-bit buffer offsets: block-relative for the input (tile + two halos), absolute for the packed weights
+    MH_REQUIRE((2LL * (W + 1) + 256) * Cin * 4 < (1LL << 31) && 9LL * Cin * Cout * 4 < (1LL << 31));
     ConvArgs p;
     p.in = in; p.B = B; p.H = H; p.W = W; p.Cin = Cin; p.wt = wt; p.Cout = Cout; p.bias = bias;
     p.epilogue = epilogue; p.out = out;
@@ -323,9 +342,9 @@ int mh_conv3x3_nhwc(const float *in, int B, int H, int W, int Cin, const float *
     p.partial = reinterpret_cast<float *>(workspace);
     dim3 grid((unsigned)ntiles, (unsigned)splitk);
     if (narrow)
-        hipLaunchKernelGGL((conv3x3_nhwc_kernel<256, 64>), grid, dim3(kThreads), 0, as_stream(stream), p);
+        launch_tile_kernel<conv3x3_nhwc_kernel<256, 64>>(grid, tile_lds_bytes<256, 64, true, false>(), as_stream(stream), p);
     else
-        hipLaunchKernelGGL((conv3x3_nhwc_kernel<128, 128>), grid, dim3(kThreads), 0, as_stream(stream), p);
+        launch_tile_kernel<conv3x3_nhwc_kernel<128, 128>>(grid, tile_lds_bytes<128, 128, true, false>(), as_stream(stream), p);
     int rc = check_launch("conv3x3_nhwc_kernel");
     if (rc || splitk == 1) return rc;
     return launch_splitk_reduce(p.partial, splitk, M, Cout, out, Cout, bias, epilogue, 0, as_stream(stream));

@@ -4,14 +4,8 @@
 // k-tile), optional split-K with a fused bias/activation reduction.  See mfma_tile.h for the tile engine.
 #include <algorithm>
 
+#include <type_traits>
 #include "mfma_tile.h"
-
-#ifndef MH_DBG
-#define MH_DBG 0
-#endif
-#ifndef MH_STAGGER
-#define MH_STAGGER 0
-#endif
 
 namespace mh {
 
@@ -43,7 +37,7 @@ __global__ __launch_bounds__(kThreads, MH_MINW) void gemm_kernel(const GemmArgs 
 {
     constexpr bool AWM = !TA, BWM = TB;          // K-contiguous global storage -> width-major LDS tile
     constexpr int FA = TileGeom<BM, AWM>::floats, FB = TileGeom<BN, BWM>::floats;
-    __shared__ __attribute__((aligned(16))) float lds[2 * (FA + FB)];
+    extern __shared__ __attribute__((aligned(16))) float lds[];   // 2 x (FA + FB) floats, see launch_tile_kernel
     auto As = [&](int buf) -> float * { return lds + buf * (FA + FB); };
     auto Bs = [&](int buf) -> float * { return lds + buf * (FA + FB) + FA; };
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -65,12 +59,17 @@ __global__ __launch_bounds__(kThreads, MH_MINW) void gemm_kernel(const GemmArgs 
         if (TB) return (n0 + r < p.N) ? p.B + (size_t)(n0 + r) * p.ldb : nullptr;
         return (r < p.K) ? p.B + (size_t)r * p.ldb : nullptr;
     };
-    auto load_tiles = [&](Stage<BM> &sa, Stage<BN> &sb, int kt) {
+    const GSrc ga = make_gsrc(p.A), gb = make_gsrc(p.B);
+    // `live` = false turns every load of the tile into a zero-returning out-of-range access (FAST) instead of
+    // skipping it: the loads of a k-tile are issued unconditionally, so their number is known to the compiler
+    auto load_tiles = [&](Stage<BM> &sa, Stage<BN> &sb, int kt, bool live) {
         const int k0 = kt * kBK;
-        if (TA) load_km<BM, FAST>(sa, a_row, k0, m0, p.M, p.vecA != 0, tid, p.A);
-        else load_wm<BM, FAST>(sa, a_row, k0, p.K, p.vecA != 0, tid, p.A);
-        if (TB) load_wm<BN, FAST>(sb, b_row, k0, p.K, p.vecB != 0, tid, p.B);
-        else load_km<BN, FAST>(sb, b_row, k0, n0, p.N, p.vecB != 0, tid, p.B);
+        auto a_live = [&](int r) -> const float * { return live ? a_row(r) : nullptr; };
+        auto b_live = [&](int r) -> const float * { return live ? b_row(r) : nullptr; };
+        if (TA) load_km<BM, FAST>(sa, a_live, k0, m0, p.M, p.vecA != 0, tid, ga);
+        else load_wm<BM, FAST>(sa, a_live, k0, p.K, p.vecA != 0, tid, ga);
+        if (TB) load_wm<BN, FAST>(sb, b_live, k0, p.K, p.vecB != 0, tid, gb);
+        else load_km<BN, FAST>(sb, b_live, k0, n0, p.N, p.vecB != 0, tid, gb);
     };
     auto store_tiles = [&](const Stage<BM> &sa, const Stage<BN> &sb, int buf) {
         if (TA) store_km<BM>(sa, As(buf), tid); else store_wm<BM>(sa, As(buf), tid);
@@ -79,40 +78,31 @@ __global__ __launch_bounds__(kThreads, MH_MINW) void gemm_kernel(const GemmArgs 
 
     Acc acc;
     acc_zero(acc);
-    Stage<BM> sa;
-    Stage<BN> sb;
-#if MH_STAGGER
-    // co-resident blocks of a CU start in lockstep; offset their phases so that one block's load/LDS-write phase
-    // overlaps another's MFMA phase
-    {
-        const int slot = (blockIdx.x >> 8) & 3;
-        for (int q = 0; q < slot; ++q) __builtin_amdgcn_s_sleep(MH_STAGGER);
-    }
-#endif
-    if (kt_begin < kt_end) {
-        load_tiles(sa, sb, kt_begin);
-        store_tiles(sa, sb, 0);
-    }
+    // Software pipeline, prefetch distance 2: while the MFMAs of k-tile kt run from LDS buffer `cur`, tile kt+1 sits
+    // in one register stage (split + written to the other LDS buffer after the MFMAs) and the global loads of tile
+    // kt+2 are in flight into the other stage -- a load has a whole iteration plus an MFMA phase to land.
+    Stage<BM> sa0, sa1;
+    Stage<BN> sb0, sb1;
+    load_tiles(sa0, sb0, kt_begin, kt_begin < kt_end);
+    store_tiles(sa0, sb0, 0);
+    load_tiles(sa1, sb1, kt_begin + 1, kt_begin + 1 < kt_end);
     __syncthreads();
-    for (int kt = kt_begin; kt < kt_end; ++kt) {
-        const int cur = (kt - kt_begin) & 1;
-        const bool more = (kt + 1 < kt_end);
-#if MH_DBG == 1      /* timing experiment: no global loads / LDS writes / barrier in the loop */
-        mma_ktile<AWM, BWM, BM, BN>(As(0), Bs(0), wm, wn, lane, acc);
-#elif MH_DBG == 2    /* timing experiment: loads + writes but no barrier */
-        if (more) load_tiles(sa, sb, kt + 1);
-        mma_ktile<AWM, BWM, BM, BN>(As(cur), Bs(cur), wm, wn, lane, acc);
-        if (more) store_tiles(sa, sb, cur ^ 1);
-#elif MH_DBG == 3    /* timing experiment: global loads only (kept live), no LDS writes, no barrier */
-        if (more) load_tiles(sa, sb, kt + 1);
-        mma_ktile<AWM, BWM, BM, BN>(As(0), Bs(0), wm, wn, lane, acc);
-        asm volatile("" ::"v"(sa.v[0].x), "v"(sb.v[0].x));
+    // one branch-free half-step (see half_step in mfma_tile.h); kt == kt_end is the phantom half-step of an odd count
+    auto step = [&](auto PAR, int kt) {
+        constexpr int cur = decltype(PAR)::value;
+        Stage<BM> &sa_next = cur ? sa0 : sa1, &sa_far = cur ? sa1 : sa0;   // tile kt+1 / tile kt+2
+        Stage<BN> &sb_next = cur ? sb0 : sb1, &sb_far = cur ? sb1 : sb0;
+        auto load_far = [&]() { load_tiles(sa_far, sb_far, kt + 2, kt + 2 < kt_end); };
+        auto store_next = [&]() { store_tiles(sa_next, sb_next, cur ^ 1); };
+#if MH_PLANES
+        half_step<BM, BN>(load_far, store_next, As(cur), Bs(cur), wm, wn, lane, acc);
 #else
-        if (more) load_tiles(sa, sb, kt + 1);
-        mma_ktile<AWM, BWM, BM, BN>(As(cur), Bs(cur), wm, wn, lane, acc);
-        if (more) store_tiles(sa, sb, cur ^ 1);
-        __syncthreads();
+        half_step_f32<BM, BN, AWM, BWM>(load_far, store_next, As(cur), Bs(cur), wm, wn, lane, acc);
 #endif
+    };
+    for (int kt = kt_begin; kt < kt_end; kt += 2) {
+        step(std::integral_constant<int, 0>{}, kt);
+        step(std::integral_constant<int, 1>{}, kt + 1);
     }
 
     if (p.splitk > 1) {
@@ -254,11 +244,17 @@ int mh_gemm_f32(int transA, int transB, int M, int N, int K, const float *A, int
     hipStream_t st = as_stream(stream);
     dim3 grid((unsigned)ntiles, (unsigned)splitk);
     // FAST: both operands 16-B aligned and their contiguous extents multiples of 4 (see load4_guarded)
-    const bool fast = p.vecA && p.vecB && ((transA ? M : K) % 4 == 0) && ((transB ? K : N) % 4 == 0);
+    // ... and each operand spans < 2 GiB (32-bit buffer offsets)
+    const unsigned long long spanA = (unsigned long long)(transA ? K : M) * lda * sizeof(float);
+    const unsigned long long spanB = (unsigned long long)(transB ? N : K) * ldb * sizeof(float);
+    const bool fast = p.vecA && p.vecB && ((transA ? M : K) % 4 == 0) && ((transB ? K : N) % 4 == 0) &&
+                      spanA < (1ull << 31) && spanB < (1ull << 31);
 #define MH_LAUNCH_GEMM2(TA_, TB_, F_)                                                                           \
     do {                                                                                                        \
-        if (narrow) hipLaunchKernelGGL((gemm_kernel<TA_, TB_, 256, 64, F_>), grid, dim3(kThreads), 0, st, p);    \
-        else hipLaunchKernelGGL((gemm_kernel<TA_, TB_, 128, 128, F_>), grid, dim3(kThreads), 0, st, p);          \
+        if (narrow) launch_tile_kernel<gemm_kernel<TA_, TB_, 256, 64, F_>>(                                     \
+                grid, tile_lds_bytes<256, 64, !TA_, TB_>(), st, p);                                             \
+        else launch_tile_kernel<gemm_kernel<TA_, TB_, 128, 128, F_>>(                                           \
+                grid, tile_lds_bytes<128, 128, !TA_, TB_>(), st, p);                                            \
     } while (0)
 #define MH_LAUNCH_GEMM(TA_, TB_)                          \
     do {                                                  \

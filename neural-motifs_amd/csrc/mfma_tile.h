@@ -34,17 +34,28 @@
 #define MH_MFMA_SPLIT 6   /* 6: bf16x6 split (fp32-accurate, default); 0: f32-input MFMA; 3: bf16x3 (2^-17, tests only) */
 #endif
 
+#ifndef MH_SPLIT_AT_STAGE
+#define MH_SPLIT_AT_STAGE 1   /* bf16 split done once per element when the k-tile is staged into LDS (bf16 planes) */
+#endif
+#define MH_PLANES (MH_MFMA_SPLIT && MH_SPLIT_AT_STAGE)
+
 namespace mh {
 
 constexpr int kBK = 16;
 constexpr int kThreads = 256;
 constexpr int kLdW = kBK + 4;   // WM row stride (floats)
 
+constexpr int kRowDw = 24;      // bf16-plane layout: dwords per operand row (3 planes x 8 dwords = 96 B)
+
 template <int WD, bool WM>
 struct TileGeom {
-    static constexpr int ld = WM ? kLdW : WD + 4;        // LDS row stride (floats); keeps 16-B alignment
+    static constexpr int ld = WM ? kLdW : WD + 4;        // fp32 layout: LDS row stride (floats); keeps 16-B alignment
+#if MH_PLANES
+    static constexpr int floats = WD * kRowDw;
+#else
     static constexpr int floats = WM ? WD * kLdW : kBK * (WD + 4);
-    static constexpr int nv = WD * kBK / 1024;            // float4 staged per thread (256 threads)
+#endif
+    static constexpr int nv = WD * kBK / 1024;            // float4 staged per thread for a WM operand (256 threads)
 };
 
 struct Acc {
@@ -232,6 +243,7 @@ __device__ __forceinline__ void mma_ktile_split(const float *__restrict__ As, co
         }
 }
 
+#if !MH_PLANES
 template <bool AWM, bool BWM, int BM, int BN>
 __device__ __forceinline__ void mma_ktile(const float *__restrict__ As, const float *__restrict__ Bs, int wm, int wn,
                                           int lane, Acc &acc)
@@ -242,23 +254,51 @@ __device__ __forceinline__ void mma_ktile(const float *__restrict__ As, const fl
     mma_ktile_f32<AWM, BWM, BM, BN>(As, Bs, wm, wn, lane, acc);
 #endif
 }
+#endif  // !MH_PLANES
 
 // Staging registers for one operand k-tile of width WD: WD/64 float4 per thread.
 template <int WD>
 struct Stage {
-    float4 v[WD * kBK / 1024];
+    float4 v[WD >= 128 ? WD / 64 : 2];   // WD = 64 staged k-major in bf16-plane mode needs a k-pair (2 float4) per thread
 };
 
-// FAST = operands are 16-B aligned with the contiguous extent a multiple of 4 (checked on the host): every float4
-// is entirely inside or entirely outside the matrix, so the load is issued from a clamped address and zeroed by a
-// select -- no per-element exec-masked branches, the k-tile's loads all stay in flight together.
+// One global operand as a block sees it: `base` is a wave-uniform origin and `rsrc` a raw buffer descriptor over
+// [base, base + 2 GiB).  Loads through the descriptor are branch-free: a lane that must read zero passes an offset
+// beyond the descriptor and the hardware returns 0 -- no exec-masked blocks around the loads, so every load of a
+// k-tile is issued unconditionally and the compiler can count them (s_waitcnt vmcnt(N) with N > 0 is what keeps
+// the loads of tile kt+2 in flight while tile kt+1 is consumed).
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+struct GSrc {
+    const float *base;
+    __amdgpu_buffer_rsrc_t rsrc;
+};
+__device__ __forceinline__ GSrc make_gsrc(const float *base)
+{
+    GSrc g;
+    g.base = base;
+    g.rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(base), 0, 0x7fffffff, 0x00020000);
+    return g;
+}
+constexpr unsigned kOobOffset = 0x80000000u;
+__device__ __forceinline__ float4 buffer_load4(const GSrc &g, unsigned byte_off)
+{
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    const auto raw = __builtin_amdgcn_raw_buffer_load_b128(g.rsrc, (int)byte_off, 0, 0);
+    static_assert(sizeof(raw) == 16, "b128");
+    const f32x4 v = __builtin_bit_cast(f32x4, raw);   // (component access on the builtin's own vector type splats)
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+
+// FAST = operands are 16-B aligned with the contiguous extent a multiple of 4 and span < 2 GiB from g.base (checked
+// on the host): every float4 is entirely inside or entirely outside the matrix -> one buffer load, see GSrc.
+// Otherwise (ragged / unaligned operands) per-element guarded loads.
 template <bool FAST>
-__device__ __forceinline__ float4 load4_guarded(const float *p, int c, int extent, bool vec, const float *safe)
+__device__ __forceinline__ float4 load4_guarded(const float *p, int c, int extent, bool vec, const GSrc &g)
 {
     if (FAST) {
         const bool ok = (p != nullptr) && (c < extent);
-        const float4 v = *reinterpret_cast<const float4 *>(ok ? p + c : safe);
-        return ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+        const unsigned off = (unsigned)((p - g.base) + c) * 4u;
+        return buffer_load4(g, ok ? off : kOobOffset);
     }
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
     if (p == nullptr) return v;
@@ -270,13 +310,14 @@ __device__ __forceinline__ float4 load4_guarded(const float *p, int c, int exten
     return v;
 }
 
+#if !MH_PLANES
 // ---- KM operand: global rows are k (contiguous along the tile's w dimension).
 // tile = kBK rows x WD floats; float4 f = tid + 256*j sits at (row f / (WD/4), float4-column f % (WD/4)).
 // row_ptr(k) returns the address of matrix element (k, 0) or nullptr when row k is all-zero / out of range;
 // `col0` = first tile column in the matrix, `ncols` = matrix extent along the contiguous dimension.
 template <int WD, bool FAST, typename RowPtr>
 __device__ __forceinline__ void load_km(Stage<WD> &s, RowPtr row_ptr, int k0, int col0, int ncols, bool vec, int tid,
-                                        const float *safe)
+                                        const GSrc &safe)
 {
     constexpr int c4n = WD / 4;
 #pragma unroll
@@ -297,13 +338,15 @@ __device__ __forceinline__ void store_km(const Stage<WD> &s, float *tile, int ti
     }
 }
 
+#endif  // !MH_PLANES
+
 // ---- WM operand: global rows are the tile's w dimension (k contiguous).  float4 f = tid + 256*j belongs to tile
 // row f / 4, k-quad f % 4: four consecutive lanes read one row's 64 contiguous bytes.
 // row_ptr(r) returns the address of element (r, k = 0) or nullptr when the row is out of range / zero;
 // `kext` = matrix extent along k.
 template <int WD, bool FAST, typename RowPtr>
 __device__ __forceinline__ void load_wm(Stage<WD> &s, RowPtr row_ptr, int k0, int kext, bool vec, int tid,
-                                        const float *safe)
+                                        const GSrc &safe)
 {
 #pragma unroll
     for (int j = 0; j < TileGeom<WD, true>::nv; ++j) {
@@ -312,6 +355,7 @@ __device__ __forceinline__ void load_wm(Stage<WD> &s, RowPtr row_ptr, int k0, in
     }
 }
 
+#if !MH_PLANES
 template <int WD>
 __device__ __forceinline__ void store_wm(const Stage<WD> &s, float *tile, int tid)
 {
@@ -321,6 +365,149 @@ __device__ __forceinline__ void store_wm(const Stage<WD> &s, float *tile, int ti
         *reinterpret_cast<float4 *>(tile + (f >> 2) * kLdW + 4 * (f & 3)) = s.v[j];
     }
 }
+
+#endif
+
+#if MH_PLANES
+// ---------------------------------------------------------------------------------------------------------------
+// bf16-plane LDS image (MH_MFMA_SPLIT with MH_SPLIT_AT_STAGE): every element is split ONCE, by the thread that
+// stages it, and LDS holds the three bf16 planes k-contiguous per operand row, whatever the global orientation:
+//     row r (96 B = 24 dwords):  [ hi: k0..k15 | mid: k0..k15 | lo: k0..k15 ]
+// dword d of a plane holds k = 2d (low half) and 2d+1 (high half); the 16-B slot index (2*plane + k/8) is XORed
+// with swz(r) = bit 3 of r.  A lane's MFMA operand (8 consecutive k of its row, one plane) is one ds_read_b128:
+// conflict-free for the four 16-lane service groups of the instruction (rows r and r+8 would otherwise meet on
+// the same banks: 8 * 96 B = 3 * 256 B).  The inner loop is then 12 ds_read_b128 + 24 MFMAs with no VALU work,
+// and a 128x128 block's double buffer is 48 KB: three blocks per CU.
+//   * WM operand: the staging thread owns 4 consecutive k of one row -> 2 packed dwords per plane -> 3 ds_write_b64
+//     (conflict-free).
+//   * KM operand: the staging thread loads a k-PAIR (rows 2kp, 2kp+1) of 4 consecutive w -> one packed dword per
+//     (w, plane) -> 12 ds_write_b32, i.e. the transposition costs nothing but narrow writes.  Lane l of a wave takes
+//     w-quad l&7 and k-pair l>>3: the 32 lanes of a write group meet at most 2-way on a bank, and a global load
+//     instruction reads 8 rows x 128 contiguous bytes.  Tile column w lives in row 64*(w/64) + 32*(w&1) + (w%64)/2
+//     (the wave's two MFMA sub-tiles interleaved), so a lane's two outputs are adjacent columns (8-byte stores).
+// ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int plane_swz(int r) { return (r >> 3) & 1; }
+
+// (x0, x1) = values at k even / k odd -> packed dwords of the hi / mid / lo planes (exact truncation split)
+__device__ __forceinline__ void split_pair(float x0, float x1, unsigned &ph, unsigned &pm, unsigned &pl)
+{
+    constexpr unsigned kTop = 0x07060302u;   // v_perm_b32: {S0.hi16, S1.hi16}
+    const unsigned u0 = __builtin_bit_cast(unsigned, x0), u1 = __builtin_bit_cast(unsigned, x1);
+    ph = __builtin_amdgcn_perm(u1, u0, kTop);
+    const float r0 = x0 - __builtin_bit_cast(float, u0 & 0xffff0000u);
+    const float r1 = x1 - __builtin_bit_cast(float, u1 & 0xffff0000u);
+    const unsigned v0 = __builtin_bit_cast(unsigned, r0), v1 = __builtin_bit_cast(unsigned, r1);
+    pm = __builtin_amdgcn_perm(v1, v0, kTop);
+    const float s0 = r0 - __builtin_bit_cast(float, v0 & 0xffff0000u);
+    const float s1 = r1 - __builtin_bit_cast(float, v1 & 0xffff0000u);
+    pl = __builtin_amdgcn_perm(__builtin_bit_cast(unsigned, s1), __builtin_bit_cast(unsigned, s0), kTop);
+}
+
+// KM task t -> (w-quad q, k-pair kp); tasks = 2*WD (8 k-pairs x WD/4 quads), 64 per wave
+template <int WD>
+__device__ __forceinline__ bool km_task(int t, int &q, int &kp)
+{
+    q = 8 * (t >> 6) + (t & 7);
+    kp = (t >> 3) & 7;
+    return (2 * WD >= kThreads) || (t < 2 * WD);
+}
+
+template <int WD, bool FAST, typename RowPtr>
+__device__ __forceinline__ void load_km(Stage<WD> &s, RowPtr row_ptr, int k0, int col0, int ncols, bool vec, int tid,
+                                        const GSrc &safe)
+{
+    constexpr int ntask = (2 * WD + kThreads - 1) / kThreads;
+#pragma unroll
+    for (int jt = 0; jt < ntask; ++jt) {
+        int q, kp;
+        if (!km_task<WD>(tid + kThreads * jt, q, kp)) continue;   // wave-uniform (WD = 64: waves 2, 3 idle)
+        s.v[2 * jt] = load4_guarded<FAST>(row_ptr(k0 + 2 * kp), col0 + 4 * q, ncols, vec, safe);
+        s.v[2 * jt + 1] = load4_guarded<FAST>(row_ptr(k0 + 2 * kp + 1), col0 + 4 * q, ncols, vec, safe);
+    }
+}
+
+template <int WD>
+__device__ __forceinline__ void store_km(const Stage<WD> &s, float *tile, int tid)
+{
+    constexpr int ntask = (2 * WD + kThreads - 1) / kThreads;
+    unsigned *t32 = reinterpret_cast<unsigned *>(tile);
+#pragma unroll
+    for (int jt = 0; jt < ntask; ++jt) {
+        int q, kp;
+        if (!km_task<WD>(tid + kThreads * jt, q, kp)) continue;
+        const float e[4] = {s.v[2 * jt].x, s.v[2 * jt].y, s.v[2 * jt].z, s.v[2 * jt].w};
+        const float o[4] = {s.v[2 * jt + 1].x, s.v[2 * jt + 1].y, s.v[2 * jt + 1].z, s.v[2 * jt + 1].w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int w = 4 * q + j;
+            const int r = 64 * (w >> 6) + 32 * (w & 1) + ((w & 63) >> 1);
+            const int sw = plane_swz(r);
+            unsigned pl[3];
+            split_pair(e[j], o[j], pl[0], pl[1], pl[2]);
+#pragma unroll
+            for (int pidx = 0; pidx < 3; ++pidx)
+                t32[r * kRowDw + 4 * ((2 * pidx + (kp >> 2)) ^ sw) + (kp & 3)] = pl[pidx];
+        }
+    }
+}
+
+template <int WD>
+__device__ __forceinline__ void store_wm(const Stage<WD> &s, float *tile, int tid)
+{
+    unsigned *t32 = reinterpret_cast<unsigned *>(tile);
+#pragma unroll
+    for (int j = 0; j < TileGeom<WD, true>::nv; ++j) {
+        const int f = tid + kThreads * j;
+        const int r = f >> 2, kq = f & 3, sw = plane_swz(r);
+        unsigned a[3], b[3];
+        split_pair(s.v[j].x, s.v[j].y, a[0], a[1], a[2]);
+        split_pair(s.v[j].z, s.v[j].w, b[0], b[1], b[2]);
+#pragma unroll
+        for (int pidx = 0; pidx < 3; ++pidx) {
+            typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+            *reinterpret_cast<u32x2 *>(t32 + r * kRowDw + 4 * ((2 * pidx + (kq >> 1)) ^ sw) + 2 * (kq & 1)) =
+                (u32x2){a[pidx], b[pidx]};
+        }
+    }
+}
+
+// The wave's operand fragments of one k-tile: [sub-tile][plane] for A and B, 12 ds_read_b128 in all.
+struct PlaneFrags {
+    bf16x8 a[2][3], b[2][3];
+};
+template <int BM, int BN>
+__device__ __forceinline__ void fetch_frags(PlaneFrags &f, const float *__restrict__ As, const float *__restrict__ Bs,
+                                            int wm, int wn, int lane)
+{
+    const int i = lane & 31, g = lane >> 5;
+    auto fetch = [&](const float *tile, int row, int pidx) -> bf16x8 {
+        return *reinterpret_cast<const bf16x8 *>(tile + row * kRowDw + 4 * ((2 * pidx + g) ^ plane_swz(row)));
+    };
+    constexpr int kOrderA[3] = {2, 0, 1}, kOrderB[3] = {0, 2, 1};   // planes in order of first use
+#pragma unroll
+    for (int o = 0; o < 3; ++o) {
+#pragma unroll
+        for (int sidx = 0; sidx < 2; ++sidx) {
+            if (MH_MFMA_SPLIT >= 6 || kOrderA[o] != 2) f.a[sidx][kOrderA[o]] = fetch(As, wm + 32 * sidx + i, kOrderA[o]);
+            if (MH_MFMA_SPLIT >= 6 || kOrderB[o] != 2) f.b[sidx][kOrderB[o]] = fetch(Bs, wn + 32 * sidx + i, kOrderB[o]);
+        }
+    }
+}
+// All MFMAs of one k-tile.  Per accumulator the six terms are added smallest first (lo*hi, hi*lo, mid*mid, mid*hi,
+// hi*mid, hi*hi); the four accumulators are interleaved so that consecutive MFMAs are independent.
+__device__ __forceinline__ void mma_frags(const PlaneFrags &f, Acc &acc)
+{
+    constexpr int kTermA[6] = {2, 0, 1, 1, 0, 0}, kTermB[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+    for (int t = (MH_MFMA_SPLIT >= 6 ? 0 : 3); t < 6; ++t)
+#pragma unroll
+        for (int sm = 0; sm < 2; ++sm)
+#pragma unroll
+            for (int sn = 0; sn < 2; ++sn)
+                acc.v[sm][sn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[sm][kTermA[t]], f.b[sn][kTermB[t]],
+                                                                        acc.v[sm][sn], 0, 0, 0);
+}
+#endif  // MH_PLANES
 
 // tile row (or column) held by MFMA index idx (0..31) of sub-tile s, for the two operand layouts
 template <bool WM>
@@ -363,6 +550,66 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblocks)
     const int start = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
     return start + idx;
 }
+
+// Launch a tile kernel with its LDS image as dynamic shared memory (sized by the layout in use: tile_lds_bytes).
+template <auto Kern, typename Args>
+inline void launch_tile_kernel(dim3 grid, size_t lds_bytes, hipStream_t st, const Args &p)
+{
+    static bool raised[64] = {};
+    int dev = 0;
+    hipGetDevice(&dev);
+    if (dev >= 0 && dev < 64 && !raised[dev]) {
+        hipFuncSetAttribute(reinterpret_cast<const void *>(Kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)lds_bytes);
+        raised[dev] = true;
+    }
+    hipLaunchKernelGGL(Kern, grid, dim3(kThreads), lds_bytes, st, p);
+}
+template <int BM, int BN, bool AWM, bool BWM>
+constexpr size_t tile_lds_bytes() { return 2 * (size_t)(TileGeom<BM, AWM>::floats + TileGeom<BN, BWM>::floats) * sizeof(float); }
+
+// One branch-free half-step of the main loop (bf16-plane mode), shared by the GEMM and the conv kernel:
+//   1. global loads of tile kt+2 (pinned at the top: two iterations of flight time),
+//   2. the 12 fragment reads of tile kt (LDS buffer `cur`),
+//   3. MFMAs of tile kt interleaved with the split + LDS write of tile kt+1 (into the other buffer), in ONE basic
+//      block: the reads are issued before the writes in program order, so the MFMAs depend on registers only and
+//      the scheduler may put the staging VALU / DS-write work into their shadow (recipe below),
+//   4. barrier.
+// Tiles beyond the last one are loaded as zeros (masked buffer loads), which makes the phantom half-step of an odd
+// tile count harmless (acc += 0) and keeps the loop free of branches -- the load count per step is static, so the
+// compiler waits with vmcnt(N > 0) and tile kt+2 stays in flight while tile kt+1 is consumed.
+#if MH_PLANES
+template <int BM, int BN, typename LoadFn, typename StoreFn>
+__device__ __forceinline__ void half_step(LoadFn load_far, StoreFn store_next, const float *As, const float *Bs, int wm,
+                                          int wn, int lane, Acc &acc)
+{
+    load_far();
+    __builtin_amdgcn_sched_barrier(0);
+    PlaneFrags f;
+    fetch_frags<BM, BN>(f, As, Bs, wm, wn, lane);
+    store_next();
+    mma_frags(f, acc);
+    __builtin_amdgcn_sched_group_barrier(0x100, 12, 0);       // fragment reads
+    __builtin_amdgcn_sched_group_barrier(0x002, 12, 0);       // first split ops while the reads land
+#pragma unroll
+    for (int i = 0; i < 24; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);    // 1 MFMA
+        __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);    // split / address VALU
+        __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);    // LDS write of the next tile
+    }
+    __syncthreads();
+}
+#else
+template <int BM, int BN, bool AWM, bool BWM, typename LoadFn, typename StoreFn>
+__device__ __forceinline__ void half_step_f32(LoadFn load_far, StoreFn store_next, const float *As, const float *Bs,
+                                              int wm, int wn, int lane, Acc &acc)
+{
+    load_far();
+    mma_ktile<AWM, BWM, BM, BN>(As, Bs, wm, wn, lane, acc);
+    store_next();
+    __syncthreads();
+}
+#endif
 
 // defined in gemm.hip
 int choose_splitk_tiles(long long tiles, int ktiles, double out_elems, double flops);
