@@ -55,7 +55,7 @@ class ConvMeter(object):
         y = self.orig(x, wt, bias, epilogue)
         e.record()
         B, H, W, Cin = x.shape
-        self.records.append((s, e, 2.0 * B * H * W * Cin * wt.shape[2] * 9))
+        self.records.append((s, e, 2.0 * B * H * W * Cin * wt.shape[1] * 9))
         return y
 
     def summary(self):

@@ -108,10 +108,10 @@ int mh_gemm_f32(int transA, int transB, int M, int N, int K, const float *A, int
  * Convolution stack, NHWC internal layout (cuDNN replacement; lib/object_detector.py:110-118,
  * :503-508, lib/get_union_boxes.py:31-39).
  *   mh_conv3x3_nhwc: 3x3, stride 1, pad 1 implicit GEMM on MFMA, fused bias + ReLU/ReLU6.
- *       in [B,H,W,Cin] (Cin % 16 == 0), wt [9][Cin][Cout] (tap-major, see mh_conv3x3_pack_weight),
+ *       in [B,H,W,Cin] (Cin % 16 == 0), wt [9][Cout][Cin] (tap-major, see mh_conv3x3_pack_weight),
  *       out [B,H,W,Cout] (Cout % 4 == 0)
- *   mh_conv3x3_pack_weight: w [Cout,Cin,3,3] (API layout) -> wt [9][Cin][Cout];
- *       flip_transpose=1 produces the dgrad weights (taps mirrored, Cin/Cout swapped: wt [9][Cout][Cin])
+ *   mh_conv3x3_pack_weight: w [Cout,Cin,3,3] (API layout) -> wt [9][Cout][Cin];
+ *       flip_transpose=1 produces the dgrad weights (taps mirrored, Cin/Cout swapped: wt [9][Cin][Cout])
  *   mh_conv_first_nchw: the 3->Cout stem reading the NCHW image directly, writing NHWC; bias+ReLU
  *   mh_maxpool2x2_nhwc: 2x2/2 max pool (floor), NHWC
  *   mh_im2col_nhwc: generic patch matrix out[B*Ho*Wo, ldo] with column (ky*kw+kx)*C + c

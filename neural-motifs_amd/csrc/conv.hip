@@ -36,7 +36,7 @@ __device__ __forceinline__ float conv_epi(float v, int epilogue)
 template <int BM, int BN>
 __global__ __launch_bounds__(kThreads, MH_MINW) void conv3x3_nhwc_kernel(const ConvArgs p)
 {
-    constexpr int FA = TileGeom<BM, true>::floats, FB = TileGeom<BN, false>::floats;   // A: NHWC pixels (WM), B: KM
+    constexpr int FA = TileGeom<BM, true>::floats, FB = TileGeom<BN, true>::floats;   // A: NHWC pixels, B: wt[tap][co][ci]: both K-contiguous (WM)
     extern __shared__ __attribute__((aligned(16))) float lds[];   // 2 x (FA + FB) floats, see launch_tile_kernel
     auto As = [&](int buf) -> float * { return lds + buf * (FA + FB); };
     auto Bs = [&](int buf) -> float * { return lds + buf * (FA + FB) + FA; };
@@ -50,23 +50,34 @@ __global__ __launch_bounds__(kThreads, MH_MINW) void conv3x3_nhwc_kernel(const C
     const int n0 = (t % p.tiles_n) * BN;
     const long long Mtot = (long long)p.B * p.H * p.W;
 
-    // this thread's A rows (fixed for the whole K loop): float4 f = tid + 256 j belongs to tile row f >> 2.
-    // A is addressed relative to a block origin one halo (W+1 pixels) before the tile's first pixel, so every tap of
-    // every valid pixel has a small non-negative 32-bit offset whatever the size of the input tensor.
-    constexpr int NVA = TileGeom<BM, true>::nv;
+    // Planned loads (mfma_tile.h): per-lane byte offsets are fixed for the whole K loop, the tap shift and the channel
+    // offset go into the scalar offset.  A is addressed relative to a block origin one halo (W+1 pixels) before the
+    // tile's first pixel, so every tap of every valid pixel has a non-negative 32-bit offset whatever the size of
+    // the input tensor; which of the 9 taps fall inside the image is a 9-bit mask per staged pixel.
+    constexpr int NVA = TileGeom<BM, true>::nv, NVB = TileGeom<BN, true>::nv;
     const int halo = (p.W + 1) * p.Cin;
     const GSrc ga = make_gsrc(p.in + (ptrdiff_t)m0 * p.Cin - halo), gb = make_gsrc(p.wt);
-    bool row_ok[NVA];
-    int py[NVA], px[NVA], in_off[NVA];
+    unsigned a_off[NVA], a_taps[NVA], b_off[NVB];
 #pragma unroll
     for (int j = 0; j < NVA; ++j) {
         const int r = (tid + kThreads * j) >> 2;
         const long long pix = m0 + r;
-        row_ok[j] = pix < Mtot;
-        const int rem = (int)((row_ok[j] ? pix : 0) % ((long long)p.H * p.W));
-        py[j] = rem / p.W;
-        px[j] = rem % p.W;
-        in_off[j] = halo + r * p.Cin + 4 * ((tid + kThreads * j) & 3);
+        const bool row_ok = pix < Mtot;
+        const int rem = (int)((row_ok ? pix : 0) % ((long long)p.H * p.W));
+        const int py = rem / p.W, px = rem % p.W;
+        unsigned mask = 0;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int dy = tap / 3 - 1, dx = tap % 3 - 1;
+            if (row_ok && (unsigned)(py + dy) < (unsigned)p.H && (unsigned)(px + dx) < (unsigned)p.W) mask |= 1u << tap;
+        }
+        a_taps[j] = mask;
+        a_off[j] = (unsigned)(r * p.Cin + 4 * ((tid + kThreads * j) & 3)) * 4u;
+    }
+#pragma unroll
+    for (int j = 0; j < NVB; ++j) {
+        const int f = tid + kThreads * j, r = f >> 2;
+        b_off[j] = (n0 + r < p.Cout) ? (unsigned)(r * p.Cin + 4 * (f & 3)) * 4u : kOobOffset;
     }
 
     const int kt_per_tap = p.Cin / kBK;
@@ -76,23 +87,20 @@ __global__ __launch_bounds__(kThreads, MH_MINW) void conv3x3_nhwc_kernel(const C
 
     // `live` = false: every load becomes a zero-returning out-of-range access (see gemm_kernel)
     auto load_tiles = [&](Stage<BM> &sa, Stage<BN> &sb, int kt, bool live) {
-        const int tap = kt / kt_per_tap;
+        const int tap = min(kt / kt_per_tap, 8);
         const int c0 = (kt - tap * kt_per_tap) * kBK;
         const int dy = tap / 3 - 1, dx = tap % 3 - 1;
-        const int shift = (dy * p.W + dx) * p.Cin + c0;
+        const unsigned a_soff = live ? (unsigned)(halo + (dy * p.W + dx) * p.Cin + c0) * 4u : kDeadTile;
+        const unsigned b_soff = live ? (unsigned)((tap * p.Cout + n0) * p.Cin + c0) * 4u : kDeadTile;
+        const unsigned bit = 1u << tap;
 #pragma unroll
-        for (int j = 0; j < NVA; ++j) {
-            const bool ok = live && row_ok[j] && (unsigned)(py[j] + dy) < (unsigned)p.H &&
-                            (unsigned)(px[j] + dx) < (unsigned)p.W;
-            sa.v[j] = buffer_load4(ga, ok ? (unsigned)(in_off[j] + shift) * 4u : kOobOffset);
-        }
-        const float *wtap = p.wt + ((size_t)tap * p.Cin + c0) * p.Cout;
-        auto b_row = [&](int k) -> const float * { return live ? wtap + (size_t)k * p.Cout : nullptr; };
-        load_km<BN, true>(sb, b_row, 0, n0, p.Cout, true, tid, gb);
+        for (int j = 0; j < NVA; ++j) sa.v[j] = buffer_load4(ga, (a_taps[j] & bit) ? a_off[j] : kOobOffset, a_soff);
+#pragma unroll
+        for (int j = 0; j < NVB; ++j) sb.v[j] = buffer_load4(gb, b_off[j], b_soff);
     };
     auto store_tiles = [&](const Stage<BM> &sa, const Stage<BN> &sb, int buf) {
         store_wm<BM>(sa, As(buf), tid);
-        store_km<BN>(sb, Bs(buf), tid);
+        store_wm<BN>(sb, Bs(buf), tid);
     };
 
     Acc acc;
@@ -114,7 +122,7 @@ __global__ __launch_bounds__(kThreads, MH_MINW) void conv3x3_nhwc_kernel(const C
 #if MH_PLANES
         half_step<BM, BN>(load_far, store_next, As(cur), Bs(cur), wm, wn, lane, acc);
 #else
-        half_step_f32<BM, BN, true, false>(load_far, store_next, As(cur), Bs(cur), wm, wn, lane, acc);
+        half_step_f32<BM, BN, true, true>(load_far, store_next, As(cur), Bs(cur), wm, wn, lane, acc);
 #endif
     };
     for (int kt = kt_begin; kt < kt_end; kt += 2) {
@@ -124,26 +132,29 @@ __global__ __launch_bounds__(kThreads, MH_MINW) void conv3x3_nhwc_kernel(const C
 
     if (p.splitk > 1) {
         float *dst = p.partial + (size_t)blockIdx.y * Mtot * p.Cout;
-        acc_foreach_pair<true, false>(acc, wm, wn, lane, [&](int r, int c, int, float v0, float v1) {
+        acc_foreach_pair<true, true>(acc, wm, wn, lane, [&](int r, int c0, int c1, float v0, float v1) {
             const long long row = m0 + r;
-            const int col = n0 + c;
-            if (row >= Mtot || col >= p.Cout) return;
-            *reinterpret_cast<float2 *>(dst + (size_t)row * p.Cout + col) = make_float2(v0, v1);
+            if (row >= Mtot) return;
+            float *q = dst + (size_t)row * p.Cout + n0;
+            if (n0 + c0 < p.Cout) q[c0] = v0;
+            if (n0 + c1 < p.Cout) q[c1] = v1;
         });
         return;
     }
-    acc_foreach_pair<true, false>(acc, wm, wn, lane, [&](int r, int c, int, float v0, float v1) {
+    // a lane holds output channels c0 and c0 + 32 of its rows: the 32 lanes of a half-wave store 128 contiguous bytes
+    const int col0 = n0 + wn + (lane & 31), col1 = col0 + 32;
+    const float bias0 = (p.bias && col0 < p.Cout) ? p.bias[col0] : 0.f, bias1 = (p.bias && col1 < p.Cout) ? p.bias[col1] : 0.f;
+    acc_foreach_pair<true, true>(acc, wm, wn, lane, [&](int r, int, int, float v0, float v1) {
         const long long row = m0 + r;
-        const int col = n0 + c;
-        if (row >= Mtot || col >= p.Cout) return;   // Cout % 4 == 0 -> col+1 is valid whenever col is
-        if (p.bias) { v0 += p.bias[col]; v1 += p.bias[col + 1]; }
-        v0 = conv_epi(v0, p.epilogue);
-        v1 = conv_epi(v1, p.epilogue);
-        *reinterpret_cast<float2 *>(p.out + (size_t)row * p.Cout + col) = make_float2(v0, v1);
+        if (row >= Mtot) return;
+        float *q = p.out + (size_t)row * p.Cout;
+        if (col0 < p.Cout) q[col0] = conv_epi(v0 + bias0, p.epilogue);
+        if (col1 < p.Cout) q[col1] = conv_epi(v1 + bias1, p.epilogue);
     });
 }
 
-// w [Cout,Cin,3,3] -> wt [9][Cin][Cout]; flip_transpose: wt[(2-ky)*3+(2-kx)][co][ci] = w[co][ci][ky][kx]
+// w [Cout,Cin,3,3] -> wt [9][Cout][Cin] (tap, output channel, input channel: K-contiguous rows for the B tile);
+// flip_transpose (dgrad weights, channel roles swapped, taps mirrored): wt[8-tap][ci][co] = w[co][ci][tap]
 __global__ void pack_weight_kernel(const float *__restrict__ w, int Cout, int Cin, int flip_transpose,
                                    float *__restrict__ wt)
 {
@@ -152,13 +163,13 @@ __global__ void pack_weight_kernel(const float *__restrict__ w, int Cout, int Ci
          idx += (long long)blockDim.x * gridDim.x) {
         // idx enumerates the OUTPUT so writes are coalesced
         if (!flip_transpose) {
-            const int co = idx % Cout;
-            const int ci = (idx / Cout) % Cin;
+            const int ci = idx % Cin;
+            const int co = (idx / Cin) % Cout;
             const int tap = idx / ((long long)Cout * Cin);
             wt[idx] = w[((size_t)co * Cin + ci) * 9 + tap];
         } else {
-            const int ci = idx % Cin;
-            const int co = (idx / Cin) % Cout;
+            const int co = idx % Cout;
+            const int ci = (idx / Cout) % Cin;
             const int tap = idx / ((long long)Cout * Cin);
             wt[idx] = w[((size_t)co * Cin + ci) * 9 + (8 - tap)];
         }
@@ -322,7 +333,7 @@ int mh_conv3x3_nhwc(const float *in, int B, int H, int W, int Cin, const float *
     MH_REQUIRE(Cin > 0 && Cin % kBK == 0 && Cout > 0 && Cout % 4 == 0);
     MH_REQUIRE(((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(wt) | reinterpret_cast<uintptr_t>(out)) & 15) == 0);
     // 32-bit buffer offsets: block-relative for the input (tile + two halos), absolute for the packed weights
-    MH_REQUIRE((2LL * (W + 1) + 256) * Cin * 4 < (1LL << 31) && 9LL * Cin * Cout * 4 < (1LL << 31));
+    MH_REQUIRE((2LL * (W + 1) + 256) * Cin * 4 < (1LL << 30) && 9LL * Cin * Cout * 4 < (1LL << 30));
     ConvArgs p;
     p.in = in; p.B = B; p.H = H; p.W = W; p.Cin = Cin; p.wt = wt; p.Cout = Cout; p.bias = bias;
     p.epilogue = epilogue; p.out = out;

@@ -60,10 +60,36 @@ __global__ __launch_bounds__(kThreads, MH_MINW) void gemm_kernel(const GemmArgs 
         return (r < p.K) ? p.B + (size_t)r * p.ldb : nullptr;
     };
     const GSrc ga = make_gsrc(p.A), gb = make_gsrc(p.B);
+#if MH_PLANES
+    // FAST operands: per-lane offsets planned once, the tile's advance goes into the scalar offset (mfma_tile.h)
+    Plan<BM> pa;
+    Plan<BN> pb;
+    if (FAST) {
+        const int ktail = (p.K % kBK) ? (p.K % kBK) : kBK;
+        if (TA) plan_km<BM>(pa, p.M - m0, p.lda, ktail, tid);
+        else plan_wm<BM>(pa, [&](int r) { return m0 + r < p.M; }, p.lda, ktail, tid);
+        if (TB) plan_wm<BN>(pb, [&](int r) { return n0 + r < p.N; }, p.ldb, ktail, tid);
+        else plan_km<BN>(pb, p.N - n0, p.ldb, ktail, tid);
+    }
+#endif
     // `live` = false turns every load of the tile into a zero-returning out-of-range access (FAST) instead of
     // skipping it: the loads of a k-tile are issued unconditionally, so their number is known to the compiler
     auto load_tiles = [&](Stage<BM> &sa, Stage<BN> &sb, int kt, bool live) {
         const int k0 = kt * kBK;
+#if MH_PLANES
+        if (FAST) {
+            const bool tail = k0 + kBK > p.K;
+            const unsigned sa_off = TA ? ((unsigned)k0 * (unsigned)p.lda + (unsigned)m0) * 4u
+                                       : ((unsigned)m0 * (unsigned)p.lda + (unsigned)k0) * 4u;
+            const unsigned sb_off = TB ? ((unsigned)n0 * (unsigned)p.ldb + (unsigned)k0) * 4u
+                                       : ((unsigned)k0 * (unsigned)p.ldb + (unsigned)n0) * 4u;
+            if (TA) load_planned_km<BM>(sa, pa, ga, live ? sa_off : kDeadTile, tail);
+            else load_planned_wm<BM>(sa, pa, ga, live ? sa_off : kDeadTile, tail);
+            if (TB) load_planned_wm<BN>(sb, pb, gb, live ? sb_off : kDeadTile, tail);
+            else load_planned_km<BN>(sb, pb, gb, live ? sb_off : kDeadTile, tail);
+            return;
+        }
+#endif
         auto a_live = [&](int r) -> const float * { return live ? a_row(r) : nullptr; };
         auto b_live = [&](int r) -> const float * { return live ? b_row(r) : nullptr; };
         if (TA) load_km<BM, FAST>(sa, a_live, k0, m0, p.M, p.vecA != 0, tid, ga);
@@ -244,11 +270,11 @@ int mh_gemm_f32(int transA, int transB, int M, int N, int K, const float *A, int
     hipStream_t st = as_stream(stream);
     dim3 grid((unsigned)ntiles, (unsigned)splitk);
     // FAST: both operands 16-B aligned and their contiguous extents multiples of 4 (see load4_guarded)
-    // ... and each operand spans < 2 GiB (32-bit buffer offsets)
+    // ... and each operand spans < 1 GiB (32-bit buffer offsets inside a 1 GiB descriptor, see GSrc)
     const unsigned long long spanA = (unsigned long long)(transA ? K : M) * lda * sizeof(float);
     const unsigned long long spanB = (unsigned long long)(transB ? N : K) * ldb * sizeof(float);
     const bool fast = p.vecA && p.vecB && ((transA ? M : K) % 4 == 0) && ((transB ? K : N) % 4 == 0) &&
-                      spanA < (1ull << 31) && spanB < (1ull << 31);
+                      spanA < (1ull << 30) && spanB < (1ull << 30);
 #define MH_LAUNCH_GEMM2(TA_, TB_, F_)                                                                           \
     do {                                                                                                        \
         if (narrow) launch_tile_kernel<gemm_kernel<TA_, TB_, 256, 64, F_>>(                                     \

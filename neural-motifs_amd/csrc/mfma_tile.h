@@ -263,11 +263,15 @@ struct Stage {
 };
 
 // One global operand as a block sees it: `base` is a wave-uniform origin and `rsrc` a raw buffer descriptor over
-// [base, base + 2 GiB).  Loads through the descriptor are branch-free: a lane that must read zero passes an offset
+// [base, base + 1 GiB).  Loads through the descriptor are branch-free: a lane that must read zero passes an offset
 // beyond the descriptor and the hardware returns 0 -- no exec-masked blocks around the loads, so every load of a
 // k-tile is issued unconditionally and the compiler can count them (s_waitcnt vmcnt(N) with N > 0 is what keeps
 // the loads of tile kt+2 in flight while tile kt+1 is consumed).
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+constexpr unsigned kBufBytes = 0x40000000u;    // operands are addressed within 1 GiB of their (block) origin
+constexpr unsigned kOobOffset = 0x80000000u;   // per-lane offset of a lane that must read zero
+constexpr unsigned kDeadTile = kBufBytes;      // scalar offset that pushes a whole tile out of range (no wrap with
+                                               // kOobOffset: 0x80000000 + 0x40000000 < 2^32)
 struct GSrc {
     const float *base;
     __amdgpu_buffer_rsrc_t rsrc;
@@ -276,20 +280,19 @@ __device__ __forceinline__ GSrc make_gsrc(const float *base)
 {
     GSrc g;
     g.base = base;
-    g.rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(base), 0, 0x7fffffff, 0x00020000);
+    g.rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(base), 0, (int)kBufBytes, 0x00020000);
     return g;
 }
-constexpr unsigned kOobOffset = 0x80000000u;
-__device__ __forceinline__ float4 buffer_load4(const GSrc &g, unsigned byte_off)
+__device__ __forceinline__ float4 buffer_load4(const GSrc &g, unsigned byte_off, unsigned sbyte_off = 0)
 {
     typedef float f32x4 __attribute__((ext_vector_type(4)));
-    const auto raw = __builtin_amdgcn_raw_buffer_load_b128(g.rsrc, (int)byte_off, 0, 0);
+    const auto raw = __builtin_amdgcn_raw_buffer_load_b128(g.rsrc, (int)byte_off, (int)sbyte_off, 0);
     static_assert(sizeof(raw) == 16, "b128");
     const f32x4 v = __builtin_bit_cast(f32x4, raw);   // (component access on the builtin's own vector type splats)
     return make_float4(v.x, v.y, v.z, v.w);
 }
 
-// FAST = operands are 16-B aligned with the contiguous extent a multiple of 4 and span < 2 GiB from g.base (checked
+// FAST = operands are 16-B aligned with the contiguous extent a multiple of 4 and span < 1 GiB from g.base (checked
 // on the host): every float4 is entirely inside or entirely outside the matrix -> one buffer load, see GSrc.
 // Otherwise (ragged / unaligned operands) per-element guarded loads.
 template <bool FAST>
@@ -508,6 +511,69 @@ __device__ __forceinline__ void mma_frags(const PlaneFrags &f, Acc &acc)
                                                                         acc.v[sm][sn], 0, 0, 0);
 }
 #endif  // MH_PLANES
+
+// ---------------------------------------------------------------------------------------------------------------
+// Planned loads (FAST operands in bf16-plane mode).  The per-lane byte offset of every staged float4 is fixed for
+// the whole K loop -- only a wave-uniform amount is added per k-tile -- so it is computed ONCE (`plan`), invalid
+// rows / columns get kOobOffset, and a k-tile's loads are nothing but buffer_load_dwordx4 v, voff, rsrc, soff with
+// the tile's advance in the scalar offset: no address VALU in the main loop.  A tile beyond the end of the loop is
+// loaded with soff = kDeadTile (zeros); the last, partial k-tile (K % 16 != 0) uses the second offset set `t`, in
+// which the lanes whose k lies beyond K are out of range too (one v_cndmask on a scalar condition per load).
+// ---------------------------------------------------------------------------------------------------------------
+template <int WD>
+struct Plan {
+    static constexpr int n = WD >= 128 ? WD / 64 : 2;
+    unsigned v[n], t[n];
+};
+
+// WM operand: float4 j of this thread = tile row f >> 2, k-quad f & 3 (f = tid + 256 j); ld in floats;
+// ktail = number of valid k in the last k-tile (1..16)
+template <int WD, typename RowOk>
+__device__ __forceinline__ void plan_wm(Plan<WD> &pl, RowOk row_ok, int ld, int ktail, int tid)
+{
+#pragma unroll
+    for (int j = 0; j < TileGeom<WD, true>::nv; ++j) {
+        const int f = tid + kThreads * j, r = f >> 2, kq = f & 3;
+        const unsigned off = ((unsigned)r * (unsigned)ld + 4u * kq) * 4u;
+        pl.v[j] = row_ok(r) ? off : kOobOffset;
+        pl.t[j] = (4 * kq < ktail) ? pl.v[j] : kOobOffset;
+    }
+}
+template <int WD>
+__device__ __forceinline__ void load_planned_wm(Stage<WD> &s, const Plan<WD> &pl, const GSrc &g, unsigned soff, bool tail)
+{
+#pragma unroll
+    for (int j = 0; j < TileGeom<WD, true>::nv; ++j) s.v[j] = buffer_load4(g, tail ? pl.t[j] : pl.v[j], soff);
+}
+
+#if MH_PLANES
+// KM operand (see km_task): float4 2jt + i = row k = 2 kp + i, columns 4q .. 4q+3 of the tile; ncols_left = number
+// of valid columns counted from the tile's first column
+template <int WD>
+__device__ __forceinline__ void plan_km(Plan<WD> &pl, int ncols_left, int ld, int ktail, int tid)
+{
+    constexpr int ntask = (2 * WD + kThreads - 1) / kThreads;
+#pragma unroll
+    for (int jt = 0; jt < ntask; ++jt) {
+        const int t = tid + kThreads * jt;
+        const int q = 8 * (t >> 6) + (t & 7), kp = (t >> 3) & 7;
+        const bool ok = (4 * q < ncols_left) && ((2 * WD >= kThreads) || (t < 2 * WD));
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const unsigned off = ((unsigned)(2 * kp + i) * (unsigned)ld + 4u * q) * 4u;
+            pl.v[2 * jt + i] = ok ? off : kOobOffset;
+            pl.t[2 * jt + i] = (2 * kp + i < ktail) ? pl.v[2 * jt + i] : kOobOffset;
+        }
+    }
+}
+template <int WD>
+__device__ __forceinline__ void load_planned_km(Stage<WD> &s, const Plan<WD> &pl, const GSrc &g, unsigned soff, bool tail)
+{
+    constexpr int ntask = (2 * WD + kThreads - 1) / kThreads;
+#pragma unroll
+    for (int j = 0; j < 2 * ntask; ++j) s.v[j] = buffer_load4(g, tail ? pl.t[j] : pl.v[j], soff);
+}
+#endif
 
 // tile row (or column) held by MFMA index idx (0..31) of sub-tile s, for the two operand layouts
 template <bool WM>

@@ -79,18 +79,43 @@ __global__ __launch_bounds__(256) void bn_partial_kernel(const float *__restrict
     }
 }
 
-// forward finalize: mean, biased var -> invstd; running stats with momentum (unbiased var), like nn.BatchNorm
-__global__ void bn_finalize_fwd_kernel(const float *__restrict__ partial, int nblk, int C, long long M, float eps,
-                                       float momentum, float *__restrict__ mean, float *__restrict__ invstd,
-                                       float *__restrict__ running_mean, float *__restrict__ running_var)
+// Column sums of the per-block partials in double: a block owns 16 channels, its 256 threads are 16 channels x 16
+// slices of the nblk partial rows (64-B coalesced reads), combined through LDS.  Returns the two sums to threads
+// 0..15 of the block (channel c = blockIdx.x * 16 + threadIdx.x).
+constexpr int kFinCh = 16, kFinSl = 16;
+__device__ __forceinline__ bool bn_partial_sums(const float *__restrict__ partial, int nblk, int C, double &s_out,
+                                                double &ss_out)
 {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
+    __shared__ double red[2][kFinSl][kFinCh];
+    const int cl = threadIdx.x % kFinCh, sl = threadIdx.x / kFinCh;
+    const int c = blockIdx.x * kFinCh + cl;
     double s = 0.0, ss = 0.0;
-    for (int b = 0; b < nblk; ++b) {
-        s += (double)partial[(size_t)b * 2 * C + c];
-        ss += (double)partial[(size_t)b * 2 * C + C + c];
-    }
+    if (c < C)
+        for (int b = sl; b < nblk; b += kFinSl) {
+            s += (double)partial[(size_t)b * 2 * C + c];
+            ss += (double)partial[(size_t)b * 2 * C + C + c];
+        }
+    red[0][sl][cl] = s;
+    red[1][sl][cl] = ss;
+    __syncthreads();
+    if (sl != 0 || c >= C) return false;
+    s = 0.0; ss = 0.0;
+#pragma unroll
+    for (int k = 0; k < kFinSl; ++k) { s += red[0][k][cl]; ss += red[1][k][cl]; }
+    s_out = s;
+    ss_out = ss;
+    return true;
+}
+
+// forward finalize: mean, biased var -> invstd; running stats with momentum (unbiased var), like nn.BatchNorm
+__global__ __launch_bounds__(kFinCh * kFinSl) void bn_finalize_fwd_kernel(
+    const float *__restrict__ partial, int nblk, int C, long long M, float eps, float momentum,
+    float *__restrict__ mean, float *__restrict__ invstd, float *__restrict__ running_mean,
+    float *__restrict__ running_var)
+{
+    double s, ss;
+    if (!bn_partial_sums(partial, nblk, C, s, ss)) return;
+    const int c = blockIdx.x * kFinCh + threadIdx.x;
     const double mu = s / (double)M;
     double var = ss / (double)M - mu * mu;
     if (var < 0.0) var = 0.0;
@@ -104,16 +129,13 @@ __global__ void bn_finalize_fwd_kernel(const float *__restrict__ partial, int nb
 }
 
 // backward finalize: dbeta = sum g, dgamma = sum g*xhat
-__global__ void bn_finalize_bwd_kernel(const float *__restrict__ partial, int nblk, int C, float *__restrict__ dgamma,
-                                       float *__restrict__ dbeta)
+__global__ __launch_bounds__(kFinCh * kFinSl) void bn_finalize_bwd_kernel(const float *__restrict__ partial, int nblk,
+                                                                          int C, float *__restrict__ dgamma,
+                                                                          float *__restrict__ dbeta)
 {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    double s = 0.0, ss = 0.0;
-    for (int b = 0; b < nblk; ++b) {
-        s += (double)partial[(size_t)b * 2 * C + c];
-        ss += (double)partial[(size_t)b * 2 * C + C + c];
-    }
+    double s, ss;
+    if (!bn_partial_sums(partial, nblk, C, s, ss)) return;
+    const int c = blockIdx.x * kFinCh + threadIdx.x;
     dbeta[c] = (float)s;
     dgamma[c] = (float)ss;
 }
@@ -300,7 +322,7 @@ int mh_bn_stats(const float *x, long long M, int C, float eps, float momentum, f
                        (const float *)nullptr, M, C, 0, 0, partial);
     rc = check_launch("bn_partial_kernel<fwd>");
     if (rc) return rc;
-    hipLaunchKernelGGL(bn_finalize_fwd_kernel, dim3(ceil_div(C, 256)), dim3(256), 0, st, partial, nblk, C, M, eps, momentum,
+    hipLaunchKernelGGL(bn_finalize_fwd_kernel, dim3(ceil_div(C, kFinCh)), dim3(kFinCh * kFinSl), 0, st, partial, nblk, C, M, eps, momentum,
                        mean, invstd, running_mean, running_var);
     return check_launch("bn_finalize_fwd_kernel");
 }
@@ -361,7 +383,7 @@ int mh_bn_bwd(const float *x, const float *g, const unsigned char *argmax, long 
                            C, H, W, partial);
     rc = check_launch("bn_partial_kernel<bwd>");
     if (rc) return rc;
-    hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3(ceil_div(C, 256)), dim3(256), 0, st, partial, nblk, C, dgamma, dbeta);
+    hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3(ceil_div(C, kFinCh)), dim3(kFinCh * kFinSl), 0, st, partial, nblk, C, dgamma, dbeta);
     rc = check_launch("bn_finalize_bwd_kernel");
     if (rc) return rc;
     if (pooled)

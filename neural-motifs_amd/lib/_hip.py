@@ -221,16 +221,16 @@ def bbox_overlaps(a, b):
 # ----------------------------------------------------------------------------------------------- conv stack
 def conv3x3_pack_weight(w, flip_transpose=False):
     Cout, Cin = w.shape[0], w.shape[1]
-    wt = torch.empty((9, Cout, Cin) if flip_transpose else (9, Cin, Cout), dtype=torch.float32, device=w.device)
+    wt = torch.empty((9, Cin, Cout) if flip_transpose else (9, Cout, Cin), dtype=torch.float32, device=w.device)
     rc = lib().mh_conv3x3_pack_weight(f32(w), Cout, Cin, c_int(int(flip_transpose)), f32(wt), stream())
     _check(rc, 'mh_conv3x3_pack_weight')
     return wt
 
 
 def conv3x3_nhwc(x, wt, bias, epilogue):
-    """x [B,H,W,Cin], wt [9,Cin,Cout] -> [B,H,W,Cout]"""
+    """x [B,H,W,Cin], wt [9,Cout,Cin] (conv3x3_pack_weight) -> [B,H,W,Cout]"""
     B, H, W, Cin = x.shape
-    Cout = wt.shape[2]
+    Cout = wt.shape[1]
     out = torch.empty(B, H, W, Cout, dtype=torch.float32, device=x.device)
     wsb = lib().mh_conv3x3_ws_bytes(B, H, W, Cin, Cout)
     ws = workspace(wsb, x.device, 'conv') if wsb else None

@@ -265,7 +265,7 @@ class _Conv3x3Fn(torch.autograd.Function):
         Cout, Cin = weight.shape[0], weight.shape[1]
         gx = gw = gb = None
         if ctx.needs_input_grad[0]:
-            wt_t = _hip.conv3x3_pack_weight(_c(weight), True)          # [9][Cout][Cin]
+            wt_t = _hip.conv3x3_pack_weight(_c(weight), True)          # [9][Cin][Cout]: the dgrad conv's weights
             gx = _hip.conv3x3_nhwc(gy, wt_t, None, EPI_NONE)
         if ctx.needs_input_grad[1]:
             cols, _, _ = _hip.im2col_nhwc(x_nhwc, 3, 3, 1, 1)          # [M, 9*Cin]

@@ -69,13 +69,14 @@ def install():
         return OB.bbox_overlaps(a, b)
 
     def conv3x3_pack_weight(w, flip_transpose=False):
+        # packed layout [9][Cout'][Cin'] of the conv that consumes it (flip_transpose: the dgrad conv, roles swapped)
         if flip_transpose:
-            return w.flip(2, 3).permute(2, 3, 0, 1).reshape(9, w.shape[0], w.shape[1]).contiguous()
-        return w.permute(2, 3, 1, 0).reshape(9, w.shape[1], w.shape[0]).contiguous()
+            return w.flip(2, 3).permute(2, 3, 1, 0).reshape(9, w.shape[1], w.shape[0]).contiguous()
+        return w.permute(2, 3, 0, 1).reshape(9, w.shape[0], w.shape[1]).contiguous()
 
     def conv3x3_nhwc(x, wt, bias, epilogue):
-        cin, cout = wt.shape[1], wt.shape[2]
-        w = wt.view(3, 3, cin, cout).permute(3, 2, 0, 1)
+        cout, cin = wt.shape[1], wt.shape[2]
+        w = wt.view(3, 3, cout, cin).permute(2, 3, 0, 1)
         y = F.conv2d(x.permute(0, 3, 1, 2), w, bias, padding=1)
         y = {0: y, 1: F.relu(y), 2: F.relu6(y)}[epilogue]
         return y.permute(0, 2, 3, 1).contiguous()
