@@ -108,16 +108,19 @@ int mh_gemm_f32(int transA, int transB, int M, int N, int K, const float *A, int
  * Convolution stack, NHWC internal layout (cuDNN replacement; lib/object_detector.py:110-118,
  * :503-508, lib/get_union_boxes.py:31-39).
  *   mh_conv3x3_nhwc: 3x3, stride 1, pad 1 implicit GEMM on MFMA, fused bias + ReLU/ReLU6.
- *       in [B,H,W,Cin] (Cin % 16 == 0), wt [9][Cout][Cin] (tap-major, see mh_conv3x3_pack_weight),
+ *       in [B,H,W,Cin] (Cin % 16 == 0), wt = packed weights of THIS conv (see mh_conv3x3_pack_weight),
  *       out [B,H,W,Cout] (Cout % 4 == 0)
- *   mh_conv3x3_pack_weight: w [Cout,Cin,3,3] (API layout) -> wt [9][Cout][Cin];
- *       flip_transpose=1 produces the dgrad weights (taps mirrored, Cin/Cout swapped: wt [9][Cin][Cout])
+ *   mh_conv3x3_pack_weight: w [Cout,Cin,3,3] (API layout) -> wt, mh_conv3x3_packed_floats(N, K) floats for a conv
+ *       with N output and K input channels: [9][N][K/16][24 dwords] = per (tap, output channel, 16 input channels)
+ *       the three bf16 planes hi|mid|lo of the exact fp32 split (bf16x6 build; plain fp32 [9][N][K] in the f32-MFMA
+ *       build).  flip_transpose=1 produces the weights of the dgrad conv (N = Cin, K = Cout, taps mirrored)
  *   mh_conv_first_nchw: the 3->Cout stem reading the NCHW image directly, writing NHWC; bias+ReLU
  *   mh_maxpool2x2_nhwc: 2x2/2 max pool (floor), NHWC
  *   mh_im2col_nhwc: generic patch matrix out[B*Ho*Wo, ldo] with column (ky*kw+kx)*C + c
  *   mh_col2im... not needed on this path (the only im2col conv takes an input without gradient)
  *   mh_nchw_to_nhwc / mh_nhwc_to_nchw: layout converters
  * ------------------------------------------------------------------------------------------- */
+size_t mh_conv3x3_packed_floats(int Cout, int Cin);
 int mh_conv3x3_pack_weight(const float *w, int Cout, int Cin, int flip_transpose, float *wt,
                            void *stream);
 size_t mh_conv3x3_ws_bytes(int B, int H, int W, int Cin, int Cout);   /* split-K scratch (0 if not split) */

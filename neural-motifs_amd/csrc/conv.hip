@@ -57,7 +57,15 @@ __global__ __launch_bounds__(kThreads, MH_MINW) void conv3x3_nhwc_kernel(const C
     constexpr int NVA = TileGeom<BM, true>::nv, NVB = TileGeom<BN, true>::nv;
     const int halo = (p.W + 1) * p.Cin;
     const GSrc ga = make_gsrc(p.in + (ptrdiff_t)m0 * p.Cin - halo), gb = make_gsrc(p.wt);
-    unsigned a_off[NVA], a_taps[NVA], b_off[NVB];
+    unsigned a_off[NVA], a_taps[NVA];
+#if MH_PLANES
+    // B = packed weights as bf16 planes, wt[tap][co][ci / 16][96 B]: chunk copies, no split (mfma_tile.h: PStage)
+    const unsigned b_row_bytes = (unsigned)(p.Cin / kBK) * (kRowDw * 4);
+    PPlan<BN> pb;
+    plan_planes<BN>(pb, [&](int r) { return n0 + r < p.Cout; }, b_row_bytes, tid);
+#else
+    unsigned b_off[NVB];
+#endif
 #pragma unroll
     for (int j = 0; j < NVA; ++j) {
         const int r = (tid + kThreads * j) >> 2;
@@ -74,11 +82,13 @@ __global__ __launch_bounds__(kThreads, MH_MINW) void conv3x3_nhwc_kernel(const C
         a_taps[j] = mask;
         a_off[j] = (unsigned)(r * p.Cin + 4 * ((tid + kThreads * j) & 3)) * 4u;
     }
+#if !MH_PLANES
 #pragma unroll
     for (int j = 0; j < NVB; ++j) {
         const int f = tid + kThreads * j, r = f >> 2;
         b_off[j] = (n0 + r < p.Cout) ? (unsigned)(r * p.Cin + 4 * (f & 3)) * 4u : kOobOffset;
     }
+#endif
 
     const int kt_per_tap = p.Cin / kBK;
     const int total_kt = 9 * kt_per_tap;
@@ -86,21 +96,34 @@ __global__ __launch_bounds__(kThreads, MH_MINW) void conv3x3_nhwc_kernel(const C
     const int kt_end = min(total_kt, kt_begin + p.ktiles_per_split);
 
     // `live` = false: every load becomes a zero-returning out-of-range access (see gemm_kernel)
-    auto load_tiles = [&](Stage<BM> &sa, Stage<BN> &sb, int kt, bool live) {
+#if MH_PLANES
+    typedef PStage<BN> StageB;
+#else
+    typedef Stage<BN> StageB;
+#endif
+    auto load_tiles = [&](Stage<BM> &sa, StageB &sb, int kt, bool live) {
         const int tap = min(kt / kt_per_tap, 8);
-        const int c0 = (kt - tap * kt_per_tap) * kBK;
+        const int g16 = kt - tap * kt_per_tap, c0 = g16 * kBK;
         const int dy = tap / 3 - 1, dx = tap % 3 - 1;
         const unsigned a_soff = live ? (unsigned)(halo + (dy * p.W + dx) * p.Cin + c0) * 4u : kDeadTile;
-        const unsigned b_soff = live ? (unsigned)((tap * p.Cout + n0) * p.Cin + c0) * 4u : kDeadTile;
         const unsigned bit = 1u << tap;
 #pragma unroll
         for (int j = 0; j < NVA; ++j) sa.v[j] = buffer_load4(ga, (a_taps[j] & bit) ? a_off[j] : kOobOffset, a_soff);
+#if MH_PLANES
+        load_planes<BN>(sb, pb, gb, live ? (unsigned)(tap * p.Cout + n0) * b_row_bytes + (unsigned)g16 * (kRowDw * 4) : kDeadTile);
+#else
+        const unsigned b_soff = live ? (unsigned)((tap * p.Cout + n0) * p.Cin + c0) * 4u : kDeadTile;
 #pragma unroll
         for (int j = 0; j < NVB; ++j) sb.v[j] = buffer_load4(gb, b_off[j], b_soff);
+#endif
     };
-    auto store_tiles = [&](const Stage<BM> &sa, const Stage<BN> &sb, int buf) {
+    auto store_tiles = [&](const Stage<BM> &sa, const StageB &sb, int buf) {
         store_wm<BM>(sa, As(buf), tid);
+#if MH_PLANES
+        store_planes<BN>(sb, pb, Bs(buf), tid);
+#else
         store_wm<BN>(sb, Bs(buf), tid);
+#endif
     };
 
     Acc acc;
@@ -108,7 +131,7 @@ __global__ __launch_bounds__(kThreads, MH_MINW) void conv3x3_nhwc_kernel(const C
     // prefetch distance 2, branch-free half-steps (see gemm_kernel): tile kt in LDS, tile kt+1 in one register
     // stage, tile kt+2 in flight; tiles beyond kt_end are zeros
     Stage<BM> sa0, sa1;
-    Stage<BN> sb0, sb1;
+    StageB sb0, sb1;
     load_tiles(sa0, sb0, kt_begin, true);
     store_tiles(sa0, sb0, 0);
     load_tiles(sa1, sb1, kt_begin + 1, kt_begin + 1 < kt_end);
@@ -116,7 +139,7 @@ __global__ __launch_bounds__(kThreads, MH_MINW) void conv3x3_nhwc_kernel(const C
     auto step = [&](auto PAR, int kt) {
         constexpr int cur = decltype(PAR)::value;
         Stage<BM> &sa_next = cur ? sa0 : sa1, &sa_far = cur ? sa1 : sa0;
-        Stage<BN> &sb_next = cur ? sb0 : sb1, &sb_far = cur ? sb1 : sb0;
+        StageB &sb_next = cur ? sb0 : sb1, &sb_far = cur ? sb1 : sb0;
         auto load_far = [&]() { load_tiles(sa_far, sb_far, kt + 2, kt + 2 < kt_end); };
         auto store_next = [&]() { store_tiles(sa_next, sb_next, cur ^ 1); };
 #if MH_PLANES
@@ -153,27 +176,40 @@ __global__ __launch_bounds__(kThreads, MH_MINW) void conv3x3_nhwc_kernel(const C
     });
 }
 
-// w [Cout,Cin,3,3] -> wt [9][Cout][Cin] (tap, output channel, input channel: K-contiguous rows for the B tile);
-// flip_transpose (dgrad weights, channel roles swapped, taps mirrored): wt[8-tap][ci][co] = w[co][ci][tap]
-__global__ void pack_weight_kernel(const float *__restrict__ w, int Cout, int Cin, int flip_transpose,
-                                   float *__restrict__ wt)
+// Packed weights of a 3x3 conv with N output and K input channels (for the dgrad conv the channel roles are swapped
+// and the taps mirrored: flip_transpose): element (tap, n, k) = w[n][k][tap], or w[k][n][8 - tap] when flipped.
+//   bf16-plane build: wt[tap][n][k / 16][24 dwords] = the LDS row image of one k-tile (hi | mid | lo, dword d of a
+//   plane = k pair (2d, 2d+1)), so the kernel stages B by 16-byte copies with no split;
+//   f32-MFMA build:   wt[tap][n][k] fp32 (K-contiguous rows) in the same buffer.
+__global__ void pack_weight_kernel(const float *__restrict__ w, int N, int K, int flip_transpose, int src_cout,
+                                   int src_cin, float *__restrict__ wt)
 {
-    const long long total = (long long)Cout * Cin * 9;
+    auto src = [&](int tap, int n, int k) -> float {
+        return flip_transpose ? w[((size_t)k * src_cin + n) * 9 + (8 - tap)] : w[((size_t)n * src_cin + k) * 9 + tap];
+    };
+#if MH_PLANES
+    const long long total = 9LL * N * (K / kBK) * kRowDw;
+    unsigned *out = reinterpret_cast<unsigned *>(wt);
     for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total;
          idx += (long long)blockDim.x * gridDim.x) {
-        // idx enumerates the OUTPUT so writes are coalesced
-        if (!flip_transpose) {
-            const int ci = idx % Cin;
-            const int co = (idx / Cin) % Cout;
-            const int tap = idx / ((long long)Cout * Cin);
-            wt[idx] = w[((size_t)co * Cin + ci) * 9 + tap];
-        } else {
-            const int co = idx % Cout;
-            const int ci = (idx / Cout) % Cin;
-            const int tap = idx / ((long long)Cout * Cin);
-            wt[idx] = w[((size_t)co * Cin + ci) * 9 + (8 - tap)];
-        }
+        const int d = idx % kRowDw, plane = d / 8, kp = d % 8;
+        long long t = idx / kRowDw;
+        const int g16 = t % (K / kBK); t /= (K / kBK);
+        const int n = t % N;
+        const int tap = (int)(t / N);
+        unsigned pl[3];
+        split_pair(src(tap, n, g16 * kBK + 2 * kp), src(tap, n, g16 * kBK + 2 * kp + 1), pl[0], pl[1], pl[2]);
+        out[idx] = pl[plane];
     }
+#else
+    const long long total = 9LL * N * K;
+    for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total;
+         idx += (long long)blockDim.x * gridDim.x) {
+        const int k = idx % K, n = (idx / K) % N, tap = (int)(idx / ((long long)N * K));
+        wt[idx] = src(tap, n, k);
+    }
+#endif
+    (void)src_cout;
 }
 
 // Stem conv: NCHW image (Cin small, e.g. 3) -> NHWC, bias + activation.  Direct VALU kernel: the layer is
@@ -301,13 +337,26 @@ using namespace mh;
 
 extern "C" {
 
+size_t mh_conv3x3_packed_floats(int Cout, int Cin)
+{
+    if (Cout <= 0 || Cin <= 0) return 0;
+#if MH_PLANES
+    return (size_t)9 * Cout * ((Cin + kBK - 1) / kBK) * kRowDw;
+#else
+    return (size_t)9 * Cout * Cin;
+#endif
+}
+
 int mh_conv3x3_pack_weight(const float *w, int Cout, int Cin, int flip_transpose, float *wt, void *stream)
 {
     MH_REQUIRE(w && wt && Cout > 0 && Cin > 0);
-    const long long total = (long long)Cout * Cin * 9;
+    // the conv that consumes the packed weights has N output and K input channels
+    const int N = flip_transpose ? Cin : Cout, K = flip_transpose ? Cout : Cin;
+    MH_REQUIRE(K % kBK == 0);
+    const long long total = (long long)mh_conv3x3_packed_floats(N, K);
     const int blocks = (int)std::min<long long>((total + 255) / 256, 4096);
-    hipLaunchKernelGGL(pack_weight_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), w, Cout, Cin, flip_transpose,
-                       wt);
+    hipLaunchKernelGGL(pack_weight_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), w, N, K, flip_transpose, Cout,
+                       Cin, wt);
     return check_launch("pack_weight_kernel");
 }
 
@@ -333,7 +382,7 @@ int mh_conv3x3_nhwc(const float *in, int B, int H, int W, int Cin, const float *
     MH_REQUIRE(Cin > 0 && Cin % kBK == 0 && Cout > 0 && Cout % 4 == 0);
     MH_REQUIRE(((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(wt) | reinterpret_cast<uintptr_t>(out)) & 15) == 0);
     // 32-bit buffer offsets: block-relative for the input (tile + two halos), absolute for the packed weights
-    MH_REQUIRE((2LL * (W + 1) + 256) * Cin * 4 < (1LL << 30) && 9LL * Cin * Cout * 4 < (1LL << 30));
+    MH_REQUIRE((2LL * (W + 1) + 256) * Cin * 4 < (1LL << 30) && (long long)mh_conv3x3_packed_floats(Cout, Cin) * 4 < (1LL << 30));
     ConvArgs p;
     p.in = in; p.B = B; p.H = H; p.W = W; p.Cin = Cin; p.wt = wt; p.Cout = Cout; p.bias = bias;
     p.epilogue = epilogue; p.out = out;

@@ -179,24 +179,26 @@ __global__ void splitk_reduce_kernel(const float *__restrict__ partial, int spli
 }
 
 // Work-distribution model shared by GEMM and conv: `tiles` output tiles of `ktiles` k-steps each are cut into
-// S k-slices.  Blocks are handed to 256 CUs greedily, so the makespan is ceil(tiles*S/256)/S tile-times; a CU that
-// holds fewer than 2 resident blocks cannot hide its barrier/LDS latency (measured ~0.8x); the partial-sum round trip
-// costs S*M*N*8 bytes of HBM traffic against 2*M*N*K flops.
+// S k-slices.  A CU holds two resident blocks (LDS / VGPR budget of the tile engine) and runs them at about half
+// speed each; a CU left with a single block only reaches ~0.6 of its two-block throughput (nothing hides its barrier
+// and LDS latency).  Equal blocks finish in lockstep, so with t1 = one tile on one fully occupied CU the makespan is
+//     floor(blocks / 512) * 2 * t1/S  +  { 0 | t1/S / 0.6 | 2 * t1/S }   for a remainder of { 0 | <= 256 | > 256 }
+// blocks (PMC: the 384-tile fc6 forward at S = 2 ran 1.5 rounds with an average of 1.2 waves per SIMD).  The
+// partial-sum round trip costs S*M*N*8 bytes of HBM traffic.
 int choose_splitk_tiles(long long tiles, int ktiles, double out_elems, double flops)
 {
-    if (tiles >= 2048 || ktiles < 16) return 1;
+    if (tiles >= 4096 || ktiles < 16) return 1;
     static const int cand[] = {1, 2, 3, 4, 5, 6, 7, 8, 10, 12, 14, 16, 20, 24, 28, 32, 40, 48, 56, 64};
+    const double t1 = flops / (double)tiles / (170e12 / 256.0);   // seconds per tile on a fully occupied CU
     double best = 1e30;
     int best_s = 1;
     for (int s : cand) {
         if (s > 1 && ktiles / s < 6) break;
-        const double blocks = (double)tiles * s;
-        const double rounds = (double)((tiles * s + 255) / 256);
-        double t_mfma = rounds / s * ((double)tiles > 0 ? 1.0 : 0.0);            // in tile-times
-        if (blocks < 512) t_mfma *= 1.2;                                         // < 2 resident blocks per CU
-        const double tile_time = flops / (double)tiles / (110e12 / 256.0);       // one tile on one CU, seconds
+        const long long blocks = tiles * s;
+        const long long rem = blocks % 512;
+        const double units = (double)(blocks / 512) * 2.0 + (rem == 0 ? 0.0 : rem <= 256 ? 1.0 / 0.6 : 2.0);
         const double t_partial = (s > 1) ? (out_elems * 8.0 * s) / 4.0e12 + 4e-6 : 0.0;
-        const double cost = t_mfma * tile_time + t_partial;
+        const double cost = units * t1 / s + t_partial;
         if (cost < best * 0.97) { best = cost; best_s = s; }
     }
     return best_s;

@@ -177,6 +177,135 @@ __device__ __forceinline__ void block_gemv(const float *const (&wrow)[NR], bool 
     }
 }
 
+// Same engine with the weights RESIDENT in registers (persistent layer kernels below): a lane always multiplies the
+// same NCH x NR x 8 weight floats, so they are loaded once per layer instead of once per timestep.  K <= NCH * 512.
+// The arithmetic (FMA order, shuffle tree, cross-wave sum) is that of block_gemv.
+template <int NR, int NCH>
+struct WResident {
+    WRegs<NR> c[NCH];
+};
+template <int NR, int NCH>
+__device__ __forceinline__ void load_resident(WResident<NR, NCH> &w, const float *const (&wrow)[NR], bool ok_rows,
+                                              bool vec, int K)
+{
+    const int tid = threadIdx.x, wave = tid >> 6, kq = tid & 15;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) load_w<NR>(w.c[c], wrow, ok_rows, vec, c * kChunk, K, wave, kq);
+}
+template <int NR, int NCH>
+__device__ __forceinline__ void block_gemv_resident(const WResident<NR, NCH> &w, const float *v, int ldv, bool vvec,
+                                                    int n, int b0, int K, float *vs, float *red, float (&tot)[NR])
+{
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, grp = lane >> 4, kq = lane & 15;
+    float acc[NR][kNB];
+#pragma unroll
+    for (int r = 0; r < NR; ++r)
+#pragma unroll
+        for (int b = 0; b < kNB; ++b) acc[r][b] = 0.f;
+    VStage st;
+    load_vstage(st, v, ldv, vvec, n, b0, 0, K, tid);
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        const int k0 = c * kChunk;
+        if (k0 < K) {                      // uniform
+            __syncthreads();               // previous chunk's LDS reads are done
+            store_vstage(st, vs, tid);
+            __syncthreads();
+            if (k0 + kChunk < K) load_vstage(st, v, ldv, vvec, n, b0, k0 + kChunk, K, tid);
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const float *vp = vs + 128 * wave + 64 * h + 4 * kq;
+#pragma unroll
+                for (int b = 0; b < kNB; ++b) {
+                    const float4 x = *reinterpret_cast<const float4 *>(vp + b * kChunk);
+#pragma unroll
+                    for (int r = 0; r < NR; ++r) {
+                        acc[r][b] = fmaf(w.c[c].v[r][h].x, x.x, acc[r][b]);
+                        acc[r][b] = fmaf(w.c[c].v[r][h].y, x.y, acc[r][b]);
+                        acc[r][b] = fmaf(w.c[c].v[r][h].z, x.z, acc[r][b]);
+                        acc[r][b] = fmaf(w.c[c].v[r][h].w, x.w, acc[r][b]);
+                    }
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < NR; ++r)
+#pragma unroll
+        for (int b = 0; b < kNB; ++b) {
+            float x = acc[r][b];
+            x += __shfl_xor(x, 1);
+            x += __shfl_xor(x, 2);
+            x += __shfl_xor(x, 4);
+            x += __shfl_xor(x, 8);
+            acc[r][b] = x;
+        }
+    if (kq < kNB) {
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            float x = 0.f;
+#pragma unroll
+            for (int b = 0; b < kNB; ++b)
+                if (kq == b) x = acc[r][b];
+            red[((wave * 4 + grp) * NR + r) * kNB + kq] = x;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < NR; ++r) tot[r] = 0.f;
+    if (tid < 4 * kNB) {
+        const int g2 = tid >> 3, b = tid & 7;
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            float x = 0.f;
+#pragma unroll
+            for (int wv = 0; wv < 4; ++wv) x += red[((wv * 4 + g2) * NR + r) * kNB + b];
+            tot[r] = x;
+        }
+    }
+}
+
+// Sequence schedule passed by value to the persistent kernels (lengths sorted descending, lengths[0] == T).
+constexpr int kSeqMaxB = 32;
+struct SeqSched {
+    int T, B, forward;
+    int lengths[kSeqMaxB];
+};
+__device__ __forceinline__ int covered_at(const SeqSched &s, int t)
+{
+    int n = 0;
+    for (int b = 0; b < s.B; ++b) n += (s.lengths[b] > t) ? 1 : 0;
+    return n;
+}
+
+#ifndef MH_BAR_SLEEP
+#define MH_BAR_SLEEP 8
+#endif
+constexpr int kBrokenWord = 48;   // counters: words 0..47 = one per layer, word 48 = "a barrier timed out"
+// Grid-wide barrier for a kernel whose blocks are all resident or will become resident without waiting on this
+// kernel (one block per 4 hidden units: <= 128 blocks).  Release / acquire at agent scope so that the plain stores
+// before the barrier are visible to every XCD after it.  The spin is bounded: on a time-out the kernel runs on
+// (wrong numbers, which the parity tests catch; every later barrier of the call is skipped) instead of hanging the device.
+__device__ __forceinline__ void grid_barrier(unsigned *counters, int slot, unsigned target)
+{
+    unsigned *counter = counters + slot;
+    unsigned *broken = counters + kBrokenWord;    // sticky: set by the first block that times out
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        // release: the block's stores (all waves: ordered before by __syncthreads) become visible at agent scope
+        __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        bool done = false;
+        for (int spin = 0; spin < (1 << 18) && !done; ++spin) {
+            done = __hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= target ||
+                   __hip_atomic_load(broken, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+            if (!done) __builtin_amdgcn_s_sleep(MH_BAR_SLEEP);
+        }
+        if (!done) __hip_atomic_store(broken, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __atomic_thread_fence(__ATOMIC_ACQUIRE);   // acquire (agent scope is HIP's default for this builtin)
+    }
+    __syncthreads();
+}
+
 // ---------------------------------------------------------------------------------------------------
 // out[b][r] = sum_k v[b][k] * wt[r][k] (+ bias[r]);  4 output rows per block.
 // ---------------------------------------------------------------------------------------------------
@@ -198,6 +327,39 @@ __global__ __launch_bounds__(kGemvThreads) void gemv_rows_kernel(int n, int R, i
             const int r2 = blockIdx.x * 4 + (threadIdx.x >> 3), b = b0 + (threadIdx.x & 7);
             if (r2 < R && b < n) out[(size_t)b * ldo + r2] = tot[0] + (bias ? bias[r2] : 0.f);
         }
+    }
+}
+
+// gate math of one (row, unit): elementWise_fp, highway_lstm_kernel.cu:108-160 (th = the 5 recurrent dot products)
+__device__ __forceinline__ void cell_fwd_math(int H, int u, const float *pi, const float (&th)[5], const float *bias,
+                                              const float *c_prev, const float *dropout, float *h_out, float *c_out,
+                                              float *go, size_t o)
+{
+    float g[5];
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+        g[k] = pi[(size_t)k * H] + th[k];               // tmp_i + tmp_h
+        if (bias) g[k] += bias[k * H + u];              // += bias
+    }
+    const float in_gate = sigmoidf_ref(g[0]);
+    const float forget_gate = sigmoidf_ref(g[1]);
+    const float act_gate = tanhf(g[2]);
+    const float out_gate = sigmoidf_ref(g[3]);
+    const float r_gate = sigmoidf_ref(g[4]);
+    const float lin_gate = pi[(size_t)5 * H];
+    float val = (forget_gate * c_prev[o]) + (in_gate * act_gate);
+    c_out[o] = val;
+    val = out_gate * tanhf(val);
+    val = (float)((double)(val * r_gate) + (1. - (double)r_gate) * (double)lin_gate);
+    if (dropout) val = val * dropout[o];
+    h_out[o] = val;
+    if (go) {
+        go[0] = in_gate;
+        go[(size_t)1 * H] = forget_gate;
+        go[(size_t)2 * H] = act_gate;
+        go[(size_t)3 * H] = out_gate;
+        go[(size_t)4 * H] = r_gate;
+        go[(size_t)5 * H] = lin_gate;
     }
 }
 
@@ -232,35 +394,9 @@ __global__ __launch_bounds__(kGemvThreads) void hw_cell_fwd_kernel(int n, int H,
         block_gemv<5>(wrow, u_ok, wvec != 0, h_prev, H, vvec != 0, n, b0, H, vs, red, th);
         const int u = blockIdx.x * 4 + (threadIdx.x >> 3), row = b0 + (threadIdx.x & 7);
         if (threadIdx.x < 4 * kNB && u < H && row < n) {
-            const float *pi = pre_i + (size_t)row * ld_i + u;
-            float g[5];
-#pragma unroll
-            for (int k = 0; k < 5; ++k) {
-                g[k] = pi[(size_t)k * H] + th[k];               // tmp_i + tmp_h
-                if (bias) g[k] += bias[k * H + u];              // += bias
-            }
-            const float in_gate = sigmoidf_ref(g[0]);
-            const float forget_gate = sigmoidf_ref(g[1]);
-            const float act_gate = tanhf(g[2]);
-            const float out_gate = sigmoidf_ref(g[3]);
-            const float r_gate = sigmoidf_ref(g[4]);
-            const float lin_gate = pi[(size_t)5 * H];
             const size_t o = (size_t)row * H + u;
-            float val = (forget_gate * c_prev[o]) + (in_gate * act_gate);
-            c_out[o] = val;
-            val = out_gate * tanhf(val);
-            val = (float)((double)(val * r_gate) + (1. - (double)r_gate) * (double)lin_gate);
-            if (dropout) val = val * dropout[o];
-            h_out[o] = val;
-            if (gates_out) {
-                float *go = gates_out + (size_t)row * 6 * H + u;
-                go[0] = in_gate;
-                go[(size_t)1 * H] = forget_gate;
-                go[(size_t)2 * H] = act_gate;
-                go[(size_t)3 * H] = out_gate;
-                go[(size_t)4 * H] = r_gate;
-                go[(size_t)5 * H] = lin_gate;
-            }
+            cell_fwd_math(H, u, pre_i + (size_t)row * ld_i + u, th, bias, c_prev, dropout, h_out, c_out,
+                          gates_out ? gates_out + (size_t)row * 6 * H + u : nullptr, o);
         }
     }
 }
@@ -293,6 +429,175 @@ __global__ void hw_cell_bwd_kernel(int n, int H, const float *__restrict__ d_out
     dg[(size_t)4 * H] = d_h * (h_prime - lin_gate) * r_gate * (1.f - r_gate);
     dg[(size_t)5 * H] = d_h * (1 - r_gate);
     d_c_in[idx] = forget_gate * d_c;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Persistent layer kernels: ALL timesteps of one layer in one launch (instead of one launch per step).  A block owns
+// 4 hidden units for the whole sequence, its slice of the recurrent weights stays in registers (40 floats per lane),
+// and the steps are separated by a grid barrier -- the only cross-block dependency is h_t (forward) / the gate
+// gradients of step t (backward).  Used when H <= 512, H % 4 == 0 and B <= 32; other shapes take the per-step path.
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kGemvThreads) void hw_layer_fwd_kernel(SeqSched s, int H, const float *__restrict__ pre_i,
+                                                                   float *hl, float *cl,
+                                                                   const float *__restrict__ wh_t,
+                                                                   const float *__restrict__ bias,
+                                                                   const float *__restrict__ dropout, float *gates,
+                                                                   unsigned *counters, int slot)
+{
+    __shared__ __attribute__((aligned(16))) float vs[kNB * kChunk];
+    __shared__ float red[4 * 4 * 5 * kNB];
+    const int lane = threadIdx.x & 63, grp = lane >> 4;
+    const int ug = blockIdx.x * 4 + grp;
+    const bool u_ok = ug < H;
+    const int us = u_ok ? ug : 0;
+    const float *const wrow[5] = {wh_t + ((size_t)0 * H + us) * H, wh_t + ((size_t)1 * H + us) * H,
+                                  wh_t + ((size_t)2 * H + us) * H, wh_t + ((size_t)3 * H + us) * H,
+                                  wh_t + ((size_t)4 * H + us) * H};
+    WResident<5, 1> w;
+    load_resident<5, 1>(w, wrow, u_ok, true, H);
+    float bias_u[5] = {0.f, 0.f, 0.f, 0.f, 0.f};   // of the unit this thread does the gate math for
+    {
+        const int u = blockIdx.x * 4 + (threadIdx.x >> 3);
+        if (bias && threadIdx.x < 4 * kNB && u < H)
+#pragma unroll
+            for (int k = 0; k < 5; ++k) bias_u[k] = bias[k * H + u];
+    }
+    const size_t numEl = (size_t)s.B * H;
+    unsigned epoch = 0;
+    for (int i = 0; i < s.T; ++i) {
+        const int t = s.forward ? i : s.T - 1 - i;
+        const int n = covered_at(s, t);
+        const int prev = s.forward ? t : (t + 2) % (s.T + 1);
+        const float *h_prev = hl + (size_t)prev * numEl, *c_prev = cl + (size_t)prev * numEl;
+        float *h_out = hl + (size_t)(t + 1) * numEl, *c_out = cl + (size_t)(t + 1) * numEl;
+        const float *pi_t = pre_i + (size_t)t * s.B * 6 * H;
+        float *g_t = gates ? gates + (size_t)t * 6 * numEl : nullptr;
+        for (int b0 = 0; b0 < n; b0 += kNB) {
+            // the gate-math threads fetch everything that does not depend on h_{t-1} BEFORE the recurrent product,
+            // so those global-memory round trips overlap it
+            const int u = blockIdx.x * 4 + (threadIdx.x >> 3), row = b0 + (threadIdx.x & 7);
+            const bool mine = threadIdx.x < 4 * kNB && u < H && row < n;
+            const size_t o = (size_t)row * H + u;
+            float pv[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, cp = 0.f, dm = 1.f;
+            if (mine) {
+                const float *pi = pi_t + (size_t)row * 6 * H + u;
+#pragma unroll
+                for (int k = 0; k < 6; ++k) pv[k] = pi[(size_t)k * H];
+                cp = c_prev[o];
+                if (dropout) dm = dropout[o];
+            }
+            float th[5];
+            block_gemv_resident<5, 1>(w, h_prev, H, true, n, b0, H, vs, red, th);
+            if (mine) {
+                float g[5];
+#pragma unroll
+                for (int k = 0; k < 5; ++k) g[k] = pv[k] + th[k] + bias_u[k];   // (tmp_i + tmp_h) + bias
+                const float in_gate = sigmoidf_ref(g[0]);
+                const float forget_gate = sigmoidf_ref(g[1]);
+                const float act_gate = tanhf(g[2]);
+                const float out_gate = sigmoidf_ref(g[3]);
+                const float r_gate = sigmoidf_ref(g[4]);
+                const float lin_gate = pv[5];
+                float val = (forget_gate * cp) + (in_gate * act_gate);
+                c_out[o] = val;
+                val = out_gate * tanhf(val);
+                val = (float)((double)(val * r_gate) + (1. - (double)r_gate) * (double)lin_gate);
+                if (dropout) val = val * dm;
+                h_out[o] = val;
+                if (g_t) {
+                    float *go = g_t + (size_t)row * 6 * H + u;
+                    go[0] = in_gate;
+                    go[(size_t)1 * H] = forget_gate;
+                    go[(size_t)2 * H] = act_gate;
+                    go[(size_t)3 * H] = out_gate;
+                    go[(size_t)4 * H] = r_gate;
+                    go[(size_t)5 * H] = lin_gate;
+                }
+            }
+        }
+        if (i + 1 < s.T) grid_barrier(counters, slot, ++epoch * gridDim.x);
+    }
+}
+
+// backward of one layer: per step  (A) elementWise_bp for the block's own units -> d_gates[t], c_grad[t+1];
+// grid barrier;  (B) h_grad[t+1][:, own units] = d_gates[t][:, :5H] * Wh[own units, :]^T  (K = 5H, weights resident).
+// (A) of the next step only needs the block's own h_grad / c_grad entries, so one barrier per step suffices.
+__global__ __launch_bounds__(kGemvThreads) void hw_layer_bwd_kernel(SeqSched s, int H, const float *__restrict__ grad_in,
+                                                                   float *h_grad, float *c_grad,
+                                                                   const float *__restrict__ cl,
+                                                                   const float *__restrict__ gates,
+                                                                   const float *__restrict__ dropout, float *dg_all,
+                                                                   const float *__restrict__ wh, unsigned *counters, int slot)
+{
+    __shared__ __attribute__((aligned(16))) float vs[kNB * kChunk];
+    __shared__ float red[4 * 4 * 1 * kNB];
+    const int lane = threadIdx.x & 63, grp = lane >> 4;
+    const int ug = blockIdx.x * 4 + grp;
+    const bool u_ok = ug < H;
+    const float *const wrow[1] = {wh + (size_t)(u_ok ? ug : 0) * 5 * H};
+    WResident<1, 5> w;
+    load_resident<1, 5>(w, wrow, u_ok, true, 5 * H);
+    const size_t numEl = (size_t)s.B * H;
+    unsigned epoch = 0;
+    // inputs of phase (A) that do not depend on the recurrence, fetched one step ahead (they overlap phase (B))
+    struct StepIn {
+        float g[6], d_out, c_o, c_p, drop;
+    };
+    auto time_of = [&](int i) { return s.forward ? s.T - 1 - i : i; };
+    auto fetch = [&](int i, StepIn &x) {
+        const int t = time_of(i), n = covered_at(s, t);
+        if (threadIdx.x >= 4 * n) return;
+        const int b = threadIdx.x >> 2, u = blockIdx.x * 4 + (threadIdx.x & 3);
+        if (u >= H) return;
+        const int prev = s.forward ? t : (t + 2) % (s.T + 1);
+        const size_t idx = (size_t)b * H + u;
+        const float *gp = gates + (size_t)t * 6 * numEl + (size_t)b * 6 * H + u;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) x.g[k] = gp[(size_t)k * H];
+        x.d_out = grad_in[(size_t)t * numEl + idx];
+        x.c_o = cl[(size_t)(t + 1) * numEl + idx];
+        x.c_p = cl[(size_t)prev * numEl + idx];
+        x.drop = dropout ? dropout[idx] : 1.f;
+    };
+    StepIn in;
+    fetch(0, in);
+    for (int i = 0; i < s.T; ++i) {
+        // the backward pass walks time in the opposite order of the layer's forward pass
+        const int t = time_of(i);
+        const int n = covered_at(s, t);
+        const int prev_grad = s.forward ? (t + 2) % (s.T + 1) : t;
+        float *dg = dg_all + (size_t)t * s.B * 6 * H;
+        if (threadIdx.x < 4 * n) {
+            const int b = threadIdx.x >> 2, u = blockIdx.x * 4 + (threadIdx.x & 3);
+            if (u < H) {
+                const size_t idx = (size_t)b * H + u;
+                float d_h = in.d_out + h_grad[(size_t)prev_grad * numEl + idx];
+                if (dropout) d_h = d_h * in.drop;
+                const float in_gate = in.g[0], forget_gate = in.g[1], act_gate = in.g[2];
+                const float out_gate = in.g[3], r_gate = in.g[4], lin_gate = in.g[5];
+                const float tc = tanhf(in.c_o);
+                const float d_o = d_h * r_gate;
+                const float d_c = d_o * out_gate * (1.f - tc * tc) + c_grad[(size_t)prev_grad * numEl + idx];
+                const float h_prime = out_gate * tc;
+                float *dgp = dg + (size_t)b * 6 * H + u;
+                dgp[0] = d_c * act_gate * in_gate * (1.f - in_gate);
+                dgp[(size_t)H] = d_c * in.c_p * forget_gate * (1.f - forget_gate);
+                dgp[(size_t)2 * H] = d_c * in_gate * (1.f - act_gate * act_gate);
+                dgp[(size_t)3 * H] = d_o * tc * out_gate * (1.f - out_gate);
+                dgp[(size_t)4 * H] = d_h * (h_prime - lin_gate) * r_gate * (1.f - r_gate);
+                dgp[(size_t)5 * H] = d_h * (1 - r_gate);
+                c_grad[(size_t)(t + 1) * numEl + idx] = forget_gate * d_c;
+            }
+        }
+        grid_barrier(counters, slot, ++epoch * gridDim.x);
+        if (i + 1 < s.T) fetch(i + 1, in);
+        for (int b0 = 0; b0 < n; b0 += kNB) {
+            float tot[1];
+            block_gemv_resident<1, 5>(w, dg, 6 * H, true, n, b0, 5 * H, vs, red, tot);
+            const int u = blockIdx.x * 4 + (threadIdx.x >> 3), row = b0 + (threadIdx.x & 7);
+            if (threadIdx.x < 4 * kNB && u < H && row < n) h_grad[(size_t)(t + 1) * numEl + (size_t)row * H + u] = tot[0];
+        }
+    }
 }
 
 // out[c] += sum_r in[r][c]   (bias gradient; the reference uses Sgemv with a ones vector, :342-355)
@@ -345,6 +650,21 @@ static LayerOffsets layer_offsets(int in_size, int H, int layer)
 }
 
 static bool al16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+constexpr size_t kCounterBytes = 256;   // grid-barrier counters of the persistent layer kernels (one per layer)
+static bool persistent_ok(int H, int B, int L)
+{
+    return H <= kChunk && H % 4 == 0 && B <= kSeqMaxB && L <= kBrokenWord;
+}
+static SeqSched make_sched(const int *lengths, int T, int B, bool forward_dir)
+{
+    SeqSched s;
+    s.T = T;
+    s.B = B;
+    s.forward = forward_dir ? 1 : 0;
+    for (int b = 0; b < kSeqMaxB; ++b) s.lengths[b] = (b < B) ? lengths[b] : 0;
+    return s;
+}
 
 static int launch_cell_fwd(int n, int H, const float *pre_i, int ld_i, const float *h_prev, const float *c_prev,
                            const float *wh_t, const float *bias, const float *dropout, float *h_out, float *c_out,
@@ -436,7 +756,7 @@ size_t mh_hwlstm_fwd_ws_bytes(int in_size, int H, int B, int L, int T)
     (void)L;
     size_t s = align_up((size_t)T * B * 6 * H * sizeof(float), 256) + align_up((size_t)5 * H * H * sizeof(float), 256);
     s += std::max(mh_gemm_ws_bytes(T * B, 6 * H, in_size, 0), mh_gemm_ws_bytes(T * B, 6 * H, H, 0));
-    return s + 256;
+    return s + kCounterBytes + 256;
 }
 
 int mh_hwlstm_fwd(int in_size, int H, int B, int L, int T, const float *x, const int *lengths_host, float *h_data,
@@ -459,10 +779,17 @@ int mh_hwlstm_fwd(int in_size, int H, int B, int L, int T, const float *x, const
     ws += align_up((size_t)T * B * 6 * H * sizeof(float), 256);
     float *wh_t = reinterpret_cast<float *>(ws);
     ws += align_up((size_t)5 * H * H * sizeof(float), 256);
-    void *gws = ws;
-    const size_t gws_bytes = ws_bytes - (size_t)(ws - reinterpret_cast<char *>(workspace));
     const size_t numEl = (size_t)B * H;
     int ts[4096], ns[4096];
+    unsigned *counters = reinterpret_cast<unsigned *>(ws);   // one barrier counter per layer
+    ws += kCounterBytes;
+    const bool persistent = persistent_ok(H, B, L) && al16(h_data) && al16(wh_t);
+    if (persistent) {
+        hipError_t e = hipMemsetAsync(counters, 0, kCounterBytes, st);
+        if (e != hipSuccess) return (int)e;
+    }
+    void *gws = ws;
+    const size_t gws_bytes = ws_bytes - (size_t)(ws - reinterpret_cast<char *>(workspace));
 
     for (int layer = 0; layer < L; ++layer) {
         const LayerOffsets o = layer_offsets(in_size, H, layer);
@@ -478,6 +805,14 @@ int mh_hwlstm_fwd(int in_size, int H, int B, int L, int T, const float *x, const
         covered_schedule(lengths_host, T, B, fwd_dir, ts, ns);
         float *hl = h_data + (size_t)layer * (T + 1) * numEl;
         float *cl = c_data + (size_t)layer * (T + 1) * numEl;
+        if (persistent) {
+            SeqSched sched = make_sched(lengths_host, T, B, fwd_dir);
+            hipLaunchKernelGGL(hw_layer_fwd_kernel, dim3(ceil_div(H, 4)), dim3(kGemvThreads), 0, st, sched, H, tmp_i, hl, cl,
+                               wh_t, bias + (size_t)5 * H * layer, dropout + (size_t)layer * numEl,
+                               is_training ? gates + (size_t)layer * T * 6 * numEl : nullptr, counters, layer);
+            MH_TRY(check_launch("hw_layer_fwd_kernel"));
+            continue;
+        }
         for (int i = 0; i < T; ++i) {
             const int t = ts[i], n = ns[i];
             if (n == 0) continue;
@@ -501,6 +836,7 @@ size_t mh_hwlstm_bwd_ws_bytes(int in_size, int H, int B, int L, int T)
     size_t s = align_up((size_t)T * B * 6 * H * sizeof(float), 256);
     s += 2 * align_up((size_t)(T + 1) * numEl * sizeof(float), 256);
     s += 2 * align_up((size_t)T * numEl * sizeof(float), 256);
+    s += kCounterBytes;
     size_t g = 0;
     const int ins[2] = {in_size, H};
     for (int i = 0; i < 2; ++i) {
@@ -538,6 +874,13 @@ int mh_hwlstm_bwd(int in_size, int H, int B, int L, int T, const float *out_grad
     ws += align_up((size_t)T * numEl * sizeof(float), 256);
     below[1] = reinterpret_cast<float *>(ws);
     ws += align_up((size_t)T * numEl * sizeof(float), 256);
+    unsigned *counters = reinterpret_cast<unsigned *>(ws);
+    ws += kCounterBytes;
+    const bool persistent = persistent_ok(H, B, L) && al16(weight) && al16(dg_all);
+    if (persistent) {
+        hipError_t e = hipMemsetAsync(counters, 0, kCounterBytes, st);
+        if (e != hipSuccess) return (int)e;
+    }
     void *gws = ws;
     const size_t gws_bytes = ws_bytes - (size_t)(ws - reinterpret_cast<char *>(workspace));
     int ts[4096], ns[4096];
@@ -556,6 +899,13 @@ int mh_hwlstm_bwd(int in_size, int H, int B, int L, int T, const float *out_grad
         covered_schedule(lengths_host, T, B, !fwd_dir ? true : false, ts, ns);
         // (for a forward-direction layer the backward visits t = T-1..0 with n growing, which is exactly the
         //  schedule of a backward-direction forward pass, and vice versa)
+        if (persistent && (o.wh % 4 == 0)) {
+            SeqSched sched = make_sched(lengths_host, T, B, fwd_dir);
+            hipLaunchKernelGGL(hw_layer_bwd_kernel, dim3(ceil_div(H, 4)), dim3(kGemvThreads), 0, st, sched, H, grad_in,
+                               h_grad, c_grad, cl, gates + (size_t)layer * T * 6 * numEl,
+                               dropout + (size_t)layer * numEl, dg_all, weight + o.wh, counters, layer);
+            MH_TRY(check_launch("hw_layer_bwd_kernel"));
+        } else
         for (int i = 0; i < T; ++i) {
             const int t = ts[i], n = ns[i];
             if (n == 0) continue;

@@ -575,6 +575,52 @@ __device__ __forceinline__ void load_planned_km(Stage<WD> &s, const Plan<WD> &pl
 }
 #endif
 
+#if MH_PLANES
+// ---------------------------------------------------------------------------------------------------------------
+// Operands that already ARE bf16 planes in global memory (packed weights): a tile row's k-tile is 96 contiguous
+// bytes in exactly the LDS row format, so staging is 16-byte chunks copied global -> registers -> LDS with no VALU:
+// chunk e = tid + 256 j is row e / 6, slot e % 6 (six consecutive lanes read one row's 96 bytes).
+// ---------------------------------------------------------------------------------------------------------------
+template <int WD>
+struct PStage {
+    static constexpr int n = (WD * 6 + kThreads - 1) / kThreads;
+    u32x4 v[n];
+};
+template <int WD>
+struct PPlan {
+    unsigned v[PStage<WD>::n];     // global byte offset of the chunk (kOobOffset: reads zeros)
+    unsigned lds[PStage<WD>::n];   // LDS byte offset of the chunk (slot swizzled)
+};
+template <int WD, typename RowOk>
+__device__ __forceinline__ void plan_planes(PPlan<WD> &pl, RowOk row_ok, unsigned row_stride_bytes, int tid)
+{
+#pragma unroll
+    for (int j = 0; j < PStage<WD>::n; ++j) {
+        const int e = tid + kThreads * j, r = e / 6, c = e % 6;
+        const bool ok = (e < WD * 6) && row_ok(r);
+        pl.v[j] = ok ? (unsigned)r * row_stride_bytes + 16u * c : kOobOffset;
+        pl.lds[j] = (unsigned)(r * kRowDw * 4 + 16 * (c ^ plane_swz(r)));
+    }
+}
+template <int WD>
+__device__ __forceinline__ void load_planes(PStage<WD> &s, const PPlan<WD> &pl, const GSrc &g, unsigned soff)
+{
+#pragma unroll
+    for (int j = 0; j < PStage<WD>::n; ++j) {
+        const auto raw = __builtin_amdgcn_raw_buffer_load_b128(g.rsrc, (int)pl.v[j], (int)soff, 0);
+        s.v[j] = __builtin_bit_cast(u32x4, raw);
+    }
+}
+template <int WD>
+__device__ __forceinline__ void store_planes(const PStage<WD> &s, const PPlan<WD> &pl, float *tile, int tid)
+{
+    char *base = reinterpret_cast<char *>(tile);
+#pragma unroll
+    for (int j = 0; j < PStage<WD>::n; ++j)
+        if ((WD * 6) % kThreads == 0 || tid + kThreads * j < WD * 6) *reinterpret_cast<u32x4 *>(base + pl.lds[j]) = s.v[j];
+}
+#endif
+
 // tile row (or column) held by MFMA index idx (0..31) of sub-tile s, for the two operand layouts
 template <bool WM>
 __device__ __forceinline__ int tile_coord(int idx, int s)

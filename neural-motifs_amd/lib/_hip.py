@@ -20,7 +20,7 @@ SYMBOLS = (
     'mh_nms_ws_bytes', 'mh_nms', 'mh_nms_batched_ws_bytes', 'mh_nms_batched',
     'mh_roi_align_fwd', 'mh_roi_align_bwd', 'mh_draw_union_boxes', 'mh_bbox_overlaps',
     'mh_gemm_ws_bytes', 'mh_gemm_auto_splitk', 'mh_gemm_f32',
-    'mh_conv3x3_pack_weight', 'mh_conv3x3_ws_bytes', 'mh_conv3x3_nhwc', 'mh_conv_first_nchw', 'mh_maxpool2x2_nhwc',
+    'mh_conv3x3_packed_floats', 'mh_conv3x3_pack_weight', 'mh_conv3x3_ws_bytes', 'mh_conv3x3_nhwc', 'mh_conv_first_nchw', 'mh_maxpool2x2_nhwc',
     'mh_im2col_nhwc', 'mh_nchw_to_nhwc', 'mh_nhwc_to_nchw',
     'mh_hwlstm_fwd_ws_bytes', 'mh_hwlstm_fwd', 'mh_hwlstm_bwd_ws_bytes', 'mh_hwlstm_bwd',
     'mh_hwlstm_cell_fwd', 'mh_hwlstm_cell_bwd', 'mh_gemv_rows',
@@ -48,6 +48,7 @@ def lib():
             getattr(L, name)          # AttributeError if the library is stale
         L.mh_last_error.restype = ctypes.c_char_p
         for name in ('mh_nms_ws_bytes', 'mh_nms_batched_ws_bytes', 'mh_gemm_ws_bytes', 'mh_conv3x3_ws_bytes', 'mh_bn_ws_bytes',
+                     'mh_conv3x3_packed_floats',
                      'mh_hwlstm_fwd_ws_bytes', 'mh_hwlstm_bwd_ws_bytes'):
             getattr(L, name).restype = ctypes.c_size_t
         _lib = L
@@ -220,15 +221,18 @@ def bbox_overlaps(a, b):
 
 # ----------------------------------------------------------------------------------------------- conv stack
 def conv3x3_pack_weight(w, flip_transpose=False):
+    """packed weights (opaque fp32 container [9, N, *]) of the conv that consumes them: N = Cout outputs, or for the
+    dgrad conv (flip_transpose) N = Cin outputs"""
     Cout, Cin = w.shape[0], w.shape[1]
-    wt = torch.empty((9, Cin, Cout) if flip_transpose else (9, Cout, Cin), dtype=torch.float32, device=w.device)
+    N, K = (Cin, Cout) if flip_transpose else (Cout, Cin)
+    wt = torch.empty(9, N, lib().mh_conv3x3_packed_floats(N, K) // (9 * N), dtype=torch.float32, device=w.device)
     rc = lib().mh_conv3x3_pack_weight(f32(w), Cout, Cin, c_int(int(flip_transpose)), f32(wt), stream())
     _check(rc, 'mh_conv3x3_pack_weight')
     return wt
 
 
 def conv3x3_nhwc(x, wt, bias, epilogue):
-    """x [B,H,W,Cin], wt [9,Cout,Cin] (conv3x3_pack_weight) -> [B,H,W,Cout]"""
+    """x [B,H,W,Cin], wt = conv3x3_pack_weight(...) [9,Cout,*] -> [B,H,W,Cout]"""
     B, H, W, Cin = x.shape
     Cout = wt.shape[1]
     out = torch.empty(B, H, W, Cout, dtype=torch.float32, device=x.device)

@@ -294,6 +294,7 @@ def _lstm_problem(lengths, in_size, H, nl, seed, p=0.0):
 
 @pytest.mark.parametrize('lengths,in_size,H,nl,p', [([5, 3, 3, 1], 24, 16, 1, 0.0), ([6, 6, 2], 40, 32, 2, 0.3),
                                                      ([4, 2, 1], 20, 8, 3, 0.2), ([7], 12, 20, 4, 0.0),
+                                                     ([3, 2], 10, 18, 2, 0.0),   # H % 4 != 0: per-step launch path
                                                      ([20] * 3 + [17, 9, 9, 4, 2, 1, 1], 712, 512, 2, 0.1)])
 def test_hwlstm_fwd_bwd(hip, lengths, in_size, H, nl, p):
     from oracle import lstm as OL

@@ -72,7 +72,7 @@ def main():
     tot_ms, tot_fl = 0.0, 0.0
     for (S, ci, co) in layers:
         x = torch.randn(B, S, S, ci, device=dev)
-        wt = torch.randn(9, co, ci, device=dev) * 0.05
+        wt = _hip.conv3x3_pack_weight(torch.randn(co, ci, 3, 3, device=dev) * 0.05)
         bias = torch.randn(co, device=dev)
         ms = timeit(lambda: _hip.conv3x3_nhwc(x, wt, bias, 1), iters=5)
         fl = 2.0 * B * S * S * ci * co * 9

@@ -22,7 +22,7 @@ for name, M, N, K, ta, tb in [('sq4096',4096,4096,4096,0,1),('fc6_fwd',1536,4096
     del a,b,out
 B=6
 for (S, ci, co, mult) in [(592,64,64,1),(296,64,128,1),(296,128,128,1),(148,128,256,1),(148,256,256,2),(74,256,512,1),(74,512,512,2),(37,512,512,3)]:
-    x = torch.randn(B, S, S, ci, device=dev); wt = torch.randn(9, co, ci, device=dev)*0.05; bias = torch.randn(co, device=dev)
+    x = torch.randn(B, S, S, ci, device=dev); wt = _hip.conv3x3_pack_weight(torch.randn(co, ci, 3, 3, device=dev) * 0.05); bias = torch.randn(co, device=dev)
     ms = timeit(lambda: _hip.conv3x3_nhwc(x, wt, bias, 1), iters=5)
     tot+=ms*mult
     print('CONV %4d %3d->%3d %8.3f ms %7.2f TF/s' % (S, ci, co, ms, 2.0*B*S*S*ci*co*9/ms/1e9), flush=True)
