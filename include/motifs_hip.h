@@ -180,6 +180,22 @@ int mh_hwlstm_cell_bwd(int n, int H, const float *d_h, const float *d_c_out, con
 int mh_gemv_rows(int n, int R, int K, const float *v, int ldv, const float *wt, int ldw,
                  const float *bias, float *out, int ldo, void *stream);
 
+/* One highway-LSTM layer over a PACKED time-major batch (PackedSequence order) in a single launch: the label
+ * decoder's recurrence under teacher forcing (lib/lstm/decoder_rnn.py:151-215; the reference steps a Python loop of
+ * cuBLAS + elementwise calls).  batch_sizes_host[T] non-increasing, N = sum.  h_buf / c_buf: B + N rows, the first
+ * B = the zero initial state (zeroed by the caller), row B + r = state of packed row r.  pre_i [N,6H] = input
+ * projection incl. bias; w_state [5H,H]; gates [N,6H] saved for the backward.  Shapes: H <= 512, H % 4 == 0,
+ * B <= 32 (MH_EINVAL otherwise -- step with mh_hwlstm_cell_fwd/bwd instead).  Workspace: mh_hwcell_seq_ws_bytes(). */
+size_t mh_hwcell_seq_ws_bytes(void);
+int mh_hwcell_seq_fwd(int H, int B, int T, const int *batch_sizes_host, const float *pre_i,
+                      const float *w_state, const float *b_state, const float *dropout /*[B,H] or NULL*/,
+                      float *h_buf, float *c_buf, float *gates, void *workspace, size_t ws_bytes, void *stream);
+int mh_hwcell_seq_bwd(int H, int B, int T, const int *batch_sizes_host, const float *dh_all /*[N,H]*/,
+                      const float *c_buf, const float *gates, const float *dropout,
+                      const float *w_state_t /*[H,5H]*/, float *d_pre /*[N,6H]*/, float *hgrad_buf,
+                      float *cgrad_buf /*scratch, B + N rows each*/, void *workspace, size_t ws_bytes,
+                      void *stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Tail of the training step: global grad-norm clip + SGD(momentum, weight decay) as multi-tensor kernels.
  * Replaces lib/pytorch_misc.py:416-455 (`clip_grad_norm`: one host sync per parameter) and torch.optim.SGD

@@ -269,6 +269,9 @@ __device__ __forceinline__ void block_gemv_resident(const WResident<NR, NCH> &w,
 constexpr int kSeqMaxB = 32;
 struct SeqSched {
     int T, B, forward;
+    int packed;   // 0: padded [T][B] rows, state slots [T+1][B] (slot 0 = initial state);  1: time-major PACKED rows
+                  // (PackedSequence order, step t = rows start(t) .. start(t)+n_t), state buffers [B + N] rows whose
+                  // first B rows are the (zero) initial state; forward direction only
     int lengths[kSeqMaxB];
 };
 __device__ __forceinline__ int covered_at(const SeqSched &s, int t)
@@ -276,6 +279,35 @@ __device__ __forceinline__ int covered_at(const SeqSched &s, int t)
     int n = 0;
     for (int b = 0; b < s.B; ++b) n += (s.lengths[b] > t) ? 1 : 0;
     return n;
+}
+// row offsets of timestep t: `io` = rows of per-step inputs/outputs (pre_i, gates, grad_in, d_gates),
+// `state` = rows of the state written at t, `before` / `after` = rows of the state of time t-1 / t+1 in walking
+// order of the FORWARD pass (for a reverse-direction layer "before" is time t+1), n_after = valid rows there.
+struct StepRows {
+    size_t io, state, before, after;
+    int n, n_after;
+};
+__device__ __forceinline__ StepRows step_rows(const SeqSched &s, int t)
+{
+    StepRows r;
+    r.n = covered_at(s, t);
+    if (!s.packed) {
+        const int tb = s.forward ? t : (t + 2) % (s.T + 1), ta = s.forward ? (t + 2) % (s.T + 1) : t;
+        r.io = (size_t)t * s.B;
+        r.state = (size_t)(t + 1) * s.B;
+        r.before = (size_t)tb * s.B;
+        r.after = (size_t)ta * s.B;
+        r.n_after = s.B;                     // rows beyond the covered ones are zero in the padded buffers
+        return r;
+    }
+    int start = 0, n_prev = 0;
+    for (int q = 0; q < t; ++q) { n_prev = covered_at(s, q); start += n_prev; }
+    r.io = (size_t)start;
+    r.state = (size_t)s.B + start;
+    r.before = (t == 0) ? 0 : (size_t)s.B + start - n_prev;
+    r.after = (t + 1 < s.T) ? (size_t)s.B + start + r.n : 0;
+    r.n_after = (t + 1 < s.T) ? covered_at(s, t + 1) : 0;
+    return r;
 }
 
 #ifndef MH_BAR_SLEEP
@@ -466,12 +498,12 @@ __global__ __launch_bounds__(kGemvThreads) void hw_layer_fwd_kernel(SeqSched s, 
     unsigned epoch = 0;
     for (int i = 0; i < s.T; ++i) {
         const int t = s.forward ? i : s.T - 1 - i;
-        const int n = covered_at(s, t);
-        const int prev = s.forward ? t : (t + 2) % (s.T + 1);
-        const float *h_prev = hl + (size_t)prev * numEl, *c_prev = cl + (size_t)prev * numEl;
-        float *h_out = hl + (size_t)(t + 1) * numEl, *c_out = cl + (size_t)(t + 1) * numEl;
-        const float *pi_t = pre_i + (size_t)t * s.B * 6 * H;
-        float *g_t = gates ? gates + (size_t)t * 6 * numEl : nullptr;
+        const StepRows rw = step_rows(s, t);
+        const int n = rw.n;
+        const float *h_prev = hl + rw.before * H, *c_prev = cl + rw.before * H;
+        float *h_out = hl + rw.state * H, *c_out = cl + rw.state * H;
+        const float *pi_t = pre_i + rw.io * 6 * H;
+        float *g_t = gates ? gates + rw.io * 6 * H : nullptr;
         for (int b0 = 0; b0 < n; b0 += kNB) {
             // the gate-math threads fetch everything that does not depend on h_{t-1} BEFORE the recurrent product,
             // so those global-memory round trips overlap it
@@ -545,39 +577,41 @@ __global__ __launch_bounds__(kGemvThreads) void hw_layer_bwd_kernel(SeqSched s, 
     };
     auto time_of = [&](int i) { return s.forward ? s.T - 1 - i : i; };
     auto fetch = [&](int i, StepIn &x) {
-        const int t = time_of(i), n = covered_at(s, t);
-        if (threadIdx.x >= 4 * n) return;
+        const int t = time_of(i);
+        const StepRows rw = step_rows(s, t);
+        if (threadIdx.x >= 4 * rw.n) return;
         const int b = threadIdx.x >> 2, u = blockIdx.x * 4 + (threadIdx.x & 3);
         if (u >= H) return;
-        const int prev = s.forward ? t : (t + 2) % (s.T + 1);
         const size_t idx = (size_t)b * H + u;
-        const float *gp = gates + (size_t)t * 6 * numEl + (size_t)b * 6 * H + u;
+        const float *gp = gates + (rw.io + b) * 6 * H + u;
 #pragma unroll
         for (int k = 0; k < 6; ++k) x.g[k] = gp[(size_t)k * H];
-        x.d_out = grad_in[(size_t)t * numEl + idx];
-        x.c_o = cl[(size_t)(t + 1) * numEl + idx];
-        x.c_p = cl[(size_t)prev * numEl + idx];
+        x.d_out = grad_in[rw.io * H + idx];
+        x.c_o = cl[rw.state * H + idx];
+        x.c_p = cl[rw.before * H + idx];
         x.drop = dropout ? dropout[idx] : 1.f;
     };
     StepIn in;
     fetch(0, in);
     for (int i = 0; i < s.T; ++i) {
-        // the backward pass walks time in the opposite order of the layer's forward pass
+        // the backward pass walks time in the opposite order of the layer's forward pass: the gradients arriving
+        // from the step processed just before sit in the rows of the state "after" t
         const int t = time_of(i);
-        const int n = covered_at(s, t);
-        const int prev_grad = s.forward ? (t + 2) % (s.T + 1) : t;
-        float *dg = dg_all + (size_t)t * s.B * 6 * H;
+        const StepRows rw = step_rows(s, t);
+        const int n = rw.n;
+        float *dg = dg_all + rw.io * 6 * H;
         if (threadIdx.x < 4 * n) {
             const int b = threadIdx.x >> 2, u = blockIdx.x * 4 + (threadIdx.x & 3);
             if (u < H) {
                 const size_t idx = (size_t)b * H + u;
-                float d_h = in.d_out + h_grad[(size_t)prev_grad * numEl + idx];
+                const bool has_rec = b < rw.n_after;
+                float d_h = in.d_out + (has_rec ? h_grad[rw.after * H + idx] : 0.f);
                 if (dropout) d_h = d_h * in.drop;
                 const float in_gate = in.g[0], forget_gate = in.g[1], act_gate = in.g[2];
                 const float out_gate = in.g[3], r_gate = in.g[4], lin_gate = in.g[5];
                 const float tc = tanhf(in.c_o);
                 const float d_o = d_h * r_gate;
-                const float d_c = d_o * out_gate * (1.f - tc * tc) + c_grad[(size_t)prev_grad * numEl + idx];
+                const float d_c = d_o * out_gate * (1.f - tc * tc) + (has_rec ? c_grad[rw.after * H + idx] : 0.f);
                 const float h_prime = out_gate * tc;
                 float *dgp = dg + (size_t)b * 6 * H + u;
                 dgp[0] = d_c * act_gate * in_gate * (1.f - in_gate);
@@ -586,7 +620,7 @@ __global__ __launch_bounds__(kGemvThreads) void hw_layer_bwd_kernel(SeqSched s, 
                 dgp[(size_t)3 * H] = d_o * tc * out_gate * (1.f - out_gate);
                 dgp[(size_t)4 * H] = d_h * (h_prime - lin_gate) * r_gate * (1.f - r_gate);
                 dgp[(size_t)5 * H] = d_h * (1 - r_gate);
-                c_grad[(size_t)(t + 1) * numEl + idx] = forget_gate * d_c;
+                c_grad[rw.state * H + idx] = forget_gate * d_c;
             }
         }
         grid_barrier(counters, slot, ++epoch * gridDim.x);
@@ -595,7 +629,7 @@ __global__ __launch_bounds__(kGemvThreads) void hw_layer_bwd_kernel(SeqSched s, 
             float tot[1];
             block_gemv_resident<1, 5>(w, dg, 6 * H, true, n, b0, 5 * H, vs, red, tot);
             const int u = blockIdx.x * 4 + (threadIdx.x >> 3), row = b0 + (threadIdx.x & 7);
-            if (threadIdx.x < 4 * kNB && u < H && row < n) h_grad[(size_t)(t + 1) * numEl + (size_t)row * H + u] = tot[0];
+            if (threadIdx.x < 4 * kNB && u < H && row < n) h_grad[rw.state * H + (size_t)row * H + u] = tot[0];
         }
     }
 }
@@ -662,6 +696,7 @@ static SeqSched make_sched(const int *lengths, int T, int B, bool forward_dir)
     s.T = T;
     s.B = B;
     s.forward = forward_dir ? 1 : 0;
+    s.packed = 0;
     for (int b = 0; b < kSeqMaxB; ++b) s.lengths[b] = (b < B) ? lengths[b] : 0;
     return s;
 }
@@ -825,6 +860,65 @@ int mh_hwlstm_fwd(int in_size, int H, int B, int L, int T, const float *x, const
         }
     }
     return MH_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// One highway-LSTM layer over a PACKED (PackedSequence, time-major) batch in one launch: the decoder recurrence of
+// lib/lstm/decoder_rnn.py:151-215 under teacher forcing (inputs known up front).  batch_sizes_host[t] = rows of step
+// t (non-increasing), N = their sum.  h_buf / c_buf have B + N rows: the first B rows are the initial state (the
+// caller zeroes them), row B + r is the state of packed row r.  Same arithmetic as mh_hwlstm_cell_fwd step by step.
+// Supported shapes: H <= 512, H % 4 == 0, B <= 32, 16-byte aligned buffers (MH_EINVAL otherwise: use the cell calls).
+// ---------------------------------------------------------------------------------------------------
+static int sched_from_batch_sizes(const int *batch_sizes, int T, int B, SeqSched &s)
+{
+    MH_REQUIRE(batch_sizes && T > 0 && B > 0 && B <= kSeqMaxB && batch_sizes[0] == B);
+    for (int t = 1; t < T; ++t) MH_REQUIRE(batch_sizes[t] >= 1 && batch_sizes[t] <= batch_sizes[t - 1]);
+    s.T = T;
+    s.B = B;
+    s.forward = 1;
+    s.packed = 1;
+    for (int b = 0; b < kSeqMaxB; ++b) {
+        int len = 0;
+        for (int t = 0; t < T; ++t) len += (batch_sizes[t] > b) ? 1 : 0;
+        s.lengths[b] = len;
+    }
+    return MH_OK;
+}
+
+size_t mh_hwcell_seq_ws_bytes(void) { return kCounterBytes; }
+
+int mh_hwcell_seq_fwd(int H, int B, int T, const int *batch_sizes_host, const float *pre_i, const float *w_state,
+                      const float *b_state, const float *dropout, float *h_buf, float *c_buf, float *gates,
+                      void *workspace, size_t ws_bytes, void *stream)
+{
+    MH_REQUIRE(H > 0 && pre_i && w_state && h_buf && c_buf && workspace && ws_bytes >= kCounterBytes);
+    MH_REQUIRE(persistent_ok(H, B, 1) && al16(w_state) && al16(h_buf) && al16(workspace));
+    SeqSched sched;
+    MH_TRY(sched_from_batch_sizes(batch_sizes_host, T, B, sched));
+    hipStream_t st = as_stream(stream);
+    hipError_t e = hipMemsetAsync(workspace, 0, kCounterBytes, st);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(hw_layer_fwd_kernel, dim3(ceil_div(H, 4)), dim3(kGemvThreads), 0, st, sched, H, pre_i, h_buf, c_buf,
+                       w_state, b_state, dropout, gates, reinterpret_cast<unsigned *>(workspace), 0);
+    return check_launch("hw_layer_fwd_kernel");
+}
+
+// backward of mh_hwcell_seq_fwd: d_pre [N,6H] (gates 0..4: gradient of input AND state projections, gate 5: d_lin)
+// from dh_all [N,H].  w_state_t = the state weight transposed to [H,5H]; hgrad_buf / cgrad_buf: scratch, B + N rows.
+int mh_hwcell_seq_bwd(int H, int B, int T, const int *batch_sizes_host, const float *dh_all, const float *c_buf,
+                      const float *gates, const float *dropout, const float *w_state_t, float *d_pre, float *hgrad_buf,
+                      float *cgrad_buf, void *workspace, size_t ws_bytes, void *stream)
+{
+    MH_REQUIRE(H > 0 && dh_all && c_buf && gates && w_state_t && d_pre && hgrad_buf && cgrad_buf && workspace);
+    MH_REQUIRE(ws_bytes >= kCounterBytes && persistent_ok(H, B, 1) && al16(w_state_t) && al16(d_pre) && al16(workspace));
+    SeqSched sched;
+    MH_TRY(sched_from_batch_sizes(batch_sizes_host, T, B, sched));
+    hipStream_t st = as_stream(stream);
+    hipError_t e = hipMemsetAsync(workspace, 0, kCounterBytes, st);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(hw_layer_bwd_kernel, dim3(ceil_div(H, 4)), dim3(kGemvThreads), 0, st, sched, H, dh_all, hgrad_buf,
+                       cgrad_buf, c_buf, gates, dropout, d_pre, w_state_t, reinterpret_cast<unsigned *>(workspace), 0);
+    return check_launch("hw_layer_bwd_kernel");
 }
 
 // workspace layout (backward): d_gates_all [T*B,6H] | h_grad [T+1,B,H] | c_grad [T+1,B,H] | below_grad x2 [T,B,H]

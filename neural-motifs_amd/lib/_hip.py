@@ -24,6 +24,7 @@ SYMBOLS = (
     'mh_im2col_nhwc', 'mh_nchw_to_nhwc', 'mh_nhwc_to_nchw',
     'mh_hwlstm_fwd_ws_bytes', 'mh_hwlstm_fwd', 'mh_hwlstm_bwd_ws_bytes', 'mh_hwlstm_bwd',
     'mh_hwlstm_cell_fwd', 'mh_hwlstm_cell_bwd', 'mh_gemv_rows',
+    'mh_hwcell_seq_ws_bytes', 'mh_hwcell_seq_fwd', 'mh_hwcell_seq_bwd',
     'mh_opt_chunk_elems', 'mh_multi_sumsq', 'mh_multi_sgd_step',
     'mh_bn_ws_bytes', 'mh_bn_stats', 'mh_bn_pool_fwd', 'mh_bn_residual_nchw', 'mh_nchw_to_nhwc_small', 'mh_bn_bwd',
 )
@@ -48,7 +49,7 @@ def lib():
             getattr(L, name)          # AttributeError if the library is stale
         L.mh_last_error.restype = ctypes.c_char_p
         for name in ('mh_nms_ws_bytes', 'mh_nms_batched_ws_bytes', 'mh_gemm_ws_bytes', 'mh_conv3x3_ws_bytes', 'mh_bn_ws_bytes',
-                     'mh_conv3x3_packed_floats',
+                     'mh_conv3x3_packed_floats', 'mh_hwcell_seq_ws_bytes',
                      'mh_hwlstm_fwd_ws_bytes', 'mh_hwlstm_bwd_ws_bytes'):
             getattr(L, name).restype = ctypes.c_size_t
         _lib = L
@@ -344,6 +345,40 @@ def hwlstm_cell_bwd(d_h, d_c_out, c_prev, c_out, gates, dropout):
                                   f32(d_gates), f32(d_c_in), stream())
     _check(rc, 'mh_hwlstm_cell_bwd')
     return d_gates, d_c_in
+
+
+def hwcell_seq_supported(H, B):
+    """shapes the single-launch packed recurrence (mh_hwcell_seq_*) accepts"""
+    return H <= 512 and H % 4 == 0 and B <= 32 and not os.environ.get('MOTIFS_STEP_DECODER')
+
+
+def hwcell_seq_fwd(pre_i_all, batch_sizes, w_state, b_state, dropout):
+    """packed recurrence in one launch; returns (h_buf, c_buf [B+N,H] with the B zero initial rows first, gates)"""
+    N, H = pre_i_all.shape[0], w_state.shape[1]
+    B, T, dev = int(batch_sizes[0]), len(batch_sizes), pre_i_all.device
+    h_buf = torch.zeros(B + N, H, dtype=torch.float32, device=dev)
+    c_buf = torch.zeros(B + N, H, dtype=torch.float32, device=dev)
+    gates = torch.empty(N, 6 * H, dtype=torch.float32, device=dev)
+    ws = workspace(lib().mh_hwcell_seq_ws_bytes(), dev, 'lstm_seq')
+    rc = lib().mh_hwcell_seq_fwd(H, B, T, _lengths_array(batch_sizes), f32(pre_i_all), f32(w_state), f32(b_state),
+                                 f32(dropout), f32(h_buf), f32(c_buf), f32(gates), ptr(ws), c_size_t(ws.numel()),
+                                 stream())
+    _check(rc, 'mh_hwcell_seq_fwd')
+    return h_buf, c_buf, gates
+
+
+def hwcell_seq_bwd(dh_all, batch_sizes, c_buf, gates, dropout, w_state_t):
+    N, H = dh_all.shape
+    B, T, dev = int(batch_sizes[0]), len(batch_sizes), dh_all.device
+    d_pre = torch.empty(N, 6 * H, dtype=torch.float32, device=dev)
+    hg = torch.empty(B + N, H, dtype=torch.float32, device=dev)
+    cg = torch.empty(B + N, H, dtype=torch.float32, device=dev)
+    ws = workspace(lib().mh_hwcell_seq_ws_bytes(), dev, 'lstm_seq')
+    rc = lib().mh_hwcell_seq_bwd(H, B, T, _lengths_array(batch_sizes), f32(dh_all), f32(c_buf), f32(gates),
+                                 f32(dropout), f32(w_state_t), f32(d_pre), f32(hg), f32(cg), ptr(ws),
+                                 c_size_t(ws.numel()), stream())
+    _check(rc, 'mh_hwcell_seq_bwd')
+    return d_pre
 
 
 def gemv_rows(v, wt, bias=None):

@@ -57,6 +57,17 @@ class _DecoderRecurrenceFn(torch.autograd.Function):
         N, H = pre_i_all.shape[0], w_state.shape[1]
         pre_i_all = pre_i_all.contiguous()
         w_state = w_state.contiguous()
+        ctx.seq = _hip.hwcell_seq_supported(H, int(batch_sizes[0]))
+        if ctx.seq:
+            # the whole recurrence in one launch (mh_hwcell_seq_fwd); the state buffers carry B zero rows in front
+            B = int(batch_sizes[0])
+            mask = None if dropout_mask is None else dropout_mask.contiguous()
+            h_buf, c_buf, gates_all = _hip.hwcell_seq_fwd(pre_i_all, [int(v) for v in batch_sizes], w_state, b_state,
+                                                          mask)
+            ctx.batch_sizes = [int(v) for v in batch_sizes]
+            ctx.has_mask = dropout_mask is not None
+            ctx.save_for_backward(w_state, h_buf, c_buf, gates_all, mask if mask is not None else h_buf[:B])
+            return h_buf[B:]
         h_all = pre_i_all.new_empty(N, H)
         c_all = pre_i_all.new_empty(N, H)
         gates_all = pre_i_all.new_empty(N, 6 * H)
@@ -78,10 +89,15 @@ class _DecoderRecurrenceFn(torch.autograd.Function):
     def backward(ctx, dh_all):
         w_state, h_all, c_all, gates_all, mask = ctx.saved_tensors
         bs = ctx.batch_sizes
-        N, H = h_all.shape
         dh_all = dh_all.contiguous()
-        d_pre = dh_all.new_zeros(N, 6 * H)
         w_state_t = w_state.t().contiguous()              # [H,5H]: row k contiguous over the gate columns
+        if ctx.seq:
+            B = bs[0]
+            d_pre = _hip.hwcell_seq_bwd(dh_all, bs, c_all, gates_all, mask if ctx.has_mask else None, w_state_t)
+            h_all = h_all[B:]
+            return (d_pre,) + _DecoderRecurrenceFn._param_grads(ctx, d_pre, h_all, bs) + (None, None)
+        N, H = h_all.shape
+        d_pre = dh_all.new_zeros(N, 6 * H)
         steps = _step_bounds(bs)
         dh_rec = dc_rec = None                             # gradients flowing from step t+1 (first n_{t+1} rows)
         for t in range(len(steps) - 1, -1, -1):
@@ -103,6 +119,11 @@ class _DecoderRecurrenceFn(torch.autograd.Function):
             if t > 0:
                 dh_rec = _hip.gemv_rows(dg[:, :5 * H], w_state_t)
                 dc_rec = dc_in
+        return (d_pre,) + _DecoderRecurrenceFn._param_grads(ctx, d_pre, h_all, bs) + (None, None)
+
+    @staticmethod
+    def _param_grads(ctx, d_pre, h_all, bs):
+        H = h_all.shape[1]
         gw = gb = None
         if ctx.needs_input_grad[1]:
             prev_rows = _prev_state_rows(bs)
@@ -112,7 +133,7 @@ class _DecoderRecurrenceFn(torch.autograd.Function):
             gw = _hip.gemm(d_pre[:, :5 * H], h_prev_all, True, False)         # [5H, H]
         if ctx.needs_input_grad[2]:
             gb = d_pre[:, :5 * H].sum(0)
-        return d_pre, gw, gb, None, None
+        return gw, gb
 
 
 class DecoderRNN(torch.nn.Module):

@@ -126,6 +126,9 @@ def install():
         xg, wg, bg = OL.highway_lstm_backward(out_grad, x, lengths, weight, dropout, H, L_, h_slots, c_slots, gates)
         return xg, (wg if need_weight_grad else None), (bg if need_weight_grad else None)
 
+    def hwcell_seq_supported(H, B):
+        return False                      # the plumbing tests exercise the per-step path
+
     def hwlstm_cell_fwd(pre_i, h_prev, c_prev, wh_t, bias_h, dropout, want_gates):
         H = h_prev.shape[1]
         ps = h_prev @ wh_t.t() + (bias_h if bias_h is not None else 0)

@@ -320,6 +320,50 @@ def test_hwlstm_fwd_bwd(hip, lengths, in_size, H, nl, p):
     np.testing.assert_array_equal(h2.cpu().numpy(), h_data.cpu().numpy())
 
 
+@pytest.mark.parametrize('H,batch_sizes', [(32, [6, 6, 5, 3, 3, 1]), (512, [6] * 9 + [5, 4, 4, 2, 1]), (20, [1, 1, 1])])
+def test_packed_recurrence_single_launch(hip, H, batch_sizes):
+    """mh_hwcell_seq_fwd/bwd (one persistent launch, grid barrier per step) == stepping the cell kernels"""
+    g = torch.Generator().manual_seed(H)
+    N, B = sum(batch_sizes), batch_sizes[0]
+    pre_i = (torch.randn(N, 6 * H, generator=g) * 0.5).cuda()
+    w = (torch.randn(5 * H, H, generator=g) * (1.0 / H ** 0.5)).cuda()
+    b = (torch.randn(5 * H, generator=g) * 0.1).cuda()
+    mask = ((torch.rand(B, H, generator=g) > 0.2).float() / 0.8).cuda()
+    dh = torch.randn(N, H, generator=g).cuda()
+    bounds, s0 = [], 0
+    for n in batch_sizes:
+        bounds.append((s0, s0 + n, n)); s0 += n
+    # reference: the per-step kernels
+    h_ref, c_ref, g_ref = [], [], []
+    h_prev = c_prev = torch.zeros(B, H, device='cuda')
+    for s, e, n in bounds:
+        h, c, gt = hip.hwlstm_cell_fwd(pre_i[s:e], h_prev[:n].contiguous(), c_prev[:n].contiguous(), w, b,
+                                       mask[:n].contiguous(), True)
+        h_ref.append(h); c_ref.append(c); g_ref.append(gt)
+        h_prev, c_prev = h, c
+    h_buf, c_buf, gates = hip.hwcell_seq_fwd(pre_i, batch_sizes, w, b, mask)
+    np.testing.assert_array_equal(h_buf[:B].cpu().numpy(), 0)
+    # (same formulas; the two kernels may contract a*b+c differently, hence not bitwise)
+    np.testing.assert_allclose(h_buf[B:].cpu().numpy(), torch.cat(h_ref).cpu().numpy(), rtol=0, atol=2e-6)
+    np.testing.assert_allclose(c_buf[B:].cpu().numpy(), torch.cat(c_ref).cpu().numpy(), rtol=0, atol=2e-6)
+    np.testing.assert_allclose(gates.cpu().numpy(), torch.cat(g_ref).cpu().numpy(), rtol=0, atol=2e-6)
+    wt = w.t().contiguous()
+    d_ref = [None] * len(bounds)
+    dh_rec = dc_rec = None
+    for t in range(len(bounds) - 1, -1, -1):
+        s, e, n = bounds[t]
+        d_h = dh[s:e].clone(); d_c = torch.zeros(n, H, device='cuda')
+        if dh_rec is not None:
+            m = dh_rec.shape[0]; d_h[:m] += dh_rec; d_c[:m] = dc_rec
+        c_prev = torch.cat(c_ref)[bounds[t - 1][0]:bounds[t - 1][0] + n].contiguous() if t > 0 else torch.zeros(n, H, device='cuda')
+        dg, dc_in = hip.hwlstm_cell_bwd(d_h, d_c, c_prev, c_ref[t].contiguous(), g_ref[t].contiguous(), mask[:n].contiguous())
+        d_ref[t] = dg
+        if t > 0:
+            dh_rec, dc_rec = hip.gemv_rows(dg[:, :5 * H], wt), dc_in
+    d_pre = hip.hwcell_seq_bwd(dh, batch_sizes, c_buf, gates, mask, wt)
+    np.testing.assert_allclose(d_pre.cpu().numpy(), torch.cat(d_ref).cpu().numpy(), rtol=0, atol=1e-5)
+
+
 def test_decoder_cell_and_gemv(hip):
     from oracle import lstm as OL
     g = torch.Generator().manual_seed(11)
