@@ -230,6 +230,11 @@ int mh_bn_pool_fwd(const float *x, long long N, int H, int W, int C, const float
 int mh_bn_residual_nchw(const float *x, long long N, int P, int C, const float *mean, const float *invstd,
                         const float *gamma, const float *beta, const float *residual_nchw, float *out_nchw,
                         void *stream);
+/* y = act(BN(x) + residual) on NHWC rows [M,C] (ResNet bottleneck epilogues, lib/resnet.py:25-46;
+ * mean/invstd from mh_bn_stats in train mode or from the running statistics in eval mode) */
+int mh_bn_apply_nhwc(const float *x, long long M, int C, const float *mean, const float *invstd,
+                     const float *gamma, const float *beta, const float *residual /*or NULL*/, int relu,
+                     float *out, void *stream);
 int mh_nchw_to_nhwc_small(const float *in_nchw, long long N, int P, int C, float *out_nhwc, void *stream);
 int mh_bn_bwd(const float *x, const float *g, const unsigned char *argmax, long long N, int H, int W, int C,
               const float *mean, const float *invstd, const float *gamma, int pooled, int relu_mask, float *dx,

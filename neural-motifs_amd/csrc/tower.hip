@@ -35,11 +35,16 @@ __global__ __launch_bounds__(256) void bn_partial_kernel(const float *__restrict
     if (BWD) {
         mu = reinterpret_cast<const float4 *>(mean)[c4];
         is = reinterpret_cast<const float4 *>(invstd)[c4];
+    } else {
+        mu = reinterpret_cast<const float4 *>(x)[c4];     // the pivot (row 0)
     }
     if (rl < nrl) {
         for (long long r = r0 + rl; r < std::min(M, r0 + kRowsPerBlock); r += nrl) {
             if (!BWD) {
-                const float4 v = reinterpret_cast<const float4 *>(x + r * C)[c4];
+                // sums of (x - pivot), pivot = row 0 of the tensor: a sample of the channel, so that
+                // var = E[(x-p)^2] - E[x-p]^2 does not cancel catastrophically when |mean| >> std
+                float4 v = reinterpret_cast<const float4 *>(x + r * C)[c4];
+                v.x -= mu.x; v.y -= mu.y; v.z -= mu.z; v.w -= mu.w;
                 s0.x += v.x; s0.y += v.y; s0.z += v.z; s0.w += v.w;
                 s1.x += v.x * v.x; s1.y += v.y * v.y; s1.z += v.z * v.z; s1.w += v.w * v.w;
             } else {
@@ -110,14 +115,15 @@ __device__ __forceinline__ bool bn_partial_sums(const float *__restrict__ partia
 // forward finalize: mean, biased var -> invstd; running stats with momentum (unbiased var), like nn.BatchNorm
 __global__ __launch_bounds__(kFinCh * kFinSl) void bn_finalize_fwd_kernel(
     const float *__restrict__ partial, int nblk, int C, long long M, float eps, float momentum,
-    float *__restrict__ mean, float *__restrict__ invstd, float *__restrict__ running_mean,
-    float *__restrict__ running_var)
+    const float *__restrict__ pivot, float *__restrict__ mean, float *__restrict__ invstd,
+    float *__restrict__ running_mean, float *__restrict__ running_var)
 {
     double s, ss;
     if (!bn_partial_sums(partial, nblk, C, s, ss)) return;
     const int c = blockIdx.x * kFinCh + threadIdx.x;
-    const double mu = s / (double)M;
-    double var = ss / (double)M - mu * mu;
+    const double dm = s / (double)M;                    // E[x - pivot], pivot = row 0 (see bn_partial_kernel)
+    const double mu = (double)pivot[c] + dm;
+    double var = ss / (double)M - dm * dm;
     if (var < 0.0) var = 0.0;
     mean[c] = (float)mu;
     invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
@@ -201,6 +207,33 @@ __global__ __launch_bounds__(256) void bn_residual_nchw_kernel(const float *__re
             const size_t o = (n * C + c) * (size_t)P + p;
             out[o] = (residual ? residual[o] : 0.f) + tile[tx][j];
         }
+    }
+}
+
+// y[m][c] = act(BN(x)[m][c] + residual[m][c])   (all NHWC rows; ResNet bottleneck epilogues, lib/resnet.py:25-46)
+__global__ __launch_bounds__(256) void bn_apply_nhwc_kernel(const float4 *__restrict__ x, const float *__restrict__ mean,
+                                                            const float *__restrict__ invstd,
+                                                            const float *__restrict__ gamma,
+                                                            const float *__restrict__ beta,
+                                                            const float4 *__restrict__ residual, long long M, int C,
+                                                            int relu, float4 *__restrict__ out)
+{
+    const int C4 = C >> 2;
+    const long long total = M * C4;
+    for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total;
+         idx += (long long)blockDim.x * gridDim.x) {
+        const int c4 = (int)(idx % C4);
+        const float4 mu = reinterpret_cast<const float4 *>(mean)[c4], is = reinterpret_cast<const float4 *>(invstd)[c4];
+        const float4 ga = reinterpret_cast<const float4 *>(gamma)[c4], be = reinterpret_cast<const float4 *>(beta)[c4];
+        const float4 v = x[idx];
+        float4 y = make_float4(bn_affine(v.x, mu.x, is.x, ga.x, be.x), bn_affine(v.y, mu.y, is.y, ga.y, be.y),
+                               bn_affine(v.z, mu.z, is.z, ga.z, be.z), bn_affine(v.w, mu.w, is.w, ga.w, be.w));
+        if (residual) {
+            const float4 r = residual[idx];
+            y.x += r.x; y.y += r.y; y.z += r.z; y.w += r.w;
+        }
+        if (relu) { y.x = fmaxf(y.x, 0.f); y.y = fmaxf(y.y, 0.f); y.z = fmaxf(y.z, 0.f); y.w = fmaxf(y.w, 0.f); }
+        out[idx] = y;
     }
 }
 
@@ -323,7 +356,7 @@ int mh_bn_stats(const float *x, long long M, int C, float eps, float momentum, f
     rc = check_launch("bn_partial_kernel<fwd>");
     if (rc) return rc;
     hipLaunchKernelGGL(bn_finalize_fwd_kernel, dim3(ceil_div(C, kFinCh)), dim3(kFinCh * kFinSl), 0, st, partial, nblk, C, M, eps, momentum,
-                       mean, invstd, running_mean, running_var);
+                       x, mean, invstd, running_mean, running_var);
     return check_launch("bn_finalize_fwd_kernel");
 }
 
@@ -347,6 +380,19 @@ int mh_bn_residual_nchw(const float *x, long long N, int P, int C, const float *
     hipLaunchKernelGGL(bn_residual_nchw_kernel, dim3(ceil_div(C, 32), ceil_div(P, 32), (unsigned)N), dim3(256), 0,
                        as_stream(stream), x, mean, invstd, gamma, beta, residual_nchw, P, C, out_nchw);
     return check_launch("bn_residual_nchw_kernel");
+}
+
+int mh_bn_apply_nhwc(const float *x, long long M, int C, const float *mean, const float *invstd, const float *gamma,
+                     const float *beta, const float *residual, int relu, float *out, void *stream)
+{
+    int rc = check_bn_args(M, C);
+    if (rc) return rc;
+    MH_REQUIRE(x && mean && invstd && gamma && beta && out);
+    MH_REQUIRE(((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(residual)) & 15) == 0);
+    hipLaunchKernelGGL(bn_apply_nhwc_kernel, dim3(grid_for(M * (C / 4))), dim3(256), 0, as_stream(stream),
+                       reinterpret_cast<const float4 *>(x), mean, invstd, gamma, beta,
+                       reinterpret_cast<const float4 *>(residual), M, C, relu, reinterpret_cast<float4 *>(out));
+    return check_launch("bn_apply_nhwc_kernel");
 }
 
 int mh_nchw_to_nhwc_small(const float *in_nchw, long long N, int P, int C, float *out_nhwc, void *stream)

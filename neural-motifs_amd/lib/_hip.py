@@ -26,7 +26,7 @@ SYMBOLS = (
     'mh_hwlstm_cell_fwd', 'mh_hwlstm_cell_bwd', 'mh_gemv_rows',
     'mh_hwcell_seq_ws_bytes', 'mh_hwcell_seq_fwd', 'mh_hwcell_seq_bwd',
     'mh_opt_chunk_elems', 'mh_multi_sumsq', 'mh_multi_sgd_step',
-    'mh_bn_ws_bytes', 'mh_bn_stats', 'mh_bn_pool_fwd', 'mh_bn_residual_nchw', 'mh_nchw_to_nhwc_small', 'mh_bn_bwd',
+    'mh_bn_ws_bytes', 'mh_bn_stats', 'mh_bn_pool_fwd', 'mh_bn_residual_nchw', 'mh_bn_apply_nhwc', 'mh_nchw_to_nhwc_small', 'mh_bn_bwd',
 )
 
 _lib = None
@@ -421,6 +421,15 @@ def bn_residual_nchw(x, mean, invstd, gamma, beta, residual):
     out = torch.empty(N, C, Hh, Ww, dtype=torch.float32, device=x.device)
     _check(lib().mh_bn_residual_nchw(f32(x), c_ll(N), Hh * Ww, C, f32(mean), f32(invstd), f32(gamma), f32(beta),
                                      f32(residual), f32(out), stream()), 'mh_bn_residual_nchw')
+    return out
+
+
+def bn_apply_nhwc(x, mean, invstd, gamma, beta, residual=None, relu=False):
+    """act(BN(x) + residual) on an NHWC tensor (last dim = channels)"""
+    C = x.shape[-1]
+    out = torch.empty_like(x)
+    _check(lib().mh_bn_apply_nhwc(f32(x), c_ll(x.numel() // C), C, f32(mean), f32(invstd), f32(gamma), f32(beta),
+                                  f32(residual), c_int(int(relu)), f32(out), stream()), 'mh_bn_apply_nhwc')
     return out
 
 

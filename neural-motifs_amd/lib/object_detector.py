@@ -5,7 +5,7 @@ proposal decode + on-device NMS, RoIAlign (coalesced NHWC gather) + fc6/fc7 on t
 batched per-class NMS (`filter_det`).
 
 Modes, constructor arguments, `forward` positional arguments, `Result` fields and state-dict keys are the
-reference's.  The ResNet-101 variant (`use_resnet=True`) is not built yet.
+reference's.  `use_resnet=True` builds the (reference-deprecated) ResNet-101 detector: lib/resnet.py.
 """
 import numpy as np
 import torch
@@ -71,6 +71,41 @@ def load_vgg(use_dropout=True, use_relu=True, use_linear=True, pretrained=False)
     return model
 
 
+def load_resnet():
+    """resnet101 minus layer4 / avgpool / fc (lib/object_detector.py:615-620); random init offline"""
+    from lib.resnet import ResNet101Trunk
+    return ResNet101Trunk()
+
+
+class ResNetCompress(nn.Sequential):
+    """Conv2d(1024, 256, 1) -> ReLU -> BatchNorm2d(256)  (lib/object_detector.py:84-88; child indices 0 and 2 carry the
+    parameters).  Runs NHWC: the 1x1 conv is one MFMA GEMM with fused bias + ReLU, BN on the HIP kernels."""
+
+    def __init__(self):
+        from lib.resnet import _BN
+        super(ResNetCompress, self).__init__(Conv1x1(1024, 256), nn.ReLU(inplace=True), _BN(256))
+
+    def forward(self, fmap):                     # logical NCHW, channels_last memory
+        from lib import _hip as H
+        with torch.no_grad():
+            x = fmap.permute(0, 2, 3, 1).contiguous()
+            B, Hh, Ww, C = x.shape
+            conv, bn = self[0], self[2]
+            y = H.gemm(x.view(-1, C), conv.weight.detach().view(conv.weight.shape[0], C), False, True,
+                       bias=conv.bias.detach(), epilogue=1).view(B, Hh, Ww, -1)
+            y = bn(y)
+        return y.permute(0, 3, 1, 2)
+
+
+class Conv1x1(nn.Module):
+    """parameter holder with nn.Conv2d's names/shapes (weight [Cout,Cin,1,1], bias [Cout])"""
+
+    def __init__(self, cin, cout):
+        super(Conv1x1, self).__init__()
+        ref = nn.Conv2d(cin, cout, kernel_size=1)
+        self.weight, self.bias = ref.weight, ref.bias
+
+
 class ObjectDetector(nn.Module):
     MODES = ('rpntrain', 'gtbox', 'refinerels', 'proposals')
 
@@ -79,8 +114,6 @@ class ObjectDetector(nn.Module):
         super(ObjectDetector, self).__init__()
         if mode not in self.MODES:
             raise ValueError("invalid mode")
-        if use_resnet:
-            raise NotImplementedError('ResNet-101 trunk: not built yet (BASELINE cfg4)')
         self.mode = mode
         self.classes = classes
         self.num_gpus = num_gpus
@@ -89,12 +122,21 @@ class ObjectDetector(nn.Module):
         self.max_per_img = max_per_img
         self.use_resnet = use_resnet
         self.thresh = thresh
-        vgg_model = load_vgg()
-        self.features = vgg_model.features
-        self.roi_fmap = vgg_model.classifier
-        self.score_fc = Linear(4096, self.num_classes)
-        self.bbox_fc = Linear(4096, self.num_classes * 4)
-        self.rpn_head = RPNHead(dim=512, input_dim=512)
+        if not self.use_resnet:
+            vgg_model = load_vgg()
+            self.features = vgg_model.features
+            self.roi_fmap = vgg_model.classifier
+            rpn_input_dim, output_dim = 512, 4096
+        else:   # "Deprecated" in the reference (lib/object_detector.py:83-99) but part of its surface
+            self.features = load_resnet()
+            self.compress = ResNetCompress()
+            self.roi_fmap = nn.Sequential(
+                Linear(256 * 7 * 7, 2048), nn.SELU(inplace=True), nn.AlphaDropout(p=0.05),
+                Linear(2048, 2048), nn.SELU(inplace=True), nn.AlphaDropout(p=0.05))
+            rpn_input_dim, output_dim = 1024, 2048
+        self.score_fc = Linear(output_dim, self.num_classes)
+        self.bbox_fc = Linear(output_dim, self.num_classes * 4)
+        self.rpn_head = RPNHead(dim=512, input_dim=rpn_input_dim)
 
     @property
     def num_classes(self):
@@ -105,7 +147,8 @@ class ObjectDetector(nn.Module):
         return self.features(x)
 
     def obj_feature_map(self, features, rois):
-        pooled = RoIAlignFunction(self.pooling_size, self.pooling_size, spatial_scale=1 / 16)(features, rois)
+        pooled = RoIAlignFunction(self.pooling_size, self.pooling_size, spatial_scale=1 / 16)(
+            self.compress(features) if self.use_resnet else features, rois)
         return self.roi_fmap(pooled.view(rois.size(0), -1))
 
     # ---------------------------------------------------------------------------------- box sources

@@ -1,0 +1,153 @@
+"""ResNet-101 trunk (conv1 .. layer3) for `ObjectDetector(use_resnet=True)` -- the reference's `load_resnet()`
+(lib/object_detector.py:615-620: torchvision `resnet101` minus layer4/avgpool/fc; feature_map :119-127) and the
+bottleneck of lib/resnet.py:8-46 (1x1 -> BN -> ReLU -> 3x3 (stride here) -> BN -> ReLU -> 1x1 -> BN, + identity or
+1x1/stride projection, ReLU).
+
+Module and parameter names are torchvision's (`conv1.weight`, `bn1.*`, `layer2.0.downsample.0.weight`, ...), so the
+reference's state dicts load.  Everything runs NHWC on the HIP kernels of libmotifs_hip.so:
+  1x1 convs            -> MFMA GEMM on the [pixels, C] view (weights used in place, [Cout, Cin] K-contiguous)
+  3x3 stride-1 convs   -> the implicit-GEMM conv kernel (packed weights cached)
+  7x7/2 stem, 3x3/2    -> im2col + MFMA GEMM
+  BatchNorm            -> mh_bn_stats (batch statistics + running-stat update in train mode, exactly like the
+                          reference, which calls detector.train() with frozen weights: train_rels.py:101) fused with
+                          the residual add and the ReLU in mh_bn_apply_nhwc; the stem's BN is fused with its 3x3/2 max-pool
+The trunk is forward-only (models/train_rels.py freezes the detector); its backward belongs to detector pre-training
+(SURVEY.md §8f)."""
+import torch
+import torch.nn as nn
+
+from lib import _hip
+from lib.hip_ops import _c
+
+BN_EPS = 1e-5
+BN_MOMENTUM = 0.1            # torchvision's BatchNorm2d default (the detector uses torchvision.models.resnet)
+
+
+class _Conv(nn.Module):
+    """bias-free conv holder with torchvision's parameter name (`weight` [Cout,Cin,k,k]) and a HIP forward on NHWC"""
+
+    def __init__(self, cin, cout, k, stride=1, pad=0):
+        super(_Conv, self).__init__()
+        self.k, self.stride, self.pad = k, stride, pad
+        self.weight = nn.Parameter(torch.empty(cout, cin, k, k))
+        n = k * k * cout
+        self.weight.data.normal_(0, (2.0 / n) ** 0.5)                       # lib/resnet.py:66-69
+        self._cache = (None, None)
+
+    def _derived(self):
+        """weight matrix / packed weights for the kernel in use, rebuilt only when the parameter changes"""
+        key = (self.weight._version, self.weight.data_ptr())
+        if self._cache[0] != key:
+            w = self.weight.detach()
+            cout, cin, k = w.shape[0], w.shape[1], self.k
+            if k == 1:
+                d = _c(w.view(cout, cin))
+            elif k == 3 and self.stride == 1 and cin % 16 == 0:
+                d = _hip.conv3x3_pack_weight(_c(w))
+            else:                                                            # im2col order: (ky*kw + kx)*C + c
+                K = k * k * cin
+                ld = (K + 3) // 4 * 4
+                d = w.new_zeros(cout, ld)
+                d[:, :K] = w.permute(0, 2, 3, 1).reshape(cout, K)
+            self._cache = (key, d)
+        return self._cache[1]
+
+    def forward(self, x):                       # x NHWC
+        B, H, W, C = x.shape
+        cout = self.weight.shape[0]
+        d = self._derived()
+        if self.k == 1:
+            if self.stride != 1:
+                x = x[:, ::self.stride, ::self.stride, :].contiguous()
+                B, H, W, C = x.shape
+            return _hip.gemm(x.view(-1, C), d, False, True).view(B, H, W, cout)
+        if self.k == 3 and self.stride == 1 and C % 16 == 0:
+            return _hip.conv3x3_nhwc(_c(x), d, None, 0)
+        cols, Ho, Wo = _hip.im2col_nhwc(_c(x), self.k, self.k, self.stride, self.pad, ldo=d.shape[1])
+        return _hip.gemm(cols, d, False, True).view(B, Ho, Wo, cout)
+
+
+class _BN(nn.Module):
+    """BatchNorm2d parameters/buffers under torchvision's names; statistics + apply on the HIP kernels"""
+
+    def __init__(self, c, momentum=BN_MOMENTUM):
+        super(_BN, self).__init__()
+        self.weight = nn.Parameter(torch.ones(c))
+        self.bias = nn.Parameter(torch.zeros(c))
+        self.register_buffer('running_mean', torch.zeros(c))
+        self.register_buffer('running_var', torch.ones(c))
+        self.momentum = momentum
+
+    def stats(self, x):
+        if self.training:
+            return _hip.bn_stats(x.view(-1, x.shape[-1]), BN_EPS, self.momentum, self.running_mean, self.running_var)
+        return self.running_mean, torch.rsqrt(self.running_var + BN_EPS)
+
+    def forward(self, x, residual=None, relu=False):
+        mean, invstd = self.stats(x)
+        return _hip.bn_apply_nhwc(x, mean, invstd, self.weight.detach(), self.bias.detach(), residual, relu)
+
+
+class Bottleneck(nn.Module):
+    expansion = 4
+
+    def __init__(self, inplanes, planes, stride=1, downsample=None):
+        super(Bottleneck, self).__init__()
+        self.conv1 = _Conv(inplanes, planes, 1)
+        self.bn1 = _BN(planes)
+        self.conv2 = _Conv(planes, planes, 3, stride=stride, pad=1)
+        self.bn2 = _BN(planes)
+        self.conv3 = _Conv(planes, planes * 4, 1)
+        self.bn3 = _BN(planes * 4)
+        self.downsample = downsample
+        self.stride = stride
+
+    def forward(self, x):                       # NHWC
+        out = self.bn1(self.conv1(x), relu=True)
+        out = self.bn2(self.conv2(out), relu=True)
+        out = self.conv3(out)
+        residual = x if self.downsample is None else self.downsample[1](self.downsample[0](x))
+        return self.bn3(out, residual=residual, relu=True)
+
+
+class ResNet101Trunk(nn.Module):
+    """resnet101 with layer4 / avgpool / fc deleted (load_resnet, lib/object_detector.py:615-620)"""
+
+    LAYERS = (3, 4, 23)
+
+    def __init__(self):
+        super(ResNet101Trunk, self).__init__()
+        self.inplanes = 64
+        self.conv1 = _Conv(3, 64, 7, stride=2, pad=3)
+        self.bn1 = _BN(64)
+        self.layer1 = self._make_layer(64, self.LAYERS[0])
+        self.layer2 = self._make_layer(128, self.LAYERS[1], stride=2)
+        self.layer3 = self._make_layer(256, self.LAYERS[2], stride=2)
+
+    def _make_layer(self, planes, blocks, stride=1):
+        downsample = None
+        if stride != 1 or self.inplanes != planes * 4:
+            downsample = nn.Sequential(_Conv(self.inplanes, planes * 4, 1, stride=stride), _BN(planes * 4))
+        layers = [Bottleneck(self.inplanes, planes, stride, downsample)]
+        self.inplanes = planes * 4
+        for _ in range(1, blocks):
+            layers.append(Bottleneck(self.inplanes, planes))
+        return nn.Sequential(*layers)
+
+    def forward(self, x):
+        """[B,3,S,S] NCHW image -> c4 [B,1024,S/16,S/16] (channels_last memory), lib/object_detector.py:119-127"""
+        if any(p.requires_grad for p in self.parameters()) and torch.is_grad_enabled():
+            raise NotImplementedError('ResNet trunk backward is not built (detector pre-training path, SURVEY.md §8f); '
+                                      'freeze the detector as models/train_rels.py does')
+        with torch.no_grad():
+            y = self.conv1(_hip.nchw_to_nhwc(_c(x)))
+            if y.shape[1] % 2 or y.shape[2] % 2:
+                raise ValueError('the fused BN + 3x3/2 max-pool needs an even stem output (image side % 4 == 0)')
+            mean, invstd = self.bn1.stats(y)
+            # relu(maxpool(BN(y))) == maxpool(relu(BN(y))): one fused kernel, then the ReLU on the 4x smaller tensor
+            y, _ = _hip.bn_pool_fwd(y, mean, invstd, self.bn1.weight.detach(), self.bn1.bias.detach())
+            y = torch.relu_(y)
+            for layer in (self.layer1, self.layer2, self.layer3):
+                for block in layer:
+                    y = block(y)
+        return y.permute(0, 3, 1, 2)

@@ -60,6 +60,57 @@ def vgg_features(sd, x, prefix='detector.features.'):
     return x
 
 
+# --------------------------------------------------------------------------- ResNet-101 detector branch
+RESNET_LAYERS = (('layer1', 3, 1), ('layer2', 4, 2), ('layer3', 23, 2))
+
+
+def _bn(sd, x, prefix, training, momentum=0.1):
+    """nn.BatchNorm2d (torchvision default momentum 0.1, eps 1e-5); in train mode batch statistics are used AND the
+    running statistics in `sd` are updated in place -- the reference runs the frozen detector in train() mode
+    (models/train_rels.py:101)"""
+    return F.batch_norm(x, sd[prefix + 'running_mean'], sd[prefix + 'running_var'], sd[prefix + 'weight'],
+                        sd[prefix + 'bias'], training, momentum, 1e-5)
+
+
+def resnet_bottleneck(sd, x, p, stride, training):
+    """Bottleneck.forward, lib/resnet.py:25-46 (stride on the 3x3; `p` = state-dict prefix of the block)"""
+    out = F.relu(_bn(sd, F.conv2d(x, sd[p + 'conv1.weight']), p + 'bn1.', training))
+    out = F.relu(_bn(sd, F.conv2d(out, sd[p + 'conv2.weight'], None, stride=stride, padding=1), p + 'bn2.', training))
+    out = _bn(sd, F.conv2d(out, sd[p + 'conv3.weight']), p + 'bn3.', training)
+    if p + 'downsample.0.weight' in sd:
+        x = _bn(sd, F.conv2d(x, sd[p + 'downsample.0.weight'], None, stride=stride), p + 'downsample.1.', training)
+    return F.relu(out + x)
+
+
+def resnet_features(sd, x, training, prefix='detector.features.', taps=None):
+    """ObjectDetector.feature_map, ResNet branch (lib/object_detector.py:119-127) over torchvision resnet101 minus
+    layer4 (load_resnet :615-620).  `taps` (dict) receives the input of every block ('layer3.22' -> tensor) and the
+    stem output ('stem')."""
+    x = F.conv2d(x, sd[prefix + 'conv1.weight'], None, stride=2, padding=3)
+    x = F.relu(_bn(sd, x, prefix + 'bn1.', training))
+    x = F.max_pool2d(x, 3, 2, 1)
+    if taps is not None:
+        taps['stem'] = x
+    for name, blocks, stride in RESNET_LAYERS:
+        for b in range(blocks):
+            if taps is not None:
+                taps['%s.%d' % (name, b)] = x
+            x = resnet_bottleneck(sd, x, '%s%s.%d.' % (prefix, name, b), stride if b == 0 else 1, training)
+    return x
+
+
+def resnet_compress(sd, fmap, training, prefix='detector.compress.'):
+    """Conv2d(1024,256,1) -> ReLU -> BatchNorm2d(256)  (lib/object_detector.py:84-88)"""
+    y = F.relu(F.conv2d(fmap, sd[prefix + '0.weight'], sd[prefix + '0.bias']))
+    return _bn(sd, y, prefix + '2.', training)
+
+
+def resnet_roi_head(sd, pooled, prefix='detector.roi_fmap.'):
+    """Linear -> SELU -> AlphaDropout -> Linear -> SELU -> AlphaDropout (:89-96), eval mode (dropout = identity)"""
+    y = F.selu(F.linear(pooled, sd[prefix + '0.weight'], sd[prefix + '0.bias']))
+    return F.selu(F.linear(y, sd[prefix + '3.weight'], sd[prefix + '3.bias']))
+
+
 class _RoIAlignFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, feat, rois, ph, pw, scale):
