@@ -207,7 +207,12 @@ class RelModel(nn.Module):
         assert mode in MODES
         self.mode = mode
         if use_resnet:
-            raise NotImplementedError('ResNet-101 variant: not built yet (BASELINE cfg4)')
+            # The reference cannot run this configuration either: with use_resnet it never creates `roi_fmap_obj`
+            # (lib/rel_model.py:360-365) but obj_feature_map uses it unconditionally (:448) -> AttributeError on the
+            # first forward.  There is therefore no reference behaviour to be identical to (BASELINE cfg4); the
+            # ResNet-101 *detector* (ObjectDetector(use_resnet=True), lib/resnet.py) is built and parity-tested.
+            raise NotImplementedError('RelModel(use_resnet=True) is broken in the reference itself '
+                                      '(rel_model.py:360-365 vs :448); use the ResNet detector on its own')
         self.pooling_size = 7
         self.embed_dim = embed_dim
         self.hidden_dim = hidden_dim
