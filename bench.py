@@ -128,7 +128,7 @@ def main():
     fc = [p for n, p in model.named_parameters() if n.startswith('roi_fmap') and p.requires_grad]
     rest = [p for n, p in model.named_parameters() if not n.startswith('roi_fmap') and p.requires_grad]
     opt = FusedClipSGD([{'params': fc, 'lr': lr / 10.0}, {'params': rest}], lr=lr, momentum=0.9, weight_decay=1e-4)
-    buckets = D.GradBuckets([p for p in model.parameters() if p.requires_grad])
+    reducer = D.OverlappedGradReducer([p for p in model.parameters() if p.requires_grad])   # inert at world 1
     blobs = [make_blob(ds, range(i * BATCH, (i + 1) * BATCH), is_train=True) for i in range(n_img // BATCH)]
     for b in blobs:
         b.scatter()                                           # inputs resident in HBM before the timed region
@@ -144,8 +144,9 @@ def main():
         else:
             loss = l_obj + l_rel
         opt.zero_grad(set_to_none=True)
-        loss.backward()
-        buckets.all_reduce()
+        reducer.prepare()
+        loss.backward()                  # N > 1: each 32 MB gradient bucket is all-reduced (RCCL) as soon as it is complete
+        reducer.finish()
         opt.step(max_norm=5.0)           # global-norm clip (5.0) + SGD(momentum, wd) in three multi-tensor launches
         return loss
 

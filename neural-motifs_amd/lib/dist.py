@@ -10,8 +10,9 @@ over ALL rows of the global batch): each rank scales its loss by rows_rank / row
 (`global_row_weights`), gradients are then SUMMED.  Frozen detector parameters never enter a bucket.
 
 Buckets are ~32 MB of fp32 (xGMI is point-to-point, 7 links x ~153 GB/s per GPU: a few large messages, not many
-small ones) and are reduced asynchronously while later buckets are still being packed; `finish()` waits and copies
-back.  Works unchanged on CPU tensors with the gloo backend (used by the world_size-2 tests).
+small ones).  `OverlappedGradReducer` launches each bucket's all-reduce from a gradient hook while backward is still
+running; `GradBuckets` is the plain post-backward variant.  Both work unchanged on CPU tensors with the gloo backend
+(used by the world_size-2 tests).
 """
 import os
 
@@ -100,3 +101,117 @@ class GradBuckets(object):
     def all_reduce(self):
         self.start()
         self.finish()
+
+
+class OverlappedGradReducer(object):
+    """Bucketed gradient all-reduce OVERLAPPED with the backward pass.
+
+    Buckets are formed in reverse registration order (the order in which backward produces gradients).  A
+    post-accumulate hook on every parameter copies its fresh gradient into the bucket's persistent flat buffer; the
+    moment a bucket and all buckets before it are complete its asynchronous all-reduce (SUM) is launched (same order
+    on every rank), so the RCCL traffic of the early
+    buckets (relation head, 0.9 GB of fc6/fc7 gradients) runs under the rest of the backward pass.  `finish()`
+    launches whatever is left (parameters that received no gradient contribute zeros), waits, and re-points each
+    `.grad` at its slice of the reduced flat buffer -- no unpack copy, and stable gradient addresses for the fused
+    optimizer's pointer table.
+
+    Stream rule (two HIP streams run the backward of the two RelModel branches): every copy records an event; the
+    launch makes the current stream wait for all events of the bucket before handing the buffer to RCCL.
+    With world_size 1 the object is inert.  CPU tensors + gloo work the same way (tests)."""
+
+    def __init__(self, params, bucket_bytes=32 << 20):
+        self.params = [p for p in params if p.requires_grad]
+        self.enabled = world_size() > 1
+        self.buckets, cur, cur_bytes = [], [], 0
+        for p in reversed(self.params):
+            nbytes = p.numel() * p.element_size()
+            if cur and cur_bytes + nbytes > bucket_bytes:
+                self.buckets.append(cur)
+                cur, cur_bytes = [], 0
+            cur.append(p)
+            cur_bytes += nbytes
+        if cur:
+            self.buckets.append(cur)
+        self._where = {}                                   # id(param) -> (bucket index, offset)
+        for bi, bucket in enumerate(self.buckets):
+            off = 0
+            for p in bucket:
+                self._where[id(p)] = (bi, off)
+                off += p.numel()
+        self._flat = [None] * len(self.buckets)
+        self._pending = [0] * len(self.buckets)
+        self._seen = [set() for _ in self.buckets]
+        self._events = [[] for _ in self.buckets]
+        self._work = [None] * len(self.buckets)
+        self._armed = False
+        self._next = 0
+        self._handles = [p.register_post_accumulate_grad_hook(self._hook) for p in self.params] if self.enabled else []
+
+    def _buffer(self, bi):
+        if self._flat[bi] is None:
+            ref = self.buckets[bi][0]
+            self._flat[bi] = torch.zeros(sum(p.numel() for p in self.buckets[bi]), dtype=ref.dtype, device=ref.device)
+        return self._flat[bi]
+
+    def prepare(self):
+        """call before every backward()"""
+        if not self.enabled:
+            return
+        for bi, bucket in enumerate(self.buckets):
+            self._pending[bi] = len(bucket)
+            self._seen[bi] = set()
+            self._events[bi] = []
+            self._work[bi] = None
+        self._next = 0
+        self._armed = True
+
+    def _hook(self, p):
+        if not self._armed:
+            return
+        bi, off = self._where[id(p)]
+        flat = self._buffer(bi)
+        flat[off:off + p.numel()].copy_(p.grad.reshape(-1))
+        if flat.is_cuda:
+            ev = torch.cuda.Event()
+            ev.record()
+            self._events[bi].append(ev)
+        self._seen[bi].add(id(p))
+        self._pending[bi] -= 1
+        # collectives must be issued in the same order on every rank: strictly by bucket index (a bucket that
+        # completes early waits for its predecessors)
+        while self._next < len(self.buckets) and self._pending[self._next] == 0:
+            self._launch(self._next)
+            self._next += 1
+
+    def _launch(self, bi):
+        flat = self._buffer(bi)
+        if flat.is_cuda:
+            cur = torch.cuda.current_stream()
+            for ev in self._events[bi]:
+                cur.wait_event(ev)
+        self._work[bi] = dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True)
+
+    def finish(self):
+        """call after backward(): reduce the stragglers, wait, re-point .grad at the reduced buffers"""
+        if not self.enabled:
+            return
+        self._armed = False
+        for bi in range(self._next, len(self.buckets)):
+            flat = self._buffer(bi)
+            for p in self.buckets[bi]:
+                if id(p) not in self._seen[bi]:
+                    _, off = self._where[id(p)]
+                    flat[off:off + p.numel()].zero_()
+            self._launch(bi)
+        self._next = len(self.buckets)
+        for bi, bucket in enumerate(self.buckets):
+            self._work[bi].wait()
+            flat = self._flat[bi]
+            for p in bucket:
+                _, off = self._where[id(p)]
+                p.grad = flat[off:off + p.numel()].view_as(p)
+
+    def remove(self):
+        for h in self._handles:
+            h.remove()
+        self._handles = []

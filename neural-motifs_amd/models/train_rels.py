@@ -87,7 +87,7 @@ if conf.ckpt is not None:
                 dst[idx].bias.data.copy_(ckpt['state_dict']['roi_fmap.%d.bias' % idx])
 
 detector.cuda()
-buckets = D.GradBuckets([p for p in detector.parameters() if p.requires_grad])
+reducer = D.OverlappedGradReducer([p for p in detector.parameters() if p.requires_grad])   # inert at world 1
 
 
 def train_batch(b, verbose=False):
@@ -100,8 +100,9 @@ def train_batch(b, verbose=False):
     else:
         loss = l_obj + l_rel
     optimizer.zero_grad(set_to_none=True)
-    loss.backward()
-    buckets.all_reduce()
+    reducer.prepare()
+    loss.backward()          # world > 1: gradient buckets are all-reduced (RCCL) while backward is still running
+    reducer.finish()
     if isinstance(optimizer, FusedClipSGD):
         optimizer.step(max_norm=conf.clip)
         if verbose and rank == 0:
