@@ -122,6 +122,8 @@ class OverlappedGradReducer(object):
     def __init__(self, params, bucket_bytes=32 << 20):
         self.params = [p for p in params if p.requires_grad]
         self.enabled = world_size() > 1
+        # MOTIFS_GRAD_SYNC=post: no hooks, every bucket is reduced in finish() (after backward) -- an escape hatch
+        self.overlap = os.environ.get('MOTIFS_GRAD_SYNC', 'overlap') != 'post'
         self.buckets, cur, cur_bytes = [], [], 0
         for p in reversed(self.params):
             nbytes = p.numel() * p.element_size()
@@ -166,7 +168,7 @@ class OverlappedGradReducer(object):
         self._armed = True
 
     def _hook(self, p):
-        if not self._armed:
+        if not self._armed or not self.overlap:
             return
         bi, off = self._where[id(p)]
         flat = self._buffer(bi)
@@ -201,7 +203,10 @@ class OverlappedGradReducer(object):
             for p in self.buckets[bi]:
                 if id(p) not in self._seen[bi]:
                     _, off = self._where[id(p)]
-                    flat[off:off + p.numel()].zero_()
+                    if p.grad is not None and not self.overlap:
+                        flat[off:off + p.numel()].copy_(p.grad.reshape(-1))
+                    else:
+                        flat[off:off + p.numel()].zero_()
             self._launch(bi)
         self._next = len(self.buckets)
         for bi, bucket in enumerate(self.buckets):

@@ -46,7 +46,8 @@ def _worker(rank, world, port, out_dir):
     params = list(net.parameters()) + list(extra.parameters())
     red = D.OverlappedGradReducer(params, bucket_bytes=64)
     assert len(red.buckets) >= 3 and red.enabled
-    for step in range(2):
+    for step in range(3):
+        red.overlap = step != 1                             # step 1 exercises the MOTIFS_GRAD_SYNC=post path
         for p in params:
             p.grad = None
         out = net(x[lo:hi])
