@@ -39,7 +39,7 @@ def build(force=False, verbose=False):
                    '-Wall', '-Wno-unused-function']
             if src in EXACT:
                 cmd += ['-ffp-contract=off']
-            for knob in ('MH_MINW', 'MH_MFMA_SPLIT', 'MH_SPLIT_AT_STAGE', 'MH_DBG', 'MH_BAR_SLEEP'):
+            for knob in ('MH_MINW', 'MH_MFMA_SPLIT', 'MH_BAR_SLEEP'):
                 if os.environ.get(knob):
                     cmd += ['-D%s=%s' % (knob, os.environ[knob])]
             if verbose:

@@ -402,9 +402,9 @@ int mh_conv3x3_nhwc(const float *in, int B, int H, int W, int Cin, const float *
     p.partial = reinterpret_cast<float *>(workspace);
     dim3 grid((unsigned)ntiles, (unsigned)splitk);
     if (narrow)
-        launch_tile_kernel<conv3x3_nhwc_kernel<256, 64>>(grid, tile_lds_bytes<256, 64, true, false>(), as_stream(stream), p);
+        launch_tile_kernel<conv3x3_nhwc_kernel<256, 64>>(grid, tile_lds_bytes<256, 64, true, true>(), as_stream(stream), p);
     else
-        launch_tile_kernel<conv3x3_nhwc_kernel<128, 128>>(grid, tile_lds_bytes<128, 128, true, false>(), as_stream(stream), p);
+        launch_tile_kernel<conv3x3_nhwc_kernel<128, 128>>(grid, tile_lds_bytes<128, 128, true, true>(), as_stream(stream), p);
     int rc = check_launch("conv3x3_nhwc_kernel");
     if (rc || splitk == 1) return rc;
     return launch_splitk_reduce(p.partial, splitk, M, Cout, out, Cout, bias, epilogue, 0, as_stream(stream));

@@ -494,7 +494,6 @@ __global__ __launch_bounds__(kGemvThreads) void hw_layer_fwd_kernel(SeqSched s, 
 #pragma unroll
             for (int k = 0; k < 5; ++k) bias_u[k] = bias[k * H + u];
     }
-    const size_t numEl = (size_t)s.B * H;
     unsigned epoch = 0;
     for (int i = 0; i < s.T; ++i) {
         const int t = s.forward ? i : s.T - 1 - i;
@@ -569,7 +568,6 @@ __global__ __launch_bounds__(kGemvThreads) void hw_layer_bwd_kernel(SeqSched s, 
     const float *const wrow[1] = {wh + (size_t)(u_ok ? ug : 0) * 5 * H};
     WResident<1, 5> w;
     load_resident<1, 5>(w, wrow, u_ok, true, 5 * H);
-    const size_t numEl = (size_t)s.B * H;
     unsigned epoch = 0;
     // inputs of phase (A) that do not depend on the recurrence, fetched one step ahead (they overlap phase (B))
     struct StepIn {

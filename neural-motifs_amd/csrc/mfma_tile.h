@@ -34,10 +34,7 @@
 #define MH_MFMA_SPLIT 6   /* 6: bf16x6 split (fp32-accurate, default); 0: f32-input MFMA; 3: bf16x3 (2^-17, tests only) */
 #endif
 
-#ifndef MH_SPLIT_AT_STAGE
-#define MH_SPLIT_AT_STAGE 1   /* bf16 split done once per element when the k-tile is staged into LDS (bf16 planes) */
-#endif
-#define MH_PLANES (MH_MFMA_SPLIT && MH_SPLIT_AT_STAGE)
+#define MH_PLANES (MH_MFMA_SPLIT != 0)   /* bf16 builds keep the operands as bf16 planes in LDS, split once at staging */
 
 namespace mh {
 
@@ -154,105 +151,17 @@ __device__ __forceinline__ void mma_ktile_f32(const float *__restrict__ As, cons
 // 2^-24 relative magnitude,
 //     a*b = a1b1 + (a1b2 + a2b1) + (a1b3 + a3b1 + a2b2) + O(2^-27 |ab|),
 // gives products accurate to fp32 rounding at 6/16 of the f32-MFMA matrix-core time (MH_MFMA_SPLIT == 6); the first
-// three terms alone (== 3) are accurate to 2^-17.  The LDS tiles, staging and epilogue are unchanged: a lane's
-// operand for the K=16 instruction is 8 consecutive k of its row -- exactly the k = 8g + step permutation above.
+// three terms alone (== 3) are accurate to 2^-17.  A lane's operand for the K=16 instruction is 8 consecutive k of
+// its row (k = 8g .. 8g+7, g = lane >> 5).  The split is done ONCE per element when a k-tile is staged (below).
 // ---------------------------------------------------------------------------------------------------------------
 typedef short bf16x8 __attribute__((ext_vector_type(8)));
-
-struct SplitFrag {
-    bf16x8 p[3];   // hi, mid, lo planes of 8 consecutive k
-};
-
-// 8 fp32 -> three bf16x8 planes (exact truncation split)
-__device__ __forceinline__ void split8(const float (&x)[8], SplitFrag &f)
-{
-    unsigned h[8], m[8], l[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const unsigned xb = __builtin_bit_cast(unsigned, x[i]);
-        const unsigned hb = xb & 0xffff0000u;
-        const float r1 = x[i] - __builtin_bit_cast(float, hb);
-        const unsigned r1b = __builtin_bit_cast(unsigned, r1);
-        const unsigned mb = r1b & 0xffff0000u;
-        const float r2 = r1 - __builtin_bit_cast(float, mb);
-        h[i] = hb; m[i] = mb; l[i] = __builtin_bit_cast(unsigned, r2);
-    }
-    unsigned ph[4], pm[4], pl[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {   // element 2i in the low half, 2i+1 in the high half
-        ph[i] = (h[2 * i] >> 16) | (h[2 * i + 1] & 0xffff0000u);
-        pm[i] = (m[2 * i] >> 16) | (m[2 * i + 1] & 0xffff0000u);
-        pl[i] = (l[2 * i] >> 16) | (l[2 * i + 1] & 0xffff0000u);
-    }
-    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-    f.p[0] = __builtin_bit_cast(bf16x8, (u32x4){ph[0], ph[1], ph[2], ph[3]});
-    f.p[1] = __builtin_bit_cast(bf16x8, (u32x4){pm[0], pm[1], pm[2], pm[3]});
-    f.p[2] = __builtin_bit_cast(bf16x8, (u32x4){pl[0], pl[1], pl[2], pl[3]});
-}
-
-// fetch the 8 k-values (k = 8g .. 8g+7) of this lane's row for both sub-tiles and split them
-template <bool WM, int WD>
-__device__ __forceinline__ void fetch_split(SplitFrag (&f)[2], const float *__restrict__ tile, int w0, int lane)
-{
-    const int i = lane & 31, g = lane >> 5;
-    float x[2][8];
-    if (WM) {
-        const float *p = tile + (w0 + i) * kLdW + 8 * g;
-#pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            const float4 lo = *reinterpret_cast<const float4 *>(p + 32 * s * kLdW);
-            const float4 hi = *reinterpret_cast<const float4 *>(p + 32 * s * kLdW + 4);
-            x[s][0] = lo.x; x[s][1] = lo.y; x[s][2] = lo.z; x[s][3] = lo.w;
-            x[s][4] = hi.x; x[s][5] = hi.y; x[s][6] = hi.z; x[s][7] = hi.w;
-        }
-    } else {
-        constexpr int ld = TileGeom<WD, false>::ld;
-        const float *p = tile + (8 * g) * ld + w0 + 2 * i;
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            const float2 v = *reinterpret_cast<const float2 *>(p + q * ld);
-            x[0][q] = v.x;
-            x[1][q] = v.y;
-        }
-    }
-    split8(x[0], f[0]);
-    split8(x[1], f[1]);
-}
-
-template <bool AWM, bool BWM, int BM, int BN>
-__device__ __forceinline__ void mma_ktile_split(const float *__restrict__ As, const float *__restrict__ Bs, int wm,
-                                                int wn, int lane, Acc &acc)
-{
-    SplitFrag a[2], b[2];
-    fetch_split<AWM, BM>(a, As, wm, lane);
-    fetch_split<BWM, BN>(b, Bs, wn, lane);
-#pragma unroll
-    for (int sm = 0; sm < 2; ++sm)
-#pragma unroll
-        for (int sn = 0; sn < 2; ++sn) {
-            f32x16 c = acc.v[sm][sn];
-#if MH_MFMA_SPLIT >= 6
-            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[sm].p[2], b[sn].p[0], c, 0, 0, 0);   // smallest terms first
-            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[sm].p[0], b[sn].p[2], c, 0, 0, 0);
-            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[sm].p[1], b[sn].p[1], c, 0, 0, 0);
-#endif
-            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[sm].p[1], b[sn].p[0], c, 0, 0, 0);
-            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[sm].p[0], b[sn].p[1], c, 0, 0, 0);
-            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[sm].p[0], b[sn].p[0], c, 0, 0, 0);
-            acc.v[sm][sn] = c;
-        }
-}
 
 #if !MH_PLANES
 template <bool AWM, bool BWM, int BM, int BN>
 __device__ __forceinline__ void mma_ktile(const float *__restrict__ As, const float *__restrict__ Bs, int wm, int wn,
                                           int lane, Acc &acc)
 {
-#if MH_MFMA_SPLIT
-    mma_ktile_split<AWM, BWM, BM, BN>(As, Bs, wm, wn, lane, acc);
-#else
     mma_ktile_f32<AWM, BWM, BM, BN>(As, Bs, wm, wn, lane, acc);
-#endif
 }
 #endif  // !MH_PLANES
 
@@ -373,7 +282,7 @@ __device__ __forceinline__ void store_wm(const Stage<WD> &s, float *tile, int ti
 
 #if MH_PLANES
 // ---------------------------------------------------------------------------------------------------------------
-// bf16-plane LDS image (MH_MFMA_SPLIT with MH_SPLIT_AT_STAGE): every element is split ONCE, by the thread that
+// bf16-plane LDS image (MH_MFMA_SPLIT != 0): every element is split ONCE, by the thread that
 // stages it, and LDS holds the three bf16 planes k-contiguous per operand row, whatever the global orientation:
 //     row r (96 B = 24 dwords):  [ hi: k0..k15 | mid: k0..k15 | lo: k0..k15 ]
 // dword d of a plane holds k = 2d (low half) and 2d+1 (high half); the 16-B slot index (2*plane + k/8) is XORed
