@@ -242,6 +242,41 @@ def main():
     out['ahlstm_layout'] = dict(weight=lstm.weight.detach().numpy(), bias=lstm.bias.detach().numpy(),
                                 dims=np.array([12, 8, 3]))
 
+    # ---------------------------------------------------------------- detector-training host samplers + box loss
+    # anchor_target_layer (lib/fpn/anchor_targets.py:16-105) with the global numpy RNG seeded per case;
+    # _sel_inds (proposal_assignments_det.py:94-118) is the sampling core of proposal_assignments_det (the rest of
+    # that function needs a CUDA device in the reference: `.cuda(rpn_rois.get_device())`);
+    # bbox_loss (lib/fpn/box_utils.py:8-25).
+    at = importlib.import_module('lib.fpn.anchor_targets')
+    det = {}
+    for case, (n_gt, seed) in enumerate([(3, 11), (20, 12), (1, 13)]):
+        gtb = rand_boxes(rs, n_gt, integer=True).astype(np.float32)
+        gtb[:, 2:] = np.maximum(gtb[:, 2:], gtb[:, :2] + 8)
+        np.random.seed(seed)
+        anchors, anchor_inds, targets, labels = at.anchor_target_layer(gtb, (592, 592))
+        det['at%d_gt' % case], det['at%d_seed' % case] = gtb, np.array(seed)
+        det['at%d_anchors' % case], det['at%d_inds' % case] = anchors, anchor_inds
+        det['at%d_targets' % case], det['at%d_labels' % case] = targets, labels
+    fake = types.ModuleType('lib.pytorch_misc_stub')
+    pad = importlib.import_module('lib.fpn.proposal_assignments.proposal_assignments_det')
+    for case, (n, seed) in enumerate([(300, 21), (40, 22), (1000, 23)]):
+        mo = rs.uniform(0, 1, n) ** 2
+        mo[rs.uniform(0, 1, n) < 0.1] = 0.0
+        np.random.seed(seed)
+        keep, num_fg = pad._sel_inds(mo.copy(), 0.5, 64, 256)
+        det['sel%d_overlaps' % case], det['sel%d_seed' % case] = mo, np.array(seed)
+        det['sel%d_keep' % case], det['sel%d_numfg' % case] = keep, np.array(num_fg)
+    bu = importlib.import_module('lib.fpn.box_utils')
+    prior = torch.from_numpy(rand_boxes(rs, 33).astype(np.float32))
+    gtbx = torch.from_numpy(rand_boxes(rs, 33).astype(np.float32))
+    deltas = torch.randn(33, 4) * 0.5
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        det['bl_loss'] = np.array(float(bu.bbox_loss(prior, deltas, gtbx)))
+    det['bl_prior'], det['bl_deltas'], det['bl_gt'] = prior.numpy(), deltas.numpy(), gtbx.numpy()
+    out['det_train'] = det
+
     for name, d in out.items():
         path = os.path.join(HERE, name + '.npz')
         np.savez_compressed(path, **{k: np.asarray(v) for k, v in d.items()})
