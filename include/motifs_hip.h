@@ -130,6 +130,12 @@ int mh_conv3x3_nhwc(const float *in, int B, int H, int W, int Cin, const float *
 int mh_conv_first_nchw(const float *in_nchw, int B, int Cin, int H, int W, const float *w /*[Cout,Cin,3,3]*/,
                        int Cout, const float *bias, int epilogue, float *out_nhwc, void *stream);
 int mh_maxpool2x2_nhwc(const float *in, int B, int H, int W, int C, float *out, void *stream);
+/* detector pre-training (models/train_detector.py; the trunk is trainable there):
+ *   mh_maxpool2x2_bwd_nhwc: gradient to the first maximal element of each window (torch semantics), gin fully written
+ *   mh_act_bwd: gradient through a fused ReLU / ReLU6 epilogue given the activated output y */
+int mh_maxpool2x2_bwd_nhwc(const float *in, const float *gout, int B, int H, int W, int C, float *gin,
+                           void *stream);
+int mh_act_bwd(const float *g, const float *y, long long n, int epilogue, float *out, void *stream);
 int mh_im2col_nhwc(const float *in, int B, int H, int W, int C, int kh, int kw, int stride, int pad,
                    float *out, int ldo, void *stream);
 int mh_nchw_to_nhwc(const float *in, int B, int C, int H, int W, float *out, void *stream);

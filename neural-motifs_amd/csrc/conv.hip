@@ -289,6 +289,55 @@ __global__ void maxpool2x2_nhwc_kernel(const float4 *__restrict__ in, int B, int
     }
 }
 
+// backward of the 2x2/2 max pool: the gradient of a pooled element goes to the FIRST maximal element of its window
+// in scan order (0,0),(0,1),(1,0),(1,1) (what torch's max_pool2d does); one thread per INPUT float4, so every input
+// element -- including an odd trailing row / column outside all windows -- is written exactly once (no memset).
+__global__ void maxpool2x2_bwd_nhwc_kernel(const float4 *__restrict__ in, const float4 *__restrict__ gout, int B, int H,
+                                           int W, int C4, float4 *__restrict__ gin)
+{
+    const int Ho = H / 2, Wo = W / 2;
+    const long long total = (long long)B * H * W * C4;
+    for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total;
+         idx += (long long)blockDim.x * gridDim.x) {
+        const int c = idx % C4;
+        long long t = idx / C4;
+        const int x = t % W; t /= W;
+        const int y = t % H;
+        const int b = t / H;
+        const int yo = y >> 1, xo = x >> 1;
+        float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (yo < Ho && xo < Wo) {
+            const float4 *p = in + (((size_t)b * H + 2 * yo) * W + 2 * xo) * C4 + c;
+            const float4 v[4] = {p[0], p[C4], p[(size_t)W * C4], p[(size_t)W * C4 + C4]};
+            const float4 g = gout[(((size_t)b * Ho + yo) * Wo + xo) * C4 + c];
+            const int me = (y & 1) * 2 + (x & 1);
+            auto first_max = [&](float a0, float a1, float a2, float a3) {
+                const float m = fmaxf(fmaxf(a0, a1), fmaxf(a2, a3));
+                return a0 == m ? 0 : a1 == m ? 1 : a2 == m ? 2 : 3;
+            };
+            if (first_max(v[0].x, v[1].x, v[2].x, v[3].x) == me) r.x = g.x;
+            if (first_max(v[0].y, v[1].y, v[2].y, v[3].y) == me) r.y = g.y;
+            if (first_max(v[0].z, v[1].z, v[2].z, v[3].z) == me) r.z = g.z;
+            if (first_max(v[0].w, v[1].w, v[2].w, v[3].w) == me) r.w = g.w;
+        }
+        gin[idx] = r;
+    }
+}
+
+// gradient through the fused conv epilogue: out = g where the activation was in its linear range (y = the ACTIVATED
+// output: y > 0 for ReLU, 0 < y < 6 for ReLU6), 0 elsewhere
+__global__ void act_bwd_kernel(const float4 *__restrict__ g, const float4 *__restrict__ y, long long n4, int epilogue,
+                               float4 *__restrict__ out)
+{
+    const float hi = (epilogue == MH_EPI_RELU6) ? 6.f : INFINITY;
+    for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < n4;
+         idx += (long long)blockDim.x * gridDim.x) {
+        const float4 gv = g[idx], yv = y[idx];
+        out[idx] = make_float4((yv.x > 0.f && yv.x < hi) ? gv.x : 0.f, (yv.y > 0.f && yv.y < hi) ? gv.y : 0.f,
+                               (yv.z > 0.f && yv.z < hi) ? gv.z : 0.f, (yv.w > 0.f && yv.w < hi) ? gv.w : 0.f);
+    }
+}
+
 // generic NHWC patch matrix: out[(b,yo,xo)][(ky*kw+kx)*C + c]; columns >= kh*kw*C (padding up to ldo) are zeroed
 __global__ void im2col_nhwc_kernel(const float *__restrict__ in, int B, int H, int W, int C, int kh, int kw,
                                    int stride, int pad, int Ho, int Wo, float *__restrict__ out, int ldo)
@@ -434,6 +483,29 @@ int mh_maxpool2x2_nhwc(const float *in, int B, int H, int W, int C, float *out, 
     hipLaunchKernelGGL(maxpool2x2_nhwc_kernel, dim3(blocks), dim3(256), 0, as_stream(stream),
                        reinterpret_cast<const float4 *>(in), B, H, W, C / 4, reinterpret_cast<float4 *>(out));
     return check_launch("maxpool2x2_nhwc_kernel");
+}
+
+int mh_maxpool2x2_bwd_nhwc(const float *in, const float *gout, int B, int H, int W, int C, float *gin, void *stream)
+{
+    MH_REQUIRE(in && gout && gin && B > 0 && H >= 2 && W >= 2 && C > 0 && C % 4 == 0);
+    MH_REQUIRE(((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(gout) | reinterpret_cast<uintptr_t>(gin)) & 15) == 0);
+    const long long total = (long long)B * H * W * (C / 4);
+    const int blocks = (int)std::min<long long>((total + 255) / 256, 256 * 16);
+    hipLaunchKernelGGL(maxpool2x2_bwd_nhwc_kernel, dim3(blocks), dim3(256), 0, as_stream(stream),
+                       reinterpret_cast<const float4 *>(in), reinterpret_cast<const float4 *>(gout), B, H, W, C / 4,
+                       reinterpret_cast<float4 *>(gin));
+    return check_launch("maxpool2x2_bwd_nhwc_kernel");
+}
+
+int mh_act_bwd(const float *g, const float *y, long long n, int epilogue, float *out, void *stream)
+{
+    MH_REQUIRE(g && y && out && n > 0 && n % 4 == 0);
+    MH_REQUIRE(epilogue == MH_EPI_RELU || epilogue == MH_EPI_RELU6);
+    MH_REQUIRE(((reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(out)) & 15) == 0);
+    const int blocks = (int)std::min<long long>((n / 4 + 255) / 256, 256 * 16);
+    hipLaunchKernelGGL(act_bwd_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), reinterpret_cast<const float4 *>(g),
+                       reinterpret_cast<const float4 *>(y), n / 4, epilogue, reinterpret_cast<float4 *>(out));
+    return check_launch("act_bwd_kernel");
 }
 
 int mh_im2col_nhwc(const float *in, int B, int H, int W, int C, int kh, int kw, int stride, int pad, float *out,

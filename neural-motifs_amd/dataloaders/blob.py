@@ -4,8 +4,10 @@ Per-step batch container with the reference's interface (dataloaders/blob.py): `
 
 Data parallelism is one process per GPU, so a Blob always describes ONE device's images (`num_gpus == 1`,
 `image_offset == 0`); the ragged torch.nn.parallel scatter of the reference (:148-153) has no counterpart.
-Anchor targets (only consumed by detector pre-training) are not produced: `train_anchor_inds`
-is an empty [0,4] index tensor with the right rank.
+Anchor targets (consumed only by detector pre-training, models/train_detector.py) are produced for mode 'det' exactly
+as the reference does while collating (blob.py:91-102): `train_anchors` [k,8] (anchor, matched GT box),
+`train_anchor_labels` [k,5] (img, h, w, A, label), `train_anchor_inds` = its first four columns.  In 'rel' mode, where
+nothing reads them, `train_anchor_inds` is an empty [0,4] tensor.  `anchor_rs` injects the sampler's RNG.
 """
 import numpy as np
 import torch
@@ -24,7 +26,9 @@ class Blob(object):
         self.imgs, self.im_sizes = [], []
         self.gt_boxes, self.gt_classes, self.gt_rels = [], [], []
         self.proposals = []
+        self.train_anchor_labels, self.train_anchors = [], []
         self.train_anchor_inds = None
+        self.anchor_rs = None
         self.proposal_chunks = None
 
     @property
@@ -42,6 +46,11 @@ class Blob(object):
         if self.is_rel:
             self.gt_rels.append(np.column_stack((i * np.ones(d['gt_relations'].shape[0], dtype=np.int64),
                                                  d['gt_relations'])))
+        if self.is_train and not self.is_rel:
+            from lib.fpn.anchor_targets import anchor_target_layer
+            anchors_, inds_, targets_, labels_ = anchor_target_layer(self.gt_boxes[-1], (h, w), rs=self.anchor_rs)
+            self.train_anchors.append(np.hstack((anchors_, targets_)))
+            self.train_anchor_labels.append(np.column_stack((i * np.ones(inds_.shape[0], dtype=np.int64), inds_, labels_)))
         if 'proposals' in d:
             self.proposals.append(np.column_stack((i * np.ones(d['proposals'].shape[0], dtype=np.float32),
                                                    d['scale'] * d['proposals'].astype(np.float32))))
@@ -55,7 +64,11 @@ class Blob(object):
             self.gt_rels = torch.from_numpy(np.concatenate(self.gt_rels, 0)).long()
         self.gt_boxes = torch.from_numpy(np.concatenate(self.gt_boxes, 0)).float()
         self.gt_classes = torch.from_numpy(np.concatenate(self.gt_classes, 0)).long()
-        if self.is_train:
+        if self.is_train and not self.is_rel:
+            self.train_anchor_labels = torch.from_numpy(np.concatenate(self.train_anchor_labels, 0)).long()
+            self.train_anchors = torch.from_numpy(np.concatenate(self.train_anchors, 0)).float()
+            self.train_anchor_inds = self.train_anchor_labels[:, :-1].contiguous()
+        elif self.is_train:
             self.train_anchor_inds = torch.zeros(0, 4, dtype=torch.long)
         if len(self.proposals) != 0:
             self.proposals = torch.from_numpy(np.concatenate(self.proposals, 0)).float()
@@ -75,6 +88,9 @@ class Blob(object):
             self.gt_rels = self._to_device(self.gt_rels)
         if self.is_train:
             self.train_anchor_inds = self._to_device(self.train_anchor_inds)
+            if not self.is_rel:
+                self.train_anchor_labels = self._to_device(self.train_anchor_labels)
+                self.train_anchors = self._to_device(self.train_anchors)
         if self.proposal_chunks is not None:
             self.proposals = self._to_device(self.proposals)
 

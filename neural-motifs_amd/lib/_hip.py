@@ -21,6 +21,7 @@ SYMBOLS = (
     'mh_roi_align_fwd', 'mh_roi_align_bwd', 'mh_draw_union_boxes', 'mh_bbox_overlaps',
     'mh_gemm_ws_bytes', 'mh_gemm_auto_splitk', 'mh_gemm_f32',
     'mh_conv3x3_packed_floats', 'mh_conv3x3_pack_weight', 'mh_conv3x3_ws_bytes', 'mh_conv3x3_nhwc', 'mh_conv_first_nchw', 'mh_maxpool2x2_nhwc',
+    'mh_maxpool2x2_bwd_nhwc', 'mh_act_bwd',
     'mh_im2col_nhwc', 'mh_nchw_to_nhwc', 'mh_nhwc_to_nchw',
     'mh_hwlstm_fwd_ws_bytes', 'mh_hwlstm_fwd', 'mh_hwlstm_bwd_ws_bytes', 'mh_hwlstm_bwd',
     'mh_hwlstm_cell_fwd', 'mh_hwlstm_cell_bwd', 'mh_gemv_rows',
@@ -260,6 +261,20 @@ def maxpool2x2_nhwc(x):
     out = torch.empty(B, H // 2, W // 2, C, dtype=torch.float32, device=x.device)
     rc = lib().mh_maxpool2x2_nhwc(f32(x), B, H, W, C, f32(out), stream())
     _check(rc, 'mh_maxpool2x2_nhwc')
+    return out
+
+
+def maxpool2x2_bwd_nhwc(x, gy):
+    B, H, W, C = x.shape
+    gx = torch.empty_like(x)
+    _check(lib().mh_maxpool2x2_bwd_nhwc(f32(x), f32(gy), B, H, W, C, f32(gx), stream()), 'mh_maxpool2x2_bwd_nhwc')
+    return gx
+
+
+def act_bwd(g, y, epilogue):
+    """gradient through a fused ReLU (1) / ReLU6 (2) epilogue; y = the activated output"""
+    out = torch.empty_like(g)
+    _check(lib().mh_act_bwd(f32(g), f32(y), c_ll(g.numel()), c_int(epilogue), f32(out), stream()), 'mh_act_bwd')
     return out
 
 

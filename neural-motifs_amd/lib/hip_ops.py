@@ -177,8 +177,8 @@ class VGG16Features(nn.Sequential):
 
     forward: NCHW image in; every layer runs in NHWC on the MFMA implicit-GEMM kernel with fused bias+ReLU; the
     returned feature map is a logical [B,512,H/16,W/16] tensor with channels_last strides (physically NHWC), which
-    RoIAlign consumes coalesced over channels.  The trunk is forward-only here: train_rels freezes the detector
-    (models/train_rels.py:50-52) -- conv backward belongs to the detector-pretraining path."""
+    RoIAlign consumes coalesced over channels.  With frozen parameters (models/train_rels.py:50-52) the forward-only
+    fast path runs; with trainable parameters (models/train_detector.py) the same layers run as autograd Functions."""
 
     CFG = (64, 64, 'M', 128, 128, 'M', 256, 256, 256, 'M', 512, 512, 512, 'M', 512, 512, 512)
 
@@ -194,8 +194,7 @@ class VGG16Features(nn.Sequential):
 
     def forward(self, x):
         if any(p.requires_grad for p in self.parameters()) and torch.is_grad_enabled():
-            raise NotImplementedError('VGG trunk backward is not built yet (detector pre-training path, '
-                                      'SURVEY.md §8f); freeze the detector as models/train_rels.py does')
+            return self._forward_trainable(x)          # detector pre-training (models/train_detector.py)
         with torch.no_grad():
             mods = list(self.children())
             first = mods[0]
@@ -211,6 +210,24 @@ class VGG16Features(nn.Sequential):
                     i += 1
                 else:
                     raise RuntimeError('unexpected module in VGG16Features')
+        return y.permute(0, 3, 1, 2)
+
+    def _forward_trainable(self, x):
+        """same layers through autograd Functions (conv backward = dgrad on the conv kernel + im2col/GEMM wgrad,
+        pool backward, activation masks): the trunk as the detector pre-training step needs it"""
+        mods = list(self.children())
+        y = _ConvFirstFn.apply(x, mods[0].weight, mods[0].bias)
+        i = 2
+        while i < len(mods):
+            m = mods[i]
+            if isinstance(m, Conv3x3):
+                y = _Conv3x3Fn.apply(y, m.weight, m.bias, EPI_RELU)
+                i += 2
+            elif isinstance(m, MaxPool2x2):
+                y = _MaxPool2x2Fn.apply(y)
+                i += 1
+            else:
+                raise RuntimeError('unexpected module in VGG16Features')
         return y.permute(0, 3, 1, 2)
 
 
@@ -247,25 +264,29 @@ class _ConvIm2colFn(torch.autograd.Function):
 
 
 class _Conv3x3Fn(torch.autograd.Function):
-    """Trainable NHWC 3x3 conv: forward = implicit GEMM; dgrad = the same kernel on flip-transposed weights;
+    """Trainable NHWC 3x3 conv with the fused bias + activation epilogue: forward = implicit GEMM; backward =
+    activation mask (mh_act_bwd on the saved output), dgrad = the same conv kernel on flip-transposed weights,
     wgrad = im2col(x)^T x dY on the GEMM."""
 
     @staticmethod
-    def forward(ctx, x_nhwc, weight, bias):
+    def forward(ctx, x_nhwc, weight, bias, epilogue=EPI_NONE):
         x_nhwc = _c(x_nhwc)
         wt = _hip.conv3x3_pack_weight(_c(weight), False)
-        y = _hip.conv3x3_nhwc(x_nhwc, wt, bias, EPI_NONE)
-        ctx.save_for_backward(x_nhwc, weight)
+        y = _hip.conv3x3_nhwc(x_nhwc, wt, bias, epilogue)
+        ctx.epilogue = epilogue
+        ctx.save_for_backward(x_nhwc, weight, y if epilogue != EPI_NONE else None)
         return y
 
     @staticmethod
     def backward(ctx, gy):
-        x_nhwc, weight = ctx.saved_tensors
+        x_nhwc, weight, y = ctx.saved_tensors
         gy = _c(gy)
+        if ctx.epilogue != EPI_NONE:
+            gy = _hip.act_bwd(gy, y, ctx.epilogue)
         Cout, Cin = weight.shape[0], weight.shape[1]
         gx = gw = gb = None
         if ctx.needs_input_grad[0]:
-            wt_t = _hip.conv3x3_pack_weight(_c(weight), True)          # [9][Cin][Cout]: the dgrad conv's weights
+            wt_t = _hip.conv3x3_pack_weight(_c(weight), True)          # the dgrad conv's weights (roles swapped)
             gx = _hip.conv3x3_nhwc(gy, wt_t, None, EPI_NONE)
         if ctx.needs_input_grad[1]:
             cols, _, _ = _hip.im2col_nhwc(x_nhwc, 3, 3, 1, 1)          # [M, 9*Cin]
@@ -273,7 +294,48 @@ class _Conv3x3Fn(torch.autograd.Function):
             gw = gwm.view(Cout, 3, 3, Cin).permute(0, 3, 1, 2).contiguous()
         if ctx.needs_input_grad[2]:
             gb = gy.view(-1, Cout).sum(0)
-        return gx, gw, gb
+        return gx, gw, gb, None
+
+
+class _ConvFirstFn(torch.autograd.Function):
+    """conv1_1 (3 -> Cout, NCHW image in, NHWC out, fused bias + ReLU) with a weight gradient: the image needs no
+    gradient, dW = im2col(image)^T x dY (K = 27, padded to 28)."""
+
+    @staticmethod
+    def forward(ctx, img_nchw, weight, bias):
+        img_nchw = _c(img_nchw)
+        y = _hip.conv_first_nchw(img_nchw, _c(weight), bias, EPI_RELU)
+        ctx.save_for_backward(img_nchw, y)
+        ctx.wshape = weight.shape
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        img, y = ctx.saved_tensors
+        Cout, Cin = ctx.wshape[0], ctx.wshape[1]
+        g = _hip.act_bwd(_c(gy), y, EPI_RELU)
+        gw = gb = None
+        if ctx.needs_input_grad[1]:
+            K = 9 * Cin
+            cols, _, _ = _hip.im2col_nhwc(_hip.nchw_to_nhwc(img), 3, 3, 1, 1, ldo=(K + 3) // 4 * 4)
+            gwm = _hip.gemm(g.view(-1, Cout), cols, True, False)[:, :K]
+            gw = gwm.reshape(Cout, 3, 3, Cin).permute(0, 3, 1, 2).contiguous()
+        if ctx.needs_input_grad[2]:
+            gb = g.view(-1, Cout).sum(0)
+        return None, gw, gb
+
+
+class _MaxPool2x2Fn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x_nhwc):
+        x_nhwc = _c(x_nhwc)
+        ctx.save_for_backward(x_nhwc)
+        return _hip.maxpool2x2_nhwc(x_nhwc)
+
+    @staticmethod
+    def backward(ctx, gy):
+        (x,) = ctx.saved_tensors
+        return _hip.maxpool2x2_bwd_nhwc(x, _c(gy))
 
 
 class Conv2dNHWC(nn.Module):
@@ -290,7 +352,7 @@ class Conv2dNHWC(nn.Module):
 
     def forward(self, x_nhwc):
         if self.k == 3 and self.stride == 1 and self.padding == 1 and self.cin % 16 == 0 and self.cout % 4 == 0:
-            return _Conv3x3Fn.apply(x_nhwc, self.weight, self.bias)
+            return _Conv3x3Fn.apply(x_nhwc, self.weight, self.bias, EPI_NONE)
         return _ConvIm2colFn.apply(x_nhwc, self.weight, self.bias, self.k, self.k, self.stride, self.padding)
 
 

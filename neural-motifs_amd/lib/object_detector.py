@@ -18,8 +18,10 @@ from lib.fpn.box_utils import bbox_preds, center_size, bbox_overlaps
 from lib.fpn.generate_anchors import generate_anchors
 from lib.fpn.nms.functions.nms import apply_nms, nms_mask_per_class
 from lib.fpn.proposal_assignments.proposal_assignments_gtbox import proposal_assignments_gtbox
+from lib.fpn.proposal_assignments.proposal_assignments_det import proposal_assignments_det
 from lib.fpn.roi_align.functions.roi_align import RoIAlignFunction
-from lib.hip_ops import (Conv3x3, Dropout, FCStack, Linear, ReLU, VGG16Features, EPI_NONE, EPI_RELU6, _is_nhwc)
+from lib.hip_ops import (Conv3x3, Dropout, FCStack, Linear, ReLU, VGG16Features, EPI_NONE, EPI_RELU6, _is_nhwc,
+                         _Conv3x3Fn, linear)
 from lib.pytorch_misc import enumerate_by_image, gather_nd
 
 
@@ -167,9 +169,10 @@ class ObjectDetector(nn.Module):
             if gt_rels is not None and self.mode == 'rpntrain':
                 raise ValueError("Training the object detector and the relationship model with detection"
                                  "at the same time isn't supported")
-            if self.mode != 'refinerels':
-                raise NotImplementedError('detector pre-training (proposal_assignments_det) is outside the '
-                                          'relation-model hot path (SURVEY.md §8f)')
+            if self.mode != 'refinerels':          # detector pre-training: sample <= 256 RoIs/img, <= 25 % foreground
+                rois, labels, bbox_targets = proposal_assignments_det(
+                    rois, gt_boxes.detach(), gt_classes.detach(), image_offset, fg_thresh=0.5,
+                    rs=getattr(self, 'sampler_rs', None))
         return rois, labels, bbox_targets, rpn_scores, rpn_box_deltas, rel_labels
 
     def gt_boxes(self, fmap, im_sizes, image_offset, gt_boxes=None, gt_classes=None, gt_rels=None,
@@ -321,8 +324,11 @@ class _Conv1x1(nn.Module):
 
     def forward_nhwc(self, x_nhwc):
         B, H, W, C = x_nhwc.shape
-        y = _hip.gemm(x_nhwc.reshape(-1, C), self.weight.detach().view(self.weight.size(0), C), False, True,
-                      bias=self.bias.detach())
+        if torch.is_grad_enabled() and (self.weight.requires_grad or x_nhwc.requires_grad):
+            y = linear(x_nhwc.reshape(-1, C), self.weight.view(self.weight.size(0), C), self.bias)
+        else:
+            y = _hip.gemm(x_nhwc.reshape(-1, C), self.weight.detach().view(self.weight.size(0), C), False, True,
+                          bias=self.bias.detach())
         return y.view(B, H, W, -1)
 
 
@@ -346,11 +352,18 @@ class RPNHead(nn.Module):
         return len(ANCHOR_RATIOS) * len(ANCHOR_SCALES)
 
     def forward(self, fmap):
-        """[B,C,h,w] feature map -> [B,h,w,A,6].  (forward-only: the RPN is frozen on the relation-model path)"""
-        with torch.no_grad():
-            x = fmap.permute(0, 2, 3, 1) if _is_nhwc(fmap) else _hip.nchw_to_nhwc(fmap.contiguous())
-            x = self.conv[0].forward_nhwc(x.contiguous(), EPI_RELU6)
-            x = self.conv[2].forward_nhwc(x)                      # NHWC == the reference's _reshape_channels
+        """[B,C,h,w] feature map -> [B,h,w,A,6] (NHWC output == the reference's _reshape_channels).  Frozen on the
+        relation-model path (forward-only kernels); trainable in detector pre-training (autograd Functions)."""
+        trainable = torch.is_grad_enabled() and (fmap.requires_grad or any(p.requires_grad for p in self.parameters()))
+        if trainable:
+            x = fmap.permute(0, 2, 3, 1).contiguous()
+            x = _Conv3x3Fn.apply(x, self.conv[0].weight, self.conv[0].bias, EPI_RELU6)
+            x = self.conv[2].forward_nhwc(x)
+        else:
+            with torch.no_grad():
+                x = fmap.permute(0, 2, 3, 1) if _is_nhwc(fmap) else _hip.nchw_to_nhwc(fmap.contiguous())
+                x = self.conv[0].forward_nhwc(x.contiguous(), EPI_RELU6)
+                x = self.conv[2].forward_nhwc(x)
         return x.view(x.size(0), x.size(1), x.size(2), self._A, self.anchor_target_dim)
 
     def anchor_preds(self, preds, train_anchor_inds, image_offset):

@@ -193,6 +193,44 @@ def detector_forward(sd, cfg, x, im_sizes, image_offset, gt_boxes, gt_classes, t
     return res
 
 
+# --------------------------------------------------------------------------- detector pre-training step (§8f rank 1)
+def _bbox_loss(prior_boxes, deltas, gt_boxes, eps=1e-4):
+    """lib/fpn/box_utils.py:8-25"""
+    pc, gc = B.center_size(prior_boxes), B.center_size(gt_boxes)
+    targets = torch.cat(((gc[:, :2] - pc[:, :2]) / pc[:, 2:], torch.log(gc[:, 2:]) - torch.log(pc[:, 2:])), 1)
+    return F.smooth_l1_loss(deltas, targets, reduction='sum') / (eps + pc.size(0))
+
+
+def detector_train_losses(sd, x, rois, labels, bbox_targets, train_anchor_labels, train_anchors, rng,
+                          fg_fraction=0.25, rpn_fg_fraction=0.5):
+    """ObjectDetector.forward in mode 'rpntrain', training (lib/object_detector.py:224-361) followed by the four
+    losses of models/train_detector.py:100-140.  `rois`, `labels`, `bbox_targets` are the outputs of the host sampler
+    (proposal_assignments_det, pinned separately by goldens); everything differentiable is restated here."""
+    fmap = vgg_features(sd, x)
+    feats = rpn_head(sd, fmap)
+    tai = train_anchor_labels[:, :-1]
+    regions = feats[tai[:, 0], tai[:, 1], tai[:, 2], tai[:, 3]]
+    rpn_scores, rpn_box_deltas = regions[:, :2], regions[:, 2:]
+    obj_fmap = vgg_classifier(sd, roi_align(fmap, rois).view(rois.size(0), -1), 'detector.roi_fmap.', True, rng)
+    scores = F.linear(obj_fmap, sd['detector.score_fc.weight'], sd['detector.score_fc.bias'])
+    box_deltas = F.linear(obj_fmap, sd['detector.bbox_fc.weight'], sd['detector.bbox_fc.bias']).view(
+        -1, scores.size(1), 4)
+    valid = (labels != 0).nonzero().squeeze(1)
+    fg, bg = valid.size(0), labels.size(0) - valid.size(0)
+    out = {'class_loss': F.cross_entropy(scores, labels)}
+    twod = valid * box_deltas.size(1) + labels[valid]
+    out['box_loss'] = _bbox_loss(rois[:, 1:][valid], box_deltas.reshape(-1, 4)[twod], bbox_targets[valid]) * (
+        2 * (1. / fg_fraction) * fg / (fg + bg + 1e-4))
+    al = train_anchor_labels[:, -1]
+    pos = (al == 1).nonzero().squeeze(1)
+    out['rpn_class_loss'] = F.cross_entropy(rpn_scores, al)
+    out['rpn_box_loss'] = _bbox_loss(train_anchors[:, :4][pos], rpn_box_deltas[pos], train_anchors[:, 4:][pos]) * (
+        2 * (1. / rpn_fg_fraction) * pos.size(0) / (al.size(0) + 1e-4))
+    out['total'] = out['class_loss'] + out['box_loss'] + out['rpn_class_loss'] + out['rpn_box_loss']
+    out.update(scores=scores, box_deltas=box_deltas, rpn_scores=rpn_scores, rpn_box_deltas=rpn_box_deltas, fmap=fmap)
+    return out
+
+
 # --------------------------------------------------------------------------- context ordering
 def transpose_packed_sequence_inds(lengths):
     """lib/pytorch_misc.py:365-384"""

@@ -89,6 +89,16 @@ def install():
     def maxpool2x2_nhwc(x):
         return F.max_pool2d(x.permute(0, 3, 1, 2), 2, 2).permute(0, 2, 3, 1).contiguous()
 
+    def maxpool2x2_bwd_nhwc(x, gy):
+        with torch.enable_grad():                        # called from inside a backward pass
+            xx = x.permute(0, 3, 1, 2).detach().clone().requires_grad_()
+            F.max_pool2d(xx, 2, 2).backward(gy.permute(0, 3, 1, 2))
+        return xx.grad.permute(0, 2, 3, 1).contiguous()
+
+    def act_bwd(g, y, epilogue):
+        m = (y > 0) if epilogue == 1 else ((y > 0) & (y < 6))
+        return g * m.to(g.dtype)
+
     def im2col_nhwc(x, kh, kw, stride, pad, ldo=None):
         B, H, W, C = x.shape
         Ho = (H + 2 * pad - kh) // stride + 1

@@ -128,3 +128,53 @@ def test_sgdet_train_step_runs(det):
     finally:
         model.eval()
         model.zero_grad(set_to_none=True)
+
+
+def test_detector_pretraining_step_parity():
+    """models/train_detector.py's step: ObjectDetector(mode='rpntrain') with a TRAINABLE trunk -- forward, the four
+    losses and the gradient of every parameter (13 trunk convs, RPN head, fc6/fc7, score/bbox heads) vs the oracle.
+    The host samplers (anchor targets, RoI assignment) are pinned by goldens in tests/test_det_samplers.py; their
+    outputs are handed to the oracle, as the relation sampler's are in the SGCls step test."""
+    if not torch.cuda.is_available():
+        pytest.fail('needs a HIP device')
+    from dataloaders.synthetic import SyntheticVG, make_blob
+    from lib import rng
+    from lib.detector_loss import detector_losses
+    from lib.object_detector import ObjectDetector
+    from oracle import model as OM
+    torch.manual_seed(1)
+    ds = SyntheticVG(num_images=2, seed=21, n_boxes=6, n_rels=4)
+    det = ObjectDetector(classes=ds.ind_to_classes, mode='rpntrain')
+    sd_cpu = {'detector.' + k: v.detach().clone() for k, v in det.state_dict().items()}
+    det.cuda().train()
+    np.random.seed(77)
+    blob = make_blob(ds, [0, 1], is_train=True, mode='det')
+    args = blob[0]                                            # CPU copies before scatter
+    cpu_imgs, tal, tan = args[0].clone(), blob.train_anchor_labels.clone(), blob.train_anchors.clone()
+    det.sampler_rs = np.random.RandomState(9)
+    rng.use_host_rng(31)
+    res = det[blob]
+    rng.use_host_rng(None)
+    losses = detector_losses(res, blob.train_anchor_labels, blob.train_anchors)
+    losses['total'].backward()
+    assert res.od_obj_labels.shape[0] <= 2 * 256 and int((res.od_obj_labels > 0).sum()) >= 1
+
+    params = {k: v.clone().requires_grad_(v.dtype.is_floating_point and 'anchors' not in k) for k, v in sd_cpu.items()}
+    rois = torch.cat((res.im_inds.float()[:, None].cpu(), res.od_box_priors.detach().cpu()), 1)
+    out = OM.detector_train_losses(params, cpu_imgs, rois, res.od_obj_labels.cpu(), res.od_box_targets.cpu(), tal, tan,
+                                   OM.HostRNG(31))
+    from test_gpu_model import rel_close, grad_close
+    rel_close(res.od_obj_dists.detach().cpu().numpy(), out['scores'].detach().numpy(), what='RoI class logits')
+    rel_close(res.od_box_deltas.detach().cpu().numpy(), out['box_deltas'].detach().numpy(), what='RoI box deltas')
+    rel_close(res.rpn_scores.detach().cpu().numpy(), out['rpn_scores'].detach().numpy(), what='RPN scores')
+    rel_close(res.rpn_box_deltas.detach().cpu().numpy(), out['rpn_box_deltas'].detach().numpy(), what='RPN deltas')
+    for k in ('class_loss', 'box_loss', 'rpn_class_loss', 'rpn_box_loss', 'total'):
+        rel_close(float(losses[k]), float(out[k]), what=k)
+    out['total'].backward()
+    checked = 0
+    for name, p in det.named_parameters():
+        ref = params['detector.' + name].grad
+        assert p.grad is not None and ref is not None, name
+        grad_close(p.grad.cpu().numpy(), ref.numpy(), what='grad ' + name[-26:], max_flipped_rows=3)
+        checked += 1
+    assert checked == 26 + 4 + 4 + 4            # 13 trunk convs, fc6/fc7, score/bbox heads, RPN head (weights + biases)

@@ -120,3 +120,35 @@ def test_eval_tuple_and_recall_pipeline(small_world):
         r = ev[mode].result_dict[mode + '_recall']
         assert 0.0 <= r[20][0] <= r[50][0] <= r[100][0] <= 1.0
     model.mode = model.context.mode = 'sgcls'
+
+
+def test_trainable_trunk_autograd_plumbing(shim):
+    """detector pre-training path: VGG16Features with trainable parameters runs through the autograd Functions
+    (conv_first / conv3x3+ReLU / 2x2 pool and their backward wiring: im2col column order, weight-gradient reshapes,
+    activation masks) and must agree with plain torch autograd on the same layers."""
+    import torch.nn.functional as F
+    from lib.hip_ops import VGG16Features
+    torch.manual_seed(0)
+    net = VGG16Features()
+    x = torch.randn(1, 3, 32, 48)
+    y = net(x)
+    assert y.requires_grad
+    (y ** 2).sum().backward()
+    convs = [m for m in net if hasattr(m, 'weight')]
+    ws = [(m.weight.detach().clone().requires_grad_(), m.bias.detach().clone().requires_grad_()) for m in convs]
+    h, i = x, 0
+    for v in VGG16Features.CFG:
+        if v == 'M':
+            h = F.max_pool2d(h, 2, 2)
+        else:
+            h = F.relu(F.conv2d(h, ws[i][0], ws[i][1], padding=1))
+            i += 1
+    (h ** 2).sum().backward()
+    np.testing.assert_allclose(y.detach().numpy(), h.detach().numpy(), atol=1e-5)
+    for m, (w, b) in zip(convs, ws):
+        np.testing.assert_allclose(m.weight.grad.numpy(), w.grad.numpy(), atol=1e-4 * float(w.grad.abs().max()) + 1e-8)
+        np.testing.assert_allclose(m.bias.grad.numpy(), b.grad.numpy(), atol=1e-4 * float(b.grad.abs().max()) + 1e-8)
+    # frozen parameters -> the forward-only fast path, no graph
+    for p in net.parameters():
+        p.requires_grad = False
+    assert not net(x).requires_grad
