@@ -24,6 +24,7 @@ extern "C" {
 
 #define MH_OK 0
 #define MH_EINVAL (-1)
+#define MH_EUNSUPPORTED (-2)   /* entry point not available in this build (caller uses the documented alternative) */
 
 /* epilogue flags for GEMM / conv */
 #define MH_EPI_NONE 0
@@ -127,6 +128,12 @@ size_t mh_conv3x3_ws_bytes(int B, int H, int W, int Cin, int Cout);   /* split-K
 int mh_conv3x3_nhwc(const float *in, int B, int H, int W, int Cin, const float *wt, int Cout,
                     const float *bias, int epilogue, float *out, void *workspace, size_t ws_bytes,
                     void *stream);
+/* weight gradient of the 3x3/1/1 conv as an implicit GEMM over the pixels (no patch matrix): dw [Cout][9*Cin]
+ * (tap-major, then input channel) from x [B,H,W,Cin] and gy [B,H,W,Cout]; Cin, Cout % 4 == 0.  MH_EUNSUPPORTED in the
+ * f32-MFMA build (use mh_im2col_nhwc + mh_gemm_f32 there). */
+size_t mh_conv3x3_wgrad_ws_bytes(int B, int H, int W, int Cin, int Cout);
+int mh_conv3x3_wgrad(const float *x, const float *gy, int B, int H, int W, int Cin, int Cout, float *dw,
+                     void *workspace, size_t ws_bytes, void *stream);
 int mh_conv_first_nchw(const float *in_nchw, int B, int Cin, int H, int W, const float *w /*[Cout,Cin,3,3]*/,
                        int Cout, const float *bias, int epilogue, float *out_nhwc, void *stream);
 int mh_maxpool2x2_nhwc(const float *in, int B, int H, int W, int C, float *out, void *stream);

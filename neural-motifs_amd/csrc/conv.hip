@@ -176,6 +176,142 @@ __global__ __launch_bounds__(kThreads, MH_MINW) void conv3x3_nhwc_kernel(const C
     });
 }
 
+#if MH_PLANES
+// ---------------------------------------------------------------------------------------------------------------
+// Weight gradient of the 3x3 / stride 1 / pad 1 conv as an implicit GEMM (no patch matrix):
+//     dW[co][tap][ci] = sum over pixels  gy[pix][co] * x[pix + shift(tap)][ci]        (0 where the tap leaves the image)
+// M' = Cout, N' = 9*Cin, K' = B*H*W pixels.  Both operands are k-major (rows = pixels): A = gy with planned loads;
+// B = x, where a staging thread's four columns lie inside one tap (Cin % 4 == 0), so its row shift is a per-thread
+// constant folded into the planned offset, and which taps are valid for a pixel comes from a 9-bit mask per pixel
+// (tap_mask_kernel), fetched one k-tile ahead so the address select never waits on it.  K' is huge and the output
+// small, so the k range is split over blockIdx.y (partials reduced by splitk_reduce).  Operand offsets are rebased
+// to the first pixel of the block's k range (32-bit offsets inside the 1 GiB descriptor).
+// ---------------------------------------------------------------------------------------------------------------
+struct WgradArgs {
+    const float *gy, *x;
+    const unsigned short *tapmask;   // [P rounded up to 16 + 16]: bit t = tap t of this pixel reads inside the image
+    int W, Cin, Cout;
+    long long P;
+    int tiles_m, tiles_n;
+    int splitk, ktiles_per_split;
+    float *out;       // [Cout][9*Cin] (splitk == 1)
+    float *partial;   // [splitk][Cout][9*Cin]
+};
+
+__global__ void tap_mask_kernel(int B, int H, int W, long long P, long long Ppad, unsigned short *__restrict__ mask)
+{
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < Ppad; i += (long long)blockDim.x * gridDim.x) {
+        unsigned m = 0;
+        if (i < P) {
+            const int rem = (int)(i % ((long long)H * W)), y = rem / W, x = rem % W;
+#pragma unroll
+            for (int t = 0; t < 9; ++t)
+                if ((unsigned)(y + t / 3 - 1) < (unsigned)H && (unsigned)(x + t % 3 - 1) < (unsigned)W) m |= 1u << t;
+        }
+        mask[i] = (unsigned short)m;
+    }
+}
+
+template <int BM, int BN>
+__global__ __launch_bounds__(kThreads, MH_MINW) void conv3x3_wgrad_kernel(const WgradArgs p)
+{
+    constexpr int FA = TileGeom<BM, false>::floats, FB = TileGeom<BN, false>::floats;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    auto As = [&](int buf) -> float * { return lds + buf * (FA + FB); };
+    auto Bs = [&](int buf) -> float * { return lds + buf * (FA + FB) + FA; };
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int wm, wn;
+    wave_origin<BM, BN>(wave, wm, wn);
+    const int t = xcd_remap(blockIdx.x, p.tiles_m * p.tiles_n);
+    const int m0 = (t / p.tiles_n) * BM, n0 = (t % p.tiles_n) * BN;
+    const int N = 9 * p.Cin;
+    const long long total_kt = (p.P + kBK - 1) / kBK;
+    const long long kt_begin = (long long)blockIdx.y * p.ktiles_per_split;
+    const long long kt_end = min(total_kt, kt_begin + p.ktiles_per_split);
+    const long long pix_begin = kt_begin * kBK;
+    const int halo = p.W + 1;
+
+    // operands rebased to the block's first pixel (B one halo earlier: every shifted row has a non-negative offset)
+    const GSrc ga = make_gsrc(p.gy + pix_begin * p.Cout + m0);
+    const GSrc gb = make_gsrc(p.x + (pix_begin - halo) * p.Cin);
+    const GSrc gm = make_gsrc(reinterpret_cast<const float *>(p.tapmask + pix_begin));
+    const int ktail = (p.P % kBK) ? (int)(p.P % kBK) : kBK;
+    Plan<BM> pa;
+    plan_km<BM>(pa, p.Cout - m0, p.Cout, ktail, tid);
+    constexpr int NTB = (2 * BN + kThreads - 1) / kThreads;
+    unsigned b_off[2 * NTB], b_bit[NTB], m_off[NTB], m_reg[NTB];
+#pragma unroll
+    for (int jt = 0; jt < NTB; ++jt) {
+        const int tt = tid + kThreads * jt;
+        const int q = 8 * (tt >> 6) + (tt & 7), kp = (tt >> 3) & 7;
+        const int col = n0 + 4 * q;
+        const bool ok = (col < N) && ((2 * BN >= kThreads) || (tt < 2 * BN));
+        const int tap = ok ? col / p.Cin : 0, ci = ok ? col % p.Cin : 0;
+        const int shift = (tap / 3 - 1) * p.W + (tap % 3 - 1);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) b_off[2 * jt + i] = (unsigned)((2 * kp + i + halo + shift) * p.Cin + ci) * 4u;
+        b_bit[jt] = ok ? (1u << tap) : 0u;
+        m_off[jt] = (unsigned)(2 * kp) * 2u;              // two consecutive 16-bit masks = one dword
+    }
+    auto load_mask = [&](long long kt, int jt) -> unsigned {
+        const auto raw = __builtin_amdgcn_raw_buffer_load_b32(gm.rsrc, (int)m_off[jt], (int)((unsigned)(kt - kt_begin) * kBK * 2u), 0);
+        return __builtin_bit_cast(unsigned, raw);
+    };
+#pragma unroll
+    for (int jt = 0; jt < NTB; ++jt) m_reg[jt] = load_mask(kt_begin, jt);
+
+    // tiles are requested strictly in order kt_begin, kt_begin+1, ...: m_reg always holds the mask of the tile being
+    // requested and is refilled with the next tile's mask (one step of flight time)
+    auto load_tiles = [&](Stage<BM> &sa, Stage<BN> &sb, long long kt, bool live) {
+        const unsigned rel = (unsigned)(kt - kt_begin) * kBK;
+        const bool tail = (kt + 1) * kBK > p.P;
+        load_planned_km<BM>(sa, pa, ga, live ? rel * (unsigned)p.Cout * 4u : kDeadTile, tail);
+        const unsigned b_soff = live ? rel * (unsigned)p.Cin * 4u : kDeadTile;
+#pragma unroll
+        for (int jt = 0; jt < NTB; ++jt) {
+            const unsigned m = m_reg[jt];
+            m_reg[jt] = load_mask(min(kt + 1, total_kt), jt);
+            sb.v[2 * jt] = buffer_load4(gb, ((m & 0xffffu) & b_bit[jt]) ? b_off[2 * jt] : kOobOffset, b_soff);
+            sb.v[2 * jt + 1] = buffer_load4(gb, ((m >> 16) & b_bit[jt]) ? b_off[2 * jt + 1] : kOobOffset, b_soff);
+        }
+    };
+    auto store_tiles = [&](const Stage<BM> &sa, const Stage<BN> &sb, int buf) {
+        store_km<BM>(sa, As(buf), tid);
+        store_km<BN>(sb, Bs(buf), tid);
+    };
+
+    Acc acc;
+    acc_zero(acc);
+    Stage<BM> sa0, sa1;
+    Stage<BN> sb0, sb1;
+    load_tiles(sa0, sb0, kt_begin, true);
+    store_tiles(sa0, sb0, 0);
+    load_tiles(sa1, sb1, kt_begin + 1, kt_begin + 1 < kt_end);
+    __syncthreads();
+    auto step = [&](auto PAR, long long kt) {
+        constexpr int cur = decltype(PAR)::value;
+        Stage<BM> &sa_next = cur ? sa0 : sa1, &sa_far = cur ? sa1 : sa0;
+        Stage<BN> &sb_next = cur ? sb0 : sb1, &sb_far = cur ? sb1 : sb0;
+        auto load_far = [&]() { load_tiles(sa_far, sb_far, kt + 2, kt + 2 < kt_end); };
+        auto store_next = [&]() { store_tiles(sa_next, sb_next, cur ^ 1); };
+        half_step<BM, BN>(load_far, store_next, As(cur), Bs(cur), wm, wn, lane, acc);
+    };
+    for (long long kt = kt_begin; kt < kt_end; kt += 2) {
+        step(std::integral_constant<int, 0>{}, kt);
+        step(std::integral_constant<int, 1>{}, kt + 1);
+    }
+
+    float *dst = (p.splitk > 1) ? p.partial + (size_t)blockIdx.y * p.Cout * N : p.out;
+    acc_foreach_pair<false, false>(acc, wm, wn, lane, [&](int r, int c0, int c1, float v0, float v1) {
+        const int row = m0 + r, col0 = n0 + c0, col1 = n0 + c1;
+        if (row >= p.Cout) return;
+        float *q = dst + (size_t)row * N;
+        if (col1 < N) *reinterpret_cast<float2 *>(q + col0) = make_float2(v0, v1);      // N % 4 == 0: col0 is even
+        else if (col0 < N) q[col0] = v0;
+    });
+}
+#endif  // MH_PLANES
+
 // Packed weights of a 3x3 conv with N output and K input channels (for the dgrad conv the channel roles are swapped
 // and the taps mirrored: flip_transpose): element (tap, n, k) = w[n][k][tap], or w[k][n][8 - tap] when flipped.
 //   bf16-plane build: wt[tap][n][k / 16][24 dwords] = the LDS row image of one k-tile (hi | mid | lo, dword d of a
@@ -457,6 +593,71 @@ int mh_conv3x3_nhwc(const float *in, int B, int H, int W, int Cin, const float *
     int rc = check_launch("conv3x3_nhwc_kernel");
     if (rc || splitk == 1) return rc;
     return launch_splitk_reduce(p.partial, splitk, M, Cout, out, Cout, bias, epilogue, 0, as_stream(stream));
+}
+
+// dW [Cout][9*Cin] (tap-major, then input channel) of the 3x3 conv from x [B,H,W,Cin] and gy [B,H,W,Cout], without
+// a patch matrix.  Workspace = tap masks + split-K partials (mh_conv3x3_wgrad_ws_bytes).  Returns MH_EUNSUPPORTED in
+// the f32-MFMA build (callers then use im2col + GEMM).
+static int wgrad_splitk(long long P, int Cin, int Cout)
+{
+    const long long tiles = (long long)ceil_div(Cout, 128) * ceil_div(9 * Cin, 128);
+    const long long ktiles = (P + kBK - 1) / kBK;
+    int s = choose_splitk_tiles(tiles, (int)std::min<long long>(ktiles, 1 << 30), (double)Cout * 9 * Cin,
+                                2.0 * 9 * Cin * (double)Cout * P);
+    // 32-bit offsets inside a 1 GiB descriptor: bound the pixels a block walks over
+    const long long max_pix = (1LL << 30) / ((long long)std::max(Cin, Cout) * 4) - 2 * 4096;
+    while (ceil_div(ktiles, (long long)s) * kBK > max_pix && s < 65535) ++s;
+    return s;
+}
+
+size_t mh_conv3x3_wgrad_ws_bytes(int B, int H, int W, int Cin, int Cout)
+{
+    const long long P = (long long)B * H * W;
+    if (P <= 0 || Cin <= 0 || Cout <= 0) return 0;
+    const size_t mask = align_up((size_t)(P + 2 * kBK + 16) * sizeof(unsigned short), 256);
+    const int s = wgrad_splitk(P, Cin, Cout);
+    return mask + (s > 1 ? align_up((size_t)s * Cout * 9 * Cin * sizeof(float), 256) : 0);
+}
+
+int mh_conv3x3_wgrad(const float *x, const float *gy, int B, int H, int W, int Cin, int Cout, float *dw,
+                     void *workspace, size_t ws_bytes, void *stream)
+{
+#if MH_PLANES
+    MH_REQUIRE(x && gy && dw && workspace && B > 0 && H > 0 && W > 0 && Cin > 0 && Cin % 4 == 0 && Cout > 0 && Cout % 4 == 0);
+    MH_REQUIRE(((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(gy) | reinterpret_cast<uintptr_t>(dw) |
+                 reinterpret_cast<uintptr_t>(workspace)) & 15) == 0);
+    MH_REQUIRE(ws_bytes >= mh_conv3x3_wgrad_ws_bytes(B, H, W, Cin, Cout));
+    MH_REQUIRE((long long)(W + 1 + 4096) * std::max(Cin, Cout) * 4 < (1LL << 28));
+    const long long P = (long long)B * H * W;
+    hipStream_t st = as_stream(stream);
+    unsigned short *mask = reinterpret_cast<unsigned short *>(workspace);
+    const size_t mask_bytes = align_up((size_t)(P + 2 * kBK + 16) * sizeof(unsigned short), 256);
+    const long long Ppad = P + 2 * kBK + 16;
+    hipLaunchKernelGGL(tap_mask_kernel, dim3((unsigned)std::min<long long>((Ppad + 255) / 256, 4096)), dim3(256), 0, st, B, H,
+                       W, P, Ppad, mask);
+    int rc = check_launch("tap_mask_kernel");
+    if (rc) return rc;
+    WgradArgs p;
+    p.gy = gy; p.x = x; p.tapmask = mask; p.W = W; p.Cin = Cin; p.Cout = Cout; p.P = P;
+    p.tiles_m = ceil_div(Cout, 128);
+    p.tiles_n = ceil_div(9 * Cin, 128);
+    const long long total_kt = (P + kBK - 1) / kBK;
+    int splitk = wgrad_splitk(P, Cin, Cout);
+    p.ktiles_per_split = (int)ceil_div(total_kt, (long long)splitk);
+    splitk = (int)ceil_div(total_kt, (long long)p.ktiles_per_split);
+    MH_REQUIRE(splitk <= 65535);
+    p.splitk = splitk;
+    p.out = dw;
+    p.partial = reinterpret_cast<float *>(reinterpret_cast<char *>(workspace) + mask_bytes);
+    dim3 grid((unsigned)(p.tiles_m * p.tiles_n), (unsigned)splitk);
+    launch_tile_kernel<conv3x3_wgrad_kernel<128, 128>>(grid, tile_lds_bytes<128, 128, false, false>(), st, p);
+    rc = check_launch("conv3x3_wgrad_kernel");
+    if (rc || splitk == 1) return rc;
+    return launch_splitk_reduce(p.partial, splitk, Cout, 9 * Cin, dw, 9 * Cin, nullptr, MH_EPI_NONE, 0, st);
+#else
+    (void)x; (void)gy; (void)B; (void)H; (void)W; (void)Cin; (void)Cout; (void)dw; (void)workspace; (void)ws_bytes; (void)stream;
+    return MH_EUNSUPPORTED;
+#endif
 }
 
 int mh_conv_first_nchw(const float *in_nchw, int B, int Cin, int H, int W, const float *w, int Cout,

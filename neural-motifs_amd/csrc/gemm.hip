@@ -188,7 +188,7 @@ __global__ void splitk_reduce_kernel(const float *__restrict__ partial, int spli
 int choose_splitk_tiles(long long tiles, int ktiles, double out_elems, double flops)
 {
     if (tiles >= 4096 || ktiles < 16) return 1;
-    static const int cand[] = {1, 2, 3, 4, 5, 6, 7, 8, 10, 12, 14, 16, 20, 24, 28, 32, 40, 48, 56, 64};
+    static const int cand[] = {1, 2, 3, 4, 5, 6, 7, 8, 10, 12, 14, 16, 20, 24, 28, 32, 40, 48, 56, 64, 80, 96, 128, 160, 192, 256};
     const double t1 = flops / (double)tiles / (170e12 / 256.0);   // seconds per tile on a fully occupied CU
     double best = 1e30;
     int best_s = 1;

@@ -20,7 +20,8 @@ SYMBOLS = (
     'mh_nms_ws_bytes', 'mh_nms', 'mh_nms_batched_ws_bytes', 'mh_nms_batched',
     'mh_roi_align_fwd', 'mh_roi_align_bwd', 'mh_draw_union_boxes', 'mh_bbox_overlaps',
     'mh_gemm_ws_bytes', 'mh_gemm_auto_splitk', 'mh_gemm_f32',
-    'mh_conv3x3_packed_floats', 'mh_conv3x3_pack_weight', 'mh_conv3x3_ws_bytes', 'mh_conv3x3_nhwc', 'mh_conv_first_nchw', 'mh_maxpool2x2_nhwc',
+    'mh_conv3x3_packed_floats', 'mh_conv3x3_pack_weight', 'mh_conv3x3_ws_bytes', 'mh_conv3x3_nhwc',
+    'mh_conv3x3_wgrad_ws_bytes', 'mh_conv3x3_wgrad', 'mh_conv_first_nchw', 'mh_maxpool2x2_nhwc',
     'mh_maxpool2x2_bwd_nhwc', 'mh_act_bwd',
     'mh_im2col_nhwc', 'mh_nchw_to_nhwc', 'mh_nhwc_to_nchw',
     'mh_hwlstm_fwd_ws_bytes', 'mh_hwlstm_fwd', 'mh_hwlstm_bwd_ws_bytes', 'mh_hwlstm_bwd',
@@ -50,7 +51,7 @@ def lib():
             getattr(L, name)          # AttributeError if the library is stale
         L.mh_last_error.restype = ctypes.c_char_p
         for name in ('mh_nms_ws_bytes', 'mh_nms_batched_ws_bytes', 'mh_gemm_ws_bytes', 'mh_conv3x3_ws_bytes', 'mh_bn_ws_bytes',
-                     'mh_conv3x3_packed_floats', 'mh_hwcell_seq_ws_bytes',
+                     'mh_conv3x3_packed_floats', 'mh_hwcell_seq_ws_bytes', 'mh_conv3x3_wgrad_ws_bytes',
                      'mh_hwlstm_fwd_ws_bytes', 'mh_hwlstm_bwd_ws_bytes'):
             getattr(L, name).restype = ctypes.c_size_t
         _lib = L
@@ -244,6 +245,20 @@ def conv3x3_nhwc(x, wt, bias, epilogue):
                                ptr(ws), c_size_t(ws.numel() if ws is not None else 0), stream())
     _check(rc, 'mh_conv3x3_nhwc')
     return out
+
+
+def conv3x3_wgrad(x, gy):
+    """dW [Cout, 9*Cin] (tap-major, then cin) of the 3x3/1/1 conv from x [B,H,W,Cin], gy [B,H,W,Cout]; None when this
+    build has no implicit-GEMM wgrad kernel (f32-MFMA build: the caller uses im2col + gemm)"""
+    B, H, W, Cin = x.shape
+    Cout = gy.shape[3]
+    dw = torch.empty(Cout, 9 * Cin, dtype=torch.float32, device=x.device)
+    ws = workspace(lib().mh_conv3x3_wgrad_ws_bytes(B, H, W, Cin, Cout), x.device, 'wgrad')
+    rc = lib().mh_conv3x3_wgrad(f32(x), f32(gy), B, H, W, Cin, Cout, f32(dw), ptr(ws), c_size_t(ws.numel()), stream())
+    if rc == -2:
+        return None
+    _check(rc, 'mh_conv3x3_wgrad')
+    return dw
 
 
 def conv_first_nchw(x, w, bias, epilogue):

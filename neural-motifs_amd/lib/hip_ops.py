@@ -289,8 +289,10 @@ class _Conv3x3Fn(torch.autograd.Function):
             wt_t = _hip.conv3x3_pack_weight(_c(weight), True)          # the dgrad conv's weights (roles swapped)
             gx = _hip.conv3x3_nhwc(gy, wt_t, None, EPI_NONE)
         if ctx.needs_input_grad[1]:
-            cols, _, _ = _hip.im2col_nhwc(x_nhwc, 3, 3, 1, 1)          # [M, 9*Cin]
-            gwm = _hip.gemm(gy.view(-1, Cout), cols, True, False)      # [Cout, 9*Cin]  (tap-major, then cin)
+            gwm = _hip.conv3x3_wgrad(x_nhwc, gy)                       # implicit GEMM over the pixels, no patch matrix
+            if gwm is None:                                            # f32-MFMA build
+                cols, _, _ = _hip.im2col_nhwc(x_nhwc, 3, 3, 1, 1)      # [M, 9*Cin]
+                gwm = _hip.gemm(gy.view(-1, Cout), cols, True, False)  # [Cout, 9*Cin]  (tap-major, then cin)
             gw = gwm.view(Cout, 3, 3, Cin).permute(0, 3, 1, 2).contiguous()
         if ctx.needs_input_grad[2]:
             gb = gy.view(-1, Cout).sum(0)

@@ -245,6 +245,40 @@ def test_conv3x3_dgrad_via_flipped_weights(hip):
     np.testing.assert_allclose(gx.permute(0, 3, 1, 2).cpu().numpy(), x.grad.float().numpy(), atol=1e-4)
 
 
+@pytest.mark.parametrize('B,H,W,Cin,Cout', [(2, 9, 11, 16, 32), (3, 7, 7, 256, 512), (1, 37, 37, 64, 128),
+                                            (2, 14, 14, 64, 64), (1, 20, 23, 128, 120), (5, 6, 5, 32, 8)])
+def test_conv3x3_weight_gradient_implicit_gemm(hip, B, H, W, Cin, Cout):
+    """mh_conv3x3_wgrad (implicit GEMM over the pixels, tap masks, split-K) vs autograd in fp64: image borders, several
+    images, pixel counts that are not a multiple of 16, n-tiles that span two taps (Cin = 64), tiny outputs."""
+    g = torch.Generator().manual_seed(B * 1000 + H * 10 + Cin)
+    x = torch.randn(B, Cin, H, W, generator=g, dtype=torch.float64)
+    gy = torch.randn(B, Cout, H, W, generator=g, dtype=torch.float64)
+    w = torch.zeros(Cout, Cin, 3, 3, dtype=torch.float64, requires_grad=True)
+    F.conv2d(x, w, None, padding=1).backward(gy)
+    got = hip.conv3x3_wgrad(x.float().permute(0, 2, 3, 1).contiguous().cuda(), gy.float().permute(0, 2, 3, 1).contiguous().cuda())
+    assert got is not None and got.shape == (Cout, 9 * Cin)
+    got = got.view(Cout, 3, 3, Cin).permute(0, 3, 1, 2).cpu().double()
+    scale = float(w.grad.abs().max())
+    np.testing.assert_allclose(got.numpy(), w.grad.numpy(), atol=2e-5 * scale)
+
+
+def test_maxpool_and_activation_backward(hip):
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn(2, 8, 9, 7, generator=g)                         # odd H and W: trailing row / column get zero gradient
+    x[0, :, :2, :2] = 1.5                                            # ties: the first maximal element takes the gradient
+    xg = x.clone().requires_grad_()
+    y = F.max_pool2d(xg, 2, 2)
+    gy = torch.randn(y.shape, generator=g)
+    y.backward(gy)
+    got = hip.maxpool2x2_bwd_nhwc(x.permute(0, 2, 3, 1).contiguous().cuda(), gy.permute(0, 2, 3, 1).contiguous().cuda())
+    np.testing.assert_array_equal(got.permute(0, 3, 1, 2).cpu().numpy(), xg.grad.numpy())
+    yv = torch.randn(3, 40, generator=g) * 4
+    gv = torch.randn(3, 40, generator=g)
+    for epi, act in ((1, torch.relu(yv)), (2, torch.clamp(yv, 0, 6))):
+        ref = gv * ((act > 0) & ((act < 6) if epi == 2 else torch.ones_like(act, dtype=torch.bool))).float()
+        np.testing.assert_array_equal(hip.act_bwd(gv.cuda(), act.cuda(), epi).cpu().numpy(), ref.numpy())
+
+
 def test_conv_first_and_pool_and_layouts(hip):
     g = torch.Generator().manual_seed(2)
     x = torch.randn(2, 3, 38, 42, generator=g)
