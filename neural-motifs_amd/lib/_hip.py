@@ -250,6 +250,8 @@ def conv3x3_nhwc(x, wt, bias, epilogue):
 def conv3x3_wgrad(x, gy):
     """dW [Cout, 9*Cin] (tap-major, then cin) of the 3x3/1/1 conv from x [B,H,W,Cin], gy [B,H,W,Cout]; None when this
     build has no implicit-GEMM wgrad kernel (f32-MFMA build: the caller uses im2col + gemm)"""
+    if os.environ.get('MOTIFS_WGRAD') == 'im2col':          # A/B switch: the patch-matrix path
+        return None
     B, H, W, Cin = x.shape
     Cout = gy.shape[3]
     dw = torch.empty(Cout, 9 * Cin, dtype=torch.float32, device=x.device)
