@@ -64,3 +64,70 @@ def test_proposal_assignments_det_properties():
         best = iou.max(1)[0]
         assert (best[:nfg] >= 0.5).all() and (best[nfg:] < 0.5).all()
         assert torch.equal(targets[m], g_im[iou.argmax(1)])
+
+
+def test_blob_det_mode_carries_the_anchor_targets():
+    """dataloaders/blob.py in 'det' training mode (reference blob.py:91-102,139-142): per image the sampled anchors,
+    their matched GT boxes and labels; train_anchor_inds = (img, h, w, A) of the labelled anchors"""
+    from dataloaders.synthetic import SyntheticVG, make_blob
+    from lib.fpn.anchor_targets import anchor_target_layer
+    ds = SyntheticVG(num_images=2, seed=5, n_boxes=7, n_rels=3)
+    np.random.seed(42)
+    blob = make_blob(ds, [0, 1], is_train=True, mode='det')
+    assert blob.train_anchor_labels.shape[1] == 5 and blob.train_anchors.shape[1] == 8
+    assert torch.equal(blob.train_anchor_inds, blob.train_anchor_labels[:, :4])
+    assert blob.train_anchor_labels.shape[0] == blob.train_anchors.shape[0] <= 2 * 256
+    assert set(blob.train_anchor_labels[:, 4].tolist()) <= {0, 1}
+    np.random.seed(42)                                        # same draws -> same targets, image by image
+    off = 0
+    for i in range(2):
+        d = ds[i]
+        a, inds, t, l = anchor_target_layer(d['gt_boxes'].astype(np.float32) * d['scale'], (592, 592))
+        n = inds.shape[0]
+        got = blob.train_anchor_labels[off:off + n].numpy()
+        assert (got[:, 0] == i).all()
+        np.testing.assert_array_equal(got[:, 1:4], inds)
+        np.testing.assert_array_equal(got[:, 4], l)
+        np.testing.assert_array_equal(blob.train_anchors[off:off + n].numpy(), np.hstack((a, t)).astype(np.float32))
+        off += n
+    assert off == blob.train_anchor_labels.shape[0]
+    assert len(blob[0]) == 8                                  # (..., proposals, train_anchor_inds)
+    # 'rel' mode keeps the empty placeholder
+    assert make_blob(ds, [0, 1], is_train=True, mode='rel').train_anchor_inds.shape == (0, 4)
+
+
+def test_detector_losses_match_the_oracle_restatement():
+    """lib/detector_loss.py (product, pure host glue) vs the loss part of oracle.model.detector_train_losses on the same
+    random predictions -- two independent statements of models/train_detector.py:100-140"""
+    from lib.detector_loss import detector_losses
+    from lib.object_detector import Result
+    from oracle import model as OM
+    g = torch.Generator().manual_seed(0)
+    n, C, k = 40, 11, 30
+    scores = torch.randn(n, C, generator=g)
+    deltas = torch.randn(n, C, 4, generator=g) * 0.3
+    labels = torch.randint(0, C, (n,), generator=g)
+    labels[::3] = 0
+    x1y1 = torch.rand(n, 2, generator=g) * 300
+    priors = torch.cat((x1y1, x1y1 + 20 + torch.rand(n, 2, generator=g) * 200), 1)
+    g1 = torch.rand(n, 2, generator=g) * 300
+    targets = torch.cat((g1, g1 + 20 + torch.rand(n, 2, generator=g) * 200), 1)
+    rpn_scores = torch.randn(k, 2, generator=g)
+    rpn_deltas = torch.randn(k, 4, generator=g) * 0.3
+    a1 = torch.rand(k, 2, generator=g) * 300
+    anchors = torch.cat((a1, a1 + 16 + torch.rand(k, 2, generator=g) * 100, a1 + 3, a1 + 40 + torch.rand(k, 2, generator=g) * 100), 1)
+    tal = torch.cat((torch.zeros(k, 4, dtype=torch.long), torch.randint(0, 2, (k, 1), generator=g)), 1)
+    res = Result(od_obj_dists=scores, od_box_deltas=deltas, od_obj_labels=labels, od_box_priors=priors,
+                 od_box_targets=targets, rpn_scores=rpn_scores, rpn_box_deltas=rpn_deltas)
+    got = detector_losses(res, tal, anchors)
+    # the oracle's arithmetic on the same tensors
+    valid = (labels != 0).nonzero().squeeze(1)
+    fg, bg = valid.numel(), n - valid.numel()
+    twod = valid * C + labels[valid]
+    box = OM._bbox_loss(priors[valid], deltas.reshape(-1, 4)[twod], targets[valid]) * (2 * 4.0 * fg / (fg + bg + 1e-4))
+    pos = (tal[:, -1] == 1).nonzero().squeeze(1)
+    rbox = OM._bbox_loss(anchors[:, :4][pos], rpn_deltas[pos], anchors[:, 4:][pos]) * (2 * 2.0 * pos.numel() / (k + 1e-4))
+    np.testing.assert_allclose(float(got['box_loss']), float(box), rtol=1e-6)
+    np.testing.assert_allclose(float(got['rpn_box_loss']), float(rbox), rtol=1e-6)
+    np.testing.assert_allclose(float(got['class_loss']), float(torch.nn.functional.cross_entropy(scores, labels)), rtol=1e-6)
+    np.testing.assert_allclose(float(got['total']), float(got['class_loss'] + got['box_loss'] + got['rpn_class_loss'] + got['rpn_box_loss']), rtol=1e-6)
