@@ -128,7 +128,9 @@ size_t mh_conv3x3_ws_bytes(int B, int H, int W, int Cin, int Cout);   /* split-K
 int mh_conv3x3_nhwc(const float *in, int B, int H, int W, int Cin, const float *wt, int Cout,
                     const float *bias, int epilogue, float *out, void *workspace, size_t ws_bytes,
                     void *stream);
-/* weight gradient of the 3x3/1/1 conv as an implicit GEMM over the pixels (no patch matrix): dw [Cout][9*Cin]
+/* replaces cuDNN's convolution weight gradient reached through nn.Conv2d autograd (mask tower conv,
+ * lib/get_union_boxes.py:31-39; every VGG / RPN conv when the detector trains, models/train_detector.py:141-146):
+ * weight gradient of the 3x3/1/1 conv as an implicit GEMM over the pixels (no patch matrix): dw [Cout][9*Cin]
  * (tap-major, then input channel) from x [B,H,W,Cin] and gy [B,H,W,Cout]; Cin, Cout % 4 == 0.  MH_EUNSUPPORTED in the
  * f32-MFMA build (use mh_im2col_nhwc + mh_gemm_f32 there). */
 size_t mh_conv3x3_wgrad_ws_bytes(int B, int H, int W, int Cin, int Cout);
@@ -137,7 +139,8 @@ int mh_conv3x3_wgrad(const float *x, const float *gy, int B, int H, int W, int C
 int mh_conv_first_nchw(const float *in_nchw, int B, int Cin, int H, int W, const float *w /*[Cout,Cin,3,3]*/,
                        int Cout, const float *bias, int epilogue, float *out_nhwc, void *stream);
 int mh_maxpool2x2_nhwc(const float *in, int B, int H, int W, int C, float *out, void *stream);
-/* detector pre-training (models/train_detector.py; the trunk is trainable there):
+/* detector pre-training (models/train_detector.py; the trunk is trainable there; replaces the autograd backward of
+ * nn.MaxPool2d / nn.ReLU in torchvision's vgg16.features, lib/object_detector.py:623-633):
  *   mh_maxpool2x2_bwd_nhwc: gradient to the first maximal element of each window (torch semantics), gin fully written
  *   mh_act_bwd: gradient through a fused ReLU / ReLU6 epilogue given the activated output y */
 int mh_maxpool2x2_bwd_nhwc(const float *in, const float *gout, int B, int H, int W, int C, float *gin,
