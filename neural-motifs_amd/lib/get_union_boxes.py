@@ -73,8 +73,11 @@ class _TowerFn(torch.autograd.Function):
         dx2, dg2, db2 = _hip.bn_bwd(y1, g_nhwc, None, mean2, invstd2, g2, True)          # through BN2 and conv.4's ReLU
         wt4_t = _hip.conv3x3_pack_weight(w4.contiguous(), True)
         dz = _hip.conv3x3_nhwc(dx2, wt4_t, None, EPI_NONE)
-        cols4, _, _ = _hip.im2col_nhwc(z, 3, 3, 1, 1)
-        dw4 = _hip.gemm(dx2.view(-1, C1), cols4, True, False).view(C1, 3, 3, w4.shape[1]).permute(0, 3, 1, 2).contiguous()
+        dw4 = _hip.conv3x3_wgrad(z, dx2)                 # implicit GEMM over the pixels: no 0.7 GB patch matrix
+        if dw4 is None:                                  # f32-MFMA build
+            cols4, _, _ = _hip.im2col_nhwc(z, 3, 3, 1, 1)
+            dw4 = _hip.gemm(dx2.view(-1, C1), cols4, True, False)
+        dw4 = dw4.view(C1, 3, 3, w4.shape[1]).permute(0, 3, 1, 2).contiguous()
         db4 = dx2.view(-1, C1).sum(0)
         dx1, dg1, db1 = _hip.bn_bwd(y0, dz, arg, mean1, invstd1, g1, True)               # pool + BN1 + conv.0's ReLU
         dwm = _hip.gemm(dx1.view(-1, C0), cols0, True, False)
