@@ -277,6 +277,107 @@ def main():
     det['bl_prior'], det['bl_deltas'], det['bl_gt'] = prior.numpy(), deltas.numpy(), gtbx.numpy()
     out['det_train'] = det
 
+    # ---------------------------------------------------------------- Visual Genome on-disk formats
+    # the reference's load_graphs / load_info / VG.__getitem__ geometry on a synthetic VG-SGG-shaped roidb.  h5py,
+    # torchvision, pycocotools are absent and dataloaders/blob.py does not parse under Python 3.10 (`async` keyword):
+    # all four are stubbed; h5py.File hands back the in-memory arrays (the reference only does roi_h5[key][...]).
+    import json
+    import tempfile
+    from PIL import Image
+    n_img = 40
+    split = np.array([2 if i % 4 == 3 else 0 for i in range(n_img)], dtype=np.int32)
+    first_box, last_box, first_rel, last_rel = [], [], [], []
+    boxes_xywh, labels, rel_pairs, rel_preds = [], [], [], []
+    for i in range(n_img):
+        nb = 0 if i in (5, 17) else rs.randint(2, 9)
+        if nb == 0:
+            first_box.append(-1); last_box.append(-1); first_rel.append(-1); last_rel.append(-1)
+            continue
+        b0 = len(boxes_xywh)
+        for _ in range(nb):
+            w_, h_ = rs.randint(20, 400), rs.randint(20, 400)
+            xc, yc = rs.randint(w_ // 2 + 1, 1024 - w_ // 2 - 1), rs.randint(h_ // 2 + 1, 1024 - h_ // 2 - 1)
+            boxes_xywh.append((xc, yc, w_, h_)); labels.append(rs.randint(1, 151))
+        first_box.append(b0); last_box.append(len(boxes_xywh) - 1)
+        nr = 0 if i in (2, 9, 22) else rs.randint(1, 12)
+        if nr == 0:
+            first_rel.append(-1); last_rel.append(-1)
+            continue
+        r0 = len(rel_pairs)
+        for _ in range(nr):
+            a_, b_ = rs.choice(nb, 2, replace=False)
+            rel_pairs.append((b0 + a_, b0 + b_)); rel_preds.append(rs.randint(1, 51))
+        if nr >= 3:                                         # duplicates of one pair with different predicates
+            rel_pairs.append(rel_pairs[r0]); rel_preds.append(rs.randint(1, 51))
+        first_rel.append(r0); last_rel.append(len(rel_pairs) - 1)
+    roidb = {'split': split, 'img_to_first_box': np.array(first_box, np.int32), 'img_to_last_box': np.array(last_box, np.int32),
+             'img_to_first_rel': np.array(first_rel, np.int32), 'img_to_last_rel': np.array(last_rel, np.int32),
+             'labels': np.array(labels, np.int32)[:, None], 'boxes_1024': np.array(boxes_xywh, np.int32),
+             'relationships': np.array(rel_pairs, np.int32), 'predicates': np.array(rel_preds, np.int32)[:, None]}
+
+    class _FakeH5(dict):
+        pass
+    h5stub = types.ModuleType('h5py')
+    h5stub.File = lambda path, mode='r': _FakeH5({k: v.copy() for k, v in roidb.items()})
+    sys.modules['h5py'] = h5stub
+    tv = types.ModuleType('torchvision'); tvt = types.ModuleType('torchvision.transforms')
+    for nm in ('Resize', 'Compose', 'ToTensor', 'Normalize'):
+        setattr(tvt, nm, type(nm, (), {'__init__': lambda self, *a, **k: None}))
+    tv.transforms = tvt
+    sys.modules['torchvision'], sys.modules['torchvision.transforms'] = tv, tvt
+    pc = types.ModuleType('pycocotools'); pcc = types.ModuleType('pycocotools.coco'); pcc.COCO = object
+    sys.modules['pycocotools'], sys.modules['pycocotools.coco'] = pc, pcc
+    blob_stub = types.ModuleType('dataloaders.blob'); blob_stub.Blob = object
+    sys.modules['dataloaders.blob'] = blob_stub
+    refvg = importlib.import_module('dataloaders.visual_genome')
+    vg = {('in_' + k): v for k, v in roidb.items()}
+    cases = [('train', -1, 6, True, True), ('train', -1, 6, True, False), ('val', -1, 6, True, False),
+             ('test', -1, 0, True, False), ('train', 20, 4, False, False), ('test', 5, 0, False, False)]
+    for ci, (mode, num_im, num_val, fer, fno) in enumerate(cases):
+        mask, bxs, cls_, rels = refvg.load_graphs('unused.h5', mode, num_im, num_val_im=num_val, filter_empty_rels=fer,
+                                                  filter_non_overlap=fno)
+        vg['lg%d_args' % ci] = np.array([{'train': 0, 'val': 1, 'test': 2}[mode], num_im, num_val, int(fer), int(fno)])
+        vg['lg%d_mask' % ci] = mask
+        vg['lg%d_counts' % ci] = np.array([b.shape[0] for b in bxs] + [-1] + [r.shape[0] for r in rels])
+        vg['lg%d_boxes' % ci] = np.concatenate(bxs, 0) if bxs else np.zeros((0, 4))
+        vg['lg%d_classes' % ci] = np.concatenate(cls_, 0) if cls_ else np.zeros((0,))
+        vg['lg%d_rels' % ci] = np.concatenate(rels, 0) if rels else np.zeros((0, 3))
+    with tempfile.TemporaryDirectory() as td:
+        info = {'label_to_idx': {'cls%03d' % i: i for i in range(1, 151)},
+                'predicate_to_idx': {'pred%02d' % i: i for i in range(1, 51)}}
+        jp = os.path.join(td, 'dicts.json')
+        json.dump(info, open(jp, 'w'))
+        itc, itp = refvg.load_info(jp)
+        vg['info_classes'], vg['info_predicates'] = np.array(itc), np.array(itp)
+        # __getitem__ geometry: flips, box clipping, im_size, duplicate-relation sampling (numpy draw order)
+        sizes = [(640, 480), (375, 500), (512, 512), (800, 333)]
+        fns = []
+        for i, (w_, h_) in enumerate(sizes):
+            fn = os.path.join(td, 'im%d.jpg' % i)
+            Image.fromarray(rs.randint(0, 255, (h_, w_, 3)).astype(np.uint8)).save(fn)
+            fns.append(fn)
+        mask, bxs, cls_, rels = refvg.load_graphs('unused.h5', 'train', -1, num_val_im=0, filter_empty_rels=True)
+        for mode in ('train', 'val'):
+            ds_ = refvg.VG.__new__(refvg.VG)
+            ds_.mode, ds_.filenames = mode, fns
+            ds_.gt_boxes, ds_.gt_classes, ds_.relationships = bxs[:4], cls_[:4], rels[:4]
+            ds_.filter_duplicate_rels = (mode == 'train')
+            ds_.rpn_rois = None
+            ds_.transform_pipeline = lambda im: torch.zeros(3, 592, 592)
+            for rep in range(3):
+                for idx in range(4):
+                    np.random.seed(1000 * rep + idx)
+                    e = ds_[idx]
+                    key = 'gi_%s_%d_%d_' % (mode, rep, idx)
+                    vg[key + 'boxes'], vg[key + 'rels'] = e['gt_boxes'], np.asarray(e['gt_relations'])
+                    vg[key + 'size'] = np.array(e['img_size'], dtype=np.float64)
+                    vg[key + 'flipped'] = np.array(int(bool(e['flipped'])))
+        vg['gi_sizes'] = np.array(sizes)
+        vg['gi_first4_counts'] = np.array([b.shape[0] for b in bxs[:4]] + [-1] + [r.shape[0] for r in rels[:4]])
+        vg['gi_first4_boxes'] = np.concatenate(bxs[:4], 0)
+        vg['gi_first4_rels'] = np.concatenate(rels[:4], 0)
+    out['vg_formats'] = vg
+
     for name, d in out.items():
         path = os.path.join(HERE, name + '.npz')
         np.savez_compressed(path, **{k: np.asarray(v) for k, v in d.items()})
