@@ -290,7 +290,9 @@ def _lstm_mask(rng, L_, Bsz, H, p, training):
 
 def context_forward(sd, cfg, obj_fmaps, obj_logits, im_inds, obj_labels, box_priors, boxes_per_cls,
                     training, rng, prefix='context.'):
-    """LinearizedContext.forward (rel_model.py:236-296) for nl_obj > 0 and nl_edge > 0."""
+    """LinearizedContext.forward (rel_model.py:236-296), including the nl_obj == 0 (decoder_lin / one-hot, :259-284)
+    and nl_edge == 0 (edge_ctx None) baseline branches; the SGDet-eval NMS of the nl_obj == 0 branch (:266-281) is
+    restated with the greedy per-class NMS of oracle/boxes.py."""
     H = cfg['hidden_dim']
     num_classes = sd[prefix + 'obj_embed.weight'].shape[0]
     obj_embed = F.softmax(obj_logits, dim=1) @ sd[prefix + 'obj_embed.weight']
@@ -302,32 +304,53 @@ def context_forward(sd, cfg, obj_fmaps, obj_logits, im_inds, obj_labels, box_pri
     pos_embed = dropout(pe, 0.1, training, rng)
     obj_pre_rep = torch.cat((obj_fmaps, obj_embed, pos_embed), 1)
 
-    # ---- obj_ctx (rel_model.py:197-234)
-    confidence = F.softmax(obj_logits, dim=1).detach()[:, 1:].max(1)[0]
-    perm, inv_perm, ls_transposed = sort_rois(cfg['order'], im_inds, confidence, box_priors)
-    obj_inp_rep = obj_pre_rep[perm].contiguous()
-    mask = _lstm_mask(rng, cfg['nl_obj'], int(ls_transposed[0]), H, cfg['rec_dropout'], training)
-    encoder_rep = L.alternating_highway_lstm(obj_inp_rep, ls_transposed, sd[prefix + 'obj_ctx_rnn.weight'],
-                                             sd[prefix + 'obj_ctx_rnn.bias'], H, cfg['nl_obj'], training, mask)
-    if cfg['mode'] != 'predcls':
-        dec_in = torch.cat((obj_inp_rep, encoder_rep), 1) if cfg['pass_in_obj_feats_to_decoder'] else encoder_rep
-        dec_p = {k[len(prefix + 'decoder_rnn.'):]: v for k, v in sd.items() if k.startswith(prefix + 'decoder_rnn.')}
-        dmask = None
-        if cfg['rec_dropout'] > 0.0:
-            # decoder_rnn.py:13-37 -- drawn in eval mode too (it is simply not applied there)
-            dmask = rng.keep_mask((int(ls_transposed[0]), H), 1.0 - cfg['rec_dropout']) / (1.0 - cfg['rec_dropout'])
-        obj_dists2, obj_preds = L.decoder_forward(
-            dec_p, dec_in, ls_transposed, H, training,
-            labels=obj_labels[perm] if obj_labels is not None else None,
-            boxes_for_nms=boxes_per_cls[perm] if boxes_per_cls is not None else None,
-            dropout_mask=dmask)
-        obj_preds = obj_preds[inv_perm]
-        obj_dists2 = obj_dists2[inv_perm]
+    if cfg['nl_obj'] > 0:
+        # ---- obj_ctx (rel_model.py:197-234)
+        confidence = F.softmax(obj_logits, dim=1).detach()[:, 1:].max(1)[0]
+        perm, inv_perm, ls_transposed = sort_rois(cfg['order'], im_inds, confidence, box_priors)
+        obj_inp_rep = obj_pre_rep[perm].contiguous()
+        mask = _lstm_mask(rng, cfg['nl_obj'], int(ls_transposed[0]), H, cfg['rec_dropout'], training)
+        encoder_rep = L.alternating_highway_lstm(obj_inp_rep, ls_transposed, sd[prefix + 'obj_ctx_rnn.weight'],
+                                                 sd[prefix + 'obj_ctx_rnn.bias'], H, cfg['nl_obj'], training, mask)
+        if cfg['mode'] != 'predcls':
+            dec_in = torch.cat((obj_inp_rep, encoder_rep), 1) if cfg['pass_in_obj_feats_to_decoder'] else encoder_rep
+            dec_p = {k[len(prefix + 'decoder_rnn.'):]: v for k, v in sd.items() if k.startswith(prefix + 'decoder_rnn.')}
+            dmask = None
+            if cfg['rec_dropout'] > 0.0:
+                # decoder_rnn.py:13-37 -- drawn in eval mode too (it is simply not applied there)
+                dmask = rng.keep_mask((int(ls_transposed[0]), H), 1.0 - cfg['rec_dropout']) / (1.0 - cfg['rec_dropout'])
+            obj_dists2, obj_preds = L.decoder_forward(
+                dec_p, dec_in, ls_transposed, H, training,
+                labels=obj_labels[perm] if obj_labels is not None else None,
+                boxes_for_nms=boxes_per_cls[perm] if boxes_per_cls is not None else None,
+                dropout_mask=dmask)
+            obj_preds = obj_preds[inv_perm]
+            obj_dists2 = obj_dists2[inv_perm]
+        else:
+            obj_preds = obj_labels
+            obj_dists2 = torch.full((obj_preds.size(0), num_classes), -1000.0)
+            obj_dists2[torch.arange(obj_preds.size(0)), obj_preds] = 1000.0
+        obj_ctx = encoder_rep[inv_perm]
     else:
-        obj_preds = obj_labels
-        obj_dists2 = torch.full((obj_preds.size(0), num_classes), -1000.0)
-        obj_dists2[torch.arange(obj_preds.size(0)), obj_preds] = 1000.0
-    obj_ctx = encoder_rep[inv_perm]
+        if cfg['mode'] == 'predcls':
+            obj_dists2 = torch.full((obj_labels.size(0), num_classes), -1000.0)          # to_onehot, pytorch_misc.py
+            obj_dists2[torch.arange(obj_labels.size(0)), obj_labels] = 1000.0
+        else:
+            obj_dists2 = F.linear(obj_pre_rep, sd[prefix + 'decoder_lin.weight'], sd[prefix + 'decoder_lin.bias'])
+        if cfg['mode'] == 'sgdet' and not training:
+            probs = F.softmax(obj_dists2, 1).detach()
+            nms_mask = torch.zeros_like(probs)
+            for c_i in range(1, num_classes):
+                keep = B.apply_nms(probs[:, c_i], boxes_per_cls[:, c_i], pre_nms_topn=probs.size(0),
+                                   post_nms_topn=probs.size(0), nms_thresh=0.3)
+                nms_mask[:, c_i][keep] = 1
+            obj_preds = (nms_mask * probs)[:, 1:].max(1)[1] + 1
+        else:
+            obj_preds = obj_labels if obj_labels is not None else obj_dists2[:, 1:].max(1)[1] + 1
+        obj_ctx = obj_pre_rep
+
+    if cfg['nl_edge'] == 0:
+        return obj_dists2, obj_preds, None
 
     # ---- edge_ctx (rel_model.py:171-195)
     edge_in_feats = torch.cat((obj_fmaps, obj_ctx), 1) if cfg['pass_in_obj_feats_to_edge'] else obj_ctx
@@ -415,7 +438,10 @@ def relmodel_forward(sd, cfg, x, im_sizes, image_offset, gt_boxes, gt_classes, t
         sd, cfg, obj_fmap, det['rm_obj_dists'].detach(), im_inds,
         det['rm_obj_labels'] if use_labels else None, boxes, det['boxes_all'], training, rng)
     P = cfg['pooling_dim']
-    edge_rep = F.linear(edge_ctx, sd['post_lstm.weight'], sd['post_lstm.bias']).view(-1, 2, P)
+    if edge_ctx is None:            # nl_edge == 0: rel_model.py:500-503 (edge_rep = self.post_emb(result.obj_preds))
+        edge_rep = sd['post_emb.weight'][obj_preds].view(-1, 2, P)
+    else:
+        edge_rep = F.linear(edge_ctx, sd['post_lstm.weight'], sd['post_lstm.bias']).view(-1, 2, P)
     subj_rep, obj_rep = edge_rep[:, 0], edge_rep[:, 1]
     prod_rep = subj_rep[rel_inds[:, 1]] * obj_rep[rel_inds[:, 2]]
     if cfg.get('use_vision', True):

@@ -152,3 +152,48 @@ def test_trainable_trunk_autograd_plumbing(shim):
     for p in net.parameters():
         p.requires_grad = False
     assert not net(x).requires_grad
+
+
+# (nl_obj == 0 with nl_edge > 0 cannot run in the reference either: the edge LSTM is built for embed_dim [+ obj_dim]
+# inputs, rel_model.py:126-136, but is fed the 4424-d obj_pre_rep as context, :284-295)
+@pytest.mark.parametrize('nl_obj,nl_edge,mode', [(0, 0, 'sgcls'), (2, 0, 'sgcls'), (0, 0, 'predcls')])
+def test_baseline_context_variants_match_the_oracle(shim, nl_obj, nl_edge, mode):
+    """the nl_obj == 0 (decoder_lin / one-hot labels) and nl_edge == 0 (post_emb instead of the edge LSTM) branches of
+    LinearizedContext / RelModel (reference lib/rel_model.py:259-296, :500-503): train forward
+    against oracle/model.py, gradients finite, and only the parameters of the chosen branch exist"""
+    from dataloaders.synthetic import SyntheticVG, make_blob
+    from lib import rng
+    from lib.rel_model import RelModel
+    from oracle import model as OM
+    torch.manual_seed(1)
+    ds = SyntheticVG(num_images=2, seed=4, n_boxes=5, n_rels=6, im_size=224)
+    kw = dict(hidden_dim=32, pooling_dim=4096, nl_obj=nl_obj, nl_edge=nl_edge, order='leftright', rec_dropout=0.1,
+              use_bias=True, pass_in_obj_feats_to_decoder=False, pass_in_obj_feats_to_edge=False, use_tanh=False,
+              limit_vision=False)
+    model = RelModel(classes=ds.ind_to_classes, rel_classes=ds.ind_to_predicates, mode=mode, num_gpus=1, **kw)
+    for _, p in model.detector.named_parameters():
+        p.requires_grad = False
+    keys = set(model.state_dict().keys())
+    assert ('context.decoder_lin.weight' in keys) == (nl_obj == 0)
+    assert ('context.obj_ctx_rnn.weight' in keys) == (nl_obj > 0)
+    assert ('post_emb.weight' in keys) == (nl_edge == 0)
+    assert ('context.edge_ctx_rnn.weight' in keys) == (nl_edge > 0)
+    model.train()
+    blob = make_blob(ds, [0, 1], is_train=True)
+    sd = _to_oracle_sd(model)
+    model.sampler_rs = np.random.RandomState(2)
+    rng.use_host_rng(13)
+    res = model[blob]
+    rng.use_host_rng(None)
+    a = blob[0]
+    out = OM.relmodel_forward(sd, dict(kw, mode=mode), a[0], a[1], 0, a[3], a[4], True, OM.HostRNG(13),
+                              rel_labels=res.rel_labels)
+    np.testing.assert_array_equal(res.obj_preds.numpy(), out['obj_preds'].numpy())
+    np.testing.assert_allclose(res.rm_obj_dists.detach().numpy(), out['rm_obj_dists'].detach().numpy(), atol=2e-4)
+    scale = max(1.0, float(out['rel_dists'].abs().max()))
+    np.testing.assert_allclose(res.rel_dists.detach().numpy(), out['rel_dists'].detach().numpy(), atol=2e-4 * scale)
+    loss = torch.nn.functional.cross_entropy(res.rel_dists, res.rel_labels[:, -1])
+    if mode != 'predcls':
+        loss = loss + torch.nn.functional.cross_entropy(res.rm_obj_dists, res.rm_obj_labels)
+    loss.backward()
+    assert all(torch.isfinite(p.grad).all() for p in model.parameters() if p.requires_grad and p.grad is not None)
