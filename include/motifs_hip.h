@@ -90,6 +90,14 @@ int mh_draw_union_boxes(const float *box_pairs, int n, int P, float offset, int 
 int mh_bbox_overlaps(const float *boxes_a, int na, const float *boxes_b, int nb, float *out,
                      void *stream);
 
+/* Recall@K triplet matching on the device (the step after the path: lib/evaluation/sg_eval.py:243-284,
+ * _compute_pred_matches).  gt_triplets / pred_triplets [n,3] = (subject class, predicate, object class);
+ * gt_boxes / pred_boxes [n,8] = subject box, object box; float64 IoU with the reference's +1 convention.
+ * first_match [G]: smallest matching prediction index (INT_MAX: none); nmatch [P]: matches per prediction. */
+int mh_triplet_match(const int *gt_triplets, const float *gt_boxes, int G, const int *pred_triplets,
+                     const float *pred_boxes, int P, double iou_thresh, int *first_match, int *nmatch,
+                     void *stream);
+
 /* ---------------------------------------------------------------------------------------------
  * FP32 GEMM on MFMA (v_mfma_f32_32x32x2_f32; exact fp32 fma chain).  Replaces the cuBLAS / nn.Linear
  * calls on the path (lib/object_detector.py:80-104, lib/rel_model.py:367-390,

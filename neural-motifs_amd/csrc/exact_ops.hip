@@ -346,6 +346,49 @@ __global__ __launch_bounds__(128) void draw_union_boxes_kernel(const float *__re
 // =====================================================================================
 // fp32 pairwise IoU (torch semantics of lib/fpn/box_utils.py:85-131)
 // =====================================================================================
+// ---------------------------------------------------------------------------------------------------
+// Triplet matching of the Recall@K evaluator on the device (lib/evaluation/sg_eval.py:243-284,
+// _compute_pred_matches): prediction p matches ground-truth relation g when the (subject, predicate, object)
+// labels are equal and both boxes overlap with IoU >= thresh.  IoU is the reference's float64 Cython formula
+// (bbox.pyx:21-61: +1 pixel convention, zero unless both extents are positive) on the float32 boxes promoted exactly.
+// Outputs: first_match[g] = smallest matching p (INT_MAX if none) -> recall@K = #{g : first_match[g] < K} / G;
+//          nmatch[p] = number of ground-truth relations prediction p matches.
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double iou_f64(const float *b, const float *q)
+{
+    const double bx1 = b[0], by1 = b[1], bx2 = b[2], by2 = b[3], qx1 = q[0], qy1 = q[1], qx2 = q[2], qy2 = q[3];
+    const double box_area = (qx2 - qx1 + 1.0) * (qy2 - qy1 + 1.0);
+    const double iw = fmin(bx2, qx2) - fmax(bx1, qx1) + 1.0;
+    if (!(iw > 0.0)) return 0.0;
+    const double ih = fmin(by2, qy2) - fmax(by1, qy1) + 1.0;
+    if (!(ih > 0.0)) return 0.0;
+    const double ua = (bx2 - bx1 + 1.0) * (by2 - by1 + 1.0) + box_area - iw * ih;
+    return iw * ih / ua;
+}
+
+__global__ void triplet_match_kernel(const int *__restrict__ gt_trip, const float *__restrict__ gt_boxes, int G,
+                                     const int *__restrict__ pred_trip, const float *__restrict__ pred_boxes, int P,
+                                     double thresh, int *__restrict__ first_match, int *__restrict__ nmatch)
+{
+    const long long total = (long long)G * P;
+    for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total;
+         idx += (long long)blockDim.x * gridDim.x) {
+        const int g = (int)(idx / P), p = (int)(idx % P);
+        const int *gt = gt_trip + 3 * g, *pt = pred_trip + 3 * p;
+        if (gt[0] != pt[0] || gt[1] != pt[1] || gt[2] != pt[2]) continue;
+        const float *gb = gt_boxes + 8 * g, *pb = pred_boxes + 8 * p;
+        if (iou_f64(pb, gb) >= thresh && iou_f64(pb + 4, gb + 4) >= thresh) {
+            atomicMin(first_match + g, p);
+            atomicAdd(nmatch + p, 1);
+        }
+    }
+}
+
+__global__ void fill_int_kernel(int *p, int n, int v)
+{
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += blockDim.x * gridDim.x) p[i] = v;
+}
+
 __global__ void bbox_overlaps_kernel(const float4 *__restrict__ a, int na, const float4 *__restrict__ b, int nb,
                                      float *__restrict__ out)
 {
@@ -489,6 +532,22 @@ int mh_draw_union_boxes(const float *box_pairs, int n, int P, float offset, int 
     hipLaunchKernelGGL(draw_union_boxes_kernel, dim3(n), dim3(128), (size_t)4 * P * sizeof(float), as_stream(stream),
                        box_pairs, P, offset, channels_last, out);
     return check_launch("draw_union_boxes_kernel");
+}
+
+int mh_triplet_match(const int *gt_triplets, const float *gt_boxes, int G, const int *pred_triplets,
+                     const float *pred_boxes, int P, double iou_thresh, int *first_match, int *nmatch, void *stream)
+{
+    MH_REQUIRE(G >= 0 && P >= 0 && first_match && nmatch);
+    hipStream_t st = as_stream(stream);
+    if (G > 0) hipLaunchKernelGGL(fill_int_kernel, dim3(ceil_div(G, 256)), dim3(256), 0, st, first_match, G, 0x7fffffff);
+    if (P > 0) hipLaunchKernelGGL(fill_int_kernel, dim3(ceil_div(P, 256)), dim3(256), 0, st, nmatch, P, 0);
+    int rc = check_launch("fill_int_kernel");
+    if (rc || G == 0 || P == 0) return rc;
+    MH_REQUIRE(gt_triplets && gt_boxes && pred_triplets && pred_boxes);
+    const long long total = (long long)G * P;
+    hipLaunchKernelGGL(triplet_match_kernel, dim3((unsigned)std::min<long long>((total + 255) / 256, 4096)), dim3(256), 0, st,
+                       gt_triplets, gt_boxes, G, pred_triplets, pred_boxes, P, iou_thresh, first_match, nmatch);
+    return check_launch("triplet_match_kernel");
 }
 
 int mh_bbox_overlaps(const float *boxes_a, int na, const float *boxes_b, int nb, float *out, void *stream)

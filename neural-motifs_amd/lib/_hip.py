@@ -18,7 +18,7 @@ SO_PATH = os.path.join(os.path.dirname(_HERE), 'csrc', 'libmotifs_hip.so')
 SYMBOLS = (
     'mh_version', 'mh_mfma_split', 'mh_last_error',
     'mh_nms_ws_bytes', 'mh_nms', 'mh_nms_batched_ws_bytes', 'mh_nms_batched',
-    'mh_roi_align_fwd', 'mh_roi_align_bwd', 'mh_draw_union_boxes', 'mh_bbox_overlaps',
+    'mh_roi_align_fwd', 'mh_roi_align_bwd', 'mh_draw_union_boxes', 'mh_bbox_overlaps', 'mh_triplet_match',
     'mh_gemm_ws_bytes', 'mh_gemm_auto_splitk', 'mh_gemm_f32',
     'mh_conv3x3_packed_floats', 'mh_conv3x3_pack_weight', 'mh_conv3x3_ws_bytes', 'mh_conv3x3_nhwc',
     'mh_conv3x3_wgrad_ws_bytes', 'mh_conv3x3_wgrad', 'mh_conv_first_nchw', 'mh_maxpool2x2_nhwc',
@@ -220,6 +220,19 @@ def bbox_overlaps(a, b):
     rc = lib().mh_bbox_overlaps(f32(a), a.shape[0], f32(b), b.shape[0], f32(out), stream())
     _check(rc, 'mh_bbox_overlaps')
     return out
+
+
+def triplet_match(gt_triplets, gt_boxes, pred_triplets, pred_boxes, iou_thresh=0.5):
+    """(first_match [G] int32, nmatch [P] int32): see mh_triplet_match"""
+    G, P = gt_triplets.shape[0], pred_triplets.shape[0]
+    dev = gt_boxes.device
+    first = torch.empty(G, dtype=torch.int32, device=dev)
+    nmatch = torch.empty(P, dtype=torch.int32, device=dev)
+    gt_t, pr_t = gt_triplets.to(torch.int32).contiguous(), pred_triplets.to(torch.int32).contiguous()
+    gt_b, pr_b = gt_boxes.float().contiguous(), pred_boxes.float().contiguous()
+    _check(lib().mh_triplet_match(ptr(gt_t), f32(gt_b), G, ptr(pr_t), f32(pr_b), P, ctypes.c_double(iou_thresh),
+                                  ptr(first), ptr(nmatch), stream()), 'mh_triplet_match')
+    return first, nmatch
 
 
 # ----------------------------------------------------------------------------------------------- conv stack

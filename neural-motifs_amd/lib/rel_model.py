@@ -373,7 +373,8 @@ class RelModel(nn.Module):
             bboxes = result.rm_box_priors
         rel_rep = F.softmax(result.rel_dists, dim=1)
         self.last_eval_result = result            # raw logits of the last eval forward (tests / debugging)
-        return filter_dets(bboxes, result.obj_scores, result.obj_preds, rel_inds[:, 1:], rel_rep)
+        return filter_dets(bboxes, result.obj_scores, result.obj_preds, rel_inds[:, 1:], rel_rep,
+                           to_numpy=not getattr(self, 'eval_on_device', False))
 
     def __getitem__(self, batch):
         """`detector[blob]` (reference :549-560); one replica per process, see lib/dist.py for the multi-GPU path"""

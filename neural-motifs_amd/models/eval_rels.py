@@ -46,6 +46,28 @@ if conf.ckpt is not None:
 all_pred_entries = []
 
 
+DEVICE_EVAL = bool(os.environ.get('MOTIFS_DEVICE_EVAL')) and conf.mode in ('sgdet', 'sgcls', 'predcls') and not conf.multi_pred
+device_recalls = {20: [], 50: [], 100: []}
+
+
+def val_batch_device(batch_num, b):
+    """Recall@K without moving the [Nrel,51] score matrix to the host (lib/evaluation/sg_eval_device.py)"""
+    from lib.evaluation.sg_eval_device import recall_at_k
+    boxes_i, objs_i, obj_scores_i, rels_i, pred_scores_i = detector[b]
+    t = lambda a: torch.from_numpy(np.asarray(a))
+    gt_boxes = t(val.gt_boxes[batch_num]).float()
+    if conf.mode == 'predcls':
+        pred_boxes, pred_classes = gt_boxes.cuda(), t(val.gt_classes[batch_num]).cuda()
+    elif conf.mode == 'sgcls':
+        pred_boxes, pred_classes = gt_boxes.cuda(), objs_i
+    else:
+        pred_boxes, pred_classes = boxes_i * (BOX_SCALE / IM_SCALE), objs_i
+    rec, _ = recall_at_k(t(val.relationships[batch_num]), gt_boxes, t(val.gt_classes[batch_num]), rels_i, pred_scores_i,
+                         pred_boxes, pred_classes)
+    for k, v in rec.items():
+        device_recalls[k].append(v)
+
+
 def val_batch(batch_num, b, evaluator):
     det_res = [detector[b]]
     for i, (boxes_i, objs_i, obj_scores_i, rels_i, pred_scores_i) in enumerate(det_res):
@@ -71,10 +93,19 @@ if conf.cache is not None and os.path.exists(conf.cache):
     evaluator[conf.mode].print_stats()
 else:
     detector.eval()
+    detector.eval_on_device = DEVICE_EVAL
     with torch.no_grad():
         for val_b, batch in enumerate(tqdm(val_loader)):
-            val_batch(val_b, batch, evaluator)
-    evaluator[conf.mode].print_stats()
+            if DEVICE_EVAL:
+                val_batch_device(val_b, batch)
+            else:
+                val_batch(val_b, batch, evaluator)
+    if DEVICE_EVAL:
+        print('======================' + conf.mode + ' (device evaluator)============================')
+        for k, v in device_recalls.items():
+            print('R@%i: %f' % (k, float(np.mean(v)) if v else 0.0))
+    else:
+        evaluator[conf.mode].print_stats()
     if conf.cache is not None:
         with open(conf.cache, 'wb') as f:
             pkl.dump(all_pred_entries, f)

@@ -254,3 +254,37 @@ def test_resnet101_detector_branch_parity():
             for k in ('features.bn1.running_mean', 'features.layer3.22.bn3.running_var', 'compress.2.running_mean'):
                 rel_close(det.state_dict()[k].cpu().numpy(), sd['detector.' + k].numpy(), what=k)
         det.load_state_dict({k[len('detector.'):]: v for k, v in sd_cpu.items()})
+
+
+def test_on_device_evaluation_equals_the_host_evaluator(world):
+    """RelModel.eval_on_device: the eval forward hands back device tensors and Recall@K is computed by
+    lib/evaluation/sg_eval_device.py (mh_triplet_match) -- same recalls as the numpy evaluator on the same forward"""
+    from config import BOX_SCALE, IM_SCALE
+    from lib.evaluation.sg_eval import BasicSceneGraphEvaluator
+    from lib.evaluation.sg_eval_device import recall_at_k
+    ds, model, sd_cpu, make_blob = world
+    model.load_state_dict({k: v.clone() for k, v in sd_cpu.items()})
+    model.eval()
+    for mode in ('sgcls', 'predcls'):
+        model.mode = model.context.mode = mode
+        for idx in (0, 1):
+            blob = make_blob(ds, [idx], is_train=False)
+            with torch.no_grad():
+                model.eval_on_device = False
+                boxes, classes, obj_scores, rels, scores = model[blob]
+                model.eval_on_device = True
+                dboxes, dclasses, dscores, drels, dpred = model[blob]
+            model.eval_on_device = False
+            assert torch.is_tensor(drels) and drels.is_cuda
+            ev = BasicSceneGraphEvaluator.all_modes()
+            ev[mode].evaluate_scene_graph_entry(
+                dict(gt_classes=ds.gt_classes[idx], gt_relations=ds.relationships[idx], gt_boxes=ds.gt_boxes[idx]),
+                dict(pred_boxes=boxes * BOX_SCALE / IM_SCALE, pred_classes=classes, pred_rel_inds=rels,
+                     obj_scores=obj_scores, rel_scores=scores))
+            t = lambda a: torch.from_numpy(np.asarray(a))
+            gtb = t(ds.gt_boxes[idx]).float()
+            pred_classes = t(ds.gt_classes[idx]).cuda() if mode == 'predcls' else dclasses
+            rec, _ = recall_at_k(t(ds.relationships[idx]), gtb, t(ds.gt_classes[idx]), drels, dpred, gtb.cuda(), pred_classes)
+            for k in (20, 50, 100):
+                assert rec[k] == ev[mode].result_dict[mode + '_recall'][k][0], (mode, idx, k)
+    model.mode = model.context.mode = 'sgcls'

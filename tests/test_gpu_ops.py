@@ -475,3 +475,32 @@ def test_fused_clip_sgd_matches_torch(hip):
         new_opt.step(max_norm=0.0)
         for p, q in zip(ref_p, new_p):
             np.testing.assert_allclose(q.detach().cpu().numpy(), p.detach().cpu().numpy(), rtol=2e-5, atol=2e-6)
+
+
+def test_device_recall_matches_the_reference_evaluator(hip, golden):
+    """lib/evaluation/sg_eval_device.py + mh_triplet_match vs the host evaluator (lib/evaluation/sg_eval.py, itself
+    pinned to the reference's BasicSceneGraphEvaluator by tests/golden/sg_eval.npz): Recall@20/50/100 and matches per
+    prediction in sgdet mode (boxes and labels both matter).  Model boxes are float32, so the stored float64 prediction
+    boxes are rounded to float32 for BOTH sides."""
+    from lib.evaluation.sg_eval import evaluate_from_dict
+    from lib.evaluation.sg_eval_device import recall_at_k
+    g = golden('sg_eval')
+    cases = sorted({k.split('_')[0] for k in g if k.startswith('c')})
+    assert len(cases) >= 3
+    nonzero = 0
+    for c in cases:
+        a = lambda name: np.asarray(g[c + '_' + name])
+        pred_boxes = a('pred_boxes').astype(np.float32)
+        result = {'sgdet_recall': {20: [], 50: [], 100: []}}
+        pred_to_gt, _, _ = evaluate_from_dict(
+            {'gt_relations': a('gt_relations'), 'gt_boxes': a('gt_boxes'), 'gt_classes': a('gt_classes')},
+            {'pred_rel_inds': a('pred_rel_inds'), 'rel_scores': a('rel_scores'), 'pred_boxes': pred_boxes.astype(np.float64),
+             'pred_classes': a('pred_classes'), 'obj_scores': a('obj_scores')}, 'sgdet', result)
+        t = lambda x: torch.from_numpy(np.asarray(x)).cuda()
+        rec, nmatch = recall_at_k(t(a('gt_relations')), t(a('gt_boxes')), t(a('gt_classes')), t(a('pred_rel_inds')),
+                                  t(a('rel_scores')).float(), t(pred_boxes), t(a('pred_classes')))
+        for k in (20, 50, 100):
+            assert rec[k] == result['sgdet_recall'][k][0], (c, k)
+        np.testing.assert_array_equal(nmatch.cpu().numpy(), np.array([len(m) for m in pred_to_gt]))
+        nonzero += int(nmatch.sum())
+    assert nonzero > 0
