@@ -378,6 +378,24 @@ def main():
         vg['gi_first4_rels'] = np.concatenate(rels[:4], 0)
     out['vg_formats'] = vg
 
+    # ---------------------------------------------------------------- GloVe text format (lib/word_vectors.py:49-113)
+    wvm = importlib.import_module('lib.word_vectors')
+    with tempfile.TemporaryDirectory() as td:
+        vocab = ['person', 'dog', 'fire', 'hydrant', 'table', 'of', 'on', 'tennis', 'racket', 'caf\u00e9']
+        rows = rs.randn(len(vocab), 6)
+        with open(os.path.join(td, 'glove.tiny.6d.txt'), 'wb') as f:
+            for w_, r_ in zip(vocab, rows):
+                f.write(w_.encode('utf-8') + b' ' + b' '.join(('%.5f' % v).encode() for v in r_) + b'\n')
+        names = ['__background__', 'person', 'fire hydrant', 'tennis racket', 'on', 'zebra crossing', 'dog']
+        torch.manual_seed(0)
+        vec = wvm.obj_edge_vectors(names, wv_type='glove.tiny', wv_dir=td, wv_dim=6)
+        wv_dict, wv_arr, wv_size = wvm.load_word_vectors(td, 'glove.tiny', 6)
+        out['glove'] = dict(txt=np.frombuffer(open(os.path.join(td, 'glove.tiny.6d.txt'), 'rb').read(), dtype=np.uint8),
+                            names=np.array(names), vectors=vec.numpy(), arr=wv_arr.numpy(),
+                            tokens=np.array([t for t, _ in sorted(wv_dict.items(), key=lambda kv: kv[1])]),
+                            known=np.array([1 if (n in wv_dict or sorted(n.split(' '), key=len, reverse=True)[0] in wv_dict)
+                                            else 0 for n in names]))
+
     for name, d in out.items():
         path = os.path.join(HERE, name + '.npz')
         np.savez_compressed(path, **{k: np.asarray(v) for k, v in d.items()})
