@@ -53,6 +53,22 @@ def test_argument_validation_needs_no_device(so_path):
     # bad arguments are reported, never abort()/exit()
     rc = lib.mh_gemm_f32(0, 0, 4, 4, 4, None, 4, None, 4, None, 4, None, 0, 0, 1, None, ctypes.c_size_t(0), None)
     assert rc == -1 and b'bad argument' in lib.mh_last_error()
+    # size queries and validation of the entry points added for the widened scope (no kernel is launched)
+    for name in ('mh_conv3x3_packed_floats', 'mh_conv3x3_wgrad_ws_bytes', 'mh_hwcell_seq_ws_bytes', 'mh_hwlstm_fwd_ws_bytes'):
+        getattr(lib, name).restype = ctypes.c_size_t
+    assert lib.mh_mfma_split() in (0, 3, 6)
+    if lib.mh_mfma_split():
+        assert lib.mh_conv3x3_packed_floats(128, 64) == 9 * 128 * (64 // 16) * 24     # bf16 planes: 1.5 x the fp32 weights
+    else:
+        assert lib.mh_conv3x3_packed_floats(128, 64) == 9 * 128 * 64
+    assert lib.mh_conv3x3_wgrad_ws_bytes(6, 37, 37, 512, 512) >= 6 * 37 * 37 * 2          # at least the tap masks
+    assert lib.mh_hwcell_seq_ws_bytes() >= 4
+    assert lib.mh_hwlstm_fwd_ws_bytes(4424, 512, 6, 2, 20) > 20 * 6 * 6 * 512 * 4
+    assert lib.mh_conv3x3_wgrad(None, None, 1, 8, 8, 16, 16, None, None, ctypes.c_size_t(0), None) in (-1, -2)
+    assert lib.mh_triplet_match(None, None, 3, None, None, 3, ctypes.c_double(0.5), None, None, None) == -1
+    assert lib.mh_hwcell_seq_fwd(513, 4, 3, None, None, None, None, None, None, None, None, None, ctypes.c_size_t(0), None) == -1
+    assert lib.mh_bn_apply_nhwc(None, ctypes.c_longlong(8), 16, None, None, None, None, None, 0, None, None) == -1
+    assert lib.mh_maxpool2x2_bwd_nhwc(None, None, 1, 4, 4, 8, None, None) == -1
 
 
 @pytest.mark.skipif(torch.cuda.is_available(), reason='checks the no-GPU failure mode')
