@@ -21,9 +21,12 @@ from lib.evaluation.sg_eval import BasicSceneGraphEvaluator
 from lib.pytorch_misc import optimistic_restore
 
 conf = ModelConfig()
-if conf.model != 'motifnet':
-    raise ValueError('only the MotifNet model family is built')
-from lib.rel_model import RelModel
+if conf.model == 'motifnet':
+    from lib.rel_model import RelModel
+elif conf.model == 'stanford':              # message-passing baseline (reference models/train_rels.py:22-27)
+    from lib.rel_model_stanford import RelModelStanford as RelModel
+else:
+    raise ValueError('unknown model %r' % conf.model)
 
 train, val, test = VG.splits(num_val_im=conf.val_size, filter_duplicate_rels=True, use_proposals=conf.use_proposals,
                              filter_non_overlap=conf.mode == 'sgdet', seed=conf.seed)

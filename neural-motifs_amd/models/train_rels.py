@@ -28,9 +28,12 @@ from lib.optim import FusedClipSGD
 from lib.pytorch_misc import optimistic_restore, clip_grad_norm, print_para
 
 conf = ModelConfig()
-if conf.model != 'motifnet':
-    raise ValueError('only the MotifNet model family is built (rel_model_stanford is out of scope)')
-from lib.rel_model import RelModel
+if conf.model == 'motifnet':
+    from lib.rel_model import RelModel
+elif conf.model == 'stanford':              # message-passing baseline (reference models/train_rels.py:22-27)
+    from lib.rel_model_stanford import RelModelStanford as RelModel
+else:
+    raise ValueError('unknown model %r' % conf.model)
 
 rank, world, local_rank = D.init_from_env()
 if world > 1 and conf.num_gpus != world:

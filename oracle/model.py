@@ -475,3 +475,54 @@ def relmodel_forward(sd, cfg, x, im_sizes, image_offset, gt_boxes, gt_classes, t
     if cfg.get('return_logits', False):
         return out, dict(rel_dists=rel_dists, rm_obj_dists=rm_obj_dists, rel_inds=rel_inds)
     return out
+
+
+# --------------------------------------------------------------------------- message-passing baseline (§8f rank 4)
+def _gru_cell(sd, prefix, x, h):
+    """nn.GRUCell: r, z, n gate order"""
+    H = h.size(1)
+    gi = F.linear(x, sd[prefix + 'weight_ih'], sd[prefix + 'bias_ih'])
+    gh = F.linear(h, sd[prefix + 'weight_hh'], sd[prefix + 'bias_hh'])
+    r = torch.sigmoid(gi[:, :H] + gh[:, :H])
+    z = torch.sigmoid(gi[:, H:2 * H] + gh[:, H:2 * H])
+    n = torch.tanh(gi[:, 2 * H:] + r * gh[:, 2 * H:])
+    return (1 - z) * n + z * h
+
+
+def stanford_message_pass(sd, rel_rep, obj_rep, rel_inds, size=512):
+    """RelModelStanford.message_pass (lib/rel_model_stanford.py:59-108)"""
+    def gate(name, a, b):
+        return torch.sigmoid(F.linear(torch.cat((a, b), 1), sd[name + '.0.weight'], sd[name + '.0.bias']))
+    vert = [_gru_cell(sd, 'node_gru.', obj_rep, torch.zeros(obj_rep.size(0), size))]
+    edge = [_gru_cell(sd, 'edge_gru.', rel_rep, torch.zeros(rel_rep.size(0), size))]
+    for i in range(3):
+        sv, ov = vert[i][rel_inds[:, 0]], vert[i][rel_inds[:, 1]]
+        ws = gate('sub_vert_w_fc', sv, edge[i]) * sv
+        wo = gate('obj_vert_w_fc', ov, edge[i]) * ov
+        edge.append(_gru_cell(sd, 'edge_gru.', ws + wo, edge[i]))
+        pre_out = gate('out_edge_w_fc', sv, edge[i]) * edge[i]
+        pre_in = gate('in_edge_w_fc', ov, edge[i]) * edge[i]
+        ctx = torch.zeros_like(vert[i])
+        ctx.index_add_(0, rel_inds[:, 0], pre_out)
+        ctx.index_add_(0, rel_inds[:, 1], pre_in)
+        vert.append(_gru_cell(sd, 'node_gru.', ctx, vert[i]))
+    return (F.linear(vert[-1], sd['obj_fc.weight'], sd['obj_fc.bias']),
+            F.linear(edge[-1], sd['rel_fc.weight'], sd['rel_fc.bias']))
+
+
+def stanford_forward_train(sd, cfg, x, im_sizes, image_offset, gt_boxes, gt_classes, rng, rel_labels):
+    """RelModelStanford.forward in training (gtbox modes): detector -> union features -> unary projections ->
+    message passing (lib/rel_model_stanford.py:110-156)"""
+    det = detector_forward(sd, cfg, x, im_sizes, image_offset, gt_boxes, gt_classes, True, rng, rel_labels=rel_labels)
+    fmap = det['fmap']
+    im_inds = det['im_inds'] - image_offset
+    boxes = det['rm_box_priors']
+    rel_inds = get_rel_inds(cfg, det['rel_labels'], im_inds, boxes, True)
+    rois = torch.cat((im_inds[:, None].float(), boxes), 1)
+    ub = union_boxes_feats(sd, fmap, rois, rel_inds[:, 1:], True)
+    vr = vgg_classifier(sd, ub.view(ub.size(0), -1), 'roi_fmap.1.', True, rng, use_dropout=False, use_relu=False)
+    obj_fmap = vgg_classifier(sd, roi_align(fmap, rois).view(rois.size(0), -1), 'roi_fmap_obj.', True, rng)
+    rel_rep = F.relu(F.linear(vr, sd['edge_unary.weight'], sd['edge_unary.bias']))
+    obj_rep = F.linear(obj_fmap, sd['obj_unary.weight'], sd['obj_unary.bias'])
+    obj_dists, rel_dists = stanford_message_pass(sd, rel_rep, obj_rep, rel_inds[:, 1:])
+    return dict(rm_obj_dists=obj_dists, rel_dists=rel_dists, rel_inds=rel_inds, rm_obj_labels=det['rm_obj_labels'])

@@ -197,3 +197,48 @@ def test_baseline_context_variants_match_the_oracle(shim, nl_obj, nl_edge, mode)
         loss = loss + torch.nn.functional.cross_entropy(res.rm_obj_dists, res.rm_obj_labels)
     loss.backward()
     assert all(torch.isfinite(p.grad).all() for p in model.parameters() if p.requires_grad and p.grad is not None)
+
+
+def test_message_passing_baseline_matches_the_oracle(shim):
+    """lib/rel_model_stanford.py (reference lib/rel_model_stanford.py:20-156): GRU message passing between object nodes
+    and relation edges on the product ops vs the oracle restatement; checkpoint key names are nn.GRUCell's"""
+    from dataloaders.synthetic import SyntheticVG, make_blob
+    from lib import rng
+    from lib.rel_model_stanford import RelModelStanford
+    from oracle import model as OM
+    torch.manual_seed(2)
+    ds = SyntheticVG(num_images=2, seed=6, n_boxes=5, n_rels=6, im_size=224)
+    model = RelModelStanford(classes=ds.ind_to_classes, rel_classes=ds.ind_to_predicates, mode='sgcls', num_gpus=1)
+    for _, p in model.detector.named_parameters():
+        p.requires_grad = False
+    keys = set(model.state_dict().keys())
+    for k in ('edge_gru.weight_ih', 'edge_gru.bias_hh', 'node_gru.weight_hh', 'sub_vert_w_fc.0.weight', 'in_edge_w_fc.0.bias',
+              'obj_unary.weight', 'edge_unary.bias', 'rel_fc.weight', 'obj_fc.bias'):
+        assert k in keys, k
+    assert not any(k.startswith(('context.', 'post_lstm.', 'post_emb.')) for k in keys)
+    assert tuple(model.edge_gru.weight_ih.shape) == (1536, 512) and tuple(model.sub_vert_w_fc[0].weight.shape) == (1, 1024)
+    model.train()
+    blob = make_blob(ds, [0, 1], is_train=True)
+    sd = _to_oracle_sd(model)
+    model.sampler_rs = np.random.RandomState(3)
+    rng.use_host_rng(21)
+    res = model[blob]
+    rng.use_host_rng(None)
+    a = blob[0]
+    cfg = dict(mode='sgcls', require_overlap=False)
+    out = OM.stanford_forward_train(sd, cfg, a[0], a[1], 0, a[3], a[4], OM.HostRNG(21), res.rel_labels)
+    assert res.rm_obj_dists.shape == (res.rm_obj_labels.shape[0], 151) and res.rel_dists.shape[1] == 51
+    np.testing.assert_allclose(res.rm_obj_dists.detach().numpy(), out['rm_obj_dists'].detach().numpy(), atol=2e-4)
+    np.testing.assert_allclose(res.rel_dists.detach().numpy(), out['rel_dists'].detach().numpy(), atol=2e-4)
+    loss = torch.nn.functional.cross_entropy(res.rm_obj_dists, res.rm_obj_labels) + \
+        torch.nn.functional.cross_entropy(res.rel_dists, res.rel_labels[:, -1])
+    loss.backward()
+    unused = [n for n, p in model.named_parameters() if p.requires_grad and p.grad is None]
+    # inherited from RelModel and never used by this model -- in the reference as well (it only deletes context,
+    # post_lstm and post_emb, rel_model_stanford.py:39-41)
+    assert unused == ['rel_compress.weight', 'rel_compress.bias', 'freq_bias.obj_baseline.weight'], unused
+    # eval returns the 5-tuple of the reference's contract
+    model.eval()
+    with torch.no_grad():
+        boxes, classes, obj_scores, rels, scores = model[make_blob(ds, [0], is_train=False)]
+    assert boxes.shape[1] == 4 and rels.shape[1] == 2 and scores.shape[1] == 51 and classes.min() >= 1
