@@ -178,70 +178,72 @@ def load_image_filenames(image_file, image_dir=VG_IMAGES, expected=108073):
     return fns
 
 
+def _images_of_split(arrays, mode, num_im, num_val_im, need_rels):
+    """indices of the images a split uses: split code (0 = train+val, 2 = test), must have boxes (and relations when
+    `need_rels`), optional truncation, then the first `num_val_im` of the train pool form 'val'"""
+    usable = (arrays['split'][:] == (2 if mode == 'test' else 0)) & (arrays['img_to_first_box'][:] >= 0)
+    if need_rels:
+        usable &= arrays['img_to_first_rel'][:] >= 0
+    ids = np.flatnonzero(usable)
+    if num_im > -1:
+        ids = ids[:num_im]
+    if num_val_im > 0 and mode == 'val':
+        ids = ids[:num_val_im]
+    elif num_val_im > 0 and mode == 'train':
+        ids = ids[num_val_im:]
+    return ids
+
+
+def _corner_boxes(center_boxes):
+    """(xc, yc, w, h) -> (x1, y1, x2, y2), in the container's integer arithmetic like the reference"""
+    assert np.all(center_boxes[:, :2] >= 0) and np.all(center_boxes[:, 2:] > 0)
+    out = center_boxes
+    out[:, :2] = out[:, :2] - out[:, 2:] / 2
+    out[:, 2:] = out[:, :2] + out[:, 2:]
+    return out
+
+
 def load_graphs(graphs_file, mode='train', num_im=-1, num_val_im=0, filter_empty_rels=True, filter_non_overlap=False):
-    """GT boxes / classes / relations of one split (reference :264-361).
-    :return: split_mask, boxes (list of [n,4] x1,y1,x2,y2 at BOX_SCALE), gt_classes (list of [n]),
-             relationships (list of [r,3]: box_ind_1, box_ind_2, predicate)"""
+    """GT boxes / classes / relations of one split from the VG-SGG container (behaviour of the reference's
+    dataloaders/visual_genome.py:264-361, pinned by tests/test_vg_loader.py).
+    :return: split_mask [num_images] bool, boxes (list of [n,4] x1,y1,x2,y2 at BOX_SCALE), gt_classes (list of [n]),
+             relationships (list of [r,3]: box_ind_1, box_ind_2, predicate; box indices local to the image)"""
     if mode not in ('train', 'val', 'test'):
         raise ValueError('{} invalid'.format(mode))
-    roi = _open_arrays(graphs_file)
-    data_split = roi['split'][:]
-    split = 2 if mode == 'test' else 0
-    split_mask = data_split == split
-    split_mask &= roi['img_to_first_box'][:] >= 0
-    if filter_empty_rels:
-        split_mask &= roi['img_to_first_rel'][:] >= 0
-    image_index = np.where(split_mask)[0]
-    if num_im > -1:
-        image_index = image_index[:num_im]
-    if num_val_im > 0:
-        if mode == 'val':
-            image_index = image_index[:num_val_im]
-        elif mode == 'train':
-            image_index = image_index[num_val_im:]
-    split_mask = np.zeros_like(data_split).astype(bool)
-    split_mask[image_index] = True
+    arrays = _open_arrays(graphs_file)
+    ids = _images_of_split(arrays, mode, num_im, num_val_im, filter_empty_rels)
+    split_mask = np.zeros(arrays['split'][:].shape[0], dtype=bool)
+    split_mask[ids] = True
 
-    all_labels = roi['labels'][:, 0]
-    all_boxes = roi['boxes_{}'.format(BOX_SCALE)][:]
-    assert np.all(all_boxes[:, :2] >= 0)
-    assert np.all(all_boxes[:, 2:] > 0)
-    all_boxes[:, :2] = all_boxes[:, :2] - all_boxes[:, 2:] / 2          # (xc, yc, w, h) -> (x1, y1, x2, y2)
-    all_boxes[:, 2:] = all_boxes[:, :2] + all_boxes[:, 2:]
-    im_to_first_box = roi['img_to_first_box'][:][split_mask]
-    im_to_last_box = roi['img_to_last_box'][:][split_mask]
-    im_to_first_rel = roi['img_to_first_rel'][:][split_mask]
-    im_to_last_rel = roi['img_to_last_rel'][:][split_mask]
-    _relations = roi['relationships'][:]
-    _relation_predicates = roi['predicates'][:, 0]
-    assert im_to_first_rel.shape[0] == im_to_last_rel.shape[0]
-    assert _relations.shape[0] == _relation_predicates.shape[0]
+    labels = arrays['labels'][:, 0]
+    corners = _corner_boxes(arrays['boxes_{}'.format(BOX_SCALE)][:])
+    pairs = arrays['relationships'][:]
+    predicates = arrays['predicates'][:, 0]
+    assert pairs.shape[0] == predicates.shape[0]
+    box_lo, box_hi = arrays['img_to_first_box'][:][ids], arrays['img_to_last_box'][:][ids]
+    rel_lo, rel_hi = arrays['img_to_first_rel'][:][ids], arrays['img_to_last_rel'][:][ids]
 
     boxes, gt_classes, relationships = [], [], []
-    for i in range(len(image_index)):
-        boxes_i = all_boxes[im_to_first_box[i]:im_to_last_box[i] + 1, :]
-        gt_classes_i = all_labels[im_to_first_box[i]:im_to_last_box[i] + 1]
-        if im_to_first_rel[i] >= 0:
-            predicates = _relation_predicates[im_to_first_rel[i]:im_to_last_rel[i] + 1]
-            obj_idx = _relations[im_to_first_rel[i]:im_to_last_rel[i] + 1] - im_to_first_box[i]
-            assert np.all(obj_idx >= 0)
-            assert np.all(obj_idx < boxes_i.shape[0])
-            rels = np.column_stack((obj_idx, predicates))
+    for k, image in enumerate(ids):
+        b0, b1 = box_lo[k], box_hi[k] + 1
+        image_boxes = corners[b0:b1, :]
+        if rel_lo[k] >= 0:
+            local = pairs[rel_lo[k]:rel_hi[k] + 1] - b0                 # global box ids -> ids inside this image
+            assert np.all(local >= 0) and np.all(local < image_boxes.shape[0])
+            rels = np.column_stack((local, predicates[rel_lo[k]:rel_hi[k] + 1]))
         else:
             assert not filter_empty_rels
             rels = np.zeros((0, 3), dtype=np.int32)
-        if filter_non_overlap:
+        if filter_non_overlap:                                           # training on SGDet: keep touching pairs only
             assert mode == 'train'
-            inters = bbox_overlaps(boxes_i, boxes_i)
-            rel_overs = inters[rels[:, 0], rels[:, 1]]
-            inc = np.where(rel_overs > 0.0)[0]
-            if inc.size > 0:
-                rels = rels[inc]
-            else:
-                split_mask[image_index[i]] = 0
+            iou = bbox_overlaps(image_boxes, image_boxes)
+            touching = np.flatnonzero(iou[rels[:, 0], rels[:, 1]] > 0.0)
+            if touching.size == 0:
+                split_mask[image] = False                                # an image without any such pair is dropped
                 continue
-        boxes.append(boxes_i)
-        gt_classes.append(gt_classes_i)
+            rels = rels[touching]
+        boxes.append(image_boxes)
+        gt_classes.append(labels[b0:b1])
         relationships.append(rels)
     return split_mask, boxes, gt_classes, relationships
 
