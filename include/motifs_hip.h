@@ -36,6 +36,9 @@ int mh_version(void);
  * 6 = bf16x6 (exact 3-way bf16 split of both operands, six bf16 MFMAs, fp32 accumulate; default),
  * 0 = f32-input MFMA (exact fp32 fma chain), 3 = bf16x3 (2^-17 products; experiments only). */
 int mh_mfma_split(void);
+/* 1 when the bf16 split rounds to nearest even (build knob MH_SPLIT_RN=1: dropped cross terms <= 2^-24|ab|, zero mean),
+ * 0 for the default truncation split (<= 2^-21|ab|, typically 2^-24.5, towards zero) or the f32-MFMA build */
+int mh_split_rne(void);
 /* name of the last kernel-launch error on this thread (for diagnostics), or "" */
 const char *mh_last_error(void);
 
@@ -99,7 +102,8 @@ int mh_triplet_match(const int *gt_triplets, const float *gt_boxes, int G, const
                      void *stream);
 
 /* ---------------------------------------------------------------------------------------------
- * FP32 GEMM on MFMA (v_mfma_f32_32x32x2_f32; exact fp32 fma chain).  Replaces the cuBLAS / nn.Linear
+ * FP32 GEMM on MFMA (bf16x6 on v_mfma_f32_32x32x16_bf16 by default, v_mfma_f32_32x32x2_f32 in the MH_MFMA_SPLIT=0
+ * build; see mh_mfma_split).  Replaces the cuBLAS / nn.Linear
  * calls on the path (lib/object_detector.py:80-104, lib/rel_model.py:367-390,
  * highway_lstm_kernel.cu:441-465).  Row-major:
  *     C[M,N] = epi( opA(A)[M,K] * opB(B)[K,N] + bias[N] )   (+ C if accumulate)

@@ -27,31 +27,37 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force=False, verbose=False):
+def build(force=False, verbose=False, out_dir=None):
+    """out_dir (or $MH_OUT): where objects and the .so go -- default next to the sources.  A variant build (another
+    MH_MFMA_SPLIT / MH_SPLIT_RN) belongs in its own directory, e.g. csrc/_variants/rn, and is loaded with
+    MOTIFS_HIP_LIB=<that .so> (lib/_hip.py)."""
+    out_dir = os.path.abspath(out_dir or os.environ.get('MH_OUT') or HERE)
+    os.makedirs(out_dir, exist_ok=True)
+    so = os.path.join(out_dir, os.path.basename(SO))
     hdrs = [os.path.join(HERE, h) for h in HEADERS]
     objs = []
     for src in SOURCES:
         s = os.path.join(HERE, src)
-        o = os.path.join(HERE, src.replace('.hip', '.o'))
+        o = os.path.join(out_dir, src.replace('.hip', '.o'))
         objs.append(o)
         if force or _stale(o, [s] + hdrs + [os.path.abspath(__file__)]):
             cmd = [HIPCC, '--offload-arch=' + ARCH, '-O3', '-std=c++17', '-fPIC', '-c', s, '-o', o,
                    '-Wall', '-Wno-unused-function']
             if src in EXACT:
                 cmd += ['-ffp-contract=off']
-            for knob in ('MH_MINW', 'MH_MFMA_SPLIT', 'MH_BAR_SLEEP'):
+            for knob in ('MH_MINW', 'MH_MFMA_SPLIT', 'MH_SPLIT_RN', 'MH_BAR_SLEEP'):
                 if os.environ.get(knob):
                     cmd += ['-D%s=%s' % (knob, os.environ[knob])]
             if verbose:
                 cmd += ['-Rpass-analysis=kernel-resource-usage']
                 print(' '.join(cmd))
             subprocess.check_call(cmd)
-    if force or _stale(SO, objs):
-        cmd = [HIPCC, '--offload-arch=' + ARCH, '-shared', '-fPIC', '-o', SO] + objs
+    if force or _stale(so, objs):
+        cmd = [HIPCC, '--offload-arch=' + ARCH, '-shared', '-fPIC', '-o', so] + objs
         if verbose:
             print(' '.join(cmd))
         subprocess.check_call(cmd)
-    return SO
+    return so
 
 
 if __name__ == '__main__':

@@ -228,6 +228,7 @@ using namespace mh;
 extern "C" {
 
 int mh_mfma_split(void) { return MH_MFMA_SPLIT; }
+int mh_split_rne(void) { return (MH_MFMA_SPLIT != 0 && MH_SPLIT_RN) ? 1 : 0; }
 
 int mh_gemm_auto_splitk(int M, int N, int K) { return (M > 0 && N > 0 && K > 0) ? choose_splitk(M, N, K) : 1; }
 

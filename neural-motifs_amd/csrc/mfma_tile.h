@@ -34,6 +34,9 @@
 #define MH_MFMA_SPLIT 6   /* 6: bf16x6 split (fp32-accurate, default); 0: f32-input MFMA; 3: bf16x3 (2^-17, tests only) */
 #endif
 
+#ifndef MH_SPLIT_RN
+#define MH_SPLIT_RN 0    /* 1: the bf16 split rounds to nearest even instead of truncating (see split_pair) */
+#endif
 #define MH_PLANES (MH_MFMA_SPLIT != 0)   /* bf16 builds keep the operands as bf16 planes in LDS, split once at staging */
 
 namespace mh {
@@ -147,11 +150,11 @@ __device__ __forceinline__ void mma_ktile_f32(const float *__restrict__ As, cons
 // gfx950's v_mfma_f32_32x32x16_bf16 retires 16 k per 32 cycles, the f32-input MFMA 2 k per 64 cycles: 16x the rate.
 // An fp32 number splits EXACTLY into three bf16 terms by truncation, a = a1 + a2 + a3 with 8 mantissa bits each
 // (a1 = top 16 bits of a; r = a - a1 is exact; a2 = top 16 bits of r; a3 = r - a2 has <= 8 significant bits), a
-// bf16 x bf16 product is exact in fp32, and the MFMA accumulates in fp32.  Keeping the six cross terms down to
-// 2^-24 relative magnitude,
-//     a*b = a1b1 + (a1b2 + a2b1) + (a1b3 + a3b1 + a2b2) + O(2^-27 |ab|),
-// gives products accurate to fp32 rounding at 6/16 of the f32-MFMA matrix-core time (MH_MFMA_SPLIT == 6); the first
-// three terms alone (== 3) are accurate to 2^-17.  A lane's operand for the K=16 instruction is 8 consecutive k of
+// bf16 x bf16 product is exact in fp32, and the MFMA accumulates in fp32.  Keeping the six largest cross terms,
+//     a*b = a1b1 + (a1b2 + a2b1) + (a1b3 + a3b1 + a2b2) + [a2b3 + a3b2 + a3b3 dropped: <= 2^-21 |ab|, 2^-24.5 typical],
+// gives products as accurate as the f32-input MFMA's (measured: DESIGN.md 3.1, profiles/r01_split_check.jsonl) at
+// 6/16 of its matrix-core time (MH_MFMA_SPLIT == 6); the first three terms alone (== 3) are accurate to 2^-17.
+// MH_SPLIT_RN=1 swaps truncation for round-to-nearest (dropped part <= 2^-24 |ab|, zero mean; see split_pair).  A lane's operand for the K=16 instruction is 8 consecutive k of
 // its row (k = 8g .. 8g+7, g = lane >> 5).  The split is done ONCE per element when a k-tile is staged (below).
 // ---------------------------------------------------------------------------------------------------------------
 typedef short bf16x8 __attribute__((ext_vector_type(8)));
@@ -300,7 +303,33 @@ __device__ __forceinline__ void store_wm(const Stage<WD> &s, float *tile, int ti
 // ---------------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ int plane_swz(int r) { return (r >> 3) & 1; }
 
-// (x0, x1) = values at k even / k odd -> packed dwords of the hi / mid / lo planes (exact truncation split)
+// (x0, x1) = values at k even / k odd -> packed dwords of the hi / mid / lo planes.  Both variants split EXACTLY
+// (hi + mid + lo == x, each term a bf16); they differ in the size of the three cross terms the inner loop drops
+// (mid*lo, lo*mid, lo*lo; tests/test_bf16x6_math.py derives the figures):
+//   MH_SPLIT_RN 0 (default): truncation.  |mid| < 2^-7|x|, |lo| < 2^-15|x|: dropped part <= 2^-21|ab|, typically
+//       2^-24.5|ab|, always towards zero.
+//   MH_SPLIT_RN 1: round-to-nearest-even via v_cvt_pk_bf16_f32.  |mid| <= 2^-8|x|, |lo| <= 2^-16|x|: dropped part
+//       <= 2^-24|ab|, typically 2^-28|ab|, zero mean; same VALU count.  (x within half a bf16 ulp of FLT_MAX rounds
+//       to inf, which truncation does not.)
+#if MH_SPLIT_RN
+typedef __bf16 bf16pair_t __attribute__((ext_vector_type(2)));
+typedef float f32pair_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned pack_rne(float lo16, float hi16)
+{
+    const f32pair_t v = {lo16, hi16};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16pair_t));
+}
+__device__ __forceinline__ void split_pair(float x0, float x1, unsigned &ph, unsigned &pm, unsigned &pl)
+{
+    ph = pack_rne(x0, x1);
+    const float r0 = x0 - __builtin_bit_cast(float, ph << 16);
+    const float r1 = x1 - __builtin_bit_cast(float, ph & 0xffff0000u);
+    pm = pack_rne(r0, r1);
+    const float s0 = r0 - __builtin_bit_cast(float, pm << 16);
+    const float s1 = r1 - __builtin_bit_cast(float, pm & 0xffff0000u);
+    pl = pack_rne(s0, s1);                     // exact: the remainder has at most 8 significant bits
+}
+#else
 __device__ __forceinline__ void split_pair(float x0, float x1, unsigned &ph, unsigned &pm, unsigned &pl)
 {
     constexpr unsigned kTop = 0x07060302u;   // v_perm_b32: {S0.hi16, S1.hi16}
@@ -314,6 +343,7 @@ __device__ __forceinline__ void split_pair(float x0, float x1, unsigned &ph, uns
     const float s1 = r1 - __builtin_bit_cast(float, v1 & 0xffff0000u);
     pl = __builtin_amdgcn_perm(__builtin_bit_cast(unsigned, s1), __builtin_bit_cast(unsigned, s0), kTop);
 }
+#endif
 
 // KM task t -> (w-quad q, k-pair kp); tasks = 2*WD (8 k-pairs x WD/4 quads), 64 per wave
 template <int WD>

@@ -12,11 +12,13 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-SO_PATH = os.path.join(os.path.dirname(_HERE), 'csrc', 'libmotifs_hip.so')
+# MOTIFS_HIP_LIB selects another BUILD of the same library (csrc/build.py with MH_OUT=...: e.g. the MH_SPLIT_RN=1 or
+# MH_MFMA_SPLIT=0 variants); it is never a fallback -- a missing file raises like the default path does
+SO_PATH = os.environ.get('MOTIFS_HIP_LIB') or os.path.join(os.path.dirname(_HERE), 'csrc', 'libmotifs_hip.so')
 
 # every symbol include/motifs_hip.h declares (checked by tests/test_cabi.py against the header)
 SYMBOLS = (
-    'mh_version', 'mh_mfma_split', 'mh_last_error',
+    'mh_version', 'mh_mfma_split', 'mh_split_rne', 'mh_last_error',
     'mh_nms_ws_bytes', 'mh_nms', 'mh_nms_batched_ws_bytes', 'mh_nms_batched',
     'mh_roi_align_fwd', 'mh_roi_align_bwd', 'mh_draw_union_boxes', 'mh_bbox_overlaps', 'mh_triplet_match',
     'mh_gemm_ws_bytes', 'mh_gemm_auto_splitk', 'mh_gemm_f32',
