@@ -12,7 +12,10 @@ Extra objects in the line:
   roofline     -- the dominant kernel (conv3x3 implicit GEMM on the matrix cores): algorithmic fp32 FLOPs / HIP-event
                   time of its launches during the timed steps, against the matrix-core peak of the evaluation the
                   library was built with (bf16x6: 2500/6 = 416.7 TFLOP/s fp32-equivalent; f32 MFMA: 157.3 TFLOP/s;
-                  `frac_of_f32_mfma_peak` is always given too).
+                  `frac_of_f32_mfma_peak` is always given too).  `traffic` = fabric-side bytes per launch of that
+                  kernel from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over the same 14 launches
+                  (collected offline, profiles/r01_conv_traffic_summary.json: a PMC pass over the whole step does not
+                  finish); `traffic_algorithmic` = input + weights + output bytes of those launches.
   cpu_baseline -- the CPU oracle (oracle/model.py, "port") timed on this host on a bounded sample of the same
                   workload (1 image, forward+backward), rank 0 at N=1 only.
 """
@@ -33,6 +36,7 @@ for p in (ROOT, os.path.join(ROOT, 'neural-motifs_amd')):
 
 PEAK_FP32_MFMA_TFLOPS = 157.3          # /opt/skills/guides/MI355X_MICROARCH.md chip table (f32-input MFMA)
 PEAK_BF16_MFMA_TFLOPS = 2500.0         # same table, dense bf16 MFMA
+TRAFFIC_SUMMARY = 'profiles/r01_conv_traffic_summary.json'   # tools/traffic_summary.py
 MODEL_KW = dict(hidden_dim=512, pooling_dim=4096, nl_obj=2, nl_edge=2, order='leftright', rec_dropout=0.1,
                 use_bias=True, pass_in_obj_feats_to_decoder=False, pass_in_obj_feats_to_edge=False, use_tanh=False,
                 limit_vision=False)
@@ -182,6 +186,13 @@ def main():
                 split, PEAK_BF16_MFMA_TFLOPS, split)
         else:
             peak, how = PEAK_FP32_MFMA_TFLOPS, 'v_mfma_f32_32x32x2_f32'
+        traffic = None
+        tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), TRAFFIC_SUMMARY)
+        if os.path.exists(tpath) and split:                  # collected on the bf16x6 build, on exactly these 14 launches
+            with open(tpath) as f:
+                traffic = json.load(f)
+            if traffic.get('launches') * args.steps != conv['launches']:
+                traffic = None                               # another launch mix: the offline figure does not apply
         line = {
             'metric': 'images/sec MotifNet-SGCls fwd+bwd', 'value': world * BATCH * args.steps / dt, 'unit': 'img/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * dt / args.steps,
@@ -191,7 +202,11 @@ def main():
                        'global_batch': world * BATCH, 'parallelism': 'dp%d' % world, 'final_loss': float(loss.item())},
             'roofline': {'bound': 'mfma', 'kernel': 'conv3x3_nhwc_kernel (implicit GEMM: VGG trunk + union tower); ' + how,
                          'achieved': conv['tflops'], 'peak': peak, 'unit': 'TFLOP/s',
-                         'frac': conv['tflops'] / peak, 'traffic': None,
+                         'frac': conv['tflops'] / peak, 'traffic': traffic['bytes_per_launch'] if traffic else None,
+                         'traffic_unit': 'bytes per launch (L2 fabric side: HBM + Infinity-Cache)',
+                         'traffic_algorithmic': traffic['algorithmic_bytes_per_launch'] if traffic else None,
+                         'traffic_source': TRAFFIC_SUMMARY + ' (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over one '
+                                           'launch per shape of this step, tools/traffic_run.sh; not re-measured by this run)',
                          'frac_of_f32_mfma_peak': conv['tflops'] / PEAK_FP32_MFMA_TFLOPS,
                          'launches': conv['launches'], 'avg_launch_ms': conv['avg_ms'],
                          'flops_per_launch': conv['flops_per_launch']},

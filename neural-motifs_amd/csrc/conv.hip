@@ -4,12 +4,19 @@
 //   M = B*H*W output pixels (NHWC row = pixel, so the GEMM's K-contiguous A rows are pixel channel vectors),
 //   N = Cout, K = 9 taps x Cin.  For each tap the A row of pixel (b,y,x) is the channel vector of pixel
 //   (b,y+dy-1,x+dx-1) or zeros outside the image: the halo is a predicate on the row pointer, no im2col buffer.
-//   B = packed weights [9][Cin][Cout] ("MC": Cout contiguous).  Epilogue fuses bias + ReLU/ReLU6.
+//   The K loop walks 16-channel chunks with the nine taps INSIDE a chunk, so the nine k-tiles of a chunk re-read the
+//   same pixels' 64-byte segments out of L1/L2 (tap-major order sent 9.6 GB per bench step to the fabric for 2.1 GB
+//   of input, this order 4.6 GB: profiles/r01_conv_traffic_*).
+//   B = packed weights wt[tap][co][ci/16][hi|mid|lo planes] (bf16x6 build).  Epilogue fuses bias + ReLU/ReLU6.
 // The same kernel computes dgrad when given flip-transposed weights (mh_conv3x3_pack_weight).
 #include <algorithm>
 
 #include <type_traits>
 #include "mfma_tile.h"
+
+#ifndef MH_CONV_TAP_MAJOR
+#define MH_CONV_TAP_MAJOR 0   /* 1: the K loop walks tap-major (all channels of tap 0, then tap 1, ...): A/B comparisons only */
+#endif
 
 namespace mh {
 
@@ -102,8 +109,14 @@ __global__ __launch_bounds__(kThreads, MH_MINW) void conv3x3_nhwc_kernel(const C
     typedef Stage<BN> StageB;
 #endif
     auto load_tiles = [&](Stage<BM> &sa, StageB &sb, int kt, bool live) {
+#if MH_CONV_TAP_MAJOR
         const int tap = min(kt / kt_per_tap, 8);
         const int g16 = kt - tap * kt_per_tap, c0 = g16 * kBK;
+#else
+        // k order = 16-channel chunk outer, tap inner: the nine k-tiles of a chunk read the same ~(BM + 2W + 2) pixels'
+        // 64-byte channel segments, so eight of the nine reads hit L1 / L2 instead of going to the fabric
+        const int g16 = kt / 9, tap = kt - 9 * g16, c0 = g16 * kBK;
+#endif
         const int dy = tap / 3 - 1, dx = tap % 3 - 1;
         const unsigned a_soff = live ? (unsigned)(halo + (dy * p.W + dx) * p.Cin + c0) * 4u : kDeadTile;
         const unsigned bit = 1u << tap;

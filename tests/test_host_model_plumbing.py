@@ -242,3 +242,31 @@ def test_message_passing_baseline_matches_the_oracle(shim):
     with torch.no_grad():
         boxes, classes, obj_scores, rels, scores = model[make_blob(ds, [0], is_train=False)]
     assert boxes.shape[1] == 4 and rels.shape[1] == 2 and scores.shape[1] == 51 and classes.min() >= 1
+
+
+def test_conv_traffic_summary_matches_the_committed_counter_files():
+    """profiles/r01_conv_traffic_summary.json (what bench.py reports as roofline.traffic) is the join of the committed
+    rocprofv3 counter CSVs with the launch list, with the guide's FETCH_SIZE x2 correction confirmed by the calibration
+    launch"""
+    import io
+    import os
+    import json
+    import contextlib
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location('traffic_summary', os.path.join(root, 'tools', 'traffic_summary.py'))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        mod.main(os.path.join(root, 'profiles', 'r01_conv_traffic'))
+    fresh = json.loads(buf.getvalue())
+    with open(os.path.join(root, 'profiles', 'r01_conv_traffic_summary.json')) as f:
+        committed = json.load(f)
+    assert fresh == committed
+    assert committed['launches'] == 14 and abs(committed['fetch_correction'] - 2.0) < 1e-3 and abs(committed['write_correction'] - 1.0) < 1e-3
+    rows = committed['per_launch']
+    assert all(r['write_bytes'] >= r['write_bytes_algorithmic'] * 0.999 for r in rows)
+    assert all(r['splitk_partials'] or abs(r['write_bytes'] / r['write_bytes_algorithmic'] - 1) < 1e-3 for r in rows)
+    assert all(r['read_bytes'] >= r['read_bytes_algorithmic'] for r in rows)
+    assert 1.0 < committed['ratio'] < 2.0

@@ -9,6 +9,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <random>
 #include <vector>
 
@@ -104,9 +105,9 @@ static int exact_copies(gemm_fn gemm)
 }
 
 // 3x3/1/1 convolution and its weight gradient against float64 loops; returns rms errors over rms of the result
-static void conv_case(void *h, double &conv_rms, double &conv_max, double &wg_rms, double &wg_max, int &wg_rc)
+static void conv_case(void *h, double &conv_rms, double &conv_max, double &wg_rms, double &wg_max, int &wg_rc,
+                      int B = 2, int H = 20, int W = 24, int Ci = 64, int Co = 64)
 {
-    const int B = 2, H = 20, W = 24, Ci = 64, Co = 64;
     sz2_fn packed = (sz2_fn)dlsym(h, "mh_conv3x3_packed_floats");
     pack_fn pack = (pack_fn)dlsym(h, "mh_conv3x3_pack_weight");
     sz5_fn cws = (sz5_fn)dlsym(h, "mh_conv3x3_ws_bytes"), gws = (sz5_fn)dlsym(h, "mh_conv3x3_wgrad_ws_bytes");
@@ -162,12 +163,25 @@ static void conv_case(void *h, double &conv_rms, double &conv_max, double &wg_rm
 
 int main(int argc, char **argv)
 {
+    bool conv_only = false;
     for (int i = 1; i < argc; ++i) {
+        if (!strcmp(argv[i], "--conv-only")) { conv_only = true; continue; }
         void *h = dlopen(argv[i], RTLD_NOW | RTLD_LOCAL);
         if (!h) { printf("dlopen %s: %s\n", argv[i], dlerror()); return 1; }
         gemm_fn gemm = (gemm_fn)dlsym(h, "mh_gemm_f32");
         int_fn split = (int_fn)dlsym(h, "mh_mfma_split"), rne = (int_fn)dlsym(h, "mh_split_rne");
         if (!gemm || !split || !rne) { printf("missing symbols in %s\n", argv[i]); return 1; }
+        if (conv_only) {      // several conv shapes: 256x64 and 128x128 tiles, split-K, ragged Cout, many small images
+            const int shp[][5] = {{2, 20, 24, 64, 64}, {1, 19, 23, 256, 192}, {5, 14, 14, 128, 256}, {1, 37, 37, 512, 64}, {1, 9, 70, 32, 100}};
+            for (const auto &q : shp) {
+                double c_rms, c_max, g_rms, g_max; int g_rc;
+                conv_case(h, c_rms, c_max, g_rms, g_max, g_rc, q[0], q[1], q[2], q[3], q[4]);
+                printf("{\"lib\": \"%s\", \"conv\": [%d, %d, %d, %d, %d], \"max_err_over_rms\": %.3e, \"rms_err_over_rms\": %.3e, "
+                       "\"wgrad_rc\": %d, \"wgrad_max_err_over_rms\": %.3e}\n", argv[i], q[0], q[1], q[2], q[3], q[4], c_max, c_rms, g_rc, g_max);
+                fflush(stdout);
+            }
+            continue;
+        }
         const Err mixed = run_case(gemm, 256, 256, 4096, false, 1), pos = run_case(gemm, 256, 256, 4096, true, 2);
         const double tf = speed(gemm, 4096, 20);
         const int bad = exact_copies(gemm);
