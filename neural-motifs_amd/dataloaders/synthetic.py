@@ -38,6 +38,11 @@ class SyntheticVG(torch.utils.data.Dataset):
             self.relationships.append(np.column_stack((sel, rs.randint(1, num_predicates, sel.shape[0]))).astype(np.int64))
 
     @property
+    def coco(self):
+        from lib.evaluation.det_map import FauxCoco
+        return FauxCoco(self.gt_classes, self.gt_boxes, len(self.ind_to_classes))
+
+    @property
     def num_classes(self):
         return len(self.ind_to_classes)
 

@@ -72,6 +72,13 @@ class VG(Dataset):
     def is_train(self):
         return self.mode.startswith('train')
 
+    @property
+    def coco(self):
+        """ground truth in the shape detection mAP is computed on (reference :103-127 builds a pycocotools COCO object;
+        here lib/evaluation/det_map.py: same boxes [x, y, w+1, h+1], areas, annotation ids from 0)"""
+        from lib.evaluation.det_map import FauxCoco
+        return FauxCoco(self.gt_classes, self.gt_boxes, len(self.ind_to_classes))
+
     @classmethod
     def splits(cls, *args, **kwargs):
         """train / val / test datasets; the synthetic stand-in when the VG files are not on this machine"""

@@ -7,8 +7,10 @@ checkpoint every train_rels run starts from, and it is the only consumer of the 
     python models/train_detector.py -b 6 -lr 1e-3 -ngpu 1 -nepoch 1 -clip 5 -max_iters 20
     torchrun --nproc-per-node 8 models/train_detector.py ... -ngpu 8      # one process per GPU, RCCL all-reduce
 
-Validation by COCO mAP (pycocotools) is not part of this environment: per epoch the driver reports the training
-losses and saves the checkpoint in the reference's format ({'epoch', 'state_dict', 'optimizer'}).
+Per epoch, like the reference (train_detector.py:158-181, :222-233): validation detections of every rank are gathered,
+rank 0 computes the COCO-protocol box mAP on the VG ground truth (lib/evaluation/det_map.py stands in for pycocotools),
+mAP at IoU .5 drives ReduceLROnPlateau, and the checkpoint is saved in the reference's format
+({'epoch', 'state_dict', 'optimizer'}).
 """
 import os
 import sys
@@ -20,10 +22,13 @@ import numpy as np
 import pandas as pd
 import torch
 
-from config import ModelConfig
+from torch.optim.lr_scheduler import ReduceLROnPlateau
+
+from config import ModelConfig, BOX_SCALE, IM_SCALE
 from dataloaders.visual_genome import VGDataLoader, VG
 from lib import dist as D
 from lib.detector_loss import detector_losses
+from lib.evaluation.det_map import detection_rows, evaluate_bbox, summarize
 from lib.object_detector import ObjectDetector
 from lib.optim import FusedClipSGD
 from lib.pytorch_misc import optimistic_restore, print_para
@@ -53,6 +58,7 @@ if rank == 0:
 
 optimizer = FusedClipSGD([p for p in detector.parameters() if p.requires_grad], weight_decay=conf.l2,
                          lr=conf.lr * world * conf.batch_size, momentum=0.9)
+scheduler = ReduceLROnPlateau(optimizer, 'max', patience=3, factor=0.1, threshold=0.001, threshold_mode='abs', cooldown=1)
 reducer = D.OverlappedGradReducer([p for p in detector.parameters() if p.requires_grad])      # inert at world 1
 
 start_epoch = -1
@@ -94,6 +100,40 @@ def train_epoch(epoch_num):
     return pd.concat(tr, axis=1)
 
 
+def val_epoch():
+    detector.eval()
+    rows, n_batches = [], 0
+    with torch.no_grad():
+        for val_b, batch in enumerate(val_loader):
+            if conf.max_iters and val_b >= conf.max_iters:
+                break
+            first_image = (val_b * world + rank) * conf.batch_size                     # _RankSampler's sharding
+            rows.append(detection_rows(detector[batch], first_image, BOX_SCALE / IM_SCALE))
+            n_batches += 1
+    dets = np.concatenate(rows, 0) if rows else np.zeros((0, 7))
+    if world > 1:
+        gathered = [None] * world
+        torch.distributed.all_gather_object(gathered, dets)
+        dets = np.concatenate(gathered, 0)
+    mAp = 0.0
+    if rank == 0:
+        if dets.shape[0] == 0:
+            print("No detections anywhere")
+        else:
+            # the reference scores every image of `val` (its loader drops the last partial batch, those images count
+            # as missed); with several ranks or a capped epoch only the images that were actually run are scored
+            covered = n_batches * world * conf.batch_size
+            img_ids = range(len(val)) if world == 1 and not conf.max_iters else range(min(covered, len(val)))
+            stats = evaluate_bbox(val.coco, dets, img_ids)
+            print(summarize(stats), flush=True)
+            mAp = float(stats[1])
+    if world > 1:
+        t = torch.tensor([mAp], dtype=torch.float64, device='cuda')
+        torch.distributed.broadcast(t, 0)
+        mAp = float(t.item())
+    return mAp
+
+
 if __name__ == '__main__':
     if rank == 0:
         print("Training starts now!")
@@ -101,9 +141,11 @@ if __name__ == '__main__':
         rez = train_epoch(epoch)
         if rank == 0:
             print("overall{:2d}: ({:.3f})\n{}".format(epoch, rez.mean(1)['total'], rez.mean(1)), flush=True)
-            if conf.save_dir is not None:
-                os.makedirs(conf.save_dir, exist_ok=True)
-                torch.save({'epoch': epoch, 'state_dict': detector.state_dict(), 'optimizer': optimizer.state_dict()},
-                           os.path.join(conf.save_dir, '{}-{}.tar'.format('vgdet', epoch)))
+        mAp = val_epoch()
+        scheduler.step(mAp)
+        if rank == 0 and conf.save_dir is not None:
+            os.makedirs(conf.save_dir, exist_ok=True)
+            torch.save({'epoch': epoch, 'state_dict': detector.state_dict(), 'optimizer': optimizer.state_dict()},
+                       os.path.join(conf.save_dir, '{}-{}.tar'.format('vgdet', epoch)))
     if world > 1:
         torch.distributed.destroy_process_group()
