@@ -195,7 +195,9 @@ class ObjectDetector(nn.Module):
                                     np.array([2000] * len(im_sizes)), nms_thresh=0.7, pre_nms_topn=6000,
                                     post_nms_topn=1000)
         if self.training:
-            raise NotImplementedError('training on precomputed proposals needs proposal_assignments_det (§8f)')
+            # the reference's branch (object_detector.py:247-252) returns sampled + all RoIs with labels for the sampled
+            # ones only, which its own loss (train_detector.py:108-111) cannot consume: no behaviour to reproduce
+            raise NotImplementedError('detector training on precomputed proposals is not runnable in the reference either')
         return rois, None, None, None, None, None
 
     def get_boxes(self, *args, **kwargs):
