@@ -91,3 +91,35 @@ def test_round_to_nearest_split_is_exact_and_tighter():
     kept = a3 * b1 + a1 * b3 + a2 * b2 + a2 * b1 + a1 * b2 + a1 * b1
     rel = (kept - exact) / exact
     assert np.abs(rel).max() < 2.0 ** -23.9 and np.abs(rel).mean() < 2.0 ** -27.5 and abs(rel.mean()) < 2.0 ** -33
+
+
+def test_f16x3_row_scaled_split_study():
+    """tools/fp16_split_study.py, the numerics case for the next inner loop: three f16 MFMAs with a
+    power-of-two scale per operand row are as accurate as the shipped six bf16 MFMAs (both far below the fp32
+    accumulation error); a single scale per tensor is not robust to rows that differ by many decades"""
+    import importlib.util
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location('fp16_split_study', os.path.join(root, 'tools', 'fp16_split_study.py'))
+    st = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(st)
+    rs = np.random.RandomState(0)
+    for kind in ('normal', 'wide', 'relu', 'outlier'):
+        a, b = st.operands(kind, rs, M=32, N=32, K=2048)
+        ref = a.astype(np.float64) @ b.astype(np.float64)
+        e_fp32 = st.errors((a @ b).astype(np.float64), ref)
+        e_bf = st.errors(st.bf16x6(a, b), ref)
+        e_row = st.errors(st.f16x3(a, b, True), ref)
+        e_tensor = st.errors(st.f16x3(a, b, False), ref)
+        assert e_row[1] < 2.0 * e_bf[1] + 1e-12 and e_row[1] < 0.5 * e_fp32[1]            # rms: same class as bf16x6, below fp32
+        assert e_row[2] < 2.0 * e_bf[2] and e_row[2] < 1.5e-7                             # median relative error ~ 2^-24
+        if kind == 'outlier':
+            assert e_tensor[2] > 1e-4                                                     # per-tensor scaling loses the bulk
+    # the split itself: h1 + h2 reproduces a*s to 2^-22 relative, and h1, h2 are exact f16 values below 65504
+    a = sample(100000, 7)
+    a = a[(np.abs(a) > 1e-30) & (np.abs(a) < 1e30)]
+    s = st.pow2_scale(np.abs(a).max())
+    big = a[np.abs(a) * s > 2.0 ** -2]                       # elements whose second term stays a normal f16
+    h1, h2 = st.split_f16(big, s)
+    assert np.abs(h1).max() <= 65504
+    assert np.all(np.abs(h1 + h2 - big.astype(np.float64) * float(s)) <= 2.0 ** -22 * np.abs(big.astype(np.float64)) * float(s))
