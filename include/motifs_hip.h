@@ -39,6 +39,9 @@ int mh_mfma_split(void);
 /* 1 when the bf16 split rounds to nearest even (build knob MH_SPLIT_RN=1: dropped cross terms <= 2^-24|ab|, zero mean),
  * 0 for the default truncation split (<= 2^-21|ab|, typically 2^-24.5, towards zero) or the f32-MFMA build */
 int mh_split_rne(void);
+/* 1 in the EXPERIMENTAL f16x3 build (MH_SPLIT_F16=1: two-term f16 split with a power-of-two scale per operand row, three
+ * f16 MFMAs per product; mh_mfma_split() == 3; workspaces then also hold the row exponents; not yet run on hardware) */
+int mh_split_f16(void);
 /* name of the last kernel-launch error on this thread (for diagnostics), or "" */
 const char *mh_last_error(void);
 

@@ -31,6 +31,10 @@ struct ConvArgs {
     int tiles_m, tiles_n;
     int splitk, ktiles_per_split;
     float *partial;   // [splitk][M][Cout] when splitk > 1
+#if MH_SPLIT_F16
+    const int *expA;  // f16x3: exponent per OUTPUT pixel [M], covering its 3x3 input neighbourhood (pixel_exponents)
+    const int *expW;  // exponent per output channel [Cout] (tail of the packed weights)
+#endif
 };
 
 __device__ __forceinline__ float conv_epi(float v, int epilogue)
@@ -67,7 +71,7 @@ __global__ __launch_bounds__(kThreads, MH_MINW) void conv3x3_nhwc_kernel(const C
     unsigned a_off[NVA], a_taps[NVA];
 #if MH_PLANES
     // B = packed weights as bf16 planes, wt[tap][co][ci / 16][96 B]: chunk copies, no split (mfma_tile.h: PStage)
-    const unsigned b_row_bytes = (unsigned)(p.Cin / kBK) * (kRowDw * 4);
+    const unsigned b_row_bytes = (unsigned)(p.Cin / kBK) * kPlaneRowBytes;
     PPlan<BN> pb;
     plan_planes<BN>(pb, [&](int r) { return n0 + r < p.Cout; }, b_row_bytes, tid);
 #else
@@ -123,15 +127,24 @@ __global__ __launch_bounds__(kThreads, MH_MINW) void conv3x3_nhwc_kernel(const C
 #pragma unroll
         for (int j = 0; j < NVA; ++j) sa.v[j] = buffer_load4(ga, (a_taps[j] & bit) ? a_off[j] : kOobOffset, a_soff);
 #if MH_PLANES
-        load_planes<BN>(sb, pb, gb, live ? (unsigned)(tap * p.Cout + n0) * b_row_bytes + (unsigned)g16 * (kRowDw * 4) : kDeadTile);
+        load_planes<BN>(sb, pb, gb, live ? (unsigned)(tap * p.Cout + n0) * b_row_bytes + (unsigned)g16 * kPlaneRowBytes : kDeadTile);
 #else
         const unsigned b_soff = live ? (unsigned)((tap * p.Cout + n0) * p.Cin + c0) * 4u : kDeadTile;
 #pragma unroll
         for (int j = 0; j < NVB; ++j) sb.v[j] = buffer_load4(gb, b_off[j], b_soff);
 #endif
     };
+#if MH_SPLIT_F16
+    // every tap of output pixel m is staged with the exponent of pixel m (it bounds the whole 3x3 neighbourhood), so the
+    // scale is constant along K = (tap, channel) and comes off in the epilogue together with the weight row's
+    StageExp<BM> ea;
+    load_stage_exp<BM>(ea, p.expA, m0, Mtot, true, tid);
+    auto unscale = [&](long long row, int col, float v) { return __builtin_ldexpf(v, -(p.expA[row] + p.expW[col])); };
+#else
+    const StageExp<BM> ea;
+#endif
     auto store_tiles = [&](const Stage<BM> &sa, const StageB &sb, int buf) {
-        store_wm<BM>(sa, As(buf), tid);
+        store_wm<BM>(sa, As(buf), tid, ea);
 #if MH_PLANES
         store_planes<BN>(sb, pb, Bs(buf), tid);
 #else
@@ -172,6 +185,10 @@ __global__ __launch_bounds__(kThreads, MH_MINW) void conv3x3_nhwc_kernel(const C
             const long long row = m0 + r;
             if (row >= Mtot) return;
             float *q = dst + (size_t)row * p.Cout + n0;
+#if MH_SPLIT_F16
+            if (n0 + c0 < p.Cout) v0 = unscale(row, n0 + c0, v0);
+            if (n0 + c1 < p.Cout) v1 = unscale(row, n0 + c1, v1);
+#endif
             if (n0 + c0 < p.Cout) q[c0] = v0;
             if (n0 + c1 < p.Cout) q[c1] = v1;
         });
@@ -184,12 +201,16 @@ __global__ __launch_bounds__(kThreads, MH_MINW) void conv3x3_nhwc_kernel(const C
         const long long row = m0 + r;
         if (row >= Mtot) return;
         float *q = p.out + (size_t)row * p.Cout;
+#if MH_SPLIT_F16
+        if (col0 < p.Cout) v0 = unscale(row, col0, v0);
+        if (col1 < p.Cout) v1 = unscale(row, col1, v1);
+#endif
         if (col0 < p.Cout) q[col0] = conv_epi(v0 + bias0, p.epilogue);
         if (col1 < p.Cout) q[col1] = conv_epi(v1 + bias1, p.epilogue);
     });
 }
 
-#if MH_PLANES
+#if MH_PLANES && !MH_SPLIT_F16     // (f16x3 build: not ported yet -- callers fall back to im2col + GEMM, as in the f32 build)
 // ---------------------------------------------------------------------------------------------------------------
 // Weight gradient of the 3x3 / stride 1 / pad 1 conv as an implicit GEMM (no patch matrix):
 //     dW[co][tap][ci] = sum over pixels  gy[pix][co] * x[pix + shift(tap)][ci]        (0 where the tap leaves the image)
@@ -323,7 +344,7 @@ __global__ __launch_bounds__(kThreads, MH_MINW) void conv3x3_wgrad_kernel(const 
         else if (col0 < N) q[col0] = v0;
     });
 }
-#endif  // MH_PLANES
+#endif  // MH_PLANES && !MH_SPLIT_F16
 
 // Packed weights of a 3x3 conv with N output and K input channels (for the dgrad conv the channel roles are swapped
 // and the taps mirrored: flip_transpose): element (tap, n, k) = w[n][k][tap], or w[k][n][8 - tap] when flipped.
@@ -336,7 +357,24 @@ __global__ void pack_weight_kernel(const float *__restrict__ w, int N, int K, in
     auto src = [&](int tap, int n, int k) -> float {
         return flip_transpose ? w[((size_t)k * src_cin + n) * 9 + (8 - tap)] : w[((size_t)n * src_cin + k) * 9 + tap];
     };
-#if MH_PLANES
+#if MH_SPLIT_F16
+    // wt[tap][n][k / 16][16 dwords] = h1 | h2 of w * 2^e[n]; the exponents e[N] (weight_exp_kernel) follow the planes
+    constexpr int row_dw = kPlaneRowBytes / 4;
+    const long long total = 9LL * N * (K / kBK) * row_dw;
+    unsigned *out = reinterpret_cast<unsigned *>(wt);
+    const int *exps = reinterpret_cast<const int *>(out + total);
+    for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total;
+         idx += (long long)blockDim.x * gridDim.x) {
+        const int d = idx % row_dw, plane = d / 8, kp = d % 8;
+        long long t = idx / row_dw;
+        const int g16 = t % (K / kBK); t /= (K / kBK);
+        const int n = t % N;
+        const int tap = (int)(t / N);
+        unsigned pl[2];
+        split_pair_f16(src(tap, n, g16 * kBK + 2 * kp), src(tap, n, g16 * kBK + 2 * kp + 1), exps[n], exps[n], pl[0], pl[1]);
+        out[idx] = pl[plane];
+    }
+#elif MH_PLANES
     const long long total = 9LL * N * (K / kBK) * kRowDw;
     unsigned *out = reinterpret_cast<unsigned *>(wt);
     for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total;
@@ -360,6 +398,43 @@ __global__ void pack_weight_kernel(const float *__restrict__ w, int N, int K, in
 #endif
     (void)src_cout;
 }
+
+#if MH_SPLIT_F16
+// exponent of output channel n over its 9*K weights (one block per n), written behind the planes
+__global__ void weight_exp_kernel(const float *__restrict__ w, int N, int K, int flip_transpose, int src_cin,
+                                  int *__restrict__ exps)
+{
+    __shared__ unsigned red[256];
+    const int n = blockIdx.x;
+    unsigned m = 0;
+    for (int i = threadIdx.x; i < 9 * K; i += 256) {
+        const int k = i / 9, tap = i % 9;
+        const float v = flip_transpose ? w[((size_t)k * src_cin + n) * 9 + tap] : w[((size_t)n * src_cin + k) * 9 + tap];
+        m = max(m, __float_as_uint(v) & 0x7fffffffu);
+    }
+    red[threadIdx.x] = m;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) red[threadIdx.x] = max(red[threadIdx.x], red[threadIdx.x + o]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) exps[n] = row_exponent(red[0]);
+}
+// exponent of OUTPUT pixel p = the exponent of the largest |x| over the pixels its nine taps read (pmax = per-pixel
+// maxima as float bits)
+__global__ void pixel_exp_kernel(const unsigned *__restrict__ pmax, int B, int H, int W, int *__restrict__ exps)
+{
+    const long long P = (long long)B * H * W;
+    for (long long p = blockIdx.x * (long long)blockDim.x + threadIdx.x; p < P; p += (long long)blockDim.x * gridDim.x) {
+        const int rem = (int)(p % ((long long)H * W)), y = rem / W, x = rem % W;
+        unsigned m = 0;
+        for (int dy = -1; dy <= 1; ++dy)
+            for (int dx = -1; dx <= 1; ++dx)
+                if ((unsigned)(y + dy) < (unsigned)H && (unsigned)(x + dx) < (unsigned)W) m = max(m, pmax[p + dy * W + dx]);
+        exps[p] = row_exponent(m);
+    }
+}
+#endif
 
 // Stem conv: NCHW image (Cin small, e.g. 3) -> NHWC, bias + activation.  Direct VALU kernel: the layer is
 // bandwidth-bound (1.2 GFLOP vs 90 MB written per 592x592 image).  One thread = one pixel x 16 output channels;
@@ -538,7 +613,11 @@ extern "C" {
 size_t mh_conv3x3_packed_floats(int Cout, int Cin)
 {
     if (Cout <= 0 || Cin <= 0) return 0;
-#if MH_PLANES
+#if MH_SPLIT_F16
+    // planes, then a tail of 9 * Cout dwords whose first Cout hold the channel exponents (the total stays a multiple of
+    // 9 * Cout, which is how callers shape the opaque container)
+    return (size_t)9 * Cout * (((Cin + kBK - 1) / kBK) * (kPlaneRowBytes / 4) + 1);
+#elif MH_PLANES
     return (size_t)9 * Cout * ((Cin + kBK - 1) / kBK) * kRowDw;
 #else
     return (size_t)9 * Cout * Cin;
@@ -552,6 +631,14 @@ int mh_conv3x3_pack_weight(const float *w, int Cout, int Cin, int flip_transpose
     const int N = flip_transpose ? Cin : Cout, K = flip_transpose ? Cout : Cin;
     MH_REQUIRE(K % kBK == 0);
     const long long total = (long long)mh_conv3x3_packed_floats(N, K);
+#if MH_SPLIT_F16
+    int *exps = reinterpret_cast<int *>(wt) + (size_t)9 * N * (K / kBK) * (kPlaneRowBytes / 4);
+    hipLaunchKernelGGL(weight_exp_kernel, dim3(N), dim3(256), 0, as_stream(stream), w, N, K, flip_transpose, Cin, exps);
+    {
+        const int rc_e = check_launch("weight_exp_kernel");
+        if (rc_e) return rc_e;
+    }
+#endif
     const int blocks = (int)std::min<long long>((total + 255) / 256, 4096);
     hipLaunchKernelGGL(pack_weight_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), w, N, K, flip_transpose, Cout,
                        Cin, wt);
@@ -570,7 +657,8 @@ size_t mh_conv3x3_ws_bytes(int B, int H, int W, int Cin, int Cout)
     const long long M = (long long)B * H * W;
     if (M <= 0 || Cin <= 0 || Cout <= 0 || Cin % kBK != 0) return 0;
     const int s = conv_splitk(M, Cin, Cout);
-    return s > 1 ? align_up((size_t)s * M * Cout * sizeof(float), 256) : 0;
+    const size_t exps = MH_SPLIT_F16 ? 2 * align_up((size_t)M * sizeof(int), 256) : 0;   // pixel exponents + their scratch
+    return exps + (s > 1 ? align_up((size_t)s * M * Cout * sizeof(float), 256) : 0);
 }
 
 int mh_conv3x3_nhwc(const float *in, int B, int H, int W, int Cin, const float *wt, int Cout, const float *bias,
@@ -593,6 +681,24 @@ int mh_conv3x3_nhwc(const float *in, int B, int H, int W, int Cin, const float *
     MH_REQUIRE(ntiles < (1LL << 31));
     const int total_kt = 9 * (Cin / kBK);
     int splitk = conv_splitk(M, Cin, Cout);
+#if MH_SPLIT_F16
+    {   // pixel exponents at the head of the workspace (mh_conv3x3_ws_bytes counts them): mandatory in this build
+        const size_t eb = align_up((size_t)M * sizeof(int), 256);
+        MH_REQUIRE(workspace && ws_bytes >= 2 * eb);
+        int *exps = reinterpret_cast<int *>(workspace);
+        int *pmax = reinterpret_cast<int *>(reinterpret_cast<char *>(workspace) + eb);
+        int rc_e = launch_row_exponents(in, true, M, Cin, Cin, pmax, as_stream(stream), /*bits_only=*/true);
+        if (rc_e) return rc_e;
+        hipLaunchKernelGGL(pixel_exp_kernel, dim3((unsigned)std::min<long long>((M + 255) / 256, 8192)), dim3(256), 0,
+                           as_stream(stream), reinterpret_cast<const unsigned *>(pmax), B, H, W, exps);
+        rc_e = check_launch("pixel_exp_kernel");
+        if (rc_e) return rc_e;
+        p.expA = exps;
+        p.expW = reinterpret_cast<const int *>(wt) + (size_t)9 * Cout * (Cin / kBK) * (kPlaneRowBytes / 4);
+        workspace = reinterpret_cast<char *>(workspace) + 2 * eb;
+        ws_bytes -= 2 * eb;
+    }
+#endif
     if (splitk > 1 && (workspace == nullptr || ws_bytes < (size_t)splitk * M * Cout * sizeof(float))) splitk = 1;
     p.ktiles_per_split = ceil_div(total_kt, splitk);
     splitk = ceil_div(total_kt, p.ktiles_per_split);
@@ -635,7 +741,7 @@ size_t mh_conv3x3_wgrad_ws_bytes(int B, int H, int W, int Cin, int Cout)
 int mh_conv3x3_wgrad(const float *x, const float *gy, int B, int H, int W, int Cin, int Cout, float *dw,
                      void *workspace, size_t ws_bytes, void *stream)
 {
-#if MH_PLANES
+#if MH_PLANES && !MH_SPLIT_F16
     MH_REQUIRE(x && gy && dw && workspace && B > 0 && H > 0 && W > 0 && Cin > 0 && Cin % 4 == 0 && Cout > 0 && Cout % 4 == 0);
     MH_REQUIRE(((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(gy) | reinterpret_cast<uintptr_t>(dw) |
                  reinterpret_cast<uintptr_t>(workspace)) & 15) == 0);

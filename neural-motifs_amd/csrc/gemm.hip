@@ -23,6 +23,9 @@ struct GemmArgs {
     float *partial;  // [splitk][M][N] when splitk > 1
     int vecA, vecB, vecC;
     int tiles_m, tiles_n;
+#if MH_SPLIT_F16
+    const int *expA, *expB;   // f16x3: power-of-two exponent per row of op(A) [M] and per column of op(B) [N]
+#endif
 };
 
 __device__ __forceinline__ float apply_epi(float v, int epilogue)
@@ -97,10 +100,23 @@ __global__ __launch_bounds__(kThreads, MH_MINW) void gemm_kernel(const GemmArgs 
         if (TB) load_wm<BN, FAST>(sb, b_live, k0, p.K, p.vecB != 0, tid, gb);
         else load_km<BN, FAST>(sb, b_live, k0, n0, p.N, p.vecB != 0, tid, gb);
     };
+#if MH_SPLIT_F16
+    StageExp<BM> ea;
+    StageExp<BN> eb;
+    load_stage_exp<BM>(ea, p.expA, m0, p.M, AWM, tid);
+    load_stage_exp<BN>(eb, p.expB, n0, p.N, BWM, tid);
+    auto store_tiles = [&](const Stage<BM> &sa, const Stage<BN> &sb, int buf) {
+        if (TA) store_km<BM>(sa, As(buf), tid, ea); else store_wm<BM>(sa, As(buf), tid, ea);
+        if (TB) store_wm<BN>(sb, Bs(buf), tid, eb); else store_km<BN>(sb, Bs(buf), tid, eb);
+    };
+    // the accumulators hold sum (a 2^ea[row]) (b 2^eb[col]): the exact inverse power of two goes on before anything else
+    auto unscale = [&](int row, int col, float v) { return __builtin_ldexpf(v, -(p.expA[row] + p.expB[col])); };
+#else
     auto store_tiles = [&](const Stage<BM> &sa, const Stage<BN> &sb, int buf) {
         if (TA) store_km<BM>(sa, As(buf), tid); else store_wm<BM>(sa, As(buf), tid);
         if (TB) store_wm<BN>(sb, Bs(buf), tid); else store_km<BN>(sb, Bs(buf), tid);
     };
+#endif
 
     Acc acc;
     acc_zero(acc);
@@ -137,6 +153,10 @@ __global__ __launch_bounds__(kThreads, MH_MINW) void gemm_kernel(const GemmArgs 
         acc_foreach_pair<AWM, BWM>(acc, wm, wn, lane, [&](int r, int c0, int c1, float v0, float v1) {
             const int row = m0 + r, col0 = n0 + c0, col1 = n0 + c1;
             if (row >= p.M) return;
+#if MH_SPLIT_F16
+            if (col0 < p.N) v0 = unscale(row, col0, v0);
+            if (col1 < p.N) v1 = unscale(row, col1, v1);
+#endif
             float *q = dst + (size_t)row * p.N;
             if (vec && col1 < p.N) *reinterpret_cast<float2 *>(q + col0) = make_float2(v0, v1);
             else { if (col0 < p.N) q[col0] = v0; if (col1 < p.N) q[col1] = v1; }
@@ -147,6 +167,10 @@ __global__ __launch_bounds__(kThreads, MH_MINW) void gemm_kernel(const GemmArgs 
         const int row = m0 + r, col0 = n0 + c0, col1 = n0 + c1;
         if (row >= p.M) return;
         const bool has0 = (col0 < p.N), has1 = (col1 < p.N);
+#if MH_SPLIT_F16
+        if (has0) v0 = unscale(row, col0, v0);
+        if (has1) v1 = unscale(row, col1, v1);
+#endif
         if (p.bias) { if (has0) v0 += p.bias[col0]; if (has1) v1 += p.bias[col1]; }
         v0 = apply_epi(v0, p.epilogue);
         v1 = apply_epi(v1, p.epilogue);
@@ -177,6 +201,65 @@ __global__ void splitk_reduce_kernel(const float *__restrict__ partial, int spli
         *q = v;
     }
 }
+
+#if MH_SPLIT_F16
+// ---------------------------------------------------------------------------------------------------------------
+// f16x3 row exponents.  An operand row (a row of op(A), a column of op(B)) is scaled by 2^e with its largest |x| in
+// [2^14, 2^15); e is constant along K, so it factors out of the dot product and is removed exactly in the epilogue.
+// Two passes over the operand: |x| maxima as float bit patterns (monotone as unsigned), then bits -> exponent in place.
+// ---------------------------------------------------------------------------------------------------------------
+__global__ void row_absmax_kernel(const float *__restrict__ X, long long rows, int cols, long long ld,
+                                  unsigned *__restrict__ out)
+{
+    const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    const float *p = X + row * ld;
+    unsigned m = 0;
+    for (int c = lane; c < cols; c += 64) m = max(m, __float_as_uint(p[c]) & 0x7fffffffu);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o));
+    if (lane == 0) out[row] = m;
+}
+// X stored [rows = k][cols = operand rows]: out[cols] (zero-initialised) collects the column maxima
+__global__ void col_absmax_kernel(const float *__restrict__ X, long long rows, int cols, long long ld, int rows_per_block,
+                                  unsigned *__restrict__ out)
+{
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= cols) return;
+    const long long r0 = (long long)blockIdx.y * rows_per_block, r1 = min(rows, r0 + rows_per_block);
+    unsigned m = 0;
+    for (long long r = r0; r < r1; ++r) m = max(m, __float_as_uint(X[r * ld + c]) & 0x7fffffffu);
+    atomicMax(out + c, m);
+}
+__global__ void bits_to_exp_kernel(unsigned *__restrict__ io, long long n)
+{
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) io[i] = (unsigned)row_exponent(io[i]);
+}
+
+// exps[n_rows] for an operand whose `n_rows` rows (the non-K index) have `kext` elements along K; k_contiguous = the
+// storage is [n_rows][kext] (ld), otherwise [kext][n_rows] (ld)
+int launch_row_exponents(const float *X, bool k_contiguous, long long n_rows, long long kext, long long ld, int *exps,
+                         hipStream_t st, bool bits_only)
+{
+    unsigned *bits = reinterpret_cast<unsigned *>(exps);
+    if (k_contiguous) {
+        hipLaunchKernelGGL(row_absmax_kernel, dim3((unsigned)ceil_div(n_rows, 4LL)), dim3(256), 0, st, X, n_rows, (int)kext,
+                           ld, bits);
+    } else {
+        hipError_t e = hipMemsetAsync(bits, 0, (size_t)n_rows * sizeof(unsigned), st);
+        if (e != hipSuccess) { set_last_error("hipMemsetAsync(row exponents)", e); return (int)e; }
+        const int rows_per_block = (int)std::max<long long>(64, ceil_div(kext, 64LL));
+        hipLaunchKernelGGL(col_absmax_kernel, dim3((unsigned)ceil_div(n_rows, 256LL), (unsigned)ceil_div(kext, (long long)rows_per_block)),
+                           dim3(256), 0, st, X, kext, (int)n_rows, ld, rows_per_block, bits);
+    }
+    int rc = check_launch("absmax_kernel");
+    if (rc || bits_only) return rc;        // bits_only: the caller combines maxima before taking exponents (conv)
+    hipLaunchKernelGGL(bits_to_exp_kernel, dim3((unsigned)ceil_div(n_rows, 256LL)), dim3(256), 0, st, bits, n_rows);
+    return check_launch("bits_to_exp_kernel");
+}
+#endif  // MH_SPLIT_F16
 
 // Work-distribution model shared by GEMM and conv: `tiles` output tiles of `ktiles` k-steps each are cut into
 // S k-slices.  A CU holds two resident blocks (LDS / VGPR budget of the tile engine) and runs them at about half
@@ -228,6 +311,7 @@ using namespace mh;
 extern "C" {
 
 int mh_mfma_split(void) { return MH_MFMA_SPLIT; }
+int mh_split_f16(void) { return MH_SPLIT_F16; }
 int mh_split_rne(void) { return (MH_MFMA_SPLIT != 0 && MH_SPLIT_RN) ? 1 : 0; }
 
 int mh_gemm_auto_splitk(int M, int N, int K) { return (M > 0 && N > 0 && K > 0) ? choose_splitk(M, N, K) : 1; }
@@ -236,8 +320,9 @@ size_t mh_gemm_ws_bytes(int M, int N, int K, int splitk)
 {
     if (M <= 0 || N <= 0 || K <= 0) return 0;
     if (splitk <= 0) splitk = choose_splitk(M, N, K);
-    if (splitk <= 1) return 0;
-    return align_up((size_t)splitk * M * N * sizeof(float), 256);
+    const size_t exps = MH_SPLIT_F16 ? align_up((size_t)M * sizeof(int), 256) + align_up((size_t)N * sizeof(int), 256) : 0;
+    if (splitk <= 1) return exps;
+    return exps + align_up((size_t)splitk * M * N * sizeof(float), 256);
 }
 
 int mh_gemm_f32(int transA, int transB, int M, int N, int K, const float *A, int lda, const float *B, int ldb,
@@ -252,8 +337,22 @@ int mh_gemm_f32(int transA, int transB, int M, int N, int K, const float *A, int
     if (splitk <= 0) splitk = choose_splitk(M, N, K);
     const int total_kt = ceil_div(K, kBK);
     splitk = std::min(std::min(splitk, total_kt), 64);
-    if (splitk > 1 && (workspace == nullptr || ws_bytes < (size_t)splitk * M * N * sizeof(float))) splitk = 1;
+    hipStream_t st = as_stream(stream);
     GemmArgs p;
+#if MH_SPLIT_F16
+    {   // the row exponents live at the head of the workspace (mh_gemm_ws_bytes counts them): mandatory in this build
+        const size_t ea = align_up((size_t)M * sizeof(int), 256), eb = align_up((size_t)N * sizeof(int), 256);
+        MH_REQUIRE(workspace && ws_bytes >= ea + eb);
+        int *expA = reinterpret_cast<int *>(workspace), *expB = reinterpret_cast<int *>(reinterpret_cast<char *>(workspace) + ea);
+        int rc_e = launch_row_exponents(A, !transA, M, K, lda, expA, st);
+        if (!rc_e) rc_e = launch_row_exponents(B, transB != 0, N, K, ldb, expB, st);
+        if (rc_e) return rc_e;
+        p.expA = expA; p.expB = expB;
+        workspace = reinterpret_cast<char *>(workspace) + ea + eb;
+        ws_bytes -= ea + eb;
+    }
+#endif
+    if (splitk > 1 && (workspace == nullptr || ws_bytes < (size_t)splitk * M * N * sizeof(float))) splitk = 1;
     p.M = M; p.N = N; p.K = K;
     p.A = A; p.lda = lda; p.B = B; p.ldb = ldb; p.C = C; p.ldc = ldc;
     p.bias = bias; p.epilogue = epilogue; p.accumulate = accumulate;
@@ -270,7 +369,6 @@ int mh_gemm_f32(int transA, int transB, int M, int N, int K, const float *A, int
     p.tiles_n = ceil_div(N, narrow ? 64 : 128);
     const long long ntiles = (long long)p.tiles_m * p.tiles_n;
     MH_REQUIRE(ntiles < (1LL << 31) && splitk <= 65535);
-    hipStream_t st = as_stream(stream);
     dim3 grid((unsigned)ntiles, (unsigned)splitk);
     // FAST: both operands 16-B aligned and their contiguous extents multiples of 4 (see load4_guarded)
     // ... and each operand spans < 1 GiB (32-bit buffer offsets inside a 1 GiB descriptor, see GSrc)

@@ -30,8 +30,16 @@
 #ifndef MH_MINW
 #define MH_MINW 2
 #endif
+#ifndef MH_SPLIT_F16
+#define MH_SPLIT_F16 0    /* 1: EXPERIMENTAL "f16x3" engine: two-term f16 split with a power-of-two scale per operand row,
+                             three v_mfma_f32_32x32x16_f16 per product (not yet run on hardware) */
+#endif
 #ifndef MH_MFMA_SPLIT
-#define MH_MFMA_SPLIT 6   /* 6: bf16x6 split (fp32-accurate, default); 0: f32-input MFMA; 3: bf16x3 (2^-17, tests only) */
+#define MH_MFMA_SPLIT (MH_SPLIT_F16 ? 3 : 6)   /* MFMAs per fp32 product: 6 = bf16x6 (default), 3 = f16x3 with MH_SPLIT_F16 /
+                                                  bf16x3 without (2^-17, tests only), 0 = f32-input MFMA */
+#endif
+#if MH_SPLIT_F16 && MH_MFMA_SPLIT != 3
+#error "MH_SPLIT_F16 needs MH_MFMA_SPLIT == 3"
 #endif
 
 #ifndef MH_SPLIT_RN
@@ -46,6 +54,9 @@ constexpr int kThreads = 256;
 constexpr int kLdW = kBK + 4;   // WM row stride (floats)
 
 constexpr int kRowDw = 24;      // bf16-plane layout: dwords per operand row (3 planes x 8 dwords = 96 B)
+constexpr int kNumPlanes = MH_SPLIT_F16 ? 2 : 3;          // planes a row really holds (f16x3: h1 | h2, third slot pair unused)
+constexpr int kPlaneChunks = 2 * kNumPlanes;              // 16-byte chunks per row of an operand stored as planes in HBM
+constexpr int kPlaneRowBytes = 16 * kPlaneChunks;         // ... and its bytes per (row, k-tile): 96 (bf16x6) / 64 (f16x3)
 
 template <int WD, bool WM>
 struct TileGeom {
@@ -345,6 +356,31 @@ __device__ __forceinline__ void split_pair(float x0, float x1, unsigned &ph, uns
 }
 #endif
 
+#if MH_SPLIT_F16
+// f16x3: (x0, x1) scaled by 2^e of their operand ROW (e0 / e1: the two elements may belong to different rows), then
+// a*2^e = h1 + h2 + r with h1 = f16(a*2^e), h2 = f16(a*2^e - h1) (round to nearest even), |r| <= 2^-24 |a*2^e|.
+// The row exponent puts the row's largest magnitude into [2^14, 2^15) (row_exponent), so nothing overflows f16.
+typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void split_pair_f16(float x0, float x1, int e0, int e1, unsigned &p1, unsigned &p2)
+{
+    const f32x2_t xs = {__builtin_ldexpf(x0, e0), __builtin_ldexpf(x1, e1)};
+    const f16x2_t h1 = __builtin_convertvector(xs, f16x2_t);
+    const f32x2_t r = xs - __builtin_convertvector(h1, f32x2_t);     // exact
+    p1 = __builtin_bit_cast(unsigned, h1);
+    p2 = __builtin_bit_cast(unsigned, __builtin_convertvector(r, f16x2_t));
+}
+// exponent e with max * 2^e in [2^14, 2^15) from the bit pattern of max = the largest |x| of a row (0 for an all-zero,
+// inf or nan row: nothing to scale / nothing to save)
+__host__ __device__ __forceinline__ int row_exponent(unsigned absmax_bits)
+{
+    const int biased = (int)(absmax_bits >> 23) & 0xff;
+    if (biased == 0 || biased == 0xff) return 0;      // zero / denormal rows need no help: denormals are < 2^-126
+    return 14 - (biased - 127);
+}
+#endif
+
 // KM task t -> (w-quad q, k-pair kp); tasks = 2*WD (8 k-pairs x WD/4 quads), 64 per wave
 template <int WD>
 __device__ __forceinline__ bool km_task(int t, int &q, int &kp)
@@ -368,8 +404,42 @@ __device__ __forceinline__ void load_km(Stage<WD> &s, RowPtr row_ptr, int k0, in
     }
 }
 
+// Row exponents of the f16x3 engine as the staging thread needs them: one per staged float4 of a WM operand (its
+// tile row), four per k-pair task of a KM operand (its four tile columns).  Empty in the other builds.
 template <int WD>
-__device__ __forceinline__ void store_km(const Stage<WD> &s, float *tile, int tid)
+struct StageExp {
+#if MH_SPLIT_F16
+    int wm[WD >= 128 ? WD / 64 : 2];
+    int km[(2 * WD + kThreads - 1) / kThreads][4];
+#endif
+};
+// exps[i] = exponent of tile row / column i (i relative to the tile origin `o0`, `n` valid entries from there)
+template <int WD>
+__device__ __forceinline__ void load_stage_exp(StageExp<WD> &se, const int *__restrict__ exps, long long o0, long long n,
+                                               bool wm, int tid)
+{
+#if MH_SPLIT_F16
+    if (wm) {
+#pragma unroll
+        for (int j = 0; j < TileGeom<WD, true>::nv; ++j) {
+            const int r = (tid + kThreads * j) >> 2;
+            se.wm[j] = (o0 + r < n) ? exps[o0 + r] : 0;
+        }
+    } else {
+        constexpr int ntask = (2 * WD + kThreads - 1) / kThreads;
+#pragma unroll
+        for (int jt = 0; jt < ntask; ++jt) {
+            int q, kp;
+            km_task<WD>(tid + kThreads * jt, q, kp);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) se.km[jt][j] = (o0 + 4 * q + j < n) ? exps[o0 + 4 * q + j] : 0;
+        }
+    }
+#endif
+}
+
+template <int WD>
+__device__ __forceinline__ void store_km(const Stage<WD> &s, float *tile, int tid, const StageExp<WD> &se = StageExp<WD>())
 {
     constexpr int ntask = (2 * WD + kThreads - 1) / kThreads;
     unsigned *t32 = reinterpret_cast<unsigned *>(tile);
@@ -385,16 +455,20 @@ __device__ __forceinline__ void store_km(const Stage<WD> &s, float *tile, int ti
             const int r = 64 * (w >> 6) + 32 * (w & 1) + ((w & 63) >> 1);
             const int sw = plane_swz(r);
             unsigned pl[3];
+#if MH_SPLIT_F16
+            split_pair_f16(e[j], o[j], se.km[jt][j], se.km[jt][j], pl[0], pl[1]);     // k, k+1 of the same column
+#else
             split_pair(e[j], o[j], pl[0], pl[1], pl[2]);
+#endif
 #pragma unroll
-            for (int pidx = 0; pidx < 3; ++pidx)
+            for (int pidx = 0; pidx < kNumPlanes; ++pidx)
                 t32[r * kRowDw + 4 * ((2 * pidx + (kp >> 2)) ^ sw) + (kp & 3)] = pl[pidx];
         }
     }
 }
 
 template <int WD>
-__device__ __forceinline__ void store_wm(const Stage<WD> &s, float *tile, int tid)
+__device__ __forceinline__ void store_wm(const Stage<WD> &s, float *tile, int tid, const StageExp<WD> &se = StageExp<WD>())
 {
     unsigned *t32 = reinterpret_cast<unsigned *>(tile);
 #pragma unroll
@@ -402,10 +476,15 @@ __device__ __forceinline__ void store_wm(const Stage<WD> &s, float *tile, int ti
         const int f = tid + kThreads * j;
         const int r = f >> 2, kq = f & 3, sw = plane_swz(r);
         unsigned a[3], b[3];
+#if MH_SPLIT_F16
+        split_pair_f16(s.v[j].x, s.v[j].y, se.wm[j], se.wm[j], a[0], a[1]);
+        split_pair_f16(s.v[j].z, s.v[j].w, se.wm[j], se.wm[j], b[0], b[1]);
+#else
         split_pair(s.v[j].x, s.v[j].y, a[0], a[1], a[2]);
         split_pair(s.v[j].z, s.v[j].w, b[0], b[1], b[2]);
+#endif
 #pragma unroll
-        for (int pidx = 0; pidx < 3; ++pidx) {
+        for (int pidx = 0; pidx < kNumPlanes; ++pidx) {
             typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
             *reinterpret_cast<u32x2 *>(t32 + r * kRowDw + 4 * ((2 * pidx + (kq >> 1)) ^ sw) + 2 * (kq & 1)) =
                 (u32x2){a[pidx], b[pidx]};
@@ -425,6 +504,17 @@ __device__ __forceinline__ void fetch_frags(PlaneFrags &f, const float *__restri
     auto fetch = [&](const float *tile, int row, int pidx) -> bf16x8 {
         return *reinterpret_cast<const bf16x8 *>(tile + row * kRowDw + 4 * ((2 * pidx + g) ^ plane_swz(row)));
     };
+#if MH_SPLIT_F16
+    constexpr int kOrderA[2] = {1, 0}, kOrderB[2] = {0, 1};         // planes in order of first use: 8 ds_read_b128
+#pragma unroll
+    for (int o = 0; o < 2; ++o) {
+#pragma unroll
+        for (int sidx = 0; sidx < 2; ++sidx) {
+            f.a[sidx][kOrderA[o]] = fetch(As, wm + 32 * sidx + i, kOrderA[o]);
+            f.b[sidx][kOrderB[o]] = fetch(Bs, wn + 32 * sidx + i, kOrderB[o]);
+        }
+    }
+#else
     constexpr int kOrderA[3] = {2, 0, 1}, kOrderB[3] = {0, 2, 1};   // planes in order of first use
 #pragma unroll
     for (int o = 0; o < 3; ++o) {
@@ -434,9 +524,26 @@ __device__ __forceinline__ void fetch_frags(PlaneFrags &f, const float *__restri
             if (MH_MFMA_SPLIT >= 6 || kOrderB[o] != 2) f.b[sidx][kOrderB[o]] = fetch(Bs, wn + 32 * sidx + i, kOrderB[o]);
         }
     }
+#endif
 }
 // All MFMAs of one k-tile.  Per accumulator the six terms are added smallest first (lo*hi, hi*lo, mid*mid, mid*hi,
 // hi*mid, hi*hi); the four accumulators are interleaved so that consecutive MFMAs are independent.
+#if MH_SPLIT_F16
+// f16x3: h2*h1, h1*h2, h1*h1 (smallest first); h2*h2 <= 2^-24 |ab| is dropped
+__device__ __forceinline__ void mma_frags(const PlaneFrags &f, Acc &acc)
+{
+    constexpr int kTermA[3] = {1, 0, 0}, kTermB[3] = {0, 1, 0};
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int sm = 0; sm < 2; ++sm)
+#pragma unroll
+            for (int sn = 0; sn < 2; ++sn)
+                acc.v[sm][sn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, f.a[sm][kTermA[t]]),
+                                                                       __builtin_bit_cast(f16x8, f.b[sn][kTermB[t]]),
+                                                                       acc.v[sm][sn], 0, 0, 0);
+}
+#else
 __device__ __forceinline__ void mma_frags(const PlaneFrags &f, Acc &acc)
 {
     constexpr int kTermA[6] = {2, 0, 1, 1, 0, 0}, kTermB[6] = {0, 2, 1, 0, 1, 0};
@@ -449,6 +556,7 @@ __device__ __forceinline__ void mma_frags(const PlaneFrags &f, Acc &acc)
                 acc.v[sm][sn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[sm][kTermA[t]], f.b[sn][kTermB[t]],
                                                                         acc.v[sm][sn], 0, 0, 0);
 }
+#endif  // MH_SPLIT_F16
 #endif  // MH_PLANES
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -522,7 +630,7 @@ __device__ __forceinline__ void load_planned_km(Stage<WD> &s, const Plan<WD> &pl
 // ---------------------------------------------------------------------------------------------------------------
 template <int WD>
 struct PStage {
-    static constexpr int n = (WD * 6 + kThreads - 1) / kThreads;
+    static constexpr int n = (WD * kPlaneChunks + kThreads - 1) / kThreads;
     u32x4 v[n];
 };
 template <int WD>
@@ -535,8 +643,8 @@ __device__ __forceinline__ void plan_planes(PPlan<WD> &pl, RowOk row_ok, unsigne
 {
 #pragma unroll
     for (int j = 0; j < PStage<WD>::n; ++j) {
-        const int e = tid + kThreads * j, r = e / 6, c = e % 6;
-        const bool ok = (e < WD * 6) && row_ok(r);
+        const int e = tid + kThreads * j, r = e / kPlaneChunks, c = e % kPlaneChunks;
+        const bool ok = (e < WD * kPlaneChunks) && row_ok(r);
         pl.v[j] = ok ? (unsigned)r * row_stride_bytes + 16u * c : kOobOffset;
         pl.lds[j] = (unsigned)(r * kRowDw * 4 + 16 * (c ^ plane_swz(r)));
     }
@@ -556,7 +664,8 @@ __device__ __forceinline__ void store_planes(const PStage<WD> &s, const PPlan<WD
     char *base = reinterpret_cast<char *>(tile);
 #pragma unroll
     for (int j = 0; j < PStage<WD>::n; ++j)
-        if ((WD * 6) % kThreads == 0 || tid + kThreads * j < WD * 6) *reinterpret_cast<u32x4 *>(base + pl.lds[j]) = s.v[j];
+        if ((WD * kPlaneChunks) % kThreads == 0 || tid + kThreads * j < WD * kPlaneChunks)
+            *reinterpret_cast<u32x4 *>(base + pl.lds[j]) = s.v[j];
 }
 #endif
 
@@ -640,6 +749,18 @@ __device__ __forceinline__ void half_step(LoadFn load_far, StoreFn store_next, c
     fetch_frags<BM, BN>(f, As, Bs, wm, wn, lane);
     store_next();
     mma_frags(f, acc);
+#if MH_SPLIT_F16
+    __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);        // fragment reads (two planes)
+    __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);
+#pragma unroll
+    for (int i = 0; i < 12; ++i) {                            // untuned: same recipe as below at half the MFMA count
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, 7, 0);
+        __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+    }
+    __syncthreads();
+    return;
+#endif
     __builtin_amdgcn_sched_group_barrier(0x100, 12, 0);       // fragment reads
     __builtin_amdgcn_sched_group_barrier(0x002, 12, 0);       // first split ops while the reads land
 #pragma unroll
@@ -663,6 +784,10 @@ __device__ __forceinline__ void half_step_f32(LoadFn load_far, StoreFn store_nex
 #endif
 
 // defined in gemm.hip
+#if MH_SPLIT_F16
+int launch_row_exponents(const float *X, bool k_contiguous, long long n_rows, long long kext, long long ld, int *exps,
+                         hipStream_t st, bool bits_only = false);
+#endif
 int choose_splitk_tiles(long long tiles, int ktiles, double out_elems, double flops);
 int launch_splitk_reduce(const float *partial, int splitk, long long M, int N, float *C, int ldc, const float *bias,
                          int epilogue, int accumulate, hipStream_t st);

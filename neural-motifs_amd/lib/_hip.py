@@ -18,7 +18,7 @@ SO_PATH = os.environ.get('MOTIFS_HIP_LIB') or os.path.join(os.path.dirname(_HERE
 
 # every symbol include/motifs_hip.h declares (checked by tests/test_cabi.py against the header)
 SYMBOLS = (
-    'mh_version', 'mh_mfma_split', 'mh_split_rne', 'mh_last_error',
+    'mh_version', 'mh_mfma_split', 'mh_split_rne', 'mh_split_f16', 'mh_last_error',
     'mh_nms_ws_bytes', 'mh_nms', 'mh_nms_batched_ws_bytes', 'mh_nms_batched',
     'mh_roi_align_fwd', 'mh_roi_align_bwd', 'mh_draw_union_boxes', 'mh_bbox_overlaps', 'mh_triplet_match',
     'mh_gemm_ws_bytes', 'mh_gemm_auto_splitk', 'mh_gemm_f32',

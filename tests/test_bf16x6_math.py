@@ -123,3 +123,31 @@ def test_f16x3_row_scaled_split_study():
     h1, h2 = st.split_f16(big, s)
     assert np.abs(h1).max() <= 65504
     assert np.all(np.abs(h1 + h2 - big.astype(np.float64) * float(s)) <= 2.0 ** -22 * np.abs(big.astype(np.float64)) * float(s))
+
+
+def test_row_exponent_bit_formula_of_the_f16x3_engine():
+    """mfma_tile.h::row_exponent (experimental MH_SPLIT_F16 build) takes the exponent from the float's bit pattern; it
+    must put every row maximum into [2^14, 2^15) -- below the f16 overflow threshold even after rounding -- and agree
+    with the floor(log2) form the numerics study uses"""
+    import os
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hdr = open(os.path.join(root, 'neural-motifs_amd', 'csrc', 'mfma_tile.h')).read()
+    body = hdr[hdr.index('int row_exponent(unsigned absmax_bits)'):]
+    body = body[:body.index('\n}')]
+    assert 'const int biased = (int)(absmax_bits >> 23) & 0xff;' in body
+    assert 'if (biased == 0 || biased == 0xff) return 0;' in body and 'return 14 - (biased - 127);' in body
+
+    def row_exponent(x):
+        bits = np.abs(np.asarray(x, dtype=np.float32)).view(np.uint32)
+        biased = ((bits >> 23) & 0xff).astype(np.int64)
+        return np.where((biased == 0) | (biased == 0xff), 0, 14 - (biased - 127))
+
+    m = np.abs(sample(100000, 11))
+    m = m[(m > 1e-37) & np.isfinite(m)]
+    e = row_exponent(m)
+    scaled = np.ldexp(m.astype(np.float64), e)
+    assert scaled.min() >= 2.0 ** 14 and scaled.max() < 2.0 ** 15
+    assert np.all(np.isfinite(np.ldexp(m, e).astype(np.float16))) and np.ldexp(m, e).astype(np.float16).max() <= 32768
+    np.testing.assert_array_equal(e, 14 - np.floor(np.log2(m.astype(np.float64))).astype(np.int64))
+    assert row_exponent(np.float32(0)) == 0 and row_exponent(np.float32(np.inf)) == 0 and row_exponent(np.float32(1e-45)) == 0

@@ -16,6 +16,15 @@
 typedef int (*gemm_fn)(int, int, int, int, int, const float *, int, const float *, int, float *, int, const float *,
                        int, int, int, void *, size_t, void *);
 typedef int (*int_fn)(void);
+typedef size_t (*gemm_ws_fn)(int, int, int, int);
+static gemm_ws_fn g_gemm_ws = nullptr;      // mh_gemm_ws_bytes of the library under test (the f16x3 build keeps row exponents there)
+
+struct GemmWs {      // workspace for an unsplit GEMM of the given shape (nullptr / 0 where the build needs none)
+    void *p = nullptr;
+    size_t n = 0;
+    GemmWs(int M, int N, int K) { n = g_gemm_ws ? g_gemm_ws(M, N, K, 1) : 0; if (n && hipMalloc(&p, n) != hipSuccess) { printf("hipMalloc ws\n"); exit(2); } }
+    ~GemmWs() { if (p) (void)hipFree(p); }
+};
 
 #define HIP_OK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(2); } } while (0)
 
@@ -33,7 +42,8 @@ static Err run_case(gemm_fn gemm, int M, int N, int K, bool positive, unsigned s
     HIP_OK(hipMalloc(&dA, A.size() * 4)); HIP_OK(hipMalloc(&dB, B.size() * 4)); HIP_OK(hipMalloc(&dC, C.size() * 4));
     HIP_OK(hipMemcpy(dA, A.data(), A.size() * 4, hipMemcpyHostToDevice));
     HIP_OK(hipMemcpy(dB, B.data(), B.size() * 4, hipMemcpyHostToDevice));
-    int rc = gemm(0, 0, M, N, K, dA, K, dB, N, dC, N, nullptr, 0, 0, 1, nullptr, 0, nullptr);
+    GemmWs ws(M, N, K);
+    int rc = gemm(0, 0, M, N, K, dA, K, dB, N, dC, N, nullptr, 0, 0, 1, ws.p, ws.n, nullptr);
     if (rc) { printf("mh_gemm_f32 rc=%d\n", rc); exit(3); }
     HIP_OK(hipDeviceSynchronize());
     HIP_OK(hipMemcpy(C.data(), dC, C.size() * 4, hipMemcpyDeviceToHost));
@@ -66,9 +76,10 @@ static double speed(gemm_fn gemm, int S, int iters)
     HIP_OK(hipMemcpy(dA, h.data(), h.size() * 4, hipMemcpyHostToDevice));
     HIP_OK(hipMemcpy(dB, h.data(), h.size() * 4, hipMemcpyHostToDevice));
     hipEvent_t e0, e1; HIP_OK(hipEventCreate(&e0)); HIP_OK(hipEventCreate(&e1));
-    for (int i = 0; i < 3; ++i) gemm(0, 1, S, S, S, dA, S, dB, S, dC, S, nullptr, 0, 0, 1, nullptr, 0, nullptr);
+    GemmWs ws(S, S, S);
+    for (int i = 0; i < 3; ++i) gemm(0, 1, S, S, S, dA, S, dB, S, dC, S, nullptr, 0, 0, 1, ws.p, ws.n, nullptr);
     HIP_OK(hipEventRecord(e0, nullptr));
-    for (int i = 0; i < iters; ++i) gemm(0, 1, S, S, S, dA, S, dB, S, dC, S, nullptr, 0, 0, 1, nullptr, 0, nullptr);
+    for (int i = 0; i < iters; ++i) gemm(0, 1, S, S, S, dA, S, dB, S, dC, S, nullptr, 0, 0, 1, ws.p, ws.n, nullptr);
     HIP_OK(hipEventRecord(e1, nullptr)); HIP_OK(hipEventSynchronize(e1));
     float ms; HIP_OK(hipEventElapsedTime(&ms, e0, e1));
     HIP_OK(hipFree(dA)); HIP_OK(hipFree(dB)); HIP_OK(hipFree(dC));
@@ -94,10 +105,11 @@ static int exact_copies(gemm_fn gemm)
     HIP_OK(hipMemcpy(dX, X.data(), X.size() * 4, hipMemcpyHostToDevice));
     HIP_OK(hipMemcpy(dP, P.data(), P.size() * 4, hipMemcpyHostToDevice));
     int bad = 0;
-    gemm(0, 0, S, S, S, dX, S, dP, S, dC, S, nullptr, 0, 0, 1, nullptr, 0, nullptr);      // C[m][(k*37+5)%S] = X[m][k]
+    GemmWs ws(S, S, S);
+    gemm(0, 0, S, S, S, dX, S, dP, S, dC, S, nullptr, 0, 0, 1, ws.p, ws.n, nullptr);      // C[m][(k*37+5)%S] = X[m][k]
     HIP_OK(hipMemcpy(C.data(), dC, C.size() * 4, hipMemcpyDeviceToHost));
     for (int m = 0; m < S; ++m) for (int k = 0; k < S; ++k) bad += C[(size_t)m * S + (k * 37 + 5) % S] != X[(size_t)m * S + k];
-    gemm(0, 0, S, S, S, dP, S, dX, S, dC, S, nullptr, 0, 0, 1, nullptr, 0, nullptr);      // C[i][n] = X[(i*37+5)%S][n]
+    gemm(0, 0, S, S, S, dP, S, dX, S, dC, S, nullptr, 0, 0, 1, ws.p, ws.n, nullptr);      // C[i][n] = X[(i*37+5)%S][n]
     HIP_OK(hipMemcpy(C.data(), dC, C.size() * 4, hipMemcpyDeviceToHost));
     for (int i = 0; i < S; ++i) for (int n = 0; n < S; ++n) bad += C[(size_t)i * S + n] != X[(size_t)((i * 37 + 5) % S) * S + n];
     HIP_OK(hipFree(dX)); HIP_OK(hipFree(dP)); HIP_OK(hipFree(dC));
@@ -169,6 +181,7 @@ int main(int argc, char **argv)
         void *h = dlopen(argv[i], RTLD_NOW | RTLD_LOCAL);
         if (!h) { printf("dlopen %s: %s\n", argv[i], dlerror()); return 1; }
         gemm_fn gemm = (gemm_fn)dlsym(h, "mh_gemm_f32");
+        g_gemm_ws = (gemm_ws_fn)dlsym(h, "mh_gemm_ws_bytes");
         int_fn split = (int_fn)dlsym(h, "mh_mfma_split"), rne = (int_fn)dlsym(h, "mh_split_rne");
         if (!gemm || !split || !rne) { printf("missing symbols in %s\n", argv[i]); return 1; }
         if (conv_only) {      // several conv shapes: 256x64 and 128x128 tiles, split-K, ragged Cout, many small images
