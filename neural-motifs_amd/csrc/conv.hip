@@ -210,7 +210,7 @@ __global__ __launch_bounds__(kThreads, MH_MINW) void conv3x3_nhwc_kernel(const C
     });
 }
 
-#if MH_PLANES && !MH_SPLIT_F16     // (f16x3 build: not ported yet -- callers fall back to im2col + GEMM, as in the f32 build)
+#if MH_PLANES
 // ---------------------------------------------------------------------------------------------------------------
 // Weight gradient of the 3x3 / stride 1 / pad 1 conv as an implicit GEMM (no patch matrix):
 //     dW[co][tap][ci] = sum over pixels  gy[pix][co] * x[pix + shift(tap)][ci]        (0 where the tap leaves the image)
@@ -230,6 +230,9 @@ struct WgradArgs {
     int splitk, ktiles_per_split;
     float *out;       // [Cout][9*Cin] (splitk == 1)
     float *partial;   // [splitk][Cout][9*Cin]
+#if MH_SPLIT_F16
+    const int *expA, *expB;   // f16x3: exponent per output channel of gy [Cout] / per input channel of x [Cin], over ALL pixels
+#endif
 };
 
 __global__ void tap_mask_kernel(int B, int H, int W, long long P, long long Ppad, unsigned short *__restrict__ mask)
@@ -309,9 +312,23 @@ __global__ __launch_bounds__(kThreads, MH_MINW) void conv3x3_wgrad_kernel(const 
             sb.v[2 * jt + 1] = buffer_load4(gb, ((m >> 16) & b_bit[jt]) ? b_off[2 * jt + 1] : kOobOffset, b_soff);
         }
     };
+    // f16x3: K = pixels, so an operand "row" is a channel: gy columns scale by their channel's exponent, x columns
+    // (tap, ci) by the exponent of ci (a shift does not change what the channel's maximum bounds)
+    StageExp<BM> ea;
+    StageExp<BN> eb;
+#if MH_SPLIT_F16
+    load_stage_exp<BM>(ea, p.expA, m0, p.Cout, false, tid);
+#pragma unroll
+    for (int jt = 0; jt < NTB; ++jt) {
+        int q, kp;
+        km_task<BN>(tid + kThreads * jt, q, kp);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) eb.km[jt][j] = (n0 + 4 * q + j < N) ? p.expB[(n0 + 4 * q + j) % p.Cin] : 0;
+    }
+#endif
     auto store_tiles = [&](const Stage<BM> &sa, const Stage<BN> &sb, int buf) {
-        store_km<BM>(sa, As(buf), tid);
-        store_km<BN>(sb, Bs(buf), tid);
+        store_km<BM>(sa, As(buf), tid, ea);
+        store_km<BN>(sb, Bs(buf), tid, eb);
     };
 
     Acc acc;
@@ -339,12 +356,16 @@ __global__ __launch_bounds__(kThreads, MH_MINW) void conv3x3_wgrad_kernel(const 
     acc_foreach_pair<false, false>(acc, wm, wn, lane, [&](int r, int c0, int c1, float v0, float v1) {
         const int row = m0 + r, col0 = n0 + c0, col1 = n0 + c1;
         if (row >= p.Cout) return;
+#if MH_SPLIT_F16
+        if (col0 < N) v0 = __builtin_ldexpf(v0, -(p.expA[row] + p.expB[col0 % p.Cin]));
+        if (col1 < N) v1 = __builtin_ldexpf(v1, -(p.expA[row] + p.expB[col1 % p.Cin]));
+#endif
         float *q = dst + (size_t)row * N;
         if (col1 < N) *reinterpret_cast<float2 *>(q + col0) = make_float2(v0, v1);      // N % 4 == 0: col0 is even
         else if (col0 < N) q[col0] = v0;
     });
 }
-#endif  // MH_PLANES && !MH_SPLIT_F16
+#endif  // MH_PLANES
 
 // Packed weights of a 3x3 conv with N output and K input channels (for the dgrad conv the channel roles are swapped
 // and the taps mirrored: flip_transpose): element (tap, n, k) = w[n][k][tap], or w[k][n][8 - tap] when flipped.
@@ -735,13 +756,14 @@ size_t mh_conv3x3_wgrad_ws_bytes(int B, int H, int W, int Cin, int Cout)
     if (P <= 0 || Cin <= 0 || Cout <= 0) return 0;
     const size_t mask = align_up((size_t)(P + 2 * kBK + 16) * sizeof(unsigned short), 256);
     const int s = wgrad_splitk(P, Cin, Cout);
-    return mask + (s > 1 ? align_up((size_t)s * Cout * 9 * Cin * sizeof(float), 256) : 0);
+    const size_t exps = MH_SPLIT_F16 ? align_up((size_t)Cout * sizeof(int), 256) + align_up((size_t)Cin * sizeof(int), 256) : 0;
+    return mask + exps + (s > 1 ? align_up((size_t)s * Cout * 9 * Cin * sizeof(float), 256) : 0);
 }
 
 int mh_conv3x3_wgrad(const float *x, const float *gy, int B, int H, int W, int Cin, int Cout, float *dw,
                      void *workspace, size_t ws_bytes, void *stream)
 {
-#if MH_PLANES && !MH_SPLIT_F16
+#if MH_PLANES
     MH_REQUIRE(x && gy && dw && workspace && B > 0 && H > 0 && W > 0 && Cin > 0 && Cin % 4 == 0 && Cout > 0 && Cout % 4 == 0);
     MH_REQUIRE(((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(gy) | reinterpret_cast<uintptr_t>(dw) |
                  reinterpret_cast<uintptr_t>(workspace)) & 15) == 0);
@@ -767,7 +789,20 @@ int mh_conv3x3_wgrad(const float *x, const float *gy, int B, int H, int W, int C
     MH_REQUIRE(splitk <= 65535);
     p.splitk = splitk;
     p.out = dw;
-    p.partial = reinterpret_cast<float *>(reinterpret_cast<char *>(workspace) + mask_bytes);
+    size_t used = mask_bytes;
+#if MH_SPLIT_F16
+    {
+        int *expA = reinterpret_cast<int *>(reinterpret_cast<char *>(workspace) + used);
+        used += align_up((size_t)Cout * sizeof(int), 256);
+        int *expB = reinterpret_cast<int *>(reinterpret_cast<char *>(workspace) + used);
+        used += align_up((size_t)Cin * sizeof(int), 256);
+        rc = launch_row_exponents(gy, false, Cout, P, Cout, expA, st);
+        if (!rc) rc = launch_row_exponents(x, false, Cin, P, Cin, expB, st);
+        if (rc) return rc;
+        p.expA = expA; p.expB = expB;
+    }
+#endif
+    p.partial = reinterpret_cast<float *>(reinterpret_cast<char *>(workspace) + used);
     dim3 grid((unsigned)(p.tiles_m * p.tiles_n), (unsigned)splitk);
     launch_tile_kernel<conv3x3_wgrad_kernel<128, 128>>(grid, tile_lds_bytes<128, 128, false, false>(), st, p);
     rc = check_launch("conv3x3_wgrad_kernel");

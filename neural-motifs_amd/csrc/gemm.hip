@@ -250,7 +250,7 @@ int launch_row_exponents(const float *X, bool k_contiguous, long long n_rows, lo
     } else {
         hipError_t e = hipMemsetAsync(bits, 0, (size_t)n_rows * sizeof(unsigned), st);
         if (e != hipSuccess) { set_last_error("hipMemsetAsync(row exponents)", e); return (int)e; }
-        const int rows_per_block = (int)std::max<long long>(64, ceil_div(kext, 64LL));
+        const int rows_per_block = (int)std::max<long long>(64, ceil_div(kext, 2048LL));     // up to 2048 row chunks x cols/256 blocks
         hipLaunchKernelGGL(col_absmax_kernel, dim3((unsigned)ceil_div(n_rows, 256LL), (unsigned)ceil_div(kext, (long long)rows_per_block)),
                            dim3(256), 0, st, X, kext, (int)n_rows, ld, rows_per_block, bits);
     }
