@@ -34,7 +34,8 @@ extern "C" {
 int mh_version(void);
 /* how the fp32 matrix products of mh_gemm_* / mh_conv3x3_* are evaluated in this build:
  * 6 = bf16x6 (exact 3-way bf16 split of both operands, six bf16 MFMAs, fp32 accumulate; default),
- * 0 = f32-input MFMA (exact fp32 fma chain), 3 = bf16x3 (2^-17 products; experiments only). */
+ * 0 = f32-input MFMA (exact fp32 fma chain), 3 = three MFMAs per product: bf16x3 (2^-17 products; experiments only) or,
+ * when mh_split_f16() is 1, the experimental row-scaled f16x3 engine. */
 int mh_mfma_split(void);
 /* 1 when the bf16 split rounds to nearest even (build knob MH_SPLIT_RN=1: dropped cross terms <= 2^-24|ab|, zero mean),
  * 0 for the default truncation split (<= 2^-21|ab|, typically 2^-24.5, towards zero) or the f32-MFMA build */
