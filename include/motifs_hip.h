@@ -25,6 +25,7 @@ extern "C" {
 #define MH_OK 0
 #define MH_EINVAL (-1)
 #define MH_EUNSUPPORTED (-2)   /* entry point not available in this build (caller uses the documented alternative) */
+#define MH_EFAULT (-3)         /* an earlier persistent-kernel launch on this device reported a device-side fault */
 
 /* epilogue flags for GEMM / conv */
 #define MH_EPI_NONE 0
@@ -178,7 +179,13 @@ int mh_nhwc_to_nchw(const float *in, int B, int C, int H, int W, float *out, voi
  *   dropout  [L,B,H]  (scaled keep mask, shared over time)
  *   gates    [L,T,B,6H] written when is_training (may be NULL otherwise)
  * The input projection x_t*Wx is hoisted out of the time loop into one MFMA GEMM per layer; the
- * recurrent part is one fused GEMV+gate kernel per (layer,t).
+ * recurrence of a whole layer is ONE persistent launch (a block owns 4 hidden units for all timesteps, Wh slice in
+ * registers, one agent-scope grid barrier per step) when H <= 512, H % 4 == 0, B <= 32; other shapes run one fused
+ * GEMV+gate kernel per (layer,t).
+ * Fault behaviour of the persistent launches (the reference only fprintf's CUDA errors, highway_lstm_kernel.cu:17-29):
+ * the barrier spin is bounded; a block that times out stores 1 into a host-pinned fault word, the launch poisons its
+ * outputs (h / gate gradients) with NaN, and EVERY later mh_hwlstm_* / mh_hwcell_seq_* call on that device returns
+ * MH_EFAULT until mh_fault_clear().  mh_fault_pending() is a host read (no synchronisation): poll it at step end.
  * Backward: out_grad [T,B,H]; outputs x_grad [T,B,in] (overwritten), weight_grad / bias_grad
  * (ACCUMULATED into, caller zero-fills) when do_weight_grad.
  * ------------------------------------------------------------------------------------------- */
@@ -227,6 +234,15 @@ int mh_hwcell_seq_bwd(int H, int B, int T, const int *batch_sizes_host, const fl
                       const float *w_state_t /*[H,5H]*/, float *d_pre /*[N,6H]*/, float *hgrad_buf,
                       float *cgrad_buf /*scratch, B + N rows each*/, void *workspace, size_t ws_bytes,
                       void *stream);
+
+/* Device-side fault state of the persistent kernels above.
+ *   mh_fault_pending(): number of devices whose fault word is set (0 = none); host read, never synchronises.
+ *   mh_fault_clear()  : re-arm the entry points after the caller has discarded the affected results.
+ *   mh_debug_lstm_barrier_fault(enable): TEST HOOK -- while enabled, persistent launches run with an unreachable
+ *                       barrier target, so the time-out path (fault word, NaN poisoning, MH_EFAULT) can be exercised. */
+int mh_fault_pending(void);
+int mh_fault_clear(void);
+int mh_debug_lstm_barrier_fault(int enable);
 
 /* ---------------------------------------------------------------------------------------------
  * Tail of the training step: global grad-norm clip + SGD(momentum, weight decay) as multi-tensor kernels.

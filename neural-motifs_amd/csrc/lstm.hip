@@ -314,14 +314,25 @@ __device__ __forceinline__ StepRows step_rows(const SeqSched &s, int t)
 #define MH_BAR_SLEEP 8
 #endif
 constexpr int kBrokenWord = 48;   // counters: words 0..47 = one per layer, word 48 = "a barrier timed out"
+// Where a timed-out grid barrier is reported: `host_word` is this device's word of a host-pinned, device-mapped array
+// (fault_ctl below) -- the kernel stores 1 there and the NEXT mh_hwlstm_* / mh_hwcell_seq_* call (and mh_fault_pending)
+// reads it on the host without synchronising anything.  `inflate` is the test hook of mh_debug_lstm_barrier_fault: it is
+// added to every barrier target, so the barrier can never complete and the time-out path runs.
+struct FaultCtl {
+    unsigned *host_word;
+    unsigned inflate;
+};
 // Grid-wide barrier for a kernel whose blocks are all resident or will become resident without waiting on this
 // kernel (one block per 4 hidden units: <= 128 blocks).  Release / acquire at agent scope so that the plain stores
-// before the barrier are visible to every XCD after it.  The spin is bounded: on a time-out the kernel runs on
-// (wrong numbers, which the parity tests catch; every later barrier of the call is skipped) instead of hanging the device.
-__device__ __forceinline__ void grid_barrier(unsigned *counters, int slot, unsigned target)
+// before the barrier are visible to every XCD after it.  The spin is bounded: on a time-out the block raises the
+// sticky `broken` word (every later barrier of the launch is skipped, so the device never hangs) AND the host-visible
+// fault word; the kernel then poisons its outputs with NaN (poison_* below) and every later LSTM entry point returns
+// MH_EFAULT until mh_fault_clear().  Nothing downstream can mistake the launch for a good one.
+__device__ __forceinline__ void grid_barrier(unsigned *counters, int slot, unsigned target, const FaultCtl &fc)
 {
     unsigned *counter = counters + slot;
     unsigned *broken = counters + kBrokenWord;    // sticky: set by the first block that times out
+    target += fc.inflate;
     __syncthreads();
     if (threadIdx.x == 0) {
         // release: the block's stores (all waves: ordered before by __syncthreads) become visible at agent scope
@@ -332,10 +343,22 @@ __device__ __forceinline__ void grid_barrier(unsigned *counters, int slot, unsig
                    __hip_atomic_load(broken, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
             if (!done) __builtin_amdgcn_s_sleep(MH_BAR_SLEEP);
         }
-        if (!done) __hip_atomic_store(broken, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (!done) {
+            __hip_atomic_store(broken, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(fc.host_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
         __atomic_thread_fence(__ATOMIC_ACQUIRE);   // acquire (agent scope is HIP's default for this builtin)
     }
     __syncthreads();
+}
+// true (block-uniform) when any barrier of this launch timed out
+__device__ __forceinline__ bool launch_broken(unsigned *counters)
+{
+    __shared__ unsigned flag;
+    __syncthreads();
+    if (threadIdx.x == 0) flag = __hip_atomic_load(counters + kBrokenWord, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    return flag != 0;
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -474,7 +497,7 @@ __global__ __launch_bounds__(kGemvThreads) void hw_layer_fwd_kernel(SeqSched s, 
                                                                    const float *__restrict__ wh_t,
                                                                    const float *__restrict__ bias,
                                                                    const float *__restrict__ dropout, float *gates,
-                                                                   unsigned *counters, int slot)
+                                                                   unsigned *counters, int slot, FaultCtl fc)
 {
     __shared__ __attribute__((aligned(16))) float vs[kNB * kChunk];
     __shared__ float red[4 * 4 * 5 * kNB];
@@ -546,7 +569,18 @@ __global__ __launch_bounds__(kGemvThreads) void hw_layer_fwd_kernel(SeqSched s, 
                 }
             }
         }
-        if (i + 1 < s.T) grid_barrier(counters, slot, ++epoch * gridDim.x);
+        if (i + 1 < s.T) grid_barrier(counters, slot, ++epoch * gridDim.x, fc);
+    }
+    // a timed-out barrier means some step read a stale h_{t-1}: make the whole layer output unmistakably invalid
+    if (launch_broken(counters)) {
+        const float nan = __builtin_nanf("");
+        for (int i = 0; i < s.T; ++i) {
+            const StepRows rw = step_rows(s, i);
+            for (int e = threadIdx.x; e < 4 * rw.n; e += blockDim.x) {
+                const int u = blockIdx.x * 4 + (e & 3);
+                if (u < H) hl[rw.state * H + (size_t)(e >> 2) * H + u] = nan;
+            }
+        }
     }
 }
 
@@ -558,7 +592,8 @@ __global__ __launch_bounds__(kGemvThreads) void hw_layer_bwd_kernel(SeqSched s, 
                                                                    const float *__restrict__ cl,
                                                                    const float *__restrict__ gates,
                                                                    const float *__restrict__ dropout, float *dg_all,
-                                                                   const float *__restrict__ wh, unsigned *counters, int slot)
+                                                                   const float *__restrict__ wh, unsigned *counters, int slot,
+                                                                   FaultCtl fc)
 {
     __shared__ __attribute__((aligned(16))) float vs[kNB * kChunk];
     __shared__ float red[4 * 4 * 1 * kNB];
@@ -621,13 +656,29 @@ __global__ __launch_bounds__(kGemvThreads) void hw_layer_bwd_kernel(SeqSched s, 
                 c_grad[rw.state * H + idx] = forget_gate * d_c;
             }
         }
-        grid_barrier(counters, slot, ++epoch * gridDim.x);
+        grid_barrier(counters, slot, ++epoch * gridDim.x, fc);
         if (i + 1 < s.T) fetch(i + 1, in);
         for (int b0 = 0; b0 < n; b0 += kNB) {
             float tot[1];
             block_gemv_resident<1, 5>(w, dg, 6 * H, true, n, b0, 5 * H, vs, red, tot);
             const int u = blockIdx.x * 4 + (threadIdx.x >> 3), row = b0 + (threadIdx.x & 7);
             if (threadIdx.x < 4 * kNB && u < H && row < n) h_grad[rw.state * H + (size_t)row * H + u] = tot[0];
+        }
+    }
+    // see hw_layer_fwd_kernel: after a timed-out barrier the gate gradients (what the caller's dgrad / wgrad GEMMs read)
+    // and the state gradients of this block's units become NaN
+    if (launch_broken(counters)) {
+        const float nan = __builtin_nanf("");
+        for (int i = 0; i < s.T; ++i) {
+            const StepRows rw = step_rows(s, i);
+            for (int e = threadIdx.x; e < 4 * rw.n; e += blockDim.x) {
+                const int u = blockIdx.x * 4 + (e & 3);
+                if (u >= H) continue;
+                float *dgp = dg_all + (rw.io + (e >> 2)) * 6 * H + u;
+#pragma unroll
+                for (int k = 0; k < 6; ++k) dgp[(size_t)k * H] = nan;
+                h_grad[rw.state * H + (size_t)(e >> 2) * H + u] = nan;
+            }
         }
     }
 }
@@ -682,6 +733,46 @@ static LayerOffsets layer_offsets(int in_size, int H, int layer)
 }
 
 static bool al16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+// ---- device-side fault reporting (see FaultCtl) -------------------------------------------------------------------
+// One host-pinned, device-mapped word per device, allocated once per process on first use (64 words = one 256-B line).
+constexpr int kMaxFaultDevices = 64;
+static unsigned *g_fault_words = nullptr;   // host address == device address (hipHostMallocMapped | Portable, coherent)
+static int g_force_barrier_fault = 0;       // mh_debug_lstm_barrier_fault
+static unsigned *fault_words()
+{
+    if (!g_fault_words) {
+        void *p = nullptr;
+        if (hipHostMalloc(&p, kMaxFaultDevices * sizeof(unsigned), hipHostMallocMapped | hipHostMallocPortable | hipHostMallocCoherent) != hipSuccess)
+            return nullptr;
+        for (int i = 0; i < kMaxFaultDevices; ++i) reinterpret_cast<unsigned *>(p)[i] = 0u;
+        g_fault_words = reinterpret_cast<unsigned *>(p);
+    }
+    return g_fault_words;
+}
+// rc != MH_OK: the allocation failed, or an earlier persistent launch on this device timed out (MH_EFAULT)
+static int fault_ctl(FaultCtl &fc)
+{
+    unsigned *w = fault_words();
+    int dev = 0;
+    if (!w || hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxFaultDevices) {
+        set_last_error("fault word (hipHostMalloc / hipGetDevice)", hipErrorOutOfMemory);
+        return (int)hipErrorOutOfMemory;
+    }
+    if (__atomic_load_n(&w[dev], __ATOMIC_RELAXED) != 0u) {
+        set_last_error("an earlier persistent LSTM launch on this device timed out in its grid barrier: every result since "
+                       "then is invalid (mh_fault_clear() re-arms the entry points)", hipErrorLaunchFailure);
+        return MH_EFAULT;
+    }
+    void *dp = nullptr;
+    if (hipHostGetDevicePointer(&dp, &w[dev], 0) != hipSuccess) {
+        set_last_error("hipHostGetDevicePointer(fault word)", hipErrorInvalidValue);
+        return (int)hipErrorInvalidValue;
+    }
+    fc.host_word = reinterpret_cast<unsigned *>(dp);
+    fc.inflate = g_force_barrier_fault ? 1u : 0u;
+    return MH_OK;
+}
 
 constexpr size_t kCounterBytes = 256;   // grid-barrier counters of the persistent layer kernels (one per layer)
 static bool persistent_ok(int H, int B, int L)
@@ -806,6 +897,8 @@ int mh_hwlstm_fwd(int in_size, int H, int B, int L, int T, const float *x, const
         MH_REQUIRE(b == 0 || lengths_host[b] <= lengths_host[b - 1]);
     }
     MH_REQUIRE(lengths_host[0] == T);
+    FaultCtl fc;
+    MH_TRY(fault_ctl(fc));
     hipStream_t st = as_stream(stream);
     char *ws = reinterpret_cast<char *>(workspace);
     float *tmp_i = reinterpret_cast<float *>(ws);
@@ -842,7 +935,7 @@ int mh_hwlstm_fwd(int in_size, int H, int B, int L, int T, const float *x, const
             SeqSched sched = make_sched(lengths_host, T, B, fwd_dir);
             hipLaunchKernelGGL(hw_layer_fwd_kernel, dim3(ceil_div(H, 4)), dim3(kGemvThreads), 0, st, sched, H, tmp_i, hl, cl,
                                wh_t, bias + (size_t)5 * H * layer, dropout + (size_t)layer * numEl,
-                               is_training ? gates + (size_t)layer * T * 6 * numEl : nullptr, counters, layer);
+                               is_training ? gates + (size_t)layer * T * 6 * numEl : nullptr, counters, layer, fc);
             MH_TRY(check_launch("hw_layer_fwd_kernel"));
             continue;
         }
@@ -893,11 +986,13 @@ int mh_hwcell_seq_fwd(int H, int B, int T, const int *batch_sizes_host, const fl
     MH_REQUIRE(persistent_ok(H, B, 1) && al16(w_state) && al16(h_buf) && al16(workspace));
     SeqSched sched;
     MH_TRY(sched_from_batch_sizes(batch_sizes_host, T, B, sched));
+    FaultCtl fc;
+    MH_TRY(fault_ctl(fc));
     hipStream_t st = as_stream(stream);
     hipError_t e = hipMemsetAsync(workspace, 0, kCounterBytes, st);
     if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL(hw_layer_fwd_kernel, dim3(ceil_div(H, 4)), dim3(kGemvThreads), 0, st, sched, H, pre_i, h_buf, c_buf,
-                       w_state, b_state, dropout, gates, reinterpret_cast<unsigned *>(workspace), 0);
+                       w_state, b_state, dropout, gates, reinterpret_cast<unsigned *>(workspace), 0, fc);
     return check_launch("hw_layer_fwd_kernel");
 }
 
@@ -911,11 +1006,13 @@ int mh_hwcell_seq_bwd(int H, int B, int T, const int *batch_sizes_host, const fl
     MH_REQUIRE(ws_bytes >= kCounterBytes && persistent_ok(H, B, 1) && al16(w_state_t) && al16(d_pre) && al16(workspace));
     SeqSched sched;
     MH_TRY(sched_from_batch_sizes(batch_sizes_host, T, B, sched));
+    FaultCtl fc;
+    MH_TRY(fault_ctl(fc));
     hipStream_t st = as_stream(stream);
     hipError_t e = hipMemsetAsync(workspace, 0, kCounterBytes, st);
     if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL(hw_layer_bwd_kernel, dim3(ceil_div(H, 4)), dim3(kGemvThreads), 0, st, sched, H, dh_all, hgrad_buf,
-                       cgrad_buf, c_buf, gates, dropout, d_pre, w_state_t, reinterpret_cast<unsigned *>(workspace), 0);
+                       cgrad_buf, c_buf, gates, dropout, d_pre, w_state_t, reinterpret_cast<unsigned *>(workspace), 0, fc);
     return check_launch("hw_layer_bwd_kernel");
 }
 
@@ -952,6 +1049,8 @@ int mh_hwlstm_bwd(int in_size, int H, int B, int L, int T, const float *out_grad
         MH_REQUIRE(lengths_host[b] >= 1 && lengths_host[b] <= T);
         MH_REQUIRE(b == 0 || lengths_host[b] <= lengths_host[b - 1]);
     }
+    FaultCtl fc;
+    MH_TRY(fault_ctl(fc));
     hipStream_t st = as_stream(stream);
     const size_t numEl = (size_t)B * H;
     char *ws = reinterpret_cast<char *>(workspace);
@@ -995,7 +1094,7 @@ int mh_hwlstm_bwd(int in_size, int H, int B, int L, int T, const float *out_grad
             SeqSched sched = make_sched(lengths_host, T, B, fwd_dir);
             hipLaunchKernelGGL(hw_layer_bwd_kernel, dim3(ceil_div(H, 4)), dim3(kGemvThreads), 0, st, sched, H, grad_in,
                                h_grad, c_grad, cl, gates + (size_t)layer * T * 6 * numEl,
-                               dropout + (size_t)layer * numEl, dg_all, weight + o.wh, counters, layer);
+                               dropout + (size_t)layer * numEl, dg_all, weight + o.wh, counters, layer, fc);
             MH_TRY(check_launch("hw_layer_bwd_kernel"));
         } else
         for (int i = 0; i < T; ++i) {
@@ -1038,6 +1137,31 @@ int mh_hwlstm_bwd(int in_size, int H, int B, int L, int T, const float *out_grad
         }
         grad_in = inp_grad;
     }
+    return MH_OK;
+}
+
+
+// ---- fault state of the persistent (grid-barrier) kernels --------------------------------------------------------
+int mh_fault_pending(void)
+{
+    const unsigned *w = g_fault_words;
+    if (!w) return 0;
+    int n = 0;
+    for (int i = 0; i < kMaxFaultDevices; ++i) n += (__atomic_load_n(&w[i], __ATOMIC_RELAXED) != 0u) ? 1 : 0;
+    return n;
+}
+
+int mh_fault_clear(void)
+{
+    unsigned *w = g_fault_words;
+    if (w)
+        for (int i = 0; i < kMaxFaultDevices; ++i) __atomic_store_n(&w[i], 0u, __ATOMIC_RELAXED);
+    return MH_OK;
+}
+
+int mh_debug_lstm_barrier_fault(int enable)
+{
+    g_force_barrier_fault = enable ? 1 : 0;
     return MH_OK;
 }
 

@@ -14,7 +14,7 @@ import torch
 
 
 class Blob(object):
-    def __init__(self, mode='det', is_train=False, num_gpus=1, primary_gpu=0, batch_size_per_gpu=3):
+    def __init__(self, mode='det', is_train=False, num_gpus=1, primary_gpu=None, batch_size_per_gpu=3):
         assert mode in ('det', 'rel')
         if num_gpus != 1:
             raise ValueError('one process per GPU: build one Blob(num_gpus=1) per rank')
@@ -75,7 +75,10 @@ class Blob(object):
             self.proposal_chunks = [self.proposals.shape[0]]
 
     def _to_device(self, x):
-        return x.cuda(self.primary_gpu, non_blocking=True)
+        # one process per GPU: the target is the device THIS rank made current (torch.cuda.set_device(local_rank) in
+        # lib/dist.init_from_env / the drivers), unless a caller pins primary_gpu explicitly (reference blob.py:20)
+        dev = torch.cuda.current_device() if self.primary_gpu is None else self.primary_gpu
+        return x.cuda(dev, non_blocking=True)
 
     def scatter(self):
         """move the batch to this process's GPU (asynchronous H2D)"""

@@ -29,6 +29,7 @@ SYMBOLS = (
     'mh_hwlstm_fwd_ws_bytes', 'mh_hwlstm_fwd', 'mh_hwlstm_bwd_ws_bytes', 'mh_hwlstm_bwd',
     'mh_hwlstm_cell_fwd', 'mh_hwlstm_cell_bwd', 'mh_gemv_rows',
     'mh_hwcell_seq_ws_bytes', 'mh_hwcell_seq_fwd', 'mh_hwcell_seq_bwd',
+    'mh_fault_pending', 'mh_fault_clear', 'mh_debug_lstm_barrier_fault',
     'mh_opt_chunk_elems', 'mh_multi_sumsq', 'mh_multi_sgd_step',
     'mh_bn_ws_bytes', 'mh_bn_stats', 'mh_bn_pool_fwd', 'mh_bn_residual_nchw', 'mh_bn_apply_nhwc', 'mh_nchw_to_nhwc_small', 'mh_bn_bwd',
 )
@@ -64,6 +65,31 @@ def _check(rc, what):
     if rc != 0:
         msg = lib().mh_last_error()
         raise HipKernelError('%s failed with status %d: %s' % (what, rc, msg.decode() if msg else ''))
+
+
+def check_faults():
+    """Raise if a persistent kernel (grid-barrier LSTM layers / decoder recurrence) reported a device-side fault since
+    the last mh_fault_clear().  A host read of a pinned word: no synchronisation, so it sees faults of launches that
+    have COMPLETED -- call it after a natural sync point (loss.item(), the eval tuple's D2H copy, optimizer step)."""
+    n = lib().mh_fault_pending()
+    if n:
+        raise HipKernelError('a persistent LSTM launch timed out in its grid barrier on %d device(s): the results of '
+                             'this step are invalid (outputs were NaN-poisoned); call lib().mh_fault_clear() to re-arm' % n)
+
+
+# Parameters updated through raw pointers (mh_multi_sgd_step) never bump torch's `_version`; anything that caches a
+# derived copy of a parameter (packed conv weights, im2col weight matrices) keys it on version_of(p) instead.
+_raw_updates = {}
+
+
+def note_raw_update(p):
+    k = p.data_ptr()
+    _raw_updates[k] = _raw_updates.get(k, 0) + 1
+
+
+def version_of(p):
+    """(torch version counter, raw-pointer update count, storage address) of a parameter"""
+    return (p._version, _raw_updates.get(p.data_ptr(), 0), p.data_ptr())
 
 
 def ptr(t):

@@ -144,7 +144,7 @@ class Conv3x3(nn.Module):
         self._packed_key = None
 
     def packed_weight(self, flip_transpose=False):
-        key = (self.weight.data_ptr(), self.weight._version, flip_transpose, self.weight.device)
+        key = (_hip.version_of(self.weight), flip_transpose, self.weight.device)
         if self._packed_key != key:
             self._packed = _hip.conv3x3_pack_weight(_c(self.weight.detach()), flip_transpose)
             self._packed_key = key

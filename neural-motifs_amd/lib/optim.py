@@ -75,6 +75,9 @@ class FusedClipSGD(torch.optim.Optimizer):
 
     @torch.no_grad()
     def step(self, max_norm=0.0, closure=None):
+        # a persistent LSTM launch of an EARLIER step that timed out (device-side fault word, lib/_hip.check_faults):
+        # refuse to apply gradients on top of it.  Host read, no synchronisation.
+        _hip.check_faults()
         n = self._build_table()
         if n == 0:
             return None
@@ -96,10 +99,11 @@ class FusedClipSGD(torch.optim.Optimizer):
         _hip._check(L.mh_multi_sgd_step(tptr, n, sumsq_ptr, ctypes.c_float(float(max_norm or 0.0)),
                                         ctypes.c_float(g0['momentum']), ctypes.c_float(g0['weight_decay']),
                                         ctypes.c_int(1 if fresh else 0), stream), 'mh_multi_sgd_step')
-        if fresh:
-            for grp in self.param_groups:
-                for p in grp['params']:
-                    if p.grad is not None:
+        for grp in self.param_groups:
+            for p in grp['params']:
+                if p.grad is not None:
+                    _hip.note_raw_update(p)          # the update went through raw pointers: torch's _version is unchanged
+                    if fresh:
                         self.state[p]['fresh'] = False
         self._steps += 1
         return None

@@ -21,6 +21,7 @@ from lib.fpn.nms.functions.nms import apply_nms
 from lib.fpn.proposal_assignments.rel_assignments import rel_assignments
 from lib.fpn.roi_align.functions.roi_align import RoIAlignFunction
 from lib.get_union_boxes import UnionBoxesAndFeats
+from lib import _hip
 from lib import rng as rng_mod
 from lib.hip_ops import Dropout, Flattener, Linear, ReLU, linear
 from lib.lstm.decoder_rnn import DecoderRNN
@@ -373,8 +374,11 @@ class RelModel(nn.Module):
             bboxes = result.rm_box_priors
         rel_rep = F.softmax(result.rel_dists, dim=1)
         self.last_eval_result = result            # raw logits of the last eval forward (tests / debugging)
-        return filter_dets(bboxes, result.obj_scores, result.obj_preds, rel_inds[:, 1:], rel_rep,
-                           to_numpy=not getattr(self, 'eval_on_device', False))
+        to_numpy = not getattr(self, 'eval_on_device', False)
+        out = filter_dets(bboxes, result.obj_scores, result.obj_preds, rel_inds[:, 1:], rel_rep, to_numpy=to_numpy)
+        if to_numpy and x.is_cuda:
+            _hip.check_faults()                   # the D2H copies above synchronised: a timed-out LSTM launch is visible now
+        return out
 
     def __getitem__(self, batch):
         """`detector[blob]` (reference :549-560); one replica per process, see lib/dist.py for the multi-GPU path"""

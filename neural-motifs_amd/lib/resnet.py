@@ -36,7 +36,7 @@ class _Conv(nn.Module):
 
     def _derived(self):
         """weight matrix / packed weights for the kernel in use, rebuilt only when the parameter changes"""
-        key = (self.weight._version, self.weight.data_ptr())
+        key = _hip.version_of(self.weight)
         if self._cache[0] != key:
             w = self.weight.detach()
             cout, cin, k = w.shape[0], w.shape[1], self.k

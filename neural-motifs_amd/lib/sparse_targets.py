@@ -1,10 +1,14 @@
 """
 FrequencyBias: log P(predicate | subject class, object class) as an embedding table [151*151, 51]
 (reference lib/sparse_targets.py:11-37).  The reference builds the counts by scanning the VG training set at
-construction time; here the counts are injectable (`fg_matrix` [C,C,P], `bg_matrix` [C,C]) and, when absent and no
-dataset is on disk, come from a seeded synthetic count tensor -- the arithmetic on the counts is
-the reference's (:20-24).
+construction time (`get_counts(must_overlap=True)`, :20); here they are injectable (`fg_matrix` [C,C,P], `bg_matrix`
+[C,C] -- the drivers pass lib.get_dataset_counts.get_counts(train)).  With no counts given the constructor does what
+the reference does when the VG files are on this machine (scan the training split) and only without a dataset on disk
+falls back to a seeded synthetic count tensor (benchmarks / parity tests on random weights).  The
+arithmetic on the counts is the reference's (:20-24).
 """
+import os
+
 import numpy as np
 import torch
 import torch.nn as nn
@@ -21,7 +25,13 @@ class FrequencyBias(nn.Module):
     def __init__(self, eps=1e-3, fg_matrix=None, bg_matrix=None, num_objs=151, num_rels=51):
         super(FrequencyBias, self).__init__()
         if fg_matrix is None or bg_matrix is None:
-            fg_matrix, bg_matrix = synthetic_counts(num_objs, num_rels)
+            from dataloaders.visual_genome import VG, VG_SGG_FN
+            if os.path.exists(VG_SGG_FN):          # a real dataset is in use: never substitute random statistics
+                from lib.get_dataset_counts import get_counts
+                fg_matrix, bg_matrix = get_counts(VG(mode='train', filter_duplicate_rels=False, num_val_im=5000),
+                                                  must_overlap=True)
+            else:
+                fg_matrix, bg_matrix = synthetic_counts(num_objs, num_rels)
         fg_matrix = np.array(fg_matrix, dtype=np.int64)
         bg_matrix = np.array(bg_matrix, dtype=np.int64) + 1
         fg_matrix[:, :, 0] = bg_matrix

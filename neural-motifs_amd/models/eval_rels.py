@@ -35,13 +35,20 @@ if conf.test:
 train_loader, val_loader = VGDataLoader.splits(train, val, mode='rel', batch_size=conf.batch_size,
                                                num_workers=conf.num_workers, num_gpus=1)
 
+# FrequencyBias statistics (reference lib/sparse_targets.py:20: get_counts over the VG training split without duplicate
+# filtering -- what the constructor does itself when the VG files are here); the synthetic stand-in is scanned directly
+freq_counts = None
+if conf.use_bias and not isinstance(train, VG):
+    from lib.get_dataset_counts import get_counts
+    freq_counts = get_counts(train, must_overlap=True)
 detector = RelModel(classes=train.ind_to_classes, rel_classes=train.ind_to_predicates, num_gpus=1, mode=conf.mode,
                     require_overlap_det=True, use_resnet=conf.use_resnet, order=conf.order, nl_edge=conf.nl_edge,
                     nl_obj=conf.nl_obj, hidden_dim=conf.hidden_dim, use_proposals=conf.use_proposals,
                     pass_in_obj_feats_to_decoder=conf.pass_in_obj_feats_to_decoder,
                     pass_in_obj_feats_to_edge=conf.pass_in_obj_feats_to_edge, pooling_dim=conf.pooling_dim,
                     rec_dropout=conf.rec_dropout, use_bias=conf.use_bias, use_tanh=conf.use_tanh,
-                    limit_vision=conf.limit_vision)
+                    limit_vision=conf.limit_vision,
+                    freq_counts=freq_counts)
 detector.cuda()
 if conf.ckpt is not None:
     optimistic_restore(detector, torch.load(conf.ckpt, map_location='cpu')['state_dict'])

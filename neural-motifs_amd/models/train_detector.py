@@ -84,6 +84,8 @@ def train_batch(b):
 
 def train_epoch(epoch_num):
     detector.train()
+    if hasattr(getattr(train_loader, 'sampler', None), 'set_epoch'):
+        train_loader.sampler.set_epoch(epoch_num)        # reshuffle every epoch (reference: DataLoader(shuffle=True))
     tr, start = [], time.time()
     for b, batch in enumerate(train_loader):
         tr.append(train_batch(batch))

@@ -47,13 +47,20 @@ train, val, _ = VG.splits(num_val_im=conf.val_size, filter_duplicate_rels=True, 
 train_loader, val_loader = VGDataLoader.splits(train, val, mode='rel', batch_size=conf.batch_size,
                                                num_workers=conf.num_workers, num_gpus=1, rank=rank, world_size=world)
 
+# FrequencyBias statistics (reference lib/sparse_targets.py:20: get_counts over the VG training split without duplicate
+# filtering -- what the constructor does itself when the VG files are here); the synthetic stand-in is scanned directly
+freq_counts = None
+if conf.use_bias and not isinstance(train, VG):
+    from lib.get_dataset_counts import get_counts
+    freq_counts = get_counts(train, must_overlap=True)
 detector = RelModel(classes=train.ind_to_classes, rel_classes=train.ind_to_predicates, num_gpus=1, mode=conf.mode,
                     require_overlap_det=True, use_resnet=conf.use_resnet, order=conf.order, nl_edge=conf.nl_edge,
                     nl_obj=conf.nl_obj, hidden_dim=conf.hidden_dim, use_proposals=conf.use_proposals,
                     pass_in_obj_feats_to_decoder=conf.pass_in_obj_feats_to_decoder,
                     pass_in_obj_feats_to_edge=conf.pass_in_obj_feats_to_edge, pooling_dim=conf.pooling_dim,
                     rec_dropout=conf.rec_dropout, use_bias=conf.use_bias, use_tanh=conf.use_tanh,
-                    limit_vision=conf.limit_vision)
+                    limit_vision=conf.limit_vision,
+                    freq_counts=freq_counts)
 
 for n, param in detector.detector.named_parameters():      # freeze the detector
     param.requires_grad = False
@@ -119,6 +126,8 @@ def train_batch(b, verbose=False):
 
 def train_epoch(epoch_num):
     detector.train()
+    if hasattr(getattr(train_loader, 'sampler', None), 'set_epoch'):
+        train_loader.sampler.set_epoch(epoch_num)        # reshuffle every epoch (reference: DataLoader(shuffle=True))
     tr, start = [], time.time()
     for b, batch in enumerate(train_loader):
         if conf.max_iters and b >= conf.max_iters:

@@ -354,6 +354,51 @@ def test_hwlstm_fwd_bwd(hip, lengths, in_size, H, nl, p):
     np.testing.assert_array_equal(h2.cpu().numpy(), h_data.cpu().numpy())
 
 
+def test_lstm_barrier_timeout_is_loud(hip):
+    """A persistent LSTM launch whose grid barrier times out must not hand back plausible numbers: with the test hook
+    making the barrier target unreachable, the launch (a) sets the host-visible fault word, (b) NaN-poisons its
+    outputs, (c) makes check_faults() raise and (d) makes the NEXT LSTM entry point return MH_EFAULT; after
+    mh_fault_clear() the same call is bit-identical to an undisturbed one."""
+    L = hip.lib()
+    x, lengths, weight, bias, drop = _lstm_problem([6, 6, 2], 40, 32, 2, seed=5, p=0.0)
+    args = (x.cuda(), lengths, weight.cuda(), bias.cuda(), drop.cuda(), 32, 2, True)
+    good_h, good_c, good_g = hip.hwlstm_fwd(*args)
+    torch.cuda.synchronize()
+    assert L.mh_fault_pending() == 0
+    hip.check_faults()
+    L.mh_debug_lstm_barrier_fault(1)
+    try:
+        h, c, g = hip.hwlstm_fwd(*args)                       # launches; the barrier cannot complete
+        torch.cuda.synchronize()
+        assert L.mh_fault_pending() == 1
+        assert torch.isnan(h[-1, 1:]).any(), 'outputs of a broken launch must be poisoned'
+        with pytest.raises(hip.HipKernelError, match='grid barrier'):
+            hip.check_faults()
+        L.mh_debug_lstm_barrier_fault(0)
+        with pytest.raises(hip.HipKernelError, match='status -3'):       # MH_EFAULT, before anything is launched
+            hip.hwlstm_fwd(*args)
+        pre_i = torch.zeros(3, 6 * 32, device='cuda')
+        with pytest.raises(hip.HipKernelError, match='status -3'):
+            hip.hwcell_seq_fwd(pre_i, [1, 1, 1], torch.zeros(5 * 32, 32, device='cuda'), torch.zeros(5 * 32, device='cuda'), None)
+    finally:
+        L.mh_debug_lstm_barrier_fault(0)
+        L.mh_fault_clear()
+    h2, c2, g2 = hip.hwlstm_fwd(*args)
+    torch.cuda.synchronize()
+    assert L.mh_fault_pending() == 0
+    np.testing.assert_array_equal(h2.cpu().numpy(), good_h.cpu().numpy())
+    # the backward launch has the same protection
+    gout = torch.randn(x.shape[0], x.shape[1], 32, generator=torch.Generator().manual_seed(1)).cuda()
+    L.mh_debug_lstm_barrier_fault(1)
+    try:
+        xg, wg, bg = hip.hwlstm_bwd(gout, x.cuda(), lengths, weight.cuda(), drop.cuda(), 32, 2, good_h, good_c, good_g)
+        torch.cuda.synchronize()
+        assert L.mh_fault_pending() == 1 and not torch.isfinite(xg).all()
+    finally:
+        L.mh_debug_lstm_barrier_fault(0)
+        L.mh_fault_clear()
+
+
 @pytest.mark.parametrize('H,batch_sizes', [(32, [6, 6, 5, 3, 3, 1]), (512, [6] * 9 + [5, 4, 4, 2, 1]), (20, [1, 1, 1])])
 def test_packed_recurrence_single_launch(hip, H, batch_sizes):
     """mh_hwcell_seq_fwd/bwd (one persistent launch, grid barrier per step) == stepping the cell kernels"""
@@ -475,6 +520,33 @@ def test_fused_clip_sgd_matches_torch(hip):
         new_opt.step(max_norm=0.0)
         for p, q in zip(ref_p, new_p):
             np.testing.assert_allclose(q.detach().cpu().numpy(), p.detach().cpu().numpy(), rtol=2e-5, atol=2e-6)
+
+def test_packed_conv_weights_follow_the_fused_optimizer(hip):
+    """FusedClipSGD updates parameters through raw pointers (torch's _version does not move): the cached packed copy
+    of a 3x3 conv weight must still be refreshed, or a no_grad forward after a step runs on stale weights (validation
+    epochs of models/train_detector.py)."""
+    from lib.hip_ops import Conv3x3
+    from lib.optim import FusedClipSGD
+    from lib.resnet import _Conv
+    torch.manual_seed(3)
+    conv = Conv3x3(16, 32).cuda()
+    rconv = _Conv(16, 32, 3, stride=1, pad=1).cuda()
+    x = torch.randn(2, 9, 11, 16, device='cuda')
+    with torch.no_grad():
+        y0 = conv.forward_nhwc(x, 0)
+        r0 = rconv(x)
+    opt = FusedClipSGD(list(conv.parameters()) + list(rconv.parameters()), lr=0.5, momentum=0.9, weight_decay=0.0)
+    for p in list(conv.parameters()) + list(rconv.parameters()):
+        p.grad = torch.randn_like(p)
+    opt.step(max_norm=0.0)
+    with torch.no_grad():
+        y1 = conv.forward_nhwc(x, 0)
+        r1 = rconv(x)
+    for got, w, b, before in ((y1, conv.weight, conv.bias, y0), (r1, rconv.weight, None, r0)):
+        ref = F.conv2d(x.cpu().permute(0, 3, 1, 2), w.detach().cpu(), None if b is None else b.detach().cpu(), padding=1)
+        np.testing.assert_allclose(got.permute(0, 3, 1, 2).cpu().numpy(), ref.numpy(), atol=1e-4)
+        assert (got - before).abs().max() > 1e-2            # the step really moved the output
+
 
 
 def test_device_recall_matches_the_reference_evaluator(hip, golden):
