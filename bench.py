@@ -43,23 +43,23 @@ MODEL_KW = dict(hidden_dim=512, pooling_dim=4096, nl_obj=2, nl_edge=2, order='le
 BATCH, N_BOXES, N_RELS = 6, 20, 30
 
 
-class ConvMeter(object):
-    """HIP-event timing of every conv3x3 implicit-GEMM launch (on the stream the kernel is launched on) plus its
-    algorithmic FLOPs (2*Cin*Cout*9*B*H*W)."""
+class KernelMeter(object):
+    """HIP-event timing of every call of one binding function (events recorded on the stream the kernel is launched
+    on) plus its algorithmic FLOPs.  `flops_of(args, kwargs, result)` -> float."""
 
-    def __init__(self, hip):
-        self.hip, self.orig, self.records, self.enabled = hip, hip.conv3x3_nhwc, [], False
-        hip.conv3x3_nhwc = self
+    def __init__(self, hip, name, flops_of):
+        self.hip, self.name, self.orig, self.flops_of = hip, name, getattr(hip, name), flops_of
+        self.records, self.enabled = [], False
+        setattr(hip, name, self)
 
-    def __call__(self, x, wt, bias, epilogue):
+    def __call__(self, *args, **kwargs):
         if not self.enabled:
-            return self.orig(x, wt, bias, epilogue)
+            return self.orig(*args, **kwargs)
         s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         s.record()
-        y = self.orig(x, wt, bias, epilogue)
+        y = self.orig(*args, **kwargs)
         e.record()
-        B, H, W, Cin = x.shape
-        self.records.append((s, e, 2.0 * B * H * W * Cin * wt.shape[1] * 9))
+        self.records.append((s, e, self.flops_of(args, kwargs, y)))
         return y
 
     def summary(self):
@@ -67,32 +67,66 @@ class ConvMeter(object):
         ms = sum(s.elapsed_time(e) for s, e, _ in self.records)
         flops = sum(f for _, _, f in self.records)
         n = max(len(self.records), 1)
-        return dict(launches=len(self.records), avg_ms=ms / n, flops_per_launch=flops / n,
+        return dict(launches=len(self.records), avg_ms=ms / n, total_ms=ms, flops_per_launch=flops / n,
                     tflops=(flops / (ms * 1e-3) / 1e12) if ms > 0 else 0.0)
 
 
-def cpu_baseline(ds, model_sd):
-    """oracle forward+backward on ONE image of the same workload (bounded sample), all host threads"""
+def _conv_flops(args, kwargs, y):
+    x, wt = args[0], args[1]
+    B, H, W, Cin = x.shape
+    return 2.0 * B * H * W * Cin * wt.shape[1] * 9
+
+
+def _gemm_flops(args, kwargs, y):
+    a = args[0]
+    return 2.0 * y.shape[0] * y.shape[1] * (a.shape[0] if (args[2] if len(args) > 2 else kwargs.get('trans_a', False)) else a.shape[1])
+
+
+def cpu_baseline(ds, model_sd, iters=3, eval_images=4):
+    """The CPU oracle (oracle/model.py, kind "port") on this host's cores, as SURVEY.md section 8d prescribes: the SAME
+    cfg2 step (b = 6: forward + backward of the trainable part) with 1 warm-up + `iters` timed iterations, and the cfg1
+    PredCls evaluation (one image per step, `eval_images` images after one warm-up).  Baseline only -- not a target."""
     from oracle import model as OM
     from dataloaders.synthetic import make_blob
     from lib.fpn.proposal_assignments.proposal_assignments_gtbox import proposal_assignments_gtbox
-    blob = make_blob(ds, [0], is_train=True)
+    torch.set_num_threads(os.cpu_count() or 1)
+    blob = make_blob(ds, range(BATCH), is_train=True)
     a = blob[0]
     rois = torch.cat((a[4][:, :1].float(), a[3]), 1)
     _, _, rel_labels = proposal_assignments_gtbox(rois, a[3], a[4], a[5], 0, rs=np.random.RandomState(0))
     trainable = {k for k in model_sd if not k.startswith('detector.') and model_sd[k].is_floating_point()
                  and 'running_' not in k and 'num_batches' not in k}
-    params = {k: v.clone().requires_grad_(k in trainable) for k, v in model_sd.items()}
     cfg = dict(MODEL_KW, mode='sgcls')
-    t0 = time.time()
-    out = OM.relmodel_forward(params, cfg, a[0], a[1], 0, a[3], a[4], True, OM.HostRNG(0), rel_labels=rel_labels)
-    loss = F.cross_entropy(out['rm_obj_dists'], out['rm_obj_labels']) + \
-        F.cross_entropy(out['rel_dists'], out['rel_labels'][:, -1])
-    loss.backward()
-    dt = time.time() - t0
-    return dict(value=1.0 / dt, unit='img/s', cores=torch.get_num_threads(), kind='port',
-                sample='1 image x (fwd+bwd) of the same SGCls step, %d relation rows, %.1f s, no warm-up'
-                       % (rel_labels.shape[0], dt))
+
+    def train_step():
+        params = {k: v.clone().requires_grad_(k in trainable) for k, v in model_sd.items()}
+        t0 = time.time()
+        out = OM.relmodel_forward(params, cfg, a[0], a[1], 0, a[3], a[4], True, OM.HostRNG(0), rel_labels=rel_labels)
+        loss = F.cross_entropy(out['rm_obj_dists'], out['rm_obj_labels']) + \
+            F.cross_entropy(out['rel_dists'], out['rel_labels'][:, -1])
+        loss.backward()
+        return time.time() - t0
+
+    warm = train_step()
+    times = [train_step() for _ in range(iters)]
+    dt = sum(times) / len(times)
+    # cfg1: PredCls eval, one image per step
+    ecfg = dict(MODEL_KW, mode='predcls')
+    etimes = []
+    with torch.no_grad():
+        for i in range(eval_images + 1):
+            eb = make_blob(ds, [i], is_train=False)[0]
+            t0 = time.time()
+            OM.relmodel_forward({k: v for k, v in model_sd.items()}, ecfg, eb[0], eb[1], 0, eb[3], eb[4], False, OM.HostRNG(0))
+            etimes.append(time.time() - t0)
+    edt = sum(etimes[1:]) / max(len(etimes) - 1, 1)
+    return dict(value=BATCH / dt, unit='img/s', cores=os.cpu_count(), kind='port',
+                sample='cfg2 SGCls step at b=%d (fwd+bwd, %d relation rows): 1 warm-up (%.1f s) + %d timed iterations '
+                       '(%s s), torch threads = os.cpu_count()' % (BATCH, rel_labels.shape[0], warm, iters,
+                                                                 ', '.join('%.1f' % t for t in times)),
+                cfg1_predcls_eval={'value': 1.0 / edt, 'unit': 'img/s',
+                                   'sample': '1 warm-up + %d images, one per step (%s s)' % (
+                                       eval_images, ', '.join('%.2f' % t for t in etimes[1:]))})
 
 
 def main():
@@ -101,6 +135,7 @@ def main():
     ap.add_argument('--steps', type=int, default=10)
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-iters', type=int, default=3, help='timed iterations of the CPU baseline (after 1 warm-up)')
     args = ap.parse_args()
 
     from lib import dist as D
@@ -136,7 +171,8 @@ def main():
     blobs = [make_blob(ds, range(i * BATCH, (i + 1) * BATCH), is_train=True) for i in range(n_img // BATCH)]
     for b in blobs:
         b.scatter()                                           # inputs resident in HBM before the timed region
-    meter = ConvMeter(_hip)
+    meter = KernelMeter(_hip, 'conv3x3_nhwc', _conv_flops)
+    gmeter = KernelMeter(_hip, 'gemm', _gemm_flops)
 
     def step(i):
         res = model[blobs[i % len(blobs)]]
@@ -162,13 +198,13 @@ def main():
     for i in range(args.warmup):
         step(i)
     barrier()
-    meter.enabled = True
+    meter.enabled = gmeter.enabled = True
     t0 = time.time()
     for i in range(args.steps):
         loss = step(args.warmup + i)
     barrier()
     dt = time.time() - t0
-    meter.enabled = False
+    meter.enabled = gmeter.enabled = False
     tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
     if world > 1:
         torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
@@ -176,6 +212,8 @@ def main():
 
     if rank == 0:
         conv = meter.summary()
+        gm = gmeter.summary()
+        _hip.check_faults()
         # `achieved` counts ALGORITHMIC fp32 flops (2*M*N*K of the convolution).  The peak is the matrix-core peak for
         # the way this build evaluates an fp32 product: six bf16 MFMAs per product (bf16x6, fp32-accurate) or the
         # f32-input MFMA.
@@ -213,11 +251,19 @@ def main():
                          'launches': conv['launches'], 'avg_launch_ms': conv['avg_ms'],
                          'flops_per_launch': conv['flops_per_launch']},
         }
+        line['roofline_gemm'] = {
+            'bound': 'mfma', 'kernel': 'gemm_kernel (fc6/fc7 x3 fwd+dgrad+wgrad, LSTM input projections, heads): every '
+                                       'mh_gemm_f32 call of the step, split-K reduces included',
+            'achieved': gm['tflops'], 'peak': peak, 'unit': 'TFLOP/s', 'frac': gm['tflops'] / peak,
+            'launches': gm['launches'], 'ms_per_step': gm['total_ms'] / args.steps,
+            'flops_per_step': gm['flops_per_launch'] * gm['launches'] / args.steps,
+            'note': 'HIP-event time of the calls; some run concurrently with the other HIP stream (context branch)'}
+        line['roofline']['ms_per_step'] = conv['total_ms'] / args.steps
         if sd_cpu is not None:
             try:
-                line['cpu_baseline'] = cpu_baseline(ds, sd_cpu)
+                line['cpu_baseline'] = cpu_baseline(ds, sd_cpu, iters=args.cpu_iters)
             except Exception as ex:                          # the baseline must never take the bench line down
-                line['cpu_baseline'] = {'value': None, 'unit': 'img/s', 'cores': torch.get_num_threads(),
+                line['cpu_baseline'] = {'value': None, 'unit': 'img/s', 'cores': os.cpu_count(),
                                         'kind': 'port', 'sample': 'failed: %r' % (ex,)}
         print(json.dumps(line), flush=True)
     if world > 1:

@@ -141,7 +141,12 @@ int mh_gemm_f32(int transA, int transB, int M, int N, int K, const float *A, int
 size_t mh_conv3x3_packed_floats(int Cout, int Cin);
 int mh_conv3x3_pack_weight(const float *w, int Cout, int Cin, int flip_transpose, float *wt,
                            void *stream);
-size_t mh_conv3x3_ws_bytes(int B, int H, int W, int Cin, int Cout);   /* split-K scratch (0 if not split) */
+size_t mh_conv3x3_ws_bytes(int B, int H, int W, int Cin, int Cout);   /* partial-sum scratch (0 if no tile is split) */
+/* The tile schedule mh_conv3x3_nhwc uses for this shape (diagnostics / tests; pure host arithmetic):
+ * out8_host = {block rows BM, block cols BN, m-tiles, n-tiles, uniform K split of the body tiles, body m-tiles,
+ * tail tiles, K slices per tail tile}.  Tiles beyond the last full round of resident blocks (2 per CU) form the tail
+ * and are cut along K, so that the leftover occupies the whole chip briefly instead of a few CUs for a block time. */
+int mh_conv3x3_schedule(int B, int H, int W, int Cin, int Cout, int *out8_host);
 int mh_conv3x3_nhwc(const float *in, int B, int H, int W, int Cin, const float *wt, int Cout,
                     const float *bias, int epilogue, float *out, void *workspace, size_t ws_bytes,
                     void *stream);

@@ -10,6 +10,7 @@
 //   B = packed weights wt[tap][co][ci/16][hi|mid|lo planes] (bf16x6 build).  Epilogue fuses bias + ReLU/ReLU6.
 // The same kernel computes dgrad when given flip-transposed weights (mh_conv3x3_pack_weight).
 #include <algorithm>
+#include <cstdlib>
 
 #include <type_traits>
 #include "mfma_tile.h"
@@ -29,8 +30,16 @@ struct ConvArgs {
     int epilogue;
     float *out;
     int tiles_m, tiles_n;
-    int splitk, ktiles_per_split;
-    float *partial;   // [splitk][M][Cout] when splitk > 1
+    // Tile schedule (conv_schedule): the grid is 1-D.  Blocks [0, tail_tiles * tail_slices) are the TAIL: the tiles left
+    // over after the last full round of resident blocks, each cut into tail_slices K slices so that the leftover keeps
+    // the whole chip busy for 1/tail_slices of a block time instead of a few CUs for a whole one.  The remaining
+    // body_tiles * splitk blocks are the BODY: whole tiles (splitk == 1, the normal case: direct epilogue, no partial
+    // sums) or, for layers with fewer tiles than resident slots, tiles cut uniformly into splitk slices.
+    int body_tiles, splitk, ktiles_per_split;
+    int tail_tiles, tail_slices, tail_ktiles;
+    long long tail_row0;   // first output row of the tail tiles (= body m-tiles * BM)
+    float *partial;        // body:  [splitk][tail_row0][Cout]       when splitk > 1
+    float *partial_tail;   // tail:  [tail_slices][M - tail_row0][Cout] when tail_slices > 1
 #if MH_SPLIT_F16
     const int *expA;  // f16x3: exponent per OUTPUT pixel [M], covering its 3x3 input neighbourhood (pixel_exponents)
     const int *expW;  // exponent per output channel [Cout] (tail of the packed weights)
@@ -54,8 +63,22 @@ __global__ __launch_bounds__(kThreads, MH_MINW) void conv3x3_nhwc_kernel(const C
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     int wm, wn;
     wave_origin<BM, BN>(wave, wm, wn);
-    const int ntiles = p.tiles_m * p.tiles_n;
-    const int t = xcd_remap(blockIdx.x, ntiles);
+    // block -> (tile, K slice), see ConvArgs
+    const int tail_blocks = p.tail_tiles * p.tail_slices;
+    const bool is_tail = (int)blockIdx.x < tail_blocks;
+    int t, slice, kt_per_slice, nslices;
+    if (is_tail) {
+        t = p.body_tiles + (int)blockIdx.x / p.tail_slices;
+        slice = (int)blockIdx.x % p.tail_slices;
+        kt_per_slice = p.tail_ktiles;
+        nslices = p.tail_slices;
+    } else {
+        const int bb = (int)blockIdx.x - tail_blocks;
+        t = xcd_remap(bb % p.body_tiles, p.body_tiles);
+        slice = bb / p.body_tiles;
+        kt_per_slice = p.ktiles_per_split;
+        nslices = p.splitk;
+    }
     // consecutive tiles walk over Cout first: they share the same input pixels (A panel) in L2
     const long long m0 = (long long)(t / p.tiles_n) * BM;
     const int n0 = (t % p.tiles_n) * BN;
@@ -103,8 +126,8 @@ __global__ __launch_bounds__(kThreads, MH_MINW) void conv3x3_nhwc_kernel(const C
 
     const int kt_per_tap = p.Cin / kBK;
     const int total_kt = 9 * kt_per_tap;
-    const int kt_begin = blockIdx.y * p.ktiles_per_split;
-    const int kt_end = min(total_kt, kt_begin + p.ktiles_per_split);
+    const int kt_begin = slice * kt_per_slice;
+    const int kt_end = min(total_kt, kt_begin + kt_per_slice);
 
     // `live` = false: every load becomes a zero-returning out-of-range access (see gemm_kernel)
 #if MH_PLANES
@@ -179,12 +202,14 @@ __global__ __launch_bounds__(kThreads, MH_MINW) void conv3x3_nhwc_kernel(const C
         step(std::integral_constant<int, 1>{}, kt + 1);
     }
 
-    if (p.splitk > 1) {
-        float *dst = p.partial + (size_t)blockIdx.y * Mtot * p.Cout;
+    if (nslices > 1) {
+        // partial sums of this K slice: rows are numbered from the first row of the block's region (body / tail)
+        const long long region_row0 = is_tail ? p.tail_row0 : 0, region_rows = is_tail ? Mtot - p.tail_row0 : p.tail_row0;
+        float *dst = (is_tail ? p.partial_tail : p.partial) + (size_t)slice * region_rows * p.Cout;
         acc_foreach_pair<true, true>(acc, wm, wn, lane, [&](int r, int c0, int c1, float v0, float v1) {
             const long long row = m0 + r;
             if (row >= Mtot) return;
-            float *q = dst + (size_t)row * p.Cout + n0;
+            float *q = dst + (size_t)(row - region_row0) * p.Cout + n0;
 #if MH_SPLIT_F16
             if (n0 + c0 < p.Cout) v0 = unscale(row, n0 + c0, v0);
             if (n0 + c1 < p.Cout) v1 = unscale(row, n0 + c1, v1);
@@ -666,20 +691,112 @@ int mh_conv3x3_pack_weight(const float *w, int Cout, int Cin, int flip_transpose
     return check_launch("pack_weight_kernel");
 }
 
-static int conv_splitk(long long M, int Cin, int Cout)
+// Tile schedule of one conv launch (see ConvArgs).  `slots` = blocks resident at once (2 per CU: VGPR-bound).
+struct ConvSchedule {
+    int bm, bn, tiles_m, tiles_n;
+    int splitk;          // uniform K split of the body tiles
+    int body_mtiles;     // m-tiles (all their n-tiles) in the body
+    int tail_slices;     // K slices of each tail tile (1 = no split)
+};
+constexpr int kSlots = 512;
+
+static ConvSchedule conv_schedule(long long M, int Cin, int Cout)
 {
+    ConvSchedule sc;
     const bool narrow = (Cout <= 64);
-    const long long tiles = ((M + (narrow ? 255 : 127)) / (narrow ? 256 : 128)) * ceil_div(Cout, narrow ? 64 : 128);
-    return choose_splitk_tiles(tiles, 9 * (Cin / kBK), (double)M * Cout, 2.0 * 9 * Cin * (double)Cout * M);
+    sc.bm = narrow ? 256 : 128;
+    sc.bn = narrow ? 64 : 128;
+    sc.tiles_m = (int)((M + sc.bm - 1) / sc.bm);
+    sc.tiles_n = ceil_div(Cout, sc.bn);
+    const int total_kt = 9 * (Cin / kBK);
+    const long long tiles = (long long)sc.tiles_m * sc.tiles_n;
+    const double t1 = 2.0 * 9 * Cin * (double)sc.bm * sc.bn / (170e12 / 256.0);   // seconds per tile on a fully occupied CU
+    const double out_bytes = (double)M * Cout * 4.0;
+    static const int cand[] = {1, 2, 3, 4, 5, 6, 8};
+    double best = 1e30;
+    sc.splitk = 1; sc.body_mtiles = sc.tiles_m; sc.tail_slices = 1;
+    // A/B switch for measurements: MH_CONV_SCHEDULE=uniform restores the round-1 schedule (every tile split alike)
+    static const bool uniform = [] { const char *e = getenv("MH_CONV_SCHEDULE"); return e && e[0] == 'u'; }();
+    if (uniform) {
+        sc.splitk = choose_splitk_tiles(tiles, total_kt, (double)M * Cout, 2.0 * 9 * Cin * (double)Cout * M);
+        return sc;
+    }
+    for (int s0 : cand) {
+        if (s0 > 1 && (total_kt / s0 < 12 || tiles * s0 > 4 * kSlots)) break;
+        const long long bpm = (long long)sc.tiles_n * s0;              // blocks per m-tile
+        const long long rounds = tiles * s0 / kSlots;                  // full rounds of resident blocks
+        long long body_m = (rounds >= 1) ? std::min<long long>(sc.tiles_m, rounds * kSlots / bpm) : 0;
+        if (rounds == 0 || body_m <= 0) body_m = sc.tiles_m;           // everything is resident at once: no tail to cut off
+        const long long body_blocks = body_m * bpm;
+        const long long tail_tiles = ((long long)sc.tiles_m - body_m) * sc.tiles_n;
+        // the tail's K slices (>= 8 k-tiles each): minimise  rounds(tail blocks) / slices  + the partial-sum round trip
+        int tsl = 1;
+        double tail_cost = 0.0;
+        if (tail_tiles > 0) {
+            double best_tail = 1e30;
+            const int max_sl = std::max(1, std::min(total_kt / 8, 64));
+            for (int c = s0; c <= std::max(s0, max_sl); ++c) {
+                const long long tb = tail_tiles * c;
+                const double rounds_t = (double)(tb / kSlots) * 2.0 + ((tb % kSlots) == 0 ? 0.0 : (tb % kSlots) <= kSlots / 2 ? 1.0 / 0.6 : 2.0);
+                const double cst = rounds_t * t1 / c + (c > 1 ? (double)tb * sc.bm * sc.bn * 8.0 / 4.0e12 + 3e-6 : 0.0);
+                if (cst < best_tail * 0.97) { best_tail = cst; tsl = c; }
+            }
+            tail_cost = best_tail;
+        }
+        const double t_block = 2.0 * t1 / s0;                          // two co-resident blocks share a CU
+        double cost;
+        if (rounds == 0) {
+            const long long blocks = tiles * s0;
+            cost = t1 / s0 * (blocks <= kSlots / 2 ? 1.0 / 0.6 : 2.0);
+        } else {
+            const double body_rounds = (double)((body_blocks + kSlots - 1) / kSlots);
+            cost = body_rounds * t_block + tail_cost;
+        }
+        if (s0 > 1) cost += out_bytes * 2.0 * s0 / 4.0e12 + 4e-6;     // body partial sums: write + read
+        if (cost < best * 0.97) {
+            best = cost;
+            sc.splitk = s0; sc.body_mtiles = (int)body_m; sc.tail_slices = tsl;
+        }
+    }
+    if (sc.body_mtiles == sc.tiles_m) sc.tail_slices = 1;
+    return sc;
+}
+
+// bytes of partial sums behind the pixel exponents (f16x3) in the workspace: body region, then tail region
+static void conv_partial_bytes(const ConvSchedule &sc, long long M, int Cin, int Cout, size_t &body, size_t &tail)
+{
+    const int total_kt = 9 * (Cin / kBK);
+    const long long row0 = std::min<long long>(M, (long long)sc.body_mtiles * sc.bm);
+    const int s0 = ceil_div(total_kt, ceil_div(total_kt, sc.splitk));
+    body = (s0 > 1) ? align_up((size_t)s0 * row0 * Cout * sizeof(float), 256) : 0;
+    const int tk = ceil_div(total_kt, sc.tail_slices), ts = ceil_div(total_kt, tk);
+    tail = (ts > 1 && row0 < M) ? align_up((size_t)ts * (M - row0) * Cout * sizeof(float), 256) : 0;
 }
 
 size_t mh_conv3x3_ws_bytes(int B, int H, int W, int Cin, int Cout)
 {
     const long long M = (long long)B * H * W;
     if (M <= 0 || Cin <= 0 || Cout <= 0 || Cin % kBK != 0) return 0;
-    const int s = conv_splitk(M, Cin, Cout);
+    const ConvSchedule sc = conv_schedule(M, Cin, Cout);
+    size_t body, tail;
+    conv_partial_bytes(sc, M, Cin, Cout, body, tail);
     const size_t exps = MH_SPLIT_F16 ? 2 * align_up((size_t)M * sizeof(int), 256) : 0;   // pixel exponents + their scratch
-    return exps + (s > 1 ? align_up((size_t)s * M * Cout * sizeof(float), 256) : 0);
+    return exps + body + tail;
+}
+
+int mh_conv3x3_schedule(int B, int H, int W, int Cin, int Cout, int *out8_host)
+{
+    const long long M = (long long)B * H * W;
+    MH_REQUIRE(out8_host && M > 0 && Cin > 0 && Cin % kBK == 0 && Cout > 0);
+    const ConvSchedule sc = conv_schedule(M, Cin, Cout);
+    const int total_kt = 9 * (Cin / kBK);
+    const int tk = ceil_div(total_kt, sc.tail_slices);
+    out8_host[0] = sc.bm; out8_host[1] = sc.bn; out8_host[2] = sc.tiles_m; out8_host[3] = sc.tiles_n;
+    out8_host[4] = ceil_div(total_kt, ceil_div(total_kt, sc.splitk));
+    out8_host[5] = sc.body_mtiles;
+    out8_host[6] = (sc.tiles_m - sc.body_mtiles) * sc.tiles_n;
+    out8_host[7] = (sc.tiles_m > sc.body_mtiles) ? ceil_div(total_kt, tk) : 1;
+    return MH_OK;
 }
 
 int mh_conv3x3_nhwc(const float *in, int B, int H, int W, int Cin, const float *wt, int Cout, const float *bias,
@@ -694,14 +811,13 @@ int mh_conv3x3_nhwc(const float *in, int B, int H, int W, int Cin, const float *
     p.in = in; p.B = B; p.H = H; p.W = W; p.Cin = Cin; p.wt = wt; p.Cout = Cout; p.bias = bias;
     p.epilogue = epilogue; p.out = out;
     const long long M = (long long)B * H * W;
-    const bool narrow = (Cout <= 64);
-    const int bm = narrow ? 256 : 128, bn = narrow ? 64 : 128;
-    p.tiles_m = (int)((M + bm - 1) / bm);
-    p.tiles_n = ceil_div(Cout, bn);
+    ConvSchedule sc = conv_schedule(M, Cin, Cout);
+    const bool narrow = (sc.bn == 64);
+    p.tiles_m = sc.tiles_m;
+    p.tiles_n = sc.tiles_n;
     const long long ntiles = (long long)p.tiles_m * p.tiles_n;
-    MH_REQUIRE(ntiles < (1LL << 31));
+    MH_REQUIRE(ntiles < (1LL << 29));
     const int total_kt = 9 * (Cin / kBK);
-    int splitk = conv_splitk(M, Cin, Cout);
 #if MH_SPLIT_F16
     {   // pixel exponents at the head of the workspace (mh_conv3x3_ws_bytes counts them): mandatory in this build
         const size_t eb = align_up((size_t)M * sizeof(int), 256);
@@ -720,19 +836,36 @@ int mh_conv3x3_nhwc(const float *in, int B, int H, int W, int Cin, const float *
         ws_bytes -= 2 * eb;
     }
 #endif
-    if (splitk > 1 && (workspace == nullptr || ws_bytes < (size_t)splitk * M * Cout * sizeof(float))) splitk = 1;
-    p.ktiles_per_split = ceil_div(total_kt, splitk);
-    splitk = ceil_div(total_kt, p.ktiles_per_split);
-    p.splitk = splitk;
+    size_t body_bytes, tail_bytes;
+    conv_partial_bytes(sc, M, Cin, Cout, body_bytes, tail_bytes);
+    if (body_bytes + tail_bytes > 0 && (workspace == nullptr || ws_bytes < body_bytes + tail_bytes)) {
+        sc.splitk = 1; sc.body_mtiles = sc.tiles_m; sc.tail_slices = 1;     // no room for partial sums: whole tiles only
+        body_bytes = tail_bytes = 0;
+    }
+    p.body_tiles = sc.body_mtiles * sc.tiles_n;
+    p.ktiles_per_split = ceil_div(total_kt, sc.splitk);
+    p.splitk = ceil_div(total_kt, p.ktiles_per_split);
+    p.tail_tiles = (sc.tiles_m - sc.body_mtiles) * sc.tiles_n;
+    p.tail_ktiles = ceil_div(total_kt, sc.tail_slices);
+    p.tail_slices = ceil_div(total_kt, p.tail_ktiles);
+    p.tail_row0 = std::min<long long>(M, (long long)sc.body_mtiles * sc.bm);
     p.partial = reinterpret_cast<float *>(workspace);
-    dim3 grid((unsigned)ntiles, (unsigned)splitk);
+    p.partial_tail = reinterpret_cast<float *>(reinterpret_cast<char *>(workspace) + body_bytes);
+    const long long nblocks = (long long)p.tail_tiles * p.tail_slices + (long long)p.body_tiles * p.splitk;
+    MH_REQUIRE(nblocks > 0 && nblocks < (1LL << 31));
+    dim3 grid((unsigned)nblocks);
     if (narrow)
         launch_tile_kernel<conv3x3_nhwc_kernel<256, 64>>(grid, tile_lds_bytes<256, 64, true, true>(), as_stream(stream), p);
     else
         launch_tile_kernel<conv3x3_nhwc_kernel<128, 128>>(grid, tile_lds_bytes<128, 128, true, true>(), as_stream(stream), p);
     int rc = check_launch("conv3x3_nhwc_kernel");
-    if (rc || splitk == 1) return rc;
-    return launch_splitk_reduce(p.partial, splitk, M, Cout, out, Cout, bias, epilogue, 0, as_stream(stream));
+    if (rc) return rc;
+    if (p.splitk > 1 && p.tail_row0 > 0)
+        rc = launch_splitk_reduce(p.partial, p.splitk, p.tail_row0, Cout, out, Cout, bias, epilogue, 0, as_stream(stream));
+    if (!rc && p.tail_tiles > 0 && p.tail_slices > 1)
+        rc = launch_splitk_reduce(p.partial_tail, p.tail_slices, M - p.tail_row0, Cout, out + (size_t)p.tail_row0 * Cout, Cout,
+                                  bias, epilogue, 0, as_stream(stream));
+    return rc;
 }
 
 // dW [Cout][9*Cin] (tap-major, then input channel) of the 3x3 conv from x [B,H,W,Cin] and gy [B,H,W,Cout], without

@@ -22,7 +22,7 @@ SYMBOLS = (
     'mh_nms_ws_bytes', 'mh_nms', 'mh_nms_batched_ws_bytes', 'mh_nms_batched',
     'mh_roi_align_fwd', 'mh_roi_align_bwd', 'mh_draw_union_boxes', 'mh_bbox_overlaps', 'mh_triplet_match',
     'mh_gemm_ws_bytes', 'mh_gemm_auto_splitk', 'mh_gemm_f32',
-    'mh_conv3x3_packed_floats', 'mh_conv3x3_pack_weight', 'mh_conv3x3_ws_bytes', 'mh_conv3x3_nhwc',
+    'mh_conv3x3_packed_floats', 'mh_conv3x3_pack_weight', 'mh_conv3x3_ws_bytes', 'mh_conv3x3_schedule', 'mh_conv3x3_nhwc',
     'mh_conv3x3_wgrad_ws_bytes', 'mh_conv3x3_wgrad', 'mh_conv_first_nchw', 'mh_maxpool2x2_nhwc',
     'mh_maxpool2x2_bwd_nhwc', 'mh_act_bwd',
     'mh_im2col_nhwc', 'mh_nchw_to_nhwc', 'mh_nhwc_to_nchw',
@@ -286,6 +286,14 @@ def conv3x3_nhwc(x, wt, bias, epilogue):
                                ptr(ws), c_size_t(ws.numel() if ws is not None else 0), stream())
     _check(rc, 'mh_conv3x3_nhwc')
     return out
+
+
+def conv3x3_schedule(B, H, W, Cin, Cout):
+    """dict of the tile schedule mh_conv3x3_nhwc uses for this shape (host arithmetic only)"""
+    out = (ctypes.c_int * 8)()
+    _check(lib().mh_conv3x3_schedule(B, H, W, Cin, Cout, out), 'mh_conv3x3_schedule')
+    keys = ('bm', 'bn', 'tiles_m', 'tiles_n', 'splitk', 'body_mtiles', 'tail_tiles', 'tail_slices')
+    return dict(zip(keys, list(out)))
 
 
 def conv3x3_wgrad(x, gy):
