@@ -789,6 +789,12 @@ int launch_row_exponents(const float *X, bool k_contiguous, long long n_rows, lo
                          hipStream_t st, bool bits_only = false);
 #endif
 int choose_splitk_tiles(long long tiles, int ktiles, double out_elems, double flops);
+// defined in conv.hip: the tile schedule of a 3x3 conv launch with bm x bn block tiles (ConvArgs explains the fields)
+struct ConvTilePlan {
+    int tiles_m, tiles_n, splitk, body_mtiles, tail_slices;
+};
+constexpr int kConvSlots = 512;   // blocks resident at once: 2 per CU
+ConvTilePlan plan_conv_tiles(long long M, int Cin, int Cout, int bm, int bn);
 int launch_splitk_reduce(const float *partial, int splitk, long long M, int N, float *C, int ldc, const float *bias,
                          int epilogue, int accumulate, hipStream_t st);
 
