@@ -3,6 +3,7 @@
 // their dgrad/wgrad).  Block tile 128x128x16, LDS double-buffered with register prefetch (one barrier per
 // k-tile), optional split-K with a fused bias/activation reduction.  See mfma_tile.h for the tile engine.
 #include <algorithm>
+#include <cstdlib>
 
 #include <type_traits>
 #include "mfma_tile.h"
@@ -23,6 +24,7 @@ struct GemmArgs {
     float *partial;  // [splitk][M][N] when splitk > 1
     int vecA, vecB, vecC;
     int tiles_m, tiles_n;
+    int patch_h, patch_w;     // patch-major tile order (mfma_tile.h: patch_tile)
 #if MH_SPLIT_F16
     const int *expA, *expB;   // f16x3: power-of-two exponent per row of op(A) [M] and per column of op(B) [N]
 #endif
@@ -48,7 +50,9 @@ __global__ __launch_bounds__(kThreads, MH_MINW) void gemm_kernel(const GemmArgs 
     wave_origin<BM, BN>(wave, wm, wn);
     const int ntiles = p.tiles_m * p.tiles_n;
     const int t = xcd_remap(blockIdx.x, ntiles);
-    const int m0 = (t / p.tiles_n) * BM, n0 = (t % p.tiles_n) * BN;
+    int tm, tn;
+    patch_tile(t, p.tiles_m, p.tiles_n, p.patch_h, p.patch_w, tm, tn);
+    const int m0 = tm * BM, n0 = tn * BN;
     const int z = blockIdx.y;
     const int total_kt = (p.K + kBK - 1) / kBK;
     const int kt_begin = z * p.ktiles_per_split;
@@ -369,6 +373,18 @@ int mh_gemm_f32(int transA, int transB, int M, int N, int K, const float *A, int
     p.tiles_n = ceil_div(N, narrow ? 64 : 128);
     const long long ntiles = (long long)p.tiles_m * p.tiles_n;
     MH_REQUIRE(ntiles < (1LL << 31) && splitk <= 65535);
+    {   // patch-major tile order: ~64 tiles per patch (what one XCD runs at a time); the operand whose panel is the
+        // more expensive to re-fetch gets the longer patch side.  MH_GEMM_PATCH=rows restores the round-1 order (A/B runs).
+        static const bool rows_order = [] { const char *e = getenv("MH_GEMM_PATCH"); return e && e[0] == 'r'; }();
+        int ph = 8, pw = 8;
+        if (rows_order) { ph = 1; pw = p.tiles_n; }
+        else {
+            if (p.tiles_m < 8) { ph = p.tiles_m; pw = std::min(p.tiles_n, 64 / ph); }
+            else if (p.tiles_n < 8) { pw = p.tiles_n; ph = std::min(p.tiles_m, 64 / pw); }
+        }
+        p.patch_h = std::max(ph, 1);
+        p.patch_w = std::max(pw, 1);
+    }
     dim3 grid((unsigned)ntiles, (unsigned)splitk);
     // FAST: both operands 16-B aligned and their contiguous extents multiples of 4 (see load4_guarded)
     // ... and each operand spans < 1 GiB (32-bit buffer offsets inside a 1 GiB descriptor, see GSrc)

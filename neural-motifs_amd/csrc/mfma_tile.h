@@ -711,6 +711,25 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblocks)
     return start + idx;
 }
 
+// Patch-major numbering of a tiles_m x tiles_n tile space: tiles are numbered patch after patch (ph x pw tiles, row-major
+// inside a patch; bands of ph tile rows, the last band / the last patch of a band may be smaller).  Composed with
+// xcd_remap, the ~64 blocks an XCD runs at any time (32 CUs x 2) form one or two compact patches: they walk K roughly in
+// step, so each k-slice of a patch's ph row panels and pw column panels is fetched from the fabric ONCE per patch and
+// served to the other blocks by that XCD's L2 -- the A operand crosses the fabric tiles_n/pw times and B tiles_m/ph times,
+// instead of 1 and 8 times with the round-1 order (row bands x all columns per XCD).
+__device__ __forceinline__ void patch_tile(int t, int tiles_m, int tiles_n, int ph, int pw, int &tm, int &tn)
+{
+    const int band = t / (ph * tiles_n);
+    int rem = t - band * (ph * tiles_n);
+    const int bh = min(ph, tiles_m - band * ph);
+    const int npw = (tiles_n + pw - 1) / pw;
+    const int j = min(rem / (bh * pw), npw - 1);
+    rem -= j * (bh * pw);
+    const int w = min(pw, tiles_n - j * pw);
+    tm = band * ph + rem / w;
+    tn = j * pw + rem % w;
+}
+
 // Launch a tile kernel with its LDS image as dynamic shared memory (sized by the layout in use: tile_lds_bytes).
 template <auto Kern, typename Args>
 inline void launch_tile_kernel(dim3 grid, size_t lds_bytes, hipStream_t st, const Args &p)
