@@ -77,19 +77,27 @@ def _conv_flops(args, kwargs, y):
     return 2.0 * B * H * W * Cin * wt.shape[1] * 9
 
 
+def _pconv_flops(args, kwargs, y):
+    xp, wt = args[0], args[1]                       # activation planes [B,H,W,Cin/16,3,16]
+    return 2.0 * xp.shape[0] * xp.shape[1] * xp.shape[2] * (xp.shape[3] * 16) * wt.shape[1] * 9
+
+
 def _gemm_flops(args, kwargs, y):
     a = args[0]
     return 2.0 * y.shape[0] * y.shape[1] * (a.shape[0] if (args[2] if len(args) > 2 else kwargs.get('trans_a', False)) else a.shape[1])
 
 
-def cpu_baseline(ds, model_sd, iters=3, eval_images=4):
+def cpu_baseline(ds, model_sd, iters=3, eval_images=3, budget_s=150.0):
     """The CPU oracle (oracle/model.py, kind "port") on this host's cores, as SURVEY.md section 8d prescribes: the SAME
-    cfg2 step (b = 6: forward + backward of the trainable part) with 1 warm-up + `iters` timed iterations, and the cfg1
-    PredCls evaluation (one image per step, `eval_images` images after one warm-up).  Baseline only -- not a target."""
+    cfg2 step (b = 6: forward + backward of the trainable part) with 1 warm-up + up to `iters` timed iterations, and the
+    cfg1 PredCls evaluation (one image per step, `eval_images` images after one warm-up).  Bounded: timed iterations stop
+    once `budget_s` seconds of CPU baseline have been spent (at least one is always timed; the count is reported).
+    Threads: torch's default for this host (one per physical core; oversubscribing the hyperthreads is slower).
+    Baseline only -- not a target."""
     from oracle import model as OM
     from dataloaders.synthetic import make_blob
     from lib.fpn.proposal_assignments.proposal_assignments_gtbox import proposal_assignments_gtbox
-    torch.set_num_threads(os.cpu_count() or 1)
+    t_start = time.time()
     blob = make_blob(ds, range(BATCH), is_train=True)
     a = blob[0]
     rois = torch.cat((a[4][:, :1].float(), a[3]), 1)
@@ -107,10 +115,7 @@ def cpu_baseline(ds, model_sd, iters=3, eval_images=4):
         loss.backward()
         return time.time() - t0
 
-    warm = train_step()
-    times = [train_step() for _ in range(iters)]
-    dt = sum(times) / len(times)
-    # cfg1: PredCls eval, one image per step
+    # cfg1 first (cheap): PredCls eval, one image per step
     ecfg = dict(MODEL_KW, mode='predcls')
     etimes = []
     with torch.no_grad():
@@ -120,10 +125,16 @@ def cpu_baseline(ds, model_sd, iters=3, eval_images=4):
             OM.relmodel_forward({k: v for k, v in model_sd.items()}, ecfg, eb[0], eb[1], 0, eb[3], eb[4], False, OM.HostRNG(0))
             etimes.append(time.time() - t0)
     edt = sum(etimes[1:]) / max(len(etimes) - 1, 1)
-    return dict(value=BATCH / dt, unit='img/s', cores=os.cpu_count(), kind='port',
-                sample='cfg2 SGCls step at b=%d (fwd+bwd, %d relation rows): 1 warm-up (%.1f s) + %d timed iterations '
-                       '(%s s), torch threads = os.cpu_count()' % (BATCH, rel_labels.shape[0], warm, iters,
-                                                                 ', '.join('%.1f' % t for t in times)),
+    warm = train_step()
+    times = [train_step()]
+    while len(times) < iters and time.time() - t_start + times[-1] < budget_s:
+        times.append(train_step())
+    dt = sum(times) / len(times)
+    return dict(value=BATCH / dt, unit='img/s', cores=os.cpu_count(), threads=torch.get_num_threads(), kind='port',
+                sample='cfg2 SGCls step at b=%d (fwd+bwd, %d relation rows): 1 warm-up (%.1f s) + %d timed iteration(s) '
+                       '(%s s); %d torch threads on %d logical cores' % (
+                           BATCH, rel_labels.shape[0], warm, len(times), ', '.join('%.1f' % t for t in times),
+                           torch.get_num_threads(), os.cpu_count() or 0),
                 cfg1_predcls_eval={'value': 1.0 / edt, 'unit': 'img/s',
                                    'sample': '1 warm-up + %d images, one per step (%s s)' % (
                                        eval_images, ', '.join('%.2f' % t for t in etimes[1:]))})
@@ -172,6 +183,7 @@ def main():
     for b in blobs:
         b.scatter()                                           # inputs resident in HBM before the timed region
     meter = KernelMeter(_hip, 'conv3x3_nhwc', _conv_flops)
+    pmeter = KernelMeter(_hip, 'conv3x3_planes', _pconv_flops)      # the frozen trunk's layers (activation planes)
     gmeter = KernelMeter(_hip, 'gemm', _gemm_flops)
 
     def step(i):
@@ -198,20 +210,24 @@ def main():
     for i in range(args.warmup):
         step(i)
     barrier()
-    meter.enabled = gmeter.enabled = True
+    meter.enabled = gmeter.enabled = pmeter.enabled = True
     t0 = time.time()
     for i in range(args.steps):
         loss = step(args.warmup + i)
     barrier()
     dt = time.time() - t0
-    meter.enabled = gmeter.enabled = False
+    meter.enabled = gmeter.enabled = pmeter.enabled = False
     tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
     if world > 1:
         torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
     dt = float(tmax.item())
 
     if rank == 0:
-        conv = meter.summary()
+        c1, c2 = meter.summary(), pmeter.summary()      # both conv3x3 implicit-GEMM kernels together
+        n = max(c1['launches'] + c2['launches'], 1)
+        ms, fl = c1['total_ms'] + c2['total_ms'], c1['flops_per_launch'] * c1['launches'] + c2['flops_per_launch'] * c2['launches']
+        conv = dict(launches=c1['launches'] + c2['launches'], avg_ms=ms / n, total_ms=ms, flops_per_launch=fl / n,
+                    tflops=(fl / (ms * 1e-3) / 1e12) if ms > 0 else 0.0)
         gm = gmeter.summary()
         _hip.check_faults()
         # `achieved` counts ALGORITHMIC fp32 flops (2*M*N*K of the convolution).  The peak is the matrix-core peak for
@@ -240,7 +256,8 @@ def main():
             'config': {'workload': 'SGCls MotifNet VGG16 train step (fwd+bwd+clip+SGD), order=leftright, nl_obj=2, '
                                    'nl_edge=2, hidden 512, batch 6/GPU, 20 GT boxes/img, <=256 rel rows/img, 592x592',
                        'global_batch': world * BATCH, 'parallelism': 'dp%d' % world, 'final_loss': float(loss.item())},
-            'roofline': {'bound': 'mfma', 'kernel': 'conv3x3_nhwc_kernel (implicit GEMM: VGG trunk + union tower); ' + how,
+            'roofline': {'bound': 'mfma', 'kernel': 'conv3x3 implicit GEMM (conv3x3_planes_kernel: %d VGG trunk launches on activation planes; '
+                                                    'conv3x3_nhwc_kernel: %d launches, union tower fwd + dgrad); ' % (c2['launches'], c1['launches']) + how,
                          'achieved': conv['tflops'], 'peak': peak, 'unit': 'TFLOP/s',
                          'frac': conv['tflops'] / peak, 'traffic': traffic['bytes_per_launch'] if traffic else None,
                          'traffic_unit': 'bytes per launch (L2 fabric side: HBM + Infinity-Cache)',
@@ -248,6 +265,8 @@ def main():
                          'traffic_source': TRAFFIC_SUMMARY + ' (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over one '
                                            'launch per shape of this step, tools/traffic_run.sh; not re-measured by this run)',
                          'frac_of_f32_mfma_peak': conv['tflops'] / PEAK_FP32_MFMA_TFLOPS,
+                         'planes_kernel': {'tflops': c2['tflops'], 'ms_per_step': c2['total_ms'] / args.steps},
+                         'nhwc_kernel': {'tflops': c1['tflops'], 'ms_per_step': c1['total_ms'] / args.steps},
                          'launches': conv['launches'], 'avg_launch_ms': conv['avg_ms'],
                          'flops_per_launch': conv['flops_per_launch']},
         }

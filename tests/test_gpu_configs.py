@@ -14,8 +14,11 @@ Bars (BASELINE.json north_star):
     |logit| stays below ~2^7: the reference's *initialisation* of post_lstm (N(0, 10/sqrt(H)), lib/rel_model.py:377-384)
     makes untrained relation logits O(1e2..1e3), where two fp32 evaluation orders of the same sum already differ by
     more than 1e-4 (an ulp at 512 is 6e-5).  Trained MotifNet logits are O(10).  Each config is therefore run twice:
-      - "calibrated": post_lstm.weight scaled by `CAL` so that max |relation logit| is O(10) as in a trained model --
-        the ABSOLUTE 1e-4 bound is asserted (and the absolute error printed);
+      - "calibrated": post_lstm.weight scaled by `CAL` = 0.04, i.e. std 0.4/sqrt(H) = 0.018 at H = 512 -- the Xavier-normal
+        scale of a 512 -> 8192 layer (0.015) instead of 25x that -- so that max |relation logit| is O(10) as in a trained
+        model (measured: ~8, of which up to 6.9 is the frequency bias): the ABSOLUTE 1e-4 bound is asserted (and the
+        absolute error printed).  The measured disagreement of two correct fp32 evaluations of this head is ~1.4e-5 of the
+        largest logit (GPU call r02_c1: 7.0e-3 at max |logit| 483), which is why the bound cannot hold at larger scales;
       - "reference init": weights exactly as the constructor leaves them -- the bound is 1e-4 of the tensor's largest
         magnitude, and the absolute error is printed next to it.
     Both runs use the same code path; only one weight tensor's scale differs.
@@ -30,7 +33,7 @@ pytestmark = pytest.mark.gpu
 MODEL_KW = dict(hidden_dim=512, pooling_dim=4096, nl_obj=2, nl_edge=2, order='leftright', rec_dropout=0.1,
                 use_bias=True, pass_in_obj_feats_to_decoder=False, pass_in_obj_feats_to_edge=False, use_tanh=False,
                 limit_vision=False)
-CAL = 0.5            # post_lstm.weight scale of the "calibrated" runs
+CAL = 0.04           # post_lstm.weight scale of the "calibrated" runs
 ABS_TOL = 1e-4
 
 
