@@ -568,7 +568,7 @@ int mh_conv3x3_planes(const void *in_planes, int B, int H, int W, int Cin, const
 int mh_f32_to_planes(const float *, long long, int, void *, void *) { return MH_EUNSUPPORTED; }
 int mh_planes_to_f32(const void *, long long, int, float *, void *) { return MH_EUNSUPPORTED; }
 size_t mh_conv3x3_planes_ws_bytes(int, int, int, int, int) { return 0; }
-int mh_conv3x3_planes(const void *, int, int, int, int, int, const float *, int, const float *, int, int, void *, float *, void *,
+int mh_conv3x3_planes(const void *, int, int, int, int, const float *, int, const float *, int, int, void *, float *, void *,
                       size_t, void *)
 {
     return MH_EUNSUPPORTED;
