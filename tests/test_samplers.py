@@ -78,3 +78,36 @@ def test_sgdet_rel_assignments_properties():
     assert fg.shape[0] > 0
     for im, s, o, p in fg:
         assert ann[(int(im), int(s) - offs[int(im)], int(o) - offs[int(im)])] == int(p)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# Draw-order equality with the REFERENCE's own samplers (tests/golden/rel_samplers.npz, written by
+# tests/golden/make_golden_samplers.py from lib/fpn/proposal_assignments/{proposal_assignments_gtbox,rel_assignments}.py
+# with numpy's global RNG seeded per case).  np.random.seed(s) and RandomState(s) are the same MT19937 stream.
+# ------------------------------------------------------------------------------------------------------------------
+def test_gtbox_sampler_equals_the_reference_draw_for_draw(golden):
+    import torch
+    from lib.fpn.proposal_assignments.proposal_assignments_gtbox import proposal_assignments_gtbox
+    g = golden('rel_samplers')
+    cases = sorted({k.split('_')[0] for k in g if k.startswith('gt')})
+    assert len(cases) == 5
+    for c in cases:
+        rois, classes, rels = (torch.from_numpy(g[c + '_' + n]) for n in ('rois', 'classes', 'rels'))
+        _, labels, rel_labels = proposal_assignments_gtbox(rois, rois[:, 1:], classes, rels, 0,
+                                                           rs=np.random.RandomState(int(g[c + '_seed'])))
+        np.testing.assert_array_equal(labels.numpy(), g[c + '_labels'])
+        np.testing.assert_array_equal(rel_labels.numpy(), g[c + '_rel_labels'])
+
+
+def test_rel_assignments_equals_the_reference_draw_for_draw(golden):
+    import torch
+    from lib.fpn.proposal_assignments.rel_assignments import rel_assignments
+    g = golden('rel_samplers')
+    cases = sorted({k.split('_')[0] for k in g if k.startswith('ra')})
+    assert len(cases) == 5
+    for c in cases:
+        a = {n: torch.from_numpy(g['%s_%s' % (c, n)]) for n in ('im_inds', 'boxes', 'labels', 'gt_boxes', 'gt_classes', 'gt_rels')}
+        got = rel_assignments(a['im_inds'], a['boxes'], a['labels'], a['gt_boxes'], a['gt_classes'], a['gt_rels'], 0,
+                              filter_non_overlap=bool(g[c + '_fno']), num_sample_per_gt=int(g[c + '_per_gt']),
+                              rs=np.random.RandomState(int(g[c + '_seed'])))
+        np.testing.assert_array_equal(got.numpy(), g[c + '_rel_labels'])
