@@ -313,7 +313,8 @@ class RelModel(nn.Module):
                                                 filter_non_overlap=True, num_sample_per_gt=1, rs=self.sampler_rs)
 
         rel_inds = self.get_rel_inds(result.rel_labels, im_inds, boxes)
-        rois = torch.cat((im_inds[:, None].float(), boxes), 1)
+        self.last_detector_obj_dists = result.rm_obj_dists.detach()   # the detector's logits of the kept boxes (the
+        rois = torch.cat((im_inds[:, None].float(), boxes), 1)        # field is overwritten by the context's below)
         fmap = result.fmap.detach()
 
         def context_branch():

@@ -193,6 +193,17 @@ def detector_forward(sd, cfg, x, im_sizes, image_offset, gt_boxes, gt_classes, t
     return res
 
 
+def sgdet_gt_matching(box_priors, im_inds, gt_boxes, gt_classes):
+    """Labels of detections in SGDet training (lib/object_detector.py:319-326): the class of the GT box of the SAME image
+    with the largest IoU, background (0) when that IoU is below 0.5."""
+    ov = B.bbox_overlaps(box_priors, gt_boxes).clone()
+    ov[im_inds[:, None] != gt_classes[None, :, 0]] = 0.0
+    max_ov, arg = ov.max(1)
+    labels = gt_classes[:, 1][arg].clone()
+    labels[max_ov < 0.5] = 0
+    return labels
+
+
 # --------------------------------------------------------------------------- detector pre-training step (§8f rank 1)
 def _bbox_loss(prior_boxes, deltas, gt_boxes, eps=1e-4):
     """lib/fpn/box_utils.py:8-25"""
@@ -416,15 +427,18 @@ def filter_dets(boxes, obj_scores, obj_classes, rel_inds, pred_scores):
 
 
 def relmodel_forward(sd, cfg, x, im_sizes, image_offset, gt_boxes, gt_classes, training, rng,
-                     rel_labels=None):
+                     rel_labels=None, det_override=None):
     """
     RelModel.forward (rel_model.py:450-547).  `sd` maps the reference's state-dict keys to CPU
     fp32 tensors (BN running stats are updated in place in training mode, as nn.BatchNorm does).
     Training returns a dict of Result fields; eval returns the filter_dets 5-tuple.
+    `det_override`: the detector stage's outputs (fmap, im_inds, rm_box_priors, rm_obj_dists, rm_obj_labels, rel_labels,
+    boxes_all) taken from elsewhere -- stage-wise parity of SGDet TRAINING, where the detections themselves are compared
+    stage by stage (tests/test_gpu_sgdet.py) and the relation model is then run on identical detections.
     """
     with torch.no_grad():   # train_rels.py:50-52 freezes the detector; rel_model.py:491 detaches fmap
-        det = detector_forward(sd, cfg, x, im_sizes, image_offset, gt_boxes, gt_classes, training, rng,
-                               rel_labels)
+        det = det_override if det_override is not None else detector_forward(
+            sd, cfg, x, im_sizes, image_offset, gt_boxes, gt_classes, training, rng, rel_labels)
     if det is None:
         return None
     im_inds = det['im_inds'] - image_offset

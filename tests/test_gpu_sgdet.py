@@ -103,28 +103,74 @@ def test_sgdet_eval_end_to_end(det):
     assert same >= 0.8 * min(boxes.shape[0], rb.shape[0])
 
 
-def test_sgdet_train_step_runs(det):
-    """SGDet training (rows a8/a9): RPN -> NMS -> detections matched to GT -> rel_assignments -> context (decoder with
-    background labels feeding back its own arg-max) -> losses -> backward."""
+def test_sgdet_train_step_parity(det):
+    """SGDet training (rows a8 / a9), stage by stage on identical inputs:
+       detections (RPN -> NMS -> RoI head -> per-class NMS: the stages tested above) ->
+       (1) GT matching of the detections: labels EXACT vs the oracle restatement of object_detector.py:319-326;
+       (2) rel_assignments: the device-resident call inside the model == the same sampler on host copies with the same
+           seed, row for row (the sampler itself is pinned draw-for-draw to the REFERENCE's function by
+           tests/test_samplers.py + tests/golden/rel_samplers.npz);
+       (3) relation model on those detections and rows: object logits / predictions, relation logits, both losses and
+           every parameter gradient vs the oracle."""
+    from lib import rng
+    from lib.fpn.proposal_assignments.rel_assignments import rel_assignments
+    from oracle import model as OM
+    from test_gpu_model import grad_close, rel_close
     ds, model, sd, make_blob = det
+    cfg = dict(mode='sgdet', hidden_dim=256, pooling_dim=4096, nl_obj=2, nl_edge=2, order='confidence', rec_dropout=0.1,
+               use_bias=True, use_tanh=False, limit_vision=False, pass_in_obj_feats_to_decoder=False,
+               pass_in_obj_feats_to_edge=False)
+    model.load_state_dict({k: v.clone() for k, v in sd.items()})
     model.train()
     try:
         blob = make_blob(ds, [0, 1], is_train=True)
-        model.sampler_rs = np.random.RandomState(2)
+        a = blob[0]
         for _, p in model.detector.named_parameters():
             p.requires_grad = False
+        model.zero_grad(set_to_none=True)
+        model.sampler_rs = np.random.RandomState(2)
+        rng.use_host_rng(55)
         res = model[blob]
-        assert res.rel_labels is not None and res.rel_labels.shape[1] == 4
+        rng.use_host_rng(None)
         n_obj = res.rm_obj_dists.shape[0]
-        assert res.rm_obj_labels.shape == (n_obj,) and res.rel_dists.shape == (res.rel_labels.shape[0], 51)
-        assert int(res.rel_labels[:, 1:3].max()) < n_obj
+        assert res.rel_labels is not None and res.rel_labels.shape[1] == 4 and int(res.rel_labels[:, 1:3].max()) < n_obj
         loss = F.cross_entropy(res.rm_obj_dists, res.rm_obj_labels) + F.cross_entropy(res.rel_dists, res.rel_labels[:, -1])
         loss.backward()
-        assert torch.isfinite(loss)
-        grads = [p.grad for n, p in model.named_parameters() if p.requires_grad]
-        assert all(g is not None and torch.isfinite(g).all() for g in grads)
-        print('sgdet train: %d detections, %d relation rows (%d fg), loss %.3f' % (
-            n_obj, res.rel_labels.shape[0], int((res.rel_labels[:, 3] > 0).sum()), loss.item()))
+        im_inds = res.im_inds.cpu()
+        boxes = res.rm_box_priors.detach().cpu()
+        # (1) GT matching
+        labels_ref = OM.sgdet_gt_matching(boxes, im_inds, a[3], a[4])
+        np.testing.assert_array_equal(res.rm_obj_labels.cpu().numpy(), labels_ref.numpy())
+        assert int((labels_ref > 0).sum()) > 0, 'the synthetic detector must match some GT boxes for this test to bite'
+        # (2) relation sampling, host replay with the same seed
+        rel_ref = rel_assignments(im_inds, boxes, labels_ref, a[3], a[4], a[5], 0, filter_non_overlap=True,
+                                  num_sample_per_gt=1, rs=np.random.RandomState(2))
+        np.testing.assert_array_equal(res.rel_labels.cpu().numpy(), rel_ref.numpy())
+        # (3) relation model on identical detections
+        trainable = {n for n, p in model.named_parameters() if p.requires_grad}
+        params = {k: v.clone().requires_grad_(k in trainable) for k, v in sd.items()}
+        override = dict(fmap=res.fmap.detach().float().cpu().contiguous(), im_inds=im_inds, rm_box_priors=boxes,
+                        rm_obj_dists=model.last_detector_obj_dists.cpu(),
+                        od_obj_dists=res.od_obj_dists.detach().cpu(), rm_obj_labels=labels_ref, rel_labels=rel_ref,
+                        boxes_all=res.boxes_all.detach().cpu())
+        out = OM.relmodel_forward(params, cfg, a[0], a[1], 0, a[3], a[4], True, OM.HostRNG(55), det_override=override)
+        np.testing.assert_array_equal(res.obj_preds.cpu().numpy(), out['obj_preds'].numpy())
+        rel_close(res.rm_obj_dists.detach().cpu().numpy(), out['rm_obj_dists'].detach().numpy(), what='sgdet object logits')
+        rel_close(res.rel_dists.detach().cpu().numpy(), out['rel_dists'].detach().numpy(), what='sgdet relation logits')
+        loss_ref = F.cross_entropy(out['rm_obj_dists'], out['rm_obj_labels']) + \
+            F.cross_entropy(out['rel_dists'], out['rel_labels'][:, -1])
+        rel_close(loss.item(), loss_ref.item(), what='sgdet loss')
+        loss_ref.backward()
+        checked = 0
+        for name, p in model.named_parameters():
+            if not p.requires_grad:
+                continue
+            assert p.grad is not None and params[name].grad is not None, name
+            grad_close(p.grad.cpu().numpy(), params[name].grad.numpy(), what='sgdet grad ' + name[-24:])
+            checked += 1
+        assert checked >= 30
+        print('sgdet train parity: %d detections (%d matched to GT), %d relation rows (%d fg), loss %.4f' % (
+            n_obj, int((labels_ref > 0).sum()), rel_ref.shape[0], int((rel_ref[:, 3] > 0).sum()), loss.item()))
     finally:
         model.eval()
         model.zero_grad(set_to_none=True)
