@@ -239,7 +239,7 @@ def main():
             how = 'fp32 products as %d bf16 MFMAs (exact 3-way split, fp32 accumulate): peak = %.0f/%d' % (
                 split, PEAK_BF16_MFMA_TFLOPS, split)
             if _hip.lib().mh_split_f16():
-                how = 'fp32 products as 3 f16 MFMAs (two-term split, row-scaled; experimental build): peak = %.0f/3' % PEAK_BF16_MFMA_TFLOPS
+                how = 'fp32 products as 3 f16 MFMAs (f16x3: two-term f16 split of row-scaled operands, fp32 accumulate): peak = %.0f/3' % PEAK_BF16_MFMA_TFLOPS
         else:
             peak, how = PEAK_FP32_MFMA_TFLOPS, 'v_mfma_f32_32x32x2_f32'
         traffic = None

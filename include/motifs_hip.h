@@ -33,16 +33,17 @@ extern "C" {
 #define MH_EPI_RELU6 2
 
 int mh_version(void);
-/* how the fp32 matrix products of mh_gemm_* / mh_conv3x3_* are evaluated in this build:
- * 6 = bf16x6 (exact 3-way bf16 split of both operands, six bf16 MFMAs, fp32 accumulate; default),
- * 0 = f32-input MFMA (exact fp32 fma chain), 3 = three MFMAs per product: bf16x3 (2^-17 products; experiments only) or,
- * when mh_split_f16() is 1, the experimental row-scaled f16x3 engine. */
+/* how the fp32 matrix products of mh_gemm_* / mh_conv3x3_* are evaluated in this build (MFMAs per fp32 product):
+ * 3 with mh_split_f16() == 1 = f16x3, the DEFAULT: each operand row is scaled by a power of two (its largest magnitude
+ *     lands in [2^14, 2^15)), every element splits into two f16 terms h1 + h2 (|remainder| <= 2^-24 |a|), three f16 MFMAs
+ *     (h1*h1 + h1*h2 + h2*h1) accumulate in fp32, the scales come off exactly in the epilogue;
+ * 6 = bf16x6 (build knob MH_SPLIT_F16=0): exact 3-way bf16 split of both operands, six bf16 MFMAs;
+ * 0 = f32-input MFMA (exact fp32 fma chain; MH_MFMA_SPLIT=0);  3 with mh_split_f16() == 0 = bf16x3 (2^-17; experiments).
+ * Measured error of all builds against float64: profiles/r02_split_check.jsonl (tools/split_check.cpp). */
 int mh_mfma_split(void);
-/* 1 when the bf16 split rounds to nearest even (build knob MH_SPLIT_RN=1: dropped cross terms <= 2^-24|ab|, zero mean),
- * 0 for the default truncation split (<= 2^-21|ab|, typically 2^-24.5, towards zero) or the f32-MFMA build */
+/* 1 when the bf16 split rounds to nearest even (build knob MH_SPLIT_RN=1, bf16x6 builds only) */
 int mh_split_rne(void);
-/* 1 in the EXPERIMENTAL f16x3 build (MH_SPLIT_F16=1: two-term f16 split with a power-of-two scale per operand row, three
- * f16 MFMAs per product; mh_mfma_split() == 3; workspaces then also hold the row exponents; not yet run on hardware) */
+/* 1 in the f16x3 build (the default); workspaces of mh_gemm_f32 / mh_conv3x3_* then also hold the row exponents */
 int mh_split_f16(void);
 /* name of the last kernel-launch error on this thread (for diagnostics), or "" */
 const char *mh_last_error(void);

@@ -29,8 +29,8 @@ def _stale(target, deps):
 
 def build(force=False, verbose=False, out_dir=None):
     """out_dir (or $MH_OUT): where objects and the .so go -- default next to the sources.  A variant build (another
-    MH_MFMA_SPLIT / MH_SPLIT_RN) belongs in its own directory, e.g. csrc/_variants/rn, and is loaded with
-    MOTIFS_HIP_LIB=<that .so> (lib/_hip.py)."""
+    engine: MH_SPLIT_F16=0 -> bf16x6, MH_MFMA_SPLIT=0 -> f32 MFMA, MH_SPLIT_RN=1) belongs in its own directory, e.g.
+    csrc/_variants/bf16x6, and is loaded with MOTIFS_HIP_LIB=<that .so> (lib/_hip.py).  The default build is f16x3."""
     out_dir = os.path.abspath(out_dir or os.environ.get('MH_OUT') or HERE)
     os.makedirs(out_dir, exist_ok=True)
     so = os.path.join(out_dir, os.path.basename(SO))

@@ -31,12 +31,13 @@
 #define MH_MINW 2
 #endif
 #ifndef MH_SPLIT_F16
-#define MH_SPLIT_F16 0    /* 1: EXPERIMENTAL "f16x3" engine: two-term f16 split with a power-of-two scale per operand row,
-                             three v_mfma_f32_32x32x16_f16 per product (not yet run on hardware) */
+#define MH_SPLIT_F16 1    /* 1 (default since round 2): "f16x3" engine -- two-term f16 split with a power-of-two scale per
+                             operand row, three v_mfma_f32_32x32x16_f16 per product; validated on MI355X by the whole
+                             -m gpu suite and tools/split_check (profiles/r02_split_check.jsonl).  0: the bf16x6 engine. */
 #endif
 #ifndef MH_MFMA_SPLIT
-#define MH_MFMA_SPLIT (MH_SPLIT_F16 ? 3 : 6)   /* MFMAs per fp32 product: 6 = bf16x6 (default), 3 = f16x3 with MH_SPLIT_F16 /
-                                                  bf16x3 without (2^-17, tests only), 0 = f32-input MFMA */
+#define MH_MFMA_SPLIT (MH_SPLIT_F16 ? 3 : 6)   /* MFMAs per fp32 product: 3 = f16x3 with MH_SPLIT_F16 (default) / bf16x3 without
+                                                  (2^-17, tests only), 6 = bf16x6 (MH_SPLIT_F16=0), 0 = f32-input MFMA */
 #endif
 #if MH_SPLIT_F16 && MH_MFMA_SPLIT != 3
 #error "MH_SPLIT_F16 needs MH_MFMA_SPLIT == 3"

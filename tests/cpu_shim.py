@@ -176,9 +176,62 @@ def install():
     def check_faults():
         return None
 
+    # ---- FusedClipSGD's two multi-tensor kernels over the SAME chunk table, on host memory (raw pointers via ctypes):
+    # lets the world_size-2 gloo test drive the real optimizer object (pointer table, re-pointed .grad buffers)
+    import ctypes
+    _rec = np.dtype([('p', '<u8'), ('g', '<u8'), ('buf', '<u8'), ('n', '<i4'), ('lr', '<f4')])
+
+    def _val(a):
+        return a.value if hasattr(a, 'value') else a
+
+    def _arr(addr, n, dt=np.float32):
+        return np.ctypeslib.as_array((ctypes.c_float * int(n)).from_address(int(addr))) if dt is np.float32 else None
+
+    def _table(tptr, n):
+        raw = (ctypes.c_uint8 * (int(n) * _rec.itemsize)).from_address(int(_val(tptr)))
+        return np.frombuffer(raw, dtype=_rec, count=int(n))
+
+    class ShimLib(object):
+        @staticmethod
+        def mh_opt_chunk_elems():
+            return 1 << 16
+
+        @staticmethod
+        def mh_fault_pending():
+            return 0
+
+        @staticmethod
+        def mh_multi_sumsq(tptr, n, partial, sumsq, stream):
+            tot = 0.0
+            for r in _table(tptr, _val(n)):
+                g = _arr(r['g'], r['n'])
+                tot += float(np.dot(g.astype(np.float64), g.astype(np.float64)))
+            _arr(_val(sumsq), 1)[0] = tot
+            return 0
+
+        @staticmethod
+        def mh_multi_sgd_step(tptr, n, sumsq, max_norm, momentum, wd, first, stream):
+            max_norm, momentum, wd, first = float(_val(max_norm)), float(_val(momentum)), float(_val(wd)), int(_val(first))
+            scale = 1.0
+            if _val(sumsq) and max_norm > 0:
+                scale = min(1.0, max_norm / (float(np.sqrt(_arr(_val(sumsq), 1)[0])) + 1e-6))
+            for r in _table(tptr, _val(n)):
+                p, g, buf = _arr(r['p'], r['n']), _arr(r['g'], r['n']), _arr(r['buf'], r['n'])
+                d = g * np.float32(scale) + np.float32(wd) * p
+                buf[:] = d if first else np.float32(momentum) * buf + d
+                p -= np.float32(r['lr']) * buf
+            return 0
+
+    def ptr(t):
+        return ctypes.c_void_p(0) if t is None else ctypes.c_void_p(t.data_ptr())
+
+    def stream():
+        return None
+
     for name, fn in list(locals().items()):
         if callable(fn) and hasattr(_hip, name) and name not in ('install',):
             setattr(_hip, name, fn)
-    _hip.lib = lambda: None
+    _hip.f32 = _hip.i32 = ptr
+    _hip.lib = lambda: ShimLib
     blob_mod.Blob._to_device = lambda self, x: x
     return _hip

@@ -57,9 +57,12 @@ def test_argument_validation_needs_no_device(so_path):
     for name in ('mh_conv3x3_packed_floats', 'mh_conv3x3_wgrad_ws_bytes', 'mh_hwcell_seq_ws_bytes', 'mh_hwlstm_fwd_ws_bytes'):
         getattr(lib, name).restype = ctypes.c_size_t
     assert lib.mh_mfma_split() in (0, 3, 6)
-    assert lib.mh_split_f16() == 0             # the f16x3 engine is an experimental variant build
-    assert lib.mh_split_rne() == 0             # the shipped default: truncation split (MH_SPLIT_RN=1 is a variant build)
-    if lib.mh_mfma_split():
+    assert lib.mh_split_f16() == 1 and lib.mh_mfma_split() == 3      # the shipped default since round 2: f16x3
+    assert lib.mh_split_rne() == 0             # (MH_SPLIT_RN=1 is a knob of the bf16x6 variant build)
+    if lib.mh_split_f16():
+        # two f16 planes (= the fp32 byte count) + one dword per (tap, output channel) holding the channel exponents
+        assert lib.mh_conv3x3_packed_floats(128, 64) == 9 * 128 * ((64 // 16) * 16 + 1)
+    elif lib.mh_mfma_split():
         assert lib.mh_conv3x3_packed_floats(128, 64) == 9 * 128 * (64 // 16) * 24     # bf16 planes: 1.5 x the fp32 weights
     else:
         assert lib.mh_conv3x3_packed_floats(128, 64) == 9 * 128 * 64

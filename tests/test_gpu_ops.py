@@ -261,12 +261,19 @@ def test_conv3x3_weight_gradient_implicit_gemm(hip, B, H, W, Cin, Cout):
     scale = float(w.grad.abs().max())
     np.testing.assert_allclose(got.numpy(), w.grad.numpy(), atol=2e-5 * scale)
 
+def _need_planes(hip):
+    if not hip.planes_supported():
+        pytest.skip('activation planes exist in the bf16x6 build only (MH_SPLIT_F16=0); this library is %s'
+                    % ('f16x3' if hip.lib().mh_split_f16() else 'split %d' % hip.lib().mh_mfma_split()))
+
+
 def test_planes_round_trip_is_exact(hip):
-    """fp32 -> (hi, mid, lo) bf16 planes -> fp32 reproduces every bit (the split is exact), also for denormals, huge
-    values and negative zero"""
+    """fp32 -> (hi, mid, lo) bf16 planes -> fp32 reproduces every bit (the split is exact), also for denormals and huge
+    values (the sign of a zero is the one thing a sum of three terms cannot carry)"""
+    _need_planes(hip)
     g = torch.Generator().manual_seed(2)
     x = torch.randn(37, 5, 48, generator=g) * torch.exp2(torch.randint(-40, 40, (37, 5, 48), generator=g).float())
-    x.view(-1)[:6] = torch.tensor([0.0, -0.0, 1e-45, -3e-39, 3.3e38, -1.0])
+    x.view(-1)[:6] = torch.tensor([0.0, 2.0 ** -130, 1e-45, -3e-39, 3.3e38, -1.0])
     p = hip.f32_to_planes(x.cuda())
     assert p.shape == (37, 5, 3, 3, 16) and p.dtype == torch.int16
     back = hip.planes_to_f32(p)
@@ -284,6 +291,7 @@ def test_conv3x3_on_activation_planes(hip, B, H, W, Cin, Cout, pool, f32out):
     """mh_conv3x3_planes (LDS-DMA staging of pre-split operands, fused ReLU [+ 2x2 max-pool], planes or fp32 out) against
     (a) the fp32-activation kernel + the separate pool kernel: BIT-identical wherever a tile is not K-split, 1e-5 of
     scale on K-split tiles (another summation grouping), and (b) the oracle (torch CPU conv) at 1e-4"""
+    _need_planes(hip)
     g = torch.Generator().manual_seed(B * 1000 + H + Cin + Cout)
     x = torch.randn(B, H, W, Cin, generator=g)
     x[0, :2, :3] = 0.0                                          # exact zeros and a big outlier through the split
@@ -311,6 +319,7 @@ def test_conv3x3_on_activation_planes(hip, B, H, W, Cin, Cout, pool, f32out):
 def test_planes_conv_is_bit_identical_on_unsplit_tiles(hip):
     """same planes, same k order, same order of the six bf16 cross terms: with one tile and no K split the two kernels
     must agree in every bit (a changed summation order would show here first)"""
+    _need_planes(hip)
     g = torch.Generator().manual_seed(9)
     for (B, H, W, Cin, Cout) in ((1, 8, 16, 32, 128), (1, 16, 16, 64, 64), (2, 8, 8, 16, 48)):
         x = torch.randn(B, H, W, Cin, generator=g).cuda()
@@ -332,6 +341,7 @@ def test_planes_conv_is_bit_identical_on_unsplit_tiles(hip):
 def test_stem_planes_and_whole_trunk_equal_the_fp32_path(hip, monkeypatch):
     """conv1_1 writing planes == conv1_1 writing fp32, and the whole frozen VGG trunk on planes (fused pools) ==
     the fp32-activation trunk, at a size where no tile is K-split differently... compared at 1e-5 of scale"""
+    _need_planes(hip)
     from lib.hip_ops import VGG16Features
     torch.manual_seed(4)
     x = torch.randn(2, 3, 64, 96).cuda()
