@@ -140,6 +140,133 @@ def cpu_baseline(ds, model_sd, iters=3, eval_images=3, budget_s=150.0):
                                        eval_images, ', '.join('%.2f' % t for t in etimes[1:]))})
 
 
+def secondary(args, rank, world, dev):
+    """Secondary rows (BASELINE.json configs other than the headline cfg2), each ONE JSON line with its own workload name:
+      cfg1  PredCls evaluation, one 592x592 image with 20 GT boxes per step (380 candidate pairs)      -- eval img/s
+      cfg3  SGDet training step, b = 6: RPN -> NMS -> RoI head -> per-class NMS -> <=64 detections/img -> GT matching ->
+            rel_assignments (<=64 rows/img) -> context + relation head, fwd + bwd + clip + SGD             -- train img/s
+      cfg4  ResNet-101 backbone (conv1..layer3, lib/resnet.py) forward at b = 6: the reference's `-resnet` RelModel cannot
+            run (lib/rel_model.py:360-365 vs :448), so the row is the trunk the config is named after       -- trunk img/s
+      cfg5  SGDet evaluation stress, b = 8, max_per_img = 80 -> all overlapping ordered pairs (<= 6320 / img) through the
+            union-box relation head                                                                        -- eval img/s
+    The random-weight detector is made confident (score_fc x30, RPN objectness x4, as tests/test_gpu_sgdet.py does) so that
+    the per-class NMS keeps max_per_img detections per image: the workload is then the configuration's worst case."""
+    from dataloaders.synthetic import SyntheticVG, make_blob
+    from lib import _hip
+    from lib.optim import FusedClipSGD
+    from lib.rel_model import RelModel
+    cfg = args.config
+    torch.manual_seed(1234)
+    cfg_id = int(cfg[3])
+    seed = 1234 + 100 * cfg_id + rank
+    np.random.seed(seed)
+    meter = KernelMeter(_hip, 'conv3x3_nhwc', _conv_flops)
+    gmeter = KernelMeter(_hip, 'gemm', _gemm_flops)
+    extra = {}
+    if cfg == 'cfg4':
+        from lib.object_detector import ObjectDetector
+        det = ObjectDetector(classes=['bg'] + ['c%d' % i for i in range(150)], mode='gtbox', use_resnet=True).to(dev).eval()
+        x = torch.randn(BATCH, 3, 592, 592, device=dev)
+        per_step, unit_name = BATCH, 'images/sec ResNet-101 trunk (conv1..layer3) forward'
+        workload = 'ResNet-101 conv1..layer3 forward (eval-mode BN), batch 6, 592x592 -> [6,1024,37,37]; 97.6 GFLOP/img'
+
+        def step(i):
+            with torch.no_grad():
+                return det.feature_map(x)
+    else:
+        mode = {'cfg1': 'predcls', 'cfg3': 'sgdet', 'cfg5': 'sgdet'}[cfg]
+        b = {'cfg1': 1, 'cfg3': BATCH, 'cfg5': 8}[cfg]
+        n_img = b * 4
+        ds = SyntheticVG(num_images=n_img, seed=seed, n_boxes=N_BOXES, n_rels=N_RELS)
+        kw = dict(MODEL_KW)
+        if mode == 'sgdet':
+            kw['order'] = 'leftright'
+        model = RelModel(classes=ds.ind_to_classes, rel_classes=ds.ind_to_predicates, mode=mode, num_gpus=1,
+                         max_per_img=80 if cfg == 'cfg5' else 64, **kw)
+        for _, p in model.detector.named_parameters():
+            p.requires_grad = False
+        if mode == 'sgdet':
+            with torch.no_grad():
+                model.detector.score_fc.weight.mul_(30.0)
+                model.detector.rpn_head.conv[2].weight.mul_(4.0)
+        model.to(dev)
+        train = cfg == 'cfg3'
+        model.train(train)
+        blobs = [make_blob(ds, range(i * b, (i + 1) * b), is_train=train) for i in range(n_img // b)]
+        for bl in blobs:
+            bl.scatter()
+        per_step = b
+        if train:
+            lr = 1e-3 * world * b
+            fc = [p for n, p in model.named_parameters() if n.startswith('roi_fmap') and p.requires_grad]
+            rest = [p for n, p in model.named_parameters() if not n.startswith('roi_fmap') and p.requires_grad]
+            opt = FusedClipSGD([{'params': fc, 'lr': lr / 10.0}, {'params': rest}], lr=lr, momentum=0.9, weight_decay=1e-4)
+            unit_name = 'images/sec MotifNet-SGDet fwd+bwd'
+            workload = ('SGDet MotifNet VGG16 train step (RPN + NMS + RoI head + per-class NMS -> <=64 detections/img, GT matching, '
+                        'rel_assignments <=64 rows/img, context LSTMs, relation head; fwd+bwd+clip+SGD), batch %d/GPU, 592x592' % b)
+
+            def step(i):
+                res = model[blobs[i % len(blobs)]]
+                loss = F.cross_entropy(res.rm_obj_dists, res.rm_obj_labels) + F.cross_entropy(res.rel_dists, res.rel_labels[:, -1])
+                opt.zero_grad(set_to_none=True)
+                loss.backward()
+                opt.step(max_norm=5.0)
+                extra['dets'], extra['rows'] = int(res.rm_obj_labels.shape[0]), int(res.rel_labels.shape[0])
+                return loss
+        else:
+            model.eval_on_device = True                       # Recall@K inputs stay on the device (no [Nrel,51] D2H per image)
+            unit_name = 'images/sec MotifNet-%s eval' % ('PredCls' if cfg == 'cfg1' else 'SGDet')
+            workload = ('PredCls evaluation forward, 1 image (20 GT boxes -> 380 pairs) per step, VGG16, 592x592' if cfg == 'cfg1' else
+                        'SGDet evaluation forward, batch 8, max_per_img 80 -> all overlapping ordered pairs through the union-box '
+                        'relation head (<= 6320 pairs/img), VGG16, 592x592')
+
+            def step(i):
+                with torch.no_grad():
+                    out = model[blobs[i % len(blobs)]]
+                extra['dets'], extra['rows'] = int(out[0].shape[0]), int(out[3].shape[0])
+                return out
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(i)
+    barrier()
+    meter.enabled = gmeter.enabled = True
+    t0 = time.time()
+    for i in range(args.steps):
+        step(args.warmup + i)
+    barrier()
+    dt = time.time() - t0
+    meter.enabled = gmeter.enabled = False
+    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
+    dt = float(tmax.item())
+    if rank == 0:
+        _hip.check_faults()
+        split = _hip.lib().mh_mfma_split()
+        peak = PEAK_BF16_MFMA_TFLOPS / split if split else PEAK_FP32_MFMA_TFLOPS
+        c, g = meter.summary(), gmeter.summary()
+        dom, dom_name = (g, 'gemm_kernel (relation-head / RoI-head / 1x1-conv GEMMs)') if g['total_ms'] >= c['total_ms'] else \
+            (c, 'conv3x3_nhwc_kernel (implicit GEMM)')
+        line = {'metric': unit_name, 'value': world * per_step * args.steps / dt, 'unit': 'img/s', 'n_gpus': world,
+                'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * dt / args.steps, 'higher_is_better': True,
+                'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+                'config': dict({'workload': workload, 'baseline_config': cfg, 'global_batch': world * per_step,
+                                'parallelism': 'dp%d' % world}, **extra),
+                'roofline': {'bound': 'mfma', 'kernel': dom_name, 'achieved': dom['tflops'], 'peak': peak, 'unit': 'TFLOP/s',
+                             'frac': dom['tflops'] / peak, 'traffic': None, 'ms_per_step': dom['total_ms'] / args.steps,
+                             'launches': dom['launches']},
+                'kernels': {'conv3x3': {'tflops': c['tflops'], 'ms_per_step': c['total_ms'] / args.steps, 'launches': c['launches']},
+                            'gemm': {'tflops': g['tflops'], 'ms_per_step': g['total_ms'] / args.steps, 'launches': g['launches']}}}
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -147,6 +274,8 @@ def main():
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-iters', type=int, default=3, help='timed iterations of the CPU baseline (after 1 warm-up)')
+    ap.add_argument('--config', default='cfg2', choices=['cfg1', 'cfg2', 'cfg3', 'cfg4', 'cfg5'],
+                    help='BASELINE.json configs[i-1]; cfg2 (default) is the headline metric, the others are secondary rows')
     args = ap.parse_args()
 
     from lib import dist as D
@@ -163,6 +292,8 @@ def main():
     from lib.optim import FusedClipSGD
     from lib.rel_model import RelModel
 
+    if args.config != 'cfg2':
+        return secondary(args, rank, world, dev)
     torch.manual_seed(1234)
     np.random.seed(1234 + 200 + rank)
     n_img = BATCH * 4

@@ -264,6 +264,24 @@ int mh_hwcell_seq_bwd(int H, int B, int T, const int *batch_sizes_host, const fl
                       float *cgrad_buf /*scratch, B + N rows each*/, void *workspace, size_t ws_bytes,
                       void *stream);
 
+/* The label decoder's greedy pass in ONE persistent launch (lib/lstm/decoder_rnn.py:205-227: the reference steps a Python
+ * loop of 3 small GEMMs + arg-max + embedding lookup per object): per step the highway-LSTM cell on
+ * enc_proj[row] + emb_proj[label fed], the class logits out = w_out * h + b_out, the arg-max over the non-background
+ * classes (ties to the lower class) and the gather of the next step's embedding row, separated by two grid barriers.
+ *   batch_sizes_host[T] non-increasing (PackedSequence), N = sum;  enc_proj [N,6H] = input projection of the encoder
+ *   part incl. bias;  emb_proj [C+1,6H] = input projection of every label embedding (row 0 = 'start', row l+1 = label l)
+ *   labels [N] int64 or NULL: teacher forcing -- a row whose label is non-zero commits that label, a background row its
+ *   arg-max (training, :205-213); NULL = pure greedy decoding (evaluation)
+ *   outputs: h_buf / c_buf [B+N,H] (first B rows = zero initial state, zeroed by the caller), logits [N,C],
+ *   fed [N] int64 (embedding row used as input of each row), commits [N] int64 (label committed at each row)
+ * Shapes as mh_hwcell_seq_fwd (H <= 512, H % 4 == 0, B <= 32); workspace >= mh_decoder_greedy_ws_bytes(N). */
+size_t mh_decoder_greedy_ws_bytes(int N);
+int mh_decoder_greedy(int H, int B, int T, const int *batch_sizes_host, int C, const float *enc_proj,
+                      const float *emb_proj, const float *w_state, const float *b_state,
+                      const float *dropout /*[B,H] or NULL*/, const float *w_out /*[C,H]*/, const float *b_out,
+                      const long long *labels, float *h_buf, float *c_buf, float *logits, long long *fed,
+                      long long *commits, void *workspace, size_t ws_bytes, void *stream);
+
 /* Device-side fault state of the persistent kernels above.
  *   mh_fault_pending(): number of devices whose fault word is set (0 = none); host read, never synchronises.
  *   mh_fault_clear()  : re-arm the entry points after the caller has discarded the affected results.

@@ -45,7 +45,7 @@ def build(force=False, verbose=False, out_dir=None):
                    '-Wall', '-Wno-unused-function']
             if src in EXACT:
                 cmd += ['-ffp-contract=off']
-            for knob in ('MH_MINW', 'MH_MFMA_SPLIT', 'MH_SPLIT_RN', 'MH_SPLIT_F16', 'MH_CONV_TAP_MAJOR', 'MH_BAR_SLEEP'):
+            for knob in ('MH_MINW', 'MH_MFMA_SPLIT', 'MH_SPLIT_RN', 'MH_SPLIT_F16', 'MH_CONV_TAP_MAJOR', 'MH_BAR_SLEEP', 'MH_F16_VALU'):
                 if os.environ.get(knob):
                     cmd += ['-D%s=%s' % (knob, os.environ[knob])]
             if verbose:

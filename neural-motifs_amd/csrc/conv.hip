@@ -715,7 +715,7 @@ int mh_conv3x3_pack_weight(const float *w, int Cout, int Cin, int flip_transpose
 namespace mh {
 ConvTilePlan plan_conv_tiles(long long M, int Cin, int Cout, int bm, int bn)
 {
-    constexpr int kSlots = kConvSlots;
+    const int kSlots = resident_slots();
     ConvTilePlan sc;
     sc.tiles_m = (int)((M + bm - 1) / bm);
     sc.tiles_n = ceil_div(Cout, bn);
@@ -748,21 +748,14 @@ ConvTilePlan plan_conv_tiles(long long M, int Cin, int Cout, int bm, int bn)
             const int max_sl = std::max(1, std::min(total_kt / 8, 64));
             for (int c = s0; c <= std::max(s0, max_sl); ++c) {
                 const long long tb = tail_tiles * c;
-                const double rounds_t = (double)(tb / kSlots) * 2.0 + ((tb % kSlots) == 0 ? 0.0 : (tb % kSlots) <= kSlots / 2 ? 1.0 / 0.6 : 2.0);
-                const double cst = rounds_t * t1 / c + (c > 1 ? (double)tb * bm * bn * 8.0 / 4.0e12 + 3e-6 : 0.0);
+                const double cst = makespan_units(tb) * t1 / c + (c > 1 ? (double)tb * bm * bn * 8.0 / 4.0e12 + 3e-6 : 0.0);
                 if (cst < best_tail * 0.97) { best_tail = cst; tsl = c; }
             }
             tail_cost = best_tail;
         }
-        const double t_block = 2.0 * t1 / s0;                          // two co-resident blocks share a CU
         double cost;
-        if (rounds == 0) {
-            const long long blocks = tiles * s0;
-            cost = t1 / s0 * (blocks <= kSlots / 2 ? 1.0 / 0.6 : 2.0);
-        } else {
-            const double body_rounds = (double)((body_blocks + kSlots - 1) / kSlots);
-            cost = body_rounds * t_block + tail_cost;
-        }
+        if (rounds == 0) cost = makespan_units(tiles * s0) * t1 / s0;
+        else cost = makespan_units(body_blocks) * t1 / s0 + tail_cost;
         if (s0 > 1) cost += out_bytes * 2.0 * s0 / 4.0e12 + 4e-6;     // body partial sums: write + read
         if (cost < best * 0.97) {
             best = cost;

@@ -437,7 +437,7 @@ static PSchedule planes_schedule(long long M, int Cin, int Cout)
     s.bn = (Cout <= 64) ? 64 : 128;
     if (s.bn == 64) s.bm = 256;
     else if (forced == 128 || forced == 256) s.bm = forced;
-    else s.bm = ((M + 255) / 256) * ceil_div(Cout, 128) >= kConvSlots ? 256 : 128;   // at least one full round of 256-row tiles
+    else s.bm = ((M + 255) / 256) * ceil_div(Cout, 128) >= resident_slots() ? 256 : 128;   // at least one full round of 256-row tiles
     const ConvTilePlan pl = plan_conv_tiles(M, Cin, Cout, s.bm, s.bn);
     s.tiles_m = pl.tiles_m; s.tiles_n = pl.tiles_n; s.splitk = pl.splitk; s.body_mtiles = pl.body_mtiles;
     s.tail_slices = pl.tail_slices;

@@ -266,12 +266,36 @@ int launch_row_exponents(const float *X, bool k_contiguous, long long n_rows, lo
 #endif  // MH_SPLIT_F16
 
 // Work-distribution model shared by GEMM and conv: `tiles` output tiles of `ktiles` k-steps each are cut into
-// S k-slices.  A CU holds two resident blocks (LDS / VGPR budget of the tile engine) and runs them at about half
-// speed each; a CU left with a single block only reaches ~0.6 of its two-block throughput (nothing hides its barrier
-// and LDS latency).  Equal blocks finish in lockstep, so with t1 = one tile on one fully occupied CU the makespan is
-//     floor(blocks / 512) * 2 * t1/S  +  { 0 | t1/S / 0.6 | 2 * t1/S }   for a remainder of { 0 | <= 256 | > 256 }
-// blocks (PMC: the 384-tile fc6 forward at S = 2 ran 1.5 rounds with an average of 1.2 waves per SIMD).  The
-// partial-sum round trip costs S*M*N*8 bytes of HBM traffic.
+// S k-slices.  A CU holds k = resident_slots() / 256 blocks of the tile engine (LDS / VGPR budget) and runs them at
+// 1/k of its speed each; a CU left with fewer blocks only reaches part of its throughput (nothing hides its barrier and
+// LDS latency: ~0.6 with a single block, measured on the bf16x6 engine).  Equal blocks finish in lockstep, so with
+// t1 = one tile on one fully occupied CU the makespan in units of t1/S is
+//     floor(blocks / slots) * k  +  j / f(j),   j = ceil(remainder / 256) blocks per CU in the last round, f(k) = 1
+// (PMC: the 384-tile fc6 forward at S = 2 ran 1.5 rounds with an average of 1.2 waves per SIMD).  The partial-sum round
+// trip costs S*M*N*8 bytes of HBM traffic.
+int resident_slots()
+{
+    static const int slots = [] {
+        const char *e = getenv("MH_SLOTS");
+        const int v = e ? atoi(e) : 0;
+        return (v >= 256 && v % 256 == 0) ? v : (MH_SPLIT_F16 ? 768 : 512);
+    }();
+    return slots;
+}
+
+double makespan_units(long long blocks)
+{
+    const int slots = resident_slots(), k = slots / 256;
+    const long long rem = blocks % slots;
+    double units = (double)(blocks / slots) * k;
+    if (rem) {
+        const int j = (int)((rem + 255) / 256);
+        const double f = (k > 1) ? 0.6 + 0.4 * (double)(j - 1) / (double)(k - 1) : 1.0;
+        units += j / f;
+    }
+    return units;
+}
+
 int choose_splitk_tiles(long long tiles, int ktiles, double out_elems, double flops)
 {
     if (tiles >= 4096 || ktiles < 16) return 1;
@@ -281,11 +305,8 @@ int choose_splitk_tiles(long long tiles, int ktiles, double out_elems, double fl
     int best_s = 1;
     for (int s : cand) {
         if (s > 1 && ktiles / s < 6) break;
-        const long long blocks = tiles * s;
-        const long long rem = blocks % 512;
-        const double units = (double)(blocks / 512) * 2.0 + (rem == 0 ? 0.0 : rem <= 256 ? 1.0 / 0.6 : 2.0);
         const double t_partial = (s > 1) ? (out_elems * 8.0 * s) / 4.0e12 + 4e-6 : 0.0;
-        const double cost = units * t1 / s + t_partial;
+        const double cost = makespan_units(tiles * s) * t1 / s + t_partial;
         if (cost < best * 0.97) { best = cost; best_s = s; }
     }
     return best_s;

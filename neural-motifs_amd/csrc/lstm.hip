@@ -584,6 +584,142 @@ __global__ __launch_bounds__(kGemvThreads) void hw_layer_fwd_kernel(SeqSched s, 
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Greedy label decoder (lib/lstm/decoder_rnn.py:205-227; eval arg-max feedback, and training steps whose GT label is
+// background): the WHOLE decode in one persistent launch.  Per step:
+//   (A) gate math of the block's 4 hidden units; the input projection is enc_proj[row] + emb_proj[prev label + 1] (the
+//       embedding-row gather of the label chosen at the previous step), the state projection is the resident-weight GEMV
+//   -- grid barrier --  (h_t complete)
+//   (B) the class logits: block j owns classes j, j + gridDim.x, ...; one wave per (class, row) dot product of length H;
+//       every non-background logit is folded into the row's 64-bit arg-max key with atomicMax
+//       (order-preserving fp32 image in the high word, 2^32-1-class in the low word: ties go to the LOWER class, which is
+//       what the reference's max(1)[1] returns)
+//   -- grid barrier --  (keys complete) -> every block decodes the winner for its next step's gather.
+// Outputs: the states h/c, the logits of every row (= self.out(h), no second pass in eval), the label fed at each row
+// (`fed`, embedding index = label + 1, 0 = 'start') and the committed label of each row.
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned long long logit_key(float v, int cls)
+{
+    unsigned u = __float_as_uint(v);
+    u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+    return ((unsigned long long)u << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned)cls);
+}
+__device__ __forceinline__ int key_class(unsigned long long k) { return (int)(0xFFFFFFFFu - (unsigned)(k & 0xFFFFFFFFull)); }
+
+__global__ __launch_bounds__(kGemvThreads) void hw_decoder_greedy_kernel(
+    SeqSched s, int H, int C, const float *__restrict__ enc_proj, const float *__restrict__ emb_proj,
+    const float *__restrict__ wh_t, const float *__restrict__ bias, const float *__restrict__ dropout,
+    const float *__restrict__ w_out, const float *__restrict__ b_out, const long long *__restrict__ labels, float *hl,
+    float *cl, float *logits, long long *fed, long long *commits, unsigned long long *keys, unsigned *counters, FaultCtl fc)
+{
+    __shared__ __attribute__((aligned(16))) float vs[kNB * kChunk];
+    __shared__ float red[4 * 4 * 5 * kNB];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, grp = lane >> 4;
+    const int ug = blockIdx.x * 4 + grp;
+    const bool u_ok = ug < H;
+    const int us = u_ok ? ug : 0;
+    const float *const wrow[5] = {wh_t + ((size_t)0 * H + us) * H, wh_t + ((size_t)1 * H + us) * H,
+                                  wh_t + ((size_t)2 * H + us) * H, wh_t + ((size_t)3 * H + us) * H,
+                                  wh_t + ((size_t)4 * H + us) * H};
+    WResident<5, 1> w;
+    load_resident<5, 1>(w, wrow, u_ok, true, H);
+    float bias_u[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+    {
+        const int u = blockIdx.x * 4 + (threadIdx.x >> 3);
+        if (bias && threadIdx.x < 4 * kNB && u < H)
+#pragma unroll
+            for (int k = 0; k < 5; ++k) bias_u[k] = bias[k * H + u];
+    }
+    // label committed at row `r` of the previous step (rows r < n of step t belong to the same sequences as rows r of
+    // step t-1: sequences are sorted by decreasing length)
+    auto committed = [&](size_t row) -> long long {
+        const unsigned long long k = __hip_atomic_load(keys + row, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const long long best = key_class(k);
+        if (labels) {
+            const long long l = labels[row];
+            return l != 0 ? l : best;
+        }
+        return best;
+    };
+    unsigned epoch = 0;
+    StepRows prev_rw = step_rows(s, 0);
+    for (int i = 0; i < s.T; ++i) {
+        const StepRows rw = step_rows(s, i);
+        const int n = rw.n;
+        const float *h_prev = hl + rw.before * H, *c_prev = cl + rw.before * H;
+        float *h_out = hl + rw.state * H, *c_out = cl + rw.state * H;
+        for (int b0 = 0; b0 < n; b0 += kNB) {
+            const int u = blockIdx.x * 4 + (threadIdx.x >> 3), row = b0 + (threadIdx.x & 7);
+            const bool mine = threadIdx.x < 4 * kNB && u < H && row < n;
+            const size_t o = (size_t)row * H + u;
+            float pv[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, cp = 0.f, dm = 1.f;
+            if (mine) {
+                const long long p = (i == 0) ? 0 : committed(prev_rw.io + row) + 1;
+                if (blockIdx.x == 0 && (threadIdx.x >> 3) == 0) fed[rw.io + row] = p;
+                const float *pi = enc_proj + (rw.io + row) * 6 * H + u;
+                const float *pe = emb_proj + (size_t)p * 6 * H + u;
+#pragma unroll
+                for (int k = 0; k < 6; ++k) pv[k] = pi[(size_t)k * H] + pe[(size_t)k * H];
+                cp = c_prev[o];
+                if (dropout) dm = dropout[o];
+            }
+            float th[5];
+            block_gemv_resident<5, 1>(w, h_prev, H, true, n, b0, H, vs, red, th);
+            if (mine) {
+                float g[5];
+#pragma unroll
+                for (int k = 0; k < 5; ++k) g[k] = pv[k] + th[k] + bias_u[k];
+                const float in_gate = sigmoidf_ref(g[0]);
+                const float forget_gate = sigmoidf_ref(g[1]);
+                const float act_gate = tanhf(g[2]);
+                const float out_gate = sigmoidf_ref(g[3]);
+                const float r_gate = sigmoidf_ref(g[4]);
+                const float lin_gate = pv[5];
+                float val = (forget_gate * cp) + (in_gate * act_gate);
+                c_out[o] = val;
+                val = out_gate * tanhf(val);
+                val = (float)((double)(val * r_gate) + (1. - (double)r_gate) * (double)lin_gate);
+                if (dropout) val = val * dm;
+                h_out[o] = val;
+            }
+        }
+        grid_barrier(counters, 0, ++epoch * gridDim.x, fc);
+        // (B) logits of this step: (class, row) pairs of this block round-robin over its 4 waves
+        const int ncls = (C > (int)blockIdx.x) ? (C - 1 - (int)blockIdx.x) / (int)gridDim.x + 1 : 0;
+        for (int q = wave; q < ncls * n; q += 4) {
+            const int c = (int)blockIdx.x + (q / n) * (int)gridDim.x, b = q % n;
+            const float *wr = w_out + (size_t)c * H, *hv = h_out + (size_t)b * H;
+            float acc = 0.f;
+            for (int k = 4 * lane; k < H; k += 256) {
+                const float4 a = *reinterpret_cast<const float4 *>(wr + k), x = *reinterpret_cast<const float4 *>(hv + k);
+                acc = fmaf(a.x, x.x, acc); acc = fmaf(a.y, x.y, acc); acc = fmaf(a.z, x.z, acc); acc = fmaf(a.w, x.w, acc);
+            }
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
+            if (lane == 0) {
+                const float v = acc + (b_out ? b_out[c] : 0.f);
+                logits[(rw.io + b) * C + c] = v;
+                if (c >= 1) atomicMax(keys + rw.io + b, logit_key(v, c));
+            }
+        }
+        grid_barrier(counters, 0, ++epoch * gridDim.x, fc);
+        if (blockIdx.x == 0 && (int)threadIdx.x < n) commits[rw.io + threadIdx.x] = committed(rw.io + threadIdx.x);
+        prev_rw = rw;
+    }
+    if (launch_broken(counters)) {
+        const float nan = __builtin_nanf("");
+        for (int i = 0; i < s.T; ++i) {
+            const StepRows rw = step_rows(s, i);
+            for (int e = threadIdx.x; e < 4 * rw.n; e += blockDim.x) {
+                const int u = blockIdx.x * 4 + (e & 3);
+                if (u < H) hl[rw.state * H + (size_t)(e >> 2) * H + u] = nan;
+            }
+            if (blockIdx.x == 0)
+                for (int e = threadIdx.x; e < rw.n * C; e += blockDim.x) logits[rw.io * C + e] = nan;
+        }
+    }
+}
+
 // backward of one layer: per step  (A) elementWise_bp for the block's own units -> d_gates[t], c_grad[t+1];
 // grid barrier;  (B) h_grad[t+1][:, own units] = d_gates[t][:, :5H] * Wh[own units, :]^T  (K = 5H, weights resident).
 // (A) of the next step only needs the block's own h_grad / c_grad entries, so one barrier per step suffices.
@@ -1014,6 +1150,33 @@ int mh_hwcell_seq_bwd(int H, int B, int T, const int *batch_sizes_host, const fl
     hipLaunchKernelGGL(hw_layer_bwd_kernel, dim3(ceil_div(H, 4)), dim3(kGemvThreads), 0, st, sched, H, dh_all, hgrad_buf,
                        cgrad_buf, c_buf, gates, dropout, d_pre, w_state_t, reinterpret_cast<unsigned *>(workspace), 0, fc);
     return check_launch("hw_layer_bwd_kernel");
+}
+
+// The greedy decoder in one launch (hw_decoder_greedy_kernel).  Workspace: barrier counters + one 64-bit arg-max key per row.
+size_t mh_decoder_greedy_ws_bytes(int N) { return kCounterBytes + align_up((size_t)std::max(N, 1) * sizeof(unsigned long long), 256); }
+
+int mh_decoder_greedy(int H, int B, int T, const int *batch_sizes_host, int C, const float *enc_proj, const float *emb_proj,
+                      const float *w_state, const float *b_state, const float *dropout, const float *w_out, const float *b_out,
+                      const long long *labels, float *h_buf, float *c_buf, float *logits, long long *fed, long long *commits,
+                      void *workspace, size_t ws_bytes, void *stream)
+{
+    MH_REQUIRE(H > 0 && C > 1 && enc_proj && emb_proj && w_state && w_out && h_buf && c_buf && logits && fed && commits && workspace);
+    MH_REQUIRE(persistent_ok(H, B, 1) && al16(w_state) && al16(h_buf) && al16(workspace) && al16(w_out));
+    SeqSched sched;
+    MH_TRY(sched_from_batch_sizes(batch_sizes_host, T, B, sched));
+    long long N = 0;
+    for (int t = 0; t < T; ++t) N += batch_sizes_host[t];
+    MH_REQUIRE(ws_bytes >= mh_decoder_greedy_ws_bytes((int)N));
+    FaultCtl fc;
+    MH_TRY(fault_ctl(fc));
+    hipStream_t st = as_stream(stream);
+    hipError_t e = hipMemsetAsync(workspace, 0, mh_decoder_greedy_ws_bytes((int)N), st);
+    if (e != hipSuccess) return (int)e;
+    unsigned long long *keys = reinterpret_cast<unsigned long long *>(reinterpret_cast<char *>(workspace) + kCounterBytes);
+    hipLaunchKernelGGL(hw_decoder_greedy_kernel, dim3(ceil_div(H, 4)), dim3(kGemvThreads), 0, st, sched, H, C, enc_proj, emb_proj,
+                       w_state, b_state, dropout, w_out, b_out, labels, h_buf, c_buf, logits, fed, commits, keys,
+                       reinterpret_cast<unsigned *>(workspace), fc);
+    return check_launch("hw_decoder_greedy_kernel");
 }
 
 // workspace layout (backward): d_gates_all [T*B,6H] | h_grad [T+1,B,H] | c_grad [T+1,B,H] | below_grad x2 [T,B,H]

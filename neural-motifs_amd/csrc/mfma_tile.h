@@ -772,10 +772,13 @@ __device__ __forceinline__ void half_step(LoadFn load_far, StoreFn store_next, c
 #if MH_SPLIT_F16
     __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);        // fragment reads (two planes)
     __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);
+#ifndef MH_F16_VALU
+#define MH_F16_VALU 7     /* split / address VALU instructions the scheduler may place behind each MFMA (build knob for A/B) */
+#endif
 #pragma unroll
-    for (int i = 0; i < 12; ++i) {                            // untuned: same recipe as below at half the MFMA count
+    for (int i = 0; i < 12; ++i) {                            // same recipe as the bf16x6 loop below at half the MFMA count
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x002, 7, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, MH_F16_VALU, 0);
         __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
     }
     __syncthreads();
@@ -813,7 +816,10 @@ int choose_splitk_tiles(long long tiles, int ktiles, double out_elems, double fl
 struct ConvTilePlan {
     int tiles_m, tiles_n, splitk, body_mtiles, tail_slices;
 };
-constexpr int kConvSlots = 512;   // blocks resident at once: 2 per CU
+// blocks of a tile kernel resident at once: 256 CUs x (3 in the f16x3 build: 154-156 VGPRs, 32 KB LDS; 2 in the bf16x6 build:
+// ~190 VGPRs, 48 KB).  MH_SLOTS overrides it for A/B runs of the schedules.
+int resident_slots();
+double makespan_units(long long blocks);   // time of `blocks` equal blocks in units of (one block alone on a full CU)
 ConvTilePlan plan_conv_tiles(long long M, int Cin, int Cout, int bm, int bn);
 int launch_splitk_reduce(const float *partial, int splitk, long long M, int N, float *C, int ldc, const float *bias,
                          int epilogue, int accumulate, hipStream_t st);

@@ -31,6 +31,7 @@ SYMBOLS = (
     'mh_hwlstm_fwd_ws_bytes', 'mh_hwlstm_fwd', 'mh_hwlstm_bwd_ws_bytes', 'mh_hwlstm_bwd',
     'mh_hwlstm_cell_fwd', 'mh_hwlstm_cell_bwd', 'mh_gemv_rows',
     'mh_hwcell_seq_ws_bytes', 'mh_hwcell_seq_fwd', 'mh_hwcell_seq_bwd',
+    'mh_decoder_greedy_ws_bytes', 'mh_decoder_greedy',
     'mh_fault_pending', 'mh_fault_clear', 'mh_debug_lstm_barrier_fault',
     'mh_opt_chunk_elems', 'mh_multi_sumsq', 'mh_multi_sgd_step',
     'mh_bn_ws_bytes', 'mh_bn_stats', 'mh_bn_pool_fwd', 'mh_bn_residual_nchw', 'mh_bn_apply_nhwc', 'mh_nchw_to_nhwc_small', 'mh_bn_bwd',
@@ -57,7 +58,8 @@ def lib():
         L.mh_last_error.restype = ctypes.c_char_p
         for name in ('mh_nms_ws_bytes', 'mh_nms_batched_ws_bytes', 'mh_gemm_ws_bytes', 'mh_conv3x3_ws_bytes', 'mh_bn_ws_bytes',
                      'mh_conv3x3_packed_floats', 'mh_hwcell_seq_ws_bytes', 'mh_conv3x3_wgrad_ws_bytes',
-                     'mh_hwlstm_fwd_ws_bytes', 'mh_hwlstm_bwd_ws_bytes', 'mh_planes_bytes', 'mh_conv3x3_planes_ws_bytes'):
+                     'mh_hwlstm_fwd_ws_bytes', 'mh_hwlstm_bwd_ws_bytes', 'mh_planes_bytes', 'mh_conv3x3_planes_ws_bytes',
+                     'mh_decoder_greedy_ws_bytes'):
             getattr(L, name).restype = ctypes.c_size_t
         _lib = L
     return _lib
@@ -515,6 +517,26 @@ def hwcell_seq_bwd(dh_all, batch_sizes, c_buf, gates, dropout, w_state_t):
                                  c_size_t(ws.numel()), stream())
     _check(rc, 'mh_hwcell_seq_bwd')
     return d_pre
+
+
+def decoder_greedy(enc_proj, emb_proj, batch_sizes, w_state, b_state, dropout, w_out, b_out, labels=None):
+    """the label decoder's greedy pass in one launch (mh_decoder_greedy).  Returns (h_all [N,H], logits [N,C],
+    fed [N] int64 embedding rows, commits [N] int64 labels)"""
+    N, H, C = enc_proj.shape[0], w_state.shape[1], w_out.shape[0]
+    B, T, dev = int(batch_sizes[0]), len(batch_sizes), enc_proj.device
+    h_buf = torch.zeros(B + N, H, dtype=torch.float32, device=dev)
+    c_buf = torch.zeros(B + N, H, dtype=torch.float32, device=dev)
+    logits = torch.empty(N, C, dtype=torch.float32, device=dev)
+    fed = torch.empty(N, dtype=torch.int64, device=dev)
+    commits = torch.empty(N, dtype=torch.int64, device=dev)
+    if labels is not None and (labels.dtype != torch.int64 or not labels.is_contiguous()):
+        raise HipKernelError('labels must be a contiguous int64 tensor')
+    ws = workspace(lib().mh_decoder_greedy_ws_bytes(N), dev, 'lstm_seq')
+    rc = lib().mh_decoder_greedy(H, B, T, _lengths_array(batch_sizes), C, f32(enc_proj), f32(emb_proj), f32(w_state),
+                                 f32(b_state), f32(dropout), f32(w_out), f32(b_out), ptr(labels), f32(h_buf), f32(c_buf),
+                                 f32(logits), ptr(fed), ptr(commits), ptr(ws), c_size_t(ws.numel()), stream())
+    _check(rc, 'mh_decoder_greedy')
+    return h_buf[B:], logits, fed, commits
 
 
 def gemv_rows(v, wt, bias=None):

@@ -119,9 +119,11 @@ class OverlappedGradReducer(object):
     launch makes the current stream wait for all events of the bucket before handing the buffer to RCCL.
     With world_size 1 the object is inert.  CPU tensors + gloo work the same way (tests)."""
 
-    def __init__(self, params, bucket_bytes=32 << 20):
+    def __init__(self, params, bucket_bytes=32 << 20, force=False):
+        """force=True arms the hooks and the collectives even at world_size 1 (RCCL self-test on a single GPU: the
+        all-reduce over one rank is the identity but runs through the same streams / events / buffers)"""
         self.params = [p for p in params if p.requires_grad]
-        self.enabled = world_size() > 1
+        self.enabled = world_size() > 1 or (force and dist.is_initialized())
         # MOTIFS_GRAD_SYNC=post: no hooks, every bucket is reduced in finish() (after backward) -- an escape hatch
         self.overlap = os.environ.get('MOTIFS_GRAD_SYNC', 'overlap') != 'post'
         self.buckets, cur, cur_bytes = [], [], 0

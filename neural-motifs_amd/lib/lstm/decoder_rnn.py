@@ -178,6 +178,15 @@ class DecoderRNN(torch.nn.Module):
         """Sequential no-grad pass that resolves which label index is fed back at every row
         (train: the GT label, or the step's non-bg arg-max where the label is 0; eval: the arg-max)."""
         H = self.hidden_size
+        if enc_proj.is_cuda and _hip.hwcell_seq_supported(H, int(batch_sizes[0])):
+            with torch.no_grad():                     # one persistent launch (mh_decoder_greedy)
+                h_all, logits, fed, commits = _hip.decoder_greedy(
+                    enc_proj.contiguous(), emb_proj.contiguous(), batch_sizes, self.state_linearity.weight.contiguous(),
+                    self.state_linearity.bias, dropout_mask, self.out.weight.contiguous(), self.out.bias,
+                    None if labels is None else labels.contiguous())
+            self._greedy_states = (h_all, logits)
+            return fed, commits
+        self._greedy_states = None
         with torch.no_grad():
             B = int(batch_sizes[0])
             h_prev = c_prev = enc_proj.new_zeros(B, H)
@@ -231,6 +240,13 @@ class DecoderRNN(torch.nn.Module):
             for n in batch_sizes:
                 assert n == 1, 'eval decodes one image at a time (reference :215)'
             fed, commits = self._greedy_feedback(enc_proj.detach(), emb_proj.detach(), batch_sizes, None, None)
+            if getattr(self, '_greedy_states', None) is not None and not torch.is_grad_enabled():
+                # the fused launch already produced the states and the class logits of every row: no second pass
+                out_dists = self._greedy_states[1]
+                self._greedy_states = None
+                if boxes_for_nms is not None:
+                    commits = self._nms_commitments(out_dists, boxes_for_nms)
+                return out_dists, commits
 
         pre_i_all = enc_proj + emb_proj.index_select(0, fed)
         h_all = _DecoderRecurrenceFn.apply(pre_i_all, self.state_linearity.weight, self.state_linearity.bias,

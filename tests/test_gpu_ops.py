@@ -545,6 +545,61 @@ def test_packed_recurrence_single_launch(hip, H, batch_sizes):
     d_pre = hip.hwcell_seq_bwd(dh, batch_sizes, c_buf, gates, mask, wt)
     np.testing.assert_allclose(d_pre.cpu().numpy(), torch.cat(d_ref).cpu().numpy(), rtol=0, atol=1e-5)
 
+@pytest.mark.parametrize('H,batch_sizes,train', [(512, [1] * 20, False), (128, [1] * 64, False), (512, [6] * 9 + [5, 4, 4, 2, 1], True),
+                                                 (64, [3, 3, 1], True)])
+def test_fused_greedy_decoder_equals_the_step_loop(hip, monkeypatch, H, batch_sizes, train):
+    """mh_decoder_greedy (whole greedy decode in one persistent launch: cell + class logits + arg-max + embedding
+    gather) against the per-step path (2 launches + torch glue per object, MOTIFS_STEP_DECODER=1): committed labels and
+    fed embedding rows EXACT, logits 1e-5; in eval the fused path also skips the second recurrence pass"""
+    from torch.nn.utils.rnn import PackedSequence
+    from lib.lstm.decoder_rnn import DecoderRNN
+    torch.manual_seed(H + len(batch_sizes))
+    classes = ['__background__'] + ['c%d' % i for i in range(1, 151)]
+    dec = DecoderRNN(classes, embed_dim=100, inputs_dim=H, hidden_dim=H, recurrent_dropout_probability=0.1).cuda()
+    dec.train(train)
+    N = sum(batch_sizes)
+    x = torch.randn(N, H, device='cuda')
+    labels = None
+    if train:
+        labels = torch.randint(0, 151, (N,), device='cuda')
+        labels[torch.rand(N, device='cuda') < 0.4] = 0                   # background rows feed back their own arg-max
+    ps = PackedSequence(x, torch.tensor(batch_sizes))
+    from lib import rng
+    outs = {}
+    for mode in ('fused', 'steps'):
+        if mode == 'steps':
+            monkeypatch.setenv('MOTIFS_STEP_DECODER', '1')
+        else:
+            monkeypatch.delenv('MOTIFS_STEP_DECODER', raising=False)
+        rng.use_host_rng(4)
+        ctxm = torch.enable_grad() if train else torch.no_grad()
+        with ctxm:
+            dists, commits = dec(ps, labels=labels)
+        rng.use_host_rng(None)
+        outs[mode] = (dists.detach().cpu().numpy(), commits.cpu().numpy())
+    np.testing.assert_array_equal(outs['fused'][1], outs['steps'][1])
+    np.testing.assert_allclose(outs['fused'][0], outs['steps'][0], atol=1e-5)
+    if train:
+        lab = labels.cpu().numpy()
+        np.testing.assert_array_equal(outs['fused'][1][lab != 0], lab[lab != 0])      # teacher forcing where a label exists
+    assert (outs['fused'][1] > 0).all()
+    # the raw entry point: fed rows = committed label of the previous step of the same sequence + 1 ('start' = 0)
+    enc = torch.randn(N, 6 * H, device='cuda') * 0.3
+    emb = torch.randn(152, 6 * H, device='cuda') * 0.3
+    h_all, logits, fed, commits = hip.decoder_greedy(enc, emb, batch_sizes, dec.state_linearity.weight.contiguous(),
+                                                     dec.state_linearity.bias, None, dec.out.weight.contiguous(), dec.out.bias)
+    fed, commits = fed.cpu().numpy(), commits.cpu().numpy()
+    start = 0
+    for t, n in enumerate(batch_sizes):
+        if t == 0:
+            assert (fed[:n] == 0).all()
+        else:
+            np.testing.assert_array_equal(fed[start:start + n], commits[start - batch_sizes[t - 1]:start - batch_sizes[t - 1] + n] + 1)
+        start += n
+    np.testing.assert_array_equal(commits, logits[:, 1:].argmax(1).cpu().numpy() + 1)
+    np.testing.assert_allclose(logits.cpu().numpy(), (h_all @ dec.out.weight.t() + dec.out.bias).detach().cpu().numpy(), atol=1e-5)
+
+
 
 def test_decoder_cell_and_gemv(hip):
     from oracle import lstm as OL
