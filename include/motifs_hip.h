@@ -282,6 +282,14 @@ int mh_decoder_greedy(int H, int B, int T, const int *batch_sizes_host, int C, c
                       const long long *labels, float *h_buf, float *c_buf, float *logits, long long *fed,
                       long long *commits, void *workspace, size_t ws_bytes, void *stream);
 
+/* Class-wise greedy suppression of the decoder's commitments in SGDet evaluation (lib/lstm/decoder_rnn.py:230-247, which
+ * moves an [N,N,C] IoU tensor and the probabilities to the host): probs [N,C] = softmax of the class logits, boxes [N,C,4]
+ * = the class-specific boxes; N rounds of {first arg-max of the table, commit its class, zero that class for every box
+ * whose class box overlaps (IoU >= thresh, +1 convention, operation order of box_utils.nms_overlaps), retire the row};
+ * commits [N] int64.  One workgroup, N*C*4 bytes of LDS (N*C <= 38400). */
+int mh_decoder_nms_commit(const float *probs, const float *boxes, int N, int C, float thresh, long long *commits,
+                          void *stream);
+
 /* Device-side fault state of the persistent kernels above.
  *   mh_fault_pending(): number of devices whose fault word is set (0 = none); host read, never synchronises.
  *   mh_fault_clear()  : re-arm the entry points after the caller has discarded the affected results.

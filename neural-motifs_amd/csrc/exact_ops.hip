@@ -405,6 +405,67 @@ __global__ void bbox_overlaps_kernel(const float4 *__restrict__ a, int na, const
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Class-wise greedy suppression of the decoder's label commitments in SGDet evaluation
+// (lib/lstm/decoder_rnn.py:230-247; the reference copies the [N,N,C] IoU tensor and the [N,C] probabilities to the
+// host and loops there).  One workgroup: the probability table lives in LDS; N rounds of
+//   (box, cls) = first arg-max of the table (row-major, like np.argmax);  commit;  zero column `cls` for every box
+//   whose class-`cls` box overlaps this one (IoU >= thresh, computed with the operation order of
+//   lib/fpn/box_utils.nms_overlaps);  retire the row (-1).
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void decoder_nms_commit_kernel(const float *__restrict__ probs, const float *__restrict__ boxes,
+                                                                 int N, int C, float thresh, long long *__restrict__ commits)
+{
+    extern __shared__ float tab[];                     // [N*C]
+    __shared__ unsigned long long red[4];
+    __shared__ int win[2];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int total = N * C;
+    for (int i = tid; i < total; i += 256) tab[i] = (i % C == 0) ? 0.f : probs[i];
+    __syncthreads();
+    for (int round = 0; round < N; ++round) {
+        // arg-max with the smallest flat index among equal values: key = (ordered value, ~index)
+        unsigned long long best = 0ull;
+        for (int i = tid; i < total; i += 256) {
+            unsigned u = __float_as_uint(tab[i]);
+            u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+            const unsigned long long k = ((unsigned long long)u << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned)i);
+            best = k > best ? k : best;
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const unsigned long long o = __shfl_xor(best, off);
+            best = o > best ? o : best;
+        }
+        if (lane == 0) red[wave] = best;
+        __syncthreads();
+        if (tid == 0) {
+            unsigned long long b = red[0];
+            for (int w = 1; w < 4; ++w) b = red[w] > b ? red[w] : b;
+            const int flat = (int)(0xFFFFFFFFu - (unsigned)(b & 0xFFFFFFFFull));
+            win[0] = flat / C;
+            win[1] = flat % C;
+            commits[flat / C] = flat % C;
+        }
+        __syncthreads();
+        const int bi = win[0], ci = win[1];
+        const float4 a = *reinterpret_cast<const float4 *>(boxes + ((size_t)bi * C + ci) * 4);
+        const float area_i = (a.z - a.x + 1.0f) * (a.w - a.y + 1.0f);
+        for (int j = tid; j < N; j += 256) {
+            const float4 b = *reinterpret_cast<const float4 *>(boxes + ((size_t)j * C + ci) * 4);
+            const float iw = fmaxf(fminf(a.z, b.z) - fmaxf(a.x, b.x) + 1.0f, 0.f);
+            const float ih = fmaxf(fminf(a.w, b.w) - fmaxf(a.y, b.y) + 1.0f, 0.f);
+            const float inters = iw * ih;
+            const float area_j = (b.z - b.x + 1.0f) * (b.w - b.y + 1.0f);
+            const float uni = (-inters + area_j) + area_i;
+            if (inters / uni >= thresh) tab[j * C + ci] = 0.0f;
+        }
+        __syncthreads();
+        for (int c = tid; c < C; c += 256) tab[bi * C + c] = -1.0f;
+        __syncthreads();
+    }
+}
+
 }  // namespace mh
 
 using namespace mh;
@@ -548,6 +609,23 @@ int mh_triplet_match(const int *gt_triplets, const float *gt_boxes, int G, const
     hipLaunchKernelGGL(triplet_match_kernel, dim3((unsigned)std::min<long long>((total + 255) / 256, 4096)), dim3(256), 0, st,
                        gt_triplets, gt_boxes, G, pred_triplets, pred_boxes, P, iou_thresh, first_match, nmatch);
     return check_launch("triplet_match_kernel");
+}
+
+int mh_decoder_nms_commit(const float *probs, const float *boxes, int N, int C, float thresh, long long *commits, void *stream)
+{
+    MH_REQUIRE(N >= 0 && C > 1);
+    if (N == 0) return MH_OK;
+    MH_REQUIRE(probs && boxes && commits && (reinterpret_cast<uintptr_t>(boxes) & 15) == 0);
+    const size_t lds = (size_t)N * C * sizeof(float);
+    MH_REQUIRE(lds <= 150 * 1024);
+    static bool raised[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64 && !raised[dev]) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(decoder_nms_commit_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+        raised[dev] = true;
+    }
+    hipLaunchKernelGGL(decoder_nms_commit_kernel, dim3(1), dim3(256), lds, as_stream(stream), probs, boxes, N, C, thresh, commits);
+    return check_launch("decoder_nms_commit_kernel");
 }
 
 int mh_bbox_overlaps(const float *boxes_a, int na, const float *boxes_b, int nb, float *out, void *stream)

@@ -31,7 +31,7 @@ SYMBOLS = (
     'mh_hwlstm_fwd_ws_bytes', 'mh_hwlstm_fwd', 'mh_hwlstm_bwd_ws_bytes', 'mh_hwlstm_bwd',
     'mh_hwlstm_cell_fwd', 'mh_hwlstm_cell_bwd', 'mh_gemv_rows',
     'mh_hwcell_seq_ws_bytes', 'mh_hwcell_seq_fwd', 'mh_hwcell_seq_bwd',
-    'mh_decoder_greedy_ws_bytes', 'mh_decoder_greedy',
+    'mh_decoder_greedy_ws_bytes', 'mh_decoder_greedy', 'mh_decoder_nms_commit',
     'mh_fault_pending', 'mh_fault_clear', 'mh_debug_lstm_barrier_fault',
     'mh_opt_chunk_elems', 'mh_multi_sumsq', 'mh_multi_sgd_step',
     'mh_bn_ws_bytes', 'mh_bn_stats', 'mh_bn_pool_fwd', 'mh_bn_residual_nchw', 'mh_bn_apply_nhwc', 'mh_nchw_to_nhwc_small', 'mh_bn_bwd',
@@ -537,6 +537,15 @@ def decoder_greedy(enc_proj, emb_proj, batch_sizes, w_state, b_state, dropout, w
                                  f32(logits), ptr(fed), ptr(commits), ptr(ws), c_size_t(ws.numel()), stream())
     _check(rc, 'mh_decoder_greedy')
     return h_buf[B:], logits, fed, commits
+
+
+def decoder_nms_commit(probs, boxes, thresh):
+    """probs [N,C] softmax, boxes [N,C,4] -> commits [N] int64 (class-wise greedy suppression on the device)"""
+    N, C = probs.shape
+    commits = torch.zeros(N, dtype=torch.int64, device=probs.device)
+    _check(lib().mh_decoder_nms_commit(f32(probs), f32(boxes), N, C, c_float(thresh), ptr(commits), stream()),
+           'mh_decoder_nms_commit')
+    return commits
 
 
 def gemv_rows(v, wt, bias=None):

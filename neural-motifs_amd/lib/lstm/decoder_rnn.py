@@ -258,8 +258,11 @@ class DecoderRNN(torch.nn.Module):
         return out_dists, commits
 
     def _nms_commitments(self, out_dists, boxes_for_nms):
-        """class-wise greedy suppression of the sampled labels in sgdet eval (reference :230-247); host side
-        like the reference (N <= 64 objects)."""
+        """class-wise greedy suppression of the sampled labels in sgdet eval (reference :230-247): one kernel on the
+        device (mh_decoder_nms_commit); the host loop below is the reference's and serves CPU tensors (tests)."""
+        if out_dists.is_cuda and out_dists.size(0) * out_dists.size(1) * 4 <= 150 * 1024:
+            return _hip.decoder_nms_commit(F.softmax(out_dists.detach(), 1).contiguous(),
+                                           boxes_for_nms.detach().float().contiguous(), self.nms_thresh)
         is_overlap = nms_overlaps(boxes_for_nms.detach()).view(
             boxes_for_nms.size(0), boxes_for_nms.size(0), boxes_for_nms.size(1)).cpu().numpy() >= self.nms_thresh
         sampled = F.softmax(out_dists.detach(), 1).cpu().numpy().copy()

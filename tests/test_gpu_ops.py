@@ -600,6 +600,37 @@ def test_fused_greedy_decoder_equals_the_step_loop(hip, monkeypatch, H, batch_si
     np.testing.assert_allclose(logits.cpu().numpy(), (h_all @ dec.out.weight.t() + dec.out.bias).detach().cpu().numpy(), atol=1e-5)
 
 
+@pytest.mark.parametrize('N', [1, 7, 64, 80])
+def test_decoder_nms_commitments_on_device_equal_the_host_loop(hip, N):
+    """mh_decoder_nms_commit == the reference's host loop (decoder_rnn.py:230-247) on the same probabilities and class
+    boxes, incl. duplicated boxes (IoU exactly 1) and tied probabilities"""
+    from lib.fpn.box_utils import nms_overlaps
+    g = torch.Generator().manual_seed(N)
+    C = 151
+    logits = torch.randn(N, C, generator=g) * 3
+    if N > 2:
+        logits[2] = logits[1]                                              # tied rows
+    probs = torch.softmax(logits, 1).cuda()
+    x1y1 = torch.rand(N, 1, 2, generator=g) * 400
+    wh = torch.rand(N, 1, 2, generator=g) * 150 + 10
+    boxes = torch.cat((x1y1, x1y1 + wh), 2).repeat(1, C, 1) + torch.randn(N, C, 4, generator=g) * 3
+    if N > 2:
+        boxes[2] = boxes[1]
+    boxes = boxes.cuda().contiguous()
+    got = hip.decoder_nms_commit(probs.contiguous(), boxes, 0.3).cpu().numpy()
+    is_overlap = (nms_overlaps(boxes).cpu().numpy() >= 0.3)
+    sampled = probs.cpu().numpy().copy()
+    sampled[:, 0] = 0
+    ref = np.zeros(N, dtype=np.int64)
+    for _ in range(N):
+        b, c = np.unravel_index(sampled.argmax(), sampled.shape)
+        ref[int(b)] = int(c)
+        sampled[is_overlap[b, :, c], c] = 0.0
+        sampled[b] = -1.0
+    np.testing.assert_array_equal(got, ref)
+    assert (got > 0).all()
+
+
 
 def test_decoder_cell_and_gemv(hip):
     from oracle import lstm as OL
