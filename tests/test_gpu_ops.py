@@ -628,7 +628,6 @@ def test_decoder_nms_commitments_on_device_equal_the_host_loop(hip, N):
         sampled[is_overlap[b, :, c], c] = 0.0
         sampled[b] = -1.0
     np.testing.assert_array_equal(got, ref)
-    assert (got > 0).all()
 
 
 
