@@ -763,4 +763,18 @@ def test_device_recall_matches_the_reference_evaluator(hip, golden):
             assert rec[k] == result['sgdet_recall'][k][0], (c, k)
         np.testing.assert_array_equal(nmatch.cpu().numpy(), np.array([len(m) for m in pred_to_gt]))
         nonzero += int(nmatch.sum())
+        # multiple predictions per pair (top 100 of all pair x predicate scores) and phrase detection (union boxes)
+        for mode, multi in (('sgdet', True), ('phrdet', False), ('phrdet', True)):
+            res2 = {mode + '_recall': {20: [], 50: [], 100: []}}
+            p2g, _, _ = evaluate_from_dict(
+                {'gt_relations': a('gt_relations'), 'gt_boxes': a('gt_boxes'), 'gt_classes': a('gt_classes')},
+                {'pred_rel_inds': a('pred_rel_inds'), 'rel_scores': a('rel_scores').astype(np.float32),
+                 'pred_boxes': pred_boxes.astype(np.float64), 'pred_classes': a('pred_classes'),
+                 'obj_scores': a('obj_scores').astype(np.float32)}, mode, res2, multiple_preds=multi)
+            rec2, nm2 = recall_at_k(t(a('gt_relations')), t(a('gt_boxes')), t(a('gt_classes')), t(a('pred_rel_inds')),
+                                    t(a('rel_scores')).float(), t(pred_boxes), t(a('pred_classes')), multiple_preds=multi,
+                                    obj_scores=t(a('obj_scores')).float(), phrdet=(mode == 'phrdet'))
+            for k in (20, 50, 100):
+                assert rec2[k] == res2[mode + '_recall'][k][0], (c, mode, multi, k)
+            np.testing.assert_array_equal(nm2.cpu().numpy(), np.array([len(m) for m in p2g]))
     assert nonzero > 0
