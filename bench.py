@@ -147,8 +147,8 @@ def secondary(args, rank, world, dev):
             rel_assignments (<=64 rows/img) -> context + relation head, fwd + bwd + clip + SGD             -- train img/s
       cfg4  ResNet-101 backbone (conv1..layer3, lib/resnet.py) forward at b = 6: the reference's `-resnet` RelModel cannot
             run (lib/rel_model.py:360-365 vs :448), so the row is the trunk the config is named after       -- trunk img/s
-      cfg5  SGDet evaluation stress, b = 8, max_per_img = 80 -> all overlapping ordered pairs (<= 6320 / img) through the
-            union-box relation head                                                                        -- eval img/s
+      cfg5  SGDet evaluation stress, one image per step (the reference's eval decoder asserts batch 1), max_per_img = 80 ->
+            all overlapping ordered pairs (<= 6320 / img) through the union-box relation head                                                                        -- eval img/s
     The random-weight detector is made confident (score_fc x30, RPN objectness x4, as tests/test_gpu_sgdet.py does) so that
     the per-class NMS keeps max_per_img detections per image: the workload is then the configuration's worst case."""
     from dataloaders.synthetic import SyntheticVG, make_blob
@@ -175,7 +175,7 @@ def secondary(args, rank, world, dev):
                 return det.feature_map(x)
     else:
         mode = {'cfg1': 'predcls', 'cfg3': 'sgdet', 'cfg5': 'sgdet'}[cfg]
-        b = {'cfg1': 1, 'cfg3': BATCH, 'cfg5': 8}[cfg]
+        b = {'cfg1': 1, 'cfg3': BATCH, 'cfg5': 1}[cfg]      # evaluation decodes one image per step (reference decoder_rnn.py:215)
         n_img = b * 4
         ds = SyntheticVG(num_images=n_img, seed=seed, n_boxes=N_BOXES, n_rels=N_RELS)
         kw = dict(MODEL_KW)
@@ -217,7 +217,7 @@ def secondary(args, rank, world, dev):
             model.eval_on_device = True                       # Recall@K inputs stay on the device (no [Nrel,51] D2H per image)
             unit_name = 'images/sec MotifNet-%s eval' % ('PredCls' if cfg == 'cfg1' else 'SGDet')
             workload = ('PredCls evaluation forward, 1 image (20 GT boxes -> 380 pairs) per step, VGG16, 592x592' if cfg == 'cfg1' else
-                        'SGDet evaluation forward, batch 8, max_per_img 80 -> all overlapping ordered pairs through the union-box '
+                        'SGDet evaluation forward, 1 image per step, max_per_img 80 -> all overlapping ordered pairs through the union-box '
                         'relation head (<= 6320 pairs/img), VGG16, 592x592')
 
             def step(i):

@@ -236,6 +236,61 @@ __global__ void col_absmax_kernel(const float *__restrict__ X, long long rows, i
     for (long long r = r0; r < r1; ++r) m = max(m, __float_as_uint(X[r * ld + c]) & 0x7fffffffu);
     atomicMax(out + c, m);
 }
+// Vector forms (16-B aligned operand, cols % 4 == 0, ld % 4 == 0): float4 loads, four independent maxima per lane.
+// LPR lanes share a row (a wave covers 64 / LPR rows), so that the 64-channel pixel rows of a conv input and the
+// 25088-wide rows of an fc6 operand both stream at full width.
+__device__ __forceinline__ unsigned absmax4(const float4 v)
+{
+    return max(max(__float_as_uint(v.x) & 0x7fffffffu, __float_as_uint(v.y) & 0x7fffffffu),
+               max(__float_as_uint(v.z) & 0x7fffffffu, __float_as_uint(v.w) & 0x7fffffffu));
+}
+template <int LPR>
+__global__ __launch_bounds__(256) void row_absmax_vec_kernel(const float *__restrict__ X, long long rows, int cols, long long ld,
+                                                             unsigned *__restrict__ out)
+{
+    constexpr int RPW = 64 / LPR;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, sub = lane % LPR, rw = lane / LPR;
+    const int n4 = cols >> 2;
+    for (long long row0 = ((long long)blockIdx.x * 4 + wave) * RPW; row0 < rows; row0 += (long long)gridDim.x * 4 * RPW) {
+        const long long row = row0 + rw;
+        unsigned m0 = 0, m1 = 0, m2 = 0, m3 = 0;
+        if (row < rows) {
+            const float4 *p = reinterpret_cast<const float4 *>(X + row * ld);
+            int c = sub;
+            for (; c + 3 * LPR < n4; c += 4 * LPR) {
+                const float4 v0 = p[c], v1 = p[c + LPR], v2 = p[c + 2 * LPR], v3 = p[c + 3 * LPR];
+                m0 = max(m0, absmax4(v0)); m1 = max(m1, absmax4(v1)); m2 = max(m2, absmax4(v2)); m3 = max(m3, absmax4(v3));
+            }
+            for (; c < n4; c += LPR) m0 = max(m0, absmax4(p[c]));
+        }
+        unsigned m = max(max(m0, m1), max(m2, m3));
+#pragma unroll
+        for (int o = LPR / 2; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o));
+        if (sub == 0 && row < rows) out[row] = m;
+    }
+}
+// columns: a thread owns 4 adjacent columns, a block 1024 columns x `rows_per_block` rows; 4 rows in flight per thread
+__global__ __launch_bounds__(256) void col_absmax_vec_kernel(const float *__restrict__ X, long long rows, int cols, long long ld,
+                                                             int rows_per_block, unsigned *__restrict__ out)
+{
+    const int c = (blockIdx.x * 256 + threadIdx.x) * 4;
+    if (c >= cols) return;
+    const long long r0 = (long long)blockIdx.y * rows_per_block, r1 = min(rows, r0 + rows_per_block);
+    unsigned m[4] = {0, 0, 0, 0};
+    auto fold = [&](const float4 v) {
+        m[0] = max(m[0], __float_as_uint(v.x) & 0x7fffffffu); m[1] = max(m[1], __float_as_uint(v.y) & 0x7fffffffu);
+        m[2] = max(m[2], __float_as_uint(v.z) & 0x7fffffffu); m[3] = max(m[3], __float_as_uint(v.w) & 0x7fffffffu);
+    };
+    long long r = r0;
+    for (; r + 3 < r1; r += 4) {
+        const float4 v0 = *reinterpret_cast<const float4 *>(X + r * ld + c), v1 = *reinterpret_cast<const float4 *>(X + (r + 1) * ld + c),
+                     v2 = *reinterpret_cast<const float4 *>(X + (r + 2) * ld + c), v3 = *reinterpret_cast<const float4 *>(X + (r + 3) * ld + c);
+        fold(v0); fold(v1); fold(v2); fold(v3);
+    }
+    for (; r < r1; ++r) fold(*reinterpret_cast<const float4 *>(X + r * ld + c));
+#pragma unroll
+    for (int k = 0; k < 4; ++k) atomicMax(out + c + k, m[k]);
+}
 __global__ void bits_to_exp_kernel(unsigned *__restrict__ io, long long n)
 {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
@@ -248,15 +303,36 @@ int launch_row_exponents(const float *X, bool k_contiguous, long long n_rows, lo
                          hipStream_t st, bool bits_only)
 {
     unsigned *bits = reinterpret_cast<unsigned *>(exps);
+    const bool vec = (reinterpret_cast<uintptr_t>(X) & 15) == 0 && ld % 4 == 0;
     if (k_contiguous) {
-        hipLaunchKernelGGL(row_absmax_kernel, dim3((unsigned)ceil_div(n_rows, 4LL)), dim3(256), 0, st, X, n_rows, (int)kext,
-                           ld, bits);
+        if (vec && kext % 4 == 0) {
+            const int n4 = (int)(kext >> 2);
+            const int lpr = n4 >= 64 ? 64 : n4 >= 32 ? 32 : n4 >= 16 ? 16 : n4 >= 8 ? 8 : 4;
+            const long long waves = ceil_div(n_rows, (long long)(64 / lpr));
+            const dim3 grid((unsigned)std::min<long long>(ceil_div(waves, 4LL), 256 * 16));
+            if (lpr == 64) hipLaunchKernelGGL(row_absmax_vec_kernel<64>, grid, dim3(256), 0, st, X, n_rows, (int)kext, ld, bits);
+            else if (lpr == 32) hipLaunchKernelGGL(row_absmax_vec_kernel<32>, grid, dim3(256), 0, st, X, n_rows, (int)kext, ld, bits);
+            else if (lpr == 16) hipLaunchKernelGGL(row_absmax_vec_kernel<16>, grid, dim3(256), 0, st, X, n_rows, (int)kext, ld, bits);
+            else if (lpr == 8) hipLaunchKernelGGL(row_absmax_vec_kernel<8>, grid, dim3(256), 0, st, X, n_rows, (int)kext, ld, bits);
+            else hipLaunchKernelGGL(row_absmax_vec_kernel<4>, grid, dim3(256), 0, st, X, n_rows, (int)kext, ld, bits);
+        } else {
+            hipLaunchKernelGGL(row_absmax_kernel, dim3((unsigned)ceil_div(n_rows, 4LL)), dim3(256), 0, st, X, n_rows, (int)kext,
+                               ld, bits);
+        }
     } else {
         hipError_t e = hipMemsetAsync(bits, 0, (size_t)n_rows * sizeof(unsigned), st);
         if (e != hipSuccess) { set_last_error("hipMemsetAsync(row exponents)", e); return (int)e; }
-        const int rows_per_block = (int)std::max<long long>(64, ceil_div(kext, 2048LL));     // up to 2048 row chunks x cols/256 blocks
-        hipLaunchKernelGGL(col_absmax_kernel, dim3((unsigned)ceil_div(n_rows, 256LL), (unsigned)ceil_div(kext, (long long)rows_per_block)),
-                           dim3(256), 0, st, X, kext, (int)n_rows, ld, rows_per_block, bits);
+        if (vec && n_rows % 4 == 0) {
+            // ~4096 blocks: 1024 columns each, the K extent cut so that every CU streams several chunks
+            const long long col_blocks = ceil_div(n_rows, 1024LL);
+            const int rows_per_block = (int)std::max<long long>(16, ceil_div(kext, std::max<long long>(1, 4096 / col_blocks)));
+            hipLaunchKernelGGL(col_absmax_vec_kernel, dim3((unsigned)col_blocks, (unsigned)ceil_div(kext, (long long)rows_per_block)),
+                               dim3(256), 0, st, X, kext, (int)n_rows, ld, rows_per_block, bits);
+        } else {
+            const int rows_per_block = (int)std::max<long long>(64, ceil_div(kext, 2048LL));     // up to 2048 row chunks x cols/256 blocks
+            hipLaunchKernelGGL(col_absmax_kernel, dim3((unsigned)ceil_div(n_rows, 256LL), (unsigned)ceil_div(kext, (long long)rows_per_block)),
+                               dim3(256), 0, st, X, kext, (int)n_rows, ld, rows_per_block, bits);
+        }
     }
     int rc = check_launch("absmax_kernel");
     if (rc || bits_only) return rc;        // bits_only: the caller combines maxima before taking exponents (conv)
@@ -278,7 +354,7 @@ int resident_slots()
     static const int slots = [] {
         const char *e = getenv("MH_SLOTS");
         const int v = e ? atoi(e) : 0;
-        return (v >= 256 && v % 256 == 0) ? v : (MH_SPLIT_F16 ? 768 : 512);
+        return (v >= 256 && v % 256 == 0) ? v : 512;
     }();
     return slots;
 }

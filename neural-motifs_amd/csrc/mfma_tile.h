@@ -816,8 +816,9 @@ int choose_splitk_tiles(long long tiles, int ktiles, double out_elems, double fl
 struct ConvTilePlan {
     int tiles_m, tiles_n, splitk, body_mtiles, tail_slices;
 };
-// blocks of a tile kernel resident at once: 256 CUs x (3 in the f16x3 build: 154-156 VGPRs, 32 KB LDS; 2 in the bf16x6 build:
-// ~190 VGPRs, 48 KB).  MH_SLOTS overrides it for A/B runs of the schedules.
+// blocks of a tile kernel the schedules assume resident at once: 2 per CU.  The f16x3 kernels fit 3 (154-156 VGPRs, 48 KB
+// LDS), but schedules built for 768 slots measured SLOWER on MI355X (trunk 6.11 ms vs 5.82 ms at 512, gpurun r02_c3);
+// MH_SLOTS overrides it for A/B runs.
 int resident_slots();
 double makespan_units(long long blocks);   // time of `blocks` equal blocks in units of (one block alone on a full CU)
 ConvTilePlan plan_conv_tiles(long long M, int Cin, int Cout, int bm, int bn);

@@ -433,9 +433,20 @@ def _lengths_array(lengths):
     return arr
 
 
+def _check_lstm_params(in_size, H, L_, weight, bias):
+    """the flat parameter vectors must have exactly the size the layer geometry implies (alternating_highway_lstm.py:
+    213-229): the kernels index them with (in_size, H, L) and would otherwise read past the end"""
+    want_w = sum(6 * H * (in_size if l == 0 else H) + 5 * H * H for l in range(L_))
+    if weight.numel() != want_w or (bias is not None and bias.numel() != 5 * H * L_):
+        raise HipKernelError('highway LSTM parameters do not match the input: %d weights / %s biases given, input size %d, '
+                             'hidden %d, %d layers need %d / %d' % (weight.numel(), None if bias is None else bias.numel(),
+                                                                   in_size, H, L_, want_w, 5 * H * L_))
+
+
 def hwlstm_fwd(x, lengths, weight, bias, dropout, H, L_, training):
     """x [T,B,in]; returns (h_data, c_data [L,T+1,B,H], gates [L,T,B,6H] or None)"""
     T, B, in_size = x.shape
+    _check_lstm_params(in_size, H, L_, weight, bias)
     dev = x.device
     h_data = torch.zeros(L_, T + 1, B, H, dtype=torch.float32, device=dev)
     c_data = torch.zeros(L_, T + 1, B, H, dtype=torch.float32, device=dev)
@@ -451,6 +462,7 @@ def hwlstm_fwd(x, lengths, weight, bias, dropout, H, L_, training):
 
 def hwlstm_bwd(out_grad, x, lengths, weight, dropout, H, L_, h_data, c_data, gates, need_weight_grad=True):
     T, B, in_size = x.shape
+    _check_lstm_params(in_size, H, L_, weight, None)
     dev = x.device
     x_grad = torch.empty_like(x)
     w_grad = torch.zeros_like(weight) if need_weight_grad else None

@@ -25,7 +25,9 @@ def _close(got, ref, what, tol=1e-4):
     assert err <= tol * scale, what
 
 
-@pytest.mark.parametrize('nl_obj,nl_edge,mode', [(0, 2, 'predcls'), (2, 0, 'sgcls'), (0, 0, 'predcls')])
+# (nl_obj = 0 with nl_edge > 0 cannot run in the reference either: its edge LSTM is built for embed_dim + hidden inputs and
+# is fed the 4424-d object representation, lib/rel_model.py:126-136 vs :284-295 -- the product raises, see below)
+@pytest.mark.parametrize('nl_obj,nl_edge,mode', [(0, 0, 'sgcls'), (2, 0, 'sgcls'), (0, 0, 'predcls')])
 def test_baseline_context_variants_on_the_gpu(nl_obj, nl_edge, mode):
     if not torch.cuda.is_available():
         pytest.fail('needs a HIP device')
@@ -73,6 +75,20 @@ def test_baseline_context_variants_on_the_gpu(nl_obj, nl_edge, mode):
             _close(p.grad.cpu().numpy(), params[name].grad.numpy(), 'grad ' + name[-30:], tol=2e-4)
             n += 1
     assert n >= 10
+
+
+def test_mismatched_lstm_input_is_refused_not_read_out_of_bounds():
+    """nl_obj = 0 with nl_edge = 2 feeds the edge LSTM a 4424+200-d input its weights were not built for (a reference
+    defect): the binding must refuse instead of letting the kernels read past the parameter vector"""
+    if not torch.cuda.is_available():
+        pytest.fail('needs a HIP device')
+    from lib import _hip
+    from lib.lstm.highway_lstm_cuda.alternating_highway_lstm import AlternatingHighwayLSTM
+    from torch.nn.utils.rnn import PackedSequence
+    lstm = AlternatingHighwayLSTM(input_size=40, hidden_size=32, num_layers=2).cuda()
+    x = PackedSequence(torch.randn(5, 48, device='cuda'), torch.tensor([2, 2, 1]))
+    with pytest.raises(_hip.HipKernelError, match='do not match the input'):
+        lstm(x)
 
 
 def test_message_passing_baseline_on_the_gpu():
