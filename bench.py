@@ -77,11 +77,6 @@ def _conv_flops(args, kwargs, y):
     return 2.0 * B * H * W * Cin * wt.shape[1] * 9
 
 
-def _pconv_flops(args, kwargs, y):
-    xp, wt = args[0], args[1]                       # activation planes [B,H,W,Cin/16,3,16]
-    return 2.0 * xp.shape[0] * xp.shape[1] * xp.shape[2] * (xp.shape[3] * 16) * wt.shape[1] * 9
-
-
 def _gemm_flops(args, kwargs, y):
     a = args[0]
     return 2.0 * y.shape[0] * y.shape[1] * (a.shape[0] if (args[2] if len(args) > 2 else kwargs.get('trans_a', False)) else a.shape[1])
@@ -314,7 +309,6 @@ def main():
     for b in blobs:
         b.scatter()                                           # inputs resident in HBM before the timed region
     meter = KernelMeter(_hip, 'conv3x3_nhwc', _conv_flops)
-    pmeter = KernelMeter(_hip, 'conv3x3_planes', _pconv_flops)      # the frozen trunk's layers (activation planes)
     gmeter = KernelMeter(_hip, 'gemm', _gemm_flops)
 
     def step(i):
@@ -341,24 +335,20 @@ def main():
     for i in range(args.warmup):
         step(i)
     barrier()
-    meter.enabled = gmeter.enabled = pmeter.enabled = True
+    meter.enabled = gmeter.enabled = True
     t0 = time.time()
     for i in range(args.steps):
         loss = step(args.warmup + i)
     barrier()
     dt = time.time() - t0
-    meter.enabled = gmeter.enabled = pmeter.enabled = False
+    meter.enabled = gmeter.enabled = False
     tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
     if world > 1:
         torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
     dt = float(tmax.item())
 
     if rank == 0:
-        c1, c2 = meter.summary(), pmeter.summary()      # both conv3x3 implicit-GEMM kernels together
-        n = max(c1['launches'] + c2['launches'], 1)
-        ms, fl = c1['total_ms'] + c2['total_ms'], c1['flops_per_launch'] * c1['launches'] + c2['flops_per_launch'] * c2['launches']
-        conv = dict(launches=c1['launches'] + c2['launches'], avg_ms=ms / n, total_ms=ms, flops_per_launch=fl / n,
-                    tflops=(fl / (ms * 1e-3) / 1e12) if ms > 0 else 0.0)
+        conv = meter.summary()
         gm = gmeter.summary()
         _hip.check_faults()
         # `achieved` counts ALGORITHMIC fp32 flops (2*M*N*K of the convolution).  The peak is the matrix-core peak for
@@ -387,8 +377,7 @@ def main():
             'config': {'workload': 'SGCls MotifNet VGG16 train step (fwd+bwd+clip+SGD), order=leftright, nl_obj=2, '
                                    'nl_edge=2, hidden 512, batch 6/GPU, 20 GT boxes/img, <=256 rel rows/img, 592x592',
                        'global_batch': world * BATCH, 'parallelism': 'dp%d' % world, 'final_loss': float(loss.item())},
-            'roofline': {'bound': 'mfma', 'kernel': 'conv3x3 implicit GEMM (conv3x3_planes_kernel: %d VGG trunk launches on activation planes; '
-                                                    'conv3x3_nhwc_kernel: %d launches, union tower fwd + dgrad); ' % (c2['launches'], c1['launches']) + how,
+            'roofline': {'bound': 'mfma', 'kernel': 'conv3x3_nhwc_kernel (implicit GEMM: 12 VGG trunk layers + union tower fwd / dgrad per step); ' + how,
                          'achieved': conv['tflops'], 'peak': peak, 'unit': 'TFLOP/s',
                          'frac': conv['tflops'] / peak, 'traffic': traffic['bytes_per_launch'] if traffic else None,
                          'traffic_unit': 'bytes per launch (L2 fabric side: HBM + Infinity-Cache)',
@@ -396,8 +385,6 @@ def main():
                          'traffic_source': TRAFFIC_SUMMARY + ' (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over one '
                                            'launch per shape of this step, tools/traffic_run.sh; not re-measured by this run)',
                          'frac_of_f32_mfma_peak': conv['tflops'] / PEAK_FP32_MFMA_TFLOPS,
-                         'planes_kernel': {'tflops': c2['tflops'], 'ms_per_step': c2['total_ms'] / args.steps},
-                         'nhwc_kernel': {'tflops': c1['tflops'], 'ms_per_step': c1['total_ms'] / args.steps},
                          'launches': conv['launches'], 'avg_launch_ms': conv['avg_ms'],
                          'flops_per_launch': conv['flops_per_launch']},
         }

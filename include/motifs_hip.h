@@ -151,29 +151,6 @@ int mh_conv3x3_schedule(int B, int H, int W, int Cin, int Cout, int *out8_host);
 int mh_conv3x3_nhwc(const float *in, int B, int H, int W, int Cin, const float *wt, int Cout,
                     const float *bias, int epilogue, float *out, void *workspace, size_t ws_bytes,
                     void *stream);
-/* ---------------------------------------------------------------------------------------------
- * The frozen trunk on ACTIVATION PLANES (bf16x6 build; MH_EUNSUPPORTED otherwise -- callers keep the fp32 entry points).
- * Replaces the same cuDNN convolutions as mh_conv3x3_nhwc (lib/object_detector.py:110-118) for layers whose output is
- * read by nothing but the next conv: an activation tensor is stored already split into its three bf16 terms,
- *     planes[row][c / 16][hi: 16 bf16 | mid: 16 bf16 | lo: 16 bf16]      96 bytes per (row, 16 channels), C % 16 == 0,
- * (the exact truncation split the fp32 kernels perform while staging), so the consuming conv stages its operands by
- * LDS-DMA with no split arithmetic; results are bit-identical to mh_conv3x3_nhwc on the same values.
- *   mh_f32_to_planes / mh_planes_to_f32 : converters (exact both ways); mh_planes_bytes(rows, C) = rows * C * 6
- *   mh_conv_first_nchw_planes           : the 3->Cout stem writing planes
- *   mh_conv3x3_planes : 3x3/1/1 conv + bias + ReLU/ReLU6 [+ 2x2/2 max-pool when `pool` (H, W even)] from input planes
- *       [B,H,W,Cin] to EITHER out_planes [B,Ho,Wo,Cout] (Cout % 16 == 0) OR out_f32 [B,Ho,Wo,Cout] NHWC (the other NULL);
- *       wt = mh_conv3x3_pack_weight(..., flip_transpose = 0); workspace >= mh_conv3x3_planes_ws_bytes (partial sums
- *       of K-split tiles)
- * ------------------------------------------------------------------------------------------- */
-size_t mh_planes_bytes(long long rows, int C);
-int mh_f32_to_planes(const float *x, long long rows, int C, void *planes, void *stream);
-int mh_planes_to_f32(const void *planes, long long rows, int C, float *x, void *stream);
-int mh_conv_first_nchw_planes(const float *in_nchw, int B, int Cin, int H, int W, const float *w, int Cout,
-                              const float *bias, int epilogue, void *out_planes, void *stream);
-size_t mh_conv3x3_planes_ws_bytes(int B, int H, int W, int Cin, int Cout);
-int mh_conv3x3_planes(const void *in_planes, int B, int H, int W, int Cin, const float *wt, int Cout,
-                      const float *bias, int epilogue, int pool, void *out_planes, float *out_f32,
-                      void *workspace, size_t ws_bytes, void *stream);
 /* replaces cuDNN's convolution weight gradient reached through nn.Conv2d autograd (mask tower conv,
  * lib/get_union_boxes.py:31-39; every VGG / RPN conv when the detector trains, models/train_detector.py:141-146):
  * weight gradient of the 3x3/1/1 conv as an implicit GEMM over the pixels (no patch matrix): dw [Cout][9*Cin]

@@ -490,7 +490,7 @@ constexpr int kStemCo = 16;
 __global__ __launch_bounds__(256) void conv_first_kernel(const float *__restrict__ in, int B, int Cin, int H, int W,
                                                          const float *__restrict__ w, int Cout,
                                                          const float *__restrict__ bias, int epilogue,
-                                                         float *__restrict__ out, char *__restrict__ out_planes)
+                                                         float *__restrict__ out)
 {
     extern __shared__ __attribute__((aligned(16))) float wl[];  // [9*Cin][Cout] + bias[Cout]
     const int K = 9 * Cin;
@@ -525,23 +525,6 @@ __global__ __launch_bounds__(256) void conv_first_kernel(const float *__restrict
                 for (int j = 0; j < kStemCo; ++j) acc[j] = fmaf(v, wr[j], acc[j]);
             }
         }
-#if MH_PLANES && !MH_SPLIT_F16
-        if (out_planes) {
-            // activation planes (conv_planes.hip): the thread's 16 channels are exactly one 96-byte (pixel, chunk) record
-            unsigned ph[8], pm[8], pl[8];
-#pragma unroll
-            for (int j = 0; j < 8; ++j)
-                split_pair(conv_epi(acc[2 * j], epilogue), conv_epi(acc[2 * j + 1], epilogue), ph[j], pm[j], pl[j]);
-            u32x4 *q = reinterpret_cast<u32x4 *>(out_planes + ((size_t)pix * groups + grp) * 96);
-            q[0] = (u32x4){ph[0], ph[1], ph[2], ph[3]};
-            q[1] = (u32x4){ph[4], ph[5], ph[6], ph[7]};
-            q[2] = (u32x4){pm[0], pm[1], pm[2], pm[3]};
-            q[3] = (u32x4){pm[4], pm[5], pm[6], pm[7]};
-            q[4] = (u32x4){pl[0], pl[1], pl[2], pl[3]};
-            q[5] = (u32x4){pl[4], pl[5], pl[6], pl[7]};
-            continue;
-        }
-#endif
         float *o = out + (size_t)pix * Cout + grp * kStemCo;
 #pragma unroll
         for (int j = 0; j < kStemCo; j += 4) {
@@ -984,28 +967,8 @@ int mh_conv_first_nchw(const float *in_nchw, int B, int Cin, int H, int W, const
     const long long total = (long long)B * H * W * (Cout / kStemCo);
     const int blocks = (int)std::min<long long>((total + 255) / 256, 256 * 8);
     hipLaunchKernelGGL(conv_first_kernel, dim3(blocks), dim3(256), lds, as_stream(stream), in_nchw, B, Cin, H, W, w,
-                       Cout, bias, epilogue, out_nhwc, static_cast<char *>(nullptr));
+                       Cout, bias, epilogue, out_nhwc);
     return check_launch("conv_first_kernel");
-}
-
-int mh_conv_first_nchw_planes(const float *in_nchw, int B, int Cin, int H, int W, const float *w, int Cout,
-                              const float *bias, int epilogue, void *out_planes, void *stream)
-{
-#if MH_PLANES && !MH_SPLIT_F16
-    MH_REQUIRE(in_nchw && w && out_planes && B > 0 && Cin > 0 && H > 0 && W > 0);
-    MH_REQUIRE(Cout > 0 && Cout % kStemCo == 0 && kStemCo == kBK);
-    MH_REQUIRE((reinterpret_cast<uintptr_t>(out_planes) & 15) == 0);
-    const size_t lds = ((size_t)9 * Cin * Cout + Cout) * sizeof(float);
-    MH_REQUIRE(lds <= 64 * 1024);
-    const long long total = (long long)B * H * W * (Cout / kStemCo);
-    const int blocks = (int)std::min<long long>((total + 255) / 256, 256 * 8);
-    hipLaunchKernelGGL(conv_first_kernel, dim3(blocks), dim3(256), lds, as_stream(stream), in_nchw, B, Cin, H, W, w,
-                       Cout, bias, epilogue, static_cast<float *>(nullptr), reinterpret_cast<char *>(out_planes));
-    return check_launch("conv_first_kernel");
-#else
-    (void)in_nchw; (void)B; (void)Cin; (void)H; (void)W; (void)w; (void)Cout; (void)bias; (void)epilogue; (void)out_planes; (void)stream;
-    return MH_EUNSUPPORTED;
-#endif
 }
 
 int mh_maxpool2x2_nhwc(const float *in, int B, int H, int W, int C, float *out, void *stream)

@@ -23,8 +23,6 @@ SYMBOLS = (
     'mh_roi_align_fwd', 'mh_roi_align_bwd', 'mh_draw_union_boxes', 'mh_bbox_overlaps', 'mh_triplet_match',
     'mh_gemm_ws_bytes', 'mh_gemm_auto_splitk', 'mh_gemm_f32',
     'mh_conv3x3_packed_floats', 'mh_conv3x3_pack_weight', 'mh_conv3x3_ws_bytes', 'mh_conv3x3_schedule', 'mh_conv3x3_nhwc',
-    'mh_planes_bytes', 'mh_f32_to_planes', 'mh_planes_to_f32', 'mh_conv_first_nchw_planes', 'mh_conv3x3_planes_ws_bytes',
-    'mh_conv3x3_planes',
     'mh_conv3x3_wgrad_ws_bytes', 'mh_conv3x3_wgrad', 'mh_conv_first_nchw', 'mh_maxpool2x2_nhwc',
     'mh_maxpool2x2_bwd_nhwc', 'mh_act_bwd',
     'mh_im2col_nhwc', 'mh_nchw_to_nhwc', 'mh_nhwc_to_nchw',
@@ -58,7 +56,7 @@ def lib():
         L.mh_last_error.restype = ctypes.c_char_p
         for name in ('mh_nms_ws_bytes', 'mh_nms_batched_ws_bytes', 'mh_gemm_ws_bytes', 'mh_conv3x3_ws_bytes', 'mh_bn_ws_bytes',
                      'mh_conv3x3_packed_floats', 'mh_hwcell_seq_ws_bytes', 'mh_conv3x3_wgrad_ws_bytes',
-                     'mh_hwlstm_fwd_ws_bytes', 'mh_hwlstm_bwd_ws_bytes', 'mh_planes_bytes', 'mh_conv3x3_planes_ws_bytes',
+                     'mh_hwlstm_fwd_ws_bytes', 'mh_hwlstm_bwd_ws_bytes',
                      'mh_decoder_greedy_ws_bytes'):
             getattr(L, name).restype = ctypes.c_size_t
         _lib = L
@@ -290,58 +288,6 @@ def conv3x3_nhwc(x, wt, bias, epilogue):
     rc = lib().mh_conv3x3_nhwc(f32(x), B, H, W, Cin, f32(wt), Cout, f32(bias), c_int(epilogue), f32(out),
                                ptr(ws), c_size_t(ws.numel() if ws is not None else 0), stream())
     _check(rc, 'mh_conv3x3_nhwc')
-    return out
-
-
-# ---- activation planes (csrc/conv_planes.hip): an NHWC activation stored as its exact 3-way bf16 split, int16 tensor
-# [B, H, W, C/16, 3, 16]
-def planes_supported():
-    return lib().mh_mfma_split() == 6 and not lib().mh_split_f16()
-
-
-def f32_to_planes(x):
-    """x [..., C] fp32 contiguous (C % 16 == 0) -> planes [..., C/16, 3, 16] int16"""
-    C = x.shape[-1]
-    rows = x.numel() // C
-    out = torch.empty(tuple(x.shape[:-1]) + (C // 16, 3, 16), dtype=torch.int16, device=x.device)
-    _check(lib().mh_f32_to_planes(f32(x), c_ll(rows), C, ptr(out), stream()), 'mh_f32_to_planes')
-    return out
-
-
-def planes_to_f32(planes):
-    C = planes.shape[-3] * 16
-    rows = planes.numel() // (C * 3)
-    out = torch.empty(tuple(planes.shape[:-3]) + (C,), dtype=torch.float32, device=planes.device)
-    _check(lib().mh_planes_to_f32(ptr(planes), c_ll(rows), C, f32(out), stream()), 'mh_planes_to_f32')
-    return out
-
-
-def conv_first_nchw_planes(x, w, bias, epilogue):
-    """x [B,Cin,H,W] NCHW, w [Cout,Cin,3,3] -> planes [B,H,W,Cout/16,3,16]"""
-    B, Cin, H, W = x.shape
-    Cout = w.shape[0]
-    out = torch.empty(B, H, W, Cout // 16, 3, 16, dtype=torch.int16, device=x.device)
-    _check(lib().mh_conv_first_nchw_planes(f32(x), B, Cin, H, W, f32(w), Cout, f32(bias), c_int(epilogue), ptr(out),
-                                           stream()), 'mh_conv_first_nchw_planes')
-    return out
-
-
-def conv3x3_planes(xp, wt, bias, epilogue, pool=False, out_fp32=False):
-    """xp planes [B,H,W,Cin/16,3,16], wt = conv3x3_pack_weight(w) -> planes [B,Ho,Wo,Cout/16,3,16] or fp32 [B,Ho,Wo,Cout];
-    pool fuses the 2x2/2 max-pool that follows the activation"""
-    B, H, W = xp.shape[0], xp.shape[1], xp.shape[2]
-    Cin, Cout = xp.shape[3] * 16, wt.shape[1]
-    Ho, Wo = (H // 2, W // 2) if pool else (H, W)
-    if out_fp32:
-        out = torch.empty(B, Ho, Wo, Cout, dtype=torch.float32, device=xp.device)
-    else:
-        out = torch.empty(B, Ho, Wo, Cout // 16, 3, 16, dtype=torch.int16, device=xp.device)
-    wsb = lib().mh_conv3x3_planes_ws_bytes(B, H, W, Cin, Cout)
-    ws = workspace(wsb, xp.device, 'conv') if wsb else None
-    rc = lib().mh_conv3x3_planes(ptr(xp), B, H, W, Cin, f32(wt), Cout, f32(bias), c_int(epilogue), c_int(int(pool)),
-                                 ptr(None if out_fp32 else out), f32(out if out_fp32 else None),
-                                 ptr(ws), c_size_t(ws.numel() if ws is not None else 0), stream())
-    _check(rc, 'mh_conv3x3_planes')
     return out
 
 

@@ -198,8 +198,6 @@ class VGG16Features(nn.Sequential):
         with torch.no_grad():
             mods = list(self.children())
             first = mods[0]
-            if self._use_planes(x):
-                return self._forward_planes(x, mods).permute(0, 3, 1, 2)
             y = _hip.conv_first_nchw(_c(x), _c(first.weight), first.bias, EPI_RELU)   # NHWC out
             i = 2
             while i < len(mods):
@@ -213,43 +211,6 @@ class VGG16Features(nn.Sequential):
                 else:
                     raise RuntimeError('unexpected module in VGG16Features')
         return y.permute(0, 3, 1, 2)
-
-    @staticmethod
-    def _use_planes(x):
-        """the activation-plane trunk (csrc/conv_planes.hip): the default in the bf16x6 build; MOTIFS_TRUNK=fp32 keeps the
-        fp32-activation kernels (A/B runs -- the two are bit-identical on unsplit tiles)"""
-        import os
-        return _hip.planes_supported() and os.environ.get('MOTIFS_TRUNK', 'planes') != 'fp32'
-
-    def _forward_planes(self, x, mods):
-        """forward-only trunk on activation planes: every intermediate activation is written ONCE, already split into its
-        bf16 terms, by the producing conv's epilogue (ReLU and the following 2x2 max-pool fused); only the final feature
-        map is fp32 NHWC"""
-        y = _hip.conv_first_nchw_planes(_c(x), _c(mods[0].weight), mods[0].bias, EPI_RELU)
-        convs = []                                     # (module, pooled?) for the 3x3 layers after the stem
-        i = 2
-        while i < len(mods):
-            m = mods[i]
-            if isinstance(m, Conv3x3):
-                pooled = i + 2 < len(mods) and isinstance(mods[i + 2], MaxPool2x2)
-                convs.append((m, pooled))
-                i += 3 if pooled else 2
-            elif isinstance(m, MaxPool2x2):
-                # a pool directly after the stem (not in VGG16): no fused producer, go through fp32
-                y = _hip.f32_to_planes(_hip.maxpool2x2_nhwc(_hip.planes_to_f32(y).view(*y.shape[:3], -1)))
-                i += 1
-            else:
-                raise RuntimeError('unexpected module in VGG16Features')
-        for k, (m, pooled) in enumerate(convs):
-            last = k == len(convs) - 1
-            H, W = y.shape[1], y.shape[2]
-            if pooled and (H % 2 or W % 2):            # odd size: floor pooling drops a row / column -- unfused
-                z = _hip.conv3x3_planes(y, m.packed_weight(), m.bias.detach(), EPI_RELU, pool=False, out_fp32=True)
-                z = _hip.maxpool2x2_nhwc(z)
-                y = z if last else _hip.f32_to_planes(z)
-            else:
-                y = _hip.conv3x3_planes(y, m.packed_weight(), m.bias.detach(), EPI_RELU, pool=pooled, out_fp32=last)
-        return y
 
     def _forward_trainable(self, x):
         """same layers through autograd Functions (conv backward = dgrad on the conv kernel + im2col/GEMM wgrad,

@@ -170,9 +170,6 @@ def install():
         r = v @ wt.t()
         return r + bias if bias is not None else r
 
-    def planes_supported():
-        return False            # the activation-plane trunk is a GPU-only data layout: host-logic tests keep fp32 NHWC
-
     def check_faults():
         return None
 

@@ -261,110 +261,6 @@ def test_conv3x3_weight_gradient_implicit_gemm(hip, B, H, W, Cin, Cout):
     scale = float(w.grad.abs().max())
     np.testing.assert_allclose(got.numpy(), w.grad.numpy(), atol=2e-5 * scale)
 
-def _need_planes(hip):
-    if not hip.planes_supported():
-        pytest.skip('activation planes exist in the bf16x6 build only (MH_SPLIT_F16=0); this library is %s'
-                    % ('f16x3' if hip.lib().mh_split_f16() else 'split %d' % hip.lib().mh_mfma_split()))
-
-
-def test_planes_round_trip_is_exact(hip):
-    """fp32 -> (hi, mid, lo) bf16 planes -> fp32 reproduces every bit (the split is exact), also for denormals and huge
-    values (the sign of a zero is the one thing a sum of three terms cannot carry)"""
-    _need_planes(hip)
-    g = torch.Generator().manual_seed(2)
-    x = torch.randn(37, 5, 48, generator=g) * torch.exp2(torch.randint(-40, 40, (37, 5, 48), generator=g).float())
-    x.view(-1)[:6] = torch.tensor([0.0, 2.0 ** -130, 1e-45, -3e-39, 3.3e38, -1.0])
-    p = hip.f32_to_planes(x.cuda())
-    assert p.shape == (37, 5, 3, 3, 16) and p.dtype == torch.int16
-    back = hip.planes_to_f32(p)
-    assert torch.equal(back.cpu().view(torch.int32), x.view(torch.int32))
-
-
-PLANE_CASES = [  # B, H, W, Cin, Cout, pool, fp32 out
-    (2, 10, 12, 16, 32, False, False), (2, 10, 12, 16, 32, True, False), (1, 37, 37, 64, 128, False, True),
-    (1, 16, 24, 64, 64, True, False), (3, 8, 8, 128, 256, True, True), (2, 30, 30, 256, 512, False, False),
-    (6, 74, 74, 64, 128, True, False), (1, 37, 37, 512, 512, False, True)]
-
-
-@pytest.mark.parametrize('B,H,W,Cin,Cout,pool,f32out', PLANE_CASES)
-def test_conv3x3_on_activation_planes(hip, B, H, W, Cin, Cout, pool, f32out):
-    """mh_conv3x3_planes (LDS-DMA staging of pre-split operands, fused ReLU [+ 2x2 max-pool], planes or fp32 out) against
-    (a) the fp32-activation kernel + the separate pool kernel: BIT-identical wherever a tile is not K-split, 1e-5 of
-    scale on K-split tiles (another summation grouping), and (b) the oracle (torch CPU conv) at 1e-4"""
-    _need_planes(hip)
-    g = torch.Generator().manual_seed(B * 1000 + H + Cin + Cout)
-    x = torch.randn(B, H, W, Cin, generator=g)
-    x[0, :2, :3] = 0.0                                          # exact zeros and a big outlier through the split
-    x[-1, -1, -1, 0] = 1.5e4
-    w = torch.randn(Cout, Cin, 3, 3, generator=g) * (2.0 / (9 * Cin)) ** 0.5
-    b = torch.randn(Cout, generator=g) * 0.1
-    xd, wt = x.cuda(), hip.conv3x3_pack_weight(w.cuda())
-    ref = hip.conv3x3_nhwc(xd, wt, b.cuda(), 1)
-    if pool:
-        ref = hip.maxpool2x2_nhwc(ref)
-    got = hip.conv3x3_planes(hip.f32_to_planes(xd), wt, b.cuda(), 1, pool=pool, out_fp32=f32out)
-    if not f32out:
-        got = hip.planes_to_f32(got).view(ref.shape)
-    sp = hip.conv3x3_schedule(B, H, W, Cin, Cout)
-    scale = float(ref.abs().max())
-    err = float((got - ref).abs().max())
-    print('planes vs fp32 kernel: max abs diff %.3e (scale %.2f), schedule %s' % (err, scale, sp))
-    assert err <= 1e-5 * scale
-    oracle = F.relu(F.conv2d(x.permute(0, 3, 1, 2), w, b, padding=1))
-    if pool:
-        oracle = F.max_pool2d(oracle, 2)
-    np.testing.assert_allclose(got.cpu().permute(0, 3, 1, 2).numpy(), oracle.numpy(), atol=1e-4 * max(1.0, scale))
-
-
-def test_planes_conv_is_bit_identical_on_unsplit_tiles(hip):
-    """same planes, same k order, same order of the six bf16 cross terms: with one tile and no K split the two kernels
-    must agree in every bit (a changed summation order would show here first)"""
-    _need_planes(hip)
-    g = torch.Generator().manual_seed(9)
-    for (B, H, W, Cin, Cout) in ((1, 8, 16, 32, 128), (1, 16, 16, 64, 64), (2, 8, 8, 16, 48)):
-        x = torch.randn(B, H, W, Cin, generator=g).cuda()
-        w = (torch.randn(Cout, Cin, 3, 3, generator=g) * 0.1).cuda()
-        b = torch.randn(Cout, generator=g).cuda()
-        wt = hip.conv3x3_pack_weight(w)
-        sp = hip.conv3x3_schedule(B, H, W, Cin, Cout)
-        ref = hip.conv3x3_nhwc(x, wt, b, 1)
-        got = hip.conv3x3_planes(hip.f32_to_planes(x), wt, b, 1, pool=False, out_fp32=True)
-        if sp['splitk'] == 1 and sp['tail_tiles'] == 0:
-            assert torch.equal(got.view(torch.int32), ref.view(torch.int32)), (B, H, W, Cin, Cout)
-        else:
-            assert float((got - ref).abs().max()) <= 1e-5 * float(ref.abs().max())
-        if Cout % 16 == 0:
-            gp = hip.planes_to_f32(hip.conv3x3_planes(hip.f32_to_planes(x), wt, b, 1)).view(ref.shape)
-            assert torch.equal(gp.view(torch.int32), got.view(torch.int32))
-
-
-def test_stem_planes_and_whole_trunk_equal_the_fp32_path(hip, monkeypatch):
-    """conv1_1 writing planes == conv1_1 writing fp32, and the whole frozen VGG trunk on planes (fused pools) ==
-    the fp32-activation trunk, at a size where no tile is K-split differently... compared at 1e-5 of scale"""
-    _need_planes(hip)
-    from lib.hip_ops import VGG16Features
-    torch.manual_seed(4)
-    x = torch.randn(2, 3, 64, 96).cuda()
-    w = (torch.randn(64, 3, 3, 3) * 0.2).cuda()
-    b = torch.randn(64).cuda()
-    a = hip.conv_first_nchw(x, w, b, 1)
-    p = hip.planes_to_f32(hip.conv_first_nchw_planes(x, w, b, 1)).view(a.shape)
-    assert torch.equal(a.view(torch.int32), p.view(torch.int32))
-    net = VGG16Features().cuda()
-    for q in net.parameters():
-        q.requires_grad = False
-    monkeypatch.setenv('MOTIFS_TRUNK', 'fp32')
-    ref = net(x)
-    monkeypatch.setenv('MOTIFS_TRUNK', 'planes')
-    got = net(x)
-    assert got.shape == ref.shape == (2, 512, 4, 6)
-    scale = float(ref.abs().max())
-    err = float((got - ref).abs().max())
-    print('trunk planes vs fp32: max abs diff %.3e (scale %.3f)' % (err, scale))
-    assert err <= 1e-5 * scale
-
-
-
 def test_maxpool_and_activation_backward(hip):
     g = torch.Generator().manual_seed(4)
     x = torch.randn(2, 8, 9, 7, generator=g)                         # odd H and W: trailing row / column get zero gradient

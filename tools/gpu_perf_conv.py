@@ -1,9 +1,8 @@
 #!/usr/bin/env python3
-"""Per-layer A/B of the trunk's conv kernels on the bench shapes (b = 6, 592x592): the fp32-activation kernel
-(mh_conv3x3_nhwc) against the activation-plane kernel (mh_conv3x3_planes, optionally with the fused 2x2 pool), and the
-fc6 GEMMs.  Environment switches are read once per process by the library, so run one process per variant:
-    MH_CONV_SCHEDULE=uniform | MH_PCONV_TILE=128|256 | MH_GEMM_PATCH=rows
-Prints TFLOP/s (fp32-equivalent) per layer and the weighted trunk total."""
+"""Per-layer timing of the trunk's conv kernel on the bench shapes (b = 6, 592x592) and of the fc6 / fc7 GEMMs.
+Environment switches are read once per process by the library, so run one process per variant:
+    MH_CONV_SCHEDULE=uniform | MH_SLOTS=768 | MH_GEMM_PATCH=rows | MOTIFS_HIP_LIB=<variant .so>
+Prints TFLOP/s (fp32-equivalent) per layer and the weighted trunk total, then one JSON line."""
 import os, sys, json, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, 'neural-motifs_amd'))
@@ -29,8 +28,9 @@ LAYERS = [('conv1_2', 592, 64, 64, True, 1), ('conv2_1', 296, 64, 128, False, 1)
           ('conv4_1', 74, 256, 512, False, 1), ('conv4_2', 74, 512, 512, False, 1), ('conv4_3', 74, 512, 512, True, 1),
           ('conv5_x', 37, 512, 512, False, 3)]
 which = sys.argv[1] if len(sys.argv) > 1 else 'all'
-out = {'env': {k: os.environ.get(k) for k in ('MH_CONV_SCHEDULE', 'MH_PCONV_TILE', 'MH_GEMM_PATCH')}}
-tot = {'fp32': 0.0, 'planes': 0.0, 'fp32+pool': 0.0, 'planes_fused': 0.0}
+out = {'env': {k: os.environ.get(k) for k in ('MH_CONV_SCHEDULE', 'MH_SLOTS', 'MH_GEMM_PATCH', 'MOTIFS_HIP_LIB')},
+       'mfma_split': _hip.lib().mh_mfma_split(), 'f16': _hip.lib().mh_split_f16()}
+tot = {'conv': 0.0, 'conv+pool': 0.0}
 for name, S, ci, co, pooled, mult in (LAYERS if which != 'gemm' else []):
     x = torch.randn(B, S, S, ci, device='cuda')
     wt = _hip.conv3x3_pack_weight(torch.randn(co, ci, 3, 3, device='cuda') * 0.05)
@@ -39,31 +39,15 @@ for name, S, ci, co, pooled, mult in (LAYERS if which != 'gemm' else []):
     ms_f = timeit(lambda: _hip.conv3x3_nhwc(x, wt, bias, 1))
     y = _hip.conv3x3_nhwc(x, wt, bias, 1)
     ms_pool = timeit(lambda: _hip.maxpool2x2_nhwc(y)) if pooled else 0.0
-    row = {'fp32_ms': ms_f, 'fp32_tf': fl / ms_f / 1e9, 'pool_ms': ms_pool}
-    if _hip.planes_supported():
-        xp = _hip.f32_to_planes(x)
-        ms_p = timeit(lambda: _hip.conv3x3_planes(xp, wt, bias, 1, pool=False, out_fp32=False))
-        row.update(planes_ms=ms_p, planes_tf=fl / ms_p / 1e9)
-        if pooled and S % 2 == 0:
-            ms_pp = timeit(lambda: _hip.conv3x3_planes(xp, wt, bias, 1, pool=True, out_fp32=False))
-            row.update(planes_pool_ms=ms_pp, planes_pool_tf=fl / ms_pp / 1e9)
-        else:
-            ms_pp = ms_p
-        tot['planes'] += ms_p * mult
-        tot['planes_fused'] += ms_pp * mult
-        del xp
-    tot['fp32'] += ms_f * mult
-    tot['fp32+pool'] += (ms_f + ms_pool) * mult
-    row['schedule'] = _hip.conv3x3_schedule(B, S, S, ci, co)
-    out[name] = row
-    print('%-8s %4d %3d->%3d  fp32 %7.3f ms %6.1f TF | planes %7.3f ms %6.1f TF | planes+pool %s | pool kernel %.3f ms' % (
-        name, S, ci, co, ms_f, row['fp32_tf'], row.get('planes_ms', 0), row.get('planes_tf', 0),
-        ('%7.3f ms %6.1f TF' % (row['planes_pool_ms'], row['planes_pool_tf'])) if 'planes_pool_ms' in row else '   -   ', ms_pool), flush=True)
+    tot['conv'] += ms_f * mult
+    tot['conv+pool'] += (ms_f + ms_pool) * mult
+    out[name] = {'ms': ms_f, 'tf': fl / ms_f / 1e9, 'pool_ms': ms_pool, 'schedule': _hip.conv3x3_schedule(B, S, S, ci, co)}
+    print('%-8s %4d %3d->%3d  %7.3f ms %6.1f TF | pool kernel %.3f ms' % (name, S, ci, co, ms_f, fl / ms_f / 1e9, ms_pool), flush=True)
     del x, wt, y
 trunk_flops = sum(2.0 * B * S * S * ci * co * 9 * m for _, S, ci, co, _, m in LAYERS)
 for k, v in tot.items():
     if v:
-        print('TRUNK %-13s %8.3f ms   %6.1f TF' % (k, v, trunk_flops / v / 1e9))
+        print('TRUNK %-10s %8.3f ms   %6.1f TF' % (k, v, trunk_flops / v / 1e9))
 out['trunk_ms'] = tot
 if which in ('all', 'gemm'):
     for name, M, N, K, ta, tb in [('fc6_fwd', 1536, 4096, 25088, 0, 1), ('fc6_dgrad', 1536, 25088, 4096, 0, 0),
