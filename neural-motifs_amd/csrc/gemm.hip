@@ -323,9 +323,10 @@ int launch_row_exponents(const float *X, bool k_contiguous, long long n_rows, lo
         hipError_t e = hipMemsetAsync(bits, 0, (size_t)n_rows * sizeof(unsigned), st);
         if (e != hipSuccess) { set_last_error("hipMemsetAsync(row exponents)", e); return (int)e; }
         if (vec && n_rows % 4 == 0) {
-            // ~4096 blocks: 1024 columns each, the K extent cut so that every CU streams several chunks
+            // ~1024 blocks of 1024 columns: enough to stream from every CU, few enough that the atomicMax traffic (one per
+            // column and row chunk) stays small next to the operand read
             const long long col_blocks = ceil_div(n_rows, 1024LL);
-            const int rows_per_block = (int)std::max<long long>(16, ceil_div(kext, std::max<long long>(1, 4096 / col_blocks)));
+            const int rows_per_block = (int)std::max<long long>(32, ceil_div(kext, std::max<long long>(1, 1024 / col_blocks)));
             hipLaunchKernelGGL(col_absmax_vec_kernel, dim3((unsigned)col_blocks, (unsigned)ceil_div(kext, (long long)rows_per_block)),
                                dim3(256), 0, st, X, kext, (int)n_rows, ld, rows_per_block, bits);
         } else {

@@ -129,6 +129,11 @@ def test_sgdet_train_step_parity(det):
             p.requires_grad = False
         model.zero_grad(set_to_none=True)
         model.sampler_rs = np.random.RandomState(2)
+        # the oracle is handed the detections (det_override), so it never draws the detector's own dropout masks: keep the
+        # (frozen) detector's Dropout layers out of the shared mask stream -- the relation model's draws then line up
+        for m in model.detector.modules():
+            if m.__class__.__name__ == 'Dropout':
+                m.eval()
         rng.use_host_rng(55)
         res = model[blob]
         rng.use_host_rng(None)
