@@ -342,13 +342,13 @@ __global__ __launch_bounds__(kThreads, MH_MINW) void conv3x3_wgrad_kernel(const 
     StageExp<BM> ea;
     StageExp<BN> eb;
 #if MH_SPLIT_F16
-    load_stage_exp<BM>(ea, p.expA, m0, p.Cout, false, tid);
+    load_stage_exp<BM>(ea, p.expA, m0, p.Cout, false, tid, true);      // |x| maxima as bit patterns (launch_operand_absmax)
 #pragma unroll
     for (int jt = 0; jt < NTB; ++jt) {
         int q, kp;
         km_task<BN>(tid + kThreads * jt, q, kp);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) eb.km[jt][j] = (n0 + 4 * q + j < N) ? p.expB[(n0 + 4 * q + j) % p.Cin] : 0;
+        for (int j = 0; j < 4; ++j) eb.km[jt][j] = (n0 + 4 * q + j < N) ? row_exponent((unsigned)p.expB[(n0 + 4 * q + j) % p.Cin]) : 0;
     }
 #endif
     auto store_tiles = [&](const Stage<BM> &sa, const Stage<BN> &sb, int buf) {
@@ -382,8 +382,8 @@ __global__ __launch_bounds__(kThreads, MH_MINW) void conv3x3_wgrad_kernel(const 
         const int row = m0 + r, col0 = n0 + c0, col1 = n0 + c1;
         if (row >= p.Cout) return;
 #if MH_SPLIT_F16
-        if (col0 < N) v0 = __builtin_ldexpf(v0, -(p.expA[row] + p.expB[col0 % p.Cin]));
-        if (col1 < N) v1 = __builtin_ldexpf(v1, -(p.expA[row] + p.expB[col1 % p.Cin]));
+        if (col0 < N) v0 = __builtin_ldexpf(v0, -(row_exponent((unsigned)p.expA[row]) + row_exponent((unsigned)p.expB[col0 % p.Cin])));
+        if (col1 < N) v1 = __builtin_ldexpf(v1, -(row_exponent((unsigned)p.expA[row]) + row_exponent((unsigned)p.expB[col1 % p.Cin])));
 #endif
         float *q = dst + (size_t)row * N;
         if (col1 < N) *reinterpret_cast<float2 *>(q + col0) = make_float2(v0, v1);      // N % 4 == 0: col0 is even
@@ -938,8 +938,7 @@ int mh_conv3x3_wgrad(const float *x, const float *gy, int B, int H, int W, int C
         used += align_up((size_t)Cout * sizeof(int), 256);
         int *expB = reinterpret_cast<int *>(reinterpret_cast<char *>(workspace) + used);
         used += align_up((size_t)Cin * sizeof(int), 256);
-        rc = launch_row_exponents(gy, false, Cout, P, Cout, expA, st);
-        if (!rc) rc = launch_row_exponents(x, false, Cin, P, Cin, expB, st);
+        rc = launch_operand_absmax(gy, false, Cout, P, Cout, expA, x, false, Cin, P, Cin, expB, st);
         if (rc) return rc;
         p.expA = expA; p.expB = expB;
     }

@@ -107,14 +107,16 @@ __global__ __launch_bounds__(kThreads, MH_MINW) void gemm_kernel(const GemmArgs 
 #if MH_SPLIT_F16
     StageExp<BM> ea;
     StageExp<BN> eb;
-    load_stage_exp<BM>(ea, p.expA, m0, p.M, AWM, tid);
-    load_stage_exp<BN>(eb, p.expB, n0, p.N, BWM, tid);
+    load_stage_exp<BM>(ea, p.expA, m0, p.M, AWM, tid, true);     // the arrays hold |x| maxima as bit patterns
+    load_stage_exp<BN>(eb, p.expB, n0, p.N, BWM, tid, true);
     auto store_tiles = [&](const Stage<BM> &sa, const Stage<BN> &sb, int buf) {
         if (TA) store_km<BM>(sa, As(buf), tid, ea); else store_wm<BM>(sa, As(buf), tid, ea);
         if (TB) store_wm<BN>(sb, Bs(buf), tid, eb); else store_km<BN>(sb, Bs(buf), tid, eb);
     };
     // the accumulators hold sum (a 2^ea[row]) (b 2^eb[col]): the exact inverse power of two goes on before anything else
-    auto unscale = [&](int row, int col, float v) { return __builtin_ldexpf(v, -(p.expA[row] + p.expB[col])); };
+    auto unscale = [&](int row, int col, float v) {
+        return __builtin_ldexpf(v, -(row_exponent((unsigned)p.expA[row]) + row_exponent((unsigned)p.expB[col])));
+    };
 #else
     auto store_tiles = [&](const Stage<BM> &sa, const Stage<BN> &sb, int buf) {
         if (TA) store_km<BM>(sa, As(buf), tid); else store_wm<BM>(sa, As(buf), tid);
@@ -236,17 +238,17 @@ __global__ void col_absmax_kernel(const float *__restrict__ X, long long rows, i
     for (long long r = r0; r < r1; ++r) m = max(m, __float_as_uint(X[r * ld + c]) & 0x7fffffffu);
     atomicMax(out + c, m);
 }
-// Vector forms (16-B aligned operand, cols % 4 == 0, ld % 4 == 0): float4 loads, four independent maxima per lane.
-// LPR lanes share a row (a wave covers 64 / LPR rows), so that the 64-channel pixel rows of a conv input and the
-// 25088-wide rows of an fc6 operand both stream at full width.
+// Vector forms (16-B aligned operand, cols % 4 == 0, ld % 4 == 0): float4 loads, several independent loads per lane.
 __device__ __forceinline__ unsigned absmax4(const float4 v)
 {
     return max(max(__float_as_uint(v.x) & 0x7fffffffu, __float_as_uint(v.y) & 0x7fffffffu),
                max(__float_as_uint(v.z) & 0x7fffffffu, __float_as_uint(v.w) & 0x7fffffffu));
 }
+// Short rows (pixel channel vectors, small GEMM operands): LPR lanes share a row, a wave covers 64 / LPR rows.
+// to_exp: write the exponent instead of the bit pattern (saves the bits -> exponent launch).
 template <int LPR>
 __global__ __launch_bounds__(256) void row_absmax_vec_kernel(const float *__restrict__ X, long long rows, int cols, long long ld,
-                                                             unsigned *__restrict__ out)
+                                                             unsigned *__restrict__ out, int to_exp)
 {
     constexpr int RPW = 64 / LPR;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, sub = lane % LPR, rw = lane / LPR;
@@ -266,31 +268,212 @@ __global__ __launch_bounds__(256) void row_absmax_vec_kernel(const float *__rest
         unsigned m = max(max(m0, m1), max(m2, m3));
 #pragma unroll
         for (int o = LPR / 2; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o));
-        if (sub == 0 && row < rows) out[row] = m;
+        if (sub == 0 && row < rows) out[row] = to_exp ? (unsigned)row_exponent(m) : m;
     }
 }
-// columns: a thread owns 4 adjacent columns, a block 1024 columns x `rows_per_block` rows; 4 rows in flight per thread
+// Long rows (fc6 operands: 25088 floats): one workgroup per row, 8 float4 in flight per thread.
+__global__ __launch_bounds__(256) void row_absmax_long_kernel(const float *__restrict__ X, long long rows, int cols, long long ld,
+                                                              unsigned *__restrict__ out, int to_exp)
+{
+    __shared__ unsigned red[4];
+    const int tid = threadIdx.x, n4 = cols >> 2;
+    for (long long row = blockIdx.x; row < rows; row += gridDim.x) {
+        const float4 *p = reinterpret_cast<const float4 *>(X + row * ld);
+        unsigned m[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        int c = tid;
+        for (; c + 7 * 256 < n4; c += 8 * 256) {
+            float4 v[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = p[c + 256 * k];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) m[k] = max(m[k], absmax4(v[k]));
+        }
+        for (; c < n4; c += 256) m[0] = max(m[0], absmax4(p[c]));
+        unsigned mm = max(max(max(m[0], m[1]), max(m[2], m[3])), max(max(m[4], m[5]), max(m[6], m[7])));
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) mm = max(mm, (unsigned)__shfl_xor((int)mm, o));
+        __syncthreads();
+        if ((tid & 63) == 0) red[tid >> 6] = mm;
+        __syncthreads();
+        if (tid == 0) {
+            const unsigned r = max(max(red[0], red[1]), max(red[2], red[3]));
+            out[row] = to_exp ? (unsigned)row_exponent(r) : r;
+        }
+    }
+}
+// Columns: a workgroup owns a strip of 256 columns (64 float4 lanes) x `rows_per_block` rows, its four waves take rows
+// r, r+4, ... with four loads in flight each; the strip's maxima are combined in LDS and ONE atomicMax per column leaves
+// the block.
 __global__ __launch_bounds__(256) void col_absmax_vec_kernel(const float *__restrict__ X, long long rows, int cols, long long ld,
                                                              int rows_per_block, unsigned *__restrict__ out)
 {
-    const int c = (blockIdx.x * 256 + threadIdx.x) * 4;
-    if (c >= cols) return;
+    __shared__ unsigned red[4][256];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = (blockIdx.x * 64 + lane) * 4;
     const long long r0 = (long long)blockIdx.y * rows_per_block, r1 = min(rows, r0 + rows_per_block);
     unsigned m[4] = {0, 0, 0, 0};
-    auto fold = [&](const float4 v) {
-        m[0] = max(m[0], __float_as_uint(v.x) & 0x7fffffffu); m[1] = max(m[1], __float_as_uint(v.y) & 0x7fffffffu);
-        m[2] = max(m[2], __float_as_uint(v.z) & 0x7fffffffu); m[3] = max(m[3], __float_as_uint(v.w) & 0x7fffffffu);
-    };
-    long long r = r0;
-    for (; r + 3 < r1; r += 4) {
-        const float4 v0 = *reinterpret_cast<const float4 *>(X + r * ld + c), v1 = *reinterpret_cast<const float4 *>(X + (r + 1) * ld + c),
-                     v2 = *reinterpret_cast<const float4 *>(X + (r + 2) * ld + c), v3 = *reinterpret_cast<const float4 *>(X + (r + 3) * ld + c);
-        fold(v0); fold(v1); fold(v2); fold(v3);
+    if (c < cols) {
+        auto fold = [&](const float4 v) {
+            m[0] = max(m[0], __float_as_uint(v.x) & 0x7fffffffu); m[1] = max(m[1], __float_as_uint(v.y) & 0x7fffffffu);
+            m[2] = max(m[2], __float_as_uint(v.z) & 0x7fffffffu); m[3] = max(m[3], __float_as_uint(v.w) & 0x7fffffffu);
+        };
+        long long r = r0 + wave;
+        for (; r + 12 < r1; r += 16) {
+            const float4 v0 = *reinterpret_cast<const float4 *>(X + r * ld + c), v1 = *reinterpret_cast<const float4 *>(X + (r + 4) * ld + c),
+                         v2 = *reinterpret_cast<const float4 *>(X + (r + 8) * ld + c), v3 = *reinterpret_cast<const float4 *>(X + (r + 12) * ld + c);
+            fold(v0); fold(v1); fold(v2); fold(v3);
+        }
+        for (; r < r1; r += 4) fold(*reinterpret_cast<const float4 *>(X + r * ld + c));
     }
-    for (; r < r1; ++r) fold(*reinterpret_cast<const float4 *>(X + r * ld + c));
 #pragma unroll
-    for (int k = 0; k < 4; ++k) atomicMax(out + c + k, m[k]);
+    for (int k = 0; k < 4; ++k) red[wave][4 * lane + k] = m[k];
+    __syncthreads();
+    const int col = blockIdx.x * 256 + threadIdx.x;
+    if (col < cols) {
+        const unsigned mm = max(max(red[0][threadIdx.x], red[1][threadIdx.x]), max(red[2][threadIdx.x], red[3][threadIdx.x]));
+        atomicMax(out + col, mm);
+    }
 }
+// ---- both operands of a GEMM in ONE launch --------------------------------------------------------------------------
+// The step is launch-bound as much as bandwidth-bound here (a GEMM call used to issue 4-6 tiny launches for its two
+// exponent arrays): blocks [0, a.nblocks) scan operand A, the rest operand B, each in the mode its storage calls for.
+struct AbsmaxPart {
+    const float *X;
+    long long rows, kext, ld;     // rows = operand rows (the non-K index), kext = extent along K
+    unsigned *bits;
+    int mode;                     // 0: K-contiguous, long rows (workgroup per row); 1: K-contiguous, lpr lanes per row;
+                                  // 2: k-major, 256-column strips + atomicMax; 3 / 4: unaligned fallbacks of 1 / 2
+    int lpr, rows_per_block, col_blocks, nblocks;
+};
+__device__ __forceinline__ void absmax_part(const AbsmaxPart &p, int bid, unsigned (*red)[256])
+{
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (p.mode == 0) {
+        const int n4 = (int)(p.kext >> 2);
+        for (long long row = bid; row < p.rows; row += p.nblocks) {
+            const float4 *q = reinterpret_cast<const float4 *>(p.X + row * p.ld);
+            unsigned m[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            int c = tid;
+            for (; c + 7 * 256 < n4; c += 8 * 256) {
+                float4 v[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) v[k] = q[c + 256 * k];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) m[k] = max(m[k], absmax4(v[k]));
+            }
+            for (; c < n4; c += 256) m[0] = max(m[0], absmax4(q[c]));
+            unsigned mm = max(max(max(m[0], m[1]), max(m[2], m[3])), max(max(m[4], m[5]), max(m[6], m[7])));
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) mm = max(mm, (unsigned)__shfl_xor((int)mm, o));
+            __syncthreads();
+            if (lane == 0) red[0][wave] = mm;
+            __syncthreads();
+            if (tid == 0) p.bits[row] = max(max(red[0][0], red[0][1]), max(red[0][2], red[0][3]));
+        }
+    } else if (p.mode == 1 || p.mode == 3) {
+        const int lpr = p.lpr, rpw = 64 / lpr, sub = lane & (lpr - 1), rw = lane / lpr;
+        for (long long row0 = ((long long)bid * 4 + wave) * rpw; row0 < p.rows; row0 += (long long)p.nblocks * 4 * rpw) {
+            const long long row = row0 + rw;
+            unsigned m0 = 0, m1 = 0;
+            if (row < p.rows) {
+                if (p.mode == 1) {
+                    const float4 *q = reinterpret_cast<const float4 *>(p.X + row * p.ld);
+                    const int n4 = (int)(p.kext >> 2);
+                    int c = sub;
+                    for (; c + lpr < n4; c += 2 * lpr) {
+                        const float4 v0 = q[c], v1 = q[c + lpr];
+                        m0 = max(m0, absmax4(v0)); m1 = max(m1, absmax4(v1));
+                    }
+                    for (; c < n4; c += lpr) m0 = max(m0, absmax4(q[c]));
+                } else {
+                    const float *q = p.X + row * p.ld;
+                    for (long long c = sub; c < p.kext; c += lpr) m0 = max(m0, __float_as_uint(q[c]) & 0x7fffffffu);
+                }
+            }
+            unsigned m = max(m0, m1);
+            for (int o = lpr >> 1; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o));
+            if (sub == 0 && row < p.rows) p.bits[row] = m;
+        }
+    } else if (p.mode == 2) {
+        const int cb = bid % p.col_blocks, chunk = bid / p.col_blocks;
+        const long long c = ((long long)cb * 64 + lane) * 4;
+        const long long r0 = (long long)chunk * p.rows_per_block, r1 = min(p.kext, r0 + p.rows_per_block);
+        unsigned m[4] = {0, 0, 0, 0};
+        if (c < p.rows) {
+            auto fold = [&](const float4 v) {
+                m[0] = max(m[0], __float_as_uint(v.x) & 0x7fffffffu); m[1] = max(m[1], __float_as_uint(v.y) & 0x7fffffffu);
+                m[2] = max(m[2], __float_as_uint(v.z) & 0x7fffffffu); m[3] = max(m[3], __float_as_uint(v.w) & 0x7fffffffu);
+            };
+            long long r = r0 + wave;
+            for (; r + 12 < r1; r += 16) {
+                const float4 v0 = *reinterpret_cast<const float4 *>(p.X + r * p.ld + c), v1 = *reinterpret_cast<const float4 *>(p.X + (r + 4) * p.ld + c),
+                             v2 = *reinterpret_cast<const float4 *>(p.X + (r + 8) * p.ld + c), v3 = *reinterpret_cast<const float4 *>(p.X + (r + 12) * p.ld + c);
+                fold(v0); fold(v1); fold(v2); fold(v3);
+            }
+            for (; r < r1; r += 4) fold(*reinterpret_cast<const float4 *>(p.X + r * p.ld + c));
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) red[wave][4 * lane + k] = m[k];
+        __syncthreads();
+        const long long col = (long long)cb * 256 + tid;
+        if (col < p.rows) atomicMax(p.bits + col, max(max(red[0][tid], red[1][tid]), max(red[2][tid], red[3][tid])));
+    } else {   // 4: k-major, unaligned: one column per thread
+        const int cb = bid % p.col_blocks, chunk = bid / p.col_blocks;
+        const long long col = (long long)cb * 256 + tid;
+        if (col < p.rows) {
+            const long long r0 = (long long)chunk * p.rows_per_block, r1 = min(p.kext, r0 + p.rows_per_block);
+            unsigned m = 0;
+            for (long long r = r0; r < r1; ++r) m = max(m, __float_as_uint(p.X[r * p.ld + col]) & 0x7fffffffu);
+            atomicMax(p.bits + col, m);
+        }
+    }
+}
+__global__ __launch_bounds__(256) void absmax_dual_kernel(const AbsmaxPart a, const AbsmaxPart b)
+{
+    __shared__ unsigned red[4][256];
+    if ((int)blockIdx.x < a.nblocks) absmax_part(a, (int)blockIdx.x, red);
+    else absmax_part(b, (int)blockIdx.x - a.nblocks, red);
+}
+static AbsmaxPart make_absmax_part(const float *X, bool k_contiguous, long long rows, long long kext, long long ld, int *bits)
+{
+    AbsmaxPart p;
+    p.X = X; p.rows = rows; p.kext = kext; p.ld = ld; p.bits = reinterpret_cast<unsigned *>(bits);
+    p.lpr = 64; p.rows_per_block = 1; p.col_blocks = 1;
+    const bool vec = (reinterpret_cast<uintptr_t>(X) & 15) == 0 && ld % 4 == 0;
+    if (k_contiguous) {
+        if (vec && kext % 4 == 0 && kext >= 4096) {
+            p.mode = 0;
+            p.nblocks = (int)std::min<long long>(rows, 256 * 32);
+        } else {
+            p.mode = (vec && kext % 4 == 0) ? 1 : 3;
+            const long long per_lane = (p.mode == 1) ? (kext >> 2) : kext;
+            p.lpr = per_lane >= 64 ? 64 : per_lane >= 32 ? 32 : per_lane >= 16 ? 16 : per_lane >= 8 ? 8 : 4;
+            p.nblocks = (int)std::min<long long>(ceil_div(ceil_div(rows, (long long)(64 / p.lpr)), 4LL), 256 * 16);
+        }
+    } else {
+        p.mode = (vec && rows % 4 == 0) ? 2 : 4;
+        p.col_blocks = (int)ceil_div(rows, 256LL);
+        p.rows_per_block = (int)std::max<long long>(64, ceil_div(kext, std::max<long long>(1, 1024 / p.col_blocks)));
+        p.nblocks = p.col_blocks * (int)ceil_div(kext, (long long)p.rows_per_block);
+    }
+    p.nblocks = std::max(p.nblocks, 1);
+    return p;
+}
+int launch_operand_absmax(const float *A, bool a_kcontig, long long a_rows, long long a_kext, long long lda, int *bitsA,
+                          const float *B, bool b_kcontig, long long b_rows, long long b_kext, long long ldb, int *bitsB,
+                          hipStream_t st)
+{
+    const AbsmaxPart a = make_absmax_part(A, a_kcontig, a_rows, a_kext, lda, bitsA);
+    const AbsmaxPart b = make_absmax_part(B, b_kcontig, b_rows, b_kext, ldb, bitsB);
+    if (!a_kcontig || !b_kcontig) {       // the column passes fold into zero-initialised words: one memset over both arrays
+        char *lo = reinterpret_cast<char *>(std::min(bitsA, bitsB)), *hi = reinterpret_cast<char *>(bitsA > bitsB ? bitsA + a_rows : bitsB + b_rows);
+        hipError_t e = hipMemsetAsync(lo, 0, (size_t)(hi - lo), st);
+        if (e != hipSuccess) { set_last_error("hipMemsetAsync(operand absmax)", e); return (int)e; }
+    }
+    hipLaunchKernelGGL(absmax_dual_kernel, dim3((unsigned)(a.nblocks + b.nblocks)), dim3(256), 0, st, a, b);
+    return check_launch("absmax_dual_kernel");
+}
+
 __global__ void bits_to_exp_kernel(unsigned *__restrict__ io, long long n)
 {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
@@ -305,28 +488,32 @@ int launch_row_exponents(const float *X, bool k_contiguous, long long n_rows, lo
     unsigned *bits = reinterpret_cast<unsigned *>(exps);
     const bool vec = (reinterpret_cast<uintptr_t>(X) & 15) == 0 && ld % 4 == 0;
     if (k_contiguous) {
+        const int to_exp = bits_only ? 0 : 1;       // one owner per row: the exponent is written directly
+        if (vec && kext % 4 == 0 && kext >= 4096) {
+            hipLaunchKernelGGL(row_absmax_long_kernel, dim3((unsigned)std::min<long long>(n_rows, 256 * 32)), dim3(256), 0, st, X,
+                               n_rows, (int)kext, ld, bits, to_exp);
+            return check_launch("row_absmax_long_kernel");
+        }
         if (vec && kext % 4 == 0) {
             const int n4 = (int)(kext >> 2);
             const int lpr = n4 >= 64 ? 64 : n4 >= 32 ? 32 : n4 >= 16 ? 16 : n4 >= 8 ? 8 : 4;
             const long long waves = ceil_div(n_rows, (long long)(64 / lpr));
             const dim3 grid((unsigned)std::min<long long>(ceil_div(waves, 4LL), 256 * 16));
-            if (lpr == 64) hipLaunchKernelGGL(row_absmax_vec_kernel<64>, grid, dim3(256), 0, st, X, n_rows, (int)kext, ld, bits);
-            else if (lpr == 32) hipLaunchKernelGGL(row_absmax_vec_kernel<32>, grid, dim3(256), 0, st, X, n_rows, (int)kext, ld, bits);
-            else if (lpr == 16) hipLaunchKernelGGL(row_absmax_vec_kernel<16>, grid, dim3(256), 0, st, X, n_rows, (int)kext, ld, bits);
-            else if (lpr == 8) hipLaunchKernelGGL(row_absmax_vec_kernel<8>, grid, dim3(256), 0, st, X, n_rows, (int)kext, ld, bits);
-            else hipLaunchKernelGGL(row_absmax_vec_kernel<4>, grid, dim3(256), 0, st, X, n_rows, (int)kext, ld, bits);
-        } else {
-            hipLaunchKernelGGL(row_absmax_kernel, dim3((unsigned)ceil_div(n_rows, 4LL)), dim3(256), 0, st, X, n_rows, (int)kext,
-                               ld, bits);
+            if (lpr == 64) hipLaunchKernelGGL(row_absmax_vec_kernel<64>, grid, dim3(256), 0, st, X, n_rows, (int)kext, ld, bits, to_exp);
+            else if (lpr == 32) hipLaunchKernelGGL(row_absmax_vec_kernel<32>, grid, dim3(256), 0, st, X, n_rows, (int)kext, ld, bits, to_exp);
+            else if (lpr == 16) hipLaunchKernelGGL(row_absmax_vec_kernel<16>, grid, dim3(256), 0, st, X, n_rows, (int)kext, ld, bits, to_exp);
+            else if (lpr == 8) hipLaunchKernelGGL(row_absmax_vec_kernel<8>, grid, dim3(256), 0, st, X, n_rows, (int)kext, ld, bits, to_exp);
+            else hipLaunchKernelGGL(row_absmax_vec_kernel<4>, grid, dim3(256), 0, st, X, n_rows, (int)kext, ld, bits, to_exp);
+            return check_launch("row_absmax_vec_kernel");
         }
+        hipLaunchKernelGGL(row_absmax_kernel, dim3((unsigned)ceil_div(n_rows, 4LL)), dim3(256), 0, st, X, n_rows, (int)kext, ld, bits);
     } else {
         hipError_t e = hipMemsetAsync(bits, 0, (size_t)n_rows * sizeof(unsigned), st);
         if (e != hipSuccess) { set_last_error("hipMemsetAsync(row exponents)", e); return (int)e; }
         if (vec && n_rows % 4 == 0) {
-            // ~1024 blocks of 1024 columns: enough to stream from every CU, few enough that the atomicMax traffic (one per
-            // column and row chunk) stays small next to the operand read
-            const long long col_blocks = ceil_div(n_rows, 1024LL);
-            const int rows_per_block = (int)std::max<long long>(32, ceil_div(kext, std::max<long long>(1, 1024 / col_blocks)));
+            // 256-column strips; the K extent is cut so that ~1024 blocks stream (>= 64 rows each): one atomic per column and chunk
+            const long long col_blocks = ceil_div(n_rows, 256LL);
+            const int rows_per_block = (int)std::max<long long>(64, ceil_div(kext, std::max<long long>(1, 1024 / col_blocks)));
             hipLaunchKernelGGL(col_absmax_vec_kernel, dim3((unsigned)col_blocks, (unsigned)ceil_div(kext, (long long)rows_per_block)),
                                dim3(256), 0, st, X, kext, (int)n_rows, ld, rows_per_block, bits);
         } else {
@@ -446,8 +633,7 @@ int mh_gemm_f32(int transA, int transB, int M, int N, int K, const float *A, int
         const size_t ea = align_up((size_t)M * sizeof(int), 256), eb = align_up((size_t)N * sizeof(int), 256);
         MH_REQUIRE(workspace && ws_bytes >= ea + eb);
         int *expA = reinterpret_cast<int *>(workspace), *expB = reinterpret_cast<int *>(reinterpret_cast<char *>(workspace) + ea);
-        int rc_e = launch_row_exponents(A, !transA, M, K, lda, expA, st);
-        if (!rc_e) rc_e = launch_row_exponents(B, transB != 0, N, K, ldb, expB, st);
+        int rc_e = launch_operand_absmax(A, !transA, M, K, lda, expA, B, transB != 0, N, K, ldb, expB, st);
         if (rc_e) return rc_e;
         p.expA = expA; p.expB = expB;
         workspace = reinterpret_cast<char *>(workspace) + ea + eb;

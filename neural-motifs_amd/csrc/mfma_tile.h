@@ -414,17 +414,20 @@ struct StageExp {
     int km[(2 * WD + kThreads - 1) / kThreads][4];
 #endif
 };
-// exps[i] = exponent of tile row / column i (i relative to the tile origin `o0`, `n` valid entries from there)
+// exps[i] = exponent of tile row / column i (i relative to the tile origin `o0`, `n` valid entries from there); with
+// `bits` the array holds the rows' largest |x| as fp32 bit patterns (what the absmax pass writes) and the exponent is
+// derived here -- no separate bits -> exponent launch
 template <int WD>
 __device__ __forceinline__ void load_stage_exp(StageExp<WD> &se, const int *__restrict__ exps, long long o0, long long n,
-                                               bool wm, int tid)
+                                               bool wm, int tid, bool bits = false)
 {
 #if MH_SPLIT_F16
+    auto ex = [&](long long i) { return bits ? row_exponent((unsigned)exps[i]) : exps[i]; };
     if (wm) {
 #pragma unroll
         for (int j = 0; j < TileGeom<WD, true>::nv; ++j) {
             const int r = (tid + kThreads * j) >> 2;
-            se.wm[j] = (o0 + r < n) ? exps[o0 + r] : 0;
+            se.wm[j] = (o0 + r < n) ? ex(o0 + r) : 0;
         }
     } else {
         constexpr int ntask = (2 * WD + kThreads - 1) / kThreads;
@@ -433,7 +436,7 @@ __device__ __forceinline__ void load_stage_exp(StageExp<WD> &se, const int *__re
             int q, kp;
             km_task<WD>(tid + kThreads * jt, q, kp);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) se.km[jt][j] = (o0 + 4 * q + j < n) ? exps[o0 + 4 * q + j] : 0;
+            for (int j = 0; j < 4; ++j) se.km[jt][j] = (o0 + 4 * q + j < n) ? ex(o0 + 4 * q + j) : 0;
         }
     }
 #endif
@@ -810,6 +813,11 @@ __device__ __forceinline__ void half_step_f32(LoadFn load_far, StoreFn store_nex
 #if MH_SPLIT_F16
 int launch_row_exponents(const float *X, bool k_contiguous, long long n_rows, long long kext, long long ld, int *exps,
                          hipStream_t st, bool bits_only = false);
+// largest |x| (fp32 bit patterns) of the rows of TWO operands in one launch (+ one memset when a k-major operand needs
+// zeroed atomics): bitsA[a_rows], bitsB[b_rows] must be ADJACENT in memory (bitsA first, 256-byte aligned sizes)
+int launch_operand_absmax(const float *A, bool a_kcontig, long long a_rows, long long a_kext, long long lda, int *bitsA,
+                          const float *B, bool b_kcontig, long long b_rows, long long b_kext, long long ldb, int *bitsB,
+                          hipStream_t st);
 #endif
 int choose_splitk_tiles(long long tiles, int ktiles, double out_elems, double flops);
 // defined in conv.hip: the tile schedule of a 3x3 conv launch with bm x bn block tiles (ConvArgs explains the fields)
