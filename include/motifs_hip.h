@@ -85,6 +85,11 @@ int mh_roi_align_fwd(const float *feat, int B, int C, int H, int W, int feat_lay
 int mh_roi_align_bwd(const float *grad_out, int B, int C, int H, int W, int feat_layout,
                      const float *rois, int n, int ph, int pw, float spatial_scale,
                      float *grad_feat, void *stream);
+/* Deterministic variant of the backward (same arguments): a gather per input pixel in a fixed (roi, bin, corner) order
+ * instead of the reference's atomicAdd scatter (roi_align_kernel.cu:157-168) -- bit-reproducible run to run; used by the
+ * detector pre-training path (models/train_detector.py), where the gradient flows into the trunk.  C <= 1024. */
+int mh_roi_align_bwd_det(const float *grad_out, int B, int C, int H, int W, int feat_layout, const float *rois, int n,
+                         int ph, int pw, float spatial_scale, float *grad_feat, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Union-box mask rasteriser.  Replaces the Cython `draw_union_boxes(bbox_pairs[N,8], pooling_size)`

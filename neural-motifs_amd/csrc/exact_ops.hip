@@ -293,6 +293,62 @@ __global__ void roi_align_bwd_kernel(const float *__restrict__ grad_out, const f
     }
 }
 
+// Deterministic backward (the detector pre-training path back-propagates through RoIAlign into
+// the trunk): a GATHER instead of the reference's atomicAdd scatter.  One workgroup per input pixel (b, Y, X); it walks the
+// RoIs of image b in order and, the sampling grid being separable, only the <= 2 bin rows and <= 2 bin columns whose
+// bilinear footprint touches the pixel; every matching corner adds the same product the scatter kernel would have added
+// (cx * (cy * grad)), in a fixed order (roi, bin row, bin column, corner) -- the result is bit-reproducible run to run.
+__global__ __launch_bounds__(256) void roi_align_bwd_gather_kernel(const float *__restrict__ grad_out, const float *__restrict__ rois,
+                                                                  int n_rois, int B, int C, int H, int W, int ph, int pw,
+                                                                  float width, float height, int layout,
+                                                                  float *__restrict__ grad_feat)
+{
+    const int pix = blockIdx.x;
+    const int X = pix % W, Y = (pix / W) % H, b = pix / (W * H);
+    constexpr int kMaxPer = 4;                              // C <= 1024 with 256 threads
+    float acc[kMaxPer] = {0.f, 0.f, 0.f, 0.f};
+    for (int n = 0; n < n_rois; ++n) {
+        const RoiGeom g = load_roi(rois, n, width, height);
+        if (g.b_in != b) continue;                          // block-uniform
+        const float height_scale = (ph > 1) ? (g.y2 - g.y1) * (H - 1) / (ph - 1) : 0;
+        const float width_scale = (pw > 1) ? (g.x2 - g.x1) * (W - 1) / (pw - 1) : 0;
+        for (int py = 0; py < ph; ++py) {
+            const float in_y = (ph > 1) ? g.y1 * (H - 1) + py * height_scale : (float)(0.5 * (g.y1 + g.y2) * (H - 1));
+            if (in_y < 0 || in_y > H - 1) continue;
+            const int top = (int)floorf(in_y), bottom = (int)ceilf(in_y);
+            if (top != Y && bottom != Y) continue;
+            const float y_lerp = in_y - top;
+            for (int px = 0; px < pw; ++px) {
+                const float in_x = (pw > 1) ? g.x1 * (W - 1) + px * width_scale : (float)(0.5 * (g.x1 + g.x2) * (W - 1));
+                if (in_x < 0 || in_x > W - 1) continue;
+                const int left = (int)floorf(in_x), right = (int)ceilf(in_x);
+                if (left != X && right != X) continue;
+                const float x_lerp = in_x - left;
+#pragma unroll
+                for (int k = 0; k < kMaxPer; ++k) {
+                    const int d = threadIdx.x + 256 * k;
+                    if (d >= C) break;
+                    const float go = grad_out[(((size_t)n * C + d) * ph + py) * pw + px];
+                    const float dtop = (1 - y_lerp) * go, dbottom = y_lerp * go;
+                    float a = acc[k];
+                    if (top == Y && left == X) a += (1 - x_lerp) * dtop;
+                    if (top == Y && right == X) a += x_lerp * dtop;
+                    if (bottom == Y && left == X) a += (1 - x_lerp) * dbottom;
+                    if (bottom == Y && right == X) a += x_lerp * dbottom;
+                    acc[k] = a;
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < kMaxPer; ++k) {
+        const int d = threadIdx.x + 256 * k;
+        if (d >= C) break;
+        if (layout == 0) grad_feat[(((size_t)b * C + d) * H + Y) * W + X] = acc[k];
+        else grad_feat[(((size_t)b * H + Y) * W + X) * C + d] = acc[k];
+    }
+}
+
 // =====================================================================================
 // union-box mask rasteriser (lib/draw_rectangles/draw_rectangles.pyx:41-66)
 // =====================================================================================
@@ -582,6 +638,20 @@ int mh_roi_align_bwd(const float *grad_out, int B, int C, int H, int W, int feat
     hipLaunchKernelGGL(roi_align_bwd_kernel, dim3(blocks), dim3(256), 0, st, grad_out, rois, n, B, C, H, W, ph, pw,
                        width, height, feat_layout, grad_feat);
     return check_launch("roi_align_bwd_kernel");
+}
+
+int mh_roi_align_bwd_det(const float *grad_out, int B, int C, int H, int W, int feat_layout, const float *rois, int n,
+                         int ph, int pw, float spatial_scale, float *grad_feat, void *stream)
+{
+    MH_REQUIRE(B > 0 && C > 0 && C <= 1024 && H > 0 && W > 0 && ph > 0 && pw > 0 && n >= 0 && grad_feat);
+    MH_REQUIRE(feat_layout == 0 || feat_layout == 1);
+    MH_REQUIRE(n == 0 || (grad_out && rois));
+    MH_REQUIRE((long long)B * H * W < (1LL << 31));
+    float width, height;
+    roi_norm(H, W, spatial_scale, &width, &height);
+    hipLaunchKernelGGL(roi_align_bwd_gather_kernel, dim3((unsigned)(B * H * W)), dim3(256), 0, as_stream(stream), grad_out, rois,
+                       n, B, C, H, W, ph, pw, width, height, feat_layout, grad_feat);
+    return check_launch("roi_align_bwd_gather_kernel");
 }
 
 int mh_draw_union_boxes(const float *box_pairs, int n, int P, float offset, int channels_last, float *out,

@@ -20,7 +20,7 @@ SO_PATH = os.environ.get('MOTIFS_HIP_LIB') or os.path.join(os.path.dirname(_HERE
 SYMBOLS = (
     'mh_version', 'mh_mfma_split', 'mh_split_rne', 'mh_split_f16', 'mh_last_error',
     'mh_nms_ws_bytes', 'mh_nms', 'mh_nms_batched_ws_bytes', 'mh_nms_batched',
-    'mh_roi_align_fwd', 'mh_roi_align_bwd', 'mh_draw_union_boxes', 'mh_bbox_overlaps', 'mh_triplet_match',
+    'mh_roi_align_fwd', 'mh_roi_align_bwd', 'mh_roi_align_bwd_det', 'mh_draw_union_boxes', 'mh_bbox_overlaps', 'mh_triplet_match',
     'mh_gemm_ws_bytes', 'mh_gemm_auto_splitk', 'mh_gemm_f32',
     'mh_conv3x3_packed_floats', 'mh_conv3x3_pack_weight', 'mh_conv3x3_ws_bytes', 'mh_conv3x3_schedule', 'mh_conv3x3_nhwc',
     'mh_conv3x3_wgrad_ws_bytes', 'mh_conv3x3_wgrad', 'mh_conv_first_nchw', 'mh_maxpool2x2_nhwc',
@@ -230,9 +230,12 @@ def roi_align_bwd(grad_out, rois, B, C, H, W, spatial_scale, nhwc):
     n, _, ph, pw = grad_out.shape
     shape = (B, H, W, C) if nhwc else (B, C, H, W)
     gf = torch.empty(shape, dtype=torch.float32, device=grad_out.device)
-    rc = lib().mh_roi_align_bwd(f32(grad_out), B, C, H, W, c_int(int(nhwc)), f32(rois), n, ph, pw,
-                                c_float(spatial_scale), f32(gf), stream())
-    _check(rc, 'mh_roi_align_bwd')
+    # deterministic gather by default (bit-reproducible gradients into the trunk); MOTIFS_ROIALIGN_BWD=atomic selects the
+    # reference-style atomicAdd scatter
+    det = os.environ.get('MOTIFS_ROIALIGN_BWD', 'gather') != 'atomic' and C <= 1024
+    fn = lib().mh_roi_align_bwd_det if det else lib().mh_roi_align_bwd
+    rc = fn(f32(grad_out), B, C, H, W, c_int(int(nhwc)), f32(rois), n, ph, pw, c_float(spatial_scale), f32(gf), stream())
+    _check(rc, 'mh_roi_align_bwd_det' if det else 'mh_roi_align_bwd')
     return gf
 
 

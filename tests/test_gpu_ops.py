@@ -115,6 +115,33 @@ def test_roi_align_bwd(hip):
     np.testing.assert_allclose(out2.permute(0, 3, 1, 2).cpu().numpy(), ref, atol=1e-5)
 
 
+def test_roi_align_bwd_gather_is_deterministic_and_equals_the_scatter(hip, monkeypatch):
+    """the default backward is the gather kernel (fixed accumulation order): bit-identical run to run, equal to the
+    reference-style atomicAdd scatter up to summation order, incl. heavily overlapping RoIs, RoIs outside the map, an
+    out-of-range image index and 600 channels (3 channel passes per thread)"""
+    from oracle import native
+    rs = np.random.RandomState(8)
+    B, C, n = 3, 600, 200
+    rois = _rois(rs, n, B)
+    rois[:40, 1:] = rois[0, 1:] + rs.uniform(-3, 3, (40, 4)).astype(np.float32)      # a pile of near-duplicates
+    rois[:40, 0] = rois[0, 0]
+    rois[41] = [1, -300, -300, -100, -50]                                           # entirely outside
+    rois[42, 0] = 7                                                                  # image index out of range
+    g = rs.randn(n, C, 7, 7).astype(np.float32)
+    a = hip.roi_align_bwd(dev(g), dev(rois), B, C, 37, 37, 1.0 / 16, nhwc=True)
+    for _ in range(3):
+        b = hip.roi_align_bwd(dev(g), dev(rois), B, C, 37, 37, 1.0 / 16, nhwc=True)
+        assert torch.equal(a.view(torch.int32), b.view(torch.int32))
+    monkeypatch.setenv('MOTIFS_ROIALIGN_BWD', 'atomic')
+    s = hip.roi_align_bwd(dev(g), dev(rois), B, C, 37, 37, 1.0 / 16, nhwc=True)
+    scale = float(s.abs().max())
+    assert float((a - s).abs().max()) <= 2e-6 * scale
+    ref = native.roi_align_bwd(g[:, :24].copy(), rois, (B, 24, 37, 37))
+    np.testing.assert_allclose(a.permute(0, 3, 1, 2)[:, :24].cpu().numpy(), ref, atol=1e-5 * max(1.0, scale))
+    nchw = hip.roi_align_bwd(dev(g), dev(rois), B, C, 37, 37, 1.0 / 16, nhwc=False)
+    assert torch.equal(nchw.permute(0, 2, 3, 1).contiguous().view(torch.int32), a.view(torch.int32))
+
+
 # ----------------------------------------------------------------------------------------------- masks / IoU
 @pytest.mark.parametrize('P', [27, 7])
 def test_draw_union_boxes_matches_reference_golden(hip, golden, P):
