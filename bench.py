@@ -10,14 +10,18 @@ collective is the gradient all-reduce.  Rank 0 prints ONE JSON line.
 
 Extra objects in the line:
   roofline     -- the dominant kernel (conv3x3 implicit GEMM on the matrix cores): algorithmic fp32 FLOPs / HIP-event
-                  time of its launches during the timed steps, against the matrix-core peak of the evaluation the
-                  library was built with (bf16x6: 2500/6 = 416.7 TFLOP/s fp32-equivalent; f32 MFMA: 157.3 TFLOP/s;
-                  `frac_of_f32_mfma_peak` is always given too).  `traffic` = fabric-side bytes per launch of that
-                  kernel from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over the same 14 launches
-                  (collected offline, profiles/r01_conv_traffic_summary.json: a PMC pass over the whole step does not
-                  finish); `traffic_algorithmic` = input + weights + output bytes of those launches.
-  cpu_baseline -- the CPU oracle (oracle/model.py, "port") timed on this host on a bounded sample of the same
-                  workload (1 image, forward+backward), rank 0 at N=1 only.
+                  time of its calls during the timed steps (a call = the kernel plus, in the f16x3 build, its two small
+                  row-exponent launches), against the matrix-core peak of the evaluation the library was built with
+                  (f16x3, the default: 2500/3 = 833 TFLOP/s fp32-equivalent; bf16x6: 2500/6 = 416.7; f32 MFMA: 157.3;
+                  `frac_of_f32_mfma_peak` and `frac_of_bf16x6_peak` are always given too).  `traffic` = fabric-side bytes
+                  per launch of that kernel from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over the same 14
+                  launches (replayed offline, profiles/r02_conv_traffic_summary.json: a PMC pass over the whole step does
+                  not finish); `traffic_algorithmic` = input + weights + output bytes of those launches.
+  roofline_gemm-- the same for every mh_gemm_f32 call of the step (fc6/fc7 of the three RoI heads, LSTM input
+                  projections, post_lstm, heads; forward, input and weight gradients).
+  cpu_baseline -- the CPU oracle (oracle/model.py, "port") timed on this host: the same cfg2 step at b = 6 (1 warm-up +
+                  3 timed iterations) and the cfg1 PredCls evaluation (1 image per step), rank 0 at N=1 only.
+  --config cfgN-- secondary rows for the other BASELINE.json configurations (see `secondary`).
 """
 import argparse
 import json
@@ -36,7 +40,7 @@ for p in (ROOT, os.path.join(ROOT, 'neural-motifs_amd')):
 
 PEAK_FP32_MFMA_TFLOPS = 157.3          # /opt/skills/guides/MI355X_MICROARCH.md chip table (f32-input MFMA)
 PEAK_BF16_MFMA_TFLOPS = 2500.0         # same table, dense bf16 MFMA
-TRAFFIC_SUMMARY = 'profiles/r01_conv_traffic_summary.json'   # tools/traffic_summary.py
+TRAFFIC_SUMMARY = 'profiles/r02_conv_traffic_summary.json'   # tools/traffic_summary.py (f16x3 build, shipped schedule)
 MODEL_KW = dict(hidden_dim=512, pooling_dim=4096, nl_obj=2, nl_edge=2, order='leftright', rec_dropout=0.1,
                 use_bias=True, pass_in_obj_feats_to_decoder=False, pass_in_obj_feats_to_edge=False, use_tanh=False,
                 limit_vision=False)
@@ -143,7 +147,7 @@ def secondary(args, rank, world, dev):
       cfg4  ResNet-101 backbone (conv1..layer3, lib/resnet.py) forward at b = 6: the reference's `-resnet` RelModel cannot
             run (lib/rel_model.py:360-365 vs :448), so the row is the trunk the config is named after       -- trunk img/s
       cfg5  SGDet evaluation stress, one image per step (the reference's eval decoder asserts batch 1), max_per_img = 80 ->
-            all overlapping ordered pairs (<= 6320 / img) through the union-box relation head                                                                        -- eval img/s
+            all 80*79 = 6320 ordered pairs (require_overlap off) through the union-box relation head                                                                        -- eval img/s
     The random-weight detector is made confident (score_fc x30, RPN objectness x4, as tests/test_gpu_sgdet.py does) so that
     the per-class NMS keeps max_per_img detections per image: the workload is then the configuration's worst case."""
     from dataloaders.synthetic import SyntheticVG, make_blob
@@ -184,8 +188,29 @@ def secondary(args, rank, world, dev):
             with torch.no_grad():
                 model.detector.score_fc.weight.mul_(30.0)
                 model.detector.rpn_head.conv[2].weight.mul_(4.0)
+        if cfg == 'cfg5':
+            model.require_overlap = False                     # the stress case: ALL N(N-1) ordered pairs, not only overlapping ones
         model.to(dev)
         train = cfg == 'cfg3'
+        if train:
+            # A random-weight detector matches (almost) no synthetic GT box, and rel_assignments would then sample ~1 row per
+            # image.  Make the workload what training sees: run the detector once in eval mode and use ITS detections as the
+            # images' ground-truth boxes (random classes, 30 random relations): GT matching then labels the detections of
+            # the timed steps (same proposals; the RoI head's dropout moves some boxes) and <= 64 rows / image are sampled.
+            model.eval()
+            model.eval_on_device = True
+            rs = np.random.RandomState(seed)
+            with torch.no_grad():
+                for i in range(n_img):
+                    out = model[make_blob(ds, [i], is_train=False)]
+                    boxes = model.last_eval_result.rm_box_priors.float().cpu().numpy()     # the boxes GT matching compares (:319-326)
+                    nb = boxes.shape[0]
+                    ds.gt_boxes[i] = (boxes * (1024.0 / 592.0)).astype(np.float32)          # stored at BOX_SCALE like VG
+                    ds.gt_classes[i] = rs.randint(1, 151, nb).astype(np.int64)
+                    pairs = np.array([(a_, b_) for a_ in range(nb) for b_ in range(nb) if a_ != b_])
+                    sel = pairs[rs.choice(len(pairs), size=min(N_RELS, len(pairs)), replace=False)]
+                    ds.relationships[i] = np.column_stack((sel, rs.randint(1, 51, sel.shape[0]))).astype(np.int64)
+            model.eval_on_device = False
         model.train(train)
         blobs = [make_blob(ds, range(i * b, (i + 1) * b), is_train=train) for i in range(n_img // b)]
         for bl in blobs:
@@ -212,8 +237,8 @@ def secondary(args, rank, world, dev):
             model.eval_on_device = True                       # Recall@K inputs stay on the device (no [Nrel,51] D2H per image)
             unit_name = 'images/sec MotifNet-%s eval' % ('PredCls' if cfg == 'cfg1' else 'SGDet')
             workload = ('PredCls evaluation forward, 1 image (20 GT boxes -> 380 pairs) per step, VGG16, 592x592' if cfg == 'cfg1' else
-                        'SGDet evaluation forward, 1 image per step, max_per_img 80 -> all overlapping ordered pairs through the union-box '
-                        'relation head (<= 6320 pairs/img), VGG16, 592x592')
+                        'SGDet evaluation forward, 1 image per step, max_per_img 80 -> ALL ordered pairs (80*79 = 6320) through the '
+                        'union-box relation head, VGG16, 592x592')
 
             def step(i):
                 with torch.no_grad():
@@ -365,7 +390,7 @@ def main():
             peak, how = PEAK_FP32_MFMA_TFLOPS, 'v_mfma_f32_32x32x2_f32'
         traffic = None
         tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), TRAFFIC_SUMMARY)
-        if os.path.exists(tpath) and split:                  # collected on the bf16x6 build, on exactly these 14 launches
+        if os.path.exists(tpath) and _hip.lib().mh_split_f16():   # collected on the f16x3 build, on exactly these 14 launches
             with open(tpath) as f:
                 traffic = json.load(f)
             if traffic.get('launches') * args.steps != conv['launches']:
@@ -383,8 +408,10 @@ def main():
                          'traffic_unit': 'bytes per launch (L2 fabric side: HBM + Infinity-Cache)',
                          'traffic_algorithmic': traffic['algorithmic_bytes_per_launch'] if traffic else None,
                          'traffic_source': TRAFFIC_SUMMARY + ' (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over one '
-                                           'launch per shape of this step, tools/traffic_run.sh; not re-measured by this run)',
+                                           'launch per shape of this step with the shipped f16x3 library, tools/traffic_run.sh + tools/traffic_summary.py; '
+                                           'replayed offline: a PMC pass over the whole step does not finish)',
                          'frac_of_f32_mfma_peak': conv['tflops'] / PEAK_FP32_MFMA_TFLOPS,
+                         'frac_of_bf16x6_peak': conv['tflops'] / (PEAK_BF16_MFMA_TFLOPS / 6.0),
                          'launches': conv['launches'], 'avg_launch_ms': conv['avg_ms'],
                          'flops_per_launch': conv['flops_per_launch']},
         }
