@@ -1,4 +1,5 @@
-// gemm.hip -- FP32 GEMM on the gfx950 matrix cores (v_mfma_f32_32x32x2_f32) for every nn.Linear-shaped
+// gemm.hip -- fp32-accurate GEMM on the gfx950 matrix cores (f16x3 by default: three v_mfma_f32_32x32x16_f16 per product,
+// mfma_tile.h) for every nn.Linear-shaped
 // contraction on the path (fc6/fc7 x3, score/bbox heads, LSTM input projections, post_lstm, rel_compress and
 // their dgrad/wgrad).  Block tile 128x128x16, LDS double-buffered with register prefetch (one barrier per
 // k-tile), optional split-K with a fused bias/activation reduction.  See mfma_tile.h for the tile engine.
