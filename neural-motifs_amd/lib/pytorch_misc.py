@@ -27,6 +27,23 @@ def optimistic_restore(network, state_dict):
     return ok
 
 
+def restore_rel_checkpoint(rel_model, ckpt, ckpt_name):
+    """What models/train_rels.py:76-96 of the reference does with `-ckpt`: a relation-model checkpoint ('.../vgrel-N.tar')
+    restores everything and resumes at its epoch; any other file is a DETECTOR checkpoint ('vg-faster-rcnn.tar',
+    'vgdet/vg-N.tar'): it fills `rel_model.detector` and seeds the relation model's two copies of the VGG fc6 / fc7
+    (`roi_fmap[1]`, `roi_fmap_obj`) from the detector's `roi_fmap`.  Returns the epoch to resume after (-1 = start)."""
+    sd = ckpt['state_dict']
+    if ckpt_name.split('-')[-2].split('/')[-1] == 'vgrel':
+        print("Loading EVERYTHING")
+        return ckpt['epoch'] if optimistic_restore(rel_model, sd) else -1
+    optimistic_restore(rel_model.detector, sd)
+    for dst in (rel_model.roi_fmap[1], rel_model.roi_fmap_obj):
+        for idx in (0, 3):
+            dst[idx].weight.data.copy_(sd['roi_fmap.%d.weight' % idx])
+            dst[idx].bias.data.copy_(sd['roi_fmap.%d.bias' % idx])
+    return -1
+
+
 class Flattener(nn.Module):
     def forward(self, x):
         return x.reshape(x.size(0), -1)

@@ -25,7 +25,7 @@ from dataloaders.visual_genome import VGDataLoader, VG
 from lib import dist as D
 from lib.evaluation.sg_eval import BasicSceneGraphEvaluator
 from lib.optim import FusedClipSGD
-from lib.pytorch_misc import optimistic_restore, clip_grad_norm, print_para
+from lib.pytorch_misc import restore_rel_checkpoint, clip_grad_norm, print_para
 
 conf = ModelConfig()
 if conf.model == 'motifnet':
@@ -83,18 +83,7 @@ def get_optim(lr):
 
 start_epoch = -1
 if conf.ckpt is not None:
-    ckpt = torch.load(conf.ckpt, map_location='cpu')
-    if conf.ckpt.split('-')[-2].split('/')[-1] == 'vgrel':
-        print("Loading EVERYTHING")
-        start_epoch = ckpt['epoch']
-        if not optimistic_restore(detector, ckpt['state_dict']):
-            start_epoch = -1
-    else:                                                     # a detector checkpoint: seed the three fc6/fc7 copies
-        optimistic_restore(detector.detector, ckpt['state_dict'])
-        for dst in (detector.roi_fmap[1], detector.roi_fmap_obj):
-            for idx in (0, 3):
-                dst[idx].weight.data.copy_(ckpt['state_dict']['roi_fmap.%d.weight' % idx])
-                dst[idx].bias.data.copy_(ckpt['state_dict']['roi_fmap.%d.bias' % idx])
+    start_epoch = restore_rel_checkpoint(detector, torch.load(conf.ckpt, map_location='cpu'), conf.ckpt)
 
 detector.cuda()
 reducer = D.OverlappedGradReducer([p for p in detector.parameters() if p.requires_grad])   # inert at world 1

@@ -270,3 +270,92 @@ def test_conv_traffic_summary_matches_the_committed_counter_files():
     assert all(r['splitk_partials'] or abs(r['write_bytes'] / r['write_bytes_algorithmic'] - 1) < 1e-3 for r in rows)
     assert all(r['read_bytes'] >= r['read_bytes_algorithmic'] for r in rows)
     assert 1.0 < committed['ratio'] < 2.0
+
+
+# ---- reference-format checkpoints (reference models/train_rels.py:76-96, lib/pytorch_misc.py:14-33) ----
+def _reference_format_detector_state():
+    """state_dict of a torch-native module tree built the way the reference's VGG ObjectDetector is
+    (lib/object_detector.py:78-104, 488-515: torchvision vgg16 `features[:-1]` and `classifier[:-1]`, score / bbox heads,
+    RPNHead.conv + the anchors buffer) -- the layout of `vg-faster-rcnn.tar`.  Nothing of the product is used to build it."""
+    from torch import nn
+    g = torch.Generator().manual_seed(11)
+    layers, cin = [], 3
+    for v in (64, 64, 'M', 128, 128, 'M', 256, 256, 256, 'M', 512, 512, 512, 'M', 512, 512, 512):
+        if v == 'M':
+            layers.append(nn.MaxPool2d(2, 2))
+        else:
+            layers += [nn.Conv2d(cin, v, 3, padding=1), nn.ReLU(True)]
+            cin = v
+
+    class RPNHead(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.conv = nn.Sequential(nn.Conv2d(512, 512, 3, padding=1), nn.ReLU6(True), nn.Conv2d(512, 6 * 20, 1))
+            self.register_buffer('anchors', torch.zeros(37, 37, 20, 4))
+
+    class Twin(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.features = nn.Sequential(*layers)
+            self.roi_fmap = nn.Sequential(nn.Linear(25088, 4096), nn.ReLU(True), nn.Dropout(), nn.Linear(4096, 4096),
+                                          nn.ReLU(True), nn.Dropout())
+            self.score_fc = nn.Linear(4096, 151)
+            self.bbox_fc = nn.Linear(4096, 151 * 4)
+            self.rpn_head = RPNHead()
+
+    sd = Twin().state_dict()
+    for k, v in sd.items():
+        v.copy_(torch.randn(v.shape, generator=g) * 0.01)
+    return sd
+
+
+def test_reference_format_checkpoints_restore(small_world, tmp_path, capsys):
+    from lib.pytorch_misc import restore_rel_checkpoint, optimistic_restore
+    _, model, _ = small_world
+    # (1) a detector checkpoint: everything of the detector is found (no "Unexpected key" / "couldn't find" / size
+    # complaints), and the relation model's fc6 / fc7 copies are seeded from it
+    sd = _reference_format_detector_state()
+    path = str(tmp_path / 'vg-faster-rcnn.tar')
+    torch.save({'epoch': 11, 'state_dict': sd}, path)
+    ckpt = torch.load(path, map_location='cpu')
+    assert optimistic_restore(model.detector, ckpt['state_dict']) is True
+    for k, v in model.detector.state_dict().items():
+        assert torch.equal(v, sd[k]), k
+    for p in model.roi_fmap[1].parameters():
+        p.data.zero_()
+    assert restore_rel_checkpoint(model, ckpt, path) == -1
+    out = capsys.readouterr().out
+    assert 'Unexpected key' not in out and "couldn't find" not in out and 'ckpt has' not in out
+    for dst in (model.roi_fmap[1], model.roi_fmap_obj):
+        for idx in (0, 3):
+            assert torch.equal(dst[idx].weight, sd['roi_fmap.%d.weight' % idx])
+            assert torch.equal(dst[idx].bias, sd['roi_fmap.%d.bias' % idx])
+    # (2) a relation-model checkpoint ('vgrel-N.tar') restores every tensor and resumes at its epoch
+    full = {k: v.clone() for k, v in model.state_dict().items()}
+    small = {k: v for k, v in full.items() if v.numel() < (1 << 22)}        # perturb the cheap tensors only
+    for k, v in small.items():
+        if v.is_floating_point():
+            v.add_(0.5)
+    path2 = str(tmp_path / 'vgrel-7.tar')
+    torch.save({'epoch': 7, 'state_dict': full}, path2)
+    assert restore_rel_checkpoint(model, torch.load(path2, map_location='cpu'), path2) == 7
+    now = model.state_dict()
+    for k, v in small.items():
+        assert torch.equal(now[k], v), k
+    # (3) a checkpoint with another class count: the mismatching tensors are reported and skipped, the rest is loaded,
+    # and the epoch is NOT resumed (reference train_rels.py:80-82)
+    bad = dict(full)
+    bad['detector.score_fc.weight'] = torch.zeros(10, 4096)
+    bad['rel_compress.bias'] = full['rel_compress.bias'] + 1.0
+    del bad['post_lstm.bias']
+    bad['not_a_module.weight'] = torch.zeros(3)
+    assert restore_rel_checkpoint(model, {'epoch': 9, 'state_dict': bad}, 'checkpoints/x/vgrel-9.tar') == -1
+    out = capsys.readouterr().out
+    assert 'detector.score_fc.weight' in out and 'post_lstm.bias' in out and 'not_a_module.weight' in out
+    assert torch.equal(model.state_dict()['rel_compress.bias'], bad['rel_compress.bias'])
+    assert torch.equal(model.state_dict()['detector.score_fc.weight'], full['detector.score_fc.weight'])
+    # leave the shared fixture as the other tests expect it: finite, moderate weights
+    for k, v in small.items():
+        if v.is_floating_point():
+            v.sub_(0.5)
+    optimistic_restore(model, full)
