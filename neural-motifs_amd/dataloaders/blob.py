@@ -12,6 +12,8 @@ nothing reads them, `train_anchor_inds` is an empty [0,4] tensor.  `anchor_rs` i
 import numpy as np
 import torch
 
+from lib.pytorch_misc import set_host
+
 
 class Blob(object):
     def __init__(self, mode='det', is_train=False, num_gpus=1, primary_gpu=None, batch_size_per_gpu=3):
@@ -74,21 +76,24 @@ class Blob(object):
             self.proposals = torch.from_numpy(np.concatenate(self.proposals, 0)).float()
             self.proposal_chunks = [self.proposals.shape[0]]
 
-    def _to_device(self, x):
+    def _to_device(self, x, mirror=False):
         # one process per GPU: the target is the device THIS rank made current (torch.cuda.set_device(local_rank) in
         # lib/dist.init_from_env / the drivers), unless a caller pins primary_gpu explicitly (reference blob.py:20)
         dev = torch.cuda.current_device() if self.primary_gpu is None else self.primary_gpu
-        return x.cuda(dev, non_blocking=True)
+        y = x.cuda(dev, non_blocking=True)
+        if mirror:                       # small GT index arrays keep their host values (lib/pytorch_misc.py: host mirrors)
+            set_host(y, x.numpy())
+        return y
 
     def scatter(self):
         """move the batch to this process's GPU (asynchronous H2D)"""
         if isinstance(self.imgs, torch.Tensor) and self.imgs.is_cuda:
             return
         self.imgs = self._to_device(self.imgs)
-        self.gt_classes = self._to_device(self.gt_classes)
-        self.gt_boxes = self._to_device(self.gt_boxes)
+        self.gt_classes = self._to_device(self.gt_classes, mirror=True)
+        self.gt_boxes = self._to_device(self.gt_boxes, mirror=True)
         if self.is_rel:
-            self.gt_rels = self._to_device(self.gt_rels)
+            self.gt_rels = self._to_device(self.gt_rels, mirror=True)
         if self.is_train:
             self.train_anchor_inds = self._to_device(self.train_anchor_inds)
             if not self.is_rel:

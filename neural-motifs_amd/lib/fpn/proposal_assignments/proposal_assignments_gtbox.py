@@ -9,7 +9,7 @@ import numpy as np
 import torch
 
 from config import RELS_PER_IMG, REL_FG_FRACTION
-from lib.pytorch_misc import enumerate_by_image
+from lib.pytorch_misc import enumerate_by_image, host_np
 
 
 def proposal_assignments_gtbox(rois, gt_boxes, gt_classes, gt_rels, image_offset, fg_thresh=0.5, rs=None):
@@ -19,11 +19,11 @@ def proposal_assignments_gtbox(rois, gt_boxes, gt_classes, gt_rels, image_offset
     """
     rs = np.random if rs is None else rs
     dev = rois.device
-    im_inds = rois[:, 0].long().cpu().numpy()
+    im_inds = host_np(rois)[:, 0].astype(np.int64)          # no device round trip when the Blob's host mirrors are attached
     n = im_inds.shape[0]
     num_im = int(im_inds[-1]) + 1
 
-    fg = gt_rels.cpu().numpy().astype(np.int64).copy()
+    fg = host_np(gt_rels).astype(np.int64).copy()
     fg[:, 0] -= image_offset
     first_box = {i: s for i, s, e in enumerate_by_image(im_inds)}
     for r in range(fg.shape[0]):

@@ -211,7 +211,7 @@ class DecoderRNN(torch.nn.Module):
                 h_prev, c_prev = h, c
         return torch.cat(fed, 0), torch.cat(commits, 0)
 
-    def forward(self, inputs, initial_state=None, labels=None, boxes_for_nms=None):
+    def forward(self, inputs, initial_state=None, labels=None, boxes_for_nms=None, labels_have_background=None):
         if not isinstance(inputs, PackedSequence):
             raise ValueError('inputs must be PackedSequence but got %s' % (type(inputs)))
         if initial_state is not None:
@@ -228,7 +228,9 @@ class DecoderRNN(torch.nn.Module):
         if self.training:
             if labels is None:
                 raise ValueError('training needs labels (teacher forcing)')
-            if bool((labels == 0).any()):
+            if labels_have_background is None:                      # unknown on the host: ask the device (synchronises)
+                labels_have_background = bool((labels == 0).any())
+            if labels_have_background:
                 fed, commits = self._greedy_feedback(enc_proj.detach(), emb_proj.detach(), batch_sizes, labels,
                                                      dropout_mask)
             else:

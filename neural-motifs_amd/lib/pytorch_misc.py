@@ -27,6 +27,31 @@ def optimistic_restore(network, state_dict):
     return ok
 
 
+# ---- host mirrors ---------------------------------------------------------------------------------------------------
+# The index work the host does in a step (relation sampling, the packing order of the LSTMs) needs the VALUES of a few
+# small integer tensors -- the image index / class / relation list of the GT boxes -- that came from the host in the first
+# place (dataloaders/blob.py).  Reading them back with .cpu() makes the host wait until the GPU has drained its queue (the
+# whole trunk), after which every small launch of the step is issued with the GPU idle: 4-5 ms of a 27 ms SGCls step
+# (profiles/r02_trace_gaps.txt).  A tensor can therefore carry a numpy copy of itself; derived tensors get theirs from
+# the places that derive them.  Mirrors are only attached to tensors nobody writes to afterwards.
+def set_host(t, arr):
+    """attach `arr` (numpy, same values as `t`) to the tensor object; returns t"""
+    t._host_np = np.asarray(arr)
+    return t
+
+
+def has_host(t):
+    return getattr(t, '_host_np', None) is not None
+
+
+def host_np(t):
+    """numpy values of `t`: the mirror when there is one (no device synchronisation), a device->host copy otherwise"""
+    if not torch.is_tensor(t):
+        return np.asarray(t)
+    a = getattr(t, '_host_np', None)
+    return a if a is not None else t.detach().cpu().numpy()
+
+
 def restore_rel_checkpoint(rel_model, ckpt, ckpt_name):
     """What models/train_rels.py:76-96 of the reference does with `-ckpt`: a relation-model checkpoint ('.../vgrel-N.tar')
     restores everything and resumes at its epoch; any other file is a DETECTOR checkpoint ('vg-faster-rcnn.tar',
@@ -75,7 +100,7 @@ def gather_nd(x, index):
 
 def enumerate_by_image(im_inds):
     """yield (image id, start, end) for every run of equal image indices (reference :278-287)"""
-    arr = im_inds.cpu().numpy() if torch.is_tensor(im_inds) else np.asarray(im_inds)
+    arr = host_np(im_inds)
     if arr.shape[0] == 0:
         return
     start, cur = 0, int(arr[0])

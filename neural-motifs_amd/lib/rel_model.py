@@ -27,7 +27,8 @@ from lib.hip_ops import Dropout, Flattener, Linear, ReLU, linear
 from lib.lstm.decoder_rnn import DecoderRNN
 from lib.lstm.highway_lstm_cuda.alternating_highway_lstm import AlternatingHighwayLSTM
 from lib.object_detector import ObjectDetector, gather_res, load_vgg
-from lib.pytorch_misc import transpose_packed_sequence_inds, to_onehot, arange, enumerate_by_image
+from lib.pytorch_misc import (transpose_packed_sequence_inds, to_onehot, arange, enumerate_by_image, has_host, host_np,
+                              set_host)
 from lib.sparse_targets import FrequencyBias
 from lib.surgery import filter_dets
 from lib.word_vectors import obj_edge_vectors
@@ -38,10 +39,11 @@ MODES = ('sgdet', 'sgcls', 'predcls')
 def _sort_by_score(im_inds, scores):
     """Permutation that orders rois for the LSTMs (reference :31-61): inside an image by descending score, images by
     decreasing object count, then time-major (TxB packed).  Returns (perm, inv_perm, batch size per timestep)."""
-    num_im = int(im_inds[-1]) + 1
+    im_host = host_np(im_inds)           # the mirror of GT-derived indices (no D2H synchronisation), else a copy
+    num_im = int(im_host[-1]) + 1
     im_key = np.zeros(num_im, dtype=np.float32)
     lengths = []
-    for i, s, e in enumerate_by_image(im_inds):
+    for i, s, e in enumerate_by_image(im_host):
         im_key[i] = 2 * (s - e) * num_im + i
         lengths.append(e - s)
     lengths = sorted(lengths, reverse=True)
@@ -134,22 +136,25 @@ class LinearizedContext(nn.Module):
         obj_embed2 = self.obj_embed2(obj_preds)
         inp_feats = torch.cat((obj_embed2, obj_feats), 1)
         confidence = F.softmax(obj_dists, dim=1).detach().view(-1)[obj_preds.detach() + arange(obj_preds) * self.num_classes]
-        perm, inv_perm, ls_transposed = self.sort_rois(im_inds.detach(), confidence, box_priors)
+        perm, inv_perm, ls_transposed = self.sort_rois(im_inds, confidence, box_priors)
         edge_input_packed = PackedSequence(inp_feats[perm], torch.tensor(ls_transposed))
         edge_reps = self.edge_ctx_rnn(edge_input_packed)[0][0]
         return edge_reps[inv_perm]
 
     def obj_ctx(self, obj_feats, obj_dists, im_inds, obj_labels=None, box_priors=None, boxes_per_cls=None):
         confidence = F.softmax(obj_dists, dim=1).detach()[:, 1:].max(1)[0]
-        perm, inv_perm, ls_transposed = self.sort_rois(im_inds.detach(), confidence, box_priors)
+        perm, inv_perm, ls_transposed = self.sort_rois(im_inds, confidence, box_priors)
         obj_inp_rep = obj_feats[perm].contiguous()
         bs = torch.tensor(ls_transposed)
         encoder_rep = self.obj_ctx_rnn(PackedSequence(obj_inp_rep, bs))[0][0]
         if self.mode != 'predcls':
             dec_in = torch.cat((obj_inp_rep, encoder_rep), 1) if self.pass_in_obj_feats_to_decoder else encoder_rep
+            # teacher forcing needs to know whether any label is background: from the labels' host mirror when they
+            # came from a Blob (no synchronisation), else the decoder asks the device
+            has_bg = bool((host_np(obj_labels) == 0).any()) if obj_labels is not None and has_host(obj_labels) else None
             obj_dists, obj_preds = self.decoder_rnn(
                 PackedSequence(dec_in, bs),
-                labels=obj_labels[perm] if obj_labels is not None else None,
+                labels=obj_labels[perm] if obj_labels is not None else None, labels_have_background=has_bg,
                 boxes_for_nms=boxes_per_cls[perm] if boxes_per_cls is not None else None)
             obj_preds = obj_preds[inv_perm]
             obj_dists = obj_dists[inv_perm]
@@ -305,6 +310,8 @@ class RelModel(nn.Module):
             return ValueError("heck")            # the reference returns (not raises) this, :474-475
 
         im_inds = result.im_inds - image_offset
+        if has_host(result.im_inds):
+            set_host(im_inds, host_np(result.im_inds) - image_offset)
         boxes = result.rm_box_priors
         if self.training and result.rel_labels is None:
             assert self.mode == 'sgdet'

@@ -33,11 +33,13 @@ def keep_mask(shape, keep_prob, device):
     """float32 {0,1} tensor on `device` with P(1) = keep_prob"""
     if _host_rng is not None:
         return _host_rng.keep_mask(shape, keep_prob, device)
-    return (torch.rand(tuple(shape), device=device) < keep_prob).float()
+    return torch.empty(tuple(shape), dtype=torch.float32, device=device).bernoulli_(keep_prob)      # one launch
 
 
 def dropout(x, p, training):
     """inverted dropout: x * mask / (1-p)   (torch.nn.Dropout semantics, mask source switchable)"""
     if not training or p == 0.0:
         return x
+    if _host_rng is None:
+        return torch.nn.functional.dropout(x, p, True)       # fused mask + scale: one launch forward, one backward
     return x * keep_mask(x.shape, 1.0 - p, x.device) / (1.0 - p)

@@ -230,5 +230,10 @@ def install():
             setattr(_hip, name, fn)
     _hip.f32 = _hip.i32 = ptr
     _hip.lib = lambda: ShimLib
-    blob_mod.Blob._to_device = lambda self, x: x
+    def _stay(self, x, mirror=False):
+        if mirror:
+            from lib.pytorch_misc import set_host
+            set_host(x, x.numpy())
+        return x
+    blob_mod.Blob._to_device = _stay
     return _hip

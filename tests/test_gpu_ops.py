@@ -134,6 +134,7 @@ def test_roi_align_bwd_gather_is_deterministic_and_equals_the_scatter(hip, monke
         assert torch.equal(a.view(torch.int32), b.view(torch.int32))
     monkeypatch.setenv('MOTIFS_ROIALIGN_BWD', 'atomic')
     s = hip.roi_align_bwd(dev(g), dev(rois), B, C, 37, 37, 1.0 / 16, nhwc=True)
+    monkeypatch.delenv('MOTIFS_ROIALIGN_BWD')
     scale = float(s.abs().max())
     assert float((a - s).abs().max()) <= 2e-6 * scale
     ref = native.roi_align_bwd(g[:, :24].copy(), rois, (B, 24, 37, 37))
