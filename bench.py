@@ -294,6 +294,8 @@ def main():
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-iters', type=int, default=3, help='timed iterations of the CPU baseline (after 1 warm-up)')
+    ap.add_argument('--host-profile', action='store_true',
+                    help='after the timed region: host enqueue time of 3 unsynchronised steps + a cProfile of 3 more (stderr)')
     ap.add_argument('--config', default='cfg2', choices=['cfg1', 'cfg2', 'cfg3', 'cfg4', 'cfg5'],
                     help='BASELINE.json configs[i-1]; cfg2 (default) is the headline metric, the others are secondary rows')
     args = ap.parse_args()
@@ -371,6 +373,29 @@ def main():
     if world > 1:
         torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
     dt = float(tmax.item())
+
+    if args.host_profile and rank == 0:
+        # where the HOST spends a step: enqueue time without synchronisation (the GPU queue is empty at the start, so this
+        # is Python + launch overhead, not waiting), then the same under cProfile
+        import cProfile
+        import io
+        import pstats
+        hs = []
+        for i in range(3):
+            t1 = time.perf_counter()
+            step(i)
+            hs.append(1e3 * (time.perf_counter() - t1))
+        barrier()
+        pr = cProfile.Profile()
+        pr.enable()
+        for i in range(3):
+            step(i)
+        pr.disable()
+        barrier()
+        buf = io.StringIO()
+        pstats.Stats(pr, stream=buf).sort_stats('tottime').print_stats(50)
+        sys.stderr.write('host enqueue ms per step, unsynchronised: %s (timed region: %.2f ms/step)\n%s\n'
+                         % (['%.2f' % h for h in hs], 1e3 * dt / args.steps, buf.getvalue()))
 
     if rank == 0:
         conv = meter.summary()
