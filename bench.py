@@ -196,7 +196,7 @@ def secondary(args, rank, world, dev):
             # A random-weight detector matches (almost) no synthetic GT box, and rel_assignments would then sample ~1 row per
             # image.  Make the workload what training sees: run the detector once in eval mode and use ITS detections as the
             # images' ground-truth boxes (random classes, 30 random relations): GT matching then labels the detections of
-            # the timed steps (same proposals; the RoI head's dropout moves some boxes) and <= 64 rows / image are sampled.
+            # the timed steps (same proposals, detector dropout off) and <= 64 rows / image are sampled.
             model.eval()
             model.eval_on_device = True
             rs = np.random.RandomState(seed)
@@ -212,6 +212,13 @@ def secondary(args, rank, world, dev):
                     ds.relationships[i] = np.column_stack((sel, rs.randint(1, 51, sel.shape[0]))).astype(np.int64)
             model.eval_on_device = False
         model.train(train)
+        if train:
+            # the frozen detector's RoI-head dropout would move the detections away from the boxes just taken as ground
+            # truth (fewer matches -> fewer relation rows): keep it off, as a trained detector's detections match their GT
+            from lib.hip_ops import Dropout
+            for m in model.detector.modules():
+                if isinstance(m, Dropout):
+                    m.eval()
         blobs = [make_blob(ds, range(i * b, (i + 1) * b), is_train=train) for i in range(n_img // b)]
         for bl in blobs:
             bl.scatter()

@@ -13,6 +13,7 @@ import torch
 
 from config import BG_THRESH_HI, BG_THRESH_LO, FG_FRACTION, ROIS_PER_IMG
 from lib.fpn.box_utils import bbox_overlaps
+from lib.pytorch_misc import h2d
 
 
 def _sel_inds(max_overlaps, fg_thresh=0.5, fg_rois_per_image=128, rois_per_image=256, rs=None):
@@ -51,7 +52,7 @@ def proposal_assignments_det(rpn_rois, gt_boxes, gt_classes, image_offset, fg_th
         keep_np, n_fg = _sel_inds(best_iou.cpu().numpy(), fg_thresh, fg_quota, ROIS_PER_IMG, rs)
         if keep_np.size == 0:
             continue
-        keep = torch.from_numpy(keep_np.astype(np.int64)).to(rpn_rois.device)
+        keep = h2d(keep_np.astype(np.int64), rpn_rois.device)
         matched = best_gt[keep] + g0
         lab = gt_classes[:, 1][matched].clone()
         lab[n_fg:] = 0                                               # everything after the foreground picks is background

@@ -13,6 +13,7 @@ import torch
 
 from config import REL_FG_FRACTION
 from lib.fpn.box_intersections_cpu.bbox import bbox_overlaps
+from lib.pytorch_misc import h2d
 
 RELS_PER_IMG_SGDET = 64
 
@@ -88,4 +89,4 @@ def rel_assignments(im_inds, rpn_rois, roi_gtlabels, gt_boxes, gt_classes, gt_re
         rows = rows[np.lexsort((rows[:, 1], rows[:, 0]))]
         out.append(np.column_stack((np.full(rows.shape[0], im, dtype=np.int64), rows)))
         seen += n
-    return torch.from_numpy(np.concatenate(out, 0)).to(dev)
+    return h2d(np.concatenate(out, 0), dev)

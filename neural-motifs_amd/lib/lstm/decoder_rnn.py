@@ -25,6 +25,7 @@ from lib import _hip
 from lib import rng
 from lib.fpn.box_utils import nms_overlaps
 from lib.hip_ops import Linear, linear
+from lib.pytorch_misc import h2d
 from lib.lstm.highway_lstm_cuda.alternating_highway_lstm import block_orthogonal
 from lib.word_vectors import obj_edge_vectors
 
@@ -127,8 +128,8 @@ class _DecoderRecurrenceFn(torch.autograd.Function):
         gw = gb = None
         if ctx.needs_input_grad[1]:
             prev_rows = _prev_state_rows(bs)
-            valid = torch.from_numpy((prev_rows >= 0)).to(h_all.device)
-            h_prev_all = h_all.index_select(0, torch.from_numpy(np.maximum(prev_rows, 0)).to(h_all.device))
+            valid = h2d((prev_rows >= 0), h_all.device)
+            h_prev_all = h_all.index_select(0, h2d(np.maximum(prev_rows, 0), h_all.device))
             h_prev_all = h_prev_all * valid[:, None].to(h_all.dtype)
             gw = _hip.gemm(d_pre[:, :5 * H], h_prev_all, True, False)         # [5H, H]
         if ctx.needs_input_grad[2]:
@@ -235,7 +236,7 @@ class DecoderRNN(torch.nn.Module):
                                                      dropout_mask)
             else:
                 # prev label of row r at step t is the label of the same sequence at step t-1
-                prev_rows = torch.from_numpy(_prev_state_rows(batch_sizes)).to(labels.device)
+                prev_rows = h2d(_prev_state_rows(batch_sizes), labels.device)
                 fed = torch.where(prev_rows >= 0, labels[prev_rows.clamp(min=0)] + 1, torch.zeros_like(labels))
                 commits = labels.clone()
         else:
@@ -275,4 +276,4 @@ class DecoderRNN(torch.nn.Module):
             commits[int(box_ind)] = int(cls_ind)
             sampled[is_overlap[box_ind, :, cls_ind], cls_ind] = 0.0
             sampled[box_ind] = -1.0
-        return torch.from_numpy(commits).to(out_dists.device)
+        return h2d(commits, out_dists.device)

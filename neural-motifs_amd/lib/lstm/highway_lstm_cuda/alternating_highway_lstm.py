@@ -16,6 +16,7 @@ from torch.nn.utils.rnn import PackedSequence
 
 from lib import _hip
 from lib import rng
+from lib.pytorch_misc import h2d
 
 
 def block_orthogonal(tensor, split_sizes, gain=1.0):
@@ -111,7 +112,7 @@ class AlternatingHighwayLSTM(torch.nn.Module):
             raise ValueError('inputs must be PackedSequence but got %s' % type(inputs))
         data, batch_sizes = inputs.data, inputs.batch_sizes
         T, B, lengths, idx = packed_layout(batch_sizes)
-        idx_dev = torch.from_numpy(idx).to(data.device, non_blocking=True)
+        idx_dev = h2d(idx, data.device)
         padded = data.new_zeros(T * B, data.shape[1]).index_copy(0, idx_dev, data).view(T, B, -1)
         mask = self.dropout_mask(B, data.device)
         out = _HighwayLSTMFn.apply(padded, self.weight, self.bias, mask, lengths, self.hidden_size,

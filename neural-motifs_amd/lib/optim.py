@@ -14,6 +14,7 @@ import numpy as np
 import torch
 
 from lib import _hip
+from lib.pytorch_misc import h2d
 
 
 class FusedClipSGD(torch.optim.Optimizer):
@@ -61,7 +62,7 @@ class FusedClipSGD(torch.optim.Optimizer):
             table = np.concatenate(parts) if parts else np.empty(0, dtype=rec)
             self._nchunks = int(table.shape[0])
             host = torch.from_numpy(table.view(np.uint8).copy())
-            self._table = host.to(dev, non_blocking=False) if dev is not None else host
+            self._table = h2d(host, dev) if dev is not None else host      # pinned + asynchronous: no host stall here
             self._table_key = key
             if dev is not None:
                 self._partial = torch.empty(max(self._nchunks, 1), dtype=torch.float32, device=dev)

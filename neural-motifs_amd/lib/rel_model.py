@@ -28,7 +28,7 @@ from lib.lstm.decoder_rnn import DecoderRNN
 from lib.lstm.highway_lstm_cuda.alternating_highway_lstm import AlternatingHighwayLSTM
 from lib.object_detector import ObjectDetector, gather_res, load_vgg
 from lib.pytorch_misc import (transpose_packed_sequence_inds, to_onehot, arange, enumerate_by_image, has_host, host_np,
-                              set_host)
+                              set_host, h2d)
 from lib.sparse_targets import FrequencyBias
 from lib.surgery import filter_dets
 from lib.word_vectors import obj_edge_vectors
@@ -48,8 +48,8 @@ def _sort_by_score(im_inds, scores):
         lengths.append(e - s)
     lengths = sorted(lengths, reverse=True)
     inds, ls_transposed = transpose_packed_sequence_inds(lengths)
-    inds = torch.from_numpy(np.asarray(inds, dtype=np.int64)).to(im_inds.device)
-    roi_order = scores - 2 * torch.from_numpy(im_key).to(scores.device)[im_inds]
+    inds = h2d(np.asarray(inds, dtype=np.int64), im_inds.device)
+    roi_order = scores - 2 * h2d(im_key, scores.device)[im_inds]
     _, perm = torch.sort(roi_order, dim=0, descending=True, stable=True)
     perm = perm[inds]
     _, inv_perm = torch.sort(perm)
@@ -124,7 +124,7 @@ class LinearizedContext(nn.Module):
         elif self.order == 'confidence':
             scores = confidence
         elif self.order == 'random':
-            scores = torch.from_numpy(np.random.rand(batch_idx.size(0)).astype(np.float32)).to(batch_idx.device)
+            scores = h2d(np.random.rand(batch_idx.size(0)).astype(np.float32), batch_idx.device)
         elif self.order == 'leftright':
             centers = cxcywh[:, 0]
             scores = centers / (centers.max() + 1)

@@ -16,7 +16,8 @@ class HostRNG(object):
 
     def keep_mask(self, shape, keep_prob, device):
         m = (self.rs.random_sample(tuple(shape)) < keep_prob).astype(np.float32)
-        return torch.from_numpy(m).to(device, non_blocking=True)
+        from lib.pytorch_misc import h2d
+        return h2d(m, device)
 
 
 _host_rng = None

@@ -110,7 +110,18 @@ def train_batch(b, verbose=False):
         clip_grad_norm([(n, p) for n, p in detector.named_parameters() if p.grad is not None], max_norm=conf.clip,
                        verbose=verbose and rank == 0, clip=True)
         optimizer.step()
-    return pd.Series({'class_loss': l_obj.item(), 'rel_loss': l_rel.item(), 'total': (l_obj + l_rel).item()})
+    # the three losses stay on the device: reading them here (the reference's `.data[0]`, :150) would drain the GPU queue
+    # every step and serialise the host's launch work of the next step with this step's kernels; train_epoch reads a whole
+    # print interval at once
+    return torch.stack((l_obj.detach(), l_rel.detach(), (l_obj + l_rel).detach()))
+
+
+LOSS_KEYS = ('class_loss', 'rel_loss', 'total')
+
+
+def _loss_frame(steps):
+    """[3] device tensors of some steps -> DataFrame (rows = LOSS_KEYS, one column per step): ONE device->host copy"""
+    return pd.DataFrame(torch.stack(steps, 1).cpu().numpy(), index=LOSS_KEYS)
 
 
 def train_epoch(epoch_num):
@@ -123,14 +134,14 @@ def train_epoch(epoch_num):
             break
         tr.append(train_batch(batch, verbose=b % (conf.print_interval * 10) == 0))
         if b % conf.print_interval == 0 and b >= conf.print_interval and rank == 0:
-            mn = pd.concat(tr[-conf.print_interval:], axis=1).mean(1)
+            mn = _loss_frame(tr[-conf.print_interval:]).mean(1)
             tpb = (time.time() - start) / conf.print_interval
             print("\ne{:2d}b{:5d}/{:5d} {:.3f}s/batch, {:.1f}m/epoch".format(epoch_num, b, len(train_loader), tpb,
                                                                              len(train_loader) * tpb / 60))
             print(mn)
             print('-----------', flush=True)
             start = time.time()
-    return pd.concat(tr, axis=1)
+    return _loss_frame(tr)
 
 
 def val_batch(batch_num, b, evaluator):
