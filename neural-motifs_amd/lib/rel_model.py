@@ -9,6 +9,8 @@ alternating-direction stacking; limit_vision multiplies only the first 2048 dims
 """
 import math
 
+import os
+
 import numpy as np
 import torch
 import torch.nn as nn
@@ -233,7 +235,7 @@ class RelModel(nn.Module):
         # Run the object/edge-context branch (RoI fc6/fc7 on ~100 rows, ~100 latency-bound LSTM/decoder step kernels
         # that occupy at most half of the CUs) on a second HIP stream, concurrently with the union-box relation head
         # (a handful of chip-filling MFMA GEMMs).  The two branches only meet at the subject/object product.
-        self.overlap_streams = True
+        self.overlap_streams = os.environ.get('MOTIFS_OVERLAP', '1') != '0'     # context branch on a second HIP stream
         self._side_stream = None
 
         self.detector = ObjectDetector(

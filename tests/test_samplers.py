@@ -111,3 +111,41 @@ def test_rel_assignments_equals_the_reference_draw_for_draw(golden):
                               filter_non_overlap=bool(g[c + '_fno']), num_sample_per_gt=int(g[c + '_per_gt']),
                               rs=np.random.RandomState(int(g[c + '_seed'])))
         np.testing.assert_array_equal(got.numpy(), g[c + '_rel_labels'])
+
+
+def test_pinned_ring_staging_logic(monkeypatch):
+    """lib/pytorch_misc._PinnedRing (the staging memory of every small host->device upload of a step): slices are
+    64-byte aligned and disjoint inside a half, values and dtypes survive, a full half switches to the other one after
+    recording events on the streams that used it, and a half is only reused after its events were waited for."""
+    import torch
+    from lib import pytorch_misc as pm
+
+    log = []
+
+    class FakeEvent(object):
+        def record(self, stream):
+            log.append(('record', stream))
+
+        def synchronize(self):
+            log.append(('sync',))
+
+    monkeypatch.setattr(torch.cuda, 'Event', FakeEvent)
+    monkeypatch.setattr(torch.cuda, 'current_stream', lambda device=None: 'stream0')
+    ring = object.__new__(pm._PinnedRing)
+    ring.half = 256
+    ring.buf = torch.zeros(512, dtype=torch.uint8)
+    ring.active, ring.pos = 0, 0
+    ring.streams, ring.events = [set(), set()], [[], []]
+    a = ring.stage(torch.arange(5, dtype=torch.int64), 'cpu')               # 40 B -> 64
+    b = ring.stage(torch.tensor([True, False, True]), 'cpu')                # 3 B -> 64
+    c = ring.stage(torch.arange(6, dtype=torch.float32).view(2, 3), 'cpu')  # 24 B -> 64
+    assert a.tolist() == [0, 1, 2, 3, 4] and b.tolist() == [True, False, True] and c.shape == (2, 3) and c[1, 2] == 5
+    assert ring.pos == 192 and ring.active == 0 and not log
+    assert a.data_ptr() % 8 == 0 and b.data_ptr() - a.data_ptr() == 64 and c.data_ptr() - b.data_ptr() == 64
+    d = ring.stage(torch.arange(20, dtype=torch.int64), 'cpu')              # 160 B: does not fit -> other half
+    assert ring.active == 1 and ring.pos == 192 and log == [('record', 'stream0')]
+    assert d.tolist() == list(range(20)) and a.tolist() == [0, 1, 2, 3, 4]   # the first half is untouched
+    e = ring.stage(torch.arange(16, dtype=torch.int64), 'cpu')              # 128 B: back to half 0, after waiting for it
+    assert ring.active == 0 and ring.pos == 128 and log == [('record', 'stream0'), ('record', 'stream0'), ('sync',)]
+    assert e.tolist() == list(range(16))
+    assert ring.stage(torch.zeros(0, 4), 'cpu').shape == (0, 4)
