@@ -9,6 +9,7 @@ Gradients must be dense fp32 and present for every parameter of the table (param
 are skipped by rebuilding the table -- this only happens if the set of used parameters changes).
 """
 import ctypes
+import os
 
 import numpy as np
 import torch
@@ -24,6 +25,13 @@ class FusedClipSGD(torch.optim.Optimizer):
         wd = {g['weight_decay'] for g in self.param_groups}
         if len(mom) != 1 or len(wd) != 1:
             raise ValueError('FusedClipSGD needs one momentum / weight_decay for all groups (per-group lr is fine)')
+        # The step is asynchronous end to end (no device->host read anywhere), so nothing stops the host from queueing
+        # many steps ahead of the GPU -- every step ahead needs its own set of activations / gradients, and the caching
+        # allocator answers with fresh hipMalloc calls of hundreds of MB (tens of ms each, device idle: gpurun r02_c8).
+        # step() therefore waits, after queueing step N, until step N - max_ahead has finished on the device: the GPU
+        # always has a full step queued, memory stays at max_ahead + 1 steps.
+        self.max_ahead = int(os.environ.get('MOTIFS_MAX_AHEAD', '1'))
+        self._done_events = []
         self._table = None
         self._table_key = None
         self._steps = 0
@@ -107,4 +115,13 @@ class FusedClipSGD(torch.optim.Optimizer):
                     if fresh:
                         self.state[p]['fresh'] = False
         self._steps += 1
+        if self.max_ahead >= 0 and self._table.is_cuda:
+            size = max(self.max_ahead, 1)
+            if not self._done_events:
+                self._done_events = [torch.cuda.Event() for _ in range(size)]
+            ev = self._done_events[self._steps % size]
+            ev.synchronize()                     # recorded `size` steps ago (a never-recorded event returns at once)
+            ev.record()
+            if self.max_ahead == 0:
+                ev.synchronize()
         return None
