@@ -393,6 +393,32 @@ def main():
             step(i)
             hs.append(1e3 * (time.perf_counter() - t1))
         barrier()
+        # stall probes: device-allocator activity per step (segments = hipMalloc / hipFree calls of the caching allocator),
+        # the same steps with Python's cyclic GC off, and the Python stack of the main thread every 20 ms
+        import faulthandler
+        import gc
+        def seg():
+            st = torch.cuda.memory_stats()
+            return (st.get('segment.all.allocated', 0), st.get('segment.all.freed', 0), st.get('num_alloc_retries', 0),
+                    st.get('reserved_bytes.all.current', 0) >> 20)
+        for label, nogc in (('gc on', False), ('gc off', True)):
+            if nogc:
+                gc.disable()
+            rows = []
+            for i in range(6):
+                s0 = seg()
+                t1 = time.perf_counter()
+                step(i)
+                rows.append(('%.1f' % (1e3 * (time.perf_counter() - t1)), tuple(b_ - a_ for a_, b_ in zip(s0, seg()))))
+            barrier()
+            gc.enable()
+            sys.stderr.write('probe [%s] host ms per step, (segments allocated, freed, retries, reserved MiB delta): %s; gc counts %s\n'
+                             % (label, rows, gc.get_count()))
+        faulthandler.dump_traceback_later(0.02, repeat=True, file=sys.stderr)
+        for i in range(6):
+            step(i)
+        faulthandler.cancel_dump_traceback_later()
+        barrier()
         pr = cProfile.Profile()
         pr.enable()
         for i in range(3):
