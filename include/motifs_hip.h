@@ -292,6 +292,10 @@ int mh_debug_lstm_barrier_fault(int enable);
  *                      d = g' + wd*p; buf = first_step ? d : momentum*buf + d; p -= lr*buf
  * ------------------------------------------------------------------------------------------- */
 int mh_opt_chunk_elems(void);
+/* Expand a HOST list of nparams records {p, g, buf, n = elements of the whole parameter, lr} (same 32-byte layout) into the
+ * device chunk table chunks[nchunks], nchunks = sum over parameters of ceil(n / mh_opt_chunk_elems()).  The list travels in
+ * the kernel arguments (no host->device copy, nothing read from params_host after the call returns). */
+int mh_opt_build_chunks(const void *params_host, int nparams, void *chunks, int nchunks, void *stream);
 int mh_multi_sumsq(const void *chunks, int nchunks, float *partial, float *sumsq_out, void *stream);
 int mh_multi_sgd_step(const void *chunks, int nchunks, const float *sumsq, float max_norm, float momentum,
                       float weight_decay, int first_step, void *stream);

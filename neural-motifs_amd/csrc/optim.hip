@@ -11,7 +11,10 @@
 //                         buf = first_step ? d : momentum * buf + d
 //                         p  = p - lr * buf
 //                      reading p,g,buf and writing p,buf once (5 x 4 B per element: HBM-bound), no host round trip.
-// The chunk table (device array of {p, g, buf, n, lr}) is built once by the caller and reused every step.
+// The chunk table (device array of {p, g, buf, n, lr}) is expanded ON THE DEVICE from the per-parameter list
+// (mh_opt_build_chunks): the list travels in the kernel arguments, so a new set of gradient addresses (autograd hands out
+// fresh .grad tensors every step) costs one tiny launch and no host->device copy -- a 140 KB pinned copy in front of the
+// clip kernels was the one place where the asynchronous step waited on the copy engine.
 #include <algorithm>
 
 #include "common.h"
@@ -104,6 +107,40 @@ __global__ __launch_bounds__(256) void multi_sgd_kernel(const OptChunk *__restri
     for (int i = 4 * n4 + threadIdx.x; i < c.n; i += 256) upd(c.p[i], c.g[i], c.buf[i], c.p[i], c.buf[i]);
 }
 
+// Per-parameter records of one expand launch, passed BY VALUE (kernel-argument segment: 96 x 32 B + 2 ints < 4 KB).
+constexpr int kParamsPerLaunch = 96;
+struct OptParamList {
+    OptChunk prm[kParamsPerLaunch];   // n = elements of the WHOLE parameter
+    int count;
+    int total_chunks;                 // chunks of these `count` parameters
+};
+__global__ __launch_bounds__(256) void expand_chunks_kernel(const OptParamList L, OptChunk *__restrict__ chunks)
+{
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= L.total_chunks) return;
+    int rem = c;
+    bool found = false;
+    OptChunk o = L.prm[0];
+    for (int i = 0; i < L.count && !found; ++i) {  // every active lane is at the same i: L.prm[i] is a scalar load
+        const OptChunk q = L.prm[i];
+        const int nc = (q.n + kChunkElems - 1) / kChunkElems;
+        if (rem < nc) {
+            o = q;
+            found = true;
+        } else {
+            rem -= nc;
+        }
+    }
+    const long long off = (long long)rem * kChunkElems;
+    OptChunk r;
+    r.p = o.p + off;
+    r.g = o.g + off;
+    r.buf = o.buf + off;
+    r.n = (int)min((long long)kChunkElems, (long long)o.n - off);
+    r.lr = o.lr;
+    chunks[c] = r;
+}
+
 }  // namespace mh
 
 using namespace mh;
@@ -111,6 +148,34 @@ using namespace mh;
 extern "C" {
 
 int mh_opt_chunk_elems(void) { return kChunkElems; }
+
+int mh_opt_build_chunks(const void *params_host, int nparams, void *chunks, int nchunks, void *stream)
+{
+    MH_REQUIRE(nparams >= 0 && nchunks >= 0);
+    if (nparams == 0) return MH_OK;
+    MH_REQUIRE(params_host && chunks);
+    const OptChunk *prm = reinterpret_cast<const OptChunk *>(params_host);
+    OptChunk *out = reinterpret_cast<OptChunk *>(chunks);
+    long long done = 0;
+    for (int i0 = 0; i0 < nparams; i0 += kParamsPerLaunch) {
+        OptParamList L;
+        L.count = std::min(kParamsPerLaunch, nparams - i0);
+        long long tot = 0;
+        for (int i = 0; i < L.count; ++i) {
+            MH_REQUIRE(prm[i0 + i].n > 0 && prm[i0 + i].p && prm[i0 + i].g && prm[i0 + i].buf);
+            L.prm[i] = prm[i0 + i];
+            tot += (prm[i0 + i].n + kChunkElems - 1) / kChunkElems;
+        }
+        MH_REQUIRE(done + tot <= nchunks);
+        L.total_chunks = (int)tot;
+        hipLaunchKernelGGL(expand_chunks_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, as_stream(stream), L, out + done);
+        int rc = check_launch("expand_chunks_kernel");
+        if (rc) return rc;
+        done += tot;
+    }
+    MH_REQUIRE(done == nchunks);
+    return MH_OK;
+}
 
 int mh_multi_sumsq(const void *chunks, int nchunks, float *partial, float *sumsq_out, void *stream)
 {

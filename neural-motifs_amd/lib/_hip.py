@@ -31,7 +31,7 @@ SYMBOLS = (
     'mh_hwcell_seq_ws_bytes', 'mh_hwcell_seq_fwd', 'mh_hwcell_seq_bwd',
     'mh_decoder_greedy_ws_bytes', 'mh_decoder_greedy', 'mh_decoder_nms_commit',
     'mh_fault_pending', 'mh_fault_clear', 'mh_debug_lstm_barrier_fault',
-    'mh_opt_chunk_elems', 'mh_multi_sumsq', 'mh_multi_sgd_step',
+    'mh_opt_chunk_elems', 'mh_opt_build_chunks', 'mh_multi_sumsq', 'mh_multi_sgd_step',
     'mh_bn_ws_bytes', 'mh_bn_stats', 'mh_bn_pool_fwd', 'mh_bn_residual_nchw', 'mh_bn_apply_nhwc', 'mh_nchw_to_nhwc_small', 'mh_bn_bwd',
 )
 

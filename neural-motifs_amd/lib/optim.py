@@ -15,7 +15,6 @@ import numpy as np
 import torch
 
 from lib import _hip
-from lib.pytorch_misc import h2d
 
 
 class FusedClipSGD(torch.optim.Optimizer):
@@ -58,24 +57,24 @@ class FusedClipSGD(torch.optim.Optimizer):
                             float(group['lr'])))
         key = tuple(key)
         if key != self._table_key:
+            # per-parameter records (32 B each) -> device chunk table, expanded by a kernel that receives the records in
+            # its arguments: no host->device copy (autograd hands out new .grad tensors, i.e. a new key, every step)
             rec = np.dtype([('p', '<u8'), ('g', '<u8'), ('buf', '<u8'), ('n', '<i4'), ('lr', '<f4')])
-            parts = []
-            for pp, gp, bp, n, lr in key:
-                offs = np.arange(0, n, chunk, dtype=np.uint64)
-                r = np.empty(offs.shape[0], dtype=rec)
-                r['p'], r['g'], r['buf'] = pp + 4 * offs, gp + 4 * offs, bp + 4 * offs
-                r['n'] = np.minimum(chunk, n - offs.astype(np.int64)).astype(np.int32)
-                r['lr'] = lr
-                parts.append(r)
-            table = np.concatenate(parts) if parts else np.empty(0, dtype=rec)
-            self._nchunks = int(table.shape[0])
-            host = torch.from_numpy(table.view(np.uint8).copy())
-            self._table = h2d(host, dev) if dev is not None else host      # pinned + asynchronous: no host stall here
-            self._table_key = key
+            prm = np.empty(len(key), dtype=rec)
+            for i, (pp, gp, bp, n, lr) in enumerate(key):
+                prm[i] = (pp, gp, bp, n, lr)
+            nchunks = int(sum((n + chunk - 1) // chunk for _, _, _, n, _ in key))
             if dev is not None:
-                self._partial = torch.empty(max(self._nchunks, 1), dtype=torch.float32, device=dev)
+                if self._table is None or self._nchunks != nchunks or self._table.device != dev:
+                    self._table = torch.empty(max(nchunks, 1) * rec.itemsize, dtype=torch.uint8, device=dev)
+                    self._partial = torch.empty(max(nchunks, 1), dtype=torch.float32, device=dev)
                 if self._sumsq is None:
                     self._sumsq = torch.zeros(1, dtype=torch.float32, device=dev)
+                _hip._check(_hip.lib().mh_opt_build_chunks(prm.ctypes.data_as(ctypes.c_void_p), len(key),
+                                                           ctypes.c_void_p(self._table.data_ptr()), nchunks, _hip.stream()),
+                            'mh_opt_build_chunks')
+            self._nchunks = nchunks
+            self._table_key = key
         return self._nchunks
 
     def last_total_norm(self):

@@ -198,6 +198,18 @@ def install():
             return 0
 
         @staticmethod
+        def mh_opt_build_chunks(params, nparams, chunks, nchunks, stream):
+            prm = _table(params, _val(nparams))
+            out = _table(chunks, _val(nchunks))
+            chunk, c = 1 << 16, 0
+            for r in prm:
+                for off in range(0, int(r['n']), chunk):
+                    out[c] = (r['p'] + 4 * off, r['g'] + 4 * off, r['buf'] + 4 * off, min(chunk, int(r['n']) - off), r['lr'])
+                    c += 1
+            assert c == _val(nchunks)
+            return 0
+
+        @staticmethod
         def mh_multi_sumsq(tptr, n, partial, sumsq, stream):
             tot = 0.0
             for r in _table(tptr, _val(n)):
