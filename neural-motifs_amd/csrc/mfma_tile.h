@@ -647,7 +647,15 @@ __device__ __forceinline__ void plan_planes(PPlan<WD> &pl, RowOk row_ok, unsigne
 {
 #pragma unroll
     for (int j = 0; j < PStage<WD>::n; ++j) {
-        const int e = tid + kThreads * j, r = e / kPlaneChunks, c = e % kPlaneChunks;
+        const int e = tid + kThreads * j, c = e % kPlaneChunks;
+        int r = e / kPlaneChunks;
+#if MH_SPLIT_F16
+        // f16x3 rows use 64 of their 96 bytes, so the four rows a 16-lane group of the ds_write_b128 covers must be chosen
+        // such that their spans tile the 256 bytes of the 64 banks: rows {0,6,4,2} / {1,7,5,3} of every 8 sit at
+        // 0,64,128,192 / 96,160,224,32 (mod 256).  Consecutive rows (0,96,192,288) put row 3 on row 0's banks: 2-way
+        // conflicts on every write (PMC: SQ_LDS_BANK_CONFLICT = 20 % of the LDS-active cycles of the conv, r02_c14).
+        r = (r & ~7) | ((0x35712460u >> (4 * (r & 7))) & 7);
+#endif
         const bool ok = (e < WD * kPlaneChunks) && row_ok(r);
         pl.v[j] = ok ? (unsigned)r * row_stride_bytes + 16u * c : kOobOffset;
         pl.lds[j] = (unsigned)(r * kRowDw * 4 + 16 * (c ^ plane_swz(r)));

@@ -128,3 +128,36 @@ def test_k_major_staging_writes_are_at_most_two_way():
                     return slot_addr(km_row(4 * q + j), p, kp >> 2) + (kp & 3)
                 worst = max(worst, worst_conflict(halves, addr, 1, 32))
     assert worst == 2
+
+
+def test_packed_plane_chunk_writes_tile_the_banks_in_f16x3():
+    """conv weights arrive as planes and are staged with ds_write_b128 (plan_planes / store_planes): eight contiguous lanes
+    per LDS cycle over 32 banks.  An f16x3 row uses 64 of its 96 bytes, so consecutive rows (0 and 96 mod 128) overlap on 8
+    banks; the row permutation of the header pairs rows whose spans tile the 128 bytes (PMC before: SQ_LDS_BANK_CONFLICT =
+    20 % of the conv's LDS cycles)."""
+    m = re.search(r'r = \(r & ~7\) \| \(\(0x([0-9a-f]+)u >> \(4 \* \(r & 7\)\)\) & 7\);', HDR)
+    assert m, 'row permutation of plan_planes not found'
+    code = int(m.group(1), 16)
+    perm = [(code >> (4 * i)) & 7 for i in range(8)]
+    assert sorted(perm) == list(range(8))
+    chunks = 4                                         # kPlaneChunks of the f16x3 build: h1 | h2, 2 x 16 B each
+    assert 'constexpr int kPlaneChunks = 2 * kNumPlanes;' in HDR and 'kNumPlanes = MH_SPLIT_F16 ? 2 : 3' in HDR
+    groups = [list(range(8 * g, 8 * g + 8)) for g in range(8)]
+
+    def worst(permute, WD):
+        w = 1
+        for j in range(WD * chunks // 256):
+            for wave in range(4):
+                def addr(lane):
+                    e = 64 * wave + lane + 256 * j
+                    r, c = e // chunks, e % chunks
+                    if permute:
+                        r = (r & ~7) | perm[r & 7]
+                    return r * K_ROW_DW + 4 * (c ^ swz(r))
+                w = max(w, worst_conflict(groups, addr, 4, 32))
+        return w
+
+    assert worst(True, 128) == 1 and worst(True, 64) == 1
+    assert worst(False, 128) == 2                      # the consecutive-row assignment this replaces
+    rows = sorted((e // chunks & ~7) | perm[(e // chunks) & 7] for e in range(128 * chunks) if e % chunks == 0)
+    assert rows == list(range(128))                    # still every row exactly once
