@@ -76,6 +76,17 @@ class Blob(object):
             self.proposals = torch.from_numpy(np.concatenate(self.proposals, 0)).float()
             self.proposal_chunks = [self.proposals.shape[0]]
 
+    def pin_memory(self):
+        """page-lock the batch (torch's DataLoader calls this in its pinning thread when `pin_memory=True`): `scatter()` is
+        then a set of asynchronous DMA copies.  From pageable memory every copy first waits for the GPU to drain its queue,
+        which serialises the host's launch work of the step behind the previous step's kernels."""
+        for name in ('imgs', 'gt_boxes', 'gt_classes', 'gt_rels', 'train_anchor_inds', 'train_anchor_labels',
+                     'train_anchors', 'proposals'):
+            t = getattr(self, name, None)
+            if torch.is_tensor(t) and not t.is_cuda and t.numel() > 0:
+                setattr(self, name, t.pin_memory())
+        return self
+
     def _to_device(self, x, mirror=False):
         # one process per GPU: the target is the device THIS rank made current (torch.cuda.set_device(local_rank) in
         # lib/dist.init_from_env / the drivers), unless a caller pins primary_gpu explicitly (reference blob.py:20)

@@ -93,4 +93,5 @@ class SyntheticLoader(object):
     def __iter__(self):
         for it in range(len(self)):
             start = (it * self.world_size + self.rank) * self.batch_size
-            yield make_blob(self.dataset, range(start, start + self.batch_size), self.is_train, self.mode)
+            blob = make_blob(self.dataset, range(start, start + self.batch_size), self.is_train, self.mode)
+            yield blob.pin_memory() if torch.cuda.is_available() else blob

@@ -308,6 +308,7 @@ class VGDataLoader(torch.utils.data.DataLoader):
                     SyntheticLoader(val_data, batch_size if mode == 'det' else 1, False, rank=rank,
                                     world_size=world_size, mode=mode))
         vb = batch_size if mode == 'det' else 1
+        kwargs.setdefault('pin_memory', torch.cuda.is_available())      # Blob.pin_memory: asynchronous scatter()
         train_load = cls(dataset=train_data, batch_size=batch_size, num_workers=num_workers, drop_last=True,
                          sampler=_RankSampler(len(train_data), batch_size, rank, world_size, True),
                          collate_fn=lambda x: vg_collate(x, mode=mode, is_train=True), **kwargs)

@@ -289,6 +289,16 @@ class RelModel(nn.Module):
         boxes of an image in eval (overlapping ones only for sgdet)"""
         if self.training:
             return rel_labels[:, :3].detach().clone()
+        if not self.require_overlap and has_host(im_inds):
+            # GT-box evaluation: every ordered pair of distinct boxes of an image, enumerated on the host from the
+            # mirrored image indices in the order nonzero() gives (row-major) -- no device->host synchronisation
+            im = host_np(im_inds)
+            cand = im[:, None] == im[None, :]
+            np.fill_diagonal(cand, False)
+            ij = np.column_stack(np.nonzero(cand)).astype(np.int64)
+            if ij.shape[0] == 0:
+                ij = np.zeros((1, 2), dtype=np.int64)
+            return h2d(np.column_stack((im[ij[:, 0]].astype(np.int64), ij)), im_inds.device)
         rel_cands = im_inds[:, None] == im_inds[None]
         rel_cands.fill_diagonal_(False)
         if self.require_overlap:

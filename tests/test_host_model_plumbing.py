@@ -61,6 +61,41 @@ def test_state_dict_keys_follow_the_reference(small_world):
     assert [n for n, _ in model.named_parameters() if n.startswith('roi_fmap')]
 
 
+def test_gt_box_training_step_reads_nothing_back_from_the_device(small_world, monkeypatch):
+    """the SGCls / PredCls training forward takes every host-side value (relation sampler, LSTM packing
+    order, teacher-forcing check) from the host mirrors a Blob attaches to its GT arrays -- no tensor.cpu() / .item() /
+    .tolist() / .numpy() on the way (on a GPU each of them would drain the queue).  The shim's kernels are exempt (they
+    stand in for device code)."""
+    import torch
+    from lib import pytorch_misc as pm
+    ds, model, make_blob = small_world
+    model.train()
+    blob = make_blob(ds, range(2), is_train=True)
+    blob.scatter()
+    assert pm.has_host(blob.gt_classes) and pm.has_host(blob.gt_boxes) and pm.has_host(blob.gt_rels)
+    before = pm.D2H_READS[0]
+    calls = []
+    import traceback
+
+    def spy(name, orig):
+        def f(self, *a, **k):
+            stack = ''.join(traceback.format_stack(limit=12))
+            if 'cpu_shim.py' not in stack and '/oracle/' not in stack:
+                calls.append((name, stack.splitlines()[-4].strip() if len(stack.splitlines()) > 4 else stack))
+            return orig(self, *a, **k)
+        return f
+    for name in ('cpu', 'item', 'tolist'):
+        monkeypatch.setattr(torch.Tensor, name, spy(name, getattr(torch.Tensor, name)))
+    res = model[blob]
+    loss = torch.nn.functional.cross_entropy(res.rm_obj_dists, res.rm_obj_labels) + \
+        torch.nn.functional.cross_entropy(res.rel_dists, res.rel_labels[:, -1])
+    loss.backward()
+    monkeypatch.undo()
+    model.zero_grad(set_to_none=True)
+    assert pm.D2H_READS[0] == before, 'a host mirror was missing somewhere on the path'
+    assert not calls, calls
+
+
 def _to_oracle_sd(model):
     return {k: v.detach().clone() for k, v in model.state_dict().items()}
 
