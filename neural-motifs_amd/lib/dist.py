@@ -44,7 +44,10 @@ def world_size():
 def global_row_weights(row_counts, device):
     """row_counts: python list of this rank's row counts per loss term.  Returns, per term, rows_rank/rows_global --
     the factor that turns a rank-local mean loss into its share of the global mean (one tiny all-reduce)."""
-    t = torch.tensor([float(c) for c in row_counts], dtype=torch.float64, device=device)
+    t = torch.tensor([float(c) for c in row_counts], dtype=torch.float64)
+    if torch.device(device).type == 'cuda':
+        from lib.pytorch_misc import h2d
+        t = h2d(t, device)                 # page-locked + asynchronous: a pageable upload would drain the GPU queue every step
     tot = t.clone()
     if world_size() > 1:
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
