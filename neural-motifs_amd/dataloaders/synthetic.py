@@ -93,5 +93,4 @@ class SyntheticLoader(object):
     def __iter__(self):
         for it in range(len(self)):
             start = (it * self.world_size + self.rank) * self.batch_size
-            blob = make_blob(self.dataset, range(start, start + self.batch_size), self.is_train, self.mode)
-            yield blob.pin_memory() if torch.cuda.is_available() else blob
+            yield make_blob(self.dataset, range(start, start + self.batch_size), self.is_train, self.mode)
