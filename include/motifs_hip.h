@@ -113,8 +113,8 @@ int mh_triplet_match(const int *gt_triplets, const float *gt_boxes, int G, const
                      void *stream);
 
 /* ---------------------------------------------------------------------------------------------
- * FP32 GEMM on MFMA (bf16x6 on v_mfma_f32_32x32x16_bf16 by default, v_mfma_f32_32x32x2_f32 in the MH_MFMA_SPLIT=0
- * build; see mh_mfma_split).  Replaces the cuBLAS / nn.Linear
+ * FP32 GEMM on MFMA (f16x3 on v_mfma_f32_32x32x16_f16 by default; bf16x6 / v_mfma_f32_32x32x2_f32 in the MH_SPLIT_F16=0 /
+ * MH_MFMA_SPLIT=0 builds; see mh_mfma_split).  Replaces the cuBLAS / nn.Linear
  * calls on the path (lib/object_detector.py:80-104, lib/rel_model.py:367-390,
  * highway_lstm_kernel.cu:441-465).  Row-major:
  *     C[M,N] = epi( opA(A)[M,K] * opB(B)[K,N] + bias[N] )   (+ C if accumulate)
@@ -135,9 +135,10 @@ int mh_gemm_f32(int transA, int transB, int M, int N, int K, const float *A, int
  *       in [B,H,W,Cin] (Cin % 16 == 0), wt = packed weights of THIS conv (see mh_conv3x3_pack_weight),
  *       out [B,H,W,Cout] (Cout % 4 == 0)
  *   mh_conv3x3_pack_weight: w [Cout,Cin,3,3] (API layout) -> wt, mh_conv3x3_packed_floats(N, K) floats for a conv
- *       with N output and K input channels: [9][N][K/16][24 dwords] = per (tap, output channel, 16 input channels)
- *       the three bf16 planes hi|mid|lo of the exact fp32 split (bf16x6 build; plain fp32 [9][N][K] in the f32-MFMA
- *       build).  flip_transpose=1 produces the weights of the dgrad conv (N = Cin, K = Cout, taps mirrored)
+ *       with N output and K input channels: per (tap, output channel, 16 input channels) the 16-bit planes of the split
+ *       -- h1|h2 (f16, 64 B) scaled by the output channel's power of two, whose exponents follow the planes, in the
+ *       default f16x3 build; hi|mid|lo (bf16, 96 B) in the bf16x6 build; plain fp32 [9][N][K] in the f32-MFMA build.
+ *       Always size the buffer with mh_conv3x3_packed_floats.  flip_transpose=1 produces the weights of the dgrad conv (N = Cin, K = Cout, taps mirrored)
  *   mh_conv_first_nchw: the 3->Cout stem reading the NCHW image directly, writing NHWC; bias+ReLU
  *   mh_maxpool2x2_nhwc: 2x2/2 max pool (floor), NHWC
  *   mh_im2col_nhwc: generic patch matrix out[B*Ho*Wo, ldo] with column (ky*kw+kx)*C + c
