@@ -53,6 +53,10 @@ def operands(kind, rs, M=64, N=64, K=4096):
         b *= np.exp2(rs.uniform(-8, 8, (K, N))).astype(np.float32)
     elif kind == 'relu':          # post-ReLU activations x small weights
         a, b = np.maximum(a, 0) * 3, b * np.float32(0.02)
+    elif kind == 'pixels':        # conv-like: post-ReLU rows (pixels) whose magnitudes span five decades, one 30x louder than all
+        a = np.maximum(a, 0) * np.power(10.0, rs.uniform(-5, 0, (M, 1))).astype(np.float32)
+        a[0, :] *= np.float32(30.0)
+        b = b * np.float32((2.0 / K) ** 0.5)
     elif kind == 'outlier':       # bulk at 1e-6, one row of A and one column of B nine decades above it
         a, b = a * np.float32(1e-6), b * np.float32(1e-6)
         a[3, :] *= np.float32(1e9)
@@ -66,15 +70,22 @@ def errors(c, ref):
     return np.abs(e).max() / rms, np.sqrt((e ** 2).mean()) / rms, float(np.median(np.abs(e) / np.abs(ref)))
 
 
+def worst_vs_bound(c, a, b, ref):
+    """max over outputs of |error| / sum_k |a||b| -- the scale of fp32's own rounding bound for that output, so that quiet
+    rows are judged against their own magnitude (the per-tensor scale of the activation planes)"""
+    den = np.abs(a.astype(np.float64)) @ np.abs(b.astype(np.float64)) + 1e-300
+    return float((np.abs(c - ref) / den).max())
+
+
 def main():
     rs = np.random.RandomState(0)
-    print('%-9s %-28s %10s %10s %12s' % ('operands', 'evaluation', 'max/rms', 'rms/rms', 'median rel'))
-    for kind in ('normal', 'wide', 'relu', 'outlier'):
+    print('%-9s %-28s %10s %10s %12s %14s' % ('operands', 'evaluation', 'max/rms', 'rms/rms', 'median rel', 'max/sum|a||b|'))
+    for kind in ('normal', 'wide', 'relu', 'pixels', 'outlier'):
         a, b = operands(kind, rs)
         ref = a.astype(np.float64) @ b.astype(np.float64)
         for name, c in (('fp32 matmul (host BLAS)', (a @ b).astype(np.float64)), ('bf16x6 truncation (shipped)', bf16x6(a, b)),
                         ('f16x3, scale per row', f16x3(a, b, True)), ('f16x3, scale per tensor', f16x3(a, b, False))):
-            print('%-9s %-28s %10.2e %10.2e %12.2e' % ((kind, name) + errors(c, ref)))
+            print('%-9s %-28s %10.2e %10.2e %12.2e %14.2e' % ((kind, name) + errors(c, ref) + (worst_vs_bound(c, a, b, ref),)))
 
 
 if __name__ == '__main__':
