@@ -74,6 +74,12 @@ def test_argument_validation_needs_no_device(so_path):
     assert lib.mh_hwcell_seq_fwd(513, 4, 3, None, None, None, None, None, None, None, None, None, ctypes.c_size_t(0), None) == -1
     assert lib.mh_bn_apply_nhwc(None, ctypes.c_longlong(8), 16, None, None, None, None, None, 0, None, None) == -1
     assert lib.mh_maxpool2x2_bwd_nhwc(None, None, 1, 4, 4, 8, None, None) == -1
+    # optimizer table: nothing to expand is fine, a record list without a destination (or with a null tensor) is not
+    assert lib.mh_opt_build_chunks(None, 0, None, 0, None) == 0
+    assert lib.mh_opt_build_chunks(None, 2, None, 2, None) == -1
+    rec = (ctypes.c_uint64 * 4)(0, 0, 0, 0)                    # {p, g, buf} = NULL, n = 0: rejected before any launch
+    assert lib.mh_opt_build_chunks(rec, 1, ctypes.c_void_p(1 << 20), 1, None) == -1
+    assert lib.mh_roi_align_bwd_det(None, 1, 2048, 4, 4, 1, None, 1, 7, 7, ctypes.c_float(1.0), None, None) == -1
 
 
 @pytest.mark.skipif(torch.cuda.is_available(), reason='checks the no-GPU failure mode')
