@@ -120,13 +120,37 @@ int mh_triplet_match(const int *gt_triplets, const float *gt_boxes, int G, const
  *     C[M,N] = epi( opA(A)[M,K] * opB(B)[K,N] + bias[N] )   (+ C if accumulate)
  *   transA 0: A stored [M,K] (lda)   1: A stored [K,M]
  *   transB 0: B stored [K,N] (ldb)   1: B stored [N,K]     (nn.Linear weight -> transB=1)
- *   bias may be NULL.  splitk <= 0 lets the library choose; >1 needs workspace >= mh_gemm_ws_bytes.
+ *   bias may be NULL.  splitk <= 0 lets the library choose.  The workspace is MANDATORY (>= mh_gemm_ws_bytes, 256-byte
+ *   aligned): since round 3 the call first writes both operands as f16 plane images into it (below), then multiplies those.
  * ------------------------------------------------------------------------------------------- */
 size_t mh_gemm_ws_bytes(int M, int N, int K, int splitk);
 int mh_gemm_auto_splitk(int M, int N, int K);
 int mh_gemm_f32(int transA, int transB, int M, int N, int K, const float *A, int lda,
                 const float *B, int ldb, float *C, int ldc, const float *bias, int epilogue,
                 int accumulate, int splitk, void *workspace, size_t ws_bytes, void *stream);
+
+/* Plane images (round 3; csrc/pl_tile.h): an operand with `rows` rows (the non-K index) and K columns stored as
+ * cell(kc, r) = 64 bytes at (kc * rows + r) * 64 = h1[16] | h2[16] (f16 terms of x * 2^e_r for k = 16 kc ..), followed
+ * (256-byte aligned) by the rows' largest |x| as fp32 bit patterns.  An image is made ONCE per operand value and reused by
+ * every product that reads the operand in that orientation (cached weight images: lib/hip_ops.py) -- the K loop of
+ * mh_gemm_planes then contains no split arithmetic at all.
+ *   mh_make_planes: k_contiguous 1: X is [rows][K] (ld); 0: X is [K][rows] (ld) -- the transposition happens here, once.
+ *   mh_gemm_planes: C[M,N] = epi(A[M,K] . B[N,K]^T + bias) (+ C); images 256-byte aligned, < 2 GiB each.
+ * Replaces the same cuBLAS calls as mh_gemm_f32 (lib/rel_model.py:366-373,403-414, lib/object_detector.py:129-138). */
+size_t mh_planes_bytes(long long rows, long long K);
+int mh_make_planes(const float *X, int k_contiguous, long long rows, long long K, long long ld, void *image, void *stream);
+size_t mh_gemm_planes_ws_bytes(int M, int N, int K, int splitk);
+int mh_gemm_planes_auto_splitk(int M, int N, int K);
+int mh_gemm_planes(int M, int N, int K, const void *A_image, const void *B_image, float *C, int ldc, const float *bias,
+                   int epilogue, int accumulate, int splitk, void *workspace, size_t ws_bytes, void *stream);
+/* A/B hooks for measurements (tools/pl_check.cpp): force a block-tile shape (-1 auto, 0 256x128, 1 128x128, 2 256x64);
+ * the round-2 in-loop-split kernel (fp32 operands split inside the K loop) kept for comparison runs. */
+void mh_debug_pl_shape(int shape);
+size_t mh_gemm_ws_bytes_v2(int M, int N, int K, int splitk);
+int mh_gemm_auto_splitk_v2(int M, int N, int K);
+int mh_gemm_f32_v2(int transA, int transB, int M, int N, int K, const float *A, int lda,
+                   const float *B, int ldb, float *C, int ldc, const float *bias, int epilogue,
+                   int accumulate, int splitk, void *workspace, size_t ws_bytes, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Convolution stack, NHWC internal layout (cuDNN replacement; lib/object_detector.py:110-118,

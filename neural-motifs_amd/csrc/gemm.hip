@@ -604,9 +604,9 @@ int mh_mfma_split(void) { return MH_MFMA_SPLIT; }
 int mh_split_f16(void) { return MH_SPLIT_F16; }
 int mh_split_rne(void) { return (MH_MFMA_SPLIT != 0 && MH_SPLIT_RN) ? 1 : 0; }
 
-int mh_gemm_auto_splitk(int M, int N, int K) { return (M > 0 && N > 0 && K > 0) ? choose_splitk(M, N, K) : 1; }
+int mh_gemm_auto_splitk_v2(int M, int N, int K) { return (M > 0 && N > 0 && K > 0) ? choose_splitk(M, N, K) : 1; }
 
-size_t mh_gemm_ws_bytes(int M, int N, int K, int splitk)
+size_t mh_gemm_ws_bytes_v2(int M, int N, int K, int splitk)
 {
     if (M <= 0 || N <= 0 || K <= 0) return 0;
     if (splitk <= 0) splitk = choose_splitk(M, N, K);
@@ -615,7 +615,7 @@ size_t mh_gemm_ws_bytes(int M, int N, int K, int splitk)
     return exps + align_up((size_t)splitk * M * N * sizeof(float), 256);
 }
 
-int mh_gemm_f32(int transA, int transB, int M, int N, int K, const float *A, int lda, const float *B, int ldb,
+int mh_gemm_f32_v2(int transA, int transB, int M, int N, int K, const float *A, int lda, const float *B, int ldb,
                 float *C, int ldc, const float *bias, int epilogue, int accumulate, int splitk, void *workspace,
                 size_t ws_bytes, void *stream)
 {

@@ -1,0 +1,416 @@
+// pl_gemm.hip -- fp32-accurate GEMM on the plane engine (pl_tile.h): C[M,N] = epi(A[M,K] . B[N,K]^T + bias), both operands
+// read as pre-split f16 plane images (no VALU in the K loop), plus the operand-preparation pass that writes such images.
+//
+//   mh_make_planes      fp32 matrix (either storage orientation) -> plane image + row maxima       (one pass per operand use)
+//   mh_gemm_planes      the product of two plane images
+//   mh_gemm_f32         the round-1/2 entry point, now = make_planes(A), make_planes(B) into the workspace + mh_gemm_planes
+// Every nn.Linear-shaped contraction of the path goes through here (fc6/fc7 x3 with cached weight images, score/bbox heads,
+// LSTM input projections, post_lstm, rel_compress and their dgrad/wgrad): reference lib/rel_model.py:366-373,403-414,
+// lib/object_detector.py:129-138 (cuBLAS there).
+#include <algorithm>
+#include <cstdlib>
+
+#include "mfma_tile.h"     // launch_row_exponents / launch_splitk_reduce / makespan_units (gemm.hip)
+#include "pl_tile.h"
+
+namespace mh {
+namespace pl {
+
+// ------------------------------------------------------------------------------------------------- operand preparation
+struct PlaneJob {
+    const float *X;
+    long long ld;
+    long long rows, K;          // operand rows (non-K index) and K extent
+    char *cells;                // [Kc][rows][64]
+    const unsigned *maxbits;    // |x| maxima (fp32 bits), one per `exp_div` consecutive rows
+    int exp_div;
+    int kmajor;                 // 0: X is [rows][K] (K contiguous); 1: X is [K][rows]
+    int vec;                    // 16-byte aligned base, ld % 4 == 0
+    int tiles_k, nblocks;       // 64 x 64 tiles along K; blocks of this job
+};
+
+// one 64 (operand rows) x 64 (k) tile: coalesced fp32 reads in the operand's own orientation, split, transpose through
+// LDS into cell order, then four contiguous 4 KB runs (one per k-chunk) leave the block as 16-byte stores
+__device__ __forceinline__ void planes_tile(const PlaneJob &p, int bid, char *lds)
+{
+    const int tid = threadIdx.x;
+    const long long tk = bid % p.tiles_k, tr = bid / p.tiles_k;
+    const long long r0 = tr * 64, k0 = tk * 64;
+    const long long Kc = (p.K + kBK - 1) / kBK;
+    auto rexp = [&](long long r) { return row_exponent(p.maxbits[r / p.exp_div]); };
+    if (!p.kmajor) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int f = tid + 256 * j, row = f >> 4, q = f & 15;
+            const long long r = r0 + row, k = k0 + 4 * q;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            int e = 0;
+            if (r < p.rows) {
+                e = rexp(r);
+                const float *src = p.X + r * p.ld + k;
+                if (p.vec && k + 3 < p.K) v = *reinterpret_cast<const float4 *>(src);
+                else {
+                    if (k + 0 < p.K) v.x = src[0];
+                    if (k + 1 < p.K) v.y = src[1];
+                    if (k + 2 < p.K) v.z = src[2];
+                    if (k + 3 < p.K) v.w = src[3];
+                }
+            }
+            unsigned a1, a2, b1, b2;
+            split2(v.x, v.y, e, a1, a2);
+            split2(v.z, v.w, e, b1, b2);
+            char *cell = lds + ((q >> 2) * 64 + row) * kCell + 8 * (q & 3);
+            *reinterpret_cast<u32x2 *>(cell) = (u32x2){a1, b1};
+            *reinterpret_cast<u32x2 *>(cell + 32) = (u32x2){a2, b2};
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int t = tid + 256 * j, quad = t & 15, kp = t >> 4;          // 4 operand rows x one k pair
+            const long long r = r0 + 4 * quad, k = k0 + 2 * kp;
+            float ev[4] = {0.f, 0.f, 0.f, 0.f}, od[4] = {0.f, 0.f, 0.f, 0.f};
+            auto fetch = [&](long long kk, float *dst) {
+                if (kk >= p.K) return;
+                const float *src = p.X + kk * p.ld + r;
+                if (p.vec && r + 3 < p.rows) {
+                    const float4 v = *reinterpret_cast<const float4 *>(src);
+                    dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w;
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        if (r + i < p.rows) dst[i] = src[i];
+                }
+            };
+            fetch(k, ev);
+            fetch(k + 1, od);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int e = (r + i < p.rows) ? rexp(r + i) : 0;
+                unsigned p1, p2;
+                split2(ev[i], od[i], e, p1, p2);
+                char *cell = lds + ((kp >> 3) * 64 + 4 * quad + i) * kCell + 4 * (kp & 7);
+                *reinterpret_cast<unsigned *>(cell) = p1;
+                *reinterpret_cast<unsigned *>(cell + 32) = p2;
+            }
+        }
+    }
+    __syncthreads();
+    const int row = tid >> 2, c = tid & 3;
+    if (r0 + row < p.rows) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const long long kc = k0 / kBK + j;
+            if (kc < Kc)
+                *reinterpret_cast<u32x4 *>(p.cells + ((size_t)kc * p.rows + r0 + row) * kCell + 16 * c) =
+                    *reinterpret_cast<const u32x4 *>(lds + (j * 64 + row) * kCell + 16 * c);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void planes_dual_kernel(const PlaneJob a, const PlaneJob b)
+{
+    __shared__ __attribute__((aligned(16))) char lds[4 * 64 * kCell];
+    if ((int)blockIdx.x < a.nblocks) planes_tile(a, (int)blockIdx.x, lds);
+    else planes_tile(b, (int)blockIdx.x - a.nblocks, lds);
+}
+
+static PlaneJob make_job(const float *X, bool k_contiguous, long long rows, long long K, long long ld, void *cells,
+                         const unsigned *maxbits, int exp_div)
+{
+    PlaneJob j;
+    j.X = X; j.ld = ld; j.rows = rows; j.K = K; j.cells = reinterpret_cast<char *>(cells); j.maxbits = maxbits;
+    j.exp_div = exp_div; j.kmajor = k_contiguous ? 0 : 1;
+    j.vec = ((reinterpret_cast<uintptr_t>(X) & 15) == 0 && ld % 4 == 0) ? 1 : 0;
+    j.tiles_k = (int)((K + 63) / 64);
+    j.nblocks = (int)(j.tiles_k * ((rows + 63) / 64));
+    return j;
+}
+
+// ------------------------------------------------------------------------------------------------- the GEMM kernel
+struct GemmArgs {
+    const char *A, *B;             // cells of A [Kc][M][64], B [Kc][N][64]
+    const unsigned *mbA, *mbB;     // row maxima (fp32 bits)
+    int M, N, Kc;
+    float *C;
+    int ldc;
+    const float *bias;
+    int epilogue, accumulate;
+    int splitk, kc_per_split;
+    float *partial;                // [splitk][M][N] when splitk > 1
+    int tiles_m, tiles_n, patch_h, patch_w;
+};
+
+__device__ __forceinline__ float epi(float v, int epilogue)
+{
+    if (epilogue == MH_EPI_RELU) return fmaxf(v, 0.f);
+    if (epilogue == MH_EPI_RELU6) return fminf(fmaxf(v, 0.f), 6.f);
+    return v;
+}
+
+template <class S>
+__global__ __launch_bounds__(kThreads, 2) void gemm_kernel(const GemmArgs p)
+{
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int wm, wn;
+    wave_origin<S>(wave, wm, wn);
+    const int t = xcd_remap(blockIdx.x, p.tiles_m * p.tiles_n);
+    int tm, tn;
+    patch_tile(t, p.tiles_m, p.tiles_n, p.patch_h, p.patch_w, tm, tn);
+    const int m0 = tm * S::bm, n0 = tn * S::bn;
+    const int z = blockIdx.y;
+    const int kt_begin = z * p.kc_per_split, kt_end = min(p.Kc, kt_begin + p.kc_per_split);
+
+    const Src sa = make_src(p.A + (size_t)m0 * kCell), sb = make_src(p.B + (size_t)n0 * kCell);
+    const unsigned strideA = (unsigned)p.M * kCell, strideB = (unsigned)p.N * kCell;
+    CopyPlan<S> cp;
+    plan_copy<S>(cp, [&](int r) { return m0 + r < p.M; }, [&](int r) { return n0 + r < p.N; }, tid);
+    FragPlan fp;
+    plan_frags<S>(fp, wm, wn, lane);
+    auto issue = [&](Stage<S> &st, int kt) {
+        const unsigned oa = (unsigned)kt * strideA, ob = (unsigned)kt * strideB;
+#pragma unroll
+        for (int j = 0; j < S::na; ++j) st.a[j] = load16(sa, cp.va[j], oa);
+#pragma unroll
+        for (int j = 0; j < S::nb; ++j) st.b[j] = load16(sb, cp.vb[j], ob);
+    };
+
+    Acc<S> acc;
+    acc_zero<S>(acc);
+    Stage<S> st;
+    char *b0 = lds, *b1 = lds + S::buf_bytes;
+    issue(st, kt_begin);
+    store_stage<S>(st, cp, b0);
+    __syncthreads();
+    int kt = kt_begin;
+    for (; kt + 1 < kt_end; kt += 2) {
+        k_step<S>([&](Stage<S> &s) { issue(s, kt + 1); }, st, cp, fp, b0, b1, acc);
+        k_step<S>([&](Stage<S> &s) { issue(s, min(kt + 2, kt_end - 1)); }, st, cp, fp, b1, b0, acc);
+    }
+    if (kt < kt_end) k_step<S>([&](Stage<S> &s) { issue(s, kt); }, st, cp, fp, b0, b1, acc);   // odd count: harmless reload
+
+    // the tile buffers are free after the last barrier: this tile's row / column exponents go there
+    int *ex = reinterpret_cast<int *>(lds);
+    for (int i = tid; i < S::bm + S::bn; i += kThreads) {
+        const bool is_a = i < S::bm;
+        const int idx = is_a ? m0 + i : n0 + (i - S::bm);
+        const bool ok = is_a ? idx < p.M : idx < p.N;
+        ex[i] = ok ? row_exponent(is_a ? p.mbA[idx] : p.mbB[idx]) : 0;
+    }
+    __syncthreads();
+    int ecol[S::sn];
+    float bcol[S::sn];
+#pragma unroll
+    for (int sn = 0; sn < S::sn; ++sn) {
+        const int c = wn + 32 * sn + (lane & 31);
+        ecol[sn] = ex[S::bm + c];
+        bcol[sn] = (p.bias && p.splitk == 1 && n0 + c < p.N) ? p.bias[n0 + c] : 0.f;
+    }
+    if (p.splitk > 1) {
+        float *dst = p.partial + (size_t)z * p.M * p.N;
+        acc_foreach<S>(acc, wm, wn, lane, [&](int r, int c, int sn, float v) {
+            const int row = m0 + r, col = n0 + c;
+            if (row < p.M && col < p.N) dst[(size_t)row * p.N + col] = __builtin_ldexpf(v, -(ex[r] + ecol[sn]));
+        });
+        return;
+    }
+    acc_foreach<S>(acc, wm, wn, lane, [&](int r, int c, int sn, float v) {
+        const int row = m0 + r, col = n0 + c;
+        if (row >= p.M || col >= p.N) return;
+        v = epi(__builtin_ldexpf(v, -(ex[r] + ecol[sn])) + bcol[sn], p.epilogue);
+        float *q = p.C + (size_t)row * p.ldc + col;
+        if (p.accumulate) v += *q;
+        *q = v;
+    });
+}
+
+typedef Shape<256, 128, 4, 2> S256x128;
+typedef Shape<128, 128, 2, 2> S128x128;
+typedef Shape<256, 64, 2, 2> S256x64;
+
+// ------------------------------------------------------------------------------------------------- host side
+struct Plan {
+    int shape;     // 0: 256x128, 1: 128x128, 2: 256x64
+    int bm, bn, splitk;
+};
+static int g_force_shape = -1;      // mh_debug_pl_shape: A/B runs
+
+static Plan plan_gemm(int M, int N, int K, int want_splitk)
+{
+    static const int bms[3] = {256, 128, 256}, bns[3] = {128, 128, 64};
+    // fp32-equivalent FLOP/s one CU sustains with a full complement of blocks of the shape (measured: DESIGN.md 5)
+    static const double rate[3] = {400e12 / 256, 330e12 / 256, 300e12 / 256};
+    const int ktiles = ceil_div(K, kBK);
+    Plan best = {1, 128, 128, 1};
+    double best_cost = 1e30;
+    for (int s = 0; s < 3; ++s) {
+        if (g_force_shape >= 0 && s != g_force_shape) continue;
+        if (g_force_shape < 0) {
+            if (s == 2 && N > 64) continue;
+            if (s != 2 && N <= 64) continue;
+            if (s == 0 && M <= 128) continue;
+        }
+        const long long tiles = (long long)ceil_div(M, bms[s]) * ceil_div(N, bns[s]);
+        const double t1 = 2.0 * bms[s] * bns[s] * (double)K / rate[s];      // one tile on a fully occupied CU
+        static const int cand[] = {1, 2, 3, 4, 5, 6, 7, 8, 10, 12, 14, 16, 20, 24, 28, 32, 40, 48, 56, 64};
+        auto consider = [&](int sk) {
+            const double t_partial = (sk > 1) ? ((double)M * N * 8.0 * sk) / 4.0e12 + 4e-6 : 0.0;
+            const double cost = makespan_units(tiles * sk) * t1 / sk + t_partial;
+            if (cost < best_cost * 0.97) { best_cost = cost; best = {s, bms[s], bns[s], sk}; }
+        };
+        if (want_splitk > 0) { consider(std::max(1, std::min(std::min(want_splitk, 64), ktiles))); continue; }
+        for (int sk : cand) {
+            if (sk > 1 && ktiles / sk < 8) break;
+            consider(sk);
+        }
+    }
+    return best;
+}
+
+static inline size_t cells_bytes(long long rows, long long K) { return (size_t)ceil_div(K, (long long)kBK) * rows * kCell; }
+static inline size_t image_bytes(long long rows, long long K) { return align_up(cells_bytes(rows, K), 256) + align_up((size_t)rows * 4, 256); }
+static inline unsigned *image_maxbits(void *image, long long rows, long long K)
+{
+    return reinterpret_cast<unsigned *>(reinterpret_cast<char *>(image) + align_up(cells_bytes(rows, K), 256));
+}
+
+static int launch_gemm(const GemmArgs &p0, const Plan &pl, hipStream_t st)
+{
+    GemmArgs p = p0;
+    p.tiles_m = ceil_div(p.M, pl.bm);
+    p.tiles_n = ceil_div(p.N, pl.bn);
+    int ph = 8, pw = 8;       // ~64 tiles per patch = what one XCD runs at a time (patch_tile)
+    if (p.tiles_m < 8) { ph = p.tiles_m; pw = std::min(p.tiles_n, std::max(1, 64 / ph)); }
+    else if (p.tiles_n < 8) { pw = p.tiles_n; ph = std::min(p.tiles_m, std::max(1, 64 / pw)); }
+    p.patch_h = std::max(ph, 1);
+    p.patch_w = std::max(pw, 1);
+    const dim3 grid((unsigned)(p.tiles_m * p.tiles_n), (unsigned)p.splitk);
+    if (pl.shape == 0) launch<gemm_kernel<S256x128>>(grid, S256x128::lds_bytes, st, p);
+    else if (pl.shape == 1) launch<gemm_kernel<S128x128>>(grid, S128x128::lds_bytes, st, p);
+    else launch<gemm_kernel<S256x64>>(grid, S256x64::lds_bytes, st, p);
+    return check_launch("pl::gemm_kernel");
+}
+
+}  // namespace pl
+}  // namespace mh
+
+using namespace mh;
+
+extern "C" {
+
+void mh_debug_pl_shape(int shape) { pl::g_force_shape = shape; }
+
+size_t mh_planes_bytes(long long rows, long long K)
+{
+    if (rows <= 0 || K <= 0) return 0;
+    return pl::image_bytes(rows, K);
+}
+
+// plane image of the operand whose `rows` rows (the non-K index) have K elements: k_contiguous = X is [rows][K] (ld),
+// otherwise X is [K][rows] (ld).  Two launches (+ one memset for k-major storage): row maxima, split.
+int mh_make_planes(const float *X, int k_contiguous, long long rows, long long K, long long ld, void *image, void *stream)
+{
+    MH_REQUIRE(X && image && rows > 0 && K > 0);
+    MH_REQUIRE(ld >= (k_contiguous ? K : rows));
+    MH_REQUIRE((reinterpret_cast<uintptr_t>(image) & 255) == 0);
+    MH_REQUIRE(pl::cells_bytes(rows, K) < (size_t)0x7ff00000u);      // 32-bit offsets inside the kernels' descriptors
+    hipStream_t st = as_stream(stream);
+    unsigned *mb = pl::image_maxbits(image, rows, K);
+    int rc = launch_row_exponents(X, k_contiguous != 0, rows, K, ld, reinterpret_cast<int *>(mb), st, /*bits_only=*/true);
+    if (rc) return rc;
+    const pl::PlaneJob a = pl::make_job(X, k_contiguous != 0, rows, K, ld, image, mb, 1);
+    pl::PlaneJob none = a;
+    none.nblocks = 0;
+    hipLaunchKernelGGL(pl::planes_dual_kernel, dim3((unsigned)a.nblocks), dim3(256), 0, st, a, none);
+    return check_launch("pl::planes_dual_kernel");
+}
+
+int mh_gemm_planes_auto_splitk(int M, int N, int K) { return (M > 0 && N > 0 && K > 0) ? pl::plan_gemm(M, N, K, 0).splitk : 1; }
+
+size_t mh_gemm_planes_ws_bytes(int M, int N, int K, int splitk)
+{
+    if (M <= 0 || N <= 0 || K <= 0) return 0;
+    const pl::Plan pln = pl::plan_gemm(M, N, K, splitk);
+    return pln.splitk > 1 ? align_up((size_t)pln.splitk * M * N * sizeof(float), 256) : 0;
+}
+
+static int gemm_planes_impl(int M, int N, int K, const void *cellsA, const unsigned *mbA, const void *cellsB, const unsigned *mbB,
+                            float *C, int ldc, const float *bias, int epilogue, int accumulate, int splitk, void *workspace,
+                            size_t ws_bytes, void *stream)
+{
+    MH_REQUIRE(M >= 0 && N >= 0 && K >= 0);
+    if (M == 0 || N == 0) return MH_OK;
+    MH_REQUIRE(cellsA && cellsB && mbA && mbB && C && K > 0 && ldc >= N);
+    MH_REQUIRE(epilogue >= MH_EPI_NONE && epilogue <= MH_EPI_RELU6);
+    MH_REQUIRE(((reinterpret_cast<uintptr_t>(cellsA) | reinterpret_cast<uintptr_t>(cellsB)) & 15) == 0);
+    MH_REQUIRE(pl::cells_bytes(M, K) < (size_t)0x7ff00000u && pl::cells_bytes(N, K) < (size_t)0x7ff00000u);
+    pl::Plan pln = pl::plan_gemm(M, N, K, splitk);
+    if (pln.splitk > 1 && (workspace == nullptr || ws_bytes < (size_t)pln.splitk * M * N * sizeof(float))) pln.splitk = 1;
+    pl::GemmArgs p;
+    p.A = reinterpret_cast<const char *>(cellsA);
+    p.B = reinterpret_cast<const char *>(cellsB);
+    p.mbA = mbA;
+    p.mbB = mbB;
+    p.M = M; p.N = N; p.Kc = ceil_div(K, pl::kBK);
+    p.C = C; p.ldc = ldc; p.bias = bias; p.epilogue = epilogue; p.accumulate = accumulate;
+    p.kc_per_split = ceil_div(p.Kc, pln.splitk);
+    p.splitk = ceil_div(p.Kc, p.kc_per_split);
+    p.partial = reinterpret_cast<float *>(workspace);
+    hipStream_t st = as_stream(stream);
+    int rc = pl::launch_gemm(p, pln, st);
+    if (rc || p.splitk == 1) return rc;
+    return launch_splitk_reduce(p.partial, p.splitk, M, N, C, ldc, bias, epilogue, accumulate, st);
+}
+
+int mh_gemm_planes(int M, int N, int K, const void *A_image, const void *B_image, float *C, int ldc, const float *bias,
+                   int epilogue, int accumulate, int splitk, void *workspace, size_t ws_bytes, void *stream)
+{
+    if (M > 0 && N > 0) MH_REQUIRE(A_image && B_image && K > 0);
+    else return MH_OK;
+    MH_REQUIRE(((reinterpret_cast<uintptr_t>(A_image) | reinterpret_cast<uintptr_t>(B_image)) & 255) == 0);
+    return gemm_planes_impl(M, N, K, A_image, pl::image_maxbits(const_cast<void *>(A_image), M, K), B_image,
+                            pl::image_maxbits(const_cast<void *>(B_image), N, K), C, ldc, bias, epilogue, accumulate, splitk,
+                            workspace, ws_bytes, stream);
+}
+
+// ---- the fp32-operand entry point (round-1 signature): images of both operands in the workspace, then the plane GEMM
+size_t mh_gemm_ws_bytes(int M, int N, int K, int splitk)
+{
+    if (M <= 0 || N <= 0 || K <= 0) return 0;
+    return align_up((size_t)M * 4, 256) + align_up((size_t)N * 4, 256) + align_up(pl::cells_bytes(M, K), 256) +
+           align_up(pl::cells_bytes(N, K), 256) + mh_gemm_planes_ws_bytes(M, N, K, splitk);
+}
+
+int mh_gemm_auto_splitk(int M, int N, int K) { return mh_gemm_planes_auto_splitk(M, N, K); }
+
+int mh_gemm_f32(int transA, int transB, int M, int N, int K, const float *A, int lda, const float *B, int ldb,
+                float *C, int ldc, const float *bias, int epilogue, int accumulate, int splitk, void *workspace,
+                size_t ws_bytes, void *stream)
+{
+    MH_REQUIRE(M >= 0 && N >= 0 && K >= 0);
+    if (M == 0 || N == 0) return MH_OK;
+    MH_REQUIRE(A && B && C && K > 0);
+    MH_REQUIRE(lda >= (transA ? M : K) && ldb >= (transB ? K : N) && ldc >= N);
+    MH_REQUIRE(epilogue >= MH_EPI_NONE && epilogue <= MH_EPI_RELU6);
+    // workspace: maxbits A | maxbits B (adjacent: the k-major pass zeroes them with one memset) | cells A | cells B | partials
+    const size_t ma = align_up((size_t)M * 4, 256), mb = align_up((size_t)N * 4, 256);
+    const size_t ca = align_up(pl::cells_bytes(M, K), 256), cb = align_up(pl::cells_bytes(N, K), 256);
+    MH_REQUIRE(workspace && (reinterpret_cast<uintptr_t>(workspace) & 255) == 0 && ws_bytes >= ma + mb + ca + cb);
+    MH_REQUIRE(pl::cells_bytes(M, K) < (size_t)0x7ff00000u && pl::cells_bytes(N, K) < (size_t)0x7ff00000u);
+    hipStream_t st = as_stream(stream);
+    char *w = reinterpret_cast<char *>(workspace);
+    unsigned *mbA = reinterpret_cast<unsigned *>(w), *mbB = reinterpret_cast<unsigned *>(w + ma);
+    char *cellsA = w + ma + mb, *cellsB = cellsA + ca;
+    int rc = launch_operand_absmax(A, !transA, M, K, lda, reinterpret_cast<int *>(mbA), B, transB != 0, N, K, ldb,
+                                   reinterpret_cast<int *>(mbB), st);
+    if (rc) return rc;
+    const pl::PlaneJob ja = pl::make_job(A, !transA, M, K, lda, cellsA, mbA, 1);
+    const pl::PlaneJob jb = pl::make_job(B, transB != 0, N, K, ldb, cellsB, mbB, 1);
+    hipLaunchKernelGGL(pl::planes_dual_kernel, dim3((unsigned)(ja.nblocks + jb.nblocks)), dim3(256), 0, st, ja, jb);
+    rc = check_launch("pl::planes_dual_kernel");
+    if (rc) return rc;
+    return gemm_planes_impl(M, N, K, cellsA, mbA, cellsB, mbB, C, ldc, bias, epilogue, accumulate, splitk, cellsB + cb,
+                            ws_bytes - (ma + mb + ca + cb), stream);
+}
+
+}  // extern "C"

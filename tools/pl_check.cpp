@@ -1,0 +1,260 @@
+// Device check of the round-3 plane GEMM (csrc/pl_gemm.hip) through the C ABI, torch-free:
+//   * accuracy of mh_gemm_f32 (operand preparation + plane GEMM) in all four storage orientations, ragged and aligned
+//     shapes, bias / ReLU / accumulate / forced split-K, against a float64 CPU product -- next to the round-2 in-loop-split
+//     kernel (mh_gemm_f32_v2) on the same inputs;
+//   * mh_make_planes + mh_gemm_planes on persistent images (the cached-weight path);
+//   * speed on the step's big shapes (fc6 forward / input gradient / weight gradient, fc7, the 120-row object fc6, 4096^3):
+//     v2 | v3 end to end (absmax + split + product) | v3 product only on ready images, per block-tile shape and split-K.
+//   hipcc -O2 tools/pl_check.cpp -o tools/_bin/pl_check -ldl
+//   tools/_bin/pl_check neural-motifs_amd/csrc/libmotifs_hip.so [--quick]
+#include <hip/hip_runtime.h>
+#include <dlfcn.h>
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+#include <random>
+#include <vector>
+
+#define HIP_OK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(2); } } while (0)
+
+typedef int (*gemm_fn)(int, int, int, int, int, const float *, int, const float *, int, float *, int, const float *, int, int, int, void *, size_t, void *);
+typedef size_t (*ws_fn)(int, int, int, int);
+typedef size_t (*pbytes_fn)(long long, long long);
+typedef int (*mkplanes_fn)(const float *, int, long long, long long, long long, void *, void *);
+typedef int (*gemmpl_fn)(int, int, int, const void *, const void *, float *, int, const float *, int, int, int, void *, size_t, void *);
+typedef void (*shape_fn)(int);
+typedef const char *(*err_fn)(void);
+
+static gemm_fn g3, g2;
+static ws_fn ws3, ws2, wspl;
+static pbytes_fn pbytes;
+static mkplanes_fn mkplanes;
+static gemmpl_fn gemmpl;
+static shape_fn set_shape;
+static err_fn last_err;
+
+struct Dev {
+    void *p = nullptr;
+    size_t n = 0;
+    explicit Dev(size_t bytes) : n(bytes) { HIP_OK(hipMalloc(&p, std::max<size_t>(bytes, 256))); }
+    ~Dev() { (void)hipFree(p); }
+    float *f() { return reinterpret_cast<float *>(p); }
+};
+
+static void fill(std::vector<float> &v, std::mt19937 &rng, bool wide)
+{
+    std::normal_distribution<float> nrm(0.f, 1.f);
+    std::uniform_real_distribution<float> expo(-8.f, 8.f);
+    for (auto &x : v) x = wide ? nrm(rng) * std::exp2(expo(rng)) : nrm(rng);
+}
+
+// C = epi(op(A) op(B) + bias) (+ C0) in float64
+static void ref_gemm(int tA, int tB, int M, int N, int K, const std::vector<float> &A, int lda, const std::vector<float> &B, int ldb,
+                     const float *bias, int epi, const std::vector<float> *C0, int ldc, std::vector<double> &R)
+{
+    R.assign((size_t)M * N, 0.0);
+    for (int m = 0; m < M; ++m)
+        for (int k = 0; k < K; ++k) {
+            const double a = tA ? A[(size_t)k * lda + m] : A[(size_t)m * lda + k];
+            double *r = &R[(size_t)m * N];
+            if (tB) for (int n = 0; n < N; ++n) r[n] += a * (double)B[(size_t)n * ldb + k];
+            else for (int n = 0; n < N; ++n) r[n] += a * (double)B[(size_t)k * ldb + n];
+        }
+    for (int m = 0; m < M; ++m)
+        for (int n = 0; n < N; ++n) {
+            double v = R[(size_t)m * N + n] + (bias ? bias[n] : 0.0);
+            if (epi == 1) v = std::max(v, 0.0);
+            if (C0) v += (*C0)[(size_t)m * ldc + n];
+            R[(size_t)m * N + n] = v;
+        }
+}
+
+struct Err { double rms_rel, max_rel; };
+static Err compare(const std::vector<float> &C, int ldc, const std::vector<double> &R, int M, int N)
+{
+    double ss = 0, se = 0, mx = 0;
+    for (int m = 0; m < M; ++m)
+        for (int n = 0; n < N; ++n) {
+            const double r = R[(size_t)m * N + n], e = (double)C[(size_t)m * ldc + n] - r;
+            ss += r * r; se += e * e; mx = std::fmax(mx, std::fabs(e));
+        }
+    const double rms = std::sqrt(ss / ((double)M * N)) + 1e-300;
+    return {std::sqrt(se / ((double)M * N)) / rms, mx / rms};
+}
+
+static int accuracy_case(const char *name, int tA, int tB, int M, int N, int K, int padA, int padB, int padC, bool wide, int use_bias,
+                         int epi, int accum, int splitk, unsigned seed)
+{
+    std::mt19937 rng(seed);
+    const int lda = (tA ? M : K) + padA, ldb = (tB ? K : N) + padB, ldc = N + padC;
+    std::vector<float> A((size_t)(tA ? K : M) * lda), B((size_t)(tB ? N : K) * ldb), C0((size_t)M * ldc), bias(N);
+    fill(A, rng, wide); fill(B, rng, wide); fill(C0, rng, false); fill(bias, rng, false);
+    Dev dA(A.size() * 4), dB(B.size() * 4), dC(C0.size() * 4), dbias(N * 4);
+    HIP_OK(hipMemcpy(dA.p, A.data(), A.size() * 4, hipMemcpyHostToDevice));
+    HIP_OK(hipMemcpy(dB.p, B.data(), B.size() * 4, hipMemcpyHostToDevice));
+    HIP_OK(hipMemcpy(dbias.p, bias.data(), N * 4, hipMemcpyHostToDevice));
+    std::vector<double> R;
+    ref_gemm(tA, tB, M, N, K, A, lda, B, ldb, use_bias ? bias.data() : nullptr, epi, accum ? &C0 : nullptr, ldc, R);
+    Err e[2];
+    int rc[2];
+    for (int v = 0; v < 2; ++v) {
+        gemm_fn g = v ? g2 : g3;
+        const size_t wsb = (v ? ws2 : ws3)(M, N, K, splitk);
+        Dev ws(wsb);
+        HIP_OK(hipMemcpy(dC.p, C0.data(), C0.size() * 4, hipMemcpyHostToDevice));
+        rc[v] = g(tA, tB, M, N, K, dA.f(), lda, dB.f(), ldb, dC.f(), ldc, use_bias ? dbias.f() : nullptr, epi, accum, splitk, ws.p, ws.n, nullptr);
+        HIP_OK(hipDeviceSynchronize());
+        std::vector<float> C(C0.size());
+        HIP_OK(hipMemcpy(C.data(), dC.p, C.size() * 4, hipMemcpyDeviceToHost));
+        e[v] = compare(C, ldc, R, M, N);
+    }
+    const bool ok = rc[0] == 0 && e[0].rms_rel < 2e-6 && e[0].max_rel < 4e-5;
+    printf("{\"check\": \"accuracy\", \"case\": \"%s\", \"tA\": %d, \"tB\": %d, \"M\": %d, \"N\": %d, \"K\": %d, \"splitk\": %d, \"rc\": %d, "
+           "\"v3_rms_rel\": %.3g, \"v3_max_rel\": %.3g, \"v2_rms_rel\": %.3g, \"v2_max_rel\": %.3g, \"ok\": %s}\n",
+           name, tA, tB, M, N, K, splitk, rc[0], e[0].rms_rel, e[0].max_rel, e[1].rms_rel, e[1].max_rel, ok ? "true" : "false");
+    if (rc[0]) printf("{\"error\": \"%s\"}\n", last_err());
+    fflush(stdout);
+    return ok ? 0 : 1;
+}
+
+// persistent images: A [M,K] K-contiguous, B given as [K,N] (k-major) -> both through mh_make_planes, every forced shape
+static int image_case(int M, int N, int K, unsigned seed)
+{
+    std::mt19937 rng(seed);
+    std::vector<float> A((size_t)M * K), B((size_t)K * N);
+    fill(A, rng, true); fill(B, rng, true);
+    Dev dA(A.size() * 4), dB(B.size() * 4), dC((size_t)M * N * 4), ia(pbytes(M, K)), ib(pbytes(N, K));
+    HIP_OK(hipMemcpy(dA.p, A.data(), A.size() * 4, hipMemcpyHostToDevice));
+    HIP_OK(hipMemcpy(dB.p, B.data(), B.size() * 4, hipMemcpyHostToDevice));
+    int rc = mkplanes(dA.f(), 1, M, K, K, ia.p, nullptr);
+    rc |= mkplanes(dB.f(), 0, N, K, N, ib.p, nullptr);
+    std::vector<double> R;
+    ref_gemm(0, 0, M, N, K, A, K, B, N, nullptr, 0, nullptr, N, R);
+    int bad = 0;
+    for (int shape = -1; shape <= 2; ++shape) {
+        set_shape(shape);
+        for (int sk : {0, 1, 3}) {
+            Dev ws(wspl(M, N, K, sk));
+            HIP_OK(hipMemset(dC.p, 0xff, (size_t)M * N * 4));
+            const int r2 = gemmpl(M, N, K, ia.p, ib.p, dC.f(), N, nullptr, 0, 0, sk, ws.p, ws.n, nullptr);
+            HIP_OK(hipDeviceSynchronize());
+            std::vector<float> C((size_t)M * N);
+            HIP_OK(hipMemcpy(C.data(), dC.p, C.size() * 4, hipMemcpyDeviceToHost));
+            const Err e = compare(C, N, R, M, N);
+            const bool ok = (rc | r2) == 0 && e.rms_rel < 2e-6 && e.max_rel < 4e-5;
+            bad += !ok;
+            printf("{\"check\": \"images\", \"M\": %d, \"N\": %d, \"K\": %d, \"shape\": %d, \"splitk\": %d, \"rc\": %d, \"rms_rel\": %.3g, \"max_rel\": %.3g, \"ok\": %s}\n",
+                   M, N, K, shape, sk, rc | r2, e.rms_rel, e.max_rel, ok ? "true" : "false");
+        }
+    }
+    set_shape(-1);
+    fflush(stdout);
+    return bad;
+}
+
+static float time_ms(int iters, const std::function<void()> &fn)
+{
+    hipEvent_t e0, e1;
+    HIP_OK(hipEventCreate(&e0)); HIP_OK(hipEventCreate(&e1));
+    for (int i = 0; i < 2; ++i) fn();
+    HIP_OK(hipEventRecord(e0, nullptr));
+    for (int i = 0; i < iters; ++i) fn();
+    HIP_OK(hipEventRecord(e1, nullptr));
+    HIP_OK(hipEventSynchronize(e1));
+    float ms;
+    HIP_OK(hipEventElapsedTime(&ms, e0, e1));
+    HIP_OK(hipEventDestroy(e0)); HIP_OK(hipEventDestroy(e1));
+    return ms / iters;
+}
+
+static void fill_dev(float *d, size_t n, unsigned seed)
+{
+    std::vector<float> h(std::min<size_t>(n, (size_t)1 << 24));
+    std::mt19937 rng(seed);
+    std::normal_distribution<float> nrm(0.f, 1.f);
+    for (auto &v : h) v = nrm(rng);
+    for (size_t o = 0; o < n; o += h.size()) HIP_OK(hipMemcpy(d + o, h.data(), std::min(h.size(), n - o) * 4, hipMemcpyHostToDevice));
+}
+
+static void speed_case(const char *name, int tA, int tB, int M, int N, int K, int iters)
+{
+    const size_t na = (size_t)M * K, nb = (size_t)N * K;
+    Dev dA(na * 4), dB(nb * 4), dC((size_t)M * N * 4);
+    fill_dev(dA.f(), na, 1); fill_dev(dB.f(), nb, 2);
+    const int lda = tA ? M : K, ldb = tB ? K : N;
+    const double flops = 2.0 * M * N * (double)K;
+    {
+        Dev ws(ws2(M, N, K, 0));
+        const float ms = time_ms(iters, [&] { g2(tA, tB, M, N, K, dA.f(), lda, dB.f(), ldb, dC.f(), N, nullptr, 0, 0, 0, ws.p, ws.n, nullptr); });
+        printf("{\"check\": \"speed\", \"case\": \"%s\", \"engine\": \"v2 in-loop split\", \"M\": %d, \"N\": %d, \"K\": %d, \"ms\": %.4f, \"tflops\": %.1f}\n", name, M, N, K, ms, flops / ms * 1e-9);
+    }
+    {
+        Dev ws(ws3(M, N, K, 0));
+        const float ms = time_ms(iters, [&] { g3(tA, tB, M, N, K, dA.f(), lda, dB.f(), ldb, dC.f(), N, nullptr, 0, 0, 0, ws.p, ws.n, nullptr); });
+        printf("{\"check\": \"speed\", \"case\": \"%s\", \"engine\": \"v3 end to end (absmax + planes + product)\", \"M\": %d, \"N\": %d, \"K\": %d, \"ms\": %.4f, \"tflops\": %.1f}\n", name, M, N, K, ms, flops / ms * 1e-9);
+    }
+    Dev ia(pbytes(M, K)), ib(pbytes(N, K));
+    {
+        const float ms_a = time_ms(iters, [&] { mkplanes(dA.f(), !tA, M, K, lda, ia.p, nullptr); });
+        const float ms_b = time_ms(iters, [&] { mkplanes(dB.f(), tB, N, K, ldb, ib.p, nullptr); });
+        printf("{\"check\": \"speed\", \"case\": \"%s\", \"engine\": \"make_planes\", \"ms_A\": %.4f, \"GBps_A\": %.0f, \"ms_B\": %.4f, \"GBps_B\": %.0f}\n", name, ms_a,
+               na * 12.0 / ms_a * 1e-6, ms_b, nb * 12.0 / ms_b * 1e-6);
+    }
+    for (int shape = -1; shape <= 1; ++shape) {
+        if (shape == 0 && M <= 128) continue;
+        set_shape(shape);
+        for (int sk : {0, 1, 2, 4, 8, 16}) {
+            if (sk > 1 && K / 16 / sk < 8) continue;
+            Dev ws(wspl(M, N, K, sk));
+            const float ms = time_ms(iters, [&] { gemmpl(M, N, K, ia.p, ib.p, dC.f(), N, nullptr, 0, 0, sk, ws.p, ws.n, nullptr); });
+            printf("{\"check\": \"speed\", \"case\": \"%s\", \"engine\": \"v3 product on images\", \"shape\": %d, \"splitk\": %d, \"ms\": %.4f, \"tflops\": %.1f}\n", name, shape, sk, ms,
+                   flops / ms * 1e-9);
+            fflush(stdout);
+        }
+    }
+    set_shape(-1);
+}
+
+int main(int argc, char **argv)
+{
+    if (argc < 2) { printf("usage: pl_check <libmotifs_hip.so> [--quick] [--speed-only]\n"); return 1; }
+    const bool quick = argc > 2 && !strcmp(argv[2], "--quick");
+    const bool speed_only = argc > 2 && !strcmp(argv[2], "--speed-only");
+    void *h = dlopen(argv[1], RTLD_NOW);
+    if (!h) { printf("dlopen: %s\n", dlerror()); return 2; }
+    g3 = (gemm_fn)dlsym(h, "mh_gemm_f32"); g2 = (gemm_fn)dlsym(h, "mh_gemm_f32_v2");
+    ws3 = (ws_fn)dlsym(h, "mh_gemm_ws_bytes"); ws2 = (ws_fn)dlsym(h, "mh_gemm_ws_bytes_v2"); wspl = (ws_fn)dlsym(h, "mh_gemm_planes_ws_bytes");
+    pbytes = (pbytes_fn)dlsym(h, "mh_planes_bytes"); mkplanes = (mkplanes_fn)dlsym(h, "mh_make_planes");
+    gemmpl = (gemmpl_fn)dlsym(h, "mh_gemm_planes"); set_shape = (shape_fn)dlsym(h, "mh_debug_pl_shape"); last_err = (err_fn)dlsym(h, "mh_last_error");
+    if (!g3 || !g2 || !ws3 || !ws2 || !wspl || !pbytes || !mkplanes || !gemmpl || !set_shape || !last_err) { printf("missing symbol\n"); return 2; }
+    int bad = 0;
+    if (!speed_only) {
+        bad += accuracy_case("NT aligned", 0, 1, 256, 256, 512, 0, 0, 0, true, 0, 0, 0, 0, 1);
+        bad += accuracy_case("NN aligned", 0, 0, 256, 384, 512, 0, 0, 0, true, 0, 0, 0, 0, 2);
+        bad += accuracy_case("TN aligned", 1, 0, 384, 256, 512, 0, 0, 0, true, 0, 0, 0, 0, 3);
+        bad += accuracy_case("TT aligned", 1, 1, 256, 256, 512, 0, 0, 0, true, 0, 0, 0, 0, 4);
+        bad += accuracy_case("NT ragged bias relu", 0, 1, 301, 151, 1003, 1, 3, 5, true, 1, 1, 0, 0, 5);
+        bad += accuracy_case("NN ragged accumulate", 0, 0, 77, 259, 130, 3, 1, 0, false, 1, 0, 1, 0, 6);
+        bad += accuracy_case("TN ragged splitk 3", 1, 0, 203, 190, 999, 1, 2, 1, true, 0, 0, 0, 3, 7);
+        bad += accuracy_case("TT ragged", 1, 1, 130, 67, 75, 2, 1, 3, false, 1, 0, 0, 0, 8);
+        bad += accuracy_case("NT narrow N=51", 0, 1, 700, 51, 4096, 0, 0, 0, false, 1, 0, 0, 0, 9);
+        bad += accuracy_case("NT 120 rows", 0, 1, 120, 512, 2048, 0, 0, 0, false, 1, 1, 0, 0, 10);
+        bad += accuracy_case("NT K=7", 0, 1, 40, 33, 7, 0, 0, 0, false, 0, 0, 0, 0, 11);
+        bad += accuracy_case("NT 600x600x600 splitk 5 accumulate", 0, 1, 600, 600, 600, 0, 0, 0, true, 1, 1, 1, 5, 12);
+        bad += image_case(520, 300, 1040, 21);
+        bad += image_case(130, 60, 200, 22);
+        printf("{\"check\": \"accuracy summary\", \"failed\": %d}\n", bad);
+    }
+    if (!quick) {
+        speed_case("fc6 forward", 0, 1, 1536, 4096, 25088, 5);
+        speed_case("fc6 input gradient", 0, 0, 1536, 25088, 4096, 5);
+        speed_case("fc6 weight gradient", 1, 0, 4096, 25088, 1536, 5);
+        speed_case("fc7 forward", 0, 1, 1536, 4096, 4096, 10);
+        speed_case("object fc6 (120 rows)", 0, 1, 120, 4096, 25088, 10);
+        speed_case("4096^3", 0, 1, 4096, 4096, 4096, 5);
+    }
+    return bad ? 1 : 0;
+}
