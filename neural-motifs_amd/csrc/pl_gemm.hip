@@ -239,7 +239,7 @@ static Plan plan_gemm(int M, int N, int K, int want_splitk)
 {
     static const int bms[3] = {256, 128, 256}, bns[3] = {128, 128, 64};
     // fp32-equivalent FLOP/s one CU sustains with a full complement of blocks of the shape (measured: DESIGN.md 5)
-    static const double rate[3] = {400e12 / 256, 330e12 / 256, 300e12 / 256};
+    static const double rate[3] = {365e12 / 256, 370e12 / 256, 300e12 / 256};      // gpurun r03_c1
     const int ktiles = ceil_div(K, kBK);
     Plan best = {1, 128, 128, 1};
     double best_cost = 1e30;

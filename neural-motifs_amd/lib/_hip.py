@@ -185,6 +185,71 @@ def gemm(a, b, trans_a=False, trans_b=False, bias=None, epilogue=0, out=None, ac
     return out
 
 
+class PlaneImage(object):
+    """An operand of the plane GEMM (csrc/pl_tile.h): `rows` rows of K elements as f16 (h1 | h2) cells + row maxima, in
+    one uint8 device buffer.  Made once per operand VALUE and orientation (make_planes), consumed by gemm_planes."""
+    __slots__ = ('buf', 'rows', 'K')
+
+    def __init__(self, buf, rows, K):
+        self.buf, self.rows, self.K = buf, int(rows), int(K)
+
+
+def make_planes(x, k_contiguous=True):
+    """plane image of the operand held by the 2-D fp32 tensor x: k_contiguous -> operand rows = x rows (x is [rows, K]);
+    otherwise operand rows = x COLUMNS (x is [K, rows]: the transposition happens in this pass)"""
+    L = lib()
+    if x.dim() != 2 or x.stride(1) != 1 or not x.is_cuda or x.dtype != torch.float32:
+        raise HipKernelError('make_planes needs a 2-D fp32 CUDA tensor with unit inner stride')
+    rows, K = (x.shape[0], x.shape[1]) if k_contiguous else (x.shape[1], x.shape[0])
+    if rows == 0 or K == 0:
+        raise HipKernelError('make_planes: empty operand')
+    buf = torch.empty(L.mh_planes_bytes(c_ll(rows), c_ll(K)), dtype=torch.uint8, device=x.device)
+    rc = L.mh_make_planes(ctypes.c_void_p(x.data_ptr()), c_int(int(k_contiguous)), c_ll(rows), c_ll(K), c_ll(x.stride(0)),
+                          ctypes.c_void_p(buf.data_ptr()), stream())
+    _check(rc, 'mh_make_planes')
+    return PlaneImage(buf, rows, K)
+
+
+def gemm_planes(a, b, bias=None, epilogue=0, out=None, accumulate=False, splitk=0):
+    """C[a.rows, b.rows] = epi(A . B^T + bias) (+ C) from two plane images with the same K"""
+    L = lib()
+    if a.K != b.K:
+        raise HipKernelError('gemm_planes inner dimensions differ: %d vs %d' % (a.K, b.K))
+    M, N, K = a.rows, b.rows, a.K
+    if out is None:
+        out = torch.empty(M, N, dtype=torch.float32, device=a.buf.device)
+        accumulate = False
+    elif out.shape != (M, N) or out.stride(1) != 1:
+        raise HipKernelError('bad output tensor for gemm_planes')
+    wsb = L.mh_gemm_planes_ws_bytes(M, N, K, splitk)
+    ws = workspace(wsb, a.buf.device, 'gemm') if wsb else None
+    rc = L.mh_gemm_planes(M, N, K, ctypes.c_void_p(a.buf.data_ptr()), ctypes.c_void_p(b.buf.data_ptr()),
+                          ctypes.c_void_p(out.data_ptr()), c_int(out.stride(0)), f32(bias), c_int(epilogue),
+                          c_int(int(accumulate)), c_int(splitk), ptr(ws), c_size_t(ws.numel() if ws is not None else 0), stream())
+    _check(rc, 'mh_gemm_planes')
+    return out
+
+
+def gemm_inloop(a, b, trans_a=False, trans_b=False, bias=None, epilogue=0):
+    """the round-2 kernel (fp32 operands split inside the K loop): kept for ONE case -- a skinny product (<= 128 rows)
+    against a big weight matrix that changes every step and is read exactly once (the trainable object fc6), where
+    writing a plane image first would cost more than the product (profiles/r03_pl_check.jsonl)"""
+    L = lib()
+    M = a.shape[1] if trans_a else a.shape[0]
+    K = a.shape[0] if trans_a else a.shape[1]
+    N = b.shape[0] if trans_b else b.shape[1]
+    out = torch.empty(M, N, dtype=torch.float32, device=a.device)
+    splitk = L.mh_gemm_auto_splitk_v2(M, N, K)
+    wsb = L.mh_gemm_ws_bytes_v2(M, N, K, splitk)
+    ws = workspace(wsb, a.device, 'gemm') if wsb else None
+    rc = L.mh_gemm_f32_v2(c_int(int(trans_a)), c_int(int(trans_b)), M, N, K, ctypes.c_void_p(a.data_ptr()), c_int(a.stride(0)),
+                          ctypes.c_void_p(b.data_ptr()), c_int(b.stride(0)), ctypes.c_void_p(out.data_ptr()), c_int(out.stride(0)),
+                          f32(bias), c_int(epilogue), c_int(0), c_int(splitk), ptr(ws),
+                          c_size_t(ws.numel() if ws is not None else 0), stream())
+    _check(rc, 'mh_gemm_f32_v2')
+    return out
+
+
 # ----------------------------------------------------------------------------------------------- NMS
 def nms(boxes_sorted, thresh):
     """boxes_sorted [n,4] fp32 (score-descending).  Returns (keep int32 [n], num_keep int32 [1]) on device."""

@@ -32,6 +32,11 @@ class _MaxPoolNHWC(nn.MaxPool2d):
         return y.permute(0, 2, 3, 1)
 
 
+# test hook (tests/parity_util.py): a dict here receives the tower's ReLU masks and pool arg-max table of the next forward,
+# so that the parity tests can hand the oracle the product's own kink decisions (oracle/model.py: TAPS)
+TAPS = None
+
+
 class _TowerFn(torch.autograd.Function):
     """Conv7x7/2+ReLU -> BN -> MaxPool3x3/2 -> Conv3x3+ReLU -> BN -> (+ union features, NCHW out) as ONE autograd
     node over the fused kernels of csrc/tower.hip (ReLU lives in the conv epilogues; BN statistics / apply / pool /
@@ -61,6 +66,9 @@ class _TowerFn(torch.autograd.Function):
         y1 = _hip.conv3x3_nhwc(z, wt4, b4, EPI_RELU)
         mean2, invstd2 = stats(y1.view(-1, C1), bn2)
         out = _hip.bn_residual_nchw(y1, mean2, invstd2, g2, be2, union_pools.contiguous())
+        if TAPS is not None:
+            TAPS.update({'union_boxes.conv.0': (y0 > 0).permute(0, 3, 1, 2).cpu(), 'union_boxes.pool': arg.cpu(),
+                         'union_boxes.conv.4': (y1 > 0).permute(0, 3, 1, 2).cpu()})
         ctx.save_for_backward(cols0, y0, arg, z, y1, mean1, invstd1, mean2, invstd2, w0, w4, g1, g2)
         return out
 

@@ -7,6 +7,7 @@ CPU.  Parameter names and shapes are the reference's (nn.Linear: weight [out,in]
 [Cout,Cin,kh,kw]) so checkpoints load unchanged.
 """
 import math
+import weakref
 
 import torch
 import torch.nn as nn
@@ -29,29 +30,68 @@ def _rows2d(t):
 
 
 # =========================================================================================== Linear
+# plane images of weights (lib/_hip.py: PlaneImage), cached per parameter VALUE: key = _hip.version_of(weight), which the
+# fused optimizer bumps through note_raw_update.  'w' = rows are output features (forward), 'wt' = rows are input features
+# (input gradient).  Frozen weights (the detector's fc6/fc7: 411 MB) are split once for the life of the process.
+_weight_images = {}
+
+
+def _weight_image(weight, transposed):
+    key = (id(weight), transposed)
+    ver = _hip.version_of(weight)
+    hit = _weight_images.get(key)
+    if hit is None or hit[0] != ver:
+        if hit is None:
+            weakref.finalize(weight, _weight_images.pop, key, None)      # the image dies with its parameter
+        hit = (ver, _hip.make_planes(_rows2d(weight.detach()), k_contiguous=not transposed))
+        _weight_images[key] = hit
+    return hit[1]
+
+
+def drop_weight_images():
+    _weight_images.clear()
+
+
+_SKINNY_ROWS = 128          # see _hip.gemm_inloop
+
+
 class _LinearFn(torch.autograd.Function):
-    """y = act(x @ W^T + b) on the FP32 MFMA GEMM; ReLU fused into the epilogue."""
+    """y = act(x @ W^T + b): fp32-accurate product on the f16 matrix cores (csrc/pl_gemm.hip), ReLU fused into the
+    epilogue.  Every operand is split into its plane image ONCE per use pattern: the weight images are cached per
+    parameter value, x / gy are imaged where they are consumed."""
 
     @staticmethod
     def forward(ctx, x, weight, bias, relu):
         x2, w2 = _rows2d(x), _rows2d(weight)
-        y = _hip.gemm(x2, w2, False, True, bias=bias, epilogue=EPI_RELU if relu else EPI_NONE)
+        epi = EPI_RELU if relu else EPI_NONE
+        if x2.shape[0] <= _SKINNY_ROWS and weight.requires_grad and w2.numel() >= (1 << 24):
+            y = _hip.gemm_inloop(x2, w2, False, True, bias=bias, epilogue=epi)
+        elif x2.shape[0] == 0:
+            y = x2.new_zeros(0, w2.shape[0])
+        else:
+            y = _hip.gemm_planes(_hip.make_planes(x2, True), _weight_image(weight, False), bias=bias, epilogue=epi)
         ctx.relu = relu
         ctx.has_bias = bias is not None
-        ctx.save_for_backward(x2, w2, y if relu else None)
+        ctx.weight = weight
+        ctx.save_for_backward(x2, y if relu else None)
         return y
 
     @staticmethod
     def backward(ctx, gy):
-        x2, w2, y = ctx.saved_tensors
+        x2, y = ctx.saved_tensors
+        weight = ctx.weight
         gy = _rows2d(gy)
         if ctx.relu:
             gy = gy * (y > 0).to(gy.dtype)
         gx = gw = gb = None
+        if gy.shape[0] == 0:
+            return (x2.new_zeros(x2.shape) if ctx.needs_input_grad[0] else None,
+                    torch.zeros_like(weight) if ctx.needs_input_grad[1] else None,
+                    torch.zeros_like(weight[:, 0]) if (ctx.has_bias and ctx.needs_input_grad[2]) else None, None)
         if ctx.needs_input_grad[0]:
-            gx = _hip.gemm(gy, w2, False, False)              # [M,N] x [N,K]
+            gx = _hip.gemm_planes(_hip.make_planes(gy, True), _weight_image(weight, True))     # [M,N] . (W^T image [K,N])^T
         if ctx.needs_input_grad[1]:
-            gw = _hip.gemm(gy, x2, True, False)               # [M,N]^T x [M,K] -> [N,K]
+            gw = _hip.gemm_planes(_hip.make_planes(gy, False), _hip.make_planes(x2, False))    # gy^T [N,M] . (x^T [K,M])^T
         if ctx.has_bias and ctx.needs_input_grad[2]:
             gb = gy.sum(0)
         return gx, gw, gb, None

@@ -36,6 +36,16 @@ def install():
             return out
         return r
 
+    def make_planes(x, k_contiguous=True):
+        m = x.detach() if k_contiguous else x.detach().t()
+        return _hip.PlaneImage(m.contiguous().clone(), m.shape[0], m.shape[1])      # .buf = the dense [rows, K] operand
+
+    def gemm_planes(a, b, bias=None, epilogue=0, out=None, accumulate=False, splitk=0):
+        return gemm(a.buf, b.buf, False, True, bias=bias, epilogue=epilogue, out=out, accumulate=accumulate)
+
+    def gemm_inloop(a, b, trans_a=False, trans_b=False, bias=None, epilogue=0):
+        return gemm(a, b, trans_a, trans_b, bias=bias, epilogue=epilogue)
+
     def nms(boxes_sorted, thresh):
         keep = native.nms(_np(boxes_sorted), thresh)
         k = torch.zeros(max(boxes_sorted.shape[0], 1), dtype=torch.int32)

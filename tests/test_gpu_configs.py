@@ -143,7 +143,7 @@ def test_cfg2_sgcls_train_step_b6_1536_rows():
     from dataloaders.synthetic import make_blob
     from lib import rng
     from oracle import model as OM
-    from test_gpu_model import grad_close
+    from parity_util import ProductMasks, assert_genuine_kinks, grad_close, oracle_forced
     ds, model, sd_init = build('sgcls', 1234 + 200, 6)
     sd = calibrated(sd_init)
     model.cuda().train()
@@ -152,7 +152,8 @@ def test_cfg2_sgcls_train_step_b6_1536_rows():
     a = blob[0]
     model.sampler_rs = np.random.RandomState(1234 + 200)
     rng.use_host_rng(77)
-    res = model[blob]
+    with ProductMasks(model) as pm:
+        res = model[blob]
     rng.use_host_rng(None)
     assert res.rel_labels.shape[0] == 1536 and res.rm_obj_labels.shape[0] == 120
     loss = F.cross_entropy(res.rm_obj_dists, res.rm_obj_labels) + F.cross_entropy(res.rel_dists, res.rel_labels[:, -1])
@@ -160,8 +161,10 @@ def test_cfg2_sgcls_train_step_b6_1536_rows():
 
     trainable = {n for n, p in model.named_parameters() if p.requires_grad}
     params = {k: v.clone().requires_grad_(k in trainable) for k, v in sd.items()}
-    out = OM.relmodel_forward(params, dict(MODEL_KW, mode='sgcls'), a[0], a[1], 0, a[3], a[4], True, OM.HostRNG(77),
-                              rel_labels=res.rel_labels.cpu())
+    with oracle_forced(pm.force) as taps:      # the product's ReLU / pool decisions: gradients at a true relative bound
+        out = OM.relmodel_forward(params, dict(MODEL_KW, mode='sgcls'), a[0], a[1], 0, a[3], a[4], True, OM.HostRNG(77),
+                                  rel_labels=res.rel_labels.cpu())
+    assert_genuine_kinks(taps)
     np.testing.assert_array_equal(res.obj_preds.cpu().numpy(), out['obj_preds'].numpy())
     np.testing.assert_array_equal(res.rel_labels.cpu().numpy(), out['rel_labels'].numpy())
     report('cfg2 trunk feature map', res.fmap.float().cpu().numpy(), out['fmap'].numpy(), abs_tol=ABS_TOL)

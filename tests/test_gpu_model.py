@@ -18,30 +18,7 @@ CFG = dict(mode='sgcls', hidden_dim=512, pooling_dim=4096, nl_obj=2, nl_edge=2, 
            pass_in_obj_feats_to_edge=False)
 
 
-def grad_close(got, ref, what='', rtol=1e-4, max_flipped_rows=2):
-    """Gradients agree to `rtol` of scale, except that a ReLU (or max-pool) input lying within rounding of its kink
-    can switch ONE unit's upstream gradient on or off between two fp32 evaluation orders: the difference is then
-    confined to that unit's row of the weight gradient (and its bias entry).  Such rows are counted, bounded and
-    printed -- never silently accepted elsewhere."""
-    got, ref = np.asarray(got, dtype=np.float64), np.asarray(ref, dtype=np.float64)
-    scale = max(1.0, float(np.abs(ref).max()))
-    err = np.abs(got - ref).reshape(got.shape[0], -1) if got.ndim else np.abs(got - ref).reshape(1, 1)
-    bad_rows = np.nonzero((err > rtol * scale).any(1))[0]
-    ok_err = float(np.delete(err, bad_rows, axis=0).max()) if len(bad_rows) < err.shape[0] else 0.0
-    print('%-28s max|ref|=%10.4f  max abs err=%.3e  (%.2e of scale)%s' % (
-        what, scale, ok_err, ok_err / scale,
-        '' if not len(bad_rows) else '  + kink-flipped rows %s (max err %.3e)' % (bad_rows.tolist(), err.max())))
-    assert len(bad_rows) <= max_flipped_rows, '%s: %d rows differ by more than %.1e of scale' % (
-        what, len(bad_rows), rtol)
-    assert err.max() <= 5e-2 * scale, what
-
-
-def rel_close(got, ref, rtol=1e-4, what=''):
-    got, ref = np.asarray(got, dtype=np.float64), np.asarray(ref, dtype=np.float64)
-    scale = max(1.0, float(np.abs(ref).max()))
-    err = float(np.abs(got - ref).max())
-    print('%-28s max|ref|=%10.4f  max abs err=%.3e  (%.2e of scale)' % (what, scale, err, err / scale))
-    assert err <= rtol * scale, '%s: max abs err %.3e > %.1e * %.3f' % (what, err, rtol, scale)
+from parity_util import ProductMasks, assert_genuine_kinks, grad_close, oracle_forced, rel_close  # noqa: E402,F401
 
 
 @pytest.fixture(scope='module')
@@ -73,15 +50,20 @@ def test_sgcls_train_step_parity(world):
     cpu_args = blob[0]
     model.sampler_rs = np.random.RandomState(5)
     rng.use_host_rng(2024)
-    res = model[blob]
+    with ProductMasks(model) as pm:
+        res = model[blob]
     rng.use_host_rng(None)
     loss = F.cross_entropy(res.rm_obj_dists, res.rm_obj_labels) + F.cross_entropy(res.rel_dists, res.rel_labels[:, -1])
     loss.backward()
 
     trainable = {n for n, p in model.named_parameters() if p.requires_grad}
     params = {k: v.clone().requires_grad_(k in trainable) for k, v in sd.items()}
-    out = OM.relmodel_forward(params, CFG, cpu_args[0], cpu_args[1], 0, cpu_args[3], cpu_args[4], True,
-                              OM.HostRNG(2024), rel_labels=res.rel_labels.cpu())
+    # the oracle evaluates with the product's ReLU / pool decisions (parity_util: kink accounting), so the gradients
+    # below are compared at 1e-4 of each tensor's OWN largest magnitude with no excused rows
+    with oracle_forced(pm.force) as taps:
+        out = OM.relmodel_forward(params, CFG, cpu_args[0], cpu_args[1], 0, cpu_args[3], cpu_args[4], True,
+                                  OM.HostRNG(2024), rel_labels=res.rel_labels.cpu())
+    assert_genuine_kinks(taps)
     np.testing.assert_array_equal(res.obj_preds.cpu().numpy(), out['obj_preds'].numpy())
     rel_close(res.fmap.float().cpu().numpy(), out['fmap'].numpy(), what='trunk feature map')
     rel_close(res.od_obj_dists.detach().cpu().numpy(), out['od_obj_dists'].numpy(), what='detector logits')
@@ -103,7 +85,7 @@ def test_sgcls_train_step_parity(world):
     assert checked >= 30
     for k in ('context.pos_embed.0.running_mean', 'context.pos_embed.0.running_var',
               'union_boxes.conv.2.running_mean', 'union_boxes.conv.6.running_var'):
-        rel_close(model.state_dict()[k].cpu().numpy(), params[k].detach().numpy(), what=k[-30:])
+        rel_close(model.state_dict()[k].cpu().numpy(), params[k].detach().numpy(), what=k[-30:], own_scale=True)
 
 
 @pytest.mark.parametrize('mode', ['predcls', 'sgcls'])

@@ -115,7 +115,7 @@ def test_sgdet_train_step_parity(det):
     from lib import rng
     from lib.fpn.proposal_assignments.rel_assignments import rel_assignments
     from oracle import model as OM
-    from test_gpu_model import grad_close, rel_close
+    from parity_util import ProductMasks, assert_genuine_kinks, grad_close, oracle_forced, rel_close
     ds, model, sd, make_blob = det
     cfg = dict(mode='sgdet', hidden_dim=256, pooling_dim=4096, nl_obj=2, nl_edge=2, order='confidence', rec_dropout=0.1,
                use_bias=True, use_tanh=False, limit_vision=False, pass_in_obj_feats_to_decoder=False,
@@ -135,7 +135,8 @@ def test_sgdet_train_step_parity(det):
             if m.__class__.__name__ == 'Dropout':
                 m.eval()
         rng.use_host_rng(55)
-        res = model[blob]
+        with ProductMasks(model) as pm:
+            res = model[blob]
         rng.use_host_rng(None)
         n_obj = res.rm_obj_dists.shape[0]
         assert res.rel_labels is not None and res.rel_labels.shape[1] == 4 and int(res.rel_labels[:, 1:3].max()) < n_obj
@@ -157,7 +158,9 @@ def test_sgdet_train_step_parity(det):
                         rm_obj_dists=model.last_detector_obj_dists.cpu(),
                         od_obj_dists=res.od_obj_dists.detach().cpu(), rm_obj_labels=labels_ref, rel_labels=rel_ref,
                         boxes_all=res.boxes_all.detach().cpu())
-        out = OM.relmodel_forward(params, cfg, a[0], a[1], 0, a[3], a[4], True, OM.HostRNG(55), det_override=override)
+        with oracle_forced(pm.force) as taps:
+            out = OM.relmodel_forward(params, cfg, a[0], a[1], 0, a[3], a[4], True, OM.HostRNG(55), det_override=override)
+        assert_genuine_kinks(taps)
         np.testing.assert_array_equal(res.obj_preds.cpu().numpy(), out['obj_preds'].numpy())
         rel_close(res.rm_obj_dists.detach().cpu().numpy(), out['rm_obj_dists'].detach().numpy(), what='sgdet object logits')
         rel_close(res.rel_dists.detach().cpu().numpy(), out['rel_dists'].detach().numpy(), what='sgdet relation logits')
@@ -213,7 +216,7 @@ def test_detector_pretraining_step_parity():
     rois = torch.cat((res.im_inds.float()[:, None].cpu(), res.od_box_priors.detach().cpu()), 1)
     out = OM.detector_train_losses(params, cpu_imgs, rois, res.od_obj_labels.cpu(), res.od_box_targets.cpu(), tal, tan,
                                    OM.HostRNG(31))
-    from test_gpu_model import rel_close, grad_close
+    from parity_util import rel_close, grad_close
     rel_close(res.od_obj_dists.detach().cpu().numpy(), out['scores'].detach().numpy(), what='RoI class logits')
     rel_close(res.od_box_deltas.detach().cpu().numpy(), out['box_deltas'].detach().numpy(), what='RoI box deltas')
     rel_close(res.rpn_scores.detach().cpu().numpy(), out['rpn_scores'].detach().numpy(), what='RPN scores')

@@ -406,3 +406,97 @@ def test_reference_format_checkpoints_restore(small_world, tmp_path, capsys):
         if v.is_floating_point():
             v.sub_(0.5)
     optimistic_restore(model, full)
+
+
+def test_kink_accounting_machinery_on_the_shim(small_world):
+    """tests/parity_util.py (used by the -m gpu gradient tests): the product's ReLU masks are captured by hooks, the
+    oracle evaluates with them, and gradients then agree at a relative bound on every tensor's OWN scale.  On the shim
+    both sides run torch CPU arithmetic, so decisions coincide almost everywhere -- what is checked here is the plumbing:
+    site names, mask shapes, the forced pool routing, and that a deliberately flipped far-from-kink unit is caught."""
+    import lib.get_union_boxes as GUB
+    from lib import rng
+    from oracle import model as OM
+    from parity_util import ProductMasks, assert_genuine_kinks, grad_close, oracle_forced
+    ds, model, make_blob = small_world
+    model.train()
+    model.zero_grad(set_to_none=True)
+    blob = make_blob(ds, [2, 3], is_train=True)
+    sd = _to_oracle_sd(model)
+    trainable = {n for n, p in model.named_parameters() if p.requires_grad}
+    params = {k: v.clone().requires_grad_(k in trainable) for k, v in sd.items()}
+    model.sampler_rs = np.random.RandomState(6)
+    rng.use_host_rng(78)
+    with ProductMasks(model) as pm:
+        res = model[blob]
+    rng.use_host_rng(None)
+    assert GUB.TAPS is None
+    assert {'roi_fmap.1.0', 'roi_fmap_obj.0', 'roi_fmap_obj.3', 'context.pos_embed.1'} <= set(pm.force)
+    assert pm.force['roi_fmap.1.0'].shape == (res.rel_labels.shape[0], 4096)
+    loss = torch.nn.functional.cross_entropy(res.rm_obj_dists, res.rm_obj_labels) + \
+        torch.nn.functional.cross_entropy(res.rel_dists, res.rel_labels[:, -1])
+    loss.backward()
+    args = blob[0]
+    # a forced pool table equal to the oracle's own arg-max (first maximum wins, like mh_bn_pool_fwd) must change nothing
+    with oracle_forced(pm.force) as taps0:
+        OM.relmodel_forward({k: v.clone() for k, v in sd.items()}, CFG, args[0], args[1], 0, args[3], args[4], True,
+                            OM.HostRNG(78), rel_labels=res.rel_labels)
+    force = dict(pm.force)
+    with oracle_forced(force) as taps:
+        out = OM.relmodel_forward(params, CFG, args[0], args[1], 0, args[3], args[4], True, OM.HostRNG(78),
+                                  rel_labels=res.rel_labels)
+    assert_genuine_kinks(taps, max_far=1e-4)
+    assert set(taps0['flips']) == set(taps['flips'])
+    loss_ref = torch.nn.functional.cross_entropy(out['rm_obj_dists'], out['rm_obj_labels']) + \
+        torch.nn.functional.cross_entropy(out['rel_dists'], out['rel_labels'][:, -1])
+    loss_ref.backward()
+    for name, p in model.named_parameters():
+        if p.requires_grad:
+            grad_close(p.grad.numpy(), params[name].grad.numpy(), what='shim grad ' + name[-24:], rtol=2e-3)
+    # a unit flipped far from the kink is refused
+    bad = dict(pm.force)
+    m = bad['roi_fmap.1.0'].clone()
+    pre = out['rel_dists']          # any tensor: find a clearly active unit through the oracle's own mask
+    own = taps['mask']['roi_fmap.1.0']
+    idx = tuple(int(i) for i in torch.nonzero(own)[0])
+    m[idx] = False
+    bad['roi_fmap.1.0'] = m
+    with oracle_forced(bad) as taps_bad:
+        OM.relmodel_forward({k: v.clone() for k, v in sd.items()}, CFG, args[0], args[1], 0, args[3], args[4], True,
+                            OM.HostRNG(78), rel_labels=res.rel_labels)
+    n_bad, far_bad, _ = taps_bad['flips']['roi_fmap.1.0']
+    assert n_bad >= 1
+    if far_bad > 1e-4:
+        with pytest.raises(AssertionError):
+            assert_genuine_kinks(taps_bad, max_far=1e-4)
+    del pre
+
+
+def test_forced_pool_routing_matches_max_pool():
+    """oracle/model.py:_max_pool_3x3s2p1 with a table built from torch's own arg-max reproduces F.max_pool2d and its
+    gradient; a table pointing at a non-maximal candidate is reported with its gap"""
+    import torch.nn.functional as F
+    from oracle import model as OM
+    torch.manual_seed(3)
+    x = torch.randn(2, 5, 8, 8, requires_grad=True)
+    y, idx = F.max_pool2d(x, 3, 2, 1, return_indices=True)
+    N, C, Ho, Wo = y.shape
+    yy, xx = idx // 8, idx % 8
+    yo = torch.arange(Ho).view(1, 1, Ho, 1)
+    xo = torch.arange(Wo).view(1, 1, 1, Wo)
+    arg = ((yy - (2 * yo - 1)) * 3 + (xx - (2 * xo - 1))).permute(0, 2, 3, 1).to(torch.uint8)      # [N,Ho,Wo,C]
+    OM.TAPS = {'force': {'p': arg}}
+    try:
+        x2 = x.detach().clone().requires_grad_(True)
+        y2 = OM._max_pool_3x3s2p1(x2, 'p')
+        assert torch.equal(y2, y) and OM.TAPS['flips']['p'][0] == 0
+        g = torch.randn_like(y)
+        y.backward(g)
+        y2.backward(g)
+        assert torch.equal(x.grad, x2.grad)
+        arg2 = arg.clone()
+        arg2[0, 1, 1, 0] = (int(arg2[0, 1, 1, 0]) + 1) % 9
+        OM.TAPS = {'force': {'p': arg2}}
+        OM._max_pool_3x3s2p1(x.detach(), 'p')
+        assert OM.TAPS['flips']['p'][0] == 1 and OM.TAPS['flips']['p'][1] > 0
+    finally:
+        OM.TAPS = None

@@ -223,6 +223,7 @@ int main(int argc, char **argv)
     if (argc < 2) { printf("usage: pl_check <libmotifs_hip.so> [--quick] [--speed-only]\n"); return 1; }
     const bool quick = argc > 2 && !strcmp(argv[2], "--quick");
     const bool speed_only = argc > 2 && !strcmp(argv[2], "--speed-only");
+    const bool pmc = argc > 2 && !strcmp(argv[2], "--pmc");
     void *h = dlopen(argv[1], RTLD_NOW);
     if (!h) { printf("dlopen: %s\n", dlerror()); return 2; }
     g3 = (gemm_fn)dlsym(h, "mh_gemm_f32"); g2 = (gemm_fn)dlsym(h, "mh_gemm_f32_v2");
@@ -231,6 +232,17 @@ int main(int argc, char **argv)
     gemmpl = (gemmpl_fn)dlsym(h, "mh_gemm_planes"); set_shape = (shape_fn)dlsym(h, "mh_debug_pl_shape"); last_err = (err_fn)dlsym(h, "mh_last_error");
     if (!g3 || !g2 || !ws3 || !ws2 || !wspl || !pbytes || !mkplanes || !gemmpl || !set_shape || !last_err) { printf("missing symbol\n"); return 2; }
     int bad = 0;
+    if (pmc) {      // a few launches of the product kernel on ready images, nothing else: the target of rocprofv3 --pmc
+        const int M = 1536, N = 4096, K = 25088;
+        Dev dA((size_t)M * K * 4), dB((size_t)N * K * 4), dC((size_t)M * N * 4), ia(pbytes(M, K)), ib(pbytes(N, K));
+        fill_dev(dA.f(), (size_t)M * K, 1); fill_dev(dB.f(), (size_t)N * K, 2);
+        mkplanes(dA.f(), 1, M, K, K, ia.p, nullptr);
+        mkplanes(dB.f(), 1, N, K, K, ib.p, nullptr);
+        Dev ws(wspl(M, N, K, 0));
+        for (int i = 0; i < 3; ++i) gemmpl(M, N, K, ia.p, ib.p, dC.f(), N, nullptr, 0, 0, 0, ws.p, ws.n, nullptr);
+        HIP_OK(hipDeviceSynchronize());
+        return 0;
+    }
     if (!speed_only) {
         bad += accuracy_case("NT aligned", 0, 1, 256, 256, 512, 0, 0, 0, true, 0, 0, 0, 0, 1);
         bad += accuracy_case("NN aligned", 0, 0, 256, 384, 512, 0, 0, 0, true, 0, 0, 0, 0, 2);
