@@ -702,3 +702,46 @@ def test_device_recall_matches_the_reference_evaluator(hip, golden):
                 assert rec2[k] == res2[mode + '_recall'][k][0], (c, mode, multi, k)
             np.testing.assert_array_equal(nm2.cpu().numpy(), np.array([len(m) for m in p2g]))
     assert nonzero > 0
+
+
+# ----------------------------------------------------------------------------------------------- reference-kernel goldens
+# tests/golden/cuda_ref.npz = outputs of the reference's OWN .cu files compiled for the CPU (oracle/build_ref_cuda.py):
+# the HIP kernels are compared with the reference's arithmetic directly, not only with our restatement of it
+def test_nms_equals_the_reference_kernel(hip, golden):
+    g = golden('cuda_ref')
+    for i in g['nms_cases']:
+        b, thr = g['nms%d_boxes' % i], float(g['nms%d_thresh' % i])
+        keep, num = hip.nms(dev(b).view(-1, 4), thr)
+        np.testing.assert_array_equal(keep[:int(num.item())].cpu().numpy(), g['nms%d_keep' % i])
+    for j in range(3):
+        keep, num = hip.nms(dev(g['nmsb%d_boxes' % j]), float(g['nmsb%d_thresh' % j]))
+        np.testing.assert_array_equal(keep[:int(num.item())].cpu().numpy(), g['nmsb%d_keep' % j])
+
+
+def test_roi_align_equals_the_reference_kernel(hip, golden):
+    g = golden('cuda_ref')
+    feat, rois = g['roi_feat'], g['roi_rois']
+    B, C = feat.shape[:2]
+    out = hip.roi_align_fwd(dev(feat), dev(rois), 7, 7, 1.0 / 16, nhwc=False)
+    np.testing.assert_array_equal(out.cpu().numpy().view(np.int32), g['roi_out'].view(np.int32))
+    out2 = hip.roi_align_fwd(dev(feat.transpose(0, 2, 3, 1)), dev(rois), 7, 7, 1.0 / 16, nhwc=True)
+    np.testing.assert_array_equal(out2.cpu().numpy().view(np.int32), g['roi_out'].view(np.int32))
+    # backward: the product's gather sums the same terms in a different (fixed) order than the reference's serialised atomics
+    gf = hip.roi_align_bwd(dev(g['roi_grad']), dev(rois), B, C, 37, 37, 1.0 / 16, nhwc=False)
+    scale = float(np.abs(g['roi_gfeat']).max())
+    np.testing.assert_allclose(gf.cpu().numpy(), g['roi_gfeat'], atol=2e-6 * scale)
+
+
+def test_hwlstm_equals_the_reference_kernels(hip, golden):
+    g = golden('cuda_ref')
+    H, nl, _ = [int(v) for v in g['lstm_dims']]
+    lengths = [int(v) for v in g['lstm_lengths']]
+    x, w, bias, drop = dev(g['lstm_x']), dev(g['lstm_w']), dev(g['lstm_bias']), dev(g['lstm_drop'])
+    h, c, gates = hip.hwlstm_fwd(x, lengths, w, bias, drop, H, nl, True)
+    np.testing.assert_allclose(h.cpu().numpy(), g['lstm_h'], atol=2e-5)
+    np.testing.assert_allclose(c.cpu().numpy(), g['lstm_c'], atol=2e-5)
+    xg, wg, bg = hip.hwlstm_bwd(dev(g['lstm_gout']), x, lengths, w, drop, H, nl, h, c, gates)
+    for got, name in ((xg, 'lstm_gx'), (wg, 'lstm_gw'), (bg, 'lstm_gb')):
+        np.testing.assert_allclose(got.cpu().numpy(), g[name], atol=2e-5 * max(1.0, float(np.abs(g[name]).max())))
+    h2, _, _ = hip.hwlstm_fwd(x, lengths, w, bias, torch.ones_like(drop), H, nl, False)
+    np.testing.assert_allclose(h2.cpu().numpy(), g['lstm_h_eval'], atol=2e-5)
