@@ -315,8 +315,15 @@ int mh_debug_lstm_barrier_fault(int enable);
  *   mh_multi_sumsq  : sumsq_out[0] = sum over all chunks of g^2 (device scalar; partial = nchunks floats scratch)
  *   mh_multi_sgd_step: g' = g * min(1, max_norm/(sqrt(sumsq)+1e-6)) (skipped when sumsq == NULL or max_norm <= 0);
  *                      d = g' + wd*p; buf = first_step ? d : momentum*buf + d; p -= lr*buf
+ *                      DEVICE-SIDE GUARD: with clipping on, a step whose sumsq is NaN / inf (gradients poisoned by a
+ *                      timed-out persistent launch, an overflow) is skipped by the kernel itself -- weights and momentum
+ *                      untouched -- and counted in a host-pinned word: the host may be several steps ahead and could not
+ *                      have stopped it.  mh_opt_skipped_steps(): total skipped steps so far (host read, no sync);
+ *                      mh_opt_skipped_clear() resets the counter.
  * ------------------------------------------------------------------------------------------- */
 int mh_opt_chunk_elems(void);
+int mh_opt_skipped_steps(void);
+int mh_opt_skipped_clear(void);
 /* Expand a HOST list of nparams records {p, g, buf, n = elements of the whole parameter, lr} (same 32-byte layout) into the
  * device chunk table chunks[nchunks], nchunks = sum over parameters of ceil(n / mh_opt_chunk_elems()).  The list travels in
  * the kernel arguments (no host->device copy, nothing read from params_host after the call returns). */

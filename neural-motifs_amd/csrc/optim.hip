@@ -72,14 +72,26 @@ __global__ __launch_bounds__(256) void sum_partials_kernel(const float *__restri
     if (threadIdx.x == 0) out[0] = (float)red[0];
 }
 
+// Device-side guard: a step whose squared gradient norm is not finite (NaN-poisoned outputs of a timed-out persistent
+// LSTM launch, an overflow) must not touch the weights -- the host runs several steps ahead and could not stop it in time
+// (ADVICE r02).  Such a step is SKIPPED here: weights and momentum stay as they are (a skipped first step zeroes the
+// momentum buffer, which is what the next step then builds on), and one lane counts the skip in a host-pinned word that
+// mh_opt_skipped_steps() reads without synchronising.
 __global__ __launch_bounds__(256) void multi_sgd_kernel(const OptChunk *__restrict__ chunks,
                                                         const float *__restrict__ sumsq, float max_norm, float momentum,
-                                                        float weight_decay, int first_step)
+                                                        float weight_decay, int first_step, unsigned *skip_word)
 {
     const OptChunk c = chunks[blockIdx.x];
     float coef = 1.f;
     if (sumsq != nullptr && max_norm > 0.f) {
-        const float total_norm = sqrtf(sumsq[0]);
+        const float ss = sumsq[0];
+        if (!(ss >= 0.f && ss < INFINITY)) {          // NaN or inf: wave-uniform
+            if (blockIdx.x == 0 && threadIdx.x == 0 && skip_word) atomicAdd(skip_word, 1u);
+            if (first_step)
+                for (int i = threadIdx.x; i < c.n; i += 256) c.buf[i] = 0.f;
+            return;
+        }
+        const float total_norm = sqrtf(ss);
         const float cc = max_norm / (total_norm + 1e-6f);
         coef = cc < 1.f ? cc : 1.f;
     }
@@ -145,9 +157,45 @@ __global__ __launch_bounds__(256) void expand_chunks_kernel(const OptParamList L
 
 using namespace mh;
 
+// one host-pinned, device-mapped counter per device (like the fault words of lstm.hip)
+constexpr int kMaxSkipDevices = 64;
+static unsigned *g_skip_words = nullptr;
+static unsigned *skip_word_for_current_device()
+{
+    if (!g_skip_words) {
+        void *p = nullptr;
+        if (hipHostMalloc(&p, kMaxSkipDevices * sizeof(unsigned), hipHostMallocMapped | hipHostMallocPortable | hipHostMallocCoherent) != hipSuccess)
+            return nullptr;
+        for (int i = 0; i < kMaxSkipDevices; ++i) reinterpret_cast<unsigned *>(p)[i] = 0u;
+        g_skip_words = reinterpret_cast<unsigned *>(p);
+    }
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxSkipDevices) return nullptr;
+    void *dp = nullptr;
+    if (hipHostGetDevicePointer(&dp, &g_skip_words[dev], 0) != hipSuccess) return nullptr;
+    return reinterpret_cast<unsigned *>(dp);
+}
+
 extern "C" {
 
 int mh_opt_chunk_elems(void) { return kChunkElems; }
+
+int mh_opt_skipped_steps(void)
+{
+    const unsigned *w = g_skip_words;
+    if (!w) return 0;
+    long long n = 0;
+    for (int i = 0; i < kMaxSkipDevices; ++i) n += __atomic_load_n(&w[i], __ATOMIC_RELAXED);
+    return (int)std::min<long long>(n, 0x7fffffff);
+}
+
+int mh_opt_skipped_clear(void)
+{
+    unsigned *w = g_skip_words;
+    if (w)
+        for (int i = 0; i < kMaxSkipDevices; ++i) __atomic_store_n(&w[i], 0u, __ATOMIC_RELAXED);
+    return MH_OK;
+}
 
 int mh_opt_build_chunks(const void *params_host, int nparams, void *chunks, int nchunks, void *stream)
 {
@@ -197,8 +245,10 @@ int mh_multi_sgd_step(const void *chunks, int nchunks, const float *sumsq, float
     MH_REQUIRE(nchunks >= 0);
     if (nchunks == 0) return MH_OK;
     MH_REQUIRE(chunks);
+    unsigned *skip = skip_word_for_current_device();
+    if (sumsq && !skip) { set_last_error("skip counter (hipHostMalloc / hipGetDevice)", hipErrorOutOfMemory); return (int)hipErrorOutOfMemory; }
     hipLaunchKernelGGL(multi_sgd_kernel, dim3(nchunks), dim3(256), 0, as_stream(stream),
-                       reinterpret_cast<const OptChunk *>(chunks), sumsq, max_norm, momentum, weight_decay, first_step);
+                       reinterpret_cast<const OptChunk *>(chunks), sumsq, max_norm, momentum, weight_decay, first_step, skip);
     return check_launch("multi_sgd_kernel");
 }
 

@@ -33,7 +33,7 @@ SYMBOLS = (
     'mh_hwcell_seq_ws_bytes', 'mh_hwcell_seq_fwd', 'mh_hwcell_seq_bwd',
     'mh_decoder_greedy_ws_bytes', 'mh_decoder_greedy', 'mh_decoder_nms_commit',
     'mh_fault_pending', 'mh_fault_clear', 'mh_debug_lstm_barrier_fault',
-    'mh_opt_chunk_elems', 'mh_opt_build_chunks', 'mh_multi_sumsq', 'mh_multi_sgd_step',
+    'mh_opt_chunk_elems', 'mh_opt_skipped_steps', 'mh_opt_skipped_clear', 'mh_opt_build_chunks', 'mh_multi_sumsq', 'mh_multi_sgd_step',
     'mh_bn_ws_bytes', 'mh_bn_stats', 'mh_bn_pool_fwd', 'mh_bn_residual_nchw', 'mh_bn_apply_nhwc', 'mh_nchw_to_nhwc_small', 'mh_bn_bwd',
 )
 
@@ -80,6 +80,15 @@ def check_faults():
     if n:
         raise HipKernelError('a persistent LSTM launch timed out in its grid barrier on %d device(s): the results of '
                              'this step are invalid (outputs were NaN-poisoned); call lib().mh_fault_clear() to re-arm' % n)
+
+
+def check_skipped_steps():
+    """Raise if the fused optimizer skipped a step on the device because the gradient norm was not finite (the kernel
+    leaves weights and momentum untouched in that case: csrc/optim.hip).  Host read of a pinned counter, no sync."""
+    n = lib().mh_opt_skipped_steps()
+    if n:
+        raise HipKernelError('%d optimizer step(s) were skipped on the device: the global gradient norm was NaN / inf '
+                             '(weights and momentum were left untouched); lib().mh_opt_skipped_clear() re-arms' % n)
 
 
 # Parameters updated through raw pointers (mh_multi_sgd_step) never bump torch's `_version`; anything that caches a

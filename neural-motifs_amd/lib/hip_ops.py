@@ -17,6 +17,25 @@ from lib.rng import dropout as rng_dropout
 
 EPI_NONE, EPI_RELU, EPI_RELU6 = 0, 1, 2
 
+# test hook (tests/parity_util.py): a dict here receives the activation masks / pool arg-max tables of the trainable trunk
+# and RPN head during the next forward, in the oracle's naming, so that the parity tests can hand the oracle the product's
+# own kink decisions (oracle/model.py: TAPS).  None in production.
+TAPS = None
+
+
+def _tap_act(name, y_nhwc, epilogue):
+    if TAPS is not None:
+        m = (y_nhwc > 0) if epilogue == EPI_RELU else ((y_nhwc > 0) & (y_nhwc < 6))
+        TAPS[name] = m.permute(0, 3, 1, 2).cpu()
+
+
+def _tap_pool2x2(name, x_nhwc):
+    """arg-max table [B,H/2,W/2,C] (dy * 2 + dx, first maximum in scan order = where mh_maxpool2x2_bwd_nhwc routes)"""
+    if TAPS is not None:
+        B, H, W, C = x_nhwc.shape
+        w = x_nhwc[:, :H // 2 * 2, :W // 2 * 2].reshape(B, H // 2, 2, W // 2, 2, C).permute(0, 1, 3, 5, 2, 4)
+        TAPS[name] = w.reshape(B, H // 2, W // 2, C, 4).argmax(-1).to(torch.uint8).cpu()
+
 
 def _c(t):
     return t if t.is_contiguous() else t.contiguous()
@@ -257,13 +276,17 @@ class VGG16Features(nn.Sequential):
         pool backward, activation masks): the trunk as the detector pre-training step needs it"""
         mods = list(self.children())
         y = _ConvFirstFn.apply(x, mods[0].weight, mods[0].bias)
-        i = 2
+        _tap_act('detector.features.0', y, EPI_RELU)
+        i, last_conv = 2, 0
         while i < len(mods):
             m = mods[i]
             if isinstance(m, Conv3x3):
                 y = _Conv3x3Fn.apply(y, m.weight, m.bias, EPI_RELU)
+                _tap_act('detector.features.%d' % i, y, EPI_RELU)
+                last_conv = i
                 i += 2
             elif isinstance(m, MaxPool2x2):
+                _tap_pool2x2('detector.features.pool%d' % last_conv, y)
                 y = _MaxPool2x2Fn.apply(y)
                 i += 1
             else:

@@ -14,6 +14,7 @@ from torch.nn import functional as F
 
 from config import ANCHOR_SIZE, ANCHOR_RATIOS, ANCHOR_SCALES
 from lib import _hip
+from lib import hip_ops
 from lib.fpn.box_utils import bbox_preds, center_size, bbox_overlaps
 from lib.fpn.generate_anchors import generate_anchors
 from lib.fpn.nms.functions.nms import apply_nms, nms_mask_per_class
@@ -367,6 +368,7 @@ class RPNHead(nn.Module):
         if trainable:
             x = fmap.permute(0, 2, 3, 1).contiguous()
             x = _Conv3x3Fn.apply(x, self.conv[0].weight, self.conv[0].bias, EPI_RELU6)
+            hip_ops._tap_act('detector.rpn_head.conv.0', x, EPI_RELU6)         # test hook, no-op in production
             x = self.conv[2].forward_nhwc(x)
         else:
             with torch.no_grad():

@@ -85,9 +85,12 @@ class FusedClipSGD(torch.optim.Optimizer):
 
     @torch.no_grad()
     def step(self, max_norm=0.0, closure=None):
-        # a persistent LSTM launch of an EARLIER step that timed out (device-side fault word, lib/_hip.check_faults):
-        # refuse to apply gradients on top of it.  Host read, no synchronisation.
+        # Host reads, no synchronisation: they see launches that have COMPLETED, i.e. steps the host enqueued up to
+        # max_ahead steps ago.  What protects the weights of the steps in between is on the device: a timed-out
+        # persistent launch NaN-poisons its outputs, the gradients and their norm become NaN, and multi_sgd_kernel
+        # skips the update and counts it (csrc/optim.hip).  Here the run is stopped as soon as either is visible.
         _hip.check_faults()
+        _hip.check_skipped_steps()
         n = self._build_table()
         if n == 0:
             return None

@@ -124,24 +124,42 @@ def _loss_frame(steps):
     return pd.DataFrame(torch.stack(steps, 1).cpu().numpy(), index=LOSS_KEYS)
 
 
+def _device_health():
+    """after a synchronisation point: raise if a persistent launch timed out or the optimizer skipped a step on the device
+    (lib/_hip.py: check_faults / check_skipped_steps) -- nothing derived from such a run may be saved"""
+    from lib import _hip
+    if torch.cuda.is_available():
+        _hip.check_faults()
+        _hip.check_skipped_steps()
+
+
 def train_epoch(epoch_num):
     detector.train()
     if hasattr(getattr(train_loader, 'sampler', None), 'set_epoch'):
         train_loader.sampler.set_epoch(epoch_num)        # reshuffle every epoch (reference: DataLoader(shuffle=True))
-    tr, start = [], time.time()
+    # losses of the steps since the last print stay on the device (no per-step sync); every print interval they move to the
+    # host in ONE copy and the device tensors are dropped (an epoch-long list of 512-byte blocks fragments the allocator)
+    pending, frames, start = [], [], time.time()
     for b, batch in enumerate(train_loader):
         if conf.max_iters and b >= conf.max_iters:
             break
-        tr.append(train_batch(batch, verbose=b % (conf.print_interval * 10) == 0))
-        if b % conf.print_interval == 0 and b >= conf.print_interval and rank == 0:
-            mn = _loss_frame(tr[-conf.print_interval:]).mean(1)
-            tpb = (time.time() - start) / conf.print_interval
-            print("\ne{:2d}b{:5d}/{:5d} {:.3f}s/batch, {:.1f}m/epoch".format(epoch_num, b, len(train_loader), tpb,
-                                                                             len(train_loader) * tpb / 60))
-            print(mn)
-            print('-----------', flush=True)
+        pending.append(train_batch(batch, verbose=b % (conf.print_interval * 10) == 0))
+        if b % conf.print_interval == 0 and b >= conf.print_interval:
+            frames.append(_loss_frame(pending))
+            pending = []
+            _device_health()                               # the copy above synchronised: faults of those steps are visible
+            if rank == 0:
+                mn = frames[-1].iloc[:, -conf.print_interval:].mean(1)
+                tpb = (time.time() - start) / conf.print_interval
+                print("\ne{:2d}b{:5d}/{:5d} {:.3f}s/batch, {:.1f}m/epoch".format(epoch_num, b, len(train_loader), tpb,
+                                                                                 len(train_loader) * tpb / 60))
+                print(mn)
+                print('-----------', flush=True)
             start = time.time()
-    return _loss_frame(tr)
+    if pending:
+        frames.append(_loss_frame(pending))
+    _device_health()
+    return pd.concat(frames, axis=1, ignore_index=True)
 
 
 def val_batch(batch_num, b, evaluator):
@@ -168,6 +186,7 @@ def val_epoch():
         torch.distributed.all_gather_object(gathered, recalls)
         for k in recalls:
             recalls[k] = [x for g in gathered for x in g[k]]
+    _device_health()
     if rank == 0:
         evaluator[conf.mode].print_stats()
     return float(np.mean(recalls[100])) if len(recalls[100]) else 0.0

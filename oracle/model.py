@@ -79,6 +79,40 @@ def _relu(x, name):
     return x * forced.to(x.dtype)
 
 
+def _relu6(x, name):
+    """F.relu6 whose BACKWARD mask (0 < x < 6) can be forced; the forward value is the clamp either way"""
+    if TAPS is None:
+        return F.relu6(x)
+    forced = TAPS.get('force', {}).get(name)
+    own = (x > 0) & (x < 6)
+    if forced is None:
+        return F.relu6(x)
+    forced = forced.reshape(x.shape)
+    diff = own != forced
+    n = int(diff.sum())
+    xd = x.detach()
+    far = float(torch.minimum(xd.abs(), (xd - 6).abs())[diff].max() / xd.abs().max()) if n else 0.0
+    TAPS.setdefault('flips', {})[name] = (n, far, int(x.numel()))
+    lin = x * forced.to(x.dtype)
+    return lin + (F.relu6(xd) - lin.detach())
+
+
+def _max_pool_2x2(x, name):
+    """F.max_pool2d(x, 2, 2) on NCHW; a forced table [N,Ho,Wo,C] (dy * 2 + dx) decides the routing"""
+    forced = None if TAPS is None else TAPS.get('force', {}).get(name)
+    if forced is None:
+        return F.max_pool2d(x, 2, 2)
+    N, C, H, W = x.shape
+    Ho, Wo = H // 2, W // 2
+    arg = forced.reshape(N, Ho, Wo, C).permute(0, 3, 1, 2).long()
+    yy = 2 * torch.arange(Ho).view(1, 1, Ho, 1) + arg // 2
+    xx = 2 * torch.arange(Wo).view(1, 1, 1, Wo) + arg % 2
+    out = x.flatten(2).gather(2, (yy * W + xx).flatten(2)).view(N, C, Ho, Wo)
+    gap = (F.max_pool2d(x.detach(), 2, 2) - out.detach()).abs()
+    TAPS.setdefault('flips', {})[name] = (int((gap > 0).sum()), float(gap.max() / x.detach().abs().max()), int(out.numel()))
+    return out
+
+
 def _max_pool_3x3s2p1(x, name):
     """F.max_pool2d(x, 3, 2, 1) on NCHW; with a forced arg-max table [N,Ho,Wo,C] (values ky*3+kx, the product's
     mh_bn_pool_fwd output) the routing follows the table instead of the oracle's own maxima"""
@@ -101,9 +135,9 @@ def _max_pool_3x3s2p1(x, name):
 
 def vgg_features(sd, x, prefix='detector.features.'):
     for idx in VGG_CONVS:
-        x = F.relu(F.conv2d(x, sd[prefix + '%d.weight' % idx], sd[prefix + '%d.bias' % idx], padding=1))
+        x = _relu(F.conv2d(x, sd[prefix + '%d.weight' % idx], sd[prefix + '%d.bias' % idx], padding=1), prefix + '%d' % idx)
         if idx in VGG_POOLS_AFTER:
-            x = F.max_pool2d(x, 2, 2)
+            x = _max_pool_2x2(x, prefix + 'pool%d' % idx)
     return x
 
 
@@ -192,7 +226,7 @@ def vgg_classifier(sd, x, prefix, training, rng, use_dropout=True, use_relu=True
 def rpn_head(sd, fmap, prefix='detector.rpn_head.'):
     """RPNHead.forward (object_detector.py:521-531) -> [B,h,w,A,6]"""
     x = F.conv2d(fmap, sd[prefix + 'conv.0.weight'], sd[prefix + 'conv.0.bias'], padding=1)
-    x = F.relu6(x)
+    x = _relu6(x, prefix + 'conv.0')
     x = F.conv2d(x, sd[prefix + 'conv.2.weight'], sd[prefix + 'conv.2.bias'])
     b, nc, h, w = x.shape
     x = x.view(b, nc, -1).transpose(1, 2).contiguous().view(b, h, w, nc)

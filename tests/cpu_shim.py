@@ -207,6 +207,17 @@ def install():
         def mh_fault_pending():
             return 0
 
+        skipped = [0]
+
+        @staticmethod
+        def mh_opt_skipped_steps():
+            return ShimLib.skipped[0]
+
+        @staticmethod
+        def mh_opt_skipped_clear():
+            ShimLib.skipped[0] = 0
+            return 0
+
         @staticmethod
         def mh_opt_build_chunks(params, nparams, chunks, nchunks, stream):
             prm = _table(params, _val(nparams))
@@ -233,7 +244,14 @@ def install():
             max_norm, momentum, wd, first = float(_val(max_norm)), float(_val(momentum)), float(_val(wd)), int(_val(first))
             scale = 1.0
             if _val(sumsq) and max_norm > 0:
-                scale = min(1.0, max_norm / (float(np.sqrt(_arr(_val(sumsq), 1)[0])) + 1e-6))
+                ss = float(_arr(_val(sumsq), 1)[0])
+                if not np.isfinite(ss):                  # the kernel's device-side guard: skip, count, zero a first-step buffer
+                    ShimLib.skipped[0] += 1
+                    if first:
+                        for r in _table(tptr, _val(n)):
+                            _arr(r['buf'], r['n'])[:] = 0
+                    return 0
+                scale = min(1.0, max_norm / (float(np.sqrt(ss)) + 1e-6))
             for r in _table(tptr, _val(n)):
                 p, g, buf = _arr(r['p'], r['n']), _arr(r['g'], r['n']), _arr(r['buf'], r['n'])
                 d = g * np.float32(scale) + np.float32(wd) * p

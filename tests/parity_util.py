@@ -57,8 +57,9 @@ class ProductMasks(object):
     reports through lib.get_union_boxes.TAPS) during the forward passes run inside it.  .force = {site name: CPU tensor}
     in the oracle's naming (state-dict prefix of the layer in front of the ReLU)."""
 
-    def __init__(self, model):
+    def __init__(self, model, extra_sites=None):
         self.model = model
+        self.extra_sites = dict(extra_sites or {})        # {oracle site name: module whose OUTPUT is the activation}
         self.force = {}
         self._handles = []
 
@@ -71,7 +72,7 @@ class ProductMasks(object):
         import lib.get_union_boxes as GUB
         m = self.model
         sites = []
-        if hasattr(m, 'roi_fmap') and not isinstance(m.roi_fmap[1], type(None)):
+        if hasattr(m, 'roi_fmap') and hasattr(m, 'union_boxes'):          # RelModel: Sequential(UnionBoxesAndFeats, FCStack)
             try:
                 sites.append(('roi_fmap.1.0', m.roi_fmap[1][0]))
             except (TypeError, IndexError):
@@ -80,18 +81,23 @@ class ProductMasks(object):
             sites += [('roi_fmap_obj.0', m.roi_fmap_obj[0]), ('roi_fmap_obj.3', m.roi_fmap_obj[3])]
         if hasattr(m, 'context') and hasattr(m.context, 'pos_embed'):
             sites.append(('context.pos_embed.1', m.context.pos_embed[2]))
+        sites += list(self.extra_sites.items())
         for name, mod in sites:
             self._handles.append(mod.register_forward_hook(self._hook(name)))
-        self._gub = GUB
-        self._tower = {}
+        import lib.hip_ops as HO
+        self._gub, self._ho = GUB, HO
+        self._tower, self._trunk = {}, {}
         GUB.TAPS = self._tower
+        HO.TAPS = self._trunk                             # trainable trunk / RPN head (detector pre-training)
         return self
 
     def __exit__(self, *exc):
         for h in self._handles:
             h.remove()
         self._gub.TAPS = None
+        self._ho.TAPS = None
         self.force.update(self._tower)
+        self.force.update(self._trunk)
         return False
 
 

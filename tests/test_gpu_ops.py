@@ -745,3 +745,37 @@ def test_hwlstm_equals_the_reference_kernels(hip, golden):
         np.testing.assert_allclose(got.cpu().numpy(), g[name], atol=2e-5 * max(1.0, float(np.abs(g[name]).max())))
     h2, _, _ = hip.hwlstm_fwd(x, lengths, w, bias, torch.ones_like(drop), H, nl, False)
     np.testing.assert_allclose(h2.cpu().numpy(), g['lstm_h_eval'], atol=2e-5)
+
+
+def test_fused_sgd_skips_a_step_with_a_non_finite_gradient_norm(hip):
+    """csrc/optim.hip: the clip + SGD kernel must not write weights when the gradient norm is NaN / inf (gradients
+    poisoned by a timed-out persistent launch) -- the host runs steps ahead and cannot stop it.  The skip is counted in a
+    host-pinned word, FusedClipSGD.step raises on the NEXT call, weights and momentum are untouched, and after the counter
+    is cleared training continues from the untouched state (a skipped FIRST step leaves zeroed momentum buffers)."""
+    from lib.optim import FusedClipSGD
+    L = hip.lib()
+    L.mh_opt_skipped_clear()
+    torch.manual_seed(0)
+    p = [torch.nn.Parameter(torch.randn(300, 70, device='cuda')), torch.nn.Parameter(torch.randn(1000, device='cuda'))]
+    opt = FusedClipSGD(p, lr=0.1, momentum=0.9, weight_decay=1e-4)
+    before = [q.detach().clone() for q in p]
+    for q in p:
+        q.grad = torch.randn_like(q)
+    p[0].grad[5, 5] = float('nan')
+    opt.step(max_norm=5.0)                      # first step, poisoned: skipped on the device
+    torch.cuda.synchronize()
+    assert L.mh_opt_skipped_steps() == 1
+    for q, b in zip(p, before):
+        assert torch.equal(q.detach(), b)
+    with pytest.raises(hip.HipKernelError, match='skipped on the device'):
+        opt.step(max_norm=5.0)
+    L.mh_opt_skipped_clear()
+    for q in p:
+        q.grad = torch.randn_like(q)
+    ref = [b - 0.1 * (g * min(1.0, 5.0 / (float(torch.sqrt(sum((x.grad ** 2).sum() for x in p))) + 1e-6)) + 1e-4 * b)
+           for b, g in zip(before, [q.grad for q in p])]
+    opt.step(max_norm=5.0)                      # momentum buffers were zeroed by the skipped first step: buf = 0.9 * 0 + d
+    torch.cuda.synchronize()
+    assert L.mh_opt_skipped_steps() == 0
+    for q, r in zip(p, ref):
+        np.testing.assert_allclose(q.detach().cpu().numpy(), r.cpu().numpy(), atol=1e-6)

@@ -204,19 +204,24 @@ def test_detector_pretraining_step_parity():
     blob = make_blob(ds, [0, 1], is_train=True, mode='det')
     args = blob[0]                                            # CPU copies before scatter
     cpu_imgs, tal, tan = args[0].clone(), blob.train_anchor_labels.clone(), blob.train_anchors.clone()
+    from parity_util import ProductMasks, assert_genuine_kinks, grad_close, oracle_forced, rel_close
     det.sampler_rs = np.random.RandomState(9)
     rng.use_host_rng(31)
-    res = det[blob]
+    # the product's ReLU / ReLU6 masks and pool routing (13 trunk convs, 4 pools, RPN conv, fc6 / fc7) go to the oracle
+    with ProductMasks(det, extra_sites={'detector.roi_fmap.0': det.roi_fmap[0], 'detector.roi_fmap.3': det.roi_fmap[3]}) as pm:
+        res = det[blob]
     rng.use_host_rng(None)
+    assert len(pm.force) == 13 + 4 + 1 + 2, sorted(pm.force)
     losses = detector_losses(res, blob.train_anchor_labels, blob.train_anchors)
     losses['total'].backward()
     assert res.od_obj_labels.shape[0] <= 2 * 256 and int((res.od_obj_labels > 0).sum()) >= 1
 
     params = {k: v.clone().requires_grad_(v.dtype.is_floating_point and 'anchors' not in k) for k, v in sd_cpu.items()}
     rois = torch.cat((res.im_inds.float()[:, None].cpu(), res.od_box_priors.detach().cpu()), 1)
-    out = OM.detector_train_losses(params, cpu_imgs, rois, res.od_obj_labels.cpu(), res.od_box_targets.cpu(), tal, tan,
-                                   OM.HostRNG(31))
-    from parity_util import rel_close, grad_close
+    with oracle_forced(pm.force) as taps:
+        out = OM.detector_train_losses(params, cpu_imgs, rois, res.od_obj_labels.cpu(), res.od_box_targets.cpu(), tal, tan,
+                                       OM.HostRNG(31))
+    assert_genuine_kinks(taps)
     rel_close(res.od_obj_dists.detach().cpu().numpy(), out['scores'].detach().numpy(), what='RoI class logits')
     rel_close(res.od_box_deltas.detach().cpu().numpy(), out['box_deltas'].detach().numpy(), what='RoI box deltas')
     rel_close(res.rpn_scores.detach().cpu().numpy(), out['rpn_scores'].detach().numpy(), what='RPN scores')
@@ -228,6 +233,6 @@ def test_detector_pretraining_step_parity():
     for name, p in det.named_parameters():
         ref = params['detector.' + name].grad
         assert p.grad is not None and ref is not None, name
-        grad_close(p.grad.cpu().numpy(), ref.numpy(), what='grad ' + name[-26:], max_flipped_rows=3)
+        grad_close(p.grad.cpu().numpy(), ref.numpy(), what='grad ' + name[-26:])
         checked += 1
     assert checked == 26 + 4 + 4 + 4            # 13 trunk convs, fc6/fc7, score/bbox heads, RPN head (weights + biases)
