@@ -153,6 +153,31 @@ int mh_gemm_f32_v2(int transA, int transB, int M, int N, int K, const float *A, 
                    int accumulate, int splitk, void *workspace, size_t ws_bytes, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * The trunk's 3x3 convolutions on the plane engine (round 3; csrc/pl_conv.hip).  Replaces cuDNN for
+ * vgg16.features (lib/object_detector.py:110-118, :623-633) on the frozen-trunk path of models/train_rels.py.
+ *   activation image  cells [C/16][B*H*W][64 B] (h1 | h2 of x * 2^e_b, e_b from the largest |x| of image b), followed
+ *                     (256-byte aligned) by maxbits[B]; written by mh_act_planes from an fp32 NHWC tensor and the
+ *                     per-image maxima its producer reported, optionally through the 2x2/2 max-pool (pool = 1).
+ *   packed weights    cells [tap][Cin/16][Cout][64 B] + maxbits[Cout] (mh_plconv_pack_weight; flip_transpose = the
+ *                     input-gradient conv's weights, as for mh_conv3x3_pack_weight).
+ *   mh_plconv3x3      out [B,H,W,Cout] fp32 = epi(conv3x3(image, packed) + bias); out_maxbits[B] (may be NULL; must be
+ *                     ZERO on entry) receives the largest |out| per image.  Workspace: mh_plconv3x3_ws_bytes (split-K
+ *                     partial sums of the tile schedule).
+ *   mh_conv_first_nchw_max = mh_conv_first_nchw that also reports those maxima (conv1_1 feeds the first image).
+ * mh_debug_plconv_shape: A/B hook (-1 auto, 0 256x128, 1 128x128, 2 256x64 block tiles). */
+size_t mh_act_planes_bytes(int B, int H, int W, int C);
+int mh_act_planes(const float *x_nhwc, const unsigned *maxbits, int B, int H, int W, int C, int pool, void *image,
+                  void *stream);
+size_t mh_plconv_packed_bytes(int Cout, int Cin);
+int mh_plconv_pack_weight(const float *w, int Cout, int Cin, int flip_transpose, void *packed, void *stream);
+size_t mh_plconv3x3_ws_bytes(int B, int H, int W, int Cin, int Cout);
+int mh_plconv3x3(const void *in_image, int B, int H, int W, int Cin, const void *packed, int Cout, const float *bias,
+                 int epilogue, float *out, unsigned *out_maxbits, void *workspace, size_t ws_bytes, void *stream);
+int mh_conv_first_nchw_max(const float *in_nchw, int B, int Cin, int H, int W, const float *w, int Cout,
+                           const float *bias, int epilogue, float *out_nhwc, unsigned *maxbits, void *stream);
+void mh_debug_plconv_shape(int shape);
+
+/* ---------------------------------------------------------------------------------------------
  * Convolution stack, NHWC internal layout (cuDNN replacement; lib/object_detector.py:110-118,
  * :503-508, lib/get_union_boxes.py:31-39).
  *   mh_conv3x3_nhwc: 3x3, stride 1, pad 1 implicit GEMM on MFMA, fused bias + ReLU/ReLU6.

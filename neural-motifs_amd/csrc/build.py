@@ -15,7 +15,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 SO = os.path.join(HERE, 'libmotifs_hip.so')
 ARCH = 'gfx950'
 EXACT = ('exact_ops.hip',)
-SOURCES = ('exact_ops.hip', 'gemm.hip', 'pl_gemm.hip', 'conv.hip', 'lstm.hip', 'optim.hip', 'tower.hip')
+SOURCES = ('exact_ops.hip', 'gemm.hip', 'pl_gemm.hip', 'pl_conv.hip', 'conv.hip', 'lstm.hip', 'optim.hip', 'tower.hip')
 HEADERS = ('common.h', 'mfma_tile.h', 'pl_tile.h', os.path.join('..', '..', 'include', 'motifs_hip.h'))
 HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
 

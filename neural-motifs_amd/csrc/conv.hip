@@ -14,6 +14,7 @@
 
 #include <type_traits>
 #include "mfma_tile.h"
+#include "pl_tile.h"     // wave_atomic_max (per-image output maxima for the plane engine, pl_conv.hip)
 
 #ifndef MH_CONV_TAP_MAJOR
 #define MH_CONV_TAP_MAJOR 0   /* 1: the K loop walks tap-major (all channels of tap 0, then tap 1, ...): A/B comparisons only */
@@ -490,7 +491,7 @@ constexpr int kStemCo = 16;
 __global__ __launch_bounds__(256) void conv_first_kernel(const float *__restrict__ in, int B, int Cin, int H, int W,
                                                          const float *__restrict__ w, int Cout,
                                                          const float *__restrict__ bias, int epilogue,
-                                                         float *__restrict__ out)
+                                                         float *__restrict__ out, unsigned *__restrict__ maxbits)
 {
     extern __shared__ __attribute__((aligned(16))) float wl[];  // [9*Cin][Cout] + bias[Cout]
     const int K = 9 * Cin;
@@ -503,6 +504,8 @@ __global__ __launch_bounds__(256) void conv_first_kernel(const float *__restrict
     __syncthreads();
     const int groups = Cout / kStemCo;
     const long long total = (long long)B * H * W * groups;
+    int cur_b = -1;            // per-image largest |output| (maxbits != nullptr): running maximum while the image is unchanged
+    unsigned vmax = 0;
     for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total;
          idx += (long long)blockDim.x * gridDim.x) {
         const int grp = idx % groups;
@@ -510,6 +513,11 @@ __global__ __launch_bounds__(256) void conv_first_kernel(const float *__restrict
         const int x = pix % W;
         const int y = (pix / W) % H;
         const int b = pix / ((long long)W * H);
+        if (maxbits && b != cur_b) {
+            if (cur_b >= 0 && vmax) atomicMax(maxbits + cur_b, vmax);
+            cur_b = b;
+            vmax = 0;
+        }
         float acc[kStemCo];
 #pragma unroll
         for (int j = 0; j < kStemCo; ++j) acc[j] = wl[K * Cout + grp * kStemCo + j];
@@ -531,8 +539,11 @@ __global__ __launch_bounds__(256) void conv_first_kernel(const float *__restrict
             float4 v = make_float4(conv_epi(acc[j], epilogue), conv_epi(acc[j + 1], epilogue),
                                    conv_epi(acc[j + 2], epilogue), conv_epi(acc[j + 3], epilogue));
             *reinterpret_cast<float4 *>(o + j) = v;
+            vmax = max(max(vmax, __float_as_uint(v.x) & 0x7fffffffu), max(__float_as_uint(v.y) & 0x7fffffffu,
+                       max(__float_as_uint(v.z) & 0x7fffffffu, __float_as_uint(v.w) & 0x7fffffffu)));
         }
     }
+    if (maxbits) pl::wave_atomic_max(maxbits, cur_b < 0 ? 0 : cur_b, cur_b < 0 ? 0u : vmax);
 }
 
 // 2x2 stride-2 max pool, NHWC, float4 over channels (C % 4 == 0)
@@ -955,8 +966,17 @@ int mh_conv3x3_wgrad(const float *x, const float *gy, int B, int H, int W, int C
 #endif
 }
 
+int mh_conv_first_nchw_max(const float *in_nchw, int B, int Cin, int H, int W, const float *w, int Cout, const float *bias,
+                           int epilogue, float *out_nhwc, unsigned *maxbits, void *stream);
 int mh_conv_first_nchw(const float *in_nchw, int B, int Cin, int H, int W, const float *w, int Cout,
                        const float *bias, int epilogue, float *out_nhwc, void *stream)
+{
+    return mh_conv_first_nchw_max(in_nchw, B, Cin, H, W, w, Cout, bias, epilogue, out_nhwc, nullptr, stream);
+}
+
+// ... and the per-image largest |output| into maxbits[B] (fp32 bits; must be ZERO before the call) for mh_act_planes
+int mh_conv_first_nchw_max(const float *in_nchw, int B, int Cin, int H, int W, const float *w, int Cout, const float *bias,
+                           int epilogue, float *out_nhwc, unsigned *maxbits, void *stream)
 {
     MH_REQUIRE(in_nchw && w && out_nhwc && B > 0 && Cin > 0 && H > 0 && W > 0);
     MH_REQUIRE(Cout > 0 && Cout % kStemCo == 0);
@@ -966,7 +986,7 @@ int mh_conv_first_nchw(const float *in_nchw, int B, int Cin, int H, int W, const
     const long long total = (long long)B * H * W * (Cout / kStemCo);
     const int blocks = (int)std::min<long long>((total + 255) / 256, 256 * 8);
     hipLaunchKernelGGL(conv_first_kernel, dim3(blocks), dim3(256), lds, as_stream(stream), in_nchw, B, Cin, H, W, w,
-                       Cout, bias, epilogue, out_nhwc);
+                       Cout, bias, epilogue, out_nhwc, maxbits);
     return check_launch("conv_first_kernel");
 }
 

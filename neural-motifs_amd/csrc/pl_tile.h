@@ -265,6 +265,20 @@ __device__ __forceinline__ void patch_tile(int t, int tiles_m, int tiles_n, int 
     tn = j * pw + rem % w;
 }
 
+// largest |x| (fp32 bits) of a wave's lanes -> ONE atomicMax when all lanes share `key` (the usual case); lanes with
+// differing keys fall back to their own atomics.  Every lane of the wave must call it.
+__device__ __forceinline__ void wave_atomic_max(unsigned *words, int key, unsigned v)
+{
+    const int key0 = __shfl(key, 0);
+    if (__all(key == key0)) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v = max(v, (unsigned)__shfl_xor((int)v, o));
+        if ((threadIdx.x & 63) == 0 && v) atomicMax(words + key0, v);
+    } else if (v) {
+        atomicMax(words + key, v);
+    }
+}
+
 template <auto Kern, typename Args>
 inline void launch(dim3 grid, size_t lds_bytes, hipStream_t st, const Args &p)
 {

@@ -23,6 +23,8 @@ SYMBOLS = (
     'mh_roi_align_fwd', 'mh_roi_align_bwd', 'mh_roi_align_bwd_det', 'mh_draw_union_boxes', 'mh_bbox_overlaps', 'mh_triplet_match',
     'mh_gemm_ws_bytes', 'mh_gemm_auto_splitk', 'mh_gemm_f32',
     'mh_planes_bytes', 'mh_make_planes', 'mh_gemm_planes_ws_bytes', 'mh_gemm_planes_auto_splitk', 'mh_gemm_planes',
+    'mh_act_planes_bytes', 'mh_act_planes', 'mh_plconv_packed_bytes', 'mh_plconv_pack_weight', 'mh_plconv3x3_ws_bytes',
+    'mh_plconv3x3', 'mh_conv_first_nchw_max', 'mh_debug_plconv_shape',
     'mh_debug_pl_shape', 'mh_gemm_ws_bytes_v2', 'mh_gemm_auto_splitk_v2', 'mh_gemm_f32_v2',
     'mh_conv3x3_packed_floats', 'mh_conv3x3_pack_weight', 'mh_conv3x3_ws_bytes', 'mh_conv3x3_schedule', 'mh_conv3x3_nhwc',
     'mh_conv3x3_wgrad_ws_bytes', 'mh_conv3x3_wgrad', 'mh_conv_first_nchw', 'mh_maxpool2x2_nhwc',
@@ -57,7 +59,8 @@ def lib():
             getattr(L, name)          # AttributeError if the library is stale
         L.mh_last_error.restype = ctypes.c_char_p
         for name in ('mh_nms_ws_bytes', 'mh_nms_batched_ws_bytes', 'mh_gemm_ws_bytes', 'mh_planes_bytes',
-                     'mh_gemm_planes_ws_bytes', 'mh_gemm_ws_bytes_v2', 'mh_conv3x3_ws_bytes', 'mh_bn_ws_bytes',
+                     'mh_gemm_planes_ws_bytes', 'mh_gemm_ws_bytes_v2', 'mh_act_planes_bytes', 'mh_plconv_packed_bytes',
+                     'mh_plconv3x3_ws_bytes', 'mh_conv3x3_ws_bytes', 'mh_bn_ws_bytes',
                      'mh_conv3x3_packed_floats', 'mh_hwcell_seq_ws_bytes', 'mh_conv3x3_wgrad_ws_bytes',
                      'mh_hwlstm_fwd_ws_bytes', 'mh_hwlstm_bwd_ws_bytes',
                      'mh_decoder_greedy_ws_bytes'):
@@ -393,6 +396,60 @@ def conv3x3_wgrad(x, gy):
         return None
     _check(rc, 'mh_conv3x3_wgrad')
     return dw
+
+
+class ActImage(object):
+    """activation plane image (csrc/pl_conv.hip) of an NHWC tensor [B,H,W,C]: uint8 buffer = cells + per-image maxima"""
+    __slots__ = ('buf', 'B', 'H', 'W', 'C')
+
+    def __init__(self, buf, B, H, W, C):
+        self.buf, self.B, self.H, self.W, self.C = buf, int(B), int(H), int(W), int(C)
+
+
+def act_planes(x_nhwc, maxbits, pool=False):
+    """fp32 NHWC tensor + its per-image |x| maxima (int32 [B], fp32 bit patterns, from the producing kernel) -> ActImage
+    of the tensor, or of its 2x2/2 max-pool"""
+    L = lib()
+    B, H, W, C = x_nhwc.shape
+    Ho, Wo = (H // 2, W // 2) if pool else (H, W)
+    buf = torch.empty(L.mh_act_planes_bytes(B, Ho, Wo, C), dtype=torch.uint8, device=x_nhwc.device)
+    rc = L.mh_act_planes(f32(x_nhwc), i32(maxbits), B, H, W, C, c_int(int(pool)), ctypes.c_void_p(buf.data_ptr()), stream())
+    _check(rc, 'mh_act_planes')
+    return ActImage(buf, B, Ho, Wo, C)
+
+
+def plconv_pack_weight(w, flip_transpose=False):
+    L = lib()
+    Cout, Cin = w.shape[0], w.shape[1]
+    N, K = (Cin, Cout) if flip_transpose else (Cout, Cin)
+    buf = torch.empty(L.mh_plconv_packed_bytes(N, K), dtype=torch.uint8, device=w.device)
+    rc = L.mh_plconv_pack_weight(f32(w), Cout, Cin, c_int(int(flip_transpose)), ctypes.c_void_p(buf.data_ptr()), stream())
+    _check(rc, 'mh_plconv_pack_weight')
+    return buf
+
+
+def plconv3x3(img, packed, cout, bias, epilogue, out_maxbits=None):
+    """3x3 / 1 / 1 conv of an ActImage with packed plane weights -> fp32 NHWC [B,H,W,cout]; out_maxbits (int32 [B], zeroed by
+    the caller) receives the per-image maxima of the output"""
+    L = lib()
+    out = torch.empty(img.B, img.H, img.W, cout, dtype=torch.float32, device=img.buf.device)
+    wsb = L.mh_plconv3x3_ws_bytes(img.B, img.H, img.W, img.C, cout)
+    ws = workspace(wsb, out.device, 'conv') if wsb else None
+    rc = L.mh_plconv3x3(ctypes.c_void_p(img.buf.data_ptr()), img.B, img.H, img.W, img.C, ctypes.c_void_p(packed.data_ptr()), cout,
+                        f32(bias), c_int(epilogue), f32(out), i32(out_maxbits), ptr(ws),
+                        c_size_t(ws.numel() if ws is not None else 0), stream())
+    _check(rc, 'mh_plconv3x3')
+    return out
+
+
+def conv_first_nchw_max(x, w, bias, epilogue, maxbits):
+    L = lib()
+    B, Cin, H, W = x.shape
+    Cout = w.shape[0]
+    out = torch.empty(B, H, W, Cout, dtype=torch.float32, device=x.device)
+    rc = L.mh_conv_first_nchw_max(f32(x), B, Cin, H, W, f32(w), Cout, f32(bias), c_int(epilogue), f32(out), i32(maxbits), stream())
+    _check(rc, 'mh_conv_first_nchw_max')
+    return out
 
 
 def conv_first_nchw(x, w, bias, epilogue):

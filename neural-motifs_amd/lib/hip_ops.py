@@ -7,6 +7,7 @@ CPU.  Parameter names and shapes are the reference's (nn.Linear: weight [out,in]
 [Cout,Cin,kh,kw]) so checkpoints load unchanged.
 """
 import math
+import os
 import weakref
 
 import torch
@@ -201,6 +202,16 @@ class Conv3x3(nn.Module):
         nn.init.kaiming_normal_(self.weight, mode='fan_out', nonlinearity='relu')
         self._packed = None
         self._packed_key = None
+        self._plane = None
+        self._plane_key = None
+
+    def plane_weight(self):
+        """packed plane image of the weights for the plane-engine conv (csrc/pl_conv.hip), cached per parameter value"""
+        key = (_hip.version_of(self.weight), self.weight.device)
+        if self._plane_key != key:
+            self._plane = _hip.plconv_pack_weight(_c(self.weight.detach()), False)
+            self._plane_key = key
+        return self._plane
 
     def packed_weight(self, flip_transpose=False):
         key = (_hip.version_of(self.weight), flip_transpose, self.weight.device)
@@ -254,6 +265,8 @@ class VGG16Features(nn.Sequential):
     def forward(self, x):
         if any(p.requires_grad for p in self.parameters()) and torch.is_grad_enabled():
             return self._forward_trainable(x)          # detector pre-training (models/train_detector.py)
+        if os.environ.get('MOTIFS_TRUNK', 'planes') == 'planes':
+            return self._forward_planes(x)
         with torch.no_grad():
             mods = list(self.children())
             first = mods[0]
@@ -269,6 +282,35 @@ class VGG16Features(nn.Sequential):
                     i += 1
                 else:
                     raise RuntimeError('unexpected module in VGG16Features')
+        return y.permute(0, 3, 1, 2)
+
+    def _forward_planes(self, x):
+        """the frozen trunk on the plane engine (csrc/pl_conv.hip): every conv reads its input as a pre-split f16 plane
+        image (no split arithmetic in the K loop) and reports the per-image maxima of what it writes; ONE converter pass
+        per layer turns the fp32 output into the next layer's image, through the 2x2 max-pool where the reference has
+        one (no separate pool launches, no per-pixel exponent passes).  MOTIFS_TRUNK=v2 selects the round-2 kernels."""
+        with torch.no_grad():
+            mods = list(self.children())
+            B = x.shape[0]
+            nconv = sum(isinstance(m, Conv3x3) for m in mods)
+            mb = torch.zeros(nconv, B, dtype=torch.int32, device=x.device)     # per-layer, per-image |y| maxima (fp32 bits)
+            first = mods[0]
+            y = _hip.conv_first_nchw_max(_c(x), _c(first.weight), first.bias, EPI_RELU, mb[0])
+            i, layer, pool = 2, 0, False
+            while i < len(mods):
+                m = mods[i]
+                if isinstance(m, Conv3x3):
+                    img = _hip.act_planes(y, mb[layer], pool=pool)
+                    layer, pool = layer + 1, False
+                    y = _hip.plconv3x3(img, m.plane_weight(), m.out_channels, m.bias.detach(), EPI_RELU, mb[layer])
+                    i += 2                      # its ReLU is fused
+                elif isinstance(m, MaxPool2x2):
+                    pool = True                 # folded into the next layer's converter
+                    i += 1
+                else:
+                    raise RuntimeError('unexpected module in VGG16Features')
+            if pool:
+                y = _hip.maxpool2x2_nhwc(y)
         return y.permute(0, 3, 1, 2)
 
     def _forward_trainable(self, x):

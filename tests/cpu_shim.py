@@ -91,6 +91,24 @@ def install():
         y = {0: y, 1: F.relu(y), 2: F.relu6(y)}[epilogue]
         return y.permute(0, 2, 3, 1).contiguous()
 
+    def conv_first_nchw_max(x, w, bias, epilogue, maxbits):
+        y = conv_first_nchw(x, w, bias, epilogue)
+        maxbits.copy_(y.abs().amax(dim=(1, 2, 3)).view(torch.int32))
+        return y
+
+    def act_planes(x_nhwc, maxbits, pool=False):
+        y = F.max_pool2d(x_nhwc.permute(0, 3, 1, 2), 2, 2).permute(0, 2, 3, 1).contiguous() if pool else x_nhwc
+        return _hip.ActImage(y, y.shape[0], y.shape[1], y.shape[2], y.shape[3])      # .buf = the dense NHWC tensor
+
+    def plconv_pack_weight(w, flip_transpose=False):
+        return conv3x3_pack_weight(w, flip_transpose)
+
+    def plconv3x3(img, packed, cout, bias, epilogue, out_maxbits=None):
+        y = conv3x3_nhwc(img.buf, packed, bias, epilogue)
+        if out_maxbits is not None:
+            out_maxbits.copy_(y.abs().amax(dim=(1, 2, 3)).view(torch.int32))
+        return y
+
     def conv_first_nchw(x, w, bias, epilogue):
         y = F.conv2d(x, w, bias, padding=1)
         y = {0: y, 1: F.relu(y), 2: F.relu6(y)}[epilogue]

@@ -218,6 +218,145 @@ static void speed_case(const char *name, int tA, int tB, int M, int N, int K, in
     set_shape(-1);
 }
 
+// ------------------------------------------------------------------------------------------------- plane conv (pl_conv.hip)
+typedef size_t (*sz4_fn)(int, int, int, int);
+typedef size_t (*sz5_fn)(int, int, int, int, int);
+typedef size_t (*sz2_fn)(int, int);
+typedef int (*actpl_fn)(const float *, const unsigned *, int, int, int, int, int, void *, void *);
+typedef int (*plpack_fn)(const float *, int, int, int, void *, void *);
+typedef int (*plconv_fn)(const void *, int, int, int, int, const void *, int, const float *, int, float *, unsigned *, void *, size_t, void *);
+typedef int (*v2pack_fn)(const float *, int, int, int, float *, void *);
+typedef int (*v2conv_fn)(const float *, int, int, int, int, const float *, int, const float *, int, float *, void *, size_t, void *);
+static sz4_fn act_bytes;
+static sz2_fn plpacked_bytes, v2packed_floats;
+static sz5_fn plconv_ws, v2conv_ws;
+static actpl_fn act_planes;
+static plpack_fn plpack;
+static plconv_fn plconv;
+static v2pack_fn v2pack;
+static v2conv_fn v2conv;
+static shape_fn set_conv_shape;
+
+static unsigned fbits(float v) { unsigned u; memcpy(&u, &v, 4); return u & 0x7fffffffu; }
+
+// B x H x W x Cin -> Cout, optional 2x2 pool in front; reference = float64 loops (small) or the round-2 kernel (big)
+static int conv_case(const char *name, int B, int H, int W, int Cin, int Cout, int pool, bool cpu_ref, unsigned seed)
+{
+    std::mt19937 rng(seed);
+    std::normal_distribution<float> nrm(0.f, 1.f);
+    const int Hi = pool ? 2 * H : H, Wi = pool ? 2 * W : W;
+    std::vector<float> x((size_t)B * Hi * Wi * Cin), w((size_t)Cout * Cin * 9), bias(Cout);
+    for (size_t i = 0; i < x.size(); ++i) { const float v = nrm(rng) * (1.f + 3.f * ((i / ((size_t)Hi * Wi * Cin)) % 3)); x[i] = v > 0 ? v : 0.f; }
+    for (auto &v : w) v = nrm(rng) * 0.05f;
+    for (auto &v : bias) v = nrm(rng) * 0.1f;
+    std::vector<unsigned> mb(B, 0);
+    for (int b = 0; b < B; ++b)
+        for (size_t i = 0; i < (size_t)Hi * Wi * Cin; ++i) mb[b] = std::max(mb[b], fbits(x[(size_t)b * Hi * Wi * Cin + i]));
+    // pooled input on the host (what the conv sees)
+    std::vector<float> xp((size_t)B * H * W * Cin);
+    for (int b = 0; b < B; ++b) for (int y = 0; y < H; ++y) for (int xx = 0; xx < W; ++xx) for (int c = 0; c < Cin; ++c) {
+        auto at = [&](int yy, int xq) { return x[(((size_t)b * Hi + yy) * Wi + xq) * Cin + c]; };
+        xp[(((size_t)b * H + y) * W + xx) * Cin + c] = pool ? std::max(std::max(at(2 * y, 2 * xx), at(2 * y, 2 * xx + 1)), std::max(at(2 * y + 1, 2 * xx), at(2 * y + 1, 2 * xx + 1))) : at(y, xx);
+    }
+    Dev dx(x.size() * 4), dxp(xp.size() * 4), dw(w.size() * 4), db(Cout * 4), dmb(B * 4), dmbo(B * 4), dout((size_t)B * H * W * Cout * 4), dref((size_t)B * H * W * Cout * 4);
+    HIP_OK(hipMemcpy(dx.p, x.data(), x.size() * 4, hipMemcpyHostToDevice));
+    HIP_OK(hipMemcpy(dxp.p, xp.data(), xp.size() * 4, hipMemcpyHostToDevice));
+    HIP_OK(hipMemcpy(dw.p, w.data(), w.size() * 4, hipMemcpyHostToDevice));
+    HIP_OK(hipMemcpy(db.p, bias.data(), Cout * 4, hipMemcpyHostToDevice));
+    HIP_OK(hipMemcpy(dmb.p, mb.data(), B * 4, hipMemcpyHostToDevice));
+    Dev img(act_bytes(B, H, W, Cin)), pk(plpacked_bytes(Cout, Cin)), ws(plconv_ws(B, H, W, Cin, Cout));
+    int rc = act_planes(dx.f(), (const unsigned *)dmb.p, B, Hi, Wi, Cin, pool, img.p, nullptr);
+    rc |= plpack(dw.f(), Cout, Cin, 0, pk.p, nullptr);
+    // reference output
+    std::vector<double> R;
+    std::vector<float> Rf((size_t)B * H * W * Cout);
+    if (cpu_ref) {
+        for (int b = 0; b < B; ++b) for (int y = 0; y < H; ++y) for (int xx = 0; xx < W; ++xx) for (int co = 0; co < Cout; ++co) {
+            double a = bias[co];
+            for (int ky = 0; ky < 3; ++ky) for (int kx = 0; kx < 3; ++kx) {
+                const int yy = y + ky - 1, xq = xx + kx - 1;
+                if (yy < 0 || yy >= H || xq < 0 || xq >= W) continue;
+                for (int ci = 0; ci < Cin; ++ci) a += (double)xp[(((size_t)b * H + yy) * W + xq) * Cin + ci] * (double)w[((size_t)co * Cin + ci) * 9 + ky * 3 + kx];
+            }
+            Rf[(((size_t)b * H + y) * W + xx) * Cout + co] = (float)std::max(a, 0.0);
+        }
+    } else {
+        Dev pk2(v2packed_floats(Cout, Cin) * 4), ws2(v2conv_ws(B, H, W, Cin, Cout));
+        rc |= v2pack(dw.f(), Cout, Cin, 0, pk2.f(), nullptr);
+        rc |= v2conv(dxp.f(), B, H, W, Cin, pk2.f(), Cout, db.f(), 1, dref.f(), ws2.p, ws2.n, nullptr);
+        HIP_OK(hipDeviceSynchronize());
+        HIP_OK(hipMemcpy(Rf.data(), dref.p, Rf.size() * 4, hipMemcpyDeviceToHost));
+    }
+    int bad = 0;
+    for (int shape = -1; shape <= 2; ++shape) {
+        set_conv_shape(shape);
+        Dev ws3(plconv_ws(B, H, W, Cin, Cout));
+        HIP_OK(hipMemset(dmbo.p, 0, B * 4));
+        HIP_OK(hipMemset(dout.p, 0xff, dout.n));
+        const int r2 = plconv(img.p, B, H, W, Cin, pk.p, Cout, db.f(), 1, dout.f(), (unsigned *)dmbo.p, ws3.p, ws3.n, nullptr);
+        HIP_OK(hipDeviceSynchronize());
+        std::vector<float> O(Rf.size());
+        std::vector<unsigned> mbo(B);
+        HIP_OK(hipMemcpy(O.data(), dout.p, O.size() * 4, hipMemcpyDeviceToHost));
+        HIP_OK(hipMemcpy(mbo.data(), dmbo.p, B * 4, hipMemcpyDeviceToHost));
+        double ss = 0, se = 0, mx = 0;
+        int mb_bad = 0;
+        for (int b = 0; b < B; ++b) {
+            unsigned m = 0;
+            for (size_t i = 0; i < (size_t)H * W * Cout; ++i) {
+                const size_t k = (size_t)b * H * W * Cout + i;
+                const double e = (double)O[k] - (double)Rf[k];
+                ss += (double)Rf[k] * Rf[k]; se += e * e; mx = std::fmax(mx, std::fabs(e));
+                m = std::max(m, fbits(O[k]));
+            }
+            mb_bad += (m != mbo[b]);
+        }
+        const double rms = std::sqrt(ss / O.size()) + 1e-300;
+        const bool ok = (rc | r2) == 0 && std::sqrt(se / O.size()) / rms < 2e-6 && mx / rms < 4e-5 && mb_bad == 0;
+        bad += !ok;
+        printf("{\"check\": \"conv\", \"case\": \"%s\", \"B\": %d, \"H\": %d, \"W\": %d, \"Cin\": %d, \"Cout\": %d, \"pool\": %d, \"ref\": \"%s\", \"shape\": %d, "
+               "\"rc\": %d, \"rms_rel\": %.3g, \"max_rel\": %.3g, \"maxbits_wrong\": %d, \"ok\": %s}\n", name, B, H, W, Cin, Cout, pool,
+               cpu_ref ? "float64" : "round-2 kernel", shape, rc | r2, std::sqrt(se / O.size()) / rms, mx / rms, mb_bad, ok ? "true" : "false");
+        if (rc | r2) printf("{\"error\": \"%s\"}\n", last_err());
+        fflush(stdout);
+    }
+    set_conv_shape(-1);
+    return bad;
+}
+
+static void conv_speed(const char *name, int B, int H, int W, int Cin, int Cout, int pool_in_front, int iters)
+{
+    const int Hi = pool_in_front ? 2 * H : H, Wi = pool_in_front ? 2 * W : W;
+    const size_t nx = (size_t)B * Hi * Wi * Cin, nxp = (size_t)B * H * W * Cin;
+    Dev dx(nx * 4), dxp(nxp * 4), dw((size_t)Cout * Cin * 9 * 4), db(Cout * 4), dmb(B * 4), dmbo(B * 4), dout((size_t)B * H * W * Cout * 4);
+    fill_dev(dx.f(), nx, 3); fill_dev(dxp.f(), nxp, 4); fill_dev(dw.f(), (size_t)Cout * Cin * 9, 5); fill_dev(db.f(), Cout, 6);
+    std::vector<unsigned> mb(B, fbits(6.0f));
+    HIP_OK(hipMemcpy(dmb.p, mb.data(), B * 4, hipMemcpyHostToDevice));
+    const double flops = 2.0 * 9 * Cin * (double)Cout * B * H * W;
+    {
+        Dev pk2(v2packed_floats(Cout, Cin) * 4), ws2(v2conv_ws(B, H, W, Cin, Cout));
+        v2pack(dw.f(), Cout, Cin, 0, pk2.f(), nullptr);
+        const float ms = time_ms(iters, [&] { v2conv(dxp.f(), B, H, W, Cin, pk2.f(), Cout, db.f(), 1, dout.f(), ws2.p, ws2.n, nullptr); });
+        printf("{\"check\": \"conv speed\", \"case\": \"%s\", \"engine\": \"v2 (split in the loop, incl. exponent passes)\", \"ms\": %.4f, \"tflops\": %.1f}\n", name, ms, flops / ms * 1e-9);
+    }
+    Dev img(act_bytes(B, H, W, Cin)), pk(plpacked_bytes(Cout, Cin));
+    plpack(dw.f(), Cout, Cin, 0, pk.p, nullptr);
+    {
+        const float ms = time_ms(iters, [&] { act_planes(dx.f(), (const unsigned *)dmb.p, B, Hi, Wi, Cin, pool_in_front, img.p, nullptr); });
+        printf("{\"check\": \"conv speed\", \"case\": \"%s\", \"engine\": \"act_planes%s\", \"ms\": %.4f, \"GBps\": %.0f}\n", name, pool_in_front ? " (2x2 pool fused)" : "", ms,
+               (nx + nxp) * 4.0 / ms * 1e-6);
+    }
+    for (int shape = -1; shape <= 2; ++shape) {
+        if (shape == 2 && Cout > 64) continue;
+        set_conv_shape(shape);
+        Dev ws3(plconv_ws(B, H, W, Cin, Cout));
+        const float ms = time_ms(iters, [&] { plconv(img.p, B, H, W, Cin, pk.p, Cout, db.f(), 1, dout.f(), (unsigned *)dmbo.p, ws3.p, ws3.n, nullptr); });
+        printf("{\"check\": \"conv speed\", \"case\": \"%s\", \"engine\": \"v3 plane conv\", \"shape\": %d, \"ms\": %.4f, \"tflops\": %.1f}\n", name, shape, ms, flops / ms * 1e-9);
+        fflush(stdout);
+    }
+    set_conv_shape(-1);
+}
+
 int main(int argc, char **argv)
 {
     if (argc < 2) { printf("usage: pl_check <libmotifs_hip.so> [--quick] [--speed-only]\n"); return 1; }
@@ -231,6 +370,33 @@ int main(int argc, char **argv)
     pbytes = (pbytes_fn)dlsym(h, "mh_planes_bytes"); mkplanes = (mkplanes_fn)dlsym(h, "mh_make_planes");
     gemmpl = (gemmpl_fn)dlsym(h, "mh_gemm_planes"); set_shape = (shape_fn)dlsym(h, "mh_debug_pl_shape"); last_err = (err_fn)dlsym(h, "mh_last_error");
     if (!g3 || !g2 || !ws3 || !ws2 || !wspl || !pbytes || !mkplanes || !gemmpl || !set_shape || !last_err) { printf("missing symbol\n"); return 2; }
+    act_bytes = (sz4_fn)dlsym(h, "mh_act_planes_bytes"); plpacked_bytes = (sz2_fn)dlsym(h, "mh_plconv_packed_bytes");
+    v2packed_floats = (sz2_fn)dlsym(h, "mh_conv3x3_packed_floats"); plconv_ws = (sz5_fn)dlsym(h, "mh_plconv3x3_ws_bytes");
+    v2conv_ws = (sz5_fn)dlsym(h, "mh_conv3x3_ws_bytes"); act_planes = (actpl_fn)dlsym(h, "mh_act_planes"); plpack = (plpack_fn)dlsym(h, "mh_plconv_pack_weight");
+    plconv = (plconv_fn)dlsym(h, "mh_plconv3x3"); v2pack = (v2pack_fn)dlsym(h, "mh_conv3x3_pack_weight"); v2conv = (v2conv_fn)dlsym(h, "mh_conv3x3_nhwc");
+    set_conv_shape = (shape_fn)dlsym(h, "mh_debug_plconv_shape");
+    if (!act_bytes || !plpacked_bytes || !v2packed_floats || !plconv_ws || !v2conv_ws || !act_planes || !plpack || !plconv || !v2pack || !v2conv || !set_conv_shape) { printf("missing conv symbol\n"); return 2; }
+    if (argc > 2 && !strcmp(argv[2], "--conv")) {
+        int badc = 0;
+        badc += conv_case("small", 3, 20, 20, 32, 64, 0, true, 31);
+        badc += conv_case("small pooled", 2, 13, 17, 16, 128, 1, true, 32);
+        badc += conv_case("ragged rows", 3, 23, 19, 64, 256, 0, true, 33);
+        badc += conv_case("conv5 (split-K)", 6, 37, 37, 512, 512, 0, false, 34);
+        badc += conv_case("conv4 pooled (tail slices)", 6, 74, 74, 256, 512, 1, false, 35);
+        badc += conv_case("conv2 pooled", 2, 296, 296, 64, 128, 1, false, 36);
+        printf("{\"check\": \"conv summary\", \"failed\": %d}\n", badc);
+        if (argc > 3 && !strcmp(argv[3], "--speed")) {
+            conv_speed("conv1_2", 6, 592, 592, 64, 64, 0, 5);
+            conv_speed("conv2_1", 6, 296, 296, 64, 128, 1, 5);
+            conv_speed("conv2_2", 6, 296, 296, 128, 128, 0, 5);
+            conv_speed("conv3_1", 6, 148, 148, 128, 256, 1, 5);
+            conv_speed("conv3_2", 6, 148, 148, 256, 256, 0, 5);
+            conv_speed("conv4_1", 6, 74, 74, 256, 512, 1, 5);
+            conv_speed("conv4_2", 6, 74, 74, 512, 512, 0, 5);
+            conv_speed("conv5_1", 6, 37, 37, 512, 512, 1, 5);
+        }
+        return badc ? 1 : 0;
+    }
     int bad = 0;
     if (pmc) {      // a few launches of the product kernel on ready images, nothing else: the target of rocprofv3 --pmc
         const int M = 1536, N = 4096, K = 25088;
