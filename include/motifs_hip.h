@@ -139,6 +139,10 @@ int mh_gemm_f32(int transA, int transB, int M, int N, int K, const float *A, int
  * Replaces the same cuBLAS calls as mh_gemm_f32 (lib/rel_model.py:366-373,403-414, lib/object_detector.py:129-138). */
 size_t mh_planes_bytes(long long rows, long long K);
 int mh_make_planes(const float *X, int k_contiguous, long long rows, long long K, long long ld, void *image, void *stream);
+/* both images of X [R][C] (ld) from one HBM read: img_rows (rows = X rows, K = C; mh_planes_bytes(R, C)) and img_cols
+ * (rows = X columns, K = R; mh_planes_bytes(C, R)) -- a Linear layer's weight / input / output gradient are each consumed in
+ * both orientations (forward + input gradient, forward + weight gradient, input + weight gradient). */
+int mh_make_planes_both(const float *X, long long R, long long C, long long ld, void *img_rows, void *img_cols, void *stream);
 size_t mh_gemm_planes_ws_bytes(int M, int N, int K, int splitk);
 int mh_gemm_planes_auto_splitk(int M, int N, int K);
 int mh_gemm_planes(int M, int N, int K, const void *A_image, const void *B_image, float *C, int ldc, const float *bias,

@@ -218,10 +218,16 @@ __global__ void roi_align_fwd_nchw(const float *__restrict__ feat, const float *
     }
 }
 
-// NHWC features: block = (roi, 64-channel chunk).  Reads are 256-B coalesced over channels; the
-// [64][ph*pw] result tile is transposed through LDS so the [n][c][y][x] output run (64*49 floats,
-// contiguous) is written with coalesced stores.
+// NHWC features: block = (roi, 64-channel chunk).  A coalesced HBM gather with an LDS transposition:
+//   * thread = (channel quad cq = tid & 15, bin group bg = tid >> 4): 16 lanes read one corner's 64 channels as 16-byte
+//     vectors (256 contiguous bytes), and every thread ISSUES ALL ITS LOADS FIRST -- up to 4 bins x 4 corners = 16
+//     independent 16-byte loads in flight -- before the first bilinear blend (round 2 issued four dependent-latency scalar
+//     loads per bin and ran at 0.83 TB/s of output, latency-bound: profiles/r02_bench_n1_kernel_stats.csv);
+//   * the [64][bins] result tile is transposed through LDS so that the [n][c][y][x] output run (64 * bins floats,
+//     contiguous and 16-byte aligned) leaves the block as 16-byte stores.
+// Arithmetic per element is unchanged (bilerp, same expression order): outputs are bit-identical to the reference kernel.
 constexpr int kRoiCh = 64;
+constexpr int kRoiBinsPerThread = 4;      // bins <= 16 * 4 take the fast path (7x7 = 49 does); larger grids loop
 __global__ __launch_bounds__(256) void roi_align_fwd_nhwc(const float *__restrict__ feat,
                                                           const float *__restrict__ rois, int B, int C, int H,
                                                           int W, int ph, int pw, float width, float height,
@@ -238,27 +244,65 @@ __global__ __launch_bounds__(256) void roi_align_fwd_nhwc(const float *__restric
     const bool valid_im = (g.b_in >= 0 && g.b_in < B);
     for (int b = threadIdx.x; b < bins; b += blockDim.x) samp[b] = make_sample(g, b / pw, b % pw, H, W, ph, pw);
     __syncthreads();
-    const int c = threadIdx.x % kRoiCh;
-    const int grp = threadIdx.x / kRoiCh;
-    const int ngrp = blockDim.x / kRoiCh;
-    const bool cvalid = (c0 + c) < C;
-    const float *img = feat + (size_t)(valid_im ? g.b_in : 0) * H * W * C + c0 + c;
-    for (int b = grp; b < bins; b += ngrp) {
-        const Sample s = samp[b];
-        float v = 0.f;
-        if (valid_im && cvalid && s.top >= 0) {
-            const float tl = img[((size_t)s.top * W + s.left) * C];
-            const float tr = img[((size_t)s.top * W + s.right) * C];
-            const float bl = img[((size_t)s.bottom * W + s.left) * C];
-            const float br = img[((size_t)s.bottom * W + s.right) * C];
-            v = bilerp(tl, tr, bl, br, s);
+    const int cq = threadIdx.x & 15, bg = threadIdx.x >> 4;
+    const bool vec = (C % 4 == 0) && (c0 + 4 * cq + 3 < C);
+    const float *img = feat + (size_t)(valid_im ? g.b_in : 0) * H * W * C + c0 + 4 * cq;
+    for (int b0 = 0; b0 < bins; b0 += 16 * kRoiBinsPerThread) {
+        float4 tl[kRoiBinsPerThread], tr[kRoiBinsPerThread], bl[kRoiBinsPerThread], br[kRoiBinsPerThread];
+        Sample sm[kRoiBinsPerThread];
+#pragma unroll
+        for (int i = 0; i < kRoiBinsPerThread; ++i) {
+            const int b = b0 + bg + 16 * i;
+            sm[i].top = -1;
+            if (b < bins) sm[i] = samp[b];
+            tl[i] = tr[i] = bl[i] = br[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (valid_im && sm[i].top >= 0) {
+                auto fetch = [&](int yy, int xx) -> float4 {
+                    const float *q = img + ((size_t)yy * W + xx) * C;
+                    if (vec) return *reinterpret_cast<const float4 *>(q);
+                    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (c0 + 4 * cq + 0 < C) v.x = q[0];
+                    if (c0 + 4 * cq + 1 < C) v.y = q[1];
+                    if (c0 + 4 * cq + 2 < C) v.z = q[2];
+                    if (c0 + 4 * cq + 3 < C) v.w = q[3];
+                    return v;
+                };
+                tl[i] = fetch(sm[i].top, sm[i].left);
+                tr[i] = fetch(sm[i].top, sm[i].right);
+                bl[i] = fetch(sm[i].bottom, sm[i].left);
+                br[i] = fetch(sm[i].bottom, sm[i].right);
+            }
         }
-        tile[c * tstride + b] = v;
+#pragma unroll
+        for (int i = 0; i < kRoiBinsPerThread; ++i) {
+            const int b = b0 + bg + 16 * i;
+            if (b >= bins) continue;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (valid_im && sm[i].top >= 0) {
+                v.x = bilerp(tl[i].x, tr[i].x, bl[i].x, br[i].x, sm[i]);
+                v.y = bilerp(tl[i].y, tr[i].y, bl[i].y, br[i].y, sm[i]);
+                v.z = bilerp(tl[i].z, tr[i].z, bl[i].z, br[i].z, sm[i]);
+                v.w = bilerp(tl[i].w, tr[i].w, bl[i].w, br[i].w, sm[i]);
+            }
+            float *t = tile + (4 * cq) * tstride + b;
+            t[0] = v.x; t[tstride] = v.y; t[2 * tstride] = v.z; t[3 * tstride] = v.w;
+        }
     }
     __syncthreads();
     const int nch = min(kRoiCh, C - c0);
     float *dst = out + ((size_t)n * C + c0) * bins;
-    for (int i = threadIdx.x; i < nch * bins; i += blockDim.x) dst[i] = tile[(i / bins) * tstride + (i % bins)];
+    const int total = nch * bins;
+    if ((reinterpret_cast<uintptr_t>(dst) & 15) == 0) {
+        for (int i = 4 * threadIdx.x; i < total; i += 4 * blockDim.x) {
+            float v[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { const int j = min(i + k, total - 1); v[k] = tile[(j / bins) * tstride + (j % bins)]; }
+            if (i + 3 < total) *reinterpret_cast<float4 *>(dst + i) = make_float4(v[0], v[1], v[2], v[3]);
+            else for (int k = 0; i + k < total; ++k) dst[i + k] = v[k];
+        }
+    } else {
+        for (int i = threadIdx.x; i < total; i += blockDim.x) dst[i] = tile[(i / bins) * tstride + (i % bins)];
+    }
 }
 
 // Backward: the reference scatters with atomicAdd (roi_align_kernel.cu:103-170); same here.

@@ -264,18 +264,30 @@ __global__ __launch_bounds__(kThreads, 2) void conv3x3_kernel(const ConvArgs p)
         });
         return;
     }
-    unsigned vmax = 0;
-    const bool one_image = (m0 / HW) == (min(m0 + S::bm, Mtot) - 1) / HW;
+    // per-image maxima of what this tile writes: a tile covers one image or straddles two (two running maxima per lane, one
+    // wave reduction + atomic each); tiles over more than two images (maps smaller than the tile) reduce row by row
+    const long long last_row = min(m0 + S::bm, Mtot) - 1;
+    const int b_lo = (int)(m0 / HW), b_hi = (int)(last_row / HW);
+    const int split = (int)min((long long)S::bm, (long long)(b_lo + 1) * HW - m0);     // first tile row of the next image
+    unsigned vlo = 0, vhi = 0;
     acc_foreach<S>(acc, wm, wn, lane, [&](int r, int c, int sn, float v) {
         const long long row = m0 + r;
         if (row >= Mtot || n0 + c >= p.Cout) return;
         v = conv_epi(__builtin_ldexpf(v, -(ex[r] + ecol[sn])) + bcol[sn], p.epilogue);
         p.out[(size_t)row * p.Cout + n0 + c] = v;
         const unsigned bits = __float_as_uint(v) & 0x7fffffffu;
-        if (one_image) vmax = max(vmax, bits);
-        else if (p.out_bits && bits) atomicMax(p.out_bits + row / HW, bits);       // a tile straddling two images: rare
+        if (b_hi - b_lo <= 1) { if (r < split) vlo = max(vlo, bits); else vhi = max(vhi, bits); }
+        else if (p.out_bits) {
+            unsigned m = bits;                       // one row = the 32 lanes of a half-wave: reduce, one atomic per row
+#pragma unroll
+            for (int o = 16; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o));
+            if ((lane & 31) == 0 && m) atomicMax(p.out_bits + row / HW, m);
+        }
     });
-    if (p.out_bits && one_image) wave_atomic_max(p.out_bits, (int)(m0 / HW), vmax);
+    if (p.out_bits && b_hi - b_lo <= 1) {
+        wave_atomic_max(p.out_bits, b_lo, vlo);
+        if (b_hi > b_lo) wave_atomic_max(p.out_bits, b_hi, vhi);
+    }
 }
 
 // C[rows][N] = epi(sum_z partial[z] + bias), and the per-image maxima of what is written (rows start at row0 of the layer)

@@ -114,6 +114,58 @@ __global__ __launch_bounds__(256) void planes_dual_kernel(const PlaneJob a, cons
     else planes_tile(b, (int)blockIdx.x - a.nblocks, lds);
 }
 
+// both images of ONE matrix from one HBM read: block (i, j) runs the K-contiguous job on X's tile (row tile i, column tile j)
+// and then the k-major job on the same 16 KB tile (its second read comes out of L1 / L2)
+__global__ __launch_bounds__(256) void planes_both_kernel(const PlaneJob rows_job, const PlaneJob cols_job)
+{
+    __shared__ __attribute__((aligned(16))) char lds[4 * 64 * kCell];
+    const int tj = (int)(blockIdx.x % rows_job.tiles_k), ti = (int)(blockIdx.x / rows_job.tiles_k);
+    planes_tile(rows_job, ti * rows_job.tiles_k + tj, lds);
+    __syncthreads();
+    planes_tile(cols_job, tj * cols_job.tiles_k + ti, lds);
+}
+
+// row AND column |x| maxima of X [R][C] in one pass (both arrays zero on entry): block = 64 rows x 256 columns; a wave owns
+// rows w, w + 4, ... (one shuffle reduction + one atomicMax per row), column maxima are combined over the four waves in LDS
+__global__ __launch_bounds__(256) void absmax_both_kernel(const float *__restrict__ X, long long R, long long C, long long ld, int vec,
+                                                          unsigned *__restrict__ rowbits, unsigned *__restrict__ colbits)
+{
+    __shared__ unsigned red[4][256];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long long c0 = (long long)blockIdx.x * 256 + 4 * lane, r0 = (long long)blockIdx.y * 64;
+    unsigned cm[4] = {0, 0, 0, 0};
+    for (int i = 0; i < 16; ++i) {
+        const long long r = r0 + wave + 4 * i;
+        unsigned v[4] = {0, 0, 0, 0};
+        if (r < R && c0 < C) {
+            const float *src = X + r * ld + c0;
+            if (vec && c0 + 3 < C) {
+                const float4 q = *reinterpret_cast<const float4 *>(src);
+                v[0] = __float_as_uint(q.x) & 0x7fffffffu; v[1] = __float_as_uint(q.y) & 0x7fffffffu;
+                v[2] = __float_as_uint(q.z) & 0x7fffffffu; v[3] = __float_as_uint(q.w) & 0x7fffffffu;
+            } else {
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if (c0 + k < C) v[k] = __float_as_uint(src[k]) & 0x7fffffffu;
+            }
+        }
+        unsigned rm = max(max(v[0], v[1]), max(v[2], v[3]));
+#pragma unroll
+        for (int k = 0; k < 4; ++k) cm[k] = max(cm[k], v[k]);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) rm = max(rm, (unsigned)__shfl_xor((int)rm, o));
+        if (lane == 0 && r < R && rm) atomicMax(rowbits + r, rm);
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) red[wave][4 * lane + k] = cm[k];
+    __syncthreads();
+    const long long col = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (col < C) {
+        const unsigned m = max(max(red[0][threadIdx.x], red[1][threadIdx.x]), max(red[2][threadIdx.x], red[3][threadIdx.x]));
+        if (m) atomicMax(colbits + col, m);
+    }
+}
+
 static PlaneJob make_job(const float *X, bool k_contiguous, long long rows, long long K, long long ld, void *cells,
                          const unsigned *maxbits, int exp_div)
 {
@@ -323,6 +375,31 @@ int mh_make_planes(const float *X, int k_contiguous, long long rows, long long K
     none.nblocks = 0;
     hipLaunchKernelGGL(pl::planes_dual_kernel, dim3((unsigned)a.nblocks), dim3(256), 0, st, a, none);
     return check_launch("pl::planes_dual_kernel");
+}
+
+// BOTH images of the matrix X [R][C] (ld): img_rows = operand rows are X's rows (K = C), img_cols = operand rows are X's
+// columns (K = R).  One pass for both sets of maxima, one pass (one HBM read) for both images: what a Linear layer needs of
+// its weight (forward / input gradient), its input (forward / weight gradient) and its output gradient.
+int mh_make_planes_both(const float *X, long long R, long long C, long long ld, void *img_rows, void *img_cols, void *stream)
+{
+    MH_REQUIRE(X && img_rows && img_cols && R > 0 && C > 0 && ld >= C);
+    MH_REQUIRE(((reinterpret_cast<uintptr_t>(img_rows) | reinterpret_cast<uintptr_t>(img_cols)) & 255) == 0);
+    MH_REQUIRE(pl::cells_bytes(R, C) < (size_t)0x7ff00000u && pl::cells_bytes(C, R) < (size_t)0x7ff00000u);
+    hipStream_t st = as_stream(stream);
+    unsigned *rb = pl::image_maxbits(img_rows, R, C), *cb = pl::image_maxbits(img_cols, C, R);
+    hipError_t e = hipMemsetAsync(rb, 0, (size_t)R * 4, st);
+    if (e == hipSuccess) e = hipMemsetAsync(cb, 0, (size_t)C * 4, st);
+    if (e != hipSuccess) { set_last_error("hipMemsetAsync(plane maxima)", e); return (int)e; }
+    const int vec = ((reinterpret_cast<uintptr_t>(X) & 15) == 0 && ld % 4 == 0) ? 1 : 0;
+    MH_REQUIRE(ceil_div(R, 64LL) <= 65535);
+    hipLaunchKernelGGL(pl::absmax_both_kernel, dim3((unsigned)ceil_div(C, 256LL), (unsigned)ceil_div(R, 64LL)), dim3(256), 0, st, X, R, C,
+                       ld, vec, rb, cb);
+    int rc = check_launch("pl::absmax_both_kernel");
+    if (rc) return rc;
+    const pl::PlaneJob jr = pl::make_job(X, true, R, C, ld, img_rows, rb, 1);
+    const pl::PlaneJob jc = pl::make_job(X, false, C, R, ld, img_cols, cb, 1);
+    hipLaunchKernelGGL(pl::planes_both_kernel, dim3((unsigned)jr.nblocks), dim3(256), 0, st, jr, jc);
+    return check_launch("pl::planes_both_kernel");
 }
 
 int mh_gemm_planes_auto_splitk(int M, int N, int K) { return (M > 0 && N > 0 && K > 0) ? pl::plan_gemm(M, N, K, 0).splitk : 1; }

@@ -22,7 +22,7 @@ SYMBOLS = (
     'mh_nms_ws_bytes', 'mh_nms', 'mh_nms_batched_ws_bytes', 'mh_nms_batched',
     'mh_roi_align_fwd', 'mh_roi_align_bwd', 'mh_roi_align_bwd_det', 'mh_draw_union_boxes', 'mh_bbox_overlaps', 'mh_triplet_match',
     'mh_gemm_ws_bytes', 'mh_gemm_auto_splitk', 'mh_gemm_f32',
-    'mh_planes_bytes', 'mh_make_planes', 'mh_gemm_planes_ws_bytes', 'mh_gemm_planes_auto_splitk', 'mh_gemm_planes',
+    'mh_planes_bytes', 'mh_make_planes', 'mh_make_planes_both', 'mh_gemm_planes_ws_bytes', 'mh_gemm_planes_auto_splitk', 'mh_gemm_planes',
     'mh_act_planes_bytes', 'mh_act_planes', 'mh_plconv_packed_bytes', 'mh_plconv_pack_weight', 'mh_plconv3x3_ws_bytes',
     'mh_plconv3x3', 'mh_conv_first_nchw_max', 'mh_debug_plconv_shape',
     'mh_debug_pl_shape', 'mh_gemm_ws_bytes_v2', 'mh_gemm_auto_splitk_v2', 'mh_gemm_f32_v2',
@@ -220,6 +220,22 @@ def make_planes(x, k_contiguous=True):
                           ctypes.c_void_p(buf.data_ptr()), stream())
     _check(rc, 'mh_make_planes')
     return PlaneImage(buf, rows, K)
+
+
+def make_planes_both(x):
+    """(image with operand rows = x rows, image with operand rows = x columns) of a 2-D fp32 tensor, one HBM read"""
+    L = lib()
+    if x.dim() != 2 or x.stride(1) != 1 or not x.is_cuda or x.dtype != torch.float32:
+        raise HipKernelError('make_planes_both needs a 2-D fp32 CUDA tensor with unit inner stride')
+    R, C = x.shape
+    if R == 0 or C == 0:
+        raise HipKernelError('make_planes_both: empty operand')
+    br = torch.empty(L.mh_planes_bytes(c_ll(R), c_ll(C)), dtype=torch.uint8, device=x.device)
+    bc = torch.empty(L.mh_planes_bytes(c_ll(C), c_ll(R)), dtype=torch.uint8, device=x.device)
+    rc = L.mh_make_planes_both(ctypes.c_void_p(x.data_ptr()), c_ll(R), c_ll(C), c_ll(x.stride(0)), ctypes.c_void_p(br.data_ptr()),
+                               ctypes.c_void_p(bc.data_ptr()), stream())
+    _check(rc, 'mh_make_planes_both')
+    return PlaneImage(br, R, C), PlaneImage(bc, C, R)
 
 
 def gemm_planes(a, b, bias=None, epilogue=0, out=None, accumulate=False, splitk=0):

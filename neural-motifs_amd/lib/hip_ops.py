@@ -56,16 +56,26 @@ def _rows2d(t):
 _weight_images = {}
 
 
-def _weight_image(weight, transposed):
-    key = (id(weight), transposed)
+def _weight_image(weight, transposed, want_both=False):
+    """image of the weight [out, in]: rows = output features (forward) or, transposed, rows = input features (input
+    gradient).  want_both (the forward of a layer whose input needs a gradient): both images from ONE pass over the weight
+    -- the backward of this step will ask for the other one."""
+    key = id(weight)
     ver = _hip.version_of(weight)
     hit = _weight_images.get(key)
     if hit is None or hit[0] != ver:
         if hit is None:
-            weakref.finalize(weight, _weight_images.pop, key, None)      # the image dies with its parameter
-        hit = (ver, _hip.make_planes(_rows2d(weight.detach()), k_contiguous=not transposed))
+            weakref.finalize(weight, _weight_images.pop, key, None)      # the images die with their parameter
+        hit = [ver, None, None]
         _weight_images[key] = hit
-    return hit[1]
+    idx = 2 if transposed else 1
+    if hit[idx] is None:
+        w2 = _rows2d(weight.detach())
+        if want_both and hit[1] is None and hit[2] is None:
+            hit[1], hit[2] = _hip.make_planes_both(w2)
+        else:
+            hit[idx] = _hip.make_planes(w2, k_contiguous=not transposed)
+    return hit[idx]
 
 
 def drop_weight_images():
@@ -77,43 +87,60 @@ _SKINNY_ROWS = 128          # see _hip.gemm_inloop
 
 class _LinearFn(torch.autograd.Function):
     """y = act(x @ W^T + b): fp32-accurate product on the f16 matrix cores (csrc/pl_gemm.hip), ReLU fused into the
-    epilogue.  Every operand is split into its plane image ONCE per use pattern: the weight images are cached per
-    parameter value, x / gy are imaged where they are consumed."""
+    epilogue.  Every operand is split into its plane images ONCE: the weight images are cached per parameter value, the
+    input's second image (for the weight gradient) is made together with the first and kept for backward instead of the
+    fp32 input, the output gradient gets both of its images from one pass."""
 
     @staticmethod
     def forward(ctx, x, weight, bias, relu):
         x2, w2 = _rows2d(x), _rows2d(weight)
         epi = EPI_RELU if relu else EPI_NONE
-        if x2.shape[0] <= _SKINNY_ROWS and weight.requires_grad and w2.numel() >= (1 << 24):
-            y = _hip.gemm_inloop(x2, w2, False, True, bias=bias, epilogue=epi)
-        elif x2.shape[0] == 0:
+        ctx.x_cols = None
+        ctx.x2 = None
+        need_wgrad, need_dgrad = ctx.needs_input_grad[1], ctx.needs_input_grad[0]      # (grad mode is off inside forward)
+        if x2.shape[0] == 0:
             y = x2.new_zeros(0, w2.shape[0])
+        elif x2.shape[0] <= _SKINNY_ROWS and weight.requires_grad and w2.numel() >= (1 << 24):
+            y = _hip.gemm_inloop(x2, w2, False, True, bias=bias, epilogue=epi)
+            ctx.x2 = x2
         else:
-            y = _hip.gemm_planes(_hip.make_planes(x2, True), _weight_image(weight, False), bias=bias, epilogue=epi)
+            if need_wgrad:
+                x_rows, ctx.x_cols = _hip.make_planes_both(x2)
+            else:
+                x_rows = _hip.make_planes(x2, True)
+            y = _hip.gemm_planes(x_rows, _weight_image(weight, False, want_both=need_dgrad), bias=bias, epilogue=epi)
         ctx.relu = relu
         ctx.has_bias = bias is not None
         ctx.weight = weight
-        ctx.save_for_backward(x2, y if relu else None)
+        ctx.x_shape = tuple(x2.shape)
+        ctx.save_for_backward(y if relu else None)
         return y
 
     @staticmethod
     def backward(ctx, gy):
-        x2, y = ctx.saved_tensors
+        (y,) = ctx.saved_tensors
         weight = ctx.weight
         gy = _rows2d(gy)
         if ctx.relu:
             gy = gy * (y > 0).to(gy.dtype)
         gx = gw = gb = None
         if gy.shape[0] == 0:
-            return (x2.new_zeros(x2.shape) if ctx.needs_input_grad[0] else None,
+            return (gy.new_zeros(ctx.x_shape) if ctx.needs_input_grad[0] else None,
                     torch.zeros_like(weight) if ctx.needs_input_grad[1] else None,
                     torch.zeros_like(weight[:, 0]) if (ctx.has_bias and ctx.needs_input_grad[2]) else None, None)
+        gy_rows = gy_cols = None
+        if ctx.needs_input_grad[0] and ctx.needs_input_grad[1]:
+            gy_rows, gy_cols = _hip.make_planes_both(gy)
         if ctx.needs_input_grad[0]:
-            gx = _hip.gemm_planes(_hip.make_planes(gy, True), _weight_image(weight, True))     # [M,N] . (W^T image [K,N])^T
+            gy_rows = gy_rows if gy_rows is not None else _hip.make_planes(gy, True)
+            gx = _hip.gemm_planes(gy_rows, _weight_image(weight, True))                     # [M,N] . (W^T image [K,N])^T
         if ctx.needs_input_grad[1]:
-            gw = _hip.gemm_planes(_hip.make_planes(gy, False), _hip.make_planes(x2, False))    # gy^T [N,M] . (x^T [K,M])^T
+            gy_cols = gy_cols if gy_cols is not None else _hip.make_planes(gy, False)
+            x_cols = ctx.x_cols if ctx.x_cols is not None else _hip.make_planes(ctx.x2, False)
+            gw = _hip.gemm_planes(gy_cols, x_cols)                                         # gy^T [N,M] . (x^T [K,M])^T
         if ctx.has_bias and ctx.needs_input_grad[2]:
             gb = gy.sum(0)
+        ctx.x_cols = ctx.x2 = None
         return gx, gw, gb, None
 
 

@@ -40,6 +40,9 @@ def install():
         m = x.detach() if k_contiguous else x.detach().t()
         return _hip.PlaneImage(m.contiguous().clone(), m.shape[0], m.shape[1])      # .buf = the dense [rows, K] operand
 
+    def make_planes_both(x):
+        return make_planes(x, True), make_planes(x, False)
+
     def gemm_planes(a, b, bias=None, epilogue=0, out=None, accumulate=False, splitk=0):
         return gemm(a.buf, b.buf, False, True, bias=bias, epilogue=epilogue, out=out, accumulate=accumulate)
 

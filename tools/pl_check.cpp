@@ -155,6 +155,44 @@ static int image_case(int M, int N, int K, unsigned seed)
     return bad;
 }
 
+// mh_make_planes_both: A [M,K] -> its row image is the A operand; B given as [K,N] -> its COLUMN image is the B operand
+typedef int (*mkboth_fn)(const float *, long long, long long, long long, void *, void *, void *);
+static mkboth_fn mkboth;
+static int both_case(int M, int N, int K, unsigned seed)
+{
+    std::mt19937 rng(seed);
+    std::vector<float> A((size_t)M * K), B((size_t)K * N);
+    fill(A, rng, true); fill(B, rng, true);
+    Dev dA(A.size() * 4), dB(B.size() * 4), dC((size_t)M * N * 4), ia(pbytes(M, K)), iat(pbytes(K, M)), ib(pbytes(K, N)), ibt(pbytes(N, K));
+    HIP_OK(hipMemcpy(dA.p, A.data(), A.size() * 4, hipMemcpyHostToDevice));
+    HIP_OK(hipMemcpy(dB.p, B.data(), B.size() * 4, hipMemcpyHostToDevice));
+    int rc = mkboth(dA.f(), M, K, K, ia.p, iat.p, nullptr);
+    rc |= mkboth(dB.f(), K, N, N, ib.p, ibt.p, nullptr);
+    std::vector<double> R;
+    ref_gemm(0, 0, M, N, K, A, K, B, N, nullptr, 0, nullptr, N, R);
+    Dev ws(wspl(M, N, K, 0));
+    rc |= gemmpl(M, N, K, ia.p, ibt.p, dC.f(), N, nullptr, 0, 0, 0, ws.p, ws.n, nullptr);
+    HIP_OK(hipDeviceSynchronize());
+    std::vector<float> C((size_t)M * N);
+    HIP_OK(hipMemcpy(C.data(), dC.p, C.size() * 4, hipMemcpyDeviceToHost));
+    const Err e = compare(C, N, R, M, N);
+    // and the transposed product from the two OTHER images: C^T [N,M] = B^T A^T -> rows image of ... = (ib as [K rows,N]) no:
+    // A^T image (rows = K, K = M) x B image (rows = K, K = N) is not a product; instead check C2 [K,K] = A^T A via iat x iat
+    std::vector<double> R2((size_t)K * K, 0.0);
+    for (int m = 0; m < M; ++m) for (int i = 0; i < K; ++i) { const double a = A[(size_t)m * K + i]; for (int j = 0; j < K; ++j) R2[(size_t)i * K + j] += a * (double)A[(size_t)m * K + j]; }
+    Dev dC2((size_t)K * K * 4), ws2(wspl(K, K, M, 0));
+    rc |= gemmpl(K, K, M, iat.p, iat.p, dC2.f(), K, nullptr, 0, 0, 0, ws2.p, ws2.n, nullptr);
+    HIP_OK(hipDeviceSynchronize());
+    std::vector<float> C2((size_t)K * K);
+    HIP_OK(hipMemcpy(C2.data(), dC2.p, C2.size() * 4, hipMemcpyDeviceToHost));
+    const Err e2 = compare(C2, K, R2, K, K);
+    const bool ok = rc == 0 && e.rms_rel < 2e-6 && e.max_rel < 4e-5 && e2.rms_rel < 2e-6 && e2.max_rel < 4e-5;
+    printf("{\"check\": \"make_planes_both\", \"M\": %d, \"N\": %d, \"K\": %d, \"rc\": %d, \"rms_rel\": %.3g, \"max_rel\": %.3g, \"AtA_rms_rel\": %.3g, \"AtA_max_rel\": %.3g, \"ok\": %s}\n",
+           M, N, K, rc, e.rms_rel, e.max_rel, e2.rms_rel, e2.max_rel, ok ? "true" : "false");
+    fflush(stdout);
+    return ok ? 0 : 1;
+}
+
 static float time_ms(int iters, const std::function<void()> &fn)
 {
     hipEvent_t e0, e1;
@@ -202,6 +240,11 @@ static void speed_case(const char *name, int tA, int tB, int M, int N, int K, in
         const float ms_b = time_ms(iters, [&] { mkplanes(dB.f(), tB, N, K, ldb, ib.p, nullptr); });
         printf("{\"check\": \"speed\", \"case\": \"%s\", \"engine\": \"make_planes\", \"ms_A\": %.4f, \"GBps_A\": %.0f, \"ms_B\": %.4f, \"GBps_B\": %.0f}\n", name, ms_a,
                na * 12.0 / ms_a * 1e-6, ms_b, nb * 12.0 / ms_b * 1e-6);
+    }
+    if (!tB) {      // B stored [K][N]: both of its images from one read (what a trainable weight / an activation costs per step)
+        Dev i1(pbytes(K, N)), i2(pbytes(N, K));
+        const float ms = time_ms(iters, [&] { mkboth(dB.f(), K, N, ldb, i1.p, i2.p, nullptr); });
+        printf("{\"check\": \"speed\", \"case\": \"%s\", \"engine\": \"make_planes_both(B)\", \"ms\": %.4f, \"GBps\": %.0f}\n", name, ms, nb * 16.0 / ms * 1e-6);
     }
     for (int shape = -1; shape <= 1; ++shape) {
         if (shape == 0 && M <= 128) continue;
@@ -369,7 +412,8 @@ int main(int argc, char **argv)
     ws3 = (ws_fn)dlsym(h, "mh_gemm_ws_bytes"); ws2 = (ws_fn)dlsym(h, "mh_gemm_ws_bytes_v2"); wspl = (ws_fn)dlsym(h, "mh_gemm_planes_ws_bytes");
     pbytes = (pbytes_fn)dlsym(h, "mh_planes_bytes"); mkplanes = (mkplanes_fn)dlsym(h, "mh_make_planes");
     gemmpl = (gemmpl_fn)dlsym(h, "mh_gemm_planes"); set_shape = (shape_fn)dlsym(h, "mh_debug_pl_shape"); last_err = (err_fn)dlsym(h, "mh_last_error");
-    if (!g3 || !g2 || !ws3 || !ws2 || !wspl || !pbytes || !mkplanes || !gemmpl || !set_shape || !last_err) { printf("missing symbol\n"); return 2; }
+    mkboth = (mkboth_fn)dlsym(h, "mh_make_planes_both");
+    if (!g3 || !g2 || !ws3 || !ws2 || !wspl || !pbytes || !mkplanes || !mkboth || !gemmpl || !set_shape || !last_err) { printf("missing symbol\n"); return 2; }
     act_bytes = (sz4_fn)dlsym(h, "mh_act_planes_bytes"); plpacked_bytes = (sz2_fn)dlsym(h, "mh_plconv_packed_bytes");
     v2packed_floats = (sz2_fn)dlsym(h, "mh_conv3x3_packed_floats"); plconv_ws = (sz5_fn)dlsym(h, "mh_plconv3x3_ws_bytes");
     v2conv_ws = (sz5_fn)dlsym(h, "mh_conv3x3_ws_bytes"); act_planes = (actpl_fn)dlsym(h, "mh_act_planes"); plpack = (plpack_fn)dlsym(h, "mh_plconv_pack_weight");
@@ -404,8 +448,10 @@ int main(int argc, char **argv)
         fill_dev(dA.f(), (size_t)M * K, 1); fill_dev(dB.f(), (size_t)N * K, 2);
         mkplanes(dA.f(), 1, M, K, K, ia.p, nullptr);
         mkplanes(dB.f(), 1, N, K, K, ib.p, nullptr);
-        Dev ws(wspl(M, N, K, 0));
-        for (int i = 0; i < 3; ++i) gemmpl(M, N, K, ia.p, ib.p, dC.f(), N, nullptr, 0, 0, 0, ws.p, ws.n, nullptr);
+        const int shape = argc > 3 ? atoi(argv[3]) : -1, sk = argc > 4 ? atoi(argv[4]) : 0;      // --pmc [shape] [splitk]
+        set_shape(shape);
+        Dev ws(wspl(M, N, K, sk));
+        for (int i = 0; i < 3; ++i) gemmpl(M, N, K, ia.p, ib.p, dC.f(), N, nullptr, 0, 0, sk, ws.p, ws.n, nullptr);
         HIP_OK(hipDeviceSynchronize());
         return 0;
     }
@@ -424,6 +470,8 @@ int main(int argc, char **argv)
         bad += accuracy_case("NT 600x600x600 splitk 5 accumulate", 0, 1, 600, 600, 600, 0, 0, 0, true, 1, 1, 1, 5, 12);
         bad += image_case(520, 300, 1040, 21);
         bad += image_case(130, 60, 200, 22);
+        bad += both_case(300, 260, 333, 23);
+        bad += both_case(64, 517, 70, 24);
         printf("{\"check\": \"accuracy summary\", \"failed\": %d}\n", bad);
     }
     if (!quick) {
