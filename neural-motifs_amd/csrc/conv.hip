@@ -506,8 +506,11 @@ __global__ __launch_bounds__(256) void conv_first_kernel(const float *__restrict
     const long long total = (long long)B * H * W * groups;
     int cur_b = -1;            // per-image largest |output| (maxbits != nullptr): running maximum while the image is unchanged
     unsigned vmax = 0;
-    for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total;
-         idx += (long long)blockDim.x * gridDim.x) {
+    // every block owns one contiguous range of (pixel, channel group) items: neighbouring lanes share input pixels in L1 as
+    // before, and a thread crosses an image boundary at most once (a grid-stride loop would flush an atomic per iteration)
+    const long long per_block = ((total + gridDim.x - 1) / gridDim.x + 255) / 256 * 256;
+    const long long lo = blockIdx.x * per_block, hi = min(total, lo + per_block);
+    for (long long idx = lo + threadIdx.x; idx < hi; idx += 256) {
         const int grp = idx % groups;
         const long long pix = idx / groups;
         const int x = pix % W;

@@ -299,7 +299,11 @@ __global__ __launch_bounds__(256) void reduce_kernel(const float *__restrict__ p
     const size_t plane = (size_t)rows * N;
     int cur = -1;
     unsigned vmax = 0;
-    for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total; idx += (long long)blockDim.x * gridDim.x) {
+    // every block owns ONE contiguous range of elements, so a thread sees its image change at most a few times (a grid-stride
+    // loop jumps ~1000 rows per iteration: at 37x37 that is a new image -- and a flush atomic -- almost every iteration)
+    const long long per_block = ((total + gridDim.x - 1) / gridDim.x + 255) / 256 * 256;
+    const long long lo = blockIdx.x * per_block, hi = min(total, lo + per_block);
+    for (long long idx = lo + threadIdx.x; idx < hi; idx += 256) {
         const long long row = idx / N;
         const int col = (int)(idx % N);
         float v = 0.f;
