@@ -9,16 +9,20 @@ For N > 1 launch with torchrun (one rank per GPU, RCCL): every rank trains on it
 collective is the gradient all-reduce.  Rank 0 prints ONE JSON line.
 
 Extra objects in the line:
-  roofline     -- the dominant kernel (conv3x3 implicit GEMM on the matrix cores): algorithmic fp32 FLOPs / HIP-event
-                  time of its calls during the timed steps (a call = the kernel plus, in the f16x3 build, its two small
-                  row-exponent launches), against the matrix-core peak of the evaluation the library was built with
-                  (f16x3, the default: 2500/3 = 833 TFLOP/s fp32-equivalent; bf16x6: 2500/6 = 416.7; f32 MFMA: 157.3;
-                  `frac_of_f32_mfma_peak` and `frac_of_bf16x6_peak` are always given too).  `traffic` = fabric-side bytes
-                  per launch of that kernel from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over the same 14
-                  launches (replayed offline, profiles/r02_conv_traffic_summary.json: a PMC pass over the whole step does
-                  not finish); `traffic_algorithmic` = input + weights + output bytes of those launches.
-  roofline_gemm-- the same for every mh_gemm_f32 call of the step (fc6/fc7 of the three RoI heads, LSTM input
-                  projections, post_lstm, heads; forward, input and weight gradients).
+  roofline     -- the dominant kernel class, the 3x3 convolutions as implicit GEMMs on the matrix cores (12 trunk layers on
+                  the plane engine, csrc/pl_conv.hip, + the union tower's forward / input-gradient conv): algorithmic fp32
+                  FLOPs / HIP-event time of the calls during the timed steps, against the matrix-core peak of the f16x3
+                  evaluation (2500/3 = 833 TFLOP/s fp32-equivalent; `frac_of_f32_mfma_peak` is given too).  `traffic` =
+                  fabric-side bytes per launch from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over a replay
+                  of the trunk's launches (profiles/r03_conv_traffic_summary.json; a PMC pass over the whole step does not
+                  finish); `traffic_algorithmic` = input + weights + output bytes of those launches.
+  roofline_gemm-- the same for every matrix product of the step: mh_gemm_planes on ready plane images (fc6/fc7 of the RoI
+                  heads fwd / dgrad / wgrad), the generic mh_gemm_f32 calls (operand preparation inside the call) and the
+                  one skinny in-loop-split product.
+  hbm_kernels  -- the HBM-bound kernels of the step, each as algorithmic bytes / HIP-event time against the 8 TB/s peak:
+                  RoIAlign forward, the activation converter (fp32 -> plane image, with the fused 2x2 pool), the operand
+                  preparation of the GEMMs, the fused clip + SGD step; and the latency-bound ones in microseconds per
+                  call: the persistent highway-LSTM layer launches.
   cpu_baseline -- the CPU oracle (oracle/model.py, "port") timed on this host: the same cfg2 step at b = 6 (1 warm-up +
                   3 timed iterations) and the cfg1 PredCls evaluation (1 image per step), rank 0 at N=1 only.
   --config cfgN-- secondary rows for the other BASELINE.json configurations (see `secondary`).
@@ -40,7 +44,8 @@ for p in (ROOT, os.path.join(ROOT, 'neural-motifs_amd')):
 
 PEAK_FP32_MFMA_TFLOPS = 157.3          # /opt/skills/guides/MI355X_MICROARCH.md chip table (f32-input MFMA)
 PEAK_BF16_MFMA_TFLOPS = 2500.0         # same table, dense bf16 MFMA
-TRAFFIC_SUMMARY = 'profiles/r02_conv_traffic_summary.json'   # tools/traffic_summary.py (f16x3 build, shipped schedule)
+TRAFFIC_SUMMARY = 'profiles/r03_conv_traffic_summary.json'   # tools/r03/traffic_summary.py (plane trunk, shipped schedule)
+PEAK_HBM_TBS = 8.0                     # same table, HBM3E
 MODEL_KW = dict(hidden_dim=512, pooling_dim=4096, nl_obj=2, nl_edge=2, order='leftright', rec_dropout=0.1,
                 use_bias=True, pass_in_obj_feats_to_decoder=False, pass_in_obj_feats_to_edge=False, use_tanh=False,
                 limit_vision=False)
@@ -49,12 +54,13 @@ BATCH, N_BOXES, N_RELS = 6, 20, 30
 
 class KernelMeter(object):
     """HIP-event timing of every call of one binding function (events recorded on the stream the kernel is launched
-    on) plus its algorithmic FLOPs.  `flops_of(args, kwargs, result)` -> float."""
+    on) plus its algorithmic work.  `work_of(args, kwargs, result)` -> flops, or (flops, bytes)."""
 
-    def __init__(self, hip, name, flops_of):
-        self.hip, self.name, self.orig, self.flops_of = hip, name, getattr(hip, name), flops_of
+    def __init__(self, hip, name, work_of, obj=None):
+        self.hip, self.name, self.work_of = hip if obj is None else obj, name, work_of
+        self.orig = getattr(self.hip, name)
         self.records, self.enabled = [], False
-        setattr(hip, name, self)
+        setattr(self.hip, name, self)
 
     def __call__(self, *args, **kwargs):
         if not self.enabled:
@@ -63,16 +69,32 @@ class KernelMeter(object):
         s.record()
         y = self.orig(*args, **kwargs)
         e.record()
-        self.records.append((s, e, self.flops_of(args, kwargs, y)))
+        w = self.work_of(args, kwargs, y)
+        self.records.append((s, e) + (tuple(w) if isinstance(w, tuple) else (w, 0.0)))
         return y
 
     def summary(self):
         torch.cuda.synchronize()
-        ms = sum(s.elapsed_time(e) for s, e, _ in self.records)
-        flops = sum(f for _, _, f in self.records)
+        ms = sum(s.elapsed_time(e) for s, e, _, _ in self.records)
+        flops = sum(r[2] for r in self.records)
+        nbytes = sum(r[3] for r in self.records)
         n = max(len(self.records), 1)
-        return dict(launches=len(self.records), avg_ms=ms / n, total_ms=ms, flops_per_launch=flops / n,
-                    tflops=(flops / (ms * 1e-3) / 1e12) if ms > 0 else 0.0)
+        return dict(launches=len(self.records), avg_ms=ms / n, total_ms=ms, flops_per_launch=flops / n, flops=flops,
+                    bytes=nbytes, tflops=(flops / (ms * 1e-3) / 1e12) if ms > 0 else 0.0,
+                    gbps=(nbytes / (ms * 1e-3) / 1e9) if ms > 0 else 0.0)
+
+
+def merge(*sums):
+    """one summary over several meters (same kernel class)"""
+    out = dict(launches=0, total_ms=0.0, flops=0.0, bytes=0.0)
+    for m in sums:
+        for k in out:
+            out[k] += m[k]
+    n = max(out['launches'], 1)
+    out['avg_ms'], out['flops_per_launch'] = out['total_ms'] / n, out['flops'] / n
+    out['tflops'] = out['flops'] / (out['total_ms'] * 1e-3) / 1e12 if out['total_ms'] > 0 else 0.0
+    out['gbps'] = out['bytes'] / (out['total_ms'] * 1e-3) / 1e9 if out['total_ms'] > 0 else 0.0
+    return out
 
 
 def _conv_flops(args, kwargs, y):
@@ -81,9 +103,76 @@ def _conv_flops(args, kwargs, y):
     return 2.0 * B * H * W * Cin * wt.shape[1] * 9
 
 
+def _plconv_flops(args, kwargs, y):
+    img, cout = args[0], args[2]
+    return 2.0 * img.B * img.H * img.W * img.C * cout * 9
+
+
 def _gemm_flops(args, kwargs, y):
     a = args[0]
     return 2.0 * y.shape[0] * y.shape[1] * (a.shape[0] if (args[2] if len(args) > 2 else kwargs.get('trans_a', False)) else a.shape[1])
+
+
+def _gemm_planes_flops(args, kwargs, y):
+    return 2.0 * args[0].rows * args[1].rows * args[0].K
+
+
+def _roi_bytes(args, kwargs, y):
+    feat = args[0]                              # algorithmic: the output written once + the feature map read once
+    return 0.0, 4.0 * (y.numel() + feat.numel())
+
+
+def _act_planes_bytes(args, kwargs, y):
+    x = args[0]                                 # fp32 in (read once) + plane image out (4 B per output element)
+    return 0.0, 4.0 * x.numel() + 4.0 * y.B * y.H * y.W * y.C
+
+
+def _make_planes_bytes(args, kwargs, y):
+    x = args[0]                                 # read once + one 4 B/element image per orientation written
+    return 0.0, 4.0 * x.numel() * (1 + (2 if isinstance(y, tuple) else 1))
+
+
+def install_meters(_hip):
+    from lib.optim import FusedClipSGD
+    m = dict(
+        plconv=KernelMeter(_hip, 'plconv3x3', _plconv_flops), conv=KernelMeter(_hip, 'conv3x3_nhwc', _conv_flops),
+        gemm_planes=KernelMeter(_hip, 'gemm_planes', _gemm_planes_flops), gemm=KernelMeter(_hip, 'gemm', _gemm_flops),
+        gemm_inloop=KernelMeter(_hip, 'gemm_inloop', _gemm_flops),
+        roi=KernelMeter(_hip, 'roi_align_fwd', _roi_bytes), act=KernelMeter(_hip, 'act_planes', _act_planes_bytes),
+        planes=KernelMeter(_hip, 'make_planes', _make_planes_bytes), planes_both=KernelMeter(_hip, 'make_planes_both', _make_planes_bytes),
+        lstm_fwd=KernelMeter(_hip, 'hwlstm_fwd', lambda a, k, y: 0.0), lstm_bwd=KernelMeter(_hip, 'hwlstm_bwd', lambda a, k, y: 0.0),
+    )
+    return m
+
+
+def set_meters(meters, on):
+    for v in meters.values():
+        v.enabled = on
+
+
+def hbm_rows(meters, steps, opt_ms=None, opt_bytes=None):
+    """the HBM-bound / latency-bound kernels of the step as roofline rows"""
+    rows = {}
+    def row(name, summ, what):
+        if summ['launches']:
+            rows[name] = {'bound': 'hbm', 'what': what, 'achieved': summ['gbps'], 'peak': PEAK_HBM_TBS * 1e3, 'unit': 'GB/s',
+                          'frac': summ['gbps'] / (PEAK_HBM_TBS * 1e3), 'launches_per_step': summ['launches'] / steps,
+                          'ms_per_step': summ['total_ms'] / steps, 'bytes_per_step': summ['bytes'] / steps}
+    row('roi_align_fwd', meters['roi'].summary(), 'RoIAlign 7x7 forward (objects + union boxes): output bytes + feature map once')
+    row('act_planes', meters['act'].summary(), 'fp32 NHWC -> plane image (2x2 pool fused where the trunk has one): bytes in + bytes out')
+    row('make_planes', merge(meters['planes'].summary(), meters['planes_both'].summary()),
+        'GEMM operand preparation (row maxima + split, both orientations from one read where both are needed): read once + images written')
+    if opt_ms is not None:
+        rows['fused_clip_sgd'] = {'bound': 'hbm', 'what': 'global-norm clip + SGD(momentum, wd) over all trainable parameters: 20 B/param',
+                                  'achieved': opt_bytes / (opt_ms * 1e-3) / 1e9, 'peak': PEAK_HBM_TBS * 1e3, 'unit': 'GB/s',
+                                  'frac': opt_bytes / (opt_ms * 1e-3) / 1e9 / (PEAK_HBM_TBS * 1e3), 'ms_per_step': opt_ms}
+    for k, what in (('lstm_fwd', 'persistent highway-LSTM forward (all layers of one context LSTM, grid barrier per step)'),
+                    ('lstm_bwd', 'persistent highway-LSTM backward')):
+        sm = meters[k].summary()
+        if sm['launches']:
+            rows[k] = {'bound': 'latency', 'what': what, 'us_per_call': 1e3 * sm['avg_ms'], 'calls_per_step': sm['launches'] / steps,
+                       'ms_per_step': sm['total_ms'] / steps}
+    return rows
 
 
 def cpu_baseline(ds, model_sd, iters=3, eval_images=3, budget_s=150.0):
@@ -159,8 +248,7 @@ def secondary(args, rank, world, dev):
     cfg_id = int(cfg[3])
     seed = 1234 + 100 * cfg_id + rank
     np.random.seed(seed)
-    meter = KernelMeter(_hip, 'conv3x3_nhwc', _conv_flops)
-    gmeter = KernelMeter(_hip, 'gemm', _gemm_flops)
+    meters = install_meters(_hip)
     extra = {}
     if cfg == 'cfg4':
         from lib.object_detector import ObjectDetector
@@ -261,13 +349,13 @@ def secondary(args, rank, world, dev):
     for i in range(args.warmup):
         step(i)
     barrier()
-    meter.enabled = gmeter.enabled = True
+    set_meters(meters, True)
     t0 = time.time()
     for i in range(args.steps):
         step(args.warmup + i)
     barrier()
     dt = time.time() - t0
-    meter.enabled = gmeter.enabled = False
+    set_meters(meters, False)
     tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
     if world > 1:
         torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
@@ -276,7 +364,8 @@ def secondary(args, rank, world, dev):
         _hip.check_faults()
         split = _hip.lib().mh_mfma_split()
         peak = PEAK_BF16_MFMA_TFLOPS / split if split else PEAK_FP32_MFMA_TFLOPS
-        c, g = meter.summary(), gmeter.summary()
+        c = merge(meters['plconv'].summary(), meters['conv'].summary())
+        g = merge(meters['gemm_planes'].summary(), meters['gemm'].summary(), meters['gemm_inloop'].summary())
         dom, dom_name = (g, 'gemm_kernel (relation-head / RoI-head / 1x1-conv GEMMs)') if g['total_ms'] >= c['total_ms'] else \
             (c, 'conv3x3_nhwc_kernel (implicit GEMM)')
         line = {'metric': unit_name, 'value': world * per_step * args.steps / dt, 'unit': 'img/s', 'n_gpus': world,
@@ -288,7 +377,8 @@ def secondary(args, rank, world, dev):
                              'frac': dom['tflops'] / peak, 'traffic': None, 'ms_per_step': dom['total_ms'] / args.steps,
                              'launches': dom['launches']},
                 'kernels': {'conv3x3': {'tflops': c['tflops'], 'ms_per_step': c['total_ms'] / args.steps, 'launches': c['launches']},
-                            'gemm': {'tflops': g['tflops'], 'ms_per_step': g['total_ms'] / args.steps, 'launches': g['launches']}}}
+                            'gemm': {'tflops': g['tflops'], 'ms_per_step': g['total_ms'] / args.steps, 'launches': g['launches']}},
+                'hbm_kernels': hbm_rows(meters, args.steps)}
         print(json.dumps(line), flush=True)
     if world > 1:
         torch.distributed.destroy_process_group()
@@ -342,8 +432,8 @@ def main():
     blobs = [make_blob(ds, range(i * BATCH, (i + 1) * BATCH), is_train=True) for i in range(n_img // BATCH)]
     for b in blobs:
         b.scatter()                                           # inputs resident in HBM before the timed region
-    meter = KernelMeter(_hip, 'conv3x3_nhwc', _conv_flops)
-    gmeter = KernelMeter(_hip, 'gemm', _gemm_flops)
+    meters = install_meters(_hip)
+    opt_events = []
 
     def step(i):
         res = model[blobs[i % len(blobs)]]
@@ -358,7 +448,13 @@ def main():
         reducer.prepare()
         loss.backward()                  # N > 1: each 32 MB gradient bucket is all-reduced (RCCL) as soon as it is complete
         reducer.finish()
+        if meters['roi'].enabled:
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev[0].record()
         opt.step(max_norm=5.0)           # global-norm clip (5.0) + SGD(momentum, wd) in three multi-tensor launches
+        if meters['roi'].enabled:
+            ev[1].record()
+            opt_events.append(ev)
         return loss
 
     def barrier():
@@ -369,13 +465,13 @@ def main():
     for i in range(args.warmup):
         step(i)
     barrier()
-    meter.enabled = gmeter.enabled = True
+    set_meters(meters, True)
     t0 = time.time()
     for i in range(args.steps):
         loss = step(args.warmup + i)
     barrier()
     dt = time.time() - t0
-    meter.enabled = gmeter.enabled = False
+    set_meters(meters, False)
     tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
     if world > 1:
         torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
@@ -431,8 +527,10 @@ def main():
                          % (['%.2f' % h for h in hs], 1e3 * dt / args.steps, buf.getvalue()))
 
     if rank == 0:
-        conv = meter.summary()
-        gm = gmeter.summary()
+        plc, c2 = meters['plconv'].summary(), meters['conv'].summary()
+        conv = merge(plc, c2)
+        gpl, gg, gi = meters['gemm_planes'].summary(), meters['gemm'].summary(), meters['gemm_inloop'].summary()
+        gm = merge(gpl, gg, gi)
         _hip.check_faults()
         # `achieved` counts ALGORITHMIC fp32 flops (2*M*N*K of the convolution).  The peak is the matrix-core peak for
         # the way this build evaluates an fp32 product: six bf16 MFMAs per product (bf16x6, fp32-accurate) or the
@@ -451,7 +549,7 @@ def main():
         if os.path.exists(tpath) and _hip.lib().mh_split_f16():   # collected on the f16x3 build, on exactly these 14 launches
             with open(tpath) as f:
                 traffic = json.load(f)
-            if traffic.get('launches') * args.steps != conv['launches']:
+            if traffic.get('launches') * args.steps != plc['launches']:
                 traffic = None                               # another launch mix: the offline figure does not apply
         line = {
             'metric': 'images/sec MotifNet-SGCls fwd+bwd', 'value': world * BATCH * args.steps / dt, 'unit': 'img/s',
@@ -460,26 +558,35 @@ def main():
             'config': {'workload': 'SGCls MotifNet VGG16 train step (fwd+bwd+clip+SGD), order=leftright, nl_obj=2, '
                                    'nl_edge=2, hidden 512, batch 6/GPU, 20 GT boxes/img, <=256 rel rows/img, 592x592',
                        'global_batch': world * BATCH, 'parallelism': 'dp%d' % world, 'final_loss': float(loss.item())},
-            'roofline': {'bound': 'mfma', 'kernel': 'conv3x3_nhwc_kernel (implicit GEMM: 12 VGG trunk layers + union tower fwd / dgrad per step); ' + how,
+            'roofline': {'bound': 'mfma', 'kernel': 'pl::conv3x3_kernel (implicit GEMM on pre-split plane images: the 12 VGG trunk layers) + conv3x3_nhwc_kernel '
+                                                    '(union tower fwd / dgrad); ' + how,
                          'achieved': conv['tflops'], 'peak': peak, 'unit': 'TFLOP/s',
                          'frac': conv['tflops'] / peak, 'traffic': traffic['bytes_per_launch'] if traffic else None,
                          'traffic_unit': 'bytes per launch (L2 fabric side: HBM + Infinity-Cache)',
                          'traffic_algorithmic': traffic['algorithmic_bytes_per_launch'] if traffic else None,
                          'traffic_source': TRAFFIC_SUMMARY + ' (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over one '
-                                           'launch per shape of this step with the shipped f16x3 library, tools/traffic_run.sh + tools/traffic_summary.py; '
-                                           'replayed offline: a PMC pass over the whole step does not finish)',
+                                           'launch per trunk layer of this step with the shipped library, tools/r03/traffic.sh; replayed offline: a '
+                                           'PMC pass over the whole step does not finish); covers the 12 pl::conv3x3_kernel launches',
                          'frac_of_f32_mfma_peak': conv['tflops'] / PEAK_FP32_MFMA_TFLOPS,
                          'frac_of_bf16x6_peak': conv['tflops'] / (PEAK_BF16_MFMA_TFLOPS / 6.0),
                          'launches': conv['launches'], 'avg_launch_ms': conv['avg_ms'],
-                         'flops_per_launch': conv['flops_per_launch']},
+                         'flops_per_launch': conv['flops_per_launch'],
+                         'trunk_only': {'tflops': plc['tflops'], 'frac': plc['tflops'] / peak, 'ms_per_step': plc['total_ms'] / args.steps,
+                                        'launches': plc['launches']}},
         }
         line['roofline_gemm'] = {
-            'bound': 'mfma', 'kernel': 'gemm_kernel (fc6/fc7 x3 fwd+dgrad+wgrad, LSTM input projections, heads): every '
-                                       'mh_gemm_f32 call of the step, split-K reduces included',
+            'bound': 'mfma', 'kernel': 'pl::gemm_kernel: every matrix product of the step -- mh_gemm_planes on ready plane images (fc6/fc7 of the '
+                                       'RoI heads: fwd, dgrad, wgrad), generic mh_gemm_f32 calls (operand preparation inside the call), the skinny '
+                                       'in-loop-split product; split-K reduces included',
             'achieved': gm['tflops'], 'peak': peak, 'unit': 'TFLOP/s', 'frac': gm['tflops'] / peak,
             'launches': gm['launches'], 'ms_per_step': gm['total_ms'] / args.steps,
             'flops_per_step': gm['flops_per_launch'] * gm['launches'] / args.steps,
+            'products_on_images': {'tflops': gpl['tflops'], 'frac': gpl['tflops'] / peak, 'ms_per_step': gpl['total_ms'] / args.steps,
+                                   'launches': gpl['launches']},
             'note': 'HIP-event time of the calls; some run concurrently with the other HIP stream (context branch)'}
+        opt_ms = sum(a.elapsed_time(b) for a, b in opt_events) / max(len(opt_events), 1) if opt_events else None
+        n_train = sum(p.numel() for p in model.parameters() if p.requires_grad)
+        line['hbm_kernels'] = hbm_rows(meters, args.steps, opt_ms, 20.0 * n_train)
         line['roofline']['ms_per_step'] = conv['total_ms'] / args.steps
         if sd_cpu is not None:
             try:

@@ -179,6 +179,17 @@ int mh_plconv3x3(const void *in_image, int B, int H, int W, int Cin, const void 
                  int epilogue, float *out, unsigned *out_maxbits, void *workspace, size_t ws_bytes, void *stream);
 int mh_conv_first_nchw_max(const float *in_nchw, int B, int Cin, int H, int W, const float *w, int Cout,
                            const float *bias, int epilogue, float *out_nhwc, unsigned *maxbits, void *stream);
+/* The same convolutions with an IMAGE output: the epilogue splits what it computed and writes the next layer's activation
+ * image itself (mh_act_planes_bytes(B, H, W, Cout)) -- no fp32 tensor, no converter pass.  The image's per-image scale comes
+ * from the bound |y| <= max|x_b| * max_n sum|w_n| + max|bias| (the true maximum is not known before the data is written);
+ * in_true_maxbits [B] = the TRUE per-image maxima of the input as reported by its producer, out_maxbits [B] (zero on entry)
+ * receives the true maxima of the output for the next layer's bound.
+ *   mh_stem_to_image: conv1_1 (NCHW image, Cin <= 4, B <= 32) straight to the image conv1_2 reads. */
+int mh_plconv3x3_to_image(const void *in_image, const unsigned *in_true_maxbits, int B, int H, int W, int Cin,
+                          const void *packed, int Cout, const float *bias, int epilogue, void *out_image,
+                          unsigned *out_maxbits, void *workspace, size_t ws_bytes, void *stream);
+int mh_stem_to_image(const float *in_nchw, int B, int Cin, int H, int W, const float *w, int Cout, const float *bias,
+                     int epilogue, void *out_image, unsigned *out_maxbits, void *stream);
 void mh_debug_plconv_shape(int shape);
 
 /* ---------------------------------------------------------------------------------------------

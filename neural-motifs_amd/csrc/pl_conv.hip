@@ -111,6 +111,25 @@ __global__ __launch_bounds__(256) void weight_maxbits_kernel(const float *__rest
     }
     if (threadIdx.x == 0) bits[n] = red[0];
 }
+// wnorm = max over output channels n of sum |w_n| (one block per n, float bits are monotone for non-negative values)
+__global__ __launch_bounds__(256) void weight_norm_kernel(const float *__restrict__ w, int N, int K, int flip_transpose, int src_cin,
+                                                          unsigned *__restrict__ wnorm_bits)
+{
+    __shared__ float red[256];
+    const int n = blockIdx.x;
+    float a = 0.f;
+    for (int i = threadIdx.x; i < 9 * K; i += 256) {
+        const int k = i / 9, tap = i % 9;
+        a += fabsf(flip_transpose ? w[((size_t)k * src_cin + n) * 9 + tap] : w[((size_t)n * src_cin + k) * 9 + tap]);
+    }
+    red[threadIdx.x] = a;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) atomicMax(wnorm_bits, __float_as_uint(red[0] * 1.0001f));      // a hair above the rounded sum
+}
 __global__ void pack_weight_kernel(const float *__restrict__ w, int N, int K, int flip_transpose, int src_cin,
                                    const unsigned *__restrict__ bits, unsigned *__restrict__ cells)
 {
@@ -141,8 +160,12 @@ struct ConvArgs {
     int Cout;
     const float *bias;
     int epilogue;
-    float *out;                // [Mtot][Cout]
-    unsigned *out_bits;        // [B], zero before the launch (may be nullptr)
+    float *out;                // [Mtot][Cout] fp32 NHWC, or nullptr when the output is written as an image:
+    char *out_cells;           // [Cout/16][Mtot][64] activation image of the output (epilogue splits it itself), or nullptr
+    unsigned *out_scale_bits;  // [B] behind out_cells: the bound whose exponent scales image b (written by block 0)
+    const unsigned *in_true_bits;   // [B] TRUE largest |x| per input image (== in_bits when the input image came from mh_act_planes)
+    const float *wnorm;        // max over output channels of sum |w| (packed weights' tail): |y| <= max|x| * wnorm + max|bias|
+    unsigned *out_bits;        // [B] TRUE largest |y| per image, zero before the launch (may be nullptr)
     int tiles_m, tiles_n;
     // tile schedule (conv.hip: ConvArgs has the long explanation): blocks [0, tail_tiles * tail_slices) = the leftover tiles
     // cut into K slices; then body_tiles * splitk blocks of whole (or uniformly split) tiles
@@ -152,8 +175,12 @@ struct ConvArgs {
     float *partial, *partial_tail;
 };
 
+constexpr int kStageOff = 4096;       // LDS offset of the image epilogue's staging (behind the exponent tables)
 template <class S>
-__global__ __launch_bounds__(kThreads, 2) void conv3x3_kernel(const ConvArgs p)
+constexpr int conv_lds_bytes() { return S::lds_bytes > kStageOff + 4 * 4096 * S::sn ? S::lds_bytes : kStageOff + 4 * 4096 * S::sn; }
+
+template <class S, bool IMG>      // IMG: the output is written as an activation image (p.out_cells), else fp32 NHWC (p.out)
+__global__ __launch_bounds__(kThreads, (S::bm * S::bn <= 128 * 128) ? 3 : 2) void conv3x3_kernel(const ConvArgs p)
 {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -237,14 +264,34 @@ __global__ __launch_bounds__(kThreads, 2) void conv3x3_kernel(const ConvArgs p)
     }
     if (kt < kt_end) k_step<S>(issue, st, cp, fp, b0, b1, acc);
 
-    // exponents of this tile's rows (their image's) and columns
+    // exponents of this tile's rows (their image's) and columns; with an image output also the OUTPUT exponent of every
+    // row's image, from the bound |y| <= max|x_b| * wnorm + max|bias| (the true maximum of y is not known before it is
+    // written; the bound costs a few bits of the two-term split's 2^18 dynamic window, never an overflow)
     int *ex = reinterpret_cast<int *>(lds);
+    unsigned *red = reinterpret_cast<unsigned *>(lds) + 2 * S::bm + S::bn;
+    float bmax = 0.f;
+    if (IMG) {
+        unsigned m = 0;
+        if (p.bias)
+            for (int n = tid; n < p.Cout; n += kThreads) m = max(m, __float_as_uint(p.bias[n]) & 0x7fffffffu);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o));
+        if (lane == 0) red[wave] = m;
+        __syncthreads();
+        bmax = __uint_as_float(max(max(red[0], red[1]), max(red[2], red[3])));
+    }
+    auto bound_bits = [&](int b) { return __float_as_uint(__uint_as_float(p.in_true_bits[b]) * p.wnorm[0] + bmax); };
     for (int i = tid; i < S::bm + S::bn; i += kThreads) {
         int e = 0;
-        if (i < S::bm) { if (m0 + i < Mtot) e = row_exponent(p.in_bits[(m0 + i) / HW]); }
-        else if (n0 + (i - S::bm) < p.Cout) e = row_exponent(p.wt_bits[n0 + (i - S::bm)]);
+        if (i < S::bm) {
+            if (m0 + i < Mtot) {
+                e = row_exponent(p.in_bits[(m0 + i) / HW]);
+                if (IMG) ex[S::bm + S::bn + i] = row_exponent(bound_bits((int)((m0 + i) / HW)));
+            } else if (IMG) ex[S::bm + S::bn + i] = 0;
+        } else if (n0 + (i - S::bm) < p.Cout) e = row_exponent(p.wt_bits[n0 + (i - S::bm)]);
         ex[i] = e;
     }
+    if (IMG && blockIdx.x == 0 && tid < p.B) p.out_scale_bits[tid] = bound_bits(tid);
     __syncthreads();
     int ecol[S::sn];
     float bcol[S::sn];
@@ -270,11 +317,7 @@ __global__ __launch_bounds__(kThreads, 2) void conv3x3_kernel(const ConvArgs p)
     const int b_lo = (int)(m0 / HW), b_hi = (int)(last_row / HW);
     const int split = (int)min((long long)S::bm, (long long)(b_lo + 1) * HW - m0);     // first tile row of the next image
     unsigned vlo = 0, vhi = 0;
-    acc_foreach<S>(acc, wm, wn, lane, [&](int r, int c, int sn, float v) {
-        const long long row = m0 + r;
-        if (row >= Mtot || n0 + c >= p.Cout) return;
-        v = conv_epi(__builtin_ldexpf(v, -(ex[r] + ecol[sn])) + bcol[sn], p.epilogue);
-        p.out[(size_t)row * p.Cout + n0 + c] = v;
+    auto track = [&](int r, long long row, float v) {
         const unsigned bits = __float_as_uint(v) & 0x7fffffffu;
         if (b_hi - b_lo <= 1) { if (r < split) vlo = max(vlo, bits); else vhi = max(vhi, bits); }
         else if (p.out_bits) {
@@ -283,7 +326,59 @@ __global__ __launch_bounds__(kThreads, 2) void conv3x3_kernel(const ConvArgs p)
             for (int o = 16; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o));
             if ((lane & 31) == 0 && m) atomicMax(p.out_bits + row / HW, m);
         }
-    });
+    };
+    if (!IMG) {
+        acc_foreach<S>(acc, wm, wn, lane, [&](int r, int c, int sn, float v) {
+            const long long row = m0 + r;
+            if (row >= Mtot || n0 + c >= p.Cout) return;
+            v = conv_epi(__builtin_ldexpf(v, -(ex[r] + ecol[sn])) + bcol[sn], p.epilogue);
+            p.out[(size_t)row * p.Cout + n0 + c] = v;
+            track(r, row, v);
+        });
+    } else {
+        // The output leaves the block AS the next layer's activation image: no fp32 round trip through HBM, no converter pass.
+        // Per 32-row sub-tile a wave turns its values into (h1, h2) halves scaled by the image's exponent, pairs neighbouring
+        // columns into dwords through one lane shuffle, lays them out as cells in its private LDS region and copies the cells
+        // out with 16-byte stores (1 KB contiguous per instruction: the 64-byte cells of consecutive pixels are adjacent).
+        char *stg = lds + kStageOff + wave * (4096 * S::sn);
+        const int j = lane & 31, g = lane >> 5;
+        const int *eo = ex + S::bm + S::bn;
+        const long long chunk0 = (n0 + wn) / kBK;
+#pragma unroll
+        for (int sm = 0; sm < S::sm; ++sm) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int rr = (r & 3) + 8 * (r >> 2) + 4 * g, tr = wm + 32 * sm + rr;
+                const long long row = m0 + tr;
+#pragma unroll
+                for (int sn = 0; sn < S::sn; ++sn) {
+                    float v = conv_epi(__builtin_ldexpf(acc.v[sm][sn][r], -(ex[tr] + ecol[sn])) + bcol[sn], p.epilogue);
+                    if (row >= Mtot || n0 + wn + 32 * sn + j >= p.Cout) v = 0.f;
+                    track(tr, row, v);
+                    const float ys = __builtin_ldexpf(v, eo[tr]);
+                    const _Float16 h1 = (_Float16)ys;
+                    const _Float16 h2 = (_Float16)(ys - (float)h1);
+                    const unsigned mine = (unsigned)__builtin_bit_cast(unsigned short, h1) | ((unsigned)__builtin_bit_cast(unsigned short, h2) << 16);
+                    const unsigned other = (unsigned)__shfl_xor((int)mine, 1);
+                    // even column lane: h1 of (me, right neighbour); odd column lane: h2 of (left neighbour, me)
+                    const unsigned dw = (j & 1) ? ((other >> 16) | (mine & 0xffff0000u)) : ((mine & 0xffffu) | (other << 16));
+                    char *cell = stg + ((2 * sn + (j >> 4)) * 32 + rr) * kCell;
+                    *reinterpret_cast<unsigned *>(cell + ((j & 1) ? 32 : 0) + 4 * ((j & 15) >> 1)) = dw;
+                }
+                __builtin_amdgcn_sched_barrier(0);      // one row at a time: keeps the epilogue inside the main loop's register budget
+            }
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < 4 * S::sn; ++i) {
+                const int q = lane + 64 * i, cc = q >> 7, rr = (q & 127) >> 2, c16 = q & 3;
+                const long long row = m0 + wm + 32 * sm + rr, chunk = chunk0 + cc;
+                if (row < Mtot && chunk * kBK < p.Cout)
+                    *reinterpret_cast<u32x4 *>(p.out_cells + ((size_t)chunk * Mtot + row) * kCell + 16 * c16) =
+                        *reinterpret_cast<const u32x4 *>(stg + (cc * 32 + rr) * kCell + 16 * c16);
+            }
+            __syncthreads();
+        }
+    }
     if (p.out_bits && b_hi - b_lo <= 1) {
         wave_atomic_max(p.out_bits, b_lo, vlo);
         if (b_hi > b_lo) wave_atomic_max(p.out_bits, b_hi, vhi);
@@ -320,6 +415,136 @@ __global__ __launch_bounds__(256) void reduce_kernel(const float *__restrict__ p
         vmax = max(vmax, __float_as_uint(v) & 0x7fffffffu);
     }
     if (out_bits) wave_atomic_max(out_bits, cur < 0 ? 0 : cur, cur < 0 ? 0u : vmax);
+}
+
+// the same reduction with an IMAGE output: thread = (row, 16-channel chunk), 256 consecutive rows of one chunk per block step
+// (64-byte reads per slice, 16 KB contiguous writes); the image's exponents come from the bound the conv kernel's block 0
+// left in scale_bits (stream order)
+__global__ __launch_bounds__(256) void reduce_planes_kernel(const float *__restrict__ partial, int nslices, long long rows, int N,
+                                                            char *__restrict__ out_cells, long long Mtot, const float *__restrict__ bias,
+                                                            int epilogue, long long row0, long long HW,
+                                                            const unsigned *__restrict__ scale_bits, unsigned *__restrict__ out_bits)
+{
+    const int G = N / kBK;
+    const size_t plane = (size_t)rows * N;
+    const long long nblk_m = (rows + 255) / 256;
+    int cur = -1;
+    unsigned vmax = 0;
+    const long long per_block = (nblk_m * G + gridDim.x - 1) / gridDim.x;
+    for (long long blk = blockIdx.x * per_block; blk < min(nblk_m * G, (blockIdx.x + 1) * per_block); ++blk) {
+        const int g = (int)(blk / nblk_m);
+        const long long r = (blk % nblk_m) * 256 + threadIdx.x;
+        if (r >= rows) continue;
+        float v[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) v[i] = bias ? bias[g * kBK + i] : 0.f;
+        for (int z = 0; z < nslices; ++z) {
+            const float4 *q = reinterpret_cast<const float4 *>(partial + z * plane + (size_t)r * N + g * kBK);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { const float4 a = q[i]; v[4 * i] += a.x; v[4 * i + 1] += a.y; v[4 * i + 2] += a.z; v[4 * i + 3] += a.w; }
+        }
+        const int b = (int)((row0 + r) / HW);
+        if (b != cur) {
+            if (cur >= 0 && vmax && out_bits) atomicMax(out_bits + cur, vmax);
+            cur = b;
+            vmax = 0;
+        }
+        const int e = row_exponent(scale_bits[b]);
+        unsigned h1[8], h2[8];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { v[i] = conv_epi(v[i], epilogue); vmax = max(vmax, __float_as_uint(v[i]) & 0x7fffffffu); }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) split2(v[2 * i], v[2 * i + 1], e, h1[i], h2[i]);
+        u32x4 *dst = reinterpret_cast<u32x4 *>(out_cells + ((size_t)g * Mtot + row0 + r) * kCell);
+        dst[0] = (u32x4){h1[0], h1[1], h1[2], h1[3]};
+        dst[1] = (u32x4){h1[4], h1[5], h1[6], h1[7]};
+        dst[2] = (u32x4){h2[0], h2[1], h2[2], h2[3]};
+        dst[3] = (u32x4){h2[4], h2[5], h2[6], h2[7]};
+    }
+    if (out_bits) wave_atomic_max(out_bits, cur < 0 ? 0 : cur, cur < 0 ? 0u : vmax);
+}
+
+// ------------------------------------------------------------------------------------------------- the stem: conv1_1
+// NCHW image (Cin = 3) -> activation IMAGE of the 64-channel output, bias + ReLU fused: the layer is write-bound (1.2 GFLOP
+// against 90 MB written per 592x592 image), so it stays on the VALU -- one thread = one pixel x one 16-channel chunk = exactly
+// one 64-byte cell -- but it now writes what conv1_2 reads (no fp32 tensor, no converter pass).  Weights live in LDS as
+// [tap * Cin][Cout]; the image exponents come from the bound max|x_b| * max_n sum|w_n| + max|bias| (in_bits = per-image
+// largest |pixel|, from a row-maxima pass over the 25 MB input).
+__global__ __launch_bounds__(256) void stem_kernel(const float *__restrict__ in, int B, int Cin, int H, int W, const float *__restrict__ w, int Cout,
+                                                   const float *__restrict__ bias, int epilogue, const unsigned *__restrict__ in_bits,
+                                                   char *__restrict__ out_cells, unsigned *__restrict__ scale_bits, unsigned *__restrict__ out_bits)
+{
+    extern __shared__ __attribute__((aligned(16))) float wl[];  // [9*Cin][Cout] + bias[Cout] + colsum[Cout]
+    const int K = 9 * Cin;
+    for (int i = threadIdx.x; i < K * Cout; i += blockDim.x) {
+        const int co = i % Cout, k = i / Cout, tap = k / Cin, ci = k % Cin;
+        wl[i] = w[((size_t)co * Cin + ci) * 9 + tap];
+    }
+    float *bl = wl + K * Cout, *cs = bl + Cout;
+    for (int i = threadIdx.x; i < Cout; i += blockDim.x) bl[i] = bias ? bias[i] : 0.f;
+    __syncthreads();
+    for (int co = threadIdx.x; co < Cout; co += blockDim.x) {
+        float a = 0.f;
+        for (int k = 0; k < K; ++k) a += fabsf(wl[k * Cout + co]);
+        cs[co] = a;
+    }
+    __syncthreads();
+    float wnorm = 0.f, bmax = 0.f;
+    for (int co = 0; co < Cout; ++co) { wnorm = fmaxf(wnorm, cs[co]); bmax = fmaxf(bmax, fabsf(bl[co])); }
+    auto bound_bits = [&](int b) { return __float_as_uint(__uint_as_float(in_bits[b]) * wnorm + bmax); };
+    if (blockIdx.x == 0 && (int)threadIdx.x < B) scale_bits[threadIdx.x] = bound_bits(threadIdx.x);
+    const int G = Cout / kBK;
+    const long long M = (long long)B * H * W, nblk_m = (M + 255) / 256;
+    int cur = -1, e = 0;
+    unsigned vmax = 0;
+    const long long per_block = (nblk_m * G + gridDim.x - 1) / gridDim.x;
+    for (long long blk = blockIdx.x * per_block; blk < min(nblk_m * G, (blockIdx.x + 1) * per_block); ++blk) {
+        const int g = (int)(blk % G);                       // the G chunks of a pixel block run back to back: inputs hit L1
+        const long long pix = (blk / G) * 256 + threadIdx.x;
+        if (pix >= M) continue;
+        const int x = (int)(pix % W), y = (int)((pix / W) % H), b = (int)(pix / ((long long)W * H));
+        if (b != cur) {
+            if (cur >= 0 && vmax && out_bits) atomicMax(out_bits + cur, vmax);
+            cur = b;
+            vmax = 0;
+            e = row_exponent(bound_bits(b));
+        }
+        float acc[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) acc[j] = bl[g * kBK + j];
+        for (int ci = 0; ci < Cin; ++ci) {
+            const float *plane = in + ((size_t)b * Cin + ci) * H * W;
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                const int yy = y + tap / 3 - 1, xx = x + tap % 3 - 1;
+                float v = 0.f;
+                if ((unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W) v = plane[(size_t)yy * W + xx];
+                const float *wr = wl + (tap * Cin + ci) * Cout + g * kBK;
+#pragma unroll
+                for (int j = 0; j < 16; ++j) acc[j] = fmaf(v, wr[j], acc[j]);
+            }
+        }
+        unsigned h1[8], h2[8];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) { acc[j] = conv_epi(acc[j], epilogue); vmax = max(vmax, __float_as_uint(acc[j]) & 0x7fffffffu); }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) split2(acc[2 * j], acc[2 * j + 1], e, h1[j], h2[j]);
+        u32x4 *dst = reinterpret_cast<u32x4 *>(out_cells + ((size_t)g * M + pix) * kCell);
+        dst[0] = (u32x4){h1[0], h1[1], h1[2], h1[3]};
+        dst[1] = (u32x4){h1[4], h1[5], h1[6], h1[7]};
+        dst[2] = (u32x4){h2[0], h2[1], h2[2], h2[3]};
+        dst[3] = (u32x4){h2[4], h2[5], h2[6], h2[7]};
+    }
+    if (out_bits) wave_atomic_max(out_bits, cur < 0 ? 0 : cur, cur < 0 ? 0u : vmax);
+}
+
+// largest |x| per image of a [B][n] fp32 tensor (bits[B] zero on entry): grid (chunks, B)
+__global__ __launch_bounds__(256) void image_absmax_kernel(const float *__restrict__ x, long long n, unsigned *__restrict__ bits)
+{
+    const float *p = x + (size_t)blockIdx.y * n;
+    unsigned m = 0;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) m = max(m, __float_as_uint(p[i]) & 0x7fffffffu);
+    wave_atomic_max(bits, (int)blockIdx.y, m);
 }
 
 typedef Shape<256, 128, 4, 2> S256x128;
@@ -389,7 +614,7 @@ int mh_act_planes(const float *x, const unsigned *maxbits, int B, int H, int W, 
 size_t mh_plconv_packed_bytes(int Cout, int Cin)
 {
     if (Cout <= 0 || Cin <= 0 || Cin % pl::kBK) return 0;
-    return align_up(pl::wt_cells_bytes(Cout, Cin), 256) + align_up((size_t)Cout * 4, 256);
+    return align_up(pl::wt_cells_bytes(Cout, Cin), 256) + align_up((size_t)Cout * 4, 256) + 256;      // cells | maxbits[Cout] | wnorm
 }
 
 int mh_plconv_pack_weight(const float *w, int Cout, int Cin, int flip_transpose, void *packed, void *stream)
@@ -401,6 +626,12 @@ int mh_plconv_pack_weight(const float *w, int Cout, int Cin, int flip_transpose,
     unsigned *bits = reinterpret_cast<unsigned *>(reinterpret_cast<char *>(packed) + align_up(pl::wt_cells_bytes(N, K), 256));
     hipLaunchKernelGGL(pl::weight_maxbits_kernel, dim3(N), dim3(256), 0, as_stream(stream), w, N, K, flip_transpose, Cin, bits);
     int rc = check_launch("pl::weight_maxbits_kernel");
+    if (rc) return rc;
+    unsigned *wnorm = reinterpret_cast<unsigned *>(reinterpret_cast<char *>(bits) + align_up((size_t)N * 4, 256));
+    hipError_t e = hipMemsetAsync(wnorm, 0, 256, as_stream(stream));
+    if (e != hipSuccess) { set_last_error("hipMemsetAsync(wnorm)", e); return (int)e; }
+    hipLaunchKernelGGL(pl::weight_norm_kernel, dim3(N), dim3(256), 0, as_stream(stream), w, N, K, flip_transpose, Cin, wnorm);
+    rc = check_launch("pl::weight_norm_kernel");
     if (rc) return rc;
     const long long total = 9LL * (K / pl::kBK) * N * 16;
     hipLaunchKernelGGL(pl::pack_weight_kernel, dim3((unsigned)std::min<long long>((total + 255) / 256, 4096)), dim3(256), 0,
@@ -418,24 +649,29 @@ size_t mh_plconv3x3_ws_bytes(int B, int H, int W, int Cin, int Cout)
     return body + tail;
 }
 
-// out [B,H,W,Cout] fp32 = epi(conv3x3(in image, packed weights) + bias); out_maxbits [B] (optional) receives the largest |out|
-// per image -- it must be ZERO before the call (atomicMax)
-int mh_plconv3x3(const void *in_image, int B, int H, int W, int Cin, const void *packed, int Cout, const float *bias,
-                 int epilogue, float *out, unsigned *out_maxbits, void *workspace, size_t ws_bytes, void *stream)
+static int plconv_impl(const void *in_image, const unsigned *in_true_maxbits, int B, int H, int W, int Cin, const void *packed,
+                       int Cout, const float *bias, int epilogue, float *out, void *out_image, unsigned *out_maxbits,
+                       void *workspace, size_t ws_bytes, void *stream)
 {
-    MH_REQUIRE(in_image && packed && out && B > 0 && H > 0 && W > 0);
+    MH_REQUIRE(in_image && packed && (out || out_image) && B > 0 && B <= 256 && H > 0 && W > 0);
     MH_REQUIRE(Cin > 0 && Cin % pl::kBK == 0 && Cout > 0 && Cout % 4 == 0);
-    MH_REQUIRE(((reinterpret_cast<uintptr_t>(in_image) | reinterpret_cast<uintptr_t>(packed) | reinterpret_cast<uintptr_t>(out)) & 15) == 0);
+    MH_REQUIRE(!out_image || (Cout % pl::kBK == 0 && in_true_maxbits));
+    MH_REQUIRE(((reinterpret_cast<uintptr_t>(in_image) | reinterpret_cast<uintptr_t>(packed) | reinterpret_cast<uintptr_t>(out) |
+                 reinterpret_cast<uintptr_t>(out_image)) & 15) == 0);
     const long long M = (long long)B * H * W;
     MH_REQUIRE(pl::act_cells_bytes(M, Cin) + (size_t)(2 * (W + 1) + 256) * pl::kCell < (size_t)0x7ff00000u &&
                pl::wt_cells_bytes(Cout, Cin) < (size_t)0x7ff00000u);
     pl::ConvArgs p;
     p.in = reinterpret_cast<const char *>(in_image);
     p.in_bits = reinterpret_cast<const unsigned *>(p.in + align_up(pl::act_cells_bytes(M, Cin), 256));
+    p.in_true_bits = in_true_maxbits ? in_true_maxbits : p.in_bits;
     p.B = B; p.H = H; p.W = W; p.Cin = Cin;
     p.wt = reinterpret_cast<const char *>(packed);
     p.wt_bits = reinterpret_cast<const unsigned *>(p.wt + align_up(pl::wt_cells_bytes(Cout, Cin), 256));
+    p.wnorm = reinterpret_cast<const float *>(reinterpret_cast<const char *>(p.wt_bits) + align_up((size_t)Cout * 4, 256));
     p.Cout = Cout; p.bias = bias; p.epilogue = epilogue; p.out = out; p.out_bits = out_maxbits;
+    p.out_cells = reinterpret_cast<char *>(out_image);
+    p.out_scale_bits = out_image ? reinterpret_cast<unsigned *>(p.out_cells + align_up(pl::act_cells_bytes(M, Cout), 256)) : nullptr;
     pl::Sched sc = pl::schedule(M, Cin, Cout);
     size_t body_bytes, tail_bytes;
     pl::partial_bytes(sc, M, Cin, Cout, body_bytes, tail_bytes);
@@ -458,13 +694,25 @@ int mh_plconv3x3(const void *in_image, int B, int H, int W, int Cin, const void 
     MH_REQUIRE(nblocks > 0 && nblocks < (1LL << 31));
     hipStream_t st = as_stream(stream);
     const dim3 grid((unsigned)nblocks);
-    if (sc.shape == 0) pl::launch<pl::conv3x3_kernel<pl::S256x128>>(grid, pl::S256x128::lds_bytes, st, p);
-    else if (sc.shape == 1) pl::launch<pl::conv3x3_kernel<pl::S128x128>>(grid, pl::S128x128::lds_bytes, st, p);
-    else pl::launch<pl::conv3x3_kernel<pl::S256x64>>(grid, pl::S256x64::lds_bytes, st, p);
+    if (out_image) {
+        if (sc.shape == 0) pl::launch<pl::conv3x3_kernel<pl::S256x128, true>>(grid, pl::conv_lds_bytes<pl::S256x128>(), st, p);
+        else if (sc.shape == 1) pl::launch<pl::conv3x3_kernel<pl::S128x128, true>>(grid, pl::conv_lds_bytes<pl::S128x128>(), st, p);
+        else pl::launch<pl::conv3x3_kernel<pl::S256x64, true>>(grid, pl::conv_lds_bytes<pl::S256x64>(), st, p);
+    } else {
+        if (sc.shape == 0) pl::launch<pl::conv3x3_kernel<pl::S256x128, false>>(grid, pl::S256x128::lds_bytes, st, p);
+        else if (sc.shape == 1) pl::launch<pl::conv3x3_kernel<pl::S128x128, false>>(grid, pl::S128x128::lds_bytes, st, p);
+        else pl::launch<pl::conv3x3_kernel<pl::S256x64, false>>(grid, pl::S256x64::lds_bytes, st, p);
+    }
     int rc = check_launch("pl::conv3x3_kernel");
     if (rc) return rc;
     const long long HW = (long long)H * W;
     auto reduce = [&](const float *part, int slices, long long rows, long long row0) {
+        if (out_image) {
+            const long long nblk = ((rows + 255) / 256) * (Cout / pl::kBK);
+            hipLaunchKernelGGL(pl::reduce_planes_kernel, dim3((unsigned)std::min<long long>(nblk, 256 * 8)), dim3(256), 0, st, part, slices, rows,
+                               Cout, p.out_cells, M, bias, epilogue, row0, HW, p.out_scale_bits, out_maxbits);
+            return check_launch("pl::reduce_planes_kernel");
+        }
         const long long total = rows * Cout;
         hipLaunchKernelGGL(pl::reduce_kernel, dim3((unsigned)std::min<long long>((total + 255) / 256, 256 * 8)), dim3(256), 0, st, part,
                            slices, rows, Cout, out + (size_t)row0 * Cout, bias, epilogue, row0, HW, out_maxbits);
@@ -473,6 +721,53 @@ int mh_plconv3x3(const void *in_image, int B, int H, int W, int Cin, const void 
     if (p.splitk > 1 && p.tail_row0 > 0) rc = reduce(p.partial, p.splitk, p.tail_row0, 0);
     if (!rc && p.tail_tiles > 0 && p.tail_slices > 1) rc = reduce(p.partial_tail, p.tail_slices, M - p.tail_row0, p.tail_row0);
     return rc;
+}
+
+// out [B,H,W,Cout] fp32 = epi(conv3x3(in image, packed weights) + bias); out_maxbits [B] (optional) receives the largest |out|
+// per image -- it must be ZERO before the call (atomicMax)
+int mh_plconv3x3(const void *in_image, int B, int H, int W, int Cin, const void *packed, int Cout, const float *bias,
+                 int epilogue, float *out, unsigned *out_maxbits, void *workspace, size_t ws_bytes, void *stream)
+{
+    MH_REQUIRE(out);
+    return plconv_impl(in_image, nullptr, B, H, W, Cin, packed, Cout, bias, epilogue, out, nullptr, out_maxbits, workspace, ws_bytes, stream);
+}
+
+// the same conv whose output leaves the kernel AS the next layer's activation image (mh_act_planes_bytes(B, H, W, Cout)): no
+// fp32 tensor, no converter pass.  in_true_maxbits [B] = the TRUE per-image maxima of the input (what its producer reported:
+// the image's own scale may be a looser bound); out_maxbits as above.
+int mh_plconv3x3_to_image(const void *in_image, const unsigned *in_true_maxbits, int B, int H, int W, int Cin, const void *packed,
+                          int Cout, const float *bias, int epilogue, void *out_image, unsigned *out_maxbits, void *workspace,
+                          size_t ws_bytes, void *stream)
+{
+    MH_REQUIRE(out_image && in_true_maxbits);
+    return plconv_impl(in_image, in_true_maxbits, B, H, W, Cin, packed, Cout, bias, epilogue, nullptr, out_image, out_maxbits, workspace,
+                       ws_bytes, stream);
+}
+
+// conv1_1: NCHW image (Cin <= 4) -> activation image of [B,H,W,Cout], bias + activation fused (csrc/pl_conv.hip: stem_kernel);
+// out_maxbits [B] zero on entry.  B <= 32 (the input's per-image maxima borrow the unused part of the image's tail).
+int mh_stem_to_image(const float *in_nchw, int B, int Cin, int H, int W, const float *w, int Cout, const float *bias, int epilogue,
+                     void *out_image, unsigned *out_maxbits, void *stream)
+{
+    MH_REQUIRE(in_nchw && w && out_image && B > 0 && B <= 32 && Cin > 0 && Cin <= 4 && H > 0 && W > 0 && Cout > 0 && Cout % pl::kBK == 0);
+    MH_REQUIRE((reinterpret_cast<uintptr_t>(out_image) & 255) == 0);
+    const long long M = (long long)B * H * W;
+    MH_REQUIRE(pl::act_cells_bytes(M, Cout) < (size_t)0x7ff00000u);
+    const size_t lds = ((size_t)9 * Cin * Cout + 2 * Cout) * sizeof(float);
+    MH_REQUIRE(lds <= 64 * 1024);
+    hipStream_t st = as_stream(stream);
+    char *cells = reinterpret_cast<char *>(out_image);
+    unsigned *scale = reinterpret_cast<unsigned *>(cells + align_up(pl::act_cells_bytes(M, Cout), 256));
+    unsigned *in_bits = scale + 32;                       // scratch behind the B scale words (the tail is >= 256 bytes)
+    hipError_t e = hipMemsetAsync(in_bits, 0, 32 * sizeof(unsigned), st);
+    if (e != hipSuccess) { set_last_error("hipMemsetAsync(stem maxima)", e); return (int)e; }
+    hipLaunchKernelGGL(pl::image_absmax_kernel, dim3(64, (unsigned)B), dim3(256), 0, st, in_nchw, (long long)Cin * H * W, in_bits);
+    int rc = check_launch("pl::image_absmax_kernel");
+    if (rc) return rc;
+    const long long nblk = ((M + 255) / 256) * (Cout / pl::kBK);
+    hipLaunchKernelGGL(pl::stem_kernel, dim3((unsigned)std::min<long long>(nblk, 256 * 16)), dim3(256), lds, st, in_nchw, B, Cin, H, W, w, Cout,
+                       bias, epilogue, in_bits, cells, scale, out_maxbits);
+    return check_launch("pl::stem_kernel");
 }
 
 }  // extern "C"

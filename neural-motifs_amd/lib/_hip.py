@@ -24,7 +24,7 @@ SYMBOLS = (
     'mh_gemm_ws_bytes', 'mh_gemm_auto_splitk', 'mh_gemm_f32',
     'mh_planes_bytes', 'mh_make_planes', 'mh_make_planes_both', 'mh_gemm_planes_ws_bytes', 'mh_gemm_planes_auto_splitk', 'mh_gemm_planes',
     'mh_act_planes_bytes', 'mh_act_planes', 'mh_plconv_packed_bytes', 'mh_plconv_pack_weight', 'mh_plconv3x3_ws_bytes',
-    'mh_plconv3x3', 'mh_conv_first_nchw_max', 'mh_debug_plconv_shape',
+    'mh_plconv3x3', 'mh_plconv3x3_to_image', 'mh_stem_to_image', 'mh_conv_first_nchw_max', 'mh_debug_plconv_shape',
     'mh_debug_pl_shape', 'mh_gemm_ws_bytes_v2', 'mh_gemm_auto_splitk_v2', 'mh_gemm_f32_v2',
     'mh_conv3x3_packed_floats', 'mh_conv3x3_pack_weight', 'mh_conv3x3_ws_bytes', 'mh_conv3x3_schedule', 'mh_conv3x3_nhwc',
     'mh_conv3x3_wgrad_ws_bytes', 'mh_conv3x3_wgrad', 'mh_conv_first_nchw', 'mh_maxpool2x2_nhwc',
@@ -456,6 +456,32 @@ def plconv3x3(img, packed, cout, bias, epilogue, out_maxbits=None):
                         c_size_t(ws.numel() if ws is not None else 0), stream())
     _check(rc, 'mh_plconv3x3')
     return out
+
+
+def plconv3x3_to_image(img, in_true_maxbits, packed, cout, bias, epilogue, out_maxbits):
+    """the same conv, output written AS the next layer's ActImage (no fp32 tensor); in_true_maxbits / out_maxbits: int32 [B]
+    true per-image maxima of input / output (out zeroed by the caller)"""
+    L = lib()
+    buf = torch.empty(L.mh_act_planes_bytes(img.B, img.H, img.W, cout), dtype=torch.uint8, device=img.buf.device)
+    wsb = L.mh_plconv3x3_ws_bytes(img.B, img.H, img.W, img.C, cout)
+    ws = workspace(wsb, buf.device, 'conv') if wsb else None
+    rc = L.mh_plconv3x3_to_image(ctypes.c_void_p(img.buf.data_ptr()), i32(in_true_maxbits), img.B, img.H, img.W, img.C,
+                                 ctypes.c_void_p(packed.data_ptr()), cout, f32(bias), c_int(epilogue), ctypes.c_void_p(buf.data_ptr()),
+                                 i32(out_maxbits), ptr(ws), c_size_t(ws.numel() if ws is not None else 0), stream())
+    _check(rc, 'mh_plconv3x3_to_image')
+    return ActImage(buf, img.B, img.H, img.W, cout)
+
+
+def stem_to_image(x, w, bias, epilogue, out_maxbits):
+    """conv1_1: NCHW image -> ActImage of its [B,H,W,Cout] output (bias + activation fused)"""
+    L = lib()
+    B, Cin, H, W = x.shape
+    Cout = w.shape[0]
+    buf = torch.empty(L.mh_act_planes_bytes(B, H, W, Cout), dtype=torch.uint8, device=x.device)
+    rc = L.mh_stem_to_image(f32(x), B, Cin, H, W, f32(w), Cout, f32(bias), c_int(epilogue), ctypes.c_void_p(buf.data_ptr()),
+                            i32(out_maxbits), stream())
+    _check(rc, 'mh_stem_to_image')
+    return ActImage(buf, B, H, W, Cout)
 
 
 def conv_first_nchw_max(x, w, bias, epilogue, maxbits):

@@ -322,14 +322,32 @@ class VGG16Features(nn.Sequential):
             nconv = sum(isinstance(m, Conv3x3) for m in mods)
             mb = torch.zeros(nconv, B, dtype=torch.int32, device=x.device)     # per-layer, per-image |y| maxima (fp32 bits)
             first = mods[0]
-            y = _hip.conv_first_nchw_max(_c(x), _c(first.weight), first.bias, EPI_RELU, mb[0])
+            direct = os.environ.get('MOTIFS_TRUNK_DIRECT', '1') != '0' and B <= 32
+            # a layer that is NOT followed by a pool hands its output to the next one as a plane image straight from its
+            # epilogue (no fp32 tensor, no converter); a layer in front of a pool (and the last one) writes fp32 NHWC and the
+            # pool happens inside the converter of the next layer's input
+            def pool_follows(idx):
+                return idx + 2 < len(mods) and isinstance(mods[idx + 2], MaxPool2x2)
+            is_last = lambda idx: idx + 2 >= len(mods)
+            y = img = None
+            if direct and not pool_follows(0):
+                img = _hip.stem_to_image(_c(x), _c(first.weight), first.bias, EPI_RELU, mb[0])
+            else:
+                y = _hip.conv_first_nchw_max(_c(x), _c(first.weight), first.bias, EPI_RELU, mb[0])
             i, layer, pool = 2, 0, False
             while i < len(mods):
                 m = mods[i]
                 if isinstance(m, Conv3x3):
-                    img = _hip.act_planes(y, mb[layer], pool=pool)
-                    layer, pool = layer + 1, False
-                    y = _hip.plconv3x3(img, m.plane_weight(), m.out_channels, m.bias.detach(), EPI_RELU, mb[layer])
+                    if img is None:
+                        img = _hip.act_planes(y, mb[layer], pool=pool)
+                    pool = False
+                    if direct and not pool_follows(i) and not is_last(i):
+                        img, y = _hip.plconv3x3_to_image(img, mb[layer], m.plane_weight(), m.out_channels, m.bias.detach(), EPI_RELU,
+                                                         mb[layer + 1]), None
+                    else:
+                        y = _hip.plconv3x3(img, m.plane_weight(), m.out_channels, m.bias.detach(), EPI_RELU, mb[layer + 1])
+                        img = None
+                    layer += 1
                     i += 2                      # its ReLU is fused
                 elif isinstance(m, MaxPool2x2):
                     pool = True                 # folded into the next layer's converter

@@ -112,6 +112,14 @@ def install():
             out_maxbits.copy_(y.abs().amax(dim=(1, 2, 3)).view(torch.int32))
         return y
 
+    def plconv3x3_to_image(img, in_true_maxbits, packed, cout, bias, epilogue, out_maxbits):
+        y = plconv3x3(img, packed, cout, bias, epilogue, out_maxbits)
+        return _hip.ActImage(y, y.shape[0], y.shape[1], y.shape[2], y.shape[3])
+
+    def stem_to_image(x, w, bias, epilogue, out_maxbits):
+        y = conv_first_nchw_max(x, w, bias, epilogue, out_maxbits)
+        return _hip.ActImage(y, y.shape[0], y.shape[1], y.shape[2], y.shape[3])
+
     def conv_first_nchw(x, w, bias, epilogue):
         y = F.conv2d(x, w, bias, padding=1)
         y = {0: y, 1: F.relu(y), 2: F.relu6(y)}[epilogue]

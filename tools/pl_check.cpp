@@ -367,6 +367,86 @@ static int conv_case(const char *name, int B, int H, int W, int Cin, int Cout, i
     return bad;
 }
 
+typedef int (*plconv_img_fn)(const void *, const unsigned *, int, int, int, int, const void *, int, const float *, int, void *, unsigned *, void *, size_t, void *);
+typedef int (*stem_img_fn)(const float *, int, int, int, int, const float *, int, const float *, int, void *, unsigned *, void *);
+typedef int (*stem_max_fn)(const float *, int, int, int, int, const float *, int, const float *, int, float *, unsigned *, void *);
+static plconv_img_fn plconv_img;
+static stem_img_fn stem_img;
+static stem_max_fn stem_max;
+
+// image-output epilogue: [stem ->] conv A (image out) -> conv B (fp32 out)  against  the same chain through fp32 tensors and
+// the converter; both are f16x3 evaluations of the same math, so they agree to a few 1e-6 of the result's rms
+static int chain_case(const char *name, int B, int H, int W, int C0, int C1, int C2, bool with_stem, unsigned seed)
+{
+    std::mt19937 rng(seed);
+    std::normal_distribution<float> nrm(0.f, 1.f);
+    const size_t M = (size_t)B * H * W;
+    std::vector<float> x(with_stem ? (size_t)B * 3 * H * W : M * C0), ws_((size_t)C0 * 27), bs(C0), wa((size_t)C1 * C0 * 9), ba(C1), wb((size_t)C2 * C1 * 9), bb(C2);
+    for (size_t i = 0; i < x.size(); ++i) { const float v = nrm(rng) * (1.f + 2.f * ((i / (x.size() / B)) % 3)); x[i] = with_stem ? v : (v > 0 ? v : 0.f); }
+    for (auto &v : ws_) v = nrm(rng) * 0.2f;
+    for (auto &v : bs) v = nrm(rng) * 0.1f;
+    for (auto &v : wa) v = nrm(rng) * 0.05f;
+    for (auto &v : ba) v = nrm(rng) * 0.1f;
+    for (auto &v : wb) v = nrm(rng) * 0.05f;
+    for (auto &v : bb) v = nrm(rng) * 0.1f;
+    Dev dx(x.size() * 4), dws(ws_.size() * 4), dbs(C0 * 4), dwa(wa.size() * 4), dba(C1 * 4), dwb(wb.size() * 4), dbb(C2 * 4);
+    HIP_OK(hipMemcpy(dx.p, x.data(), x.size() * 4, hipMemcpyHostToDevice));
+    HIP_OK(hipMemcpy(dws.p, ws_.data(), ws_.size() * 4, hipMemcpyHostToDevice)); HIP_OK(hipMemcpy(dbs.p, bs.data(), C0 * 4, hipMemcpyHostToDevice));
+    HIP_OK(hipMemcpy(dwa.p, wa.data(), wa.size() * 4, hipMemcpyHostToDevice)); HIP_OK(hipMemcpy(dba.p, ba.data(), C1 * 4, hipMemcpyHostToDevice));
+    HIP_OK(hipMemcpy(dwb.p, wb.data(), wb.size() * 4, hipMemcpyHostToDevice)); HIP_OK(hipMemcpy(dbb.p, bb.data(), C2 * 4, hipMemcpyHostToDevice));
+    Dev pka(plpacked_bytes(C1, C0)), pkb(plpacked_bytes(C2, C1));
+    int rc = plpack(dwa.f(), C1, C0, 0, pka.p, nullptr) | plpack(dwb.f(), C2, C1, 0, pkb.p, nullptr);
+    Dev mb(3 * B * 4), mb2(3 * B * 4);
+    HIP_OK(hipMemset(mb.p, 0, mb.n)); HIP_OK(hipMemset(mb2.p, 0, mb2.n));
+    unsigned *m0 = (unsigned *)mb.p, *m1 = m0 + B, *m2 = m1 + B, *n0_ = (unsigned *)mb2.p, *n1 = n0_ + B, *n2 = n1 + B;
+    Dev y0(M * C0 * 4), y1(M * C1 * 4), outA(M * C2 * 4), outB(M * C2 * 4);
+    Dev img0(act_bytes(B, H, W, C0)), img1(act_bytes(B, H, W, C1)), jmg0(act_bytes(B, H, W, C0)), jmg1(act_bytes(B, H, W, C1));
+    Dev wsa(plconv_ws(B, H, W, C0, C1)), wsb(plconv_ws(B, H, W, C1, C2));
+    // path 1: through fp32 tensors + converters
+    if (with_stem) {
+        rc |= stem_max(dx.f(), B, 3, H, W, dws.f(), C0, dbs.f(), 1, y0.f(), m0, nullptr);
+        rc |= act_planes(y0.f(), m0, B, H, W, C0, 0, img0.p, nullptr);
+    } else {
+        std::vector<unsigned> hb(B, 0);
+        for (int b = 0; b < B; ++b) for (size_t i = 0; i < (size_t)H * W * C0; ++i) hb[b] = std::max(hb[b], fbits(x[(size_t)b * H * W * C0 + i]));
+        HIP_OK(hipMemcpy(m0, hb.data(), B * 4, hipMemcpyHostToDevice)); HIP_OK(hipMemcpy(n0_, hb.data(), B * 4, hipMemcpyHostToDevice));
+        rc |= act_planes(dx.f(), m0, B, H, W, C0, 0, img0.p, nullptr);
+    }
+    rc |= plconv(img0.p, B, H, W, C0, pka.p, C1, dba.f(), 1, y1.f(), m1, wsa.p, wsa.n, nullptr);
+    rc |= act_planes(y1.f(), m1, B, H, W, C1, 0, img1.p, nullptr);
+    rc |= plconv(img1.p, B, H, W, C1, pkb.p, C2, dbb.f(), 1, outA.f(), m2, wsb.p, wsb.n, nullptr);
+    // path 2: image outputs
+    const void *in2 = img0.p;
+    if (with_stem) { rc |= stem_img(dx.f(), B, 3, H, W, dws.f(), C0, dbs.f(), 1, jmg0.p, n0_, nullptr); in2 = jmg0.p; }
+    int bad = 0;
+    for (int shape = -1; shape <= 2; ++shape) {
+        set_conv_shape(shape);
+        HIP_OK(hipMemset(n1, 0, B * 4)); HIP_OK(hipMemset(n2, 0, B * 4));
+        Dev wsa2(plconv_ws(B, H, W, C0, C1)), wsb2(plconv_ws(B, H, W, C1, C2));
+        int r2 = plconv_img(in2, n0_, B, H, W, C0, pka.p, C1, dba.f(), 1, jmg1.p, n1, wsa2.p, wsa2.n, nullptr);
+        r2 |= plconv(jmg1.p, B, H, W, C1, pkb.p, C2, dbb.f(), 1, outB.f(), n2, wsb2.p, wsb2.n, nullptr);
+        HIP_OK(hipDeviceSynchronize());
+        std::vector<float> A(M * C2), Bv(M * C2);
+        std::vector<unsigned> ma(3 * B), mbv(3 * B);
+        HIP_OK(hipMemcpy(A.data(), outA.p, A.size() * 4, hipMemcpyDeviceToHost)); HIP_OK(hipMemcpy(Bv.data(), outB.p, Bv.size() * 4, hipMemcpyDeviceToHost));
+        HIP_OK(hipMemcpy(ma.data(), mb.p, ma.size() * 4, hipMemcpyDeviceToHost)); HIP_OK(hipMemcpy(mbv.data(), mb2.p, mbv.size() * 4, hipMemcpyDeviceToHost));
+        double ss = 0, se = 0, mx = 0;
+        for (size_t i = 0; i < A.size(); ++i) { const double e = (double)A[i] - Bv[i]; ss += (double)A[i] * A[i]; se += e * e; mx = std::fmax(mx, std::fabs(e)); }
+        const double rms = std::sqrt(ss / A.size()) + 1e-300;
+        int mdiff = 0;      // true maxima of the middle layer agree up to the two evaluations' rounding
+        for (int b = 0; b < B; ++b) { float fa, fb; memcpy(&fa, &ma[B + b], 4); memcpy(&fb, &mbv[B + b], 4); mdiff += std::fabs(fa - fb) > 1e-5 * std::fabs(fa); }
+        const bool ok = (rc | r2) == 0 && std::sqrt(se / A.size()) / rms < 3e-6 && mx / rms < 6e-5 && mdiff == 0;
+        bad += !ok;
+        printf("{\"check\": \"conv image output\", \"case\": \"%s\", \"B\": %d, \"H\": %d, \"W\": %d, \"C\": [%d, %d, %d], \"stem\": %d, \"shape\": %d, \"rc\": %d, "
+               "\"rms_rel\": %.3g, \"max_rel\": %.3g, \"mid_maxima_differ\": %d, \"ok\": %s}\n", name, B, H, W, C0, C1, C2, with_stem ? 1 : 0, shape, rc | r2,
+               std::sqrt(se / A.size()) / rms, mx / rms, mdiff, ok ? "true" : "false");
+        if (rc | r2) printf("{\"error\": \"%s\"}\n", last_err());
+        fflush(stdout);
+    }
+    set_conv_shape(-1);
+    return bad;
+}
+
 static void conv_speed(const char *name, int B, int H, int W, int Cin, int Cout, int pool_in_front, int iters)
 {
     const int Hi = pool_in_front ? 2 * H : H, Wi = pool_in_front ? 2 * W : W;
@@ -419,7 +499,35 @@ int main(int argc, char **argv)
     v2conv_ws = (sz5_fn)dlsym(h, "mh_conv3x3_ws_bytes"); act_planes = (actpl_fn)dlsym(h, "mh_act_planes"); plpack = (plpack_fn)dlsym(h, "mh_plconv_pack_weight");
     plconv = (plconv_fn)dlsym(h, "mh_plconv3x3"); v2pack = (v2pack_fn)dlsym(h, "mh_conv3x3_pack_weight"); v2conv = (v2conv_fn)dlsym(h, "mh_conv3x3_nhwc");
     set_conv_shape = (shape_fn)dlsym(h, "mh_debug_plconv_shape");
-    if (!act_bytes || !plpacked_bytes || !v2packed_floats || !plconv_ws || !v2conv_ws || !act_planes || !plpack || !plconv || !v2pack || !v2conv || !set_conv_shape) { printf("missing conv symbol\n"); return 2; }
+    plconv_img = (plconv_img_fn)dlsym(h, "mh_plconv3x3_to_image"); stem_img = (stem_img_fn)dlsym(h, "mh_stem_to_image"); stem_max = (stem_max_fn)dlsym(h, "mh_conv_first_nchw_max");
+    if (!act_bytes || !plpacked_bytes || !v2packed_floats || !plconv_ws || !v2conv_ws || !act_planes || !plpack || !plconv || !v2pack || !v2conv || !set_conv_shape || !plconv_img || !stem_img || !stem_max) { printf("missing conv symbol\n"); return 2; }
+    if (argc > 2 && !strcmp(argv[2], "--conv-replay")) {
+        // the 12 trunk launches of one bench step (b = 6, 592x592), each once: the target of the rocprofv3 --pmc FETCH_SIZE /
+        // WRITE_SIZE passes behind bench.py's roofline.traffic (tools/r03/traffic.sh); prints the algorithmic bytes per launch
+        struct L { const char *name; int H, Cin, Cout, pool; } layers[] = {
+            {"conv1_2", 592, 64, 64, 0}, {"conv2_1", 296, 64, 128, 1}, {"conv2_2", 296, 128, 128, 0}, {"conv3_1", 148, 128, 256, 1},
+            {"conv3_2", 148, 256, 256, 0}, {"conv3_3", 148, 256, 256, 0}, {"conv4_1", 74, 256, 512, 1}, {"conv4_2", 74, 512, 512, 0},
+            {"conv4_3", 74, 512, 512, 0}, {"conv5_1", 37, 512, 512, 1}, {"conv5_2", 37, 512, 512, 0}, {"conv5_3", 37, 512, 512, 0}};
+        const int B = 6;
+        for (const L &l : layers) {
+            const int Hi = l.pool ? 2 * l.H : l.H;
+            const size_t nx = (size_t)B * Hi * Hi * l.Cin;
+            Dev dx(nx * 4), dw((size_t)l.Cout * l.Cin * 9 * 4), db(l.Cout * 4), dmb(B * 4), dmbo(B * 4), dout((size_t)B * l.H * l.H * l.Cout * 4);
+            fill_dev(dx.f(), nx, 3); fill_dev(dw.f(), (size_t)l.Cout * l.Cin * 9, 5); fill_dev(db.f(), l.Cout, 6);
+            std::vector<unsigned> mb(B, fbits(6.0f));
+            HIP_OK(hipMemcpy(dmb.p, mb.data(), B * 4, hipMemcpyHostToDevice));
+            HIP_OK(hipMemset(dmbo.p, 0, B * 4));
+            Dev img(act_bytes(B, l.H, l.H, l.Cin)), pk(plpacked_bytes(l.Cout, l.Cin)), ws3(plconv_ws(B, l.H, l.H, l.Cin, l.Cout));
+            plpack(dw.f(), l.Cout, l.Cin, 0, pk.p, nullptr);
+            act_planes(dx.f(), (const unsigned *)dmb.p, B, Hi, Hi, l.Cin, l.pool, img.p, nullptr);
+            plconv(img.p, B, l.H, l.H, l.Cin, pk.p, l.Cout, db.f(), 1, dout.f(), (unsigned *)dmbo.p, ws3.p, ws3.n, nullptr);
+            HIP_OK(hipDeviceSynchronize());
+            const double M = (double)B * l.H * l.H;
+            printf("{\"layer\": \"%s\", \"H\": %d, \"Cin\": %d, \"Cout\": %d, \"algorithmic_read_bytes\": %.0f, \"algorithmic_write_bytes\": %.0f, \"flops\": %.0f}\n",
+                   l.name, l.H, l.Cin, l.Cout, 4.0 * (M * l.Cin + 9.0 * l.Cin * l.Cout), 4.0 * M * l.Cout, 2.0 * 9 * l.Cin * l.Cout * M);
+        }
+        return 0;
+    }
     if (argc > 2 && !strcmp(argv[2], "--conv")) {
         int badc = 0;
         badc += conv_case("small", 3, 20, 20, 32, 64, 0, true, 31);
@@ -428,6 +536,11 @@ int main(int argc, char **argv)
         badc += conv_case("conv5 (split-K)", 6, 37, 37, 512, 512, 0, false, 34);
         badc += conv_case("conv4 pooled (tail slices)", 6, 74, 74, 256, 512, 1, false, 35);
         badc += conv_case("conv2 pooled", 2, 296, 296, 64, 128, 1, false, 36);
+        badc += chain_case("small", 3, 20, 20, 32, 64, 128, false, 41);
+        badc += chain_case("ragged rows, Cout 64", 2, 23, 19, 64, 64, 64, false, 42);
+        badc += chain_case("stem", 3, 24, 31, 64, 64, 128, true, 43);
+        badc += chain_case("conv5-like (split-K)", 6, 37, 37, 512, 512, 512, false, 44);
+        badc += chain_case("conv4-like (tail slices)", 6, 74, 74, 256, 512, 256, false, 45);
         printf("{\"check\": \"conv summary\", \"failed\": %d}\n", badc);
         if (argc > 3 && !strcmp(argv[3], "--speed")) {
             conv_speed("conv1_2", 6, 592, 592, 64, 64, 0, 5);
