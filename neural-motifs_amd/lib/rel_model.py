@@ -204,7 +204,7 @@ class RelModel(nn.Module):
                  embed_dim=200, hidden_dim=256, pooling_dim=2048, nl_obj=1, nl_edge=2, use_resnet=False,
                  order='confidence', thresh=0.01, use_proposals=False, pass_in_obj_feats_to_decoder=True,
                  pass_in_obj_feats_to_edge=True, rec_dropout=0.0, use_bias=True, use_tanh=True, limit_vision=True,
-                 max_per_img=64, freq_counts=None):
+                 max_per_img=64, freq_counts=None, resnet_obj_fmap=None):
         """Arguments as in the reference (lib/rel_model.py:303-308) plus two additions: `max_per_img` (the reference
         hard-codes 64, :345; BASELINE cfg5 needs 80) and `freq_counts=(fg_matrix, bg_matrix)` to inject the
         predicate statistics instead of scanning the dataset at construction time."""
@@ -214,17 +214,20 @@ class RelModel(nn.Module):
         self.num_gpus = num_gpus
         assert mode in MODES
         self.mode = mode
-        if use_resnet:
-            # The reference cannot run this configuration either: with use_resnet it never creates `roi_fmap_obj`
+        self.use_resnet = use_resnet
+        if use_resnet and resnet_obj_fmap != 'layer4':
+            # The reference cannot run this configuration: with use_resnet it never creates `roi_fmap_obj`
             # (lib/rel_model.py:360-365) but obj_feature_map uses it unconditionally (:448) -> AttributeError on the
-            # first forward.  There is therefore no reference behaviour to be identical to (BASELINE cfg4); the
-            # ResNet-101 *detector* (ObjectDetector(use_resnet=True), lib/resnet.py) is built and parity-tested.
+            # first forward.  DRAFT (branch draft/resnet-relmodel): `resnet_obj_fmap='layer4'` is the documented repair --
+            # the object branch gets its own copy of the layer4 stack, exactly as the VGG branch has its own fc6 / fc7 copy.
             raise NotImplementedError('RelModel(use_resnet=True) is broken in the reference itself '
-                                      '(rel_model.py:360-365 vs :448); use the ResNet detector on its own')
+                                      "(rel_model.py:360-365 vs :448); pass resnet_obj_fmap='layer4' for the repaired model")
+        if use_resnet and pooling_dim != 2048:
+            raise ValueError('the ResNet relation head produces 2048 features per pair: pooling_dim must be 2048')
         self.pooling_size = 7
         self.embed_dim = embed_dim
         self.hidden_dim = hidden_dim
-        self.obj_dim = 4096
+        self.obj_dim = 2048 if use_resnet else 4096          # lib/rel_model.py:330
         self.pooling_dim = pooling_dim
         self.use_bias = use_bias
         self.use_vision = use_vision
@@ -249,14 +252,19 @@ class RelModel(nn.Module):
                                          pass_in_obj_feats_to_decoder=pass_in_obj_feats_to_decoder,
                                          pass_in_obj_feats_to_edge=pass_in_obj_feats_to_edge)
 
-        self.union_boxes = UnionBoxesAndFeats(pooling_size=self.pooling_size, stride=16, dim=512)
+        self.union_boxes = UnionBoxesAndFeats(pooling_size=self.pooling_size, stride=16, dim=1024 if use_resnet else 512)
 
-        roi_fmap = [Flattener(),
-                    load_vgg(use_dropout=False, use_relu=False, use_linear=pooling_dim == 4096).classifier]
-        if pooling_dim != 4096:
-            roi_fmap.append(Linear(4096, pooling_dim))
-        self.roi_fmap = nn.Sequential(*roi_fmap)
-        self.roi_fmap_obj = load_vgg().classifier
+        if use_resnet:
+            from lib.resnet import Layer4Stack, AvgPoolNHWC
+            self.roi_fmap = nn.Sequential(Layer4Stack(relu_end=False), AvgPoolNHWC(), Flattener())
+            self.roi_fmap_obj = nn.Sequential(Layer4Stack(relu_end=False), AvgPoolNHWC(), Flattener())   # the repair
+        else:
+            roi_fmap = [Flattener(),
+                        load_vgg(use_dropout=False, use_relu=False, use_linear=pooling_dim == 4096).classifier]
+            if pooling_dim != 4096:
+                roi_fmap.append(Linear(4096, pooling_dim))
+            self.roi_fmap = nn.Sequential(*roi_fmap)
+            self.roi_fmap_obj = load_vgg().classifier
 
         self.post_lstm = Linear(self.hidden_dim, self.pooling_dim * 2)
         self.post_lstm.weight.data.normal_(0, 10.0 * math.sqrt(1.0 / self.hidden_dim))
@@ -311,7 +319,7 @@ class RelModel(nn.Module):
 
     def obj_feature_map(self, features, rois):
         pooled = RoIAlignFunction(self.pooling_size, self.pooling_size, spatial_scale=1 / 16)(features, rois)
-        return self.roi_fmap_obj(pooled.view(rois.size(0), -1))
+        return self.roi_fmap_obj(pooled if self.use_resnet else pooled.view(rois.size(0), -1))
 
     def forward(self, x, im_sizes, image_offset, gt_boxes=None, gt_classes=None, gt_rels=None, proposals=None,
                 train_anchor_inds=None, return_fmap=False):

@@ -17,7 +17,7 @@ import torch
 import torch.nn as nn
 
 from lib import _hip
-from lib.hip_ops import _c
+from lib.hip_ops import _c, _Conv3x3Fn, linear, EPI_NONE, EPI_RELU
 
 BN_EPS = 1e-5
 BN_MOMENTUM = 0.1            # torchvision's BatchNorm2d default (the detector uses torchvision.models.resnet)
@@ -55,6 +55,14 @@ class _Conv(nn.Module):
     def forward(self, x):                       # x NHWC
         B, H, W, C = x.shape
         cout = self.weight.shape[0]
+        if torch.is_grad_enabled() and (x.requires_grad or self.weight.requires_grad):
+            # DRAFT (branch draft/resnet-relmodel): autograd path for the relation model's trainable layer4 copies --
+            # stride-1 1x1 (GEMM) and 3x3 (implicit GEMM) only, which is all layer4 at 7x7 needs
+            if self.k == 1 and self.stride == 1:
+                return linear(x.reshape(-1, C), self.weight.view(cout, C)).view(B, H, W, cout)
+            if self.k == 3 and self.stride == 1 and C % 16 == 0:
+                return _Conv3x3Fn.apply(x, self.weight, None, EPI_NONE)
+            raise NotImplementedError('trainable ResNet conv: only stride-1 1x1 / 3x3 (layer4 of the relation model)')
         d = self._derived()
         if self.k == 1:
             if self.stride != 1:
@@ -65,6 +73,29 @@ class _Conv(nn.Module):
             return _hip.conv3x3_nhwc(_c(x), d, None, 0)
         cols, Ho, Wo = _hip.im2col_nhwc(_c(x), self.k, self.k, self.stride, self.pad, ldo=d.shape[1])
         return _hip.gemm(cols, d, False, True).view(B, Ho, Wo, cout)
+
+
+class _BNFn(torch.autograd.Function):
+    """DRAFT: train-mode BatchNorm + residual + ReLU on NHWC through the HIP kernels, with its backward: the ReLU mask on
+    the saved output (mh_act_bwd), then mh_bn_bwd (dense form: gradient through the batch statistics, dgamma, dbeta);
+    the residual branch receives the masked gradient unchanged."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, residual, relu, mean, invstd):
+        x = _c(x)
+        y = _hip.bn_apply_nhwc(x, mean, invstd, gamma.detach(), beta.detach(), None if residual is None else _c(residual), relu)
+        ctx.relu, ctx.has_res = bool(relu), residual is not None
+        ctx.save_for_backward(x, gamma.detach(), mean, invstd, y if relu else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        x, gamma, mean, invstd, y = ctx.saved_tensors
+        g = _c(g)
+        if ctx.relu:
+            g = _hip.act_bwd(g, y, EPI_RELU)
+        dx, dgamma, dbeta = _hip.bn_bwd(x, g, None, mean, invstd, gamma, False)
+        return dx, dgamma, dbeta, (g if ctx.has_res else None), None, None, None
 
 
 class _BN(nn.Module):
@@ -85,6 +116,10 @@ class _BN(nn.Module):
 
     def forward(self, x, residual=None, relu=False):
         mean, invstd = self.stats(x)
+        if torch.is_grad_enabled() and (x.requires_grad or self.weight.requires_grad):
+            if not self.training:
+                raise NotImplementedError('BatchNorm backward is built for train mode (batch statistics) only')
+            return _BNFn.apply(x, self.weight, self.bias, residual, relu, mean, invstd)
         return _hip.bn_apply_nhwc(x, mean, invstd, self.weight.detach(), self.bias.detach(), residual, relu)
 
 
@@ -101,13 +136,14 @@ class Bottleneck(nn.Module):
         self.bn3 = _BN(planes * 4)
         self.downsample = downsample
         self.stride = stride
+        self.relu_end = True            # lib/resnet.py:126-131: the last block of the relation model's layer4 ends without ReLU
 
     def forward(self, x):                       # NHWC
         out = self.bn1(self.conv1(x), relu=True)
         out = self.bn2(self.conv2(out), relu=True)
         out = self.conv3(out)
         residual = x if self.downsample is None else self.downsample[1](self.downsample[0](x))
-        return self.bn3(out, residual=residual, relu=True)
+        return self.bn3(out, residual=residual, relu=self.relu_end)
 
 
 class ResNet101Trunk(nn.Module):
@@ -151,3 +187,30 @@ class ResNet101Trunk(nn.Module):
                 for block in layer:
                     y = block(y)
         return y.permute(0, 3, 1, 2)
+
+
+class Layer4Stack(nn.Sequential):
+    """DRAFT: `resnet_l4(relu_end)` of the reference (lib/resnet.py:126-133): torchvision's layer4 (3 bottlenecks, 1024 ->
+    2048) with the stride taken out of the first block, as the relation model's RoI feature extractor
+    (lib/rel_model.py:360-365).  Child names are torchvision's (`0.conv1.weight`, `0.downsample.0.weight`, ...), so
+    `roi_fmap.0.*` keys of a reference checkpoint load.  Input: RoI features [n, 1024, 7, 7] (logical NCHW); the blocks run
+    NHWC on the HIP kernels, with autograd when the parameters train."""
+
+    def __init__(self, relu_end=True):
+        down = nn.Sequential(_Conv(1024, 2048, 1), _BN(2048))
+        blocks = [Bottleneck(1024, 512, 1, down), Bottleneck(2048, 512), Bottleneck(2048, 512)]
+        blocks[-1].relu_end = relu_end
+        super(Layer4Stack, self).__init__(*blocks)
+
+    def forward(self, x):
+        y = x.permute(0, 2, 3, 1).contiguous()                  # NCHW-shaped RoI features -> NHWC
+        for block in self:
+            y = block(y)
+        return y                                                # [n, 7, 7, 2048]
+
+
+class AvgPoolNHWC(nn.Module):
+    """nn.AvgPool2d(7) + Flattener of the reference on the NHWC output of Layer4Stack: [n, 7, 7, C] -> [n, C]"""
+
+    def forward(self, x):
+        return x.mean((1, 2))

@@ -186,6 +186,23 @@ def resnet_compress(sd, fmap, training, prefix='detector.compress.'):
     return _bn(sd, y, prefix + '2.', training)
 
 
+def resnet_l4_head(sd, x, prefix, training, relu_end=False):
+    """DRAFT (branch draft/resnet-relmodel): the relation model's RoI feature extractor in the ResNet configuration,
+    nn.Sequential(resnet_l4(relu_end=False), nn.AvgPool2d(7), Flattener()) (lib/rel_model.py:360-365, lib/resnet.py:126-133):
+    torchvision's layer4 with the stride removed from block 0, the last block without its final ReLU, then the 7x7 mean.
+    x [n,1024,7,7] -> [n,2048]; `prefix` e.g. 'roi_fmap.0.'"""
+    for b in range(3):
+        p = '%s%d.' % (prefix, b)
+        last = (b == 2) and not relu_end
+        out = F.relu(_bn(sd, F.conv2d(x, sd[p + 'conv1.weight']), p + 'bn1.', training))
+        out = F.relu(_bn(sd, F.conv2d(out, sd[p + 'conv2.weight'], None, stride=1, padding=1), p + 'bn2.', training))
+        out = _bn(sd, F.conv2d(out, sd[p + 'conv3.weight']), p + 'bn3.', training)
+        if p + 'downsample.0.weight' in sd:
+            x = _bn(sd, F.conv2d(x, sd[p + 'downsample.0.weight']), p + 'downsample.1.', training)
+        x = out + x if last else F.relu(out + x)
+    return x.mean((2, 3))
+
+
 def resnet_roi_head(sd, pooled, prefix='detector.roi_fmap.'):
     """Linear -> SELU -> AlphaDropout -> Linear -> SELU -> AlphaDropout (:89-96), eval mode (dropout = identity)"""
     y = F.selu(F.linear(pooled, sd[prefix + '0.weight'], sd[prefix + '0.bias']))
@@ -240,13 +257,17 @@ def detector_forward(sd, cfg, x, im_sizes, image_offset, gt_boxes, gt_classes, t
     Returns a dict with the Result fields the RelModel reads.
     `rel_labels`: the sampled relation rows (host sampler output) for gtbox training.
     """
-    fmap = vgg_features(sd, x)
+    resnet = cfg.get('use_resnet', False)
+    fmap = resnet_features(sd, x, training) if resnet else vgg_features(sd, x)
     res = {'fmap': fmap}
     if cfg['mode'] in ('sgcls', 'predcls'):
         im_inds = gt_classes[:, 0] - image_offset
         rois = torch.cat((im_inds.float()[:, None], gt_boxes), 1)
-        obj_fmap = vgg_classifier(sd, roi_align(fmap, rois).view(rois.size(0), -1),
-                                  'detector.roi_fmap.', training, rng)
+        if resnet:      # lib/object_detector.py:129-138 with the compress conv in front of RoIAlign (:84-96), dropout = identity
+            obj_fmap = resnet_roi_head(sd, roi_align(resnet_compress(sd, fmap, training), rois).view(rois.size(0), -1))
+        else:
+            obj_fmap = vgg_classifier(sd, roi_align(fmap, rois).view(rois.size(0), -1),
+                                      'detector.roi_fmap.', training, rng)
         od_obj_dists = F.linear(obj_fmap, sd['detector.score_fc.weight'], sd['detector.score_fc.bias'])
         res.update(im_inds=rois[:, 0].long() + image_offset, rm_obj_dists=od_obj_dists,
                    od_obj_dists=od_obj_dists, rm_box_priors=rois[:, 1:], rm_obj_labels=gt_classes[:, 1],
@@ -527,7 +548,10 @@ def relmodel_forward(sd, cfg, x, im_sizes, image_offset, gt_boxes, gt_classes, t
     rel_inds = get_rel_inds(cfg, det['rel_labels'], im_inds, boxes, training)
     rois = torch.cat((im_inds[:, None].float(), boxes), 1)
     fmap = det['fmap'].detach()
-    obj_fmap = vgg_classifier(sd, roi_align(fmap, rois).view(rois.size(0), -1), 'roi_fmap_obj.', training, rng)
+    if cfg.get('use_resnet', False):    # the repaired model: the object branch owns a copy of the layer4 stack
+        obj_fmap = resnet_l4_head(sd, roi_align(fmap, rois), 'roi_fmap_obj.0.', training)
+    else:
+        obj_fmap = vgg_classifier(sd, roi_align(fmap, rois).view(rois.size(0), -1), 'roi_fmap_obj.', training, rng)
     use_labels = training or cfg['mode'] == 'predcls'
     rm_obj_dists, obj_preds, edge_ctx = context_forward(
         sd, cfg, obj_fmap, det['rm_obj_dists'].detach(), im_inds,
@@ -541,8 +565,11 @@ def relmodel_forward(sd, cfg, x, im_sizes, image_offset, gt_boxes, gt_classes, t
     prod_rep = subj_rep[rel_inds[:, 1]] * obj_rep[rel_inds[:, 2]]
     if cfg.get('use_vision', True):
         ub = union_boxes_feats(sd, fmap, rois, rel_inds[:, 1:], training)
-        vr = vgg_classifier(sd, ub.view(ub.size(0), -1), 'roi_fmap.1.', training, rng,
-                            use_dropout=False, use_relu=False)
+        if cfg.get('use_resnet', False):
+            vr = resnet_l4_head(sd, ub, 'roi_fmap.0.', training)
+        else:
+            vr = vgg_classifier(sd, ub.view(ub.size(0), -1), 'roi_fmap.1.', training, rng,
+                                use_dropout=False, use_relu=False)
         if cfg['limit_vision']:
             prod_rep = torch.cat((prod_rep[:, :2048] * vr[:, :2048], prod_rep[:, 2048:]), 1)
         else:

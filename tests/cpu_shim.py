@@ -141,6 +141,37 @@ def install():
         m = (y > 0) if epilogue == 1 else ((y > 0) & (y < 6))
         return g * m.to(g.dtype)
 
+    # ---- BatchNorm kernels (ResNet branch; DRAFT draft/resnet-relmodel) ----
+    def bn_stats(x2d, eps, momentum, running_mean=None, running_var=None):
+        M = x2d.shape[0]
+        mean = x2d.double().mean(0)
+        var = x2d.double().var(0, unbiased=False)
+        if running_mean is not None:
+            running_mean.mul_(1 - momentum).add_(momentum * mean.float())
+            running_var.mul_(1 - momentum).add_(momentum * (var * M / max(M - 1, 1)).float())
+        return mean.float(), (1.0 / torch.sqrt(var + eps)).float()
+
+    def bn_apply_nhwc(x, mean, invstd, gamma, beta, residual=None, relu=False):
+        y = (x - mean) * invstd * gamma + beta
+        if residual is not None:
+            y = y + residual
+        return torch.relu(y) if relu else y
+
+    def bn_pool_fwd(x, mean, invstd, gamma, beta):
+        y = ((x - mean) * invstd * gamma + beta).permute(0, 3, 1, 2)
+        z = F.max_pool2d(y, 3, 2, 1).permute(0, 2, 3, 1).contiguous()
+        return z, torch.zeros(z.shape, dtype=torch.uint8)
+
+    def bn_bwd(x, g, argmax, mean, invstd, gamma, relu_mask):
+        assert argmax is None and not relu_mask, 'shim: dense BatchNorm backward only'
+        C = x.shape[-1]
+        x2, g2 = x.reshape(-1, C).double(), g.reshape(-1, C).double()
+        M = x2.shape[0]
+        xhat = (x2 - mean.double()) * invstd.double()
+        dbeta, dgamma = g2.sum(0), (g2 * xhat).sum(0)
+        dx = gamma.double() * invstd.double() * (g2 - dbeta / M - xhat * dgamma / M)
+        return dx.float().view(x.shape), dgamma.float(), dbeta.float()
+
     def im2col_nhwc(x, kh, kw, stride, pad, ldo=None):
         B, H, W, C = x.shape
         Ho = (H + 2 * pad - kh) // stride + 1

@@ -198,3 +198,61 @@ def test_cfg2_sgcls_train_step_b6_1536_rows():
     np.testing.assert_array_equal(res2.obj_preds.cpu().numpy(), out2['obj_preds'].numpy())
     report('cfg2 relation logits (ref. init)', res2.rel_dists.cpu().numpy(), out2['rel_dists'].numpy(), rel_tol=1e-4)
     report('cfg2 object logits (ref. init)', res2.rm_obj_dists.cpu().numpy(), out2['rm_obj_dists'].numpy(), abs_tol=ABS_TOL)
+
+
+def test_cfg4_resnet_relation_head_train_step():
+    """DRAFT (branch draft/resnet-relmodel, never run on hardware): BASELINE cfg4's model -- RelModel(use_resnet=True) with
+    the documented repair resnet_obj_fmap='layer4' (the reference never builds roi_fmap_obj for this configuration,
+    rel_model.py:360-365 vs :448) -- SGCls train step against the oracle restatement of the same repaired model.  The
+    random-weight trunk is replaced by a lively fixed feature map (a random 101-layer trunk maps noise to a near-constant
+    map, on which the train-mode BatchNorms of layer4 are chaotic even inside the oracle; the trunk has its own parity test)."""
+    from dataloaders.synthetic import SyntheticVG, make_blob
+    from lib import rng
+    from lib.rel_model import RelModel
+    from oracle import model as OM
+    seed = 1234 + 400
+    torch.manual_seed(seed)
+    ds = SyntheticVG(num_images=2, seed=seed, n_boxes=8, n_rels=10, im_size=224)
+    cfg = dict(mode='sgcls', hidden_dim=64, pooling_dim=2048, nl_obj=1, nl_edge=1, order='leftright', rec_dropout=0.0,
+               use_bias=True, use_tanh=False, limit_vision=False, pass_in_obj_feats_to_decoder=False,
+               pass_in_obj_feats_to_edge=False)
+    model = RelModel(classes=ds.ind_to_classes, rel_classes=ds.ind_to_predicates, num_gpus=1, use_resnet=True,
+                     resnet_obj_fmap='layer4', **cfg)
+    for _, p in model.detector.named_parameters():
+        p.requires_grad = False
+    with torch.no_grad():
+        model.post_lstm.weight.mul_(CAL)
+    g = torch.Generator().manual_seed(17)
+    fixed_fmap = torch.relu(torch.randn(2, 1024, 14, 14, generator=g))
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    model.cuda().train()
+    for m in model.detector.modules():
+        if isinstance(m, torch.nn.AlphaDropout):
+            m.eval()
+    dev_fmap = fixed_fmap.cuda().contiguous(memory_format=torch.channels_last)
+    model.detector.features.forward = lambda x: dev_fmap
+    blob = make_blob(ds, range(2), is_train=True)
+    rng.use_host_rng(11)
+    model.sampler_rs = np.random.RandomState(3)
+    res = model[blob]
+    rng.use_host_rng(None)
+    loss = F.cross_entropy(res.rm_obj_dists, res.rm_obj_labels) + F.cross_entropy(res.rel_dists, res.rel_labels[:, -1])
+    loss.backward()
+    osd = {k: v.clone().requires_grad_(v.is_floating_point() and not k.startswith('detector.') and 'running' not in k
+                                       and 'num_batches' not in k) for k, v in sd.items()}
+    cpu_blob = make_blob(ds, range(2), is_train=True)
+    x, im_sizes, off, gt_boxes, gt_classes, gt_rels = cpu_blob[0][:6]
+    det = dict(fmap=fixed_fmap, im_inds=res.im_inds.cpu(), rm_box_priors=res.rm_box_priors.detach().cpu(),
+               rm_obj_dists=model.last_detector_obj_dists.cpu(), od_obj_dists=model.last_detector_obj_dists.cpu(),
+               rm_obj_labels=res.rm_obj_labels.cpu(), rel_labels=res.rel_labels.cpu(), boxes_all=None)
+    ref = OM.relmodel_forward(osd, dict(cfg, use_resnet=True, use_vision=True), x, im_sizes, off, gt_boxes, gt_classes, True,
+                              OM.HostRNG(11), rel_labels=res.rel_labels.cpu(), det_override=det)
+    report('cfg4 relation logits', res.rel_dists.detach().cpu().numpy(), ref['rel_dists'].detach().numpy(), rel_tol=1e-4)
+    report('cfg4 object logits', res.rm_obj_dists.detach().cpu().numpy(), ref['rm_obj_dists'].detach().numpy(), rel_tol=1e-4)
+    oloss = F.cross_entropy(ref['rm_obj_dists'], ref['rm_obj_labels']) + F.cross_entropy(ref['rel_dists'], ref['rel_labels'][:, -1])
+    oloss.backward()
+    params = dict(model.named_parameters())
+    for name, tol in (('roi_fmap.0.2.conv3.weight', 2e-3), ('roi_fmap.0.2.conv2.weight', 2e-3), ('roi_fmap_obj.0.2.bn3.bias', 2e-3),
+                      ('post_lstm.weight', 2e-3), ('roi_fmap.0.0.conv1.weight', 3e-2), ('roi_fmap_obj.0.0.conv2.weight', 3e-2),
+                      ('roi_fmap.0.0.downsample.1.bias', 3e-2)):
+        report('cfg4 grad ' + name, params[name].grad.cpu().numpy(), osd[name].grad.numpy(), rel_tol=tol)
