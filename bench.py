@@ -233,8 +233,9 @@ def secondary(args, rank, world, dev):
       cfg1  PredCls evaluation, one 592x592 image with 20 GT boxes per step (380 candidate pairs)      -- eval img/s
       cfg3  SGDet training step, b = 6: RPN -> NMS -> RoI head -> per-class NMS -> <=64 detections/img -> GT matching ->
             rel_assignments (<=64 rows/img) -> context + relation head, fwd + bwd + clip + SGD             -- train img/s
-      cfg4  ResNet-101 backbone (conv1..layer3, lib/resnet.py) forward at b = 6: the reference's `-resnet` RelModel cannot
-            run (lib/rel_model.py:360-365 vs :448), so the row is the trunk the config is named after       -- trunk img/s
+      cfg4  SGCls training step of the ResNet-101 MotifNet, b = 6: the reference's `-resnet` RelModel cannot run (lib/rel_model.py:360-365
+            vs :448); the row times the model with the documented repair (resnet_obj_fmap='layer4').  MOTIFS_CFG4=trunk: the
+            conv1..layer3 trunk forward alone                                                          -- train img/s
       cfg5  SGDet evaluation stress, one image per step (the reference's eval decoder asserts batch 1), max_per_img = 80 ->
             all 80*79 = 6320 ordered pairs (require_overlap off) through the union-box relation head                                                                        -- eval img/s
     The random-weight detector is made confident (score_fc x30, RPN objectness x4, as tests/test_gpu_sgdet.py does) so that
@@ -250,7 +251,7 @@ def secondary(args, rank, world, dev):
     np.random.seed(seed)
     meters = install_meters(_hip)
     extra = {}
-    if cfg == 'cfg4':
+    if cfg == 'cfg4' and os.environ.get('MOTIFS_CFG4', 'model') == 'trunk':
         from lib.object_detector import ObjectDetector
         det = ObjectDetector(classes=['bg'] + ['c%d' % i for i in range(150)], mode='gtbox', use_resnet=True).to(dev).eval()
         x = torch.randn(BATCH, 3, 592, 592, device=dev)
@@ -260,6 +261,38 @@ def secondary(args, rank, world, dev):
         def step(i):
             with torch.no_grad():
                 return det.feature_map(x)
+    elif cfg == 'cfg4':
+        # the config's MODEL: SGCls train step of RelModel(use_resnet=True) with the documented repair (the reference never builds
+        # roi_fmap_obj for this configuration, lib/rel_model.py:360-365 vs :448): frozen ResNet-101 trunk (conv1..layer3, train-mode
+        # BN like the reference), layer4 copies as the object / relation RoI heads (1.46 GFLOP per union RoI), pooling_dim 2048
+        n_img = BATCH * 4
+        ds = SyntheticVG(num_images=n_img, seed=seed, n_boxes=N_BOXES, n_rels=N_RELS)
+        kw = dict(MODEL_KW, pooling_dim=2048)
+        model = RelModel(classes=ds.ind_to_classes, rel_classes=ds.ind_to_predicates, mode='sgcls', num_gpus=1, use_resnet=True,
+                         resnet_obj_fmap='layer4', **kw)
+        for _, p in model.detector.named_parameters():
+            p.requires_grad = False
+        model.to(dev).train()
+        blobs = [make_blob(ds, range(i * BATCH, (i + 1) * BATCH), is_train=True) for i in range(n_img // BATCH)]
+        for bl in blobs:
+            bl.scatter()
+        lr = 1e-3 * world * BATCH
+        fc = [p for n, p in model.named_parameters() if n.startswith('roi_fmap') and p.requires_grad]
+        rest = [p for n, p in model.named_parameters() if not n.startswith('roi_fmap') and p.requires_grad]
+        opt = FusedClipSGD([{'params': fc, 'lr': lr / 10.0}, {'params': rest}], lr=lr, momentum=0.9, weight_decay=1e-4)
+        per_step, unit_name = BATCH, 'images/sec MotifNet-SGCls (ResNet-101) fwd+bwd'
+        workload = ('SGCls MotifNet ResNet-101 train step (fwd+bwd+clip+SGD): frozen conv1..layer3 trunk, trainable layer4 copies as object / '
+                    'relation RoI heads, batch 6/GPU, 20 GT boxes/img, <=256 rel rows/img, 592x592; use_resnet repaired with '
+                    "resnet_obj_fmap='layer4'")
+
+        def step(i):
+            res = model[blobs[i % len(blobs)]]
+            loss = F.cross_entropy(res.rm_obj_dists, res.rm_obj_labels) + F.cross_entropy(res.rel_dists, res.rel_labels[:, -1])
+            opt.zero_grad(set_to_none=True)
+            loss.backward()
+            opt.step(max_norm=5.0)
+            extra['rows'] = int(res.rel_labels.shape[0])
+            return loss
     else:
         mode = {'cfg1': 'predcls', 'cfg3': 'sgdet', 'cfg5': 'sgdet'}[cfg]
         b = {'cfg1': 1, 'cfg3': BATCH, 'cfg5': 1}[cfg]      # evaluation decodes one image per step (reference decoder_rnn.py:215)
@@ -393,8 +426,10 @@ def main():
     ap.add_argument('--cpu-iters', type=int, default=3, help='timed iterations of the CPU baseline (after 1 warm-up)')
     ap.add_argument('--host-profile', action='store_true',
                     help='after the timed region: host enqueue time of 3 unsynchronised steps + a cProfile of 3 more (stderr)')
-    ap.add_argument('--config', default='cfg2', choices=['cfg1', 'cfg2', 'cfg3', 'cfg4', 'cfg5'],
-                    help='BASELINE.json configs[i-1]; cfg2 (default) is the headline metric, the others are secondary rows')
+    ap.add_argument('--config', default='cfg2', choices=['cfg1', 'cfg2', 'cfg3', 'cfg4', 'cfg5', 'recipe'],
+                    help='BASELINE.json configs[i-1]; cfg2 (default) is the headline metric, the others are secondary rows; '
+                         'recipe = cfg2 with the edge-context LSTM of the shipped training script (-nl_edge 4, '
+                         'scripts/train_models_sgcls.sh:19-21; SURVEY.md 8d)')
     args = ap.parse_args()
 
     from lib import dist as D
@@ -411,17 +446,18 @@ def main():
     from lib.optim import FusedClipSGD
     from lib.rel_model import RelModel
 
-    if args.config != 'cfg2':
+    if args.config not in ('cfg2', 'recipe'):
         return secondary(args, rank, world, dev)
+    model_kw = dict(MODEL_KW, nl_edge=4) if args.config == 'recipe' else MODEL_KW
     torch.manual_seed(1234)
     np.random.seed(1234 + 200 + rank)
     n_img = BATCH * 4
     ds = SyntheticVG(num_images=n_img, seed=1234 + 200 + rank, n_boxes=N_BOXES, n_rels=N_RELS)
-    model = RelModel(classes=ds.ind_to_classes, rel_classes=ds.ind_to_predicates, mode='sgcls', num_gpus=1, **MODEL_KW)
+    model = RelModel(classes=ds.ind_to_classes, rel_classes=ds.ind_to_predicates, mode='sgcls', num_gpus=1, **model_kw)
     for _, p in model.detector.named_parameters():           # models/train_rels.py:50-52
         p.requires_grad = False
     sd_cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and args.config == 'cfg2':
         sd_cpu = {k: v.detach().clone() for k, v in model.state_dict().items()}
     model.to(dev).train()
     lr = 1e-3 * world * BATCH                                 # train_rels.py:192
@@ -434,13 +470,16 @@ def main():
         b.scatter()                                           # inputs resident in HBM before the timed region
     meters = install_meters(_hip)
     opt_events = []
+    roww = D.RowWeights(dev)
+    if world > 1:
+        model.rows_hook = roww.start          # the row-count all-reduce starts inside the forward pass, asynchronously
 
     def step(i):
         res = model[blobs[i % len(blobs)]]
         l_obj = F.cross_entropy(res.rm_obj_dists, res.rm_obj_labels)
         l_rel = F.cross_entropy(res.rel_dists, res.rel_labels[:, -1])
         if world > 1:
-            w = D.global_row_weights([res.rm_obj_labels.shape[0], res.rel_labels.shape[0]], dev)
+            w = roww.get()
             loss = l_obj * w[0] + l_rel * w[1]
         else:
             loss = l_obj + l_rel
@@ -552,11 +591,12 @@ def main():
             if traffic.get('launches') * args.steps != plc['launches']:
                 traffic = None                               # another launch mix: the offline figure does not apply
         line = {
-            'metric': 'images/sec MotifNet-SGCls fwd+bwd', 'value': world * BATCH * args.steps / dt, 'unit': 'img/s',
+            'metric': 'images/sec MotifNet-SGCls fwd+bwd' + (' (shipped recipe: nl_edge 4)' if args.config == 'recipe' else ''),
+            'value': world * BATCH * args.steps / dt, 'unit': 'img/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * dt / args.steps,
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
             'config': {'workload': 'SGCls MotifNet VGG16 train step (fwd+bwd+clip+SGD), order=leftright, nl_obj=2, '
-                                   'nl_edge=2, hidden 512, batch 6/GPU, 20 GT boxes/img, <=256 rel rows/img, 592x592',
+                                   'nl_edge=%d, hidden 512, batch 6/GPU, 20 GT boxes/img, <=256 rel rows/img, 592x592' % model_kw['nl_edge'],
                        'global_batch': world * BATCH, 'parallelism': 'dp%d' % world, 'final_loss': float(loss.item())},
             'roofline': {'bound': 'mfma', 'kernel': 'pl::conv3x3_kernel (implicit GEMM on pre-split plane images: the 12 VGG trunk layers) + conv3x3_nhwc_kernel '
                                                     '(union tower fwd / dgrad); ' + how,

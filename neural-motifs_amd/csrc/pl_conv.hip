@@ -41,19 +41,22 @@ struct ActArgs {
     unsigned *maxbits_out;     // copy of maxbits behind the cells (the image is self-contained)
 };
 
-// thread = one output pixel x one 16-channel chunk; the 256 threads of a block take 256 consecutive pixels of one chunk:
-// reads are 64-byte segments (4 segments per pixel when pooling), writes are 16 KB contiguous.
+// thread = one output pixel x one 16-channel chunk.  Lanes run over the chunks of a pixel first (Gb = min(C/16, 16) chunks,
+// then the next pixel): a pixel's Gb * 64 input bytes are read as one contiguous run (4 runs when pooling), and the cells of
+// one chunk written by a wave are 64 / Gb consecutive pixels = a 256 B .. 1 KB run.  (The first version walked pixels first:
+// every lane of a load touched a different 64-byte segment, 2.2-3.9 TB/s; profiles/r03_pl_conv_check.jsonl.)
 __global__ __launch_bounds__(256) void act_planes_kernel(const ActArgs p)
 {
     const int Ho = p.pool ? p.H / 2 : p.H, Wo = p.pool ? p.W / 2 : p.W;
     const long long Mo = (long long)p.B * Ho * Wo;
-    const int G = p.C / kBK;
-    const long long nblk_m = (Mo + 255) / 256;
+    const int G = p.C / kBK, Gb = G < 16 ? G : 16, ngrp = (G + Gb - 1) / Gb;
+    const int ppb = 256 / Gb;                                             // pixels per block step (threads beyond ppb * Gb idle)
+    const long long nblk_m = (Mo + ppb - 1) / ppb;
     if (blockIdx.x == 0 && threadIdx.x < p.B) p.maxbits_out[threadIdx.x] = p.maxbits[threadIdx.x];
-    for (long long blk = blockIdx.x; blk < nblk_m * G; blk += gridDim.x) {
-        const int g = (int)(blk / nblk_m);
-        const long long m = (blk % nblk_m) * 256 + threadIdx.x;
-        if (m >= Mo) continue;
+    for (long long blk = blockIdx.x; blk < nblk_m * ngrp; blk += gridDim.x) {
+        const int g = (int)(blk % ngrp) * Gb + (int)(threadIdx.x % Gb);
+        const long long m = (blk / ngrp) * ppb + threadIdx.x / Gb;
+        if (m >= Mo || g >= G || (int)threadIdx.x >= ppb * Gb) continue;
         const int b = (int)(m / ((long long)Ho * Wo));
         const int rem = (int)(m % ((long long)Ho * Wo)), yo = rem / Wo, xo = rem % Wo;
         const int e = row_exponent(p.maxbits[b]);
@@ -606,7 +609,8 @@ int mh_act_planes(const float *x, const unsigned *maxbits, int B, int H, int W, 
     p.x = x; p.maxbits = maxbits; p.B = B; p.H = H; p.W = W; p.C = C; p.pool = pool ? 1 : 0;
     p.cells = reinterpret_cast<char *>(image);
     p.maxbits_out = reinterpret_cast<unsigned *>(p.cells + align_up(pl::act_cells_bytes(Mo, C), 256));
-    const long long nblk = ((Mo + 255) / 256) * (C / pl::kBK);
+    const int G = C / pl::kBK, Gb = G < 16 ? G : 16;
+    const long long nblk = ((Mo + 256 / Gb - 1) / (256 / Gb)) * ((G + Gb - 1) / Gb);
     hipLaunchKernelGGL(pl::act_planes_kernel, dim3((unsigned)std::min<long long>(nblk, 256 * 64)), dim3(256), 0, as_stream(stream), p);
     return check_launch("pl::act_planes_kernel");
 }

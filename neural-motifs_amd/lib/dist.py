@@ -54,6 +54,31 @@ def global_row_weights(row_counts, device):
     return (t / tot.clamp(min=1.0)).float()
 
 
+class RowWeights(object):
+    """`global_row_weights` without a blocking collective in front of backward: the two row counts are known as soon as
+    the relation sampler has run (early in the forward pass: RelModel.rows_hook), so the tiny all-reduce is launched THERE,
+    asynchronously, and has long finished when the loss is formed.  `get()` returns rows_rank / rows_global per term."""
+
+    def __init__(self, device):
+        self.device = torch.device(device)
+        self._local = self._tot = self._work = None
+
+    def start(self, *row_counts):
+        t = torch.tensor([float(c) for c in row_counts], dtype=torch.float64)
+        if self.device.type == 'cuda':
+            from lib.pytorch_misc import h2d
+            t = h2d(t, self.device)
+        self._local, self._tot, self._work = t, t.clone(), None
+        if world_size() > 1:
+            self._work = dist.all_reduce(self._tot, op=dist.ReduceOp.SUM, async_op=True)
+
+    def get(self):
+        if self._work is not None:
+            self._work.wait()
+            self._work = None
+        return (self._local / self._tot.clamp(min=1.0)).float()
+
+
 class GradBuckets(object):
     """Flatten-and-all-reduce of the gradients of `params` in fixed buckets."""
 
@@ -152,7 +177,23 @@ class OverlappedGradReducer(object):
         self._work = [None] * len(self.buckets)
         self._armed = False
         self._next = 0
+        self._handed = set()
+        self.stats = {'copied_bytes': 0, 'in_place_bytes': 0}      # gradient bytes copied into / born inside the buckets
         self._handles = [p.register_post_accumulate_grad_hook(self._hook) for p in self.params] if self.enabled else []
+
+    def grad_view(self, p):
+        """a FRESH view of p's slot in its bucket's flat buffer, or None (not a bucketed parameter / reducer inert).  A
+        producer that writes its gradient through this view (lib/hip_ops.py: the weight-gradient GEMM's `out=`) and returns
+        it from backward lets autograd adopt the view as `.grad` -- the gradient is born inside the bucket and the hook has
+        nothing to copy (0.9 of the 1.1 GB of gradients per step are fc6 / fc7 weight gradients)."""
+        if not (self.enabled and self.overlap and self._armed):
+            return None
+        w = self._where.get(id(p))
+        if w is None or id(p) in self._handed:      # a slot is handed out ONCE per backward: a parameter used twice gets its
+            return None                             # second contribution as an ordinary tensor, which autograd adds on top
+        self._handed.add(id(p))
+        bi, off = w
+        return self._buffer(bi)[off:off + p.numel()].view_as(p)
 
     def _buffer(self, bi):
         if self._flat[bi] is None:
@@ -171,13 +212,20 @@ class OverlappedGradReducer(object):
             self._work[bi] = None
         self._next = 0
         self._armed = True
+        self._handed = set()
+        from lib import hip_ops
+        hip_ops.GRAD_SINK = self.grad_view          # producers may write weight gradients straight into the buckets
 
     def _hook(self, p):
         if not self._armed or not self.overlap:
             return
         bi, off = self._where[id(p)]
         flat = self._buffer(bi)
-        flat[off:off + p.numel()].copy_(p.grad.reshape(-1))
+        if p.grad.data_ptr() != flat.data_ptr() + off * flat.element_size():     # not already written in place (grad_view)
+            flat[off:off + p.numel()].copy_(p.grad.reshape(-1))
+            self.stats['copied_bytes'] += p.numel() * p.element_size()
+        else:
+            self.stats['in_place_bytes'] += p.numel() * p.element_size()
         if flat.is_cuda:
             ev = torch.cuda.Event()
             ev.record()
@@ -203,6 +251,8 @@ class OverlappedGradReducer(object):
         if not self.enabled:
             return
         self._armed = False
+        from lib import hip_ops
+        hip_ops.GRAD_SINK = None
         for bi in range(self._next, len(self.buckets)):
             flat = self._buffer(bi)
             for p in self.buckets[bi]:

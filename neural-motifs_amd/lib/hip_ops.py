@@ -84,6 +84,10 @@ def drop_weight_images():
 
 _SKINNY_ROWS = 128          # see _hip.gemm_inloop
 
+# multi-GPU: while a backward pass runs under lib.dist.OverlappedGradReducer this is its `grad_view`: a weight-gradient GEMM
+# writes its result straight into the parameter's slot of the gradient bucket (no copy into the bucket afterwards)
+GRAD_SINK = None
+
 
 class _LinearFn(torch.autograd.Function):
     """y = act(x @ W^T + b): fp32-accurate product on the f16 matrix cores (csrc/pl_gemm.hip), ReLU fused into the
@@ -137,7 +141,8 @@ class _LinearFn(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             gy_cols = gy_cols if gy_cols is not None else _hip.make_planes(gy, False)
             x_cols = ctx.x_cols if ctx.x_cols is not None else _hip.make_planes(ctx.x2, False)
-            gw = _hip.gemm_planes(gy_cols, x_cols)                                         # gy^T [N,M] . (x^T [K,M])^T
+            sink = GRAD_SINK(weight) if (GRAD_SINK is not None and weight.is_contiguous()) else None
+            gw = _hip.gemm_planes(gy_cols, x_cols, out=sink)                               # gy^T [N,M] . (x^T [K,M])^T
         if ctx.has_bias and ctx.needs_input_grad[2]:
             gb = gy.sum(0)
         ctx.x_cols = ctx.x2 = None

@@ -218,7 +218,7 @@ class RelModel(nn.Module):
         if use_resnet and resnet_obj_fmap != 'layer4':
             # The reference cannot run this configuration: with use_resnet it never creates `roi_fmap_obj`
             # (lib/rel_model.py:360-365) but obj_feature_map uses it unconditionally (:448) -> AttributeError on the
-            # first forward.  DRAFT (branch draft/resnet-relmodel): `resnet_obj_fmap='layer4'` is the documented repair --
+            # first forward.  `resnet_obj_fmap='layer4'` is the documented repair --
             # the object branch gets its own copy of the layer4 stack, exactly as the VGG branch has its own fc6 / fc7 copy.
             raise NotImplementedError('RelModel(use_resnet=True) is broken in the reference itself '
                                       "(rel_model.py:360-365 vs :448); pass resnet_obj_fmap='layer4' for the repaired model")
@@ -340,6 +340,10 @@ class RelModel(nn.Module):
                                                 filter_non_overlap=True, num_sample_per_gt=1, rs=self.sampler_rs)
 
         rel_inds = self.get_rel_inds(result.rel_labels, im_inds, boxes)
+        if self.training and getattr(self, 'rows_hook', None) is not None:
+            # multi-GPU: both loss terms' row counts are known here, long before the losses: lib.dist.RowWeights launches
+            # its (tiny, asynchronous) all-reduce now instead of blocking in front of backward
+            self.rows_hook(int(result.rm_obj_labels.shape[0]), int(result.rel_labels.shape[0]))
         self.last_detector_obj_dists = result.rm_obj_dists.detach()   # the detector's logits of the kept boxes (the
         rois = torch.cat((im_inds[:, None].float(), boxes), 1)        # field is overwritten by the context's below)
         fmap = result.fmap.detach()

@@ -56,7 +56,7 @@ class _Conv(nn.Module):
         B, H, W, C = x.shape
         cout = self.weight.shape[0]
         if torch.is_grad_enabled() and (x.requires_grad or self.weight.requires_grad):
-            # DRAFT (branch draft/resnet-relmodel): autograd path for the relation model's trainable layer4 copies --
+            # autograd path for the relation model's trainable layer4 copies --
             # stride-1 1x1 (GEMM) and 3x3 (implicit GEMM) only, which is all layer4 at 7x7 needs
             if self.k == 1 and self.stride == 1:
                 return linear(x.reshape(-1, C), self.weight.view(cout, C)).view(B, H, W, cout)
@@ -76,7 +76,7 @@ class _Conv(nn.Module):
 
 
 class _BNFn(torch.autograd.Function):
-    """DRAFT: train-mode BatchNorm + residual + ReLU on NHWC through the HIP kernels, with its backward: the ReLU mask on
+    """train-mode BatchNorm + residual + ReLU on NHWC through the HIP kernels, with its backward: the ReLU mask on
     the saved output (mh_act_bwd), then mh_bn_bwd (dense form: gradient through the batch statistics, dgamma, dbeta);
     the residual branch receives the masked gradient unchanged."""
 
@@ -190,7 +190,7 @@ class ResNet101Trunk(nn.Module):
 
 
 class Layer4Stack(nn.Sequential):
-    """DRAFT: `resnet_l4(relu_end)` of the reference (lib/resnet.py:126-133): torchvision's layer4 (3 bottlenecks, 1024 ->
+    """`resnet_l4(relu_end)` of the reference (lib/resnet.py:126-133): torchvision's layer4 (3 bottlenecks, 1024 ->
     2048) with the stride taken out of the first block, as the relation model's RoI feature extractor
     (lib/rel_model.py:360-365).  Child names are torchvision's (`0.conv1.weight`, `0.downsample.0.weight`, ...), so
     `roi_fmap.0.*` keys of a reference checkpoint load.  Input: RoI features [n, 1024, 7, 7] (logical NCHW); the blocks run

@@ -187,7 +187,7 @@ def resnet_compress(sd, fmap, training, prefix='detector.compress.'):
 
 
 def resnet_l4_head(sd, x, prefix, training, relu_end=False):
-    """DRAFT (branch draft/resnet-relmodel): the relation model's RoI feature extractor in the ResNet configuration,
+    """the relation model's RoI feature extractor in the ResNet configuration,
     nn.Sequential(resnet_l4(relu_end=False), nn.AvgPool2d(7), Flattener()) (lib/rel_model.py:360-365, lib/resnet.py:126-133):
     torchvision's layer4 with the stride removed from block 0, the last block without its final ReLU, then the 7x7 mean.
     x [n,1024,7,7] -> [n,2048]; `prefix` e.g. 'roi_fmap.0.'"""

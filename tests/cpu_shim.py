@@ -141,7 +141,7 @@ def install():
         m = (y > 0) if epilogue == 1 else ((y > 0) & (y < 6))
         return g * m.to(g.dtype)
 
-    # ---- BatchNorm kernels (ResNet branch; DRAFT draft/resnet-relmodel) ----
+    # ---- BatchNorm kernels (ResNet branch) ----
     def bn_stats(x2d, eps, momentum, running_mean=None, running_var=None):
         M = x2d.shape[0]
         mean = x2d.double().mean(0)

@@ -79,9 +79,12 @@ def _worker(rank, world, port, out_dir):
     red = D.OverlappedGradReducer([p for p in model.parameters() if p.requires_grad], bucket_bytes=8 << 20)
     assert red.enabled and len(red.buckets) >= 3
     ptrs = None
+    roww = D.RowWeights('cpu')
+    model.rows_hook = roww.start              # the row-count all-reduce is launched inside the forward pass, asynchronously
     for step in range(STEPS):
         l_obj, l_rel, n_obj, n_rel = _losses(model, ds, SHARDS[rank], step)
-        w = D.global_row_weights([n_obj, n_rel], 'cpu')
+        w = roww.get()
+        assert torch.equal(w, D.global_row_weights([n_obj, n_rel], 'cpu'))
         opt.zero_grad(set_to_none=True)
         red.prepare()
         (l_obj * w[0] + l_rel * w[1]).backward()
@@ -90,6 +93,8 @@ def _worker(rank, world, port, out_dir):
         assert ptrs is None or ptrs == now, 'reduced gradients must keep their addresses (fused optimizer pointer table)'
         ptrs = now
         opt.step(max_norm=5.0)
+    # the big weight gradients (fc6 / fc7 / post_lstm ...) were written straight into their buckets by the GEMMs
+    assert red.stats['in_place_bytes'] > 0.8 * (red.stats['in_place_bytes'] + red.stats['copied_bytes']), red.stats
     torch.save({n: p.detach().clone() for n, p in model.named_parameters() if p.requires_grad},
                os.path.join(out_dir, 'params%d.pt' % rank))
     dist.barrier()

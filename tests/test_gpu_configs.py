@@ -201,7 +201,7 @@ def test_cfg2_sgcls_train_step_b6_1536_rows():
 
 
 def test_cfg4_resnet_relation_head_train_step():
-    """DRAFT (branch draft/resnet-relmodel, never run on hardware): BASELINE cfg4's model -- RelModel(use_resnet=True) with
+    """BASELINE cfg4's model -- RelModel(use_resnet=True) with
     the documented repair resnet_obj_fmap='layer4' (the reference never builds roi_fmap_obj for this configuration,
     rel_model.py:360-365 vs :448) -- SGCls train step against the oracle restatement of the same repaired model.  The
     random-weight trunk is replaced by a lively fixed feature map (a random 101-layer trunk maps noise to a near-constant

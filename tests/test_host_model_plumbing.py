@@ -320,7 +320,7 @@ def test_conv_traffic_summary_matches_the_committed_counter_files():
 
 
 def test_resnet_relation_model_matches_the_oracle(shim):
-    """DRAFT (branch draft/resnet-relmodel): BASELINE cfg4's model, RelModel(use_resnet=True), with the documented repair
+    """BASELINE cfg4's model, RelModel(use_resnet=True), with the documented repair
     (`resnet_obj_fmap='layer4'`: the object branch gets its own layer4 copy; the reference never builds one,
     rel_model.py:360-365 vs :448) -- module wiring, state-dict keys, logits and gradients of the trainable layer4 stacks
     against the oracle restatement, on the CPU shim."""
