@@ -454,8 +454,9 @@ int mh_gemm_planes(int M, int N, int K, const void *A_image, const void *B_image
 size_t mh_gemm_ws_bytes(int M, int N, int K, int splitk)
 {
     if (M <= 0 || N <= 0 || K <= 0) return 0;
-    return align_up((size_t)M * 4, 256) + align_up((size_t)N * 4, 256) + align_up(pl::cells_bytes(M, K), 256) +
-           align_up(pl::cells_bytes(N, K), 256) + mh_gemm_planes_ws_bytes(M, N, K, splitk);
+    const size_t v3 = align_up((size_t)M * 4, 256) + align_up((size_t)N * 4, 256) + align_up(pl::cells_bytes(M, K), 256) +
+                      align_up(pl::cells_bytes(N, K), 256) + mh_gemm_planes_ws_bytes(M, N, K, splitk);
+    return std::max(v3, mh_gemm_ws_bytes_v2(M, N, K, splitk));
 }
 
 int mh_gemm_auto_splitk(int M, int N, int K) { return mh_gemm_planes_auto_splitk(M, N, K); }
@@ -469,6 +470,11 @@ int mh_gemm_f32(int transA, int transB, int M, int N, int K, const float *A, int
     MH_REQUIRE(A && B && C && K > 0);
     MH_REQUIRE(lda >= (transA ? M : K) && ldb >= (transB ? K : N) && ldc >= N);
     MH_REQUIRE(epilogue >= MH_EPI_NONE && epilogue <= MH_EPI_RELU6);
+    // One-shot operands of a SMALL or thin product are not worth an image each (two extra passes + launches per operand,
+    // gpurun r03_c6: 50 such calls per step cost 1.0 ms of preparation for 0.3 ms of products): those go to the in-loop-split
+    // kernel, which reads the fp32 operands once.  Images pay where the product is big (>= 20 GFLOP) and K is deep.
+    if (pl::g_force_shape < 0 && (2.0 * M * N * (double)K < 20e9 || K < 512))
+        return mh_gemm_f32_v2(transA, transB, M, N, K, A, lda, B, ldb, C, ldc, bias, epilogue, accumulate, splitk, workspace, ws_bytes, stream);
     // workspace: maxbits A | maxbits B (adjacent: the k-major pass zeroes them with one memset) | cells A | cells B | partials
     const size_t ma = align_up((size_t)M * 4, 256), mb = align_up((size_t)N * 4, 256);
     const size_t ca = align_up(pl::cells_bytes(M, K), 256), cb = align_up(pl::cells_bytes(N, K), 256);

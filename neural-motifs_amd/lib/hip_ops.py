@@ -102,11 +102,15 @@ class _LinearFn(torch.autograd.Function):
         ctx.x_cols = None
         ctx.x2 = None
         need_wgrad, need_dgrad = ctx.needs_input_grad[1], ctx.needs_input_grad[0]      # (grad mode is off inside forward)
-        if x2.shape[0] == 0:
-            y = x2.new_zeros(0, w2.shape[0])
-        elif x2.shape[0] <= _SKINNY_ROWS and weight.requires_grad and w2.numel() >= (1 << 24):
+        M, K, N = x2.shape[0], x2.shape[1], w2.shape[0]
+        # plane images pay for big, deep products (and for cached weights); small / thin ones and the skinny product against a
+        # big weight that changes every step read their fp32 operands once in the in-loop-split kernel (_hip.gemm_inloop)
+        ctx.images = M > 0 and 2.0 * M * N * K >= 20e9 and K >= 512 and not (M <= _SKINNY_ROWS and weight.requires_grad)
+        if M == 0:
+            y = x2.new_zeros(0, N)
+        elif not ctx.images:
             y = _hip.gemm_inloop(x2, w2, False, True, bias=bias, epilogue=epi)
-            ctx.x2 = x2
+            ctx.x2 = x2 if need_wgrad else None
         else:
             if need_wgrad:
                 x_rows, ctx.x_cols = _hip.make_planes_both(x2)
@@ -132,17 +136,28 @@ class _LinearFn(torch.autograd.Function):
             return (gy.new_zeros(ctx.x_shape) if ctx.needs_input_grad[0] else None,
                     torch.zeros_like(weight) if ctx.needs_input_grad[1] else None,
                     torch.zeros_like(weight[:, 0]) if (ctx.has_bias and ctx.needs_input_grad[2]) else None, None)
-        gy_rows = gy_cols = None
-        if ctx.needs_input_grad[0] and ctx.needs_input_grad[1]:
-            gy_rows, gy_cols = _hip.make_planes_both(gy)
-        if ctx.needs_input_grad[0]:
-            gy_rows = gy_rows if gy_rows is not None else _hip.make_planes(gy, True)
-            gx = _hip.gemm_planes(gy_rows, _weight_image(weight, True))                     # [M,N] . (W^T image [K,N])^T
-        if ctx.needs_input_grad[1]:
-            gy_cols = gy_cols if gy_cols is not None else _hip.make_planes(gy, False)
-            x_cols = ctx.x_cols if ctx.x_cols is not None else _hip.make_planes(ctx.x2, False)
-            sink = GRAD_SINK(weight) if (GRAD_SINK is not None and weight.is_contiguous()) else None
-            gw = _hip.gemm_planes(gy_cols, x_cols, out=sink)                               # gy^T [N,M] . (x^T [K,M])^T
+        if not ctx.images:
+            w2 = _rows2d(weight.detach())
+            if ctx.needs_input_grad[0]:
+                gx = _hip.gemm_inloop(gy, w2, False, False)                                # [M,N] . [N,K]
+            if ctx.needs_input_grad[1]:
+                M, K, N = ctx.x_shape[0], ctx.x_shape[1], gy.shape[1]
+                if 2.0 * M * N * K >= 20e9 and M >= 96:        # the skinny layer's weight gradient is a big product again
+                    sink = GRAD_SINK(weight) if (GRAD_SINK is not None and weight.is_contiguous()) else None
+                    gw = _hip.gemm_planes(_hip.make_planes(gy, False), _hip.make_planes(ctx.x2, False), out=sink)
+                else:
+                    gw = _hip.gemm_inloop(gy, ctx.x2, True, False)                         # [M,N]^T . [M,K]
+        else:
+            gy_rows = gy_cols = None
+            if ctx.needs_input_grad[0] and ctx.needs_input_grad[1]:
+                gy_rows, gy_cols = _hip.make_planes_both(gy)
+            if ctx.needs_input_grad[0]:
+                gy_rows = gy_rows if gy_rows is not None else _hip.make_planes(gy, True)
+                gx = _hip.gemm_planes(gy_rows, _weight_image(weight, True))                 # [M,N] . (W^T image [K,N])^T
+            if ctx.needs_input_grad[1]:
+                gy_cols = gy_cols if gy_cols is not None else _hip.make_planes(gy, False)
+                sink = GRAD_SINK(weight) if (GRAD_SINK is not None and weight.is_contiguous()) else None
+                gw = _hip.gemm_planes(gy_cols, ctx.x_cols, out=sink)                       # gy^T [N,M] . (x^T [K,M])^T
         if ctx.has_bias and ctx.needs_input_grad[2]:
             gb = gy.sum(0)
         ctx.x_cols = ctx.x2 = None
