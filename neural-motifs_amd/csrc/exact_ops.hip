@@ -234,8 +234,13 @@ __global__ __launch_bounds__(256) void roi_align_fwd_nhwc(const float *__restric
                                                           float *__restrict__ out)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];  // [bins] samples (6 words) + tile
-    const int n = blockIdx.x;
-    const int c0 = blockIdx.y * kRoiCh;
+    // 1-D grid, CHANNEL CHUNK FASTEST: consecutive block ids go round-robin over the 8 XCDs, so with C = 512 (8 chunks) every
+    // block of chunk c runs on XCD c, whose 4 MB L2 then holds that chunk of the whole feature map (6 x 37 x 37 x 64 x 4 B =
+    // 2.1 MB) -- the 4x over-read of the bilinear gather is served by L2 instead of the fabric (r03_c6: 0.96 TB/s of output
+    // with (roi, chunk) blocks spread over all XCDs, each re-fetching the map from the Infinity Cache)
+    const int nchunks = (C + kRoiCh - 1) / kRoiCh;
+    const int n = blockIdx.x / nchunks;
+    const int c0 = (blockIdx.x % nchunks) * kRoiCh;
     const int bins = ph * pw;
     Sample *samp = reinterpret_cast<Sample *>(lds);
     float *tile = lds + bins * (sizeof(Sample) / sizeof(float));  // [kRoiCh][bins+1]
@@ -659,8 +664,8 @@ int mh_roi_align_fwd(const float *feat, int B, int C, int H, int W, int feat_lay
     const int bins = ph * pw;
     const size_t lds = (size_t)bins * sizeof(Sample) + (size_t)kRoiCh * (bins + 1) * sizeof(float);
     MH_REQUIRE(lds <= 64 * 1024);
-    MH_REQUIRE(ceil_div(C, kRoiCh) <= 65535);
-    hipLaunchKernelGGL(roi_align_fwd_nhwc, dim3(n, ceil_div(C, kRoiCh)), dim3(256), lds, st, feat, rois, B, C, H, W,
+    MH_REQUIRE((long long)n * ceil_div(C, kRoiCh) < (1LL << 31));
+    hipLaunchKernelGGL(roi_align_fwd_nhwc, dim3((unsigned)(n * ceil_div(C, kRoiCh))), dim3(256), lds, st, feat, rois, B, C, H, W,
                        ph, pw, width, height, out);
     return check_launch("roi_align_fwd_nhwc");
 }

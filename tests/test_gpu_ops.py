@@ -779,3 +779,70 @@ def test_fused_sgd_skips_a_step_with_a_non_finite_gradient_norm(hip):
     assert L.mh_opt_skipped_steps() == 0
     for q, r in zip(p, ref):
         np.testing.assert_allclose(q.detach().cpu().numpy(), r.cpu().numpy(), atol=1e-6)
+
+
+# ----------------------------------------------------------------------------------------------- plane engine (round 3)
+def test_linear_on_plane_images_forward_backward_and_cache(hip):
+    """hip_ops.Linear above the image threshold (2 M N K >= 20 GFLOP): forward, input gradient and weight gradient run
+    on cached / freshly made plane images (csrc/pl_gemm.hip) and agree with a float64 product; the weight images follow the
+    parameter's value (a raw-pointer update invalidates them)"""
+    from lib import hip_ops
+    torch.manual_seed(0)
+    M, K, N = 1024, 5120, 2048
+    lin = hip_ops.Linear(K, N).cuda()
+    x = torch.randn(M, K, device='cuda', requires_grad=True)
+    y = lin(x, relu=True)
+    g = torch.randn_like(y)
+    y.backward(g)
+    x64, w64, b64 = x.detach().double(), lin.weight.detach().double(), lin.bias.detach().double()
+    pre = x64 @ w64.t() + b64
+    ref = pre.clamp_min(0)
+    gm = g.double() * (pre > 0)
+    scale = float(ref.abs().max())
+    assert float((y.double() - ref).abs().max()) <= 2e-6 * scale
+    flips = ((y.detach() > 0) != (pre > 0))
+    assert int(flips.sum()) <= 4
+    gm = g.double() * (y.detach() > 0)          # the product's own kink decisions
+    gx_ref, gw_ref, gb_ref = gm @ w64, gm.t() @ x64, gm.sum(0)
+    for got, want in ((x.grad, gx_ref), (lin.weight.grad, gw_ref), (lin.bias.grad, gb_ref)):
+        assert float((got.double() - want).abs().max()) <= 3e-6 * float(want.abs().max())
+    key = id(lin.weight)
+    assert key in hip_ops._weight_images and hip_ops._weight_images[key][1] is not None and hip_ops._weight_images[key][2] is not None
+    old = hip_ops._weight_images[key][1]
+    with torch.no_grad():
+        lin.weight.data_ptr()
+        lin.weight.add_(1.0)                     # torch version counter moves
+    y2 = lin(x.detach(), relu=False)
+    assert hip_ops._weight_images[key][1] is not old
+    ref2 = x64 @ (w64 + 1.0).t() + b64
+    assert float((y2.double() - ref2).abs().max()) <= 2e-6 * float(ref2.abs().max())
+
+
+@pytest.mark.parametrize('direct', ['1', '0'])
+def test_vgg_trunk_on_the_plane_engine_matches_the_in_loop_engine(hip, direct, monkeypatch):
+    """VGG16Features frozen forward: plane engine (image-output epilogues / converter passes) vs the round-2 kernels vs a
+    float64 torch reference, on 3 images of different brightness (per-image scales)"""
+    from lib import hip_ops
+    torch.manual_seed(1)
+    f = hip_ops.VGG16Features().cuda()
+    for p in f.parameters():
+        p.requires_grad = False
+    x = torch.randn(3, 3, 96, 80, device='cuda') * torch.tensor([1.0, 7.0, 0.1], device='cuda').view(3, 1, 1, 1)
+    monkeypatch.setenv('MOTIFS_TRUNK', 'planes')
+    monkeypatch.setenv('MOTIFS_TRUNK_DIRECT', direct)
+    y_pl = f(x).float()
+    monkeypatch.setenv('MOTIFS_TRUNK', 'v2')
+    y_v2 = f(x).float()
+    ref = x.double()
+    mods = list(f.children())
+    for m in mods:
+        if isinstance(m, hip_ops.Conv3x3):
+            ref = torch.nn.functional.conv2d(ref, m.weight.double(), m.bias.double(), padding=1).clamp_min(0)
+        elif isinstance(m, hip_ops.MaxPool2x2):
+            ref = torch.nn.functional.max_pool2d(ref, 2, 2)
+    assert y_pl.shape == ref.shape == y_v2.shape
+    for b in range(3):
+        s = float(ref[b].abs().max())
+        e_pl, e_v2 = float((y_pl[b].double() - ref[b]).abs().max()), float((y_v2[b].double() - ref[b]).abs().max())
+        print('trunk image %d: max|ref| %.3e  plane engine err %.2e  in-loop engine err %.2e' % (b, s, e_pl, e_v2))
+        assert e_pl <= 1e-5 * s and e_v2 <= 1e-5 * s
