@@ -191,6 +191,7 @@ int mh_plconv3x3_to_image(const void *in_image, const unsigned *in_true_maxbits,
 int mh_stem_to_image(const float *in_nchw, int B, int Cin, int H, int W, const float *w, int Cout, const float *bias,
                      int epilogue, void *out_image, unsigned *out_maxbits, void *stream);
 void mh_debug_plconv_shape(int shape);
+void mh_debug_plconv_splitk(int splitk);   /* 0 = the planner's schedule; > 0 = every tile in that many K slices (sweeps) */
 
 /* ---------------------------------------------------------------------------------------------
  * Convolution stack, NHWC internal layout (cuDNN replacement; lib/object_detector.py:110-118,

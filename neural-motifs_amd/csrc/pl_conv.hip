@@ -554,6 +554,7 @@ typedef Shape<256, 128, 4, 2> S256x128;
 typedef Shape<128, 128, 2, 2> S128x128;
 typedef Shape<256, 64, 2, 2> S256x64;
 static int g_conv_shape = -1;       // mh_debug_plconv_shape
+static int g_conv_splitk = 0;       // mh_debug_plconv_splitk: > 0 = every tile cut into that many K slices (measurement sweeps)
 
 static inline size_t act_cells_bytes(long long M, int C) { return (size_t)(C / kBK) * M * kCell; }
 static inline size_t wt_cells_bytes(int Cout, int Cin) { return (size_t)9 * (Cin / kBK) * Cout * kCell; }
@@ -569,6 +570,7 @@ static Sched schedule(long long M, int Cin, int Cout)
     s.bm = (s.shape == 1) ? 128 : 256;
     s.bn = (s.shape == 2) ? 64 : 128;
     s.pl = plan_conv_tiles(M, Cin, Cout, s.bm, s.bn);
+    if (g_conv_splitk > 0) { s.pl.splitk = std::min(g_conv_splitk, 9 * (Cin / kBK)); s.pl.body_mtiles = s.pl.tiles_m; s.pl.tail_slices = 1; }
     return s;
 }
 static void partial_bytes(const Sched &sc, long long M, int Cin, int Cout, size_t &body, size_t &tail)
@@ -589,6 +591,7 @@ using namespace mh;
 extern "C" {
 
 void mh_debug_plconv_shape(int shape) { pl::g_conv_shape = shape; }
+void mh_debug_plconv_splitk(int splitk) { pl::g_conv_splitk = splitk; }
 
 size_t mh_act_planes_bytes(int B, int H, int W, int C)
 {

@@ -17,6 +17,7 @@
 namespace mh {
 
 constexpr int kRowsPerBlock = 128;
+constexpr int kBnGroup = 1024;       // channels one block of the statistics kernels covers (grid.y = groups)
 
 // ---- per-channel partial sums of (x, x^2) or (g, g*xhat): block b covers rows [b*128, b*128+128) ---------------
 // threads: c4 = tid % (C/4) float4 columns, lane-row = tid / (C/4); partial[b][0/1][C]
@@ -26,9 +27,12 @@ __global__ __launch_bounds__(256) void bn_partial_kernel(const float *__restrict
                                                          const float *__restrict__ mean, const float *__restrict__ invstd,
                                                          long long M, int C, int H, int W, float *__restrict__ partial)
 {
-    extern __shared__ __attribute__((aligned(16))) float red[];   // [rl][2][C]
-    const int C4 = C >> 2;
-    const int c4 = threadIdx.x % C4, rl = threadIdx.x / C4, nrl = blockDim.x / C4;
+    extern __shared__ __attribute__((aligned(16))) float red[];   // [rl][2][Cb]
+    // blockIdx.y = group of up to 1024 channels (C = 2048 in the ResNet layer4 stacks: two groups); c4 indexes float4
+    // columns of the WHOLE row, Cb / C4b are the group's extent
+    const int c_off = (int)blockIdx.y * kBnGroup, Cb = min(kBnGroup, C - c_off), C4b = Cb >> 2;
+    const int rl = threadIdx.x / C4b, nrl = blockDim.x / C4b;
+    const int c4 = (c_off >> 2) + threadIdx.x % C4b, c4l = threadIdx.x % C4b;
     const long long r0 = (long long)blockIdx.x * kRowsPerBlock;
     float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0;
     float4 mu = s0, is = s0;
@@ -73,14 +77,14 @@ __global__ __launch_bounds__(256) void bn_partial_kernel(const float *__restrict
                 s1.z += gv.z * (xv.z - mu.z) * is.z; s1.w += gv.w * (xv.w - mu.w) * is.w;
             }
         }
-        reinterpret_cast<float4 *>(red + (size_t)(rl * 2 + 0) * C)[c4] = s0;
-        reinterpret_cast<float4 *>(red + (size_t)(rl * 2 + 1) * C)[c4] = s1;
+        reinterpret_cast<float4 *>(red + (size_t)(rl * 2 + 0) * Cb)[c4l] = s0;
+        reinterpret_cast<float4 *>(red + (size_t)(rl * 2 + 1) * Cb)[c4l] = s1;
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < 2 * C; i += blockDim.x) {
+    for (int i = threadIdx.x; i < 2 * Cb; i += blockDim.x) {
         float s = 0.f;
-        for (int q = 0; q < nrl; ++q) s += red[(size_t)q * 2 * C + i];
-        partial[(size_t)blockIdx.x * 2 * C + i] = s;
+        for (int q = 0; q < nrl; ++q) s += red[(size_t)q * 2 * Cb + i];
+        partial[(size_t)blockIdx.x * 2 * C + (i < Cb ? c_off + i : C + c_off + (i - Cb))] = s;
     }
 }
 
@@ -334,7 +338,7 @@ size_t mh_bn_ws_bytes(long long M, int C)
 
 static int check_bn_args(long long M, int C)
 {
-    MH_REQUIRE(M > 0 && C > 0 && C % 4 == 0 && C <= 1024 && (C / 4) <= 256);
+    MH_REQUIRE(M > 0 && C > 0 && C % 4 == 0 && C <= 8192 && (C <= kBnGroup || C % kBnGroup == 0));
     return MH_OK;
 }
 
@@ -349,8 +353,8 @@ int mh_bn_stats(const float *x, long long M, int C, float eps, float momentum, f
     hipStream_t st = as_stream(stream);
     const int nblk = (int)((M + kRowsPerBlock - 1) / kRowsPerBlock);
     float *partial = reinterpret_cast<float *>(workspace);
-    const int nrl = 256 / (C / 4);
-    hipLaunchKernelGGL((bn_partial_kernel<false, false>), dim3(nblk), dim3(256), (size_t)nrl * 2 * C * sizeof(float), st, x,
+    const int Cb = std::min(C, kBnGroup), nrl = 256 / (Cb / 4);
+    hipLaunchKernelGGL((bn_partial_kernel<false, false>), dim3(nblk, ceil_div(C, kBnGroup)), dim3(256), (size_t)nrl * 2 * Cb * sizeof(float), st, x,
                        (const float *)nullptr, (const unsigned char *)nullptr, (const float *)nullptr,
                        (const float *)nullptr, M, C, 0, 0, partial);
     rc = check_launch("bn_partial_kernel<fwd>");
@@ -419,13 +423,14 @@ int mh_bn_bwd(const float *x, const float *g, const unsigned char *argmax, long 
     hipStream_t st = as_stream(stream);
     const int nblk = (int)((Mg + kRowsPerBlock - 1) / kRowsPerBlock);
     float *partial = reinterpret_cast<float *>(workspace);
-    const int nrl = 256 / (C / 4);
-    const size_t lds = (size_t)nrl * 2 * C * sizeof(float);
+    const int Cb = std::min(C, kBnGroup), nrl = 256 / (Cb / 4);
+    const size_t lds = (size_t)nrl * 2 * Cb * sizeof(float);
+    const dim3 pgrid(nblk, ceil_div(C, kBnGroup));
     if (pooled)
-        hipLaunchKernelGGL((bn_partial_kernel<true, true>), dim3(nblk), dim3(256), lds, st, x, g, argmax, mean, invstd, Mg,
+        hipLaunchKernelGGL((bn_partial_kernel<true, true>), pgrid, dim3(256), lds, st, x, g, argmax, mean, invstd, Mg,
                            C, H, W, partial);
     else
-        hipLaunchKernelGGL((bn_partial_kernel<true, false>), dim3(nblk), dim3(256), lds, st, x, g, argmax, mean, invstd, Mg,
+        hipLaunchKernelGGL((bn_partial_kernel<true, false>), pgrid, dim3(256), lds, st, x, g, argmax, mean, invstd, Mg,
                            C, H, W, partial);
     rc = check_launch("bn_partial_kernel<bwd>");
     if (rc) return rc;

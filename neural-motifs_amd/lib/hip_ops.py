@@ -83,6 +83,7 @@ def drop_weight_images():
 
 
 _SKINNY_ROWS = 128          # see _hip.gemm_inloop
+_LINEAR_ENGINE = os.environ.get('MOTIFS_LINEAR', 'auto')      # 'inloop': every Linear on the in-loop-split kernel (A/B switch)
 
 # multi-GPU: while a backward pass runs under lib.dist.OverlappedGradReducer this is its `grad_view`: a weight-gradient GEMM
 # writes its result straight into the parameter's slot of the gradient bucket (no copy into the bucket afterwards)
@@ -105,7 +106,8 @@ class _LinearFn(torch.autograd.Function):
         M, K, N = x2.shape[0], x2.shape[1], w2.shape[0]
         # plane images pay for big, deep products (and for cached weights); small / thin ones and the skinny product against a
         # big weight that changes every step read their fp32 operands once in the in-loop-split kernel (_hip.gemm_inloop)
-        ctx.images = M > 0 and 2.0 * M * N * K >= 20e9 and K >= 512 and not (M <= _SKINNY_ROWS and weight.requires_grad)
+        ctx.images = (M > 0 and 2.0 * M * N * K >= 20e9 and K >= 512 and not (M <= _SKINNY_ROWS and weight.requires_grad)
+                      and _LINEAR_ENGINE != 'inloop')
         if M == 0:
             y = x2.new_zeros(0, N)
         elif not ctx.images:

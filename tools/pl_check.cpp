@@ -278,7 +278,7 @@ static plpack_fn plpack;
 static plconv_fn plconv;
 static v2pack_fn v2pack;
 static v2conv_fn v2conv;
-static shape_fn set_conv_shape;
+static shape_fn set_conv_shape, set_conv_splitk;
 
 static unsigned fbits(float v) { unsigned u; memcpy(&u, &v, 4); return u & 0x7fffffffu; }
 
@@ -447,6 +447,33 @@ static int chain_case(const char *name, int B, int H, int W, int C0, int C1, int
     return bad;
 }
 
+// shape x split-K sweep of one layer (the planner's choice is the row with splitk 0)
+static void conv_sweep(const char *name, int B, int H, int W, int Cin, int Cout, int iters)
+{
+    const size_t nx = (size_t)B * H * W * Cin;
+    Dev dx(nx * 4), dw((size_t)Cout * Cin * 9 * 4), db(Cout * 4), dmb(B * 4), dmbo(B * 4), dout((size_t)B * H * W * Cout * 4);
+    fill_dev(dx.f(), nx, 3); fill_dev(dw.f(), (size_t)Cout * Cin * 9, 5); fill_dev(db.f(), Cout, 6);
+    std::vector<unsigned> mb(B, fbits(6.0f));
+    HIP_OK(hipMemcpy(dmb.p, mb.data(), B * 4, hipMemcpyHostToDevice));
+    const double flops = 2.0 * 9 * Cin * (double)Cout * B * H * W;
+    Dev img(act_bytes(B, H, W, Cin)), pk(plpacked_bytes(Cout, Cin)), oimg(act_bytes(B, H, W, Cout));
+    plpack(dw.f(), Cout, Cin, 0, pk.p, nullptr);
+    act_planes(dx.f(), (const unsigned *)dmb.p, B, H, W, Cin, 0, img.p, nullptr);
+    for (int shape = 0; shape <= 2; ++shape) {
+        if (shape == 2 && Cout > 64) continue;
+        for (int sk : {0, 1, 2, 3, 4, 6}) {
+            set_conv_shape(shape); set_conv_splitk(sk);
+            Dev ws3(plconv_ws(B, H, W, Cin, Cout));
+            const float ms = time_ms(iters, [&] { plconv(img.p, B, H, W, Cin, pk.p, Cout, db.f(), 1, dout.f(), (unsigned *)dmbo.p, ws3.p, ws3.n, nullptr); });
+            const float msi = time_ms(iters, [&] { plconv_img(img.p, (const unsigned *)dmb.p, B, H, W, Cin, pk.p, Cout, db.f(), 1, oimg.p, (unsigned *)dmbo.p, ws3.p, ws3.n, nullptr); });
+            printf("{\"check\": \"conv sweep\", \"case\": \"%s\", \"shape\": %d, \"splitk\": %d, \"ms\": %.4f, \"tflops\": %.1f, \"ms_image_out\": %.4f, \"tflops_image_out\": %.1f}\n",
+                   name, shape, sk, ms, flops / ms * 1e-9, msi, flops / msi * 1e-9);
+            fflush(stdout);
+        }
+    }
+    set_conv_shape(-1); set_conv_splitk(0);
+}
+
 static void conv_speed(const char *name, int B, int H, int W, int Cin, int Cout, int pool_in_front, int iters)
 {
     const int Hi = pool_in_front ? 2 * H : H, Wi = pool_in_front ? 2 * W : W;
@@ -499,6 +526,7 @@ int main(int argc, char **argv)
     v2conv_ws = (sz5_fn)dlsym(h, "mh_conv3x3_ws_bytes"); act_planes = (actpl_fn)dlsym(h, "mh_act_planes"); plpack = (plpack_fn)dlsym(h, "mh_plconv_pack_weight");
     plconv = (plconv_fn)dlsym(h, "mh_plconv3x3"); v2pack = (v2pack_fn)dlsym(h, "mh_conv3x3_pack_weight"); v2conv = (v2conv_fn)dlsym(h, "mh_conv3x3_nhwc");
     set_conv_shape = (shape_fn)dlsym(h, "mh_debug_plconv_shape");
+    set_conv_splitk = (shape_fn)dlsym(h, "mh_debug_plconv_splitk");
     plconv_img = (plconv_img_fn)dlsym(h, "mh_plconv3x3_to_image"); stem_img = (stem_img_fn)dlsym(h, "mh_stem_to_image"); stem_max = (stem_max_fn)dlsym(h, "mh_conv_first_nchw_max");
     if (!act_bytes || !plpacked_bytes || !v2packed_floats || !plconv_ws || !v2conv_ws || !act_planes || !plpack || !plconv || !v2pack || !v2conv || !set_conv_shape || !plconv_img || !stem_img || !stem_max) { printf("missing conv symbol\n"); return 2; }
     if (argc > 2 && !strcmp(argv[2], "--conv-replay")) {
@@ -526,6 +554,14 @@ int main(int argc, char **argv)
             printf("{\"layer\": \"%s\", \"H\": %d, \"Cin\": %d, \"Cout\": %d, \"algorithmic_read_bytes\": %.0f, \"algorithmic_write_bytes\": %.0f, \"flops\": %.0f}\n",
                    l.name, l.H, l.Cin, l.Cout, 4.0 * (M * l.Cin + 9.0 * l.Cin * l.Cout), 4.0 * M * l.Cout, 2.0 * 9 * l.Cin * l.Cout * M);
         }
+        return 0;
+    }
+    if (argc > 2 && !strcmp(argv[2], "--conv-sweep")) {
+        conv_sweep("conv1_2", 6, 592, 592, 64, 64, 5);
+        conv_sweep("conv2_1", 6, 296, 296, 64, 128, 5);
+        conv_sweep("conv3_1", 6, 148, 148, 128, 256, 5);
+        conv_sweep("conv4_2", 6, 74, 74, 512, 512, 5);
+        conv_sweep("conv5_1", 6, 37, 37, 512, 512, 10);
         return 0;
     }
     if (argc > 2 && !strcmp(argv[2], "--conv")) {
