@@ -136,6 +136,8 @@ def install_meters(_hip):
     from lib.optim import FusedClipSGD
     m = dict(
         plconv=KernelMeter(_hip, 'plconv3x3', _plconv_flops), conv=KernelMeter(_hip, 'conv3x3_nhwc', _conv_flops),
+        plconv_img=KernelMeter(_hip, 'plconv3x3_to_image', lambda a, k, y: 2.0 * a[0].B * a[0].H * a[0].W * a[0].C * a[3] * 9),
+        stem=KernelMeter(_hip, 'stem_to_image', lambda a, k, y: (0.0, 4.0 * a[0].numel() + float(y.buf.numel()))),
         gemm_planes=KernelMeter(_hip, 'gemm_planes', _gemm_planes_flops), gemm=KernelMeter(_hip, 'gemm', _gemm_flops),
         gemm_inloop=KernelMeter(_hip, 'gemm_inloop', _gemm_flops),
         roi=KernelMeter(_hip, 'roi_align_fwd', _roi_bytes), act=KernelMeter(_hip, 'act_planes', _act_planes_bytes),
@@ -159,6 +161,7 @@ def hbm_rows(meters, steps, opt_ms=None, opt_bytes=None):
                           'frac': summ['gbps'] / (PEAK_HBM_TBS * 1e3), 'launches_per_step': summ['launches'] / steps,
                           'ms_per_step': summ['total_ms'] / steps, 'bytes_per_step': summ['bytes'] / steps}
     row('roi_align_fwd', meters['roi'].summary(), 'RoIAlign 7x7 forward (objects + union boxes): output bytes + feature map once')
+    row('stem_to_image', meters['stem'].summary(), 'conv1_1 (3 -> 64 channels, VALU) writing its output as a plane image: NCHW input + image bytes')
     row('act_planes', meters['act'].summary(), 'fp32 NHWC -> plane image (2x2 pool fused where the trunk has one): bytes in + bytes out')
     row('make_planes', merge(meters['planes'].summary(), meters['planes_both'].summary()),
         'GEMM operand preparation (row maxima + split, both orientations from one read where both are needed): read once + images written')
@@ -173,6 +176,28 @@ def hbm_rows(meters, steps, opt_ms=None, opt_bytes=None):
             rows[k] = {'bound': 'latency', 'what': what, 'us_per_call': 1e3 * sm['avg_ms'], 'calls_per_step': sm['launches'] / steps,
                        'ms_per_step': sm['total_ms'] / steps}
     return rows
+
+
+def calibration():
+    """a fixed product on ready plane images (4096^3, 10 launches, HIP events): the matrix-pipe rate THIS box sustains.  The
+    sustained clock under MFMA load differs between boxes of the pool (power management: MI355X_MICROARCH.md), so step
+    times of different gpurun calls are compared through this number"""
+    from lib import _hip
+    a = torch.randn(4096, 4096, device='cuda')
+    b = torch.randn(4096, 4096, device='cuda')
+    ia, ib = _hip.make_planes(a, True), _hip.make_planes(b, True)
+    out = torch.empty(4096, 4096, device='cuda')
+    for _ in range(3):
+        _hip.gemm_planes(ia, ib, out=out)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(10):
+        _hip.gemm_planes(ia, ib, out=out)
+    e1.record()
+    e1.synchronize()
+    ms = e0.elapsed_time(e1) / 10
+    return {'plane_gemm_4096_tflops': 2.0 * 4096 ** 3 / ms * 1e-9, 'ms': ms,
+            'what': 'pl::gemm_kernel on ready images, 4096^3, mean of 10 back-to-back launches after the timed region'}
 
 
 def cpu_baseline(ds, model_sd, iters=3, eval_images=3, budget_s=150.0):
@@ -389,6 +414,21 @@ def secondary(args, rank, world, dev):
     barrier()
     dt = time.time() - t0
     set_meters(meters, False)
+    if args.host_profile and rank == 0:
+        # where the host spends a step of this configuration (cProfile over 5 more steps): the D2H round trips show up as time
+        # inside .item() / .cpu() / nonzero() -- the host waiting for the queue to drain
+        import cProfile
+        import io
+        import pstats
+        pr = cProfile.Profile()
+        pr.enable()
+        for i in range(5):
+            step(args.warmup + args.steps + i)
+        torch.cuda.synchronize()
+        pr.disable()
+        buf = io.StringIO()
+        pstats.Stats(pr, stream=buf).sort_stats('tottime').print_stats(40)
+        sys.stderr.write(buf.getvalue())
     tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
     if world > 1:
         torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
@@ -397,7 +437,7 @@ def secondary(args, rank, world, dev):
         _hip.check_faults()
         split = _hip.lib().mh_mfma_split()
         peak = PEAK_BF16_MFMA_TFLOPS / split if split else PEAK_FP32_MFMA_TFLOPS
-        c = merge(meters['plconv'].summary(), meters['conv'].summary())
+        c = merge(meters['plconv'].summary(), meters['plconv_img'].summary(), meters['conv'].summary())
         g = merge(meters['gemm_planes'].summary(), meters['gemm'].summary(), meters['gemm_inloop'].summary())
         dom, dom_name = (g, 'gemm_kernel (relation-head / RoI-head / 1x1-conv GEMMs)') if g['total_ms'] >= c['total_ms'] else \
             (c, 'conv3x3_nhwc_kernel (implicit GEMM)')
@@ -566,7 +606,7 @@ def main():
                          % (['%.2f' % h for h in hs], 1e3 * dt / args.steps, buf.getvalue()))
 
     if rank == 0:
-        plc, c2 = meters['plconv'].summary(), meters['conv'].summary()
+        plc, c2 = merge(meters['plconv'].summary(), meters['plconv_img'].summary()), meters['conv'].summary()
         conv = merge(plc, c2)
         gpl, gg, gi = meters['gemm_planes'].summary(), meters['gemm'].summary(), meters['gemm_inloop'].summary()
         gm = merge(gpl, gg, gi)
@@ -628,6 +668,7 @@ def main():
         n_train = sum(p.numel() for p in model.parameters() if p.requires_grad)
         line['hbm_kernels'] = hbm_rows(meters, args.steps, opt_ms, 20.0 * n_train)
         line['roofline']['ms_per_step'] = conv['total_ms'] / args.steps
+        line['calibration'] = calibration()
         if sd_cpu is not None:
             try:
                 line['cpu_baseline'] = cpu_baseline(ds, sd_cpu, iters=args.cpu_iters)

@@ -335,6 +335,7 @@ int mh_decoder_greedy(int H, int B, int T, const int *batch_sizes_host, int C, c
  * = the class-specific boxes; N rounds of {first arg-max of the table, commit its class, zero that class for every box
  * whose class box overlaps (IoU >= thresh, +1 convention, operation order of box_utils.nms_overlaps), retire the row};
  * commits [N] int64.  One workgroup, N*C*4 bytes of LDS (N*C <= 38400). */
+size_t mh_decoder_nms_commit_max_bytes(void);   /* largest N*C*4 table the kernel holds in LDS on the current device (0: query failed) */
 int mh_decoder_nms_commit(const float *probs, const float *boxes, int N, int C, float thresh, long long *commits,
                           void *stream);
 

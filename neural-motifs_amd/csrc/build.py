@@ -18,6 +18,7 @@ EXACT = ('exact_ops.hip',)
 SOURCES = ('exact_ops.hip', 'gemm.hip', 'pl_gemm.hip', 'pl_conv.hip', 'conv.hip', 'lstm.hip', 'optim.hip', 'tower.hip')
 HEADERS = ('common.h', 'mfma_tile.h', 'pl_tile.h', os.path.join('..', '..', 'include', 'motifs_hip.h'))
 HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
+PACKED_OK = ('gemm.hip', 'conv.hip', 'pl_gemm.hip', 'pl_conv.hip')     # see build(): packed FP32 VALU ops only here
 
 
 def _stale(target, deps):
@@ -45,6 +46,19 @@ def build(force=False, verbose=False, out_dir=None):
                    '-Wall', '-Wno-unused-function']
             if src in EXACT:
                 cmd += ['-ffp-contract=off']
+            # No packed-FP32 VALU instructions (v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32) outside the MFMA tile engines.  On
+            # MI355X the packed ops of the RoIAlign kernel (SLP-vectorised bilinear interpolation: v_pk_add_f32 with neg
+            # modifiers, v_pk_mul_f32 with op_sel broadcasts) returned wrong LOW halves in lanes 48-63 while waves of an
+            # MFMA + packed-VALU kernel from ANOTHER HIP stream shared its SIMD: 44 of 45 concurrent launches wrong next to the
+            # in-loop-split conv, 0 of 45 with the scalar forms; alone every kernel is bit-exact.  The two-stream evaluation
+            # forward was wrong by 1e-2 because of it.  Evidence and the search that led here: profiles/r03_packed_f32_
+            # coresidency.txt, tools/r03/diag2..diag9.  The tile engines (PACKED_OK) keep their packed ops: the in-loop-split
+            # kernels are VALU-bound (-12 % step throughput without them) and as VICTIMS they came out clean in the
+            # co-residency matrix; everything else is latency- or HBM-bound and loses nothing.  MH_PACKED_F32=1 / 0 forces
+            # the compiler default / the scalar forms for every file (A/B builds).
+            packed = os.environ.get('MH_PACKED_F32')
+            if packed == '0' or (packed != '1' and src not in PACKED_OK):
+                cmd += ['-Xclang', '-target-feature', '-Xclang', '-packed-fp32-ops']
             for knob in ('MH_MINW', 'MH_MFMA_SPLIT', 'MH_SPLIT_RN', 'MH_SPLIT_F16', 'MH_CONV_TAP_MAJOR', 'MH_BAR_SLEEP', 'MH_F16_VALU'):
                 if os.environ.get(knob):
                     cmd += ['-D%s=%s' % (knob, os.environ[knob])]

@@ -6,6 +6,8 @@
 // gfx950 notes: wavefront = 64, so one wave covers a whole 64-box NMS tile and the per-row
 // suppression words are native 64-bit lane values; cross-lane traffic uses readlane/ballot, not LDS.
 #include <algorithm>
+#include <cstdlib>
+#include <atomic>
 
 #include "common.h"
 
@@ -228,6 +230,7 @@ __global__ void roi_align_fwd_nchw(const float *__restrict__ feat, const float *
 // Arithmetic per element is unchanged (bilerp, same expression order): outputs are bit-identical to the reference kernel.
 constexpr int kRoiCh = 64;
 constexpr int kRoiBinsPerThread = 4;      // bins <= 16 * 4 take the fast path (7x7 = 49 does); larger grids loop
+template <bool VEC>
 __global__ __launch_bounds__(256) void roi_align_fwd_nhwc(const float *__restrict__ feat,
                                                           const float *__restrict__ rois, int B, int C, int H,
                                                           int W, int ph, int pw, float width, float height,
@@ -243,14 +246,22 @@ __global__ __launch_bounds__(256) void roi_align_fwd_nhwc(const float *__restric
     const int c0 = (blockIdx.x % nchunks) * kRoiCh;
     const int bins = ph * pw;
     Sample *samp = reinterpret_cast<Sample *>(lds);
-    float *tile = lds + bins * (sizeof(Sample) / sizeof(float));  // [kRoiCh][bins+1]
-    const int tstride = bins + 1;
+    // staging tile, BIN-major [bins][kRoiCh + 1]: a thread's four channels of one bin are four consecutive words -- banks
+    // (bg + 4 cq + k) % 64 on the way in, consecutive bins one bank apart on the way out: conflict-free both ways.
+    // NOTE (round 3): this file is compiled WITHOUT packed FP32 VALU instructions (csrc/build.py).  With them, the
+    // SLP-vectorised interpolation below returned wrong low halves in lanes 48-63 whenever MFMA waves of another HIP stream
+    // shared the SIMD (profiles/r03_packed_f32_coresidency.txt); neither the load pattern nor this staging had a part in it.
+    float *tile = lds + bins * (sizeof(Sample) / sizeof(float));
+    constexpr int kTileLd = kRoiCh + 1;
     const RoiGeom g = load_roi(rois, n, width, height);
     const bool valid_im = (g.b_in >= 0 && g.b_in < B);
     for (int b = threadIdx.x; b < bins; b += blockDim.x) samp[b] = make_sample(g, b / pw, b % pw, H, W, ph, pw);
     __syncthreads();
     const int cq = threadIdx.x & 15, bg = threadIdx.x >> 4;
-    const bool vec = (C % 4 == 0) && (c0 + 4 * cq + 3 < C);
+    float *const t0 = tile + bg * kTileLd + 4 * cq;
+    // VEC (C % 4 == 0 and the chunk lies inside C: the launcher decides): every corner is ONE unconditional 16-byte load --
+    // a bin outside the map (top < 0) or beyond `bins` reads pixel (0, 0) and its result is discarded, so the 16 loads of a
+    // thread are straight-line code the compiler keeps in flight together.
     const float *img = feat + (size_t)(valid_im ? g.b_in : 0) * H * W * C + c0 + 4 * cq;
     for (int b0 = 0; b0 < bins; b0 += 16 * kRoiBinsPerThread) {
         float4 tl[kRoiBinsPerThread], tr[kRoiBinsPerThread], bl[kRoiBinsPerThread], br[kRoiBinsPerThread];
@@ -258,25 +269,24 @@ __global__ __launch_bounds__(256) void roi_align_fwd_nhwc(const float *__restric
 #pragma unroll
         for (int i = 0; i < kRoiBinsPerThread; ++i) {
             const int b = b0 + bg + 16 * i;
-            sm[i].top = -1;
-            if (b < bins) sm[i] = samp[b];
-            tl[i] = tr[i] = bl[i] = br[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (valid_im && sm[i].top >= 0) {
-                auto fetch = [&](int yy, int xx) -> float4 {
-                    const float *q = img + ((size_t)yy * W + xx) * C;
-                    if (vec) return *reinterpret_cast<const float4 *>(q);
-                    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (c0 + 4 * cq + 0 < C) v.x = q[0];
-                    if (c0 + 4 * cq + 1 < C) v.y = q[1];
-                    if (c0 + 4 * cq + 2 < C) v.z = q[2];
-                    if (c0 + 4 * cq + 3 < C) v.w = q[3];
-                    return v;
-                };
-                tl[i] = fetch(sm[i].top, sm[i].left);
-                tr[i] = fetch(sm[i].top, sm[i].right);
-                bl[i] = fetch(sm[i].bottom, sm[i].left);
-                br[i] = fetch(sm[i].bottom, sm[i].right);
-            }
+            sm[i] = samp[min(b, bins - 1)];
+            if (b >= bins) sm[i].top = -1;
+            const bool in = sm[i].top >= 0;
+            const int y0 = in ? sm[i].top : 0, y1 = in ? sm[i].bottom : 0, x0 = in ? sm[i].left : 0, x1 = in ? sm[i].right : 0;
+            auto fetch = [&](int yy, int xx) -> float4 {
+                const float *q = img + ((size_t)yy * W + xx) * C;
+                if (VEC) return *reinterpret_cast<const float4 *>(q);
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (c0 + 4 * cq + 0 < C) v.x = q[0];
+                if (c0 + 4 * cq + 1 < C) v.y = q[1];
+                if (c0 + 4 * cq + 2 < C) v.z = q[2];
+                if (c0 + 4 * cq + 3 < C) v.w = q[3];
+                return v;
+            };
+            tl[i] = fetch(y0, x0);
+            tr[i] = fetch(y0, x1);
+            bl[i] = fetch(y1, x0);
+            br[i] = fetch(y1, x1);
         }
 #pragma unroll
         for (int i = 0; i < kRoiBinsPerThread; ++i) {
@@ -289,8 +299,8 @@ __global__ __launch_bounds__(256) void roi_align_fwd_nhwc(const float *__restric
                 v.z = bilerp(tl[i].z, tr[i].z, bl[i].z, br[i].z, sm[i]);
                 v.w = bilerp(tl[i].w, tr[i].w, bl[i].w, br[i].w, sm[i]);
             }
-            float *t = tile + (4 * cq) * tstride + b;
-            t[0] = v.x; t[tstride] = v.y; t[2 * tstride] = v.z; t[3 * tstride] = v.w;
+            float *t = t0 + (b0 + 16 * i) * kTileLd;
+            t[0] = v.x; t[1] = v.y; t[2] = v.z; t[3] = v.w;
         }
     }
     __syncthreads();
@@ -301,12 +311,12 @@ __global__ __launch_bounds__(256) void roi_align_fwd_nhwc(const float *__restric
         for (int i = 4 * threadIdx.x; i < total; i += 4 * blockDim.x) {
             float v[4];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) { const int j = min(i + k, total - 1); v[k] = tile[(j / bins) * tstride + (j % bins)]; }
+            for (int k = 0; k < 4; ++k) { const int j = min(i + k, total - 1); v[k] = tile[(j % bins) * kTileLd + (j / bins)]; }
             if (i + 3 < total) *reinterpret_cast<float4 *>(dst + i) = make_float4(v[0], v[1], v[2], v[3]);
             else for (int k = 0; i + k < total; ++k) dst[i + k] = v[k];
         }
     } else {
-        for (int i = threadIdx.x; i < total; i += blockDim.x) dst[i] = tile[(i / bins) * tstride + (i % bins)];
+        for (int i = threadIdx.x; i < total; i += blockDim.x) dst[i] = tile[(i % bins) * kTileLd + (i / bins)];
     }
 }
 
@@ -662,11 +672,14 @@ int mh_roi_align_fwd(const float *feat, int B, int C, int H, int W, int feat_lay
         return check_launch("roi_align_fwd_nchw");
     }
     const int bins = ph * pw;
-    const size_t lds = (size_t)bins * sizeof(Sample) + (size_t)kRoiCh * (bins + 1) * sizeof(float);
+    const size_t lds = (size_t)bins * sizeof(Sample) + (size_t)bins * (kRoiCh + 1) * sizeof(float);
     MH_REQUIRE(lds <= 64 * 1024);
     MH_REQUIRE((long long)n * ceil_div(C, kRoiCh) < (1LL << 31));
-    hipLaunchKernelGGL(roi_align_fwd_nhwc, dim3((unsigned)(n * ceil_div(C, kRoiCh))), dim3(256), lds, st, feat, rois, B, C, H, W,
-                       ph, pw, width, height, out);
+    const dim3 grid((unsigned)(n * ceil_div(C, kRoiCh)));
+    if (C % kRoiCh == 0 && (reinterpret_cast<uintptr_t>(feat) & 15) == 0)
+        hipLaunchKernelGGL(roi_align_fwd_nhwc<true>, grid, dim3(256), lds, st, feat, rois, B, C, H, W, ph, pw, width, height, out);
+    else
+        hipLaunchKernelGGL(roi_align_fwd_nhwc<false>, grid, dim3(256), lds, st, feat, rois, B, C, H, W, ph, pw, width, height, out);
     return check_launch("roi_align_fwd_nhwc");
 }
 
@@ -730,18 +743,32 @@ int mh_triplet_match(const int *gt_triplets, const float *gt_boxes, int G, const
     return check_launch("triplet_match_kernel");
 }
 
+// largest score table (N * C * 4 bytes) the single-workgroup kernel can hold in LDS on the current device: what the device
+// reports as its per-block limit (160 KB on gfx950) minus 10 KB for the kernel's static arrays; 0 if the query fails
+size_t mh_decoder_nms_commit_max_bytes()
+{
+    int dev = 0, v = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 0;
+    if (hipDeviceGetAttribute(&v, hipDeviceAttributeMaxSharedMemoryPerBlock, dev) != hipSuccess || v <= 10 * 1024) return 0;
+    return (size_t)std::min(v - 10 * 1024, 150 * 1024);
+}
+
 int mh_decoder_nms_commit(const float *probs, const float *boxes, int N, int C, float thresh, long long *commits, void *stream)
 {
     MH_REQUIRE(N >= 0 && C > 1);
     if (N == 0) return MH_OK;
     MH_REQUIRE(probs && boxes && commits && (reinterpret_cast<uintptr_t>(boxes) & 15) == 0);
     const size_t lds = (size_t)N * C * sizeof(float);
-    MH_REQUIRE(lds <= 150 * 1024);
-    static bool raised[64] = {};
+    const size_t cap = mh_decoder_nms_commit_max_bytes();
+    MH_REQUIRE(cap > 0 && lds <= cap);
+    static std::atomic<unsigned long long> raised{0};          // bit d: the dynamic-LDS limit of the kernel was raised on device d
     int dev = 0;
-    if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64 && !raised[dev]) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(decoder_nms_commit_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-        raised[dev] = true;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = -1;
+    if (dev < 0 || !((raised.load(std::memory_order_acquire) >> dev) & 1ULL)) {
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(decoder_nms_commit_kernel),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)cap);
+        if (e != hipSuccess) { set_last_error("hipFuncSetAttribute(decoder_nms_commit_kernel, dynamic LDS)", e); return (int)e; }
+        if (dev >= 0) raised.fetch_or(1ULL << dev, std::memory_order_release);
     }
     hipLaunchKernelGGL(decoder_nms_commit_kernel, dim3(1), dim3(256), lds, as_stream(stream), probs, boxes, N, C, thresh, commits);
     return check_launch("decoder_nms_commit_kernel");

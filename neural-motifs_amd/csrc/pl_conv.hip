@@ -563,13 +563,26 @@ struct Sched {
     int shape, bm, bn;
     ConvTilePlan pl;
 };
+// Block-tile shape and K slicing of one launch, from the r03_c10 sweep (profiles/r03_conv_sweep.jsonl; b = 6, 592 x 592):
+//   * 128x128 tiles (three blocks per CU) beat 256x128 on every layer with Cout >= 128 (+6 % conv4 .. +14 % conv2_1 / conv3_1,
+//     conv5: 203 vs 165 TF/s); Cout <= 64 keeps 256x64;
+//   * cutting the leftover tiles of the last round into K slices (plan_conv_tiles) pays when the launch is a few rounds long
+//     (conv4: 1028 tiles, 329 vs 303 TF/s) and costs 3-8 % on the long launches (conv1_2 .. conv3_1: the tail is < 1 % of the
+//     work, the extra reduce launch and its partial sums are not);
+//   * a launch that fits in one round is NOT split (conv5: 260 tiles, 203 TF/s whole vs 157-163 in 2-6 slices) unless it has
+//     fewer tiles than a quarter of the resident slots.
 static Sched schedule(long long M, int Cin, int Cout)
 {
     Sched s;
-    s.shape = (g_conv_shape >= 0) ? g_conv_shape : (Cout <= 64 ? 2 : 0);
+    s.shape = (g_conv_shape >= 0) ? g_conv_shape : (Cout <= 64 ? 2 : 1);
     s.bm = (s.shape == 1) ? 128 : 256;
     s.bn = (s.shape == 2) ? 64 : 128;
     s.pl = plan_conv_tiles(M, Cin, Cout, s.bm, s.bn);
+    const long long tiles = (long long)s.pl.tiles_m * s.pl.tiles_n;
+    const int slots = resident_slots();
+    const long long rounds = tiles / slots;
+    const bool whole = (rounds == 0) ? tiles > slots / 4 : rounds > 3;
+    if (whole) { s.pl.splitk = 1; s.pl.body_mtiles = s.pl.tiles_m; s.pl.tail_slices = 1; }
     if (g_conv_splitk > 0) { s.pl.splitk = std::min(g_conv_splitk, 9 * (Cin / kBK)); s.pl.body_mtiles = s.pl.tiles_m; s.pl.tail_slices = 1; }
     return s;
 }

@@ -24,7 +24,7 @@ SYMBOLS = (
     'mh_gemm_ws_bytes', 'mh_gemm_auto_splitk', 'mh_gemm_f32',
     'mh_planes_bytes', 'mh_make_planes', 'mh_make_planes_both', 'mh_gemm_planes_ws_bytes', 'mh_gemm_planes_auto_splitk', 'mh_gemm_planes',
     'mh_act_planes_bytes', 'mh_act_planes', 'mh_plconv_packed_bytes', 'mh_plconv_pack_weight', 'mh_plconv3x3_ws_bytes',
-    'mh_plconv3x3', 'mh_plconv3x3_to_image', 'mh_stem_to_image', 'mh_conv_first_nchw_max', 'mh_debug_plconv_shape', 'mh_debug_plconv_splitk',
+    'mh_plconv3x3', 'mh_plconv3x3_to_image', 'mh_stem_to_image', 'mh_conv_first_nchw_max', 'mh_debug_plconv_shape', 'mh_debug_plconv_splitk', 'mh_decoder_nms_commit_max_bytes',
     'mh_debug_pl_shape', 'mh_gemm_ws_bytes_v2', 'mh_gemm_auto_splitk_v2', 'mh_gemm_f32_v2',
     'mh_conv3x3_packed_floats', 'mh_conv3x3_pack_weight', 'mh_conv3x3_ws_bytes', 'mh_conv3x3_schedule', 'mh_conv3x3_nhwc',
     'mh_conv3x3_wgrad_ws_bytes', 'mh_conv3x3_wgrad', 'mh_conv_first_nchw', 'mh_maxpool2x2_nhwc',
@@ -63,7 +63,7 @@ def lib():
                      'mh_plconv3x3_ws_bytes', 'mh_conv3x3_ws_bytes', 'mh_bn_ws_bytes',
                      'mh_conv3x3_packed_floats', 'mh_hwcell_seq_ws_bytes', 'mh_conv3x3_wgrad_ws_bytes',
                      'mh_hwlstm_fwd_ws_bytes', 'mh_hwlstm_bwd_ws_bytes',
-                     'mh_decoder_greedy_ws_bytes'):
+                     'mh_decoder_greedy_ws_bytes', 'mh_decoder_nms_commit_max_bytes'):
             getattr(L, name).restype = ctypes.c_size_t
         _lib = L
     return _lib
@@ -258,7 +258,7 @@ def gemm_planes(a, b, bias=None, epilogue=0, out=None, accumulate=False, splitk=
     return out
 
 
-def gemm_inloop(a, b, trans_a=False, trans_b=False, bias=None, epilogue=0):
+def gemm_inloop(a, b, trans_a=False, trans_b=False, bias=None, epilogue=0, out=None):
     """the round-2 kernel (fp32 operands split inside the K loop): kept for ONE case -- a skinny product (<= 128 rows)
     against a big weight matrix that changes every step and is read exactly once (the trainable object fc6), where
     writing a plane image first would cost more than the product (profiles/r03_pl_check.jsonl)"""
@@ -266,7 +266,10 @@ def gemm_inloop(a, b, trans_a=False, trans_b=False, bias=None, epilogue=0):
     M = a.shape[1] if trans_a else a.shape[0]
     K = a.shape[0] if trans_a else a.shape[1]
     N = b.shape[0] if trans_b else b.shape[1]
-    out = torch.empty(M, N, dtype=torch.float32, device=a.device)
+    if out is None:
+        out = torch.empty(M, N, dtype=torch.float32, device=a.device)
+    elif tuple(out.shape) != (M, N) or out.stride(1) != 1 or out.dtype != torch.float32:
+        raise HipKernelError('bad output tensor for gemm_inloop')
     splitk = L.mh_gemm_auto_splitk_v2(M, N, K)
     wsb = L.mh_gemm_ws_bytes_v2(M, N, K, splitk)
     ws = workspace(wsb, a.device, 'gemm') if wsb else None
@@ -674,6 +677,11 @@ def decoder_greedy(enc_proj, emb_proj, batch_sizes, w_state, b_state, dropout, w
                                  f32(logits), ptr(fed), ptr(commits), ptr(ws), c_size_t(ws.numel()), stream())
     _check(rc, 'mh_decoder_greedy')
     return h_buf[B:], logits, fed, commits
+
+
+def decoder_nms_commit_fits(n, c):
+    """whether the [n, c] score table fits the single-workgroup suppression kernel's LDS on the current device"""
+    return n * c * 4 <= lib().mh_decoder_nms_commit_max_bytes()
 
 
 def decoder_nms_commit(probs, boxes, thresh):

@@ -9,28 +9,34 @@ import torch
 from lib import _hip
 
 
-def _nms_single_im(scores, boxes, pre_nms_topn=12000, post_nms_topn=2000, nms_thresh=0.7):
+def _nms_launch(scores, boxes, pre_nms_topn, nms_thresh):
+    """sort + suppression of one image, nothing read back: (score order, keep list, device count)"""
     _, idx = torch.sort(scores, dim=0, descending=True, stable=True)
     if idx.size(0) > pre_nms_topn:
         idx = idx[:pre_nms_topn]
     boxes_sorted = boxes[idx].contiguous().float()
     keep, num = _hip.nms(boxes_sorted, float(nms_thresh))
-    num_out = min(int(num.item()), post_nms_topn)           # the only host sync: the result size
-    return idx[keep[:num_out].long()]
+    return idx, keep, num
 
 
 def apply_nms(scores, boxes, pre_nms_topn=12000, post_nms_topn=2000, boxes_per_im=None, nms_thresh=0.7):
-    """indices (into `scores`) of the kept boxes in score order; with `boxes_per_im` also the count per image"""
+    """indices (into `scores`) of the kept boxes in score order; with `boxes_per_im` also the count per image.
+    The suppression of EVERY image is enqueued first; the result sizes come back in ONE device->host copy (the reference
+    reads one count per image, lib/fpn/nms/functions/nms.py:18 -- six queue drains per SGDet step at b = 6)."""
     just_inds = boxes_per_im is None
     if boxes_per_im is None:
         boxes_per_im = [boxes.size(0)]
-    s, keep, im_per = 0, [], []
+    s, launched = 0, []
     for bpi in boxes_per_im:
         e = s + int(bpi)
-        keep_im = _nms_single_im(scores[s:e], boxes[s:e], pre_nms_topn, post_nms_topn, nms_thresh)
-        keep.append(keep_im + s)
-        im_per.append(keep_im.size(0))
+        launched.append(_nms_launch(scores[s:e], boxes[s:e], pre_nms_topn, nms_thresh) + (s,))
         s = e
+    counts = torch.cat([num.view(-1)[:1] for _, _, num, _ in launched]).cpu().tolist()      # the only host sync
+    keep, im_per = [], []
+    for (idx, kp, _, s0), cnt in zip(launched, counts):
+        num_out = min(int(cnt), post_nms_topn)
+        keep.append(idx[kp[:num_out].long()] + s0)
+        im_per.append(num_out)
     inds = torch.cat(keep, 0)
     if just_inds:
         return inds
@@ -56,5 +62,7 @@ def nms_mask_per_class(scores, boxes, class_ids, nms_thresh, post_nms_topn):
     valid = torch.arange(n, device=scores.device)[None, :] < num[:, None]                 # [k,n]
     rows = torch.gather(idx.t(), 1, keep.clamp(min=0, max=n - 1))                          # original roi ids
     cls = class_ids[:, None].expand(k, n)
-    mask[rows[valid], cls[valid]] = 1
+    # scatter without a boolean gather (rows[valid] would read the count back): kept entries add 1, the others add 0
+    mask.view(-1).index_add_(0, (rows * C + cls).reshape(-1), valid.reshape(-1).to(mask.dtype))
+    mask.clamp_(max=1.0)
     return mask

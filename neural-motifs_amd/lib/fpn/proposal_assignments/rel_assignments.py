@@ -13,7 +13,7 @@ import torch
 
 from config import REL_FG_FRACTION
 from lib.fpn.box_intersections_cpu.bbox import bbox_overlaps
-from lib.pytorch_misc import h2d
+from lib.pytorch_misc import h2d, host_np
 
 RELS_PER_IMG_SGDET = 64
 
@@ -28,12 +28,15 @@ def rel_assignments(im_inds, rpn_rois, roi_gtlabels, gt_boxes, gt_classes, gt_re
     rs = np.random if rs is None else rs
     dev = rpn_rois.device
     fg_per_image = int(np.round(REL_FG_FRACTION * RELS_PER_IMG_SGDET))
-    det_im = im_inds.cpu().numpy()
-    det_boxes = rpn_rois.detach().cpu().numpy().astype(np.float64)
-    det_labels = roi_gtlabels.cpu().numpy()
-    gtb = gt_boxes.cpu().numpy().astype(np.float64)
-    gtc = gt_classes.cpu().numpy().copy()
-    gtr = gt_rels.cpu().numpy().copy()
+    # ONE device->host copy for what only the device knows (detection boxes + their matched labels; fp32 holds a class id
+    # exactly); image indices and the ground truth come from their host mirrors when the caller attached them
+    packed = torch.cat((rpn_rois.detach().float(), roi_gtlabels.detach().float()[:, None]), 1).cpu().numpy()
+    det_boxes = packed[:, :4].astype(np.float64)
+    det_labels = packed[:, 4].astype(np.int64)
+    det_im = host_np(im_inds)
+    gtb = host_np(gt_boxes).astype(np.float64)
+    gtc = host_np(gt_classes).copy()
+    gtr = host_np(gt_rels).copy()
     gtc[:, 0] -= image_offset
     gtr[:, 0] -= image_offset
     num_im = int(gtc[:, 0].max()) + 1

@@ -148,7 +148,8 @@ class _LinearFn(torch.autograd.Function):
                     sink = GRAD_SINK(weight) if (GRAD_SINK is not None and weight.is_contiguous()) else None
                     gw = _hip.gemm_planes(_hip.make_planes(gy, False), _hip.make_planes(ctx.x2, False), out=sink)
                 else:
-                    gw = _hip.gemm_inloop(gy, ctx.x2, True, False)                         # [M,N]^T . [M,K]
+                    sink = GRAD_SINK(weight) if (GRAD_SINK is not None and weight.is_contiguous()) else None
+                    gw = _hip.gemm_inloop(gy, ctx.x2, True, False, out=sink)               # [M,N]^T . [M,K]
         else:
             gy_rows = gy_cols = None
             if ctx.needs_input_grad[0] and ctx.needs_input_grad[1]:

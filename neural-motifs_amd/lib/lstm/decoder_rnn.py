@@ -263,7 +263,7 @@ class DecoderRNN(torch.nn.Module):
     def _nms_commitments(self, out_dists, boxes_for_nms):
         """class-wise greedy suppression of the sampled labels in sgdet eval (reference :230-247): one kernel on the
         device (mh_decoder_nms_commit); the host loop below is the reference's and serves CPU tensors (tests)."""
-        if out_dists.is_cuda and out_dists.size(0) * out_dists.size(1) * 4 <= 150 * 1024:
+        if out_dists.is_cuda and _hip.decoder_nms_commit_fits(out_dists.size(0), out_dists.size(1)):
             return _hip.decoder_nms_commit(F.softmax(out_dists.detach(), 1).contiguous(),
                                            boxes_for_nms.detach().float().contiguous(), self.nms_thresh)
         is_overlap = nms_overlaps(boxes_for_nms.detach()).view(

@@ -231,6 +231,8 @@ class ObjectDetector(nn.Module):
                 return Result()
             nms_inds, nms_scores, nms_preds, nms_boxes_assign, nms_boxes, nms_imgs = nms_out
             im_inds = nms_imgs + image_offset
+            if has_host(nms_imgs):
+                set_host(im_inds, host_np(nms_imgs) + image_offset)
             obj_dists = od_obj_dists[nms_inds]
             obj_fmap = obj_fmap[nms_inds]
             box_deltas = od_box_deltas[nms_inds]
@@ -262,22 +264,44 @@ class ObjectDetector(nn.Module):
             im_inds=im_inds, fmap=fmap if return_fmap else None)
 
     def nms_boxes(self, obj_dists, rois, box_deltas, im_sizes):
-        """class-specific box decode + per-image detection filter (reference :363-408)"""
+        """class-specific box decode + per-image detection filter (reference :363-408).  The filter of every image is
+        enqueued without reading anything back (filter_det_device); the detection counts of all images come back in ONE
+        copy."""
         boxes = bbox_preds(rois[:, None, 1:].expand_as(box_deltas).contiguous().view(-1, 4),
                            box_deltas.reshape(-1, 4)).view(*box_deltas.size()).detach().clone()
         inds = rois[:, 0].long().contiguous()
-        dets = []
+        if has_host(rois):
+            set_host(inds, host_np(rois)[:, 0].astype(np.int64))
+        elif getattr(rois, '_host_im', None) is not None:
+            set_host(inds, rois._host_im)
+        pending = []
         for i, s, e in enumerate_by_image(inds):
             h, w = im_sizes[i, :2]
             boxes[s:e, :, 0].clamp_(min=0, max=float(w) - 1)
             boxes[s:e, :, 1].clamp_(min=0, max=float(h) - 1)
             boxes[s:e, :, 2].clamp_(min=0, max=float(w) - 1)
             boxes[s:e, :, 3].clamp_(min=0, max=float(h) - 1)
-            d = filter_det(F.softmax(obj_dists[s:e].detach(), 1), boxes[s:e], start_ind=s,
-                           nms_filter_duplicates=self.nms_filter_duplicates, max_per_img=self.max_per_img,
-                           thresh=self.thresh)
-            if d is not None:
-                dets.append(d)
+            sc = F.softmax(obj_dists[s:e].detach(), 1)
+            if self.nms_filter_duplicates:
+                pending.append((i,) + filter_det_device(sc, boxes[s:e], start_ind=s, max_per_img=self.max_per_img, thresh=self.thresh))
+            else:
+                d = filter_det(sc, boxes[s:e], start_ind=s, nms_filter_duplicates=False, max_per_img=self.max_per_img,
+                               thresh=self.thresh)
+                if d is not None:
+                    pending.append((i,) + d + (None,))
+        counts = None
+        if any(p[4] is not None for p in pending):
+            counts = torch.stack([p[4] for p in pending if p[4] is not None]).cpu().tolist()     # the only host sync
+        dets, im_host, ci = [], [], 0
+        for i, d_inds, d_scores, d_labels, cnt in pending:
+            if cnt is not None:
+                k = int(counts[ci])
+                ci += 1
+                if k == 0:
+                    continue
+                d_inds, d_scores, d_labels = d_inds[:k], d_scores[:k], d_labels[:k]
+            dets.append((d_inds, d_scores, d_labels))
+            im_host += [i] * int(d_inds.shape[0])
         if len(dets) == 0:
             print("nothing was detected", flush=True)
             return None
@@ -285,7 +309,8 @@ class ObjectDetector(nn.Module):
         twod_inds = nms_inds * boxes.size(1) + nms_labels
         nms_boxes_assign = boxes.view(-1, 4)[twod_inds]
         nms_boxes = torch.cat((rois[:, 1:][nms_inds][:, None], boxes[nms_inds][:, 1:]), 1)
-        return nms_inds, nms_scores, nms_labels, nms_boxes_assign, nms_boxes, inds[nms_inds]
+        nms_imgs = set_host(inds[nms_inds], np.asarray(im_host, dtype=np.int64))     # the image of every detection, known on the host
+        return nms_inds, nms_scores, nms_labels, nms_boxes_assign, nms_boxes, nms_imgs
 
     def __getitem__(self, batch):
         """`detector[blob]` (reference :410-422).  Data parallelism is one process per GPU (lib/dist.py); inside a
@@ -295,6 +320,26 @@ class ObjectDetector(nn.Module):
             raise RuntimeError('in-process multi-GPU replication is replaced by one process per GPU: launch with '
                                'torchrun and keep num_gpus=1 per rank')
         return self(*batch[0])
+
+
+def filter_det_device(scores, boxes, start_ind=0, max_per_img=100, thresh=0.001, pre_nms_topn=6000, post_nms_topn=300,
+                      nms_thresh=0.3):
+    """filter_det (nms_filter_duplicates=True) without a device->host read: returns (roi ids, scores, labels) of the
+    top `max_per_img` candidates in the reference's order and the NUMBER of them that are detections as a device scalar.
+    Same result as filter_det: per-class suppression runs over ALL foreground classes instead of the ones whose best score
+    beats `thresh` (a class below the threshold cannot contribute -- every entry it keeps scores <= thresh and is cut by the
+    final `> thresh`; where it wins a roi's maximum, the reference has 0 there and drops the roi as well), and
+    nonzero() + sort becomes one stable sort over all rois (zeros sort last, ties keep roi order)."""
+    n, C = scores.shape
+    if n > pre_nms_topn:
+        raise NotImplementedError('more rois per image than pre_nms_topn')
+    class_ids = torch.arange(1, C, device=scores.device)
+    nms_mask = nms_mask_per_class(scores, boxes, class_ids, nms_thresh, post_nms_topn)
+    scores_pre, labels_pre = (nms_mask * scores).max(1)
+    vs, order = torch.sort(scores_pre, dim=0, descending=True, stable=True)
+    count = (vs > thresh).sum().clamp(max=max_per_img)
+    top = order[:max_per_img]
+    return top + start_ind, vs[:max_per_img], labels_pre[top], count
 
 
 def filter_det(scores, boxes, start_ind=0, max_per_img=100, thresh=0.001, pre_nms_topn=6000, post_nms_topn=300,
@@ -413,4 +458,6 @@ def filter_roi_proposals(box_preds, class_preds, boxes_per_im, nms_thresh=0.7, p
     inds, im_per = apply_nms(class_preds, box_preds, pre_nms_topn=pre_nms_topn, post_nms_topn=post_nms_topn,
                              boxes_per_im=boxes_per_im, nms_thresh=nms_thresh)
     img_inds = torch.cat([torch.full((n,), float(val), device=box_preds.device) for val, n in enumerate(im_per)], 0)
-    return torch.cat((img_inds[:, None], box_preds[inds]), 1)
+    rois = torch.cat((img_inds[:, None], box_preds[inds]), 1)
+    rois._host_im = np.repeat(np.arange(len(im_per), dtype=np.int64), im_per)     # image of every roi, known on the host
+    return rois

@@ -3,6 +3,7 @@ Small tensor / numpy helpers with the reference's names (lib/pytorch_misc.py) --
 index arithmetic for packed sequences, per-image enumeration, gradient clipping, checkpoint restore.
 """
 import os
+import threading
 
 import numpy as np
 import torch
@@ -74,8 +75,13 @@ class _PinnedRing(object):
         self.active, self.pos = 0, 0
         self.streams = [set(), set()]          # streams that copied out of each half since it became active
         self.events = [[], []]
+        self.lock = threading.Lock()
 
     def stage(self, t, device):
+        with self.lock:                     # callers: the main thread and autograd engine threads (index uploads in backward)
+            return self._stage(t, device)
+
+    def _stage(self, t, device):
         n = t.numel() * t.element_size()
         if n == 0:
             return torch.empty(t.shape, dtype=t.dtype, device=device)
@@ -103,6 +109,7 @@ class _PinnedRing(object):
 
 
 _rings = {}
+_rings_lock = threading.Lock()
 
 
 def h2d(x, device):
@@ -124,7 +131,10 @@ def h2d(x, device):
         return t.pin_memory().to(device, non_blocking=True)
     ring = _rings.get(device.index)
     if ring is None:
-        ring = _rings[device.index] = _PinnedRing()
+        with _rings_lock:
+            ring = _rings.get(device.index)
+            if ring is None:
+                ring = _rings[device.index] = _PinnedRing()
     return ring.stage(t.contiguous(), device)
 
 

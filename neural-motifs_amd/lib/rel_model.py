@@ -335,8 +335,9 @@ class RelModel(nn.Module):
         boxes = result.rm_box_priors
         if self.training and result.rel_labels is None:
             assert self.mode == 'sgdet'
-            result.rel_labels = rel_assignments(im_inds.detach(), boxes.detach(), result.rm_obj_labels.detach(),
-                                                gt_boxes.detach(), gt_classes.detach(), gt_rels.detach(), image_offset,
+            # index / ground-truth tensors are passed as they are (no .detach(): a new tensor object would drop the host mirror)
+            result.rel_labels = rel_assignments(im_inds, boxes.detach(), result.rm_obj_labels.detach(),
+                                                gt_boxes, gt_classes, gt_rels, image_offset,
                                                 filter_non_overlap=True, num_sample_per_gt=1, rs=self.sampler_rs)
 
         rel_inds = self.get_rel_inds(result.rel_labels, im_inds, boxes)

@@ -102,7 +102,7 @@ def highway_lstm_forward(x, lengths, weight, bias, dropout, hidden_size, num_lay
             c_new = (forget_gate * c_in) + (in_gate * act_gate)
             val = out_gate * torch.tanh(c_new)
             # `val * r_gate + (1. - r_gate) * lin_gate` : the literal 1. makes the sum double
-            val = ((val * r_gate).double() + (1.0 - r_gate.double()) * lin_gate.double()).float()
+            val = ((val * r_gate).double() + (1.0 - r_gate.double()) * lin_gate.double()).to(val.dtype)      # .float() in fp32
             val = val * dropout[layer][:n]
             pad = x.new_zeros(B - n, H)
             h_slots[layer][t + 1] = torch.cat((val, pad), 0) if n < B else val

@@ -214,7 +214,8 @@ class _RoIAlignFn(torch.autograd.Function):
     def forward(ctx, feat, rois, ph, pw, scale):
         ctx.save_for_backward(rois)
         ctx.meta = (tuple(feat.shape), scale)
-        return torch.from_numpy(native.roi_align_fwd(feat.detach().numpy(), rois.numpy(), ph, pw, scale))
+        # (an fp64 evaluation -- tests measuring the fp32 rounding floor -- interpolates the fp32-rounded map: the reference op is fp32)
+        return torch.from_numpy(native.roi_align_fwd(feat.detach().float().numpy(), rois.float().numpy(), ph, pw, scale)).to(feat.dtype)
 
     @staticmethod
     def backward(ctx, g):
@@ -262,7 +263,7 @@ def detector_forward(sd, cfg, x, im_sizes, image_offset, gt_boxes, gt_classes, t
     res = {'fmap': fmap}
     if cfg['mode'] in ('sgcls', 'predcls'):
         im_inds = gt_classes[:, 0] - image_offset
-        rois = torch.cat((im_inds.float()[:, None], gt_boxes), 1)
+        rois = torch.cat((im_inds.to(gt_boxes.dtype)[:, None], gt_boxes), 1)
         if resnet:      # lib/object_detector.py:129-138 with the compress conv in front of RoIAlign (:84-96), dropout = identity
             obj_fmap = resnet_roi_head(sd, roi_align(resnet_compress(sd, fmap, training), rois).view(rois.size(0), -1))
         else:
@@ -487,8 +488,8 @@ def union_boxes_feats(sd, fmap, rois, union_inds, training, prefix='union_boxes.
                             torch.min(rois[:, 1:3][union_inds[:, 0]], rois[:, 1:3][union_inds[:, 1]]),
                             torch.max(rois[:, 3:5][union_inds[:, 0]], rois[:, 3:5][union_inds[:, 1]])), 1)
     union_pools = roi_align(fmap, union_rois, pooling_size, pooling_size, 1.0 / 16)
-    pair_rois = torch.cat((rois[:, 1:][union_inds[:, 0]], rois[:, 1:][union_inds[:, 1]]), 1).numpy()
-    rects = torch.from_numpy(native.draw_union_boxes(pair_rois, pooling_size * 4 - 1) - np.float32(0.5))
+    pair_rois = torch.cat((rois[:, 1:][union_inds[:, 0]], rois[:, 1:][union_inds[:, 1]]), 1).float().numpy()
+    rects = torch.from_numpy(native.draw_union_boxes(pair_rois, pooling_size * 4 - 1) - np.float32(0.5)).to(fmap.dtype)
     x = F.conv2d(rects, sd[prefix + 'conv.0.weight'], sd[prefix + 'conv.0.bias'], stride=2, padding=3)
     x = _relu(x, prefix + 'conv.0')
     x = F.batch_norm(x, sd[prefix + 'conv.2.running_mean'], sd[prefix + 'conv.2.running_var'],
@@ -546,7 +547,7 @@ def relmodel_forward(sd, cfg, x, im_sizes, image_offset, gt_boxes, gt_classes, t
     im_inds = det['im_inds'] - image_offset
     boxes = det['rm_box_priors']
     rel_inds = get_rel_inds(cfg, det['rel_labels'], im_inds, boxes, training)
-    rois = torch.cat((im_inds[:, None].float(), boxes), 1)
+    rois = torch.cat((im_inds[:, None].to(boxes.dtype), boxes), 1)
     fmap = det['fmap'].detach()
     if cfg.get('use_resnet', False):    # the repaired model: the object branch owns a copy of the layer4 stack
         obj_fmap = resnet_l4_head(sd, roi_align(fmap, rois), 'roi_fmap_obj.0.', training)
@@ -640,7 +641,7 @@ def stanford_forward_train(sd, cfg, x, im_sizes, image_offset, gt_boxes, gt_clas
     im_inds = det['im_inds'] - image_offset
     boxes = det['rm_box_priors']
     rel_inds = get_rel_inds(cfg, det['rel_labels'], im_inds, boxes, True)
-    rois = torch.cat((im_inds[:, None].float(), boxes), 1)
+    rois = torch.cat((im_inds[:, None].to(boxes.dtype), boxes), 1)
     ub = union_boxes_feats(sd, fmap, rois, rel_inds[:, 1:], True)
     vr = vgg_classifier(sd, ub.view(ub.size(0), -1), 'roi_fmap.1.', True, rng, use_dropout=False, use_relu=False)
     obj_fmap = vgg_classifier(sd, roi_align(fmap, rois).view(rois.size(0), -1), 'roi_fmap_obj.', True, rng)

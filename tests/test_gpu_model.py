@@ -270,3 +270,50 @@ def test_on_device_evaluation_equals_the_host_evaluator(world):
             for k in (20, 50, 100):
                 assert rec[k] == ev[mode].result_dict[mode + '_recall'][k][0], (mode, idx, k)
     model.mode = model.context.mode = 'sgcls'
+
+
+def test_two_stream_train_step_equals_the_one_stream_step():
+    """the context branch on a second HIP stream (RelModel.overlap_streams, what bench.py and training run) must compute what
+    the sequential step computes: logits, losses and every gradient of a training step with dropout off, two streams vs one.
+    (Round 3 found the two-stream forward wrong by 1e-2 -- RoIAlign's packed-FP32 arithmetic next to MFMA waves of the other
+    stream -- and nothing tested it: the oracle parity tests draw their dropout masks from the host stream, which forces
+    sequential issue.)"""
+    if not torch.cuda.is_available():
+        pytest.fail('needs a HIP device')
+    from dataloaders.synthetic import SyntheticVG, make_blob
+    from lib.rel_model import RelModel
+    torch.manual_seed(3)
+    ds = SyntheticVG(num_images=4, seed=21, n_boxes=12, n_rels=14)
+    model = RelModel(classes=ds.ind_to_classes, rel_classes=ds.ind_to_predicates, mode='sgcls', num_gpus=1,
+                     hidden_dim=512, pooling_dim=4096, nl_obj=2, nl_edge=2, order='leftright', rec_dropout=0.0,
+                     use_bias=True, pass_in_obj_feats_to_decoder=False, pass_in_obj_feats_to_edge=False,
+                     use_tanh=False, limit_vision=False)
+    for _, p in model.detector.named_parameters():
+        p.requires_grad = False
+    model.cuda().train()
+    for m in model.modules():
+        if m.__class__.__name__ in ('Dropout', 'AlphaDropout'):
+            m.eval()
+    blob = make_blob(ds, [0, 1, 2, 3], is_train=True)
+
+    def step(overlap):
+        model.overlap_streams = overlap
+        model.zero_grad(set_to_none=True)
+        model.sampler_rs = np.random.RandomState(9)
+        res = model[blob]
+        loss = F.cross_entropy(res.rm_obj_dists, res.rm_obj_labels) + F.cross_entropy(res.rel_dists, res.rel_labels[:, -1])
+        loss.backward()
+        torch.cuda.synchronize()
+        return (res.rm_obj_dists.detach().clone(), res.rel_dists.detach().clone(), float(loss),
+                {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None})
+
+    one = step(False)
+    for trial in range(3):
+        two = step(True)
+        assert torch.equal(one[0], two[0]) and torch.equal(one[1], two[1]), 'logits differ between the one- and the two-stream step'
+        assert one[2] == two[2]
+        assert set(one[3]) == set(two[3])
+        for name, g in one[3].items():
+            err = float((g - two[3][name]).abs().max())
+            assert err <= 1e-6 * float(g.abs().max()) + 1e-30, '%s: gradient differs by %.3e (max %.3e)' % (name, err, float(g.abs().max()))
+    model.overlap_streams = True

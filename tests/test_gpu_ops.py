@@ -846,3 +846,36 @@ def test_vgg_trunk_on_the_plane_engine_matches_the_in_loop_engine(hip, direct, m
         e_pl, e_v2 = float((y_pl[b].double() - ref[b]).abs().max()), float((y_v2[b].double() - ref[b]).abs().max())
         print('trunk image %d: max|ref| %.3e  plane engine err %.2e  in-loop engine err %.2e' % (b, s, e_pl, e_v2))
         assert e_pl <= 1e-5 * s and e_v2 <= 1e-5 * s
+
+
+# ----------------------------------------------------------------------------------------------- co-residency
+def test_roi_align_is_exact_next_to_the_in_loop_split_conv_on_another_stream(hip):
+    """Regression guard for the round-3 two-stream corruption: RoIAlign launched on a side stream while the in-loop-split conv
+    (MFMA + packed-VALU waves) runs on the main stream must return exactly what it returns alone.  With packed FP32 VALU
+    instructions in the RoIAlign kernel 44 of 45 such launches were wrong (lanes 48-63, low halves): csrc/build.py compiles
+    everything outside the tile engines without them (profiles/r03_packed_f32_coresidency.txt)."""
+    torch.manual_seed(0)
+    fmap = torch.randn(1, 37, 37, 512, device='cuda').relu_()
+    n = 20
+    xy = torch.rand(n, 2, device='cuda') * 300
+    wh = torch.rand(n, 2, device='cuda') * 250 + 20
+    rois = torch.cat((torch.zeros(n, 1, device='cuda'), xy, (xy + wh).clamp(max=591)), 1).contiguous()
+    z = torch.randn(380, 7, 7, 256, device='cuda')
+    wt = hip.conv3x3_pack_weight(torch.randn(512, 256, 3, 3, device='cuda') * 0.01, False)
+    bias = torch.zeros(512, device='cuda')
+    big, w6 = torch.randn(380, 25088, device='cuda'), torch.randn(4096, 25088, device='cuda') * 0.01
+    ref = hip.roi_align_fwd(fmap, rois, 7, 7, 1 / 16, True)
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    wrong = 0
+    for aggressor in (lambda: hip.conv3x3_nhwc(z, wt, bias, 1), lambda: hip.gemm_inloop(big, w6, False, True)):
+        for _ in range(10):
+            torch.cuda.synchronize()
+            side.wait_stream(torch.cuda.current_stream())
+            keep = [aggressor() for _ in range(2)]
+            with torch.cuda.stream(side):
+                outs = [hip.roi_align_fwd(fmap, rois, 7, 7, 1 / 16, True) for _ in range(3)]
+            keep += [aggressor() for _ in range(2)]
+            torch.cuda.synchronize()
+            wrong += sum(not torch.equal(o, ref) for o in outs)
+    assert wrong == 0, '%d of 60 concurrent RoIAlign launches differ from the stand-alone result' % wrong

@@ -105,7 +105,7 @@ def test_sgdet_eval_end_to_end(det):
     print('sgdet e2e: %d detections (oracle on its own detector: %d), %d coincide' % (boxes.shape[0], rb.shape[0], same))
 
 
-def _oracle_on_product_detections(model, sd, cfg, a, got, tag, logits_tol=1e-4):
+def _oracle_on_product_detections(model, sd, cfg, a, got, tag, logits_tol=1e-4, fp64_floor=False):
     """the oracle's relation model (eval mode) on the detections of the product's last forward: object labels, boxes and the
     set of candidate pairs EXACT; the ranked pair list exact wherever two ranking scores are separated by more than their
     rounding; object / relation logits and scores within `logits_tol` of scale"""
@@ -119,11 +119,31 @@ def _oracle_on_product_detections(model, sd, cfg, a, got, tag, logits_tol=1e-4):
     with torch.no_grad():
         ref, rl = OM.relmodel_forward({k: v.clone() for k, v in sd.items()}, dict(cfg, return_logits=True), a[0], a[1], 0, a[3], a[4],
                                       False, OM.HostRNG(0), det_override=override)
+    floor = {}
+    if fp64_floor:
+        # The fp32 rounding floor of these tensors: the same oracle evaluated in float64 on the same detections.  At cfg5's
+        # size (80-step recurrences, 6320 pairs) two correct fp32 evaluations differ by more than 1e-4 of scale: the fp32
+        # ORACLE is 7.7e-5 of scale away from the float64 result, the product 5.2e-5 (gpurun r03_c20) -- so the logits are
+        # held to 1e-4 of scale against the FLOAT64 evaluation, must not be further from it than twice the fp32 oracle is,
+        # and the product-vs-fp32-oracle bound is widened by the fp32 oracle's own measured error.
+        dbl = lambda t: t.double() if torch.is_tensor(t) and t.is_floating_point() else t
+        with torch.no_grad():
+            _, rl64 = OM.relmodel_forward({k: dbl(v.clone()) for k, v in sd.items()}, dict(cfg, return_logits=True), a[0].double(), a[1], 0,
+                                          dbl(a[3]), a[4], False, OM.HostRNG(0), det_override={k: dbl(v) for k, v in override.items()})
+        for k, prod in (('rm_obj_dists', last.rm_obj_dists), ('rel_dists', last.rel_dists)):
+            r64 = rl64[k].numpy()
+            sc = max(1.0, float(np.abs(r64).max()))
+            e_prod = float(np.abs(prod.double().cpu().numpy() - r64).max()) / sc
+            e_o32 = float(np.abs(rl[k].double().numpy() - r64).max()) / sc
+            print('%s %-13s vs the float64 oracle: product %.3e, float32 oracle %.3e (of scale %.4g)' % (tag, k, e_prod, e_o32, sc))
+            assert e_prod <= logits_tol, '%s %s: %.3e of scale from the float64 evaluation' % (tag, k, e_prod)
+            assert e_prod <= 2.0 * e_o32 + 1e-6, '%s %s: product %.3e vs fp32 oracle %.3e from the float64 evaluation' % (tag, k, e_prod, e_o32)
+            floor[k] = e_o32
     boxes, objs, obj_scores, rels, pred_scores = got
     np.testing.assert_array_equal(objs, ref[1])                                     # decoded labels
     np.testing.assert_array_equal(boxes, ref[0])                                    # class-specific boxes of those labels
-    rel_close(last.rm_obj_dists.cpu().numpy(), rl['rm_obj_dists'].numpy(), rtol=logits_tol, what=tag + ' object logits')
-    rel_close(last.rel_dists.cpu().numpy(), rl['rel_dists'].numpy(), rtol=logits_tol, what=tag + ' relation logits')
+    rel_close(last.rm_obj_dists.cpu().numpy(), rl['rm_obj_dists'].numpy(), rtol=logits_tol + floor.get('rm_obj_dists', 0.0), what=tag + ' object logits')
+    rel_close(last.rel_dists.cpu().numpy(), rl['rel_dists'].numpy(), rtol=logits_tol + floor.get('rel_dists', 0.0), what=tag + ' relation logits')
     rel_close(obj_scores, ref[2], rtol=logits_tol, what=tag + ' object scores')
     key = lambda r: r[:, 0] * 1000 + r[:, 1]
     assert sorted(key(rels).tolist()) == sorted(key(ref[3]).tolist())               # the same candidate pairs
@@ -320,7 +340,7 @@ def test_cfg5_sgdet_eval_80_detections_all_pairs(det_big):
     n = got[0].shape[0]
     assert n == 80, 'the confident detector should fill max_per_img (got %d)' % n
     assert got[3].shape[0] == 80 * 79
-    _oracle_on_product_detections(model, sd, cfg, a, got, tag='cfg5')
+    _oracle_on_product_detections(model, sd, cfg, a, got, tag='cfg5', fp64_floor=True)
     model.require_overlap = True
 
 
