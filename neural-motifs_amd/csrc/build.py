@@ -29,9 +29,9 @@ def _stale(target, deps):
 
 
 def build(force=False, verbose=False, out_dir=None):
-    """out_dir (or $MH_OUT): where objects and the .so go -- default next to the sources.  A variant build (another
-    engine: MH_SPLIT_F16=0 -> bf16x6, MH_MFMA_SPLIT=0 -> f32 MFMA, MH_SPLIT_RN=1) belongs in its own directory, e.g.
-    csrc/_variants/bf16x6, and is loaded with MOTIFS_HIP_LIB=<that .so> (lib/_hip.py).  The default build is f16x3."""
+    """out_dir (or $MH_OUT): where objects and the .so go -- default next to the sources.  A variant build (a build knob
+    below, MH_PACKED_F32) belongs in its own directory, e.g. csrc/_variants/pk, and is loaded with MOTIFS_HIP_LIB=<that .so>
+    (lib/_hip.py)."""
     out_dir = os.path.abspath(out_dir or os.environ.get('MH_OUT') or HERE)
     os.makedirs(out_dir, exist_ok=True)
     so = os.path.join(out_dir, os.path.basename(SO))
@@ -59,7 +59,7 @@ def build(force=False, verbose=False, out_dir=None):
             packed = os.environ.get('MH_PACKED_F32')
             if packed == '0' or (packed != '1' and src not in PACKED_OK):
                 cmd += ['-Xclang', '-target-feature', '-Xclang', '-packed-fp32-ops']
-            for knob in ('MH_MINW', 'MH_MFMA_SPLIT', 'MH_SPLIT_RN', 'MH_SPLIT_F16', 'MH_CONV_TAP_MAJOR', 'MH_BAR_SLEEP', 'MH_F16_VALU'):
+            for knob in ('MH_MINW', 'MH_CONV_TAP_MAJOR', 'MH_BAR_SLEEP', 'MH_F16_VALU'):
                 if os.environ.get(knob):
                     cmd += ['-D%s=%s' % (knob, os.environ[knob])]
             if verbose:

@@ -41,10 +41,8 @@ struct ConvArgs {
     long long tail_row0;   // first output row of the tail tiles (= body m-tiles * BM)
     float *partial;        // body:  [splitk][tail_row0][Cout]       when splitk > 1
     float *partial_tail;   // tail:  [tail_slices][M - tail_row0][Cout] when tail_slices > 1
-#if MH_SPLIT_F16
     const int *expA;  // f16x3: exponent per OUTPUT pixel [M], covering its 3x3 input neighbourhood (pixel_exponents)
     const int *expW;  // exponent per output channel [Cout] (tail of the packed weights)
-#endif
 };
 
 __device__ __forceinline__ float conv_epi(float v, int epilogue)
@@ -93,14 +91,10 @@ __global__ __launch_bounds__(kThreads, MH_MINW) void conv3x3_nhwc_kernel(const C
     const int halo = (p.W + 1) * p.Cin;
     const GSrc ga = make_gsrc(p.in + (ptrdiff_t)m0 * p.Cin - halo), gb = make_gsrc(p.wt);
     unsigned a_off[NVA], a_taps[NVA];
-#if MH_PLANES
     // B = packed weights as bf16 planes, wt[tap][co][ci / 16][96 B]: chunk copies, no split (mfma_tile.h: PStage)
     const unsigned b_row_bytes = (unsigned)(p.Cin / kBK) * kPlaneRowBytes;
     PPlan<BN> pb;
     plan_planes<BN>(pb, [&](int r) { return n0 + r < p.Cout; }, b_row_bytes, tid);
-#else
-    unsigned b_off[NVB];
-#endif
 #pragma unroll
     for (int j = 0; j < NVA; ++j) {
         const int r = (tid + kThreads * j) >> 2;
@@ -117,13 +111,6 @@ __global__ __launch_bounds__(kThreads, MH_MINW) void conv3x3_nhwc_kernel(const C
         a_taps[j] = mask;
         a_off[j] = (unsigned)(r * p.Cin + 4 * ((tid + kThreads * j) & 3)) * 4u;
     }
-#if !MH_PLANES
-#pragma unroll
-    for (int j = 0; j < NVB; ++j) {
-        const int f = tid + kThreads * j, r = f >> 2;
-        b_off[j] = (n0 + r < p.Cout) ? (unsigned)(r * p.Cin + 4 * (f & 3)) * 4u : kOobOffset;
-    }
-#endif
 
     const int kt_per_tap = p.Cin / kBK;
     const int total_kt = 9 * kt_per_tap;
@@ -131,11 +118,7 @@ __global__ __launch_bounds__(kThreads, MH_MINW) void conv3x3_nhwc_kernel(const C
     const int kt_end = min(total_kt, kt_begin + kt_per_slice);
 
     // `live` = false: every load becomes a zero-returning out-of-range access (see gemm_kernel)
-#if MH_PLANES
     typedef PStage<BN> StageB;
-#else
-    typedef Stage<BN> StageB;
-#endif
     auto load_tiles = [&](Stage<BM> &sa, StageB &sb, int kt, bool live) {
 #if MH_CONV_TAP_MAJOR
         const int tap = min(kt / kt_per_tap, 8);
@@ -150,30 +133,16 @@ __global__ __launch_bounds__(kThreads, MH_MINW) void conv3x3_nhwc_kernel(const C
         const unsigned bit = 1u << tap;
 #pragma unroll
         for (int j = 0; j < NVA; ++j) sa.v[j] = buffer_load4(ga, (a_taps[j] & bit) ? a_off[j] : kOobOffset, a_soff);
-#if MH_PLANES
         load_planes<BN>(sb, pb, gb, live ? (unsigned)(tap * p.Cout + n0) * b_row_bytes + (unsigned)g16 * kPlaneRowBytes : kDeadTile);
-#else
-        const unsigned b_soff = live ? (unsigned)((tap * p.Cout + n0) * p.Cin + c0) * 4u : kDeadTile;
-#pragma unroll
-        for (int j = 0; j < NVB; ++j) sb.v[j] = buffer_load4(gb, b_off[j], b_soff);
-#endif
     };
-#if MH_SPLIT_F16
     // every tap of output pixel m is staged with the exponent of pixel m (it bounds the whole 3x3 neighbourhood), so the
     // scale is constant along K = (tap, channel) and comes off in the epilogue together with the weight row's
     StageExp<BM> ea;
     load_stage_exp<BM>(ea, p.expA, m0, Mtot, true, tid);
     auto unscale = [&](long long row, int col, float v) { return __builtin_ldexpf(v, -(p.expA[row] + p.expW[col])); };
-#else
-    const StageExp<BM> ea;
-#endif
     auto store_tiles = [&](const Stage<BM> &sa, const StageB &sb, int buf) {
         store_wm<BM>(sa, As(buf), tid, ea);
-#if MH_PLANES
         store_planes<BN>(sb, pb, Bs(buf), tid);
-#else
-        store_wm<BN>(sb, Bs(buf), tid);
-#endif
     };
 
     Acc acc;
@@ -192,11 +161,7 @@ __global__ __launch_bounds__(kThreads, MH_MINW) void conv3x3_nhwc_kernel(const C
         StageB &sb_next = cur ? sb0 : sb1, &sb_far = cur ? sb1 : sb0;
         auto load_far = [&]() { load_tiles(sa_far, sb_far, kt + 2, kt + 2 < kt_end); };
         auto store_next = [&]() { store_tiles(sa_next, sb_next, cur ^ 1); };
-#if MH_PLANES
         half_step<BM, BN>(load_far, store_next, As(cur), Bs(cur), wm, wn, lane, acc);
-#else
-        half_step_f32<BM, BN, true, true>(load_far, store_next, As(cur), Bs(cur), wm, wn, lane, acc);
-#endif
     };
     for (int kt = kt_begin; kt < kt_end; kt += 2) {
         step(std::integral_constant<int, 0>{}, kt);
@@ -211,10 +176,8 @@ __global__ __launch_bounds__(kThreads, MH_MINW) void conv3x3_nhwc_kernel(const C
             const long long row = m0 + r;
             if (row >= Mtot) return;
             float *q = dst + (size_t)(row - region_row0) * p.Cout + n0;
-#if MH_SPLIT_F16
             if (n0 + c0 < p.Cout) v0 = unscale(row, n0 + c0, v0);
             if (n0 + c1 < p.Cout) v1 = unscale(row, n0 + c1, v1);
-#endif
             if (n0 + c0 < p.Cout) q[c0] = v0;
             if (n0 + c1 < p.Cout) q[c1] = v1;
         });
@@ -227,16 +190,13 @@ __global__ __launch_bounds__(kThreads, MH_MINW) void conv3x3_nhwc_kernel(const C
         const long long row = m0 + r;
         if (row >= Mtot) return;
         float *q = p.out + (size_t)row * p.Cout;
-#if MH_SPLIT_F16
         if (col0 < p.Cout) v0 = unscale(row, col0, v0);
         if (col1 < p.Cout) v1 = unscale(row, col1, v1);
-#endif
         if (col0 < p.Cout) q[col0] = conv_epi(v0 + bias0, p.epilogue);
         if (col1 < p.Cout) q[col1] = conv_epi(v1 + bias1, p.epilogue);
     });
 }
 
-#if MH_PLANES
 // ---------------------------------------------------------------------------------------------------------------
 // Weight gradient of the 3x3 / stride 1 / pad 1 conv as an implicit GEMM (no patch matrix):
 //     dW[co][tap][ci] = sum over pixels  gy[pix][co] * x[pix + shift(tap)][ci]        (0 where the tap leaves the image)
@@ -256,9 +216,7 @@ struct WgradArgs {
     int splitk, ktiles_per_split;
     float *out;       // [Cout][9*Cin] (splitk == 1)
     float *partial;   // [splitk][Cout][9*Cin]
-#if MH_SPLIT_F16
     const int *expA, *expB;   // f16x3: exponent per output channel of gy [Cout] / per input channel of x [Cin], over ALL pixels
-#endif
 };
 
 __global__ void tap_mask_kernel(int B, int H, int W, long long P, long long Ppad, unsigned short *__restrict__ mask)
@@ -342,7 +300,6 @@ __global__ __launch_bounds__(kThreads, MH_MINW) void conv3x3_wgrad_kernel(const 
     // (tap, ci) by the exponent of ci (a shift does not change what the channel's maximum bounds)
     StageExp<BM> ea;
     StageExp<BN> eb;
-#if MH_SPLIT_F16
     load_stage_exp<BM>(ea, p.expA, m0, p.Cout, false, tid, true);      // |x| maxima as bit patterns (launch_operand_absmax)
 #pragma unroll
     for (int jt = 0; jt < NTB; ++jt) {
@@ -351,7 +308,6 @@ __global__ __launch_bounds__(kThreads, MH_MINW) void conv3x3_wgrad_kernel(const 
 #pragma unroll
         for (int j = 0; j < 4; ++j) eb.km[jt][j] = (n0 + 4 * q + j < N) ? row_exponent((unsigned)p.expB[(n0 + 4 * q + j) % p.Cin]) : 0;
     }
-#endif
     auto store_tiles = [&](const Stage<BM> &sa, const Stage<BN> &sb, int buf) {
         store_km<BM>(sa, As(buf), tid, ea);
         store_km<BN>(sb, Bs(buf), tid, eb);
@@ -382,16 +338,13 @@ __global__ __launch_bounds__(kThreads, MH_MINW) void conv3x3_wgrad_kernel(const 
     acc_foreach_pair<false, false>(acc, wm, wn, lane, [&](int r, int c0, int c1, float v0, float v1) {
         const int row = m0 + r, col0 = n0 + c0, col1 = n0 + c1;
         if (row >= p.Cout) return;
-#if MH_SPLIT_F16
         if (col0 < N) v0 = __builtin_ldexpf(v0, -(row_exponent((unsigned)p.expA[row]) + row_exponent((unsigned)p.expB[col0 % p.Cin])));
         if (col1 < N) v1 = __builtin_ldexpf(v1, -(row_exponent((unsigned)p.expA[row]) + row_exponent((unsigned)p.expB[col1 % p.Cin])));
-#endif
         float *q = dst + (size_t)row * N;
         if (col1 < N) *reinterpret_cast<float2 *>(q + col0) = make_float2(v0, v1);      // N % 4 == 0: col0 is even
         else if (col0 < N) q[col0] = v0;
     });
 }
-#endif  // MH_PLANES
 
 // Packed weights of a 3x3 conv with N output and K input channels (for the dgrad conv the channel roles are swapped
 // and the taps mirrored: flip_transpose): element (tap, n, k) = w[n][k][tap], or w[k][n][8 - tap] when flipped.
@@ -404,7 +357,6 @@ __global__ void pack_weight_kernel(const float *__restrict__ w, int N, int K, in
     auto src = [&](int tap, int n, int k) -> float {
         return flip_transpose ? w[((size_t)k * src_cin + n) * 9 + (8 - tap)] : w[((size_t)n * src_cin + k) * 9 + tap];
     };
-#if MH_SPLIT_F16
     // wt[tap][n][k / 16][16 dwords] = h1 | h2 of w * 2^e[n]; the exponents e[N] (weight_exp_kernel) follow the planes
     constexpr int row_dw = kPlaneRowBytes / 4;
     const long long total = 9LL * N * (K / kBK) * row_dw;
@@ -421,32 +373,9 @@ __global__ void pack_weight_kernel(const float *__restrict__ w, int N, int K, in
         split_pair_f16(src(tap, n, g16 * kBK + 2 * kp), src(tap, n, g16 * kBK + 2 * kp + 1), exps[n], exps[n], pl[0], pl[1]);
         out[idx] = pl[plane];
     }
-#elif MH_PLANES
-    const long long total = 9LL * N * (K / kBK) * kRowDw;
-    unsigned *out = reinterpret_cast<unsigned *>(wt);
-    for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total;
-         idx += (long long)blockDim.x * gridDim.x) {
-        const int d = idx % kRowDw, plane = d / 8, kp = d % 8;
-        long long t = idx / kRowDw;
-        const int g16 = t % (K / kBK); t /= (K / kBK);
-        const int n = t % N;
-        const int tap = (int)(t / N);
-        unsigned pl[3];
-        split_pair(src(tap, n, g16 * kBK + 2 * kp), src(tap, n, g16 * kBK + 2 * kp + 1), pl[0], pl[1], pl[2]);
-        out[idx] = pl[plane];
-    }
-#else
-    const long long total = 9LL * N * K;
-    for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total;
-         idx += (long long)blockDim.x * gridDim.x) {
-        const int k = idx % K, n = (idx / K) % N, tap = (int)(idx / ((long long)N * K));
-        wt[idx] = src(tap, n, k);
-    }
-#endif
     (void)src_cout;
 }
 
-#if MH_SPLIT_F16
 // exponent of output channel n over its 9*K weights (one block per n), written behind the planes
 __global__ void weight_exp_kernel(const float *__restrict__ w, int N, int K, int flip_transpose, int src_cin,
                                   int *__restrict__ exps)
@@ -481,7 +410,6 @@ __global__ void pixel_exp_kernel(const unsigned *__restrict__ pmax, int B, int H
         exps[p] = row_exponent(m);
     }
 }
-#endif
 
 // Stem conv: NCHW image (Cin small, e.g. 3) -> NHWC, bias + activation.  Direct VALU kernel: the layer is
 // bandwidth-bound (1.2 GFLOP vs 90 MB written per 592x592 image).  One thread = one pixel x 16 output channels;
@@ -673,15 +601,9 @@ extern "C" {
 size_t mh_conv3x3_packed_floats(int Cout, int Cin)
 {
     if (Cout <= 0 || Cin <= 0) return 0;
-#if MH_SPLIT_F16
     // planes, then a tail of 9 * Cout dwords whose first Cout hold the channel exponents (the total stays a multiple of
     // 9 * Cout, which is how callers shape the opaque container)
     return (size_t)9 * Cout * (((Cin + kBK - 1) / kBK) * (kPlaneRowBytes / 4) + 1);
-#elif MH_PLANES
-    return (size_t)9 * Cout * ((Cin + kBK - 1) / kBK) * kRowDw;
-#else
-    return (size_t)9 * Cout * Cin;
-#endif
 }
 
 int mh_conv3x3_pack_weight(const float *w, int Cout, int Cin, int flip_transpose, float *wt, void *stream)
@@ -691,14 +613,12 @@ int mh_conv3x3_pack_weight(const float *w, int Cout, int Cin, int flip_transpose
     const int N = flip_transpose ? Cin : Cout, K = flip_transpose ? Cout : Cin;
     MH_REQUIRE(K % kBK == 0);
     const long long total = (long long)mh_conv3x3_packed_floats(N, K);
-#if MH_SPLIT_F16
     int *exps = reinterpret_cast<int *>(wt) + (size_t)9 * N * (K / kBK) * (kPlaneRowBytes / 4);
     hipLaunchKernelGGL(weight_exp_kernel, dim3(N), dim3(256), 0, as_stream(stream), w, N, K, flip_transpose, Cin, exps);
     {
         const int rc_e = check_launch("weight_exp_kernel");
         if (rc_e) return rc_e;
     }
-#endif
     const int blocks = (int)std::min<long long>((total + 255) / 256, 4096);
     hipLaunchKernelGGL(pack_weight_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), w, N, K, flip_transpose, Cout,
                        Cin, wt);
@@ -803,7 +723,7 @@ size_t mh_conv3x3_ws_bytes(int B, int H, int W, int Cin, int Cout)
     const ConvSchedule sc = conv_schedule(M, Cin, Cout);
     size_t body, tail;
     conv_partial_bytes(sc, M, Cin, Cout, body, tail);
-    const size_t exps = MH_SPLIT_F16 ? 2 * align_up((size_t)M * sizeof(int), 256) : 0;   // pixel exponents + their scratch
+    const size_t exps = 2 * align_up((size_t)M * sizeof(int), 256);   // pixel exponents + their scratch
     return exps + body + tail;
 }
 
@@ -841,7 +761,6 @@ int mh_conv3x3_nhwc(const float *in, int B, int H, int W, int Cin, const float *
     const long long ntiles = (long long)p.tiles_m * p.tiles_n;
     MH_REQUIRE(ntiles < (1LL << 29));
     const int total_kt = 9 * (Cin / kBK);
-#if MH_SPLIT_F16
     {   // pixel exponents at the head of the workspace (mh_conv3x3_ws_bytes counts them): mandatory in this build
         const size_t eb = align_up((size_t)M * sizeof(int), 256);
         MH_REQUIRE(workspace && ws_bytes >= 2 * eb);
@@ -858,7 +777,6 @@ int mh_conv3x3_nhwc(const float *in, int B, int H, int W, int Cin, const float *
         workspace = reinterpret_cast<char *>(workspace) + 2 * eb;
         ws_bytes -= 2 * eb;
     }
-#endif
     size_t body_bytes, tail_bytes;
     conv_partial_bytes(sc, M, Cin, Cout, body_bytes, tail_bytes);
     if (body_bytes + tail_bytes > 0 && (workspace == nullptr || ws_bytes < body_bytes + tail_bytes)) {
@@ -912,14 +830,13 @@ size_t mh_conv3x3_wgrad_ws_bytes(int B, int H, int W, int Cin, int Cout)
     if (P <= 0 || Cin <= 0 || Cout <= 0) return 0;
     const size_t mask = align_up((size_t)(P + 2 * kBK + 16) * sizeof(unsigned short), 256);
     const int s = wgrad_splitk(P, Cin, Cout);
-    const size_t exps = MH_SPLIT_F16 ? align_up((size_t)Cout * sizeof(int), 256) + align_up((size_t)Cin * sizeof(int), 256) : 0;
+    const size_t exps = align_up((size_t)Cout * sizeof(int), 256) + align_up((size_t)Cin * sizeof(int), 256);
     return mask + exps + (s > 1 ? align_up((size_t)s * Cout * 9 * Cin * sizeof(float), 256) : 0);
 }
 
 int mh_conv3x3_wgrad(const float *x, const float *gy, int B, int H, int W, int Cin, int Cout, float *dw,
                      void *workspace, size_t ws_bytes, void *stream)
 {
-#if MH_PLANES
     MH_REQUIRE(x && gy && dw && workspace && B > 0 && H > 0 && W > 0 && Cin > 0 && Cin % 4 == 0 && Cout > 0 && Cout % 4 == 0);
     MH_REQUIRE(((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(gy) | reinterpret_cast<uintptr_t>(dw) |
                  reinterpret_cast<uintptr_t>(workspace)) & 15) == 0);
@@ -946,7 +863,6 @@ int mh_conv3x3_wgrad(const float *x, const float *gy, int B, int H, int W, int C
     p.splitk = splitk;
     p.out = dw;
     size_t used = mask_bytes;
-#if MH_SPLIT_F16
     {
         int *expA = reinterpret_cast<int *>(reinterpret_cast<char *>(workspace) + used);
         used += align_up((size_t)Cout * sizeof(int), 256);
@@ -956,17 +872,12 @@ int mh_conv3x3_wgrad(const float *x, const float *gy, int B, int H, int W, int C
         if (rc) return rc;
         p.expA = expA; p.expB = expB;
     }
-#endif
     p.partial = reinterpret_cast<float *>(reinterpret_cast<char *>(workspace) + used);
     dim3 grid((unsigned)(p.tiles_m * p.tiles_n), (unsigned)splitk);
     launch_tile_kernel<conv3x3_wgrad_kernel<128, 128>>(grid, tile_lds_bytes<128, 128, false, false>(), st, p);
     rc = check_launch("conv3x3_wgrad_kernel");
     if (rc || splitk == 1) return rc;
     return launch_splitk_reduce(p.partial, splitk, Cout, 9 * Cin, dw, 9 * Cin, nullptr, MH_EPI_NONE, 0, st);
-#else
-    (void)x; (void)gy; (void)B; (void)H; (void)W; (void)Cin; (void)Cout; (void)dw; (void)workspace; (void)ws_bytes; (void)stream;
-    return MH_EUNSUPPORTED;
-#endif
 }
 
 int mh_conv_first_nchw_max(const float *in_nchw, int B, int Cin, int H, int W, const float *w, int Cout, const float *bias,

@@ -26,9 +26,7 @@ struct GemmArgs {
     int vecA, vecB, vecC;
     int tiles_m, tiles_n;
     int patch_h, patch_w;     // patch-major tile order (mfma_tile.h: patch_tile)
-#if MH_SPLIT_F16
     const int *expA, *expB;   // f16x3: power-of-two exponent per row of op(A) [M] and per column of op(B) [N]
-#endif
 };
 
 __device__ __forceinline__ float apply_epi(float v, int epilogue)
@@ -68,7 +66,6 @@ __global__ __launch_bounds__(kThreads, MH_MINW) void gemm_kernel(const GemmArgs 
         return (r < p.K) ? p.B + (size_t)r * p.ldb : nullptr;
     };
     const GSrc ga = make_gsrc(p.A), gb = make_gsrc(p.B);
-#if MH_PLANES
     // FAST operands: per-lane offsets planned once, the tile's advance goes into the scalar offset (mfma_tile.h)
     Plan<BM> pa;
     Plan<BN> pb;
@@ -79,12 +76,10 @@ __global__ __launch_bounds__(kThreads, MH_MINW) void gemm_kernel(const GemmArgs 
         if (TB) plan_wm<BN>(pb, [&](int r) { return n0 + r < p.N; }, p.ldb, ktail, tid);
         else plan_km<BN>(pb, p.N - n0, p.ldb, ktail, tid);
     }
-#endif
     // `live` = false turns every load of the tile into a zero-returning out-of-range access (FAST) instead of
     // skipping it: the loads of a k-tile are issued unconditionally, so their number is known to the compiler
     auto load_tiles = [&](Stage<BM> &sa, Stage<BN> &sb, int kt, bool live) {
         const int k0 = kt * kBK;
-#if MH_PLANES
         if (FAST) {
             const bool tail = k0 + kBK > p.K;
             const unsigned sa_off = TA ? ((unsigned)k0 * (unsigned)p.lda + (unsigned)m0) * 4u
@@ -97,7 +92,6 @@ __global__ __launch_bounds__(kThreads, MH_MINW) void gemm_kernel(const GemmArgs 
             else load_planned_km<BN>(sb, pb, gb, live ? sb_off : kDeadTile, tail);
             return;
         }
-#endif
         auto a_live = [&](int r) -> const float * { return live ? a_row(r) : nullptr; };
         auto b_live = [&](int r) -> const float * { return live ? b_row(r) : nullptr; };
         if (TA) load_km<BM, FAST>(sa, a_live, k0, m0, p.M, p.vecA != 0, tid, ga);
@@ -105,7 +99,6 @@ __global__ __launch_bounds__(kThreads, MH_MINW) void gemm_kernel(const GemmArgs 
         if (TB) load_wm<BN, FAST>(sb, b_live, k0, p.K, p.vecB != 0, tid, gb);
         else load_km<BN, FAST>(sb, b_live, k0, n0, p.N, p.vecB != 0, tid, gb);
     };
-#if MH_SPLIT_F16
     StageExp<BM> ea;
     StageExp<BN> eb;
     load_stage_exp<BM>(ea, p.expA, m0, p.M, AWM, tid, true);     // the arrays hold |x| maxima as bit patterns
@@ -118,12 +111,6 @@ __global__ __launch_bounds__(kThreads, MH_MINW) void gemm_kernel(const GemmArgs 
     auto unscale = [&](int row, int col, float v) {
         return __builtin_ldexpf(v, -(row_exponent((unsigned)p.expA[row]) + row_exponent((unsigned)p.expB[col])));
     };
-#else
-    auto store_tiles = [&](const Stage<BM> &sa, const Stage<BN> &sb, int buf) {
-        if (TA) store_km<BM>(sa, As(buf), tid); else store_wm<BM>(sa, As(buf), tid);
-        if (TB) store_wm<BN>(sb, Bs(buf), tid); else store_km<BN>(sb, Bs(buf), tid);
-    };
-#endif
 
     Acc acc;
     acc_zero(acc);
@@ -143,11 +130,7 @@ __global__ __launch_bounds__(kThreads, MH_MINW) void gemm_kernel(const GemmArgs 
         Stage<BN> &sb_next = cur ? sb0 : sb1, &sb_far = cur ? sb1 : sb0;
         auto load_far = [&]() { load_tiles(sa_far, sb_far, kt + 2, kt + 2 < kt_end); };
         auto store_next = [&]() { store_tiles(sa_next, sb_next, cur ^ 1); };
-#if MH_PLANES
         half_step<BM, BN>(load_far, store_next, As(cur), Bs(cur), wm, wn, lane, acc);
-#else
-        half_step_f32<BM, BN, AWM, BWM>(load_far, store_next, As(cur), Bs(cur), wm, wn, lane, acc);
-#endif
     };
     for (int kt = kt_begin; kt < kt_end; kt += 2) {
         step(std::integral_constant<int, 0>{}, kt);
@@ -160,10 +143,8 @@ __global__ __launch_bounds__(kThreads, MH_MINW) void gemm_kernel(const GemmArgs 
         acc_foreach_pair<AWM, BWM>(acc, wm, wn, lane, [&](int r, int c0, int c1, float v0, float v1) {
             const int row = m0 + r, col0 = n0 + c0, col1 = n0 + c1;
             if (row >= p.M) return;
-#if MH_SPLIT_F16
             if (col0 < p.N) v0 = unscale(row, col0, v0);
             if (col1 < p.N) v1 = unscale(row, col1, v1);
-#endif
             float *q = dst + (size_t)row * p.N;
             if (vec && col1 < p.N) *reinterpret_cast<float2 *>(q + col0) = make_float2(v0, v1);
             else { if (col0 < p.N) q[col0] = v0; if (col1 < p.N) q[col1] = v1; }
@@ -174,10 +155,8 @@ __global__ __launch_bounds__(kThreads, MH_MINW) void gemm_kernel(const GemmArgs 
         const int row = m0 + r, col0 = n0 + c0, col1 = n0 + c1;
         if (row >= p.M) return;
         const bool has0 = (col0 < p.N), has1 = (col1 < p.N);
-#if MH_SPLIT_F16
         if (has0) v0 = unscale(row, col0, v0);
         if (has1) v1 = unscale(row, col1, v1);
-#endif
         if (p.bias) { if (has0) v0 += p.bias[col0]; if (has1) v1 += p.bias[col1]; }
         v0 = apply_epi(v0, p.epilogue);
         v1 = apply_epi(v1, p.epilogue);
@@ -209,7 +188,6 @@ __global__ void splitk_reduce_kernel(const float *__restrict__ partial, int spli
     }
 }
 
-#if MH_SPLIT_F16
 // ---------------------------------------------------------------------------------------------------------------
 // f16x3 row exponents.  An operand row (a row of op(A), a column of op(B)) is scaled by 2^e with its largest |x| in
 // [2^14, 2^15); e is constant along K, so it factors out of the dot product and is removed exactly in the epilogue.
@@ -528,7 +506,6 @@ int launch_row_exponents(const float *X, bool k_contiguous, long long n_rows, lo
     hipLaunchKernelGGL(bits_to_exp_kernel, dim3((unsigned)ceil_div(n_rows, 256LL)), dim3(256), 0, st, bits, n_rows);
     return check_launch("bits_to_exp_kernel");
 }
-#endif  // MH_SPLIT_F16
 
 // Work-distribution model shared by GEMM and conv: `tiles` output tiles of `ktiles` k-steps each are cut into
 // S k-slices.  A CU holds k = resident_slots() / 256 blocks of the tile engine (LDS / VGPR budget) and runs them at
@@ -602,7 +579,7 @@ extern "C" {
 
 int mh_mfma_split(void) { return MH_MFMA_SPLIT; }
 int mh_split_f16(void) { return MH_SPLIT_F16; }
-int mh_split_rne(void) { return (MH_MFMA_SPLIT != 0 && MH_SPLIT_RN) ? 1 : 0; }
+int mh_split_rne(void) { return 0; }      /* the bf16 round-to-nearest split variant is gone (round 3); kept for ABI stability */
 
 int mh_gemm_auto_splitk_v2(int M, int N, int K) { return (M > 0 && N > 0 && K > 0) ? choose_splitk(M, N, K) : 1; }
 
@@ -610,7 +587,7 @@ size_t mh_gemm_ws_bytes_v2(int M, int N, int K, int splitk)
 {
     if (M <= 0 || N <= 0 || K <= 0) return 0;
     if (splitk <= 0) splitk = choose_splitk(M, N, K);
-    const size_t exps = MH_SPLIT_F16 ? align_up((size_t)M * sizeof(int), 256) + align_up((size_t)N * sizeof(int), 256) : 0;
+    const size_t exps = align_up((size_t)M * sizeof(int), 256) + align_up((size_t)N * sizeof(int), 256);
     if (splitk <= 1) return exps;
     return exps + align_up((size_t)splitk * M * N * sizeof(float), 256);
 }
@@ -629,7 +606,6 @@ int mh_gemm_f32_v2(int transA, int transB, int M, int N, int K, const float *A, 
     splitk = std::min(std::min(splitk, total_kt), 64);
     hipStream_t st = as_stream(stream);
     GemmArgs p;
-#if MH_SPLIT_F16
     {   // the row exponents live at the head of the workspace (mh_gemm_ws_bytes counts them): mandatory in this build
         const size_t ea = align_up((size_t)M * sizeof(int), 256), eb = align_up((size_t)N * sizeof(int), 256);
         MH_REQUIRE(workspace && ws_bytes >= ea + eb);
@@ -640,7 +616,6 @@ int mh_gemm_f32_v2(int transA, int transB, int M, int N, int K, const float *A, 
         workspace = reinterpret_cast<char *>(workspace) + ea + eb;
         ws_bytes -= ea + eb;
     }
-#endif
     if (splitk > 1 && (workspace == nullptr || ws_bytes < (size_t)splitk * M * N * sizeof(float))) splitk = 1;
     p.M = M; p.N = N; p.K = K;
     p.A = A; p.lda = lda; p.B = B; p.ldb = ldb; p.C = C; p.ldc = ldc;

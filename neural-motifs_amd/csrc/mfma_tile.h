@@ -4,25 +4,17 @@
 // (16 VGPRs each).  Two block shapes are used:
 //   128x128 (waves 2x2)  -- the default
 //   256x64  (waves 4x1)  -- for N <= 64 (the 64-channel VGG layer), so no MFMA issues on padding columns
-// Two interchangeable inner loops compute the same fp32 result (selected at build time, MH_MFMA_SPLIT):
-//   6 (default): "bf16x6" -- each fp32 operand is split exactly into three bf16 terms in registers and six
-//      v_mfma_f32_32x32x16_bf16 accumulate the cross terms in fp32 (see below): 6/16 of the matrix-core time of
-//   0: v_mfma_f32_32x32x2_f32, the f32-input MFMA (an exact fp32 fma chain, 64 cycles per 2 k).
-// Measured error against fp64 is the same for both (tools/gemm_accuracy.py).
+// The inner loop is "f16x3": an fp32 operand row is scaled by a power of two and split into two f16 terms by the thread that
+// stages it (once per block), the LDS image holds the (h1 | h2) planes, and three v_mfma_f32_32x32x16_f16 per accumulator
+// and k-tile accumulate h2*h1', h1*h2', h1*h1' in fp32 (error against fp64: tools/split_check.cpp,
+// profiles/r02_split_check.jsonl).  This is the round-2 engine: since round 3 the big products run on pre-split plane images
+// with no arithmetic in the K loop (pl_tile.h); this header serves the small products, the mask tower's conv and the conv
+// weight gradient.
 //
-// An operand tile lives in LDS as fp32 in the orientation its GLOBAL storage has, so that staging is always a
-// straight 16-byte copy (global_load_dwordx4 -> ds_write_b128), never a transposing scatter:
-//   * "KM" (k-major, [k][w], row stride w+4): operands stored with the tile's row/column dimension contiguous
-//     (B of y = x*W when W is [K,N]; both operands of a weight gradient).  The wave's 64 rows are interleaved over
-//     its two 32-row MFMA sub-tiles (tile row 2i+s -> sub-tile s), so one ds_read_b64 feeds both sub-tiles.
-//   * "WM" (width-major, [w][k], row stride 16+4): operands stored K-contiguous (activations, nn.Linear weights,
-//     NHWC pixels).  Sub-tile s owns tile rows i+32s; a lane reads 4 consecutive k of its row with one
-//     ds_read_b128 (conflict-free at stride 20: the 16 lanes of a service group cover all 64 banks).
-// The k index of a tile is permuted consistently for both operands: MFMA lane group g = lane>>5 takes
-// k = 8g + step (step = 0..7): the f32 loop runs 8 steps of 2 k, the bf16 loop consumes the lane's 8 k at once
-// (order of the fp32 summation over k changes, nothing else).
-// In the f32 loop the LDS reads of step kk+1 are issued before the 4 MFMAs of step kk (order pinned with
-// sched_group_barrier) so the MFMA issue covers the LDS latency in-wave.
+// Operand orientations: "WM" (width-major, K-contiguous: activations, nn.Linear weights, NHWC pixels) and "KM" (k-major:
+// the tile's row / column dimension contiguous -- B of y = x*W with W [K,N], both operands of a weight gradient, which are
+// transposed in registers through k-pairs while being split).  The k index of a tile is permuted consistently for both
+// operands: MFMA lane group g = lane>>5 takes k = 8g .. 8g+7 (the order of the fp32 summation over k changes, nothing else).
 // Accumulator (C/D) map of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5), r in [0,16).
 #pragma once
 #include "common.h"
@@ -30,23 +22,12 @@
 #ifndef MH_MINW
 #define MH_MINW 2
 #endif
-#ifndef MH_SPLIT_F16
-#define MH_SPLIT_F16 1    /* 1 (default since round 2): "f16x3" engine -- two-term f16 split with a power-of-two scale per
-                             operand row, three v_mfma_f32_32x32x16_f16 per product; validated on MI355X by the whole
-                             -m gpu suite and tools/split_check (profiles/r02_split_check.jsonl).  0: the bf16x6 engine. */
-#endif
-#ifndef MH_MFMA_SPLIT
-#define MH_MFMA_SPLIT (MH_SPLIT_F16 ? 3 : 6)   /* MFMAs per fp32 product: 3 = f16x3 with MH_SPLIT_F16 (default) / bf16x3 without
-                                                  (2^-17, tests only), 6 = bf16x6 (MH_SPLIT_F16=0), 0 = f32-input MFMA */
-#endif
-#if MH_SPLIT_F16 && MH_MFMA_SPLIT != 3
-#error "MH_SPLIT_F16 needs MH_MFMA_SPLIT == 3"
-#endif
-
-#ifndef MH_SPLIT_RN
-#define MH_SPLIT_RN 0    /* 1: the bf16 split rounds to nearest even instead of truncating (see split_pair) */
-#endif
-#define MH_PLANES (MH_MFMA_SPLIT != 0)   /* bf16 builds keep the operands as bf16 planes in LDS, split once at staging */
+// The engine of this header is "f16x3": two-term f16 split with a power-of-two scale per operand row, three
+// v_mfma_f32_32x32x16_f16 per product.  Round 1 / 2 carried two more builds of the same kernels (bf16x6: three-term bf16
+// split, six MFMAs; f32-input MFMA) behind MH_SPLIT_F16 / MH_MFMA_SPLIT / MH_SPLIT_RN; their measurements are in
+// profiles/r01_split_check.jsonl and r02_split_check.jsonl, their code was removed in round 3 (git history: c0ffe9e).
+#define MH_MFMA_SPLIT 3      /* MFMAs per fp32 product (reported by mh_mfma_split()) */
+#define MH_SPLIT_F16 1       /* reported by mh_split_f16() */
 
 namespace mh {
 
@@ -55,18 +36,14 @@ constexpr int kThreads = 256;
 constexpr int kLdW = kBK + 4;   // WM row stride (floats)
 
 constexpr int kRowDw = 24;      // bf16-plane layout: dwords per operand row (3 planes x 8 dwords = 96 B)
-constexpr int kNumPlanes = MH_SPLIT_F16 ? 2 : 3;          // planes a row really holds (f16x3: h1 | h2, third slot pair unused)
+constexpr int kNumPlanes = 2;          // planes a row really holds (h1 | h2; the row keeps round 1's 96-byte stride, third slot pair unused)
 constexpr int kPlaneChunks = 2 * kNumPlanes;              // 16-byte chunks per row of an operand stored as planes in HBM
 constexpr int kPlaneRowBytes = 16 * kPlaneChunks;         // ... and its bytes per (row, k-tile): 96 (bf16x6) / 64 (f16x3)
 
 template <int WD, bool WM>
 struct TileGeom {
     static constexpr int ld = WM ? kLdW : WD + 4;        // fp32 layout: LDS row stride (floats); keeps 16-B alignment
-#if MH_PLANES
     static constexpr int floats = WD * kRowDw;
-#else
-    static constexpr int floats = WM ? WD * kLdW : kBK * (WD + 4);
-#endif
     static constexpr int nv = WD * kBK / 1024;            // float4 staged per thread for a WM operand (256 threads)
 };
 
@@ -171,14 +148,6 @@ __device__ __forceinline__ void mma_ktile_f32(const float *__restrict__ As, cons
 // ---------------------------------------------------------------------------------------------------------------
 typedef short bf16x8 __attribute__((ext_vector_type(8)));
 
-#if !MH_PLANES
-template <bool AWM, bool BWM, int BM, int BN>
-__device__ __forceinline__ void mma_ktile(const float *__restrict__ As, const float *__restrict__ Bs, int wm, int wn,
-                                          int lane, Acc &acc)
-{
-    mma_ktile_f32<AWM, BWM, BM, BN>(As, Bs, wm, wn, lane, acc);
-}
-#endif  // !MH_PLANES
 
 // Staging registers for one operand k-tile of width WD: WD/64 float4 per thread.
 template <int WD>
@@ -237,35 +206,6 @@ __device__ __forceinline__ float4 load4_guarded(const float *p, int c, int exten
     return v;
 }
 
-#if !MH_PLANES
-// ---- KM operand: global rows are k (contiguous along the tile's w dimension).
-// tile = kBK rows x WD floats; float4 f = tid + 256*j sits at (row f / (WD/4), float4-column f % (WD/4)).
-// row_ptr(k) returns the address of matrix element (k, 0) or nullptr when row k is all-zero / out of range;
-// `col0` = first tile column in the matrix, `ncols` = matrix extent along the contiguous dimension.
-template <int WD, bool FAST, typename RowPtr>
-__device__ __forceinline__ void load_km(Stage<WD> &s, RowPtr row_ptr, int k0, int col0, int ncols, bool vec, int tid,
-                                        const GSrc &safe)
-{
-    constexpr int c4n = WD / 4;
-#pragma unroll
-    for (int j = 0; j < TileGeom<WD, false>::nv; ++j) {
-        const int f = tid + kThreads * j;
-        s.v[j] = load4_guarded<FAST>(row_ptr(k0 + f / c4n), col0 + 4 * (f % c4n), ncols, vec, safe);
-    }
-}
-
-template <int WD>
-__device__ __forceinline__ void store_km(const Stage<WD> &s, float *tile, int tid)
-{
-    constexpr int c4n = WD / 4;
-#pragma unroll
-    for (int j = 0; j < TileGeom<WD, false>::nv; ++j) {
-        const int f = tid + kThreads * j;
-        *reinterpret_cast<float4 *>(tile + (f / c4n) * TileGeom<WD, false>::ld + 4 * (f % c4n)) = s.v[j];
-    }
-}
-
-#endif  // !MH_PLANES
 
 // ---- WM operand: global rows are the tile's w dimension (k contiguous).  float4 f = tid + 256*j belongs to tile
 // row f / 4, k-quad f % 4: four consecutive lanes read one row's 64 contiguous bytes.
@@ -282,20 +222,7 @@ __device__ __forceinline__ void load_wm(Stage<WD> &s, RowPtr row_ptr, int k0, in
     }
 }
 
-#if !MH_PLANES
-template <int WD>
-__device__ __forceinline__ void store_wm(const Stage<WD> &s, float *tile, int tid)
-{
-#pragma unroll
-    for (int j = 0; j < TileGeom<WD, true>::nv; ++j) {
-        const int f = tid + kThreads * j;
-        *reinterpret_cast<float4 *>(tile + (f >> 2) * kLdW + 4 * (f & 3)) = s.v[j];
-    }
-}
 
-#endif
-
-#if MH_PLANES
 // ---------------------------------------------------------------------------------------------------------------
 // bf16-plane LDS image (MH_MFMA_SPLIT != 0): every element is split ONCE, by the thread that
 // stages it, and LDS holds the three bf16 planes k-contiguous per operand row, whatever the global orientation:
@@ -323,25 +250,6 @@ __device__ __forceinline__ int plane_swz(int r) { return (r >> 3) & 1; }
 //   MH_SPLIT_RN 1: round-to-nearest-even via v_cvt_pk_bf16_f32.  |mid| <= 2^-8|x|, |lo| <= 2^-16|x|: dropped part
 //       <= 2^-24|ab|, typically 2^-28|ab|, zero mean; same VALU count.  (x within half a bf16 ulp of FLT_MAX rounds
 //       to inf, which truncation does not.)
-#if MH_SPLIT_RN
-typedef __bf16 bf16pair_t __attribute__((ext_vector_type(2)));
-typedef float f32pair_t __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ unsigned pack_rne(float lo16, float hi16)
-{
-    const f32pair_t v = {lo16, hi16};
-    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16pair_t));
-}
-__device__ __forceinline__ void split_pair(float x0, float x1, unsigned &ph, unsigned &pm, unsigned &pl)
-{
-    ph = pack_rne(x0, x1);
-    const float r0 = x0 - __builtin_bit_cast(float, ph << 16);
-    const float r1 = x1 - __builtin_bit_cast(float, ph & 0xffff0000u);
-    pm = pack_rne(r0, r1);
-    const float s0 = r0 - __builtin_bit_cast(float, pm << 16);
-    const float s1 = r1 - __builtin_bit_cast(float, pm & 0xffff0000u);
-    pl = pack_rne(s0, s1);                     // exact: the remainder has at most 8 significant bits
-}
-#else
 __device__ __forceinline__ void split_pair(float x0, float x1, unsigned &ph, unsigned &pm, unsigned &pl)
 {
     constexpr unsigned kTop = 0x07060302u;   // v_perm_b32: {S0.hi16, S1.hi16}
@@ -355,9 +263,7 @@ __device__ __forceinline__ void split_pair(float x0, float x1, unsigned &ph, uns
     const float s1 = r1 - __builtin_bit_cast(float, v1 & 0xffff0000u);
     pl = __builtin_amdgcn_perm(__builtin_bit_cast(unsigned, s1), __builtin_bit_cast(unsigned, s0), kTop);
 }
-#endif
 
-#if MH_SPLIT_F16
 // f16x3: (x0, x1) scaled by 2^e of their operand ROW (e0 / e1: the two elements may belong to different rows), then
 // a*2^e = h1 + h2 + r with h1 = f16(a*2^e), h2 = f16(a*2^e - h1) (round to nearest even), |r| <= 2^-24 |a*2^e|.
 // The row exponent puts the row's largest magnitude into [2^14, 2^15) (row_exponent), so nothing overflows f16.
@@ -380,7 +286,6 @@ __host__ __device__ __forceinline__ int row_exponent(unsigned absmax_bits)
     if (biased == 0 || biased == 0xff) return 0;      // zero / denormal rows need no help: denormals are < 2^-126
     return 14 - (biased - 127);
 }
-#endif
 
 // KM task t -> (w-quad q, k-pair kp); tasks = 2*WD (8 k-pairs x WD/4 quads), 64 per wave
 template <int WD>
@@ -409,10 +314,8 @@ __device__ __forceinline__ void load_km(Stage<WD> &s, RowPtr row_ptr, int k0, in
 // tile row), four per k-pair task of a KM operand (its four tile columns).  Empty in the other builds.
 template <int WD>
 struct StageExp {
-#if MH_SPLIT_F16
     int wm[WD >= 128 ? WD / 64 : 2];
     int km[(2 * WD + kThreads - 1) / kThreads][4];
-#endif
 };
 // exps[i] = exponent of tile row / column i (i relative to the tile origin `o0`, `n` valid entries from there); with
 // `bits` the array holds the rows' largest |x| as fp32 bit patterns (what the absmax pass writes) and the exponent is
@@ -421,7 +324,6 @@ template <int WD>
 __device__ __forceinline__ void load_stage_exp(StageExp<WD> &se, const int *__restrict__ exps, long long o0, long long n,
                                                bool wm, int tid, bool bits = false)
 {
-#if MH_SPLIT_F16
     auto ex = [&](long long i) { return bits ? row_exponent((unsigned)exps[i]) : exps[i]; };
     if (wm) {
 #pragma unroll
@@ -439,7 +341,6 @@ __device__ __forceinline__ void load_stage_exp(StageExp<WD> &se, const int *__re
             for (int j = 0; j < 4; ++j) se.km[jt][j] = (o0 + 4 * q + j < n) ? ex(o0 + 4 * q + j) : 0;
         }
     }
-#endif
 }
 
 template <int WD>
@@ -459,11 +360,7 @@ __device__ __forceinline__ void store_km(const Stage<WD> &s, float *tile, int ti
             const int r = 64 * (w >> 6) + 32 * (w & 1) + ((w & 63) >> 1);
             const int sw = plane_swz(r);
             unsigned pl[3];
-#if MH_SPLIT_F16
             split_pair_f16(e[j], o[j], se.km[jt][j], se.km[jt][j], pl[0], pl[1]);     // k, k+1 of the same column
-#else
-            split_pair(e[j], o[j], pl[0], pl[1], pl[2]);
-#endif
 #pragma unroll
             for (int pidx = 0; pidx < kNumPlanes; ++pidx)
                 t32[r * kRowDw + 4 * ((2 * pidx + (kp >> 2)) ^ sw) + (kp & 3)] = pl[pidx];
@@ -480,13 +377,8 @@ __device__ __forceinline__ void store_wm(const Stage<WD> &s, float *tile, int ti
         const int f = tid + kThreads * j;
         const int r = f >> 2, kq = f & 3, sw = plane_swz(r);
         unsigned a[3], b[3];
-#if MH_SPLIT_F16
         split_pair_f16(s.v[j].x, s.v[j].y, se.wm[j], se.wm[j], a[0], a[1]);
         split_pair_f16(s.v[j].z, s.v[j].w, se.wm[j], se.wm[j], b[0], b[1]);
-#else
-        split_pair(s.v[j].x, s.v[j].y, a[0], a[1], a[2]);
-        split_pair(s.v[j].z, s.v[j].w, b[0], b[1], b[2]);
-#endif
 #pragma unroll
         for (int pidx = 0; pidx < kNumPlanes; ++pidx) {
             typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
@@ -508,7 +400,6 @@ __device__ __forceinline__ void fetch_frags(PlaneFrags &f, const float *__restri
     auto fetch = [&](const float *tile, int row, int pidx) -> bf16x8 {
         return *reinterpret_cast<const bf16x8 *>(tile + row * kRowDw + 4 * ((2 * pidx + g) ^ plane_swz(row)));
     };
-#if MH_SPLIT_F16
     constexpr int kOrderA[2] = {1, 0}, kOrderB[2] = {0, 1};         // planes in order of first use: 8 ds_read_b128
 #pragma unroll
     for (int o = 0; o < 2; ++o) {
@@ -518,21 +409,9 @@ __device__ __forceinline__ void fetch_frags(PlaneFrags &f, const float *__restri
             f.b[sidx][kOrderB[o]] = fetch(Bs, wn + 32 * sidx + i, kOrderB[o]);
         }
     }
-#else
-    constexpr int kOrderA[3] = {2, 0, 1}, kOrderB[3] = {0, 2, 1};   // planes in order of first use
-#pragma unroll
-    for (int o = 0; o < 3; ++o) {
-#pragma unroll
-        for (int sidx = 0; sidx < 2; ++sidx) {
-            if (MH_MFMA_SPLIT >= 6 || kOrderA[o] != 2) f.a[sidx][kOrderA[o]] = fetch(As, wm + 32 * sidx + i, kOrderA[o]);
-            if (MH_MFMA_SPLIT >= 6 || kOrderB[o] != 2) f.b[sidx][kOrderB[o]] = fetch(Bs, wn + 32 * sidx + i, kOrderB[o]);
-        }
-    }
-#endif
 }
 // All MFMAs of one k-tile.  Per accumulator the six terms are added smallest first (lo*hi, hi*lo, mid*mid, mid*hi,
 // hi*mid, hi*hi); the four accumulators are interleaved so that consecutive MFMAs are independent.
-#if MH_SPLIT_F16
 // f16x3: h2*h1, h1*h2, h1*h1 (smallest first); h2*h2 <= 2^-24 |ab| is dropped
 __device__ __forceinline__ void mma_frags(const PlaneFrags &f, Acc &acc)
 {
@@ -547,21 +426,6 @@ __device__ __forceinline__ void mma_frags(const PlaneFrags &f, Acc &acc)
                                                                        __builtin_bit_cast(f16x8, f.b[sn][kTermB[t]]),
                                                                        acc.v[sm][sn], 0, 0, 0);
 }
-#else
-__device__ __forceinline__ void mma_frags(const PlaneFrags &f, Acc &acc)
-{
-    constexpr int kTermA[6] = {2, 0, 1, 1, 0, 0}, kTermB[6] = {0, 2, 1, 0, 1, 0};
-#pragma unroll
-    for (int t = (MH_MFMA_SPLIT >= 6 ? 0 : 3); t < 6; ++t)
-#pragma unroll
-        for (int sm = 0; sm < 2; ++sm)
-#pragma unroll
-            for (int sn = 0; sn < 2; ++sn)
-                acc.v[sm][sn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[sm][kTermA[t]], f.b[sn][kTermB[t]],
-                                                                        acc.v[sm][sn], 0, 0, 0);
-}
-#endif  // MH_SPLIT_F16
-#endif  // MH_PLANES
 
 // ---------------------------------------------------------------------------------------------------------------
 // Planned loads (FAST operands in bf16-plane mode).  The per-lane byte offset of every staged float4 is fixed for
@@ -597,7 +461,6 @@ __device__ __forceinline__ void load_planned_wm(Stage<WD> &s, const Plan<WD> &pl
     for (int j = 0; j < TileGeom<WD, true>::nv; ++j) s.v[j] = buffer_load4(g, tail ? pl.t[j] : pl.v[j], soff);
 }
 
-#if MH_PLANES
 // KM operand (see km_task): float4 2jt + i = row k = 2 kp + i, columns 4q .. 4q+3 of the tile; ncols_left = number
 // of valid columns counted from the tile's first column
 template <int WD>
@@ -624,9 +487,7 @@ __device__ __forceinline__ void load_planned_km(Stage<WD> &s, const Plan<WD> &pl
 #pragma unroll
     for (int j = 0; j < 2 * ntask; ++j) s.v[j] = buffer_load4(g, tail ? pl.t[j] : pl.v[j], soff);
 }
-#endif
 
-#if MH_PLANES
 // ---------------------------------------------------------------------------------------------------------------
 // Operands that already ARE bf16 planes in global memory (packed weights): a tile row's k-tile is 96 contiguous
 // bytes in exactly the LDS row format, so staging is 16-byte chunks copied global -> registers -> LDS with no VALU:
@@ -649,13 +510,11 @@ __device__ __forceinline__ void plan_planes(PPlan<WD> &pl, RowOk row_ok, unsigne
     for (int j = 0; j < PStage<WD>::n; ++j) {
         const int e = tid + kThreads * j, c = e % kPlaneChunks;
         int r = e / kPlaneChunks;
-#if MH_SPLIT_F16
         // f16x3 rows use 64 of their 96 bytes, so the four rows a 16-lane group of the ds_write_b128 covers must be chosen
         // such that their spans tile the 256 bytes of the 64 banks: rows {0,6,4,2} / {1,7,5,3} of every 8 sit at
         // 0,64,128,192 / 96,160,224,32 (mod 256).  Consecutive rows (0,96,192,288) put row 3 on row 0's banks: 2-way
         // conflicts on every write (PMC: SQ_LDS_BANK_CONFLICT = 20 % of the LDS-active cycles of the conv, r02_c14).
         r = (r & ~7) | ((0x35712460u >> (4 * (r & 7))) & 7);
-#endif
         const bool ok = (e < WD * kPlaneChunks) && row_ok(r);
         pl.v[j] = ok ? (unsigned)r * row_stride_bytes + 16u * c : kOobOffset;
         pl.lds[j] = (unsigned)(r * kRowDw * 4 + 16 * (c ^ plane_swz(r)));
@@ -679,7 +538,6 @@ __device__ __forceinline__ void store_planes(const PStage<WD> &s, const PPlan<WD
         if ((WD * kPlaneChunks) % kThreads == 0 || tid + kThreads * j < WD * kPlaneChunks)
             *reinterpret_cast<u32x4 *>(base + pl.lds[j]) = s.v[j];
 }
-#endif
 
 // tile row (or column) held by MFMA index idx (0..31) of sub-tile s, for the two operand layouts
 template <bool WM>
@@ -769,7 +627,6 @@ constexpr size_t tile_lds_bytes() { return 2 * (size_t)(TileGeom<BM, AWM>::float
 // Tiles beyond the last one are loaded as zeros (masked buffer loads), which makes the phantom half-step of an odd
 // tile count harmless (acc += 0) and keeps the loop free of branches -- the load count per step is static, so the
 // compiler waits with vmcnt(N > 0) and tile kt+2 stays in flight while tile kt+1 is consumed.
-#if MH_PLANES
 template <int BM, int BN, typename LoadFn, typename StoreFn>
 __device__ __forceinline__ void half_step(LoadFn load_far, StoreFn store_next, const float *As, const float *Bs, int wm,
                                           int wn, int lane, Acc &acc)
@@ -780,7 +637,6 @@ __device__ __forceinline__ void half_step(LoadFn load_far, StoreFn store_next, c
     fetch_frags<BM, BN>(f, As, Bs, wm, wn, lane);
     store_next();
     mma_frags(f, acc);
-#if MH_SPLIT_F16
     __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);        // fragment reads (two planes)
     __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);
 #ifndef MH_F16_VALU
@@ -794,7 +650,6 @@ __device__ __forceinline__ void half_step(LoadFn load_far, StoreFn store_next, c
     }
     __syncthreads();
     return;
-#endif
     __builtin_amdgcn_sched_group_barrier(0x100, 12, 0);       // fragment reads
     __builtin_amdgcn_sched_group_barrier(0x002, 12, 0);       // first split ops while the reads land
 #pragma unroll
@@ -805,20 +660,8 @@ __device__ __forceinline__ void half_step(LoadFn load_far, StoreFn store_next, c
     }
     __syncthreads();
 }
-#else
-template <int BM, int BN, bool AWM, bool BWM, typename LoadFn, typename StoreFn>
-__device__ __forceinline__ void half_step_f32(LoadFn load_far, StoreFn store_next, const float *As, const float *Bs,
-                                              int wm, int wn, int lane, Acc &acc)
-{
-    load_far();
-    mma_ktile<AWM, BWM, BM, BN>(As, Bs, wm, wn, lane, acc);
-    store_next();
-    __syncthreads();
-}
-#endif
 
 // defined in gemm.hip
-#if MH_SPLIT_F16
 int launch_row_exponents(const float *X, bool k_contiguous, long long n_rows, long long kext, long long ld, int *exps,
                          hipStream_t st, bool bits_only = false);
 // largest |x| (fp32 bit patterns) of the rows of TWO operands in one launch (+ one memset when a k-major operand needs
@@ -826,7 +669,6 @@ int launch_row_exponents(const float *X, bool k_contiguous, long long n_rows, lo
 int launch_operand_absmax(const float *A, bool a_kcontig, long long a_rows, long long a_kext, long long lda, int *bitsA,
                           const float *B, bool b_kcontig, long long b_rows, long long b_kext, long long ldb, int *bitsB,
                           hipStream_t st);
-#endif
 int choose_splitk_tiles(long long tiles, int ktiles, double out_elems, double flops);
 // defined in conv.hip: the tile schedule of a 3x3 conv launch with bm x bn block tiles (ConvArgs explains the fields)
 struct ConvTilePlan {

@@ -119,7 +119,8 @@ def _oracle_on_product_detections(model, sd, cfg, a, got, tag, logits_tol=1e-4, 
     with torch.no_grad():
         ref, rl = OM.relmodel_forward({k: v.clone() for k, v in sd.items()}, dict(cfg, return_logits=True), a[0], a[1], 0, a[3], a[4],
                                       False, OM.HostRNG(0), det_override=override)
-    floor = {}
+    floor, ref_scores = {}, None
+    key2 = lambda r: r[:, 0] * 1000 + r[:, 1]
     if fp64_floor:
         # The fp32 rounding floor of these tensors: the same oracle evaluated in float64 on the same detections.  At cfg5's
         # size (80-step recurrences, 6320 pairs) two correct fp32 evaluations differ by more than 1e-4 of scale: the fp32
@@ -128,7 +129,7 @@ def _oracle_on_product_detections(model, sd, cfg, a, got, tag, logits_tol=1e-4, 
         # and the product-vs-fp32-oracle bound is widened by the fp32 oracle's own measured error.
         dbl = lambda t: t.double() if torch.is_tensor(t) and t.is_floating_point() else t
         with torch.no_grad():
-            _, rl64 = OM.relmodel_forward({k: dbl(v.clone()) for k, v in sd.items()}, dict(cfg, return_logits=True), a[0].double(), a[1], 0,
+            ref_scores, rl64 = OM.relmodel_forward({k: dbl(v.clone()) for k, v in sd.items()}, dict(cfg, return_logits=True), a[0].double(), a[1], 0,
                                           dbl(a[3]), a[4], False, OM.HostRNG(0), det_override={k: dbl(v) for k, v in override.items()})
         for k, prod in (('rm_obj_dists', last.rm_obj_dists), ('rel_dists', last.rel_dists)):
             r64 = rl64[k].numpy()
@@ -144,7 +145,10 @@ def _oracle_on_product_detections(model, sd, cfg, a, got, tag, logits_tol=1e-4, 
     np.testing.assert_array_equal(boxes, ref[0])                                    # class-specific boxes of those labels
     rel_close(last.rm_obj_dists.cpu().numpy(), rl['rm_obj_dists'].numpy(), rtol=logits_tol + floor.get('rm_obj_dists', 0.0), what=tag + ' object logits')
     rel_close(last.rel_dists.cpu().numpy(), rl['rel_dists'].numpy(), rtol=logits_tol + floor.get('rel_dists', 0.0), what=tag + ' relation logits')
-    rel_close(obj_scores, ref[2], rtol=logits_tol, what=tag + ' object scores')
+    # scores / probabilities (softmax outputs): against the float64 evaluation where the fp32 floor was measured, else the fp32 oracle
+    sc_ref = ref if ref_scores is None else ref_scores
+    assert ref_scores is None or (np.array_equal(ref_scores[1], ref[1]) and np.array_equal(np.sort(key2(ref_scores[3])), np.sort(key2(ref[3]))))
+    rel_close(obj_scores, np.asarray(sc_ref[2], dtype=np.float64), rtol=logits_tol, what=tag + ' object scores')
     key = lambda r: r[:, 0] * 1000 + r[:, 1]
     assert sorted(key(rels).tolist()) == sorted(key(ref[3]).tolist())               # the same candidate pairs
 
@@ -155,8 +159,8 @@ def _oracle_on_product_detections(model, sd, cfg, a, got, tag, logits_tol=1e-4, 
     eps = 1e-5 * max(1.0, float(sr.max()))
     firm = np.concatenate(([True], gaps > eps)) & np.concatenate((gaps > eps, [True]))
     np.testing.assert_array_equal(rels[firm], ref[3][firm])
-    og, orr = np.argsort(key(rels), kind='stable'), np.argsort(key(ref[3]), kind='stable')
-    rel_close(pred_scores[og], ref[4][orr], rtol=logits_tol, what=tag + ' predicate probabilities')
+    og, orr = np.argsort(key(rels), kind='stable'), np.argsort(key(sc_ref[3]), kind='stable')
+    rel_close(pred_scores[og], np.asarray(sc_ref[4], dtype=np.float64)[orr], rtol=logits_tol, what=tag + ' predicate probabilities')
     print('%s: %d detections, %d pairs, %d of them firmly ranked' % (tag, boxes.shape[0], rels.shape[0], int(firm.sum())))
     return ref
 

@@ -141,7 +141,7 @@ def test_packed_plane_chunk_writes_tile_the_banks_in_f16x3():
     perm = [(code >> (4 * i)) & 7 for i in range(8)]
     assert sorted(perm) == list(range(8))
     chunks = 4                                         # kPlaneChunks of the f16x3 build: h1 | h2, 2 x 16 B each
-    assert 'constexpr int kPlaneChunks = 2 * kNumPlanes;' in HDR and 'kNumPlanes = MH_SPLIT_F16 ? 2 : 3' in HDR
+    assert 'constexpr int kPlaneChunks = 2 * kNumPlanes;' in HDR and 'constexpr int kNumPlanes = 2;' in HDR
     groups = [list(range(8 * g, 8 * g + 8)) for g in range(8)]
 
     def worst(permute, WD):
