@@ -574,7 +574,9 @@ struct Sched {
 static Sched schedule(long long M, int Cin, int Cout)
 {
     Sched s;
-    s.shape = (g_conv_shape >= 0) ? g_conv_shape : (Cout <= 64 ? 2 : 1);
+    // MH_PLCONV_SHAPE=0|1: block tile of the Cout >= 128 layers for A/B runs of the whole step (0 = 256x128, 1 = 128x128)
+    static const int env_shape = [] { const char *e = getenv("MH_PLCONV_SHAPE"); return e ? atoi(e) : -1; }();
+    s.shape = (g_conv_shape >= 0) ? g_conv_shape : (Cout <= 64 ? 2 : (env_shape >= 0 ? env_shape : 1));
     s.bm = (s.shape == 1) ? 128 : 256;
     s.bn = (s.shape == 2) ? 64 : 128;
     s.pl = plan_conv_tiles(M, Cin, Cout, s.bm, s.bn);

@@ -315,7 +315,12 @@ class VGG16Features(nn.Sequential):
     def forward(self, x):
         if any(p.requires_grad for p in self.parameters()) and torch.is_grad_enabled():
             return self._forward_trainable(x)          # detector pre-training (models/train_detector.py)
-        if os.environ.get('MOTIFS_TRUNK', 'planes') == 'planes':
+        # Engine of the frozen trunk: plane images (csrc/pl_conv.hip) for batches, the round-2 in-loop kernels for a single
+        # image -- at b = 1 most layers have fewer tiles than one round of resident blocks and the converters' launches are
+        # not paid back (cfg1 evaluation: 2.06 ms of conv per image on planes, 1.5 ms on the in-loop kernels).
+        # MOTIFS_TRUNK=planes|v2 forces one engine.
+        engine = os.environ.get('MOTIFS_TRUNK', 'auto')
+        if engine == 'planes' or (engine == 'auto' and x.shape[0] >= 2):
             return self._forward_planes(x)
         with torch.no_grad():
             mods = list(self.children())

@@ -154,11 +154,14 @@ def _oracle_on_product_detections(model, sd, cfg, a, got, tag, logits_tol=1e-4, 
 
     def ranking(t):
         return t[4][:, 1:].max(1) * t[2][t[3][:, 0]] * t[2][t[3][:, 1]]
-    sr = ranking(ref)
+    # ranked order: exact wherever two ranking scores (a product of three probabilities) are separated by more than their
+    # rounding -- 1e-5 of scale normally, three times the probability tolerance where the fp32 floor was measured (cfg5)
+    rank_ref = ref if ref_scores is None else tuple(np.asarray(t) for t in ref_scores)
+    sr = ranking(rank_ref)
     gaps = np.abs(np.diff(sr))
-    eps = 1e-5 * max(1.0, float(sr.max()))
+    eps = (1e-5 if ref_scores is None else 3.0 * logits_tol) * max(1.0, float(sr.max()))
     firm = np.concatenate(([True], gaps > eps)) & np.concatenate((gaps > eps, [True]))
-    np.testing.assert_array_equal(rels[firm], ref[3][firm])
+    np.testing.assert_array_equal(rels[firm], rank_ref[3][firm])
     og, orr = np.argsort(key(rels), kind='stable'), np.argsort(key(sc_ref[3]), kind='stable')
     rel_close(pred_scores[og], np.asarray(sc_ref[4], dtype=np.float64)[orr], rtol=logits_tol, what=tag + ' predicate probabilities')
     print('%s: %d detections, %d pairs, %d of them firmly ranked' % (tag, boxes.shape[0], rels.shape[0], int(firm.sum())))

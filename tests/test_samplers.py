@@ -136,6 +136,8 @@ def test_pinned_ring_staging_logic(monkeypatch):
     ring.buf = torch.zeros(512, dtype=torch.uint8)
     ring.active, ring.pos = 0, 0
     ring.streams, ring.events = [set(), set()], [[], []]
+    import threading
+    ring.lock = threading.Lock()
     a = ring.stage(torch.arange(5, dtype=torch.int64), 'cpu')               # 40 B -> 64
     b = ring.stage(torch.tensor([True, False, True]), 'cpu')                # 3 B -> 64
     c = ring.stage(torch.arange(6, dtype=torch.float32).view(2, 3), 'cpu')  # 24 B -> 64
