@@ -13,9 +13,11 @@ highway LSTM and of its label decoder.
 
 The forward is written with differentiable torch ops, so torch.autograd is an
 independent check of the hand-written backward restatement (tests/test_oracle_lstm.py).
-The reference ships no CPU path or vectors for these kernels: PARITY UNPINNED for the
-LSTM arithmetic itself; the decoder is pinned against the reference's own Python
-DecoderRNN (tests/golden/decoder_*.npz).
+PINNED (round 3): the reference ships no CPU path for these kernels, so its own highway_lstm_kernel.cu is compiled
+for the CPU (oracle/build_ref_cuda.py, oracle/cuda_cpu/: a launch / thread / cuBLAS shim around the unmodified file) and
+its forward + backward outputs on seeded inputs are committed as tests/golden/cuda_ref.npz; this restatement equals them
+to 2e-6 (tests/test_oracle_ref_cuda.py).  The decoder is pinned against the reference's own Python DecoderRNN
+(tests/golden/decoder_*.npz).
 """
 import numpy as np
 import torch

@@ -14,6 +14,11 @@
  *
  * Each function cites the reference file:line it restates
  * (paths relative to /root/reference).
+ *
+ * PINNED: the mask rasteriser and the float64 IoU against the reference's own .pyx files compiled into oracle/_ref/
+ * (make -C oracle ref); NMS and RoIAlign (forward + backward) against the reference's own nms_kernel.cu /
+ * roi_align_kernel.cu compiled for the CPU (oracle/build_ref_cuda.py) -- bit-exact on the seeded cases of
+ * tests/golden/cuda_ref.npz (tests/test_oracle_ref_cuda.py).
  */
 #include <math.h>
 #include <stdint.h>
