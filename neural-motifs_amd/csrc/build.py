@@ -28,6 +28,30 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+def compile_flags(src):
+    """the device-code-relevant flags of one source file (shared by build() and tests/test_cabi.py's ISA check)"""
+    cmd = ['--offload-arch=' + ARCH, '-O3', '-std=c++17', '-Wall', '-Wno-unused-function']
+    if src in EXACT:
+        cmd += ['-ffp-contract=off']
+    # No packed-FP32 VALU instructions (v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32) outside the MFMA tile engines.  On
+    # MI355X the packed ops of the RoIAlign kernel (SLP-vectorised bilinear interpolation: v_pk_add_f32 with neg
+    # modifiers, v_pk_mul_f32 with op_sel broadcasts) returned wrong LOW halves in lanes 48-63 while waves of an
+    # MFMA + packed-VALU kernel from ANOTHER HIP stream shared its SIMD: 44 of 45 concurrent launches wrong next to the
+    # in-loop-split conv, 0 of 45 with the scalar forms; alone every kernel is bit-exact.  The two-stream evaluation
+    # forward was wrong by 1e-2 because of it.  Evidence and the search that led here: profiles/r03_packed_f32_
+    # coresidency.txt, tools/r03/diag2..diag9.  The tile engines (PACKED_OK) keep their packed ops: the in-loop-split
+    # kernels are VALU-bound (-12 % step throughput without them) and as VICTIMS they came out clean in the
+    # co-residency matrix; everything else is latency- or HBM-bound and loses nothing.  MH_PACKED_F32=1 / 0 forces
+    # the compiler default / the scalar forms for every file (A/B builds).
+    packed = os.environ.get('MH_PACKED_F32')
+    if packed == '0' or (packed != '1' and src not in PACKED_OK):
+        cmd += ['-Xclang', '-target-feature', '-Xclang', '-packed-fp32-ops']
+    for knob in ('MH_MINW', 'MH_CONV_TAP_MAJOR', 'MH_BAR_SLEEP', 'MH_F16_VALU'):
+        if os.environ.get(knob):
+            cmd += ['-D%s=%s' % (knob, os.environ[knob])]
+    return cmd
+
+
 def build(force=False, verbose=False, out_dir=None):
     """out_dir (or $MH_OUT): where objects and the .so go -- default next to the sources.  A variant build (a build knob
     below, MH_PACKED_F32) belongs in its own directory, e.g. csrc/_variants/pk, and is loaded with MOTIFS_HIP_LIB=<that .so>
@@ -42,26 +66,7 @@ def build(force=False, verbose=False, out_dir=None):
         o = os.path.join(out_dir, src.replace('.hip', '.o'))
         objs.append(o)
         if force or _stale(o, [s] + hdrs + [os.path.abspath(__file__)]):
-            cmd = [HIPCC, '--offload-arch=' + ARCH, '-O3', '-std=c++17', '-fPIC', '-c', s, '-o', o,
-                   '-Wall', '-Wno-unused-function']
-            if src in EXACT:
-                cmd += ['-ffp-contract=off']
-            # No packed-FP32 VALU instructions (v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32) outside the MFMA tile engines.  On
-            # MI355X the packed ops of the RoIAlign kernel (SLP-vectorised bilinear interpolation: v_pk_add_f32 with neg
-            # modifiers, v_pk_mul_f32 with op_sel broadcasts) returned wrong LOW halves in lanes 48-63 while waves of an
-            # MFMA + packed-VALU kernel from ANOTHER HIP stream shared its SIMD: 44 of 45 concurrent launches wrong next to the
-            # in-loop-split conv, 0 of 45 with the scalar forms; alone every kernel is bit-exact.  The two-stream evaluation
-            # forward was wrong by 1e-2 because of it.  Evidence and the search that led here: profiles/r03_packed_f32_
-            # coresidency.txt, tools/r03/diag2..diag9.  The tile engines (PACKED_OK) keep their packed ops: the in-loop-split
-            # kernels are VALU-bound (-12 % step throughput without them) and as VICTIMS they came out clean in the
-            # co-residency matrix; everything else is latency- or HBM-bound and loses nothing.  MH_PACKED_F32=1 / 0 forces
-            # the compiler default / the scalar forms for every file (A/B builds).
-            packed = os.environ.get('MH_PACKED_F32')
-            if packed == '0' or (packed != '1' and src not in PACKED_OK):
-                cmd += ['-Xclang', '-target-feature', '-Xclang', '-packed-fp32-ops']
-            for knob in ('MH_MINW', 'MH_CONV_TAP_MAJOR', 'MH_BAR_SLEEP', 'MH_F16_VALU'):
-                if os.environ.get(knob):
-                    cmd += ['-D%s=%s' % (knob, os.environ[knob])]
+            cmd = [HIPCC] + compile_flags(src) + ['-fPIC', '-c', s, '-o', o]
             if verbose:
                 cmd += ['-Rpass-analysis=kernel-resource-usage']
                 print(' '.join(cmd))

@@ -89,3 +89,27 @@ def test_hot_path_fails_loudly_without_gpu(so_path):
         _hip.gemm(torch.zeros(4, 4), torch.zeros(4, 4))
     with pytest.raises(_hip.HipKernelError):
         _hip.nms(torch.zeros(4, 4), 0.5)
+
+
+def test_no_packed_fp32_valu_outside_the_tile_engines(tmp_path):
+    """csrc/build.py's packed-FP32 policy: every source outside the MFMA tile engines carries the flag
+    that removes v_pk_{add,mul,fma}_f32, and the device assembly of the bit-exact operator file (RoIAlign: the kernel whose
+    packed interpolation went wrong next to MFMA waves of another stream) really contains none."""
+    import importlib.util
+    import re
+    import subprocess
+    spec = importlib.util.spec_from_file_location('mh_build_flags', os.path.join(ROOT, 'neural-motifs_amd', 'csrc', 'build.py'))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    assert not os.environ.get('MH_PACKED_F32'), 'an A/B build knob is set in the environment'
+    for src in mod.SOURCES:
+        has = '-packed-fp32-ops' in mod.compile_flags(src)
+        assert has == (src not in mod.PACKED_OK), src
+    assert set(mod.PACKED_OK) == {'gemm.hip', 'conv.hip', 'pl_gemm.hip', 'pl_conv.hip'}
+    out = str(tmp_path / 'exact_ops.s')
+    subprocess.check_call([mod.HIPCC] + mod.compile_flags('exact_ops.hip') + ['-S', '--cuda-device-only', '-w', '-o', out,
+                                                                             os.path.join(mod.HERE, 'exact_ops.hip')],
+                          stderr=subprocess.DEVNULL)
+    asm = open(out).read()
+    assert 'roi_align_fwd_nhwc' in asm
+    assert not re.search(r'\bv_pk_(add|mul|fma)_f32\b', asm)
