@@ -11,7 +11,7 @@ for set in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY 
            "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_SALU SQ_INST_CYCLES_VMEM SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" \
            "FETCH_SIZE" "WRITE_SIZE"; do
   i=$((i+1))
-  ( cd /tmp && timeout 150 rocprofv3 --pmc $set --kernel-trace --output-format csv -d /tmp/pmc_${TAG}_$i -- $CMD > /tmp/pmc_${TAG}_$i.log 2>&1 )
+  ( cd /tmp && timeout 40 rocprofv3 --pmc $set --kernel-trace --output-format csv -d /tmp/pmc_${TAG}_$i -- $CMD > /tmp/pmc_${TAG}_$i.log 2>&1 )
   f=$(ls /tmp/pmc_${TAG}_$i/*/*counter_collection.csv 2>/dev/null | head -1)
   if [ -n "$f" ]; then cp $f $OUT/set$i.csv; else echo "set $i failed"; tail -5 /tmp/pmc_${TAG}_$i.log; fi
 done
