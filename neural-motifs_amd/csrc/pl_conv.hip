@@ -235,22 +235,29 @@ __global__ __launch_bounds__(kThreads, (S::bm * S::bn <= 128 * 128) ? 3 : 2) voi
     FragPlan fp;
     plan_frags<S>(fp, wm, wn, lane);
     const unsigned strideA = (unsigned)(Mtot * kCell), strideB = (unsigned)p.Cout * kCell;     // bytes per 16-channel chunk
-    // the tile the next issue() loads: (chunk it_g, tap it_tap), advanced incrementally (no division in the loop); once the
-    // last tile of the slice has been issued the state stays there (the harmless reload of the final step)
-    int it_kt = kt_begin, it_g = kt_begin / 9, it_tap = kt_begin - 9 * it_g;
+    // Per-k-tile operand offsets come from a table in LDS (behind the tile buffers / the image staging), built once per block:
+    // entry kt = (A scalar offset, B scalar offset, tap bit) of (chunk kt / 9, tap kt % 9).  The first version advanced
+    // (chunk, tap) counters and recomputed both offsets every k-tile: 27 scalar instructions, six of them s_mul_i32, in
+    // front of the next tile's loads (profiles/r03_pmc_plane_conv_set3.csv: 2.6 SALU per MFMA on the 288-k-tile layers).
+    // issue() reads the entry of the tile AFTER the one it loads, so the LDS latency hides behind a step's MFMAs.
+    uint4 *ktab = reinterpret_cast<uint4 *>(lds + (IMG ? conv_lds_bytes<S>() : S::lds_bytes));
+    for (int i = tid; i < total_kt; i += kThreads) {
+        const int g = i / 9, tap = i - 9 * g, dy = tap / 3, dx = tap - 3 * dy;
+        ktab[i] = make_uint4((unsigned)g * strideA + (unsigned)(halo + (dy - 1) * p.W + (dx - 1)) * kCell,
+                             (unsigned)(tap * G + g) * strideB, 1u << tap, 0u);
+    }
+    __syncthreads();
+    int it_kt = kt_begin;
+    uint4 ent = ktab[it_kt];
     auto issue = [&](Stage<S> &st) {
-        const int dy = (it_tap * 11) >> 5, dx = it_tap - 3 * dy;            // tap / 3, tap % 3 for tap in [0, 9)
-        const unsigned oa = (unsigned)it_g * strideA + (unsigned)(halo + (dy - 1) * p.W + (dx - 1)) * kCell;
-        const unsigned ob = (unsigned)(it_tap * G + it_g) * strideB;
-        const unsigned bit = 1u << it_tap;
+        const unsigned oa = (unsigned)__builtin_amdgcn_readfirstlane((int)ent.x), ob = (unsigned)__builtin_amdgcn_readfirstlane((int)ent.y),
+                       bit = (unsigned)__builtin_amdgcn_readfirstlane((int)ent.z);
 #pragma unroll
         for (int j = 0; j < S::na; ++j) st.a[j] = load16(sa, (a_taps[j] & bit) ? cp.va[j] : kOob, oa);
 #pragma unroll
         for (int j = 0; j < S::nb; ++j) st.b[j] = load16(sb, cp.vb[j], ob);
-        if (it_kt + 1 < kt_end) {
-            ++it_kt;
-            if (++it_tap == 9) { it_tap = 0; ++it_g; }
-        }
+        if (it_kt + 1 < kt_end) ++it_kt;        // after the last tile of the slice the state stays (the harmless reload of the final step)
+        ent = ktab[it_kt];
     };
 
     Acc<S> acc;
@@ -716,14 +723,17 @@ static int plconv_impl(const void *in_image, const unsigned *in_true_maxbits, in
     MH_REQUIRE(nblocks > 0 && nblocks < (1LL << 31));
     hipStream_t st = as_stream(stream);
     const dim3 grid((unsigned)nblocks);
+    constexpr size_t kTabMax = 1024 * 16;                          // the per-k-tile offset table lives in LDS (16 B per k-tile)
+    MH_REQUIRE(total_kt <= 1024);
+    const size_t tab_bytes = (size_t)total_kt * 16;
     if (out_image) {
-        if (sc.shape == 0) pl::launch<pl::conv3x3_kernel<pl::S256x128, true>>(grid, pl::conv_lds_bytes<pl::S256x128>(), st, p);
-        else if (sc.shape == 1) pl::launch<pl::conv3x3_kernel<pl::S128x128, true>>(grid, pl::conv_lds_bytes<pl::S128x128>(), st, p);
-        else pl::launch<pl::conv3x3_kernel<pl::S256x64, true>>(grid, pl::conv_lds_bytes<pl::S256x64>(), st, p);
+        if (sc.shape == 0) pl::launch<pl::conv3x3_kernel<pl::S256x128, true>>(grid, pl::conv_lds_bytes<pl::S256x128>() + tab_bytes, st, p, pl::conv_lds_bytes<pl::S256x128>() + kTabMax);
+        else if (sc.shape == 1) pl::launch<pl::conv3x3_kernel<pl::S128x128, true>>(grid, pl::conv_lds_bytes<pl::S128x128>() + tab_bytes, st, p, pl::conv_lds_bytes<pl::S128x128>() + kTabMax);
+        else pl::launch<pl::conv3x3_kernel<pl::S256x64, true>>(grid, pl::conv_lds_bytes<pl::S256x64>() + tab_bytes, st, p, pl::conv_lds_bytes<pl::S256x64>() + kTabMax);
     } else {
-        if (sc.shape == 0) pl::launch<pl::conv3x3_kernel<pl::S256x128, false>>(grid, pl::S256x128::lds_bytes, st, p);
-        else if (sc.shape == 1) pl::launch<pl::conv3x3_kernel<pl::S128x128, false>>(grid, pl::S128x128::lds_bytes, st, p);
-        else pl::launch<pl::conv3x3_kernel<pl::S256x64, false>>(grid, pl::S256x64::lds_bytes, st, p);
+        if (sc.shape == 0) pl::launch<pl::conv3x3_kernel<pl::S256x128, false>>(grid, pl::S256x128::lds_bytes + tab_bytes, st, p, pl::S256x128::lds_bytes + kTabMax);
+        else if (sc.shape == 1) pl::launch<pl::conv3x3_kernel<pl::S128x128, false>>(grid, pl::S128x128::lds_bytes + tab_bytes, st, p, pl::S128x128::lds_bytes + kTabMax);
+        else pl::launch<pl::conv3x3_kernel<pl::S256x64, false>>(grid, pl::S256x64::lds_bytes + tab_bytes, st, p, pl::S256x64::lds_bytes + kTabMax);
     }
     int rc = check_launch("pl::conv3x3_kernel");
     if (rc) return rc;

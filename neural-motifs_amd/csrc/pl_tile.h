@@ -280,13 +280,15 @@ __device__ __forceinline__ void wave_atomic_max(unsigned *words, int key, unsign
 }
 
 template <auto Kern, typename Args>
-inline void launch(dim3 grid, size_t lds_bytes, hipStream_t st, const Args &p)
+inline void launch(dim3 grid, size_t lds_bytes, hipStream_t st, const Args &p, size_t lds_max = 0)
 {
+    // lds_max: the largest dynamic LDS size ANY launch of this kernel may ask for (the attribute is set once per device)
     static bool raised[64] = {};
     int dev = 0;
     (void)hipGetDevice(&dev);
     if (dev >= 0 && dev < 64 && !raised[dev]) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(Kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(Kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)(lds_max > lds_bytes ? lds_max : lds_bytes));
         raised[dev] = true;
     }
     hipLaunchKernelGGL(Kern, grid, dim3(kThreads), lds_bytes, st, p);
