@@ -7,7 +7,7 @@
 //   The K loop walks 16-channel chunks with the nine taps INSIDE a chunk, so the nine k-tiles of a chunk re-read the
 //   same pixels' 64-byte segments out of L1/L2 (tap-major order sent 9.6 GB per bench step to the fabric for 2.1 GB
 //   of input, this order 4.6 GB: profiles/r01_conv_traffic_*).
-//   B = packed weights wt[tap][co][ci/16][hi|mid|lo planes] (bf16x6 build).  Epilogue fuses bias + ReLU/ReLU6.
+//   B = packed weights wt[tap][co][ci/16][h1|h2 planes + one unused slot pair].  Epilogue fuses bias + ReLU/ReLU6.
 // The same kernel computes dgrad when given flip-transposed weights (mh_conv3x3_pack_weight).
 #include <algorithm>
 #include <cstdlib>
@@ -91,7 +91,7 @@ __global__ __launch_bounds__(kThreads, MH_MINW) void conv3x3_nhwc_kernel(const C
     const int halo = (p.W + 1) * p.Cin;
     const GSrc ga = make_gsrc(p.in + (ptrdiff_t)m0 * p.Cin - halo), gb = make_gsrc(p.wt);
     unsigned a_off[NVA], a_taps[NVA];
-    // B = packed weights as bf16 planes, wt[tap][co][ci / 16][96 B]: chunk copies, no split (mfma_tile.h: PStage)
+    // B = packed weights as f16 planes, wt[tap][co][ci / 16][96 B]: chunk copies, no split (mfma_tile.h: PStage)
     const unsigned b_row_bytes = (unsigned)(p.Cin / kBK) * kPlaneRowBytes;
     PPlan<BN> pb;
     plan_planes<BN>(pb, [&](int r) { return n0 + r < p.Cout; }, b_row_bytes, tid);

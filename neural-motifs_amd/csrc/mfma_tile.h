@@ -135,16 +135,14 @@ __device__ __forceinline__ void mma_ktile_f32(const float *__restrict__ As, cons
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// FP32-accurate products on the BF16 matrix cores ("bf16x6").
-// gfx950's v_mfma_f32_32x32x16_bf16 retires 16 k per 32 cycles, the f32-input MFMA 2 k per 64 cycles: 16x the rate.
-// An fp32 number splits EXACTLY into three bf16 terms by truncation, a = a1 + a2 + a3 with 8 mantissa bits each
-// (a1 = top 16 bits of a; r = a - a1 is exact; a2 = top 16 bits of r; a3 = r - a2 has <= 8 significant bits), a
-// bf16 x bf16 product is exact in fp32, and the MFMA accumulates in fp32.  Keeping the six largest cross terms,
-//     a*b = a1b1 + (a1b2 + a2b1) + (a1b3 + a3b1 + a2b2) + [a2b3 + a3b2 + a3b3 dropped: <= 2^-21 |ab|, 2^-24.5 typical],
-// gives products as accurate as the f32-input MFMA's (measured: DESIGN.md 3.1, profiles/r01_split_check.jsonl) at
-// 6/16 of its matrix-core time (MH_MFMA_SPLIT == 6); the first three terms alone (== 3) are accurate to 2^-17.
-// MH_SPLIT_RN=1 swaps truncation for round-to-nearest (dropped part <= 2^-24 |ab|, zero mean; see split_pair).  A lane's operand for the K=16 instruction is 8 consecutive k of
-// its row (k = 8g .. 8g+7, g = lane >> 5).  The split is done ONCE per element when a k-tile is staged (below).
+// FP32-accurate products on the f16 matrix cores ("f16x3").
+// gfx950's v_mfma_f32_32x32x16_f16 retires 16 k per 32 cycles, the f32-input MFMA 2 k per 64 cycles: 16x the rate.
+// A row of an operand is scaled by 2^e (row_exponent: its largest magnitude lands in [2^14, 2^15)) and every element is
+// split into two f16 terms, a*2^e = h1 + h2 + r with |r| <= 2^-24 |a*2^e|; f16 x f16 products are exact in fp32 and the
+// MFMA accumulates in fp32, so three MFMAs (h2*h1', h1*h2', h1*h1') give the product to ~2^-22 and the scales come off
+// exactly in the epilogue (measured against float64: DESIGN.md 3.1, profiles/r02_split_check.jsonl).  A lane's operand for
+// the K=16 instruction is 8 consecutive k of its row (k = 8g .. 8g+7, g = lane >> 5).  The split is done ONCE per element
+// when a k-tile is staged (below).  The vector type keeps round 1's name: 8 x 16 bits, here f16 bit patterns.
 // ---------------------------------------------------------------------------------------------------------------
 typedef short bf16x8 __attribute__((ext_vector_type(8)));
 
@@ -224,14 +222,13 @@ __device__ __forceinline__ void load_wm(Stage<WD> &s, RowPtr row_ptr, int k0, in
 
 
 // ---------------------------------------------------------------------------------------------------------------
-// bf16-plane LDS image (MH_MFMA_SPLIT != 0): every element is split ONCE, by the thread that
-// stages it, and LDS holds the three bf16 planes k-contiguous per operand row, whatever the global orientation:
-//     row r (96 B = 24 dwords):  [ hi: k0..k15 | mid: k0..k15 | lo: k0..k15 ]
+// Plane LDS image: every element is split ONCE, by the thread that stages it, and LDS holds the planes k-contiguous per
+// operand row, whatever the global orientation (the row keeps round 1's three-plane stride; f16x3 fills two):
+//     row r (96 B = 24 dwords):  [ h1: k0..k15 | h2: k0..k15 | unused ]
 // dword d of a plane holds k = 2d (low half) and 2d+1 (high half); the 16-B slot index (2*plane + k/8) is XORed
 // with swz(r) = bit 3 of r.  A lane's MFMA operand (8 consecutive k of its row, one plane) is one ds_read_b128:
 // conflict-free for the four 16-lane service groups of the instruction (rows r and r+8 would otherwise meet on
-// the same banks: 8 * 96 B = 3 * 256 B).  The inner loop is then 12 ds_read_b128 + 24 MFMAs with no VALU work,
-// and a 128x128 block's double buffer is 48 KB: three blocks per CU.
+// the same banks: 8 * 96 B = 3 * 256 B).  A 128x128 block's double buffer is 48 KB: three blocks per CU.
 //   * WM operand: the staging thread owns 4 consecutive k of one row -> 2 packed dwords per plane -> 3 ds_write_b64
 //     (conflict-free).
 //   * KM operand: the staging thread loads a k-PAIR (rows 2kp, 2kp+1) of 4 consecutive w -> one packed dword per
@@ -242,27 +239,6 @@ __device__ __forceinline__ void load_wm(Stage<WD> &s, RowPtr row_ptr, int k0, in
 // ---------------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ int plane_swz(int r) { return (r >> 3) & 1; }
 
-// (x0, x1) = values at k even / k odd -> packed dwords of the hi / mid / lo planes.  Both variants split EXACTLY
-// (hi + mid + lo == x, each term a bf16); they differ in the size of the three cross terms the inner loop drops
-// (mid*lo, lo*mid, lo*lo; tests/test_bf16x6_math.py derives the figures):
-//   MH_SPLIT_RN 0 (default): truncation.  |mid| < 2^-7|x|, |lo| < 2^-15|x|: dropped part <= 2^-21|ab|, typically
-//       2^-24.5|ab|, always towards zero.
-//   MH_SPLIT_RN 1: round-to-nearest-even via v_cvt_pk_bf16_f32.  |mid| <= 2^-8|x|, |lo| <= 2^-16|x|: dropped part
-//       <= 2^-24|ab|, typically 2^-28|ab|, zero mean; same VALU count.  (x within half a bf16 ulp of FLT_MAX rounds
-//       to inf, which truncation does not.)
-__device__ __forceinline__ void split_pair(float x0, float x1, unsigned &ph, unsigned &pm, unsigned &pl)
-{
-    constexpr unsigned kTop = 0x07060302u;   // v_perm_b32: {S0.hi16, S1.hi16}
-    const unsigned u0 = __builtin_bit_cast(unsigned, x0), u1 = __builtin_bit_cast(unsigned, x1);
-    ph = __builtin_amdgcn_perm(u1, u0, kTop);
-    const float r0 = x0 - __builtin_bit_cast(float, u0 & 0xffff0000u);
-    const float r1 = x1 - __builtin_bit_cast(float, u1 & 0xffff0000u);
-    const unsigned v0 = __builtin_bit_cast(unsigned, r0), v1 = __builtin_bit_cast(unsigned, r1);
-    pm = __builtin_amdgcn_perm(v1, v0, kTop);
-    const float s0 = r0 - __builtin_bit_cast(float, v0 & 0xffff0000u);
-    const float s1 = r1 - __builtin_bit_cast(float, v1 & 0xffff0000u);
-    pl = __builtin_amdgcn_perm(__builtin_bit_cast(unsigned, s1), __builtin_bit_cast(unsigned, s0), kTop);
-}
 
 // f16x3: (x0, x1) scaled by 2^e of their operand ROW (e0 / e1: the two elements may belong to different rows), then
 // a*2^e = h1 + h2 + r with h1 = f16(a*2^e), h2 = f16(a*2^e - h1) (round to nearest even), |r| <= 2^-24 |a*2^e|.

@@ -184,7 +184,9 @@ def test_gemm_against_fp64(hip, M, N, K, ta, tb):
     bias = torch.randn(N, generator=g)
     ref = ((a.t() if ta else a).double() @ (b.t() if tb else b).double())
     out = hip.gemm(a.cuda(), b.cuda(), bool(ta), bool(tb))
-    tol = 2e-6 * K ** 0.5 * 4 + 1e-5
+    # N(0,1) operands: rms(C) = sqrt(K).  The largest error over the six-million-entry products of tools/pl_check.cpp is 5.0e-6 of
+    # rms(C) on either engine (profiles/r03_pl_check.jsonl: max_rel); the bound is four times that (round 2 allowed 6.4e-5)
+    tol = (2e-5 * K ** 0.5 + 1e-5) / 8
     np.testing.assert_allclose(out.cpu().numpy(), ref.float().numpy(), atol=tol * 8)
     # asymmetric operands: a transposed C-write would show as O(1) error
     out2 = hip.gemm(a.cuda(), b.cuda(), bool(ta), bool(tb), bias=bias.cuda(), epilogue=1)
@@ -207,9 +209,11 @@ def test_gemm_small_integers_are_exact(hip):
     np.testing.assert_array_equal(out.cpu().numpy(), (a.double() @ b.double().t()).float().numpy())
 
 
-def test_gemm_keeps_all_24_mantissa_bits(hip):
-    """bf16x6 reconstructs the full fp32 operand: a selection matrix (one power of two per column) must copy
-    full-mantissa values through the matrix cores bit for bit, from either operand side."""
+def test_gemm_copies_23_bit_operands_exactly(hip):
+    """A selection matrix (one power of two per column) must copy operand values through the matrix cores bit for bit, from
+    either operand side -- for values of up to 23 significant bits: the two-term f16 split carries 11 + 11 bits plus the
+    sign of the second term (22-23 bits), not fp32's full 24 (the bf16x6 engine of round 1, which
+    reconstructed all 24, is gone)."""
     g = torch.Generator().manual_seed(1)
     a = (torch.randint(-2 ** 23, 2 ** 23, (200, 150), generator=g) | 1).float() * 2.0 ** -11
     sel = torch.zeros(150, 90)
