@@ -31,3 +31,29 @@ def test_cited_tools_and_tests_exist():
         if not os.path.exists(path) or (m.group(2) and ('def ' + m.group(2)) not in open(path).read()):
             bad.append(m.group(0))
     assert not bad, bad
+
+
+def test_committed_bench_line_follows_the_contract():
+    """the JSON line bench.py printed on the GPU box (profiles/r03_bench_n1.json) carries every field of the bench contract:
+    the headline fields, config.workload (no model keys), roofline {bound, achieved, peak, unit, frac, traffic} with
+    frac == achieved / peak, and cpu_baseline {value, unit, cores, kind, sample}"""
+    import json
+    d = json.loads(open(os.path.join(ROOT, 'profiles', 'r03_bench_n1.json')).read().strip().split('\n')[-1])
+    for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline',
+              'dtype', 'data', 'config', 'roofline', 'cpu_baseline'):
+        assert k in d, k
+    base = json.load(open(os.path.join(ROOT, 'BASELINE.json')))
+    assert d['unit'] == 'img/s' and d['higher_is_better'] is True and d['scaling'] == 'weak' and d['n_gpus'] == 1
+    assert d['vs_baseline'] is None and d['data'] == 'synthetic' and d['dtype'] == 'f32'
+    assert 'workload' in d['config'] and 'model' not in d['config']
+    assert abs(d['value'] - 6 * d['steps'] / (d['ms_per_step'] * 1e-3 * d['steps'])) < 1e-6 * d['value']      # b = 6 images per step
+    r = d['roofline']
+    for k in ('bound', 'achieved', 'peak', 'unit', 'frac', 'traffic'):
+        assert k in r, k
+    assert r['bound'] == 'mfma' and r['unit'] == 'TFLOP/s' and abs(r['frac'] - r['achieved'] / r['peak']) < 1e-9
+    assert abs(r['peak'] - 2500.0 / 3.0) < 1e-6 and r['traffic'] >= r['traffic_algorithmic'] > 0
+    c = d['cpu_baseline']
+    for k in ('value', 'unit', 'cores', 'kind', 'sample'):
+        assert k in c, k
+    assert c['kind'] == 'port' and c['unit'] == 'img/s' and 0 < c['value'] < d['value']
+    assert isinstance(base.get('metric', ''), str)
