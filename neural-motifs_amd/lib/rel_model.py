@@ -58,6 +58,30 @@ def _sort_by_score(im_inds, scores):
     return perm, inv_perm, ls_transposed
 
 
+class _LateBackward(torch.autograd.Function):
+    """Identity whose backward runs the backward pass of a sub-graph that was built EARLIER in the forward.
+
+    Why: autograd executes ready nodes in reverse creation order.  The two-stream forward enqueues the union-box branch
+    first (a few chip-filling kernels on the main stream) and the context branch second (~200 small launches on the side
+    stream), so backward starts with the context branch: the host spends ~4 ms enqueuing its small kernels while the main
+    stream -- whose big fc6 / fc7 gradient GEMMs autograd has not reached yet -- sits idle (kernel trace of round 3:
+    main stream idle 3.9 ms per step during the context backward, tools/trace_gaps.py).  Wrapping the union-box
+    branch's OUTPUT in this node, created after the context branch, makes it the first thing backward runs: it launches the
+    branch's whole backward (nested autograd call, gradients accumulate into the parameters as usual), and the context
+    branch's launches then overlap with those GEMMs.  The branch's inputs (frozen feature map, boxes) need no gradient."""
+
+    @staticmethod
+    def forward(ctx, leaf, holder):
+        ctx.holder = holder
+        return leaf.view_as(leaf)
+
+    @staticmethod
+    def backward(ctx, g):
+        inner = ctx.holder.pop()
+        torch.autograd.backward(inner, g)
+        return None, None
+
+
 class LinearizedContext(nn.Module):
     """object context -> label decoder -> edge context"""
 
@@ -240,6 +264,10 @@ class RelModel(nn.Module):
         # (a handful of chip-filling MFMA GEMMs).  The two branches only meet at the subject/object product.
         self.overlap_streams = os.environ.get('MOTIFS_OVERLAP', '1') != '0'     # context branch on a second HIP stream
         self._side_stream = None
+        # Backward ORDER of the two branches (see _LateBackward): 'auto' (default) = the union-box branch's backward is issued
+        # first whenever the two-stream forward is used with a frozen trunk; '0' = autograd's own order (context branch
+        # first); 'force' = also on one stream / on the CPU (tests)
+        self.late_vr_backward = os.environ.get('MOTIFS_LATE_VR', 'auto')
 
         self.detector = ObjectDetector(
             classes=classes,
@@ -286,6 +314,10 @@ class RelModel(nn.Module):
     @property
     def num_rels(self):
         return len(self.rel_classes)
+
+    def _late_ok(self, fmap):
+        # the re-ordered backward hands no gradient to the feature map: only with a frozen trunk (the relation drivers)
+        return self.training and torch.is_grad_enabled() and not fmap.requires_grad
 
     def visual_rep(self, features, rois, pair_inds):
         assert pair_inds.size(1) == 2
@@ -368,6 +400,7 @@ class RelModel(nn.Module):
                 self._side_stream = torch.cuda.Stream(device=x.device)
             side = self._side_stream
             side.wait_stream(main)                                   # fmap / rois / labels are ready
+            late = self._late_ok(fmap) and self.late_vr_backward in ('auto', '1', 'force')
             vr = self.visual_rep(fmap, rois, rel_inds[:, 1:])         # big kernels first: the GPU is busy while
             with torch.cuda.stream(side):                             # the host enqueues the small ones
                 for t in (fmap, rois, im_inds, boxes, result.rm_obj_dists):
@@ -377,8 +410,13 @@ class RelModel(nn.Module):
             for t in (edge_rep, result.obj_fmap, result.rm_obj_dists, result.obj_preds):
                 if torch.is_tensor(t):
                     t.record_stream(main)
+            if late and vr.requires_grad:
+                vr = _LateBackward.apply(vr.detach().requires_grad_(True), [vr])
         else:
             edge_rep = context_branch()
+            if self.use_vision and self.late_vr_backward == 'force' and self._late_ok(fmap):
+                vr_inner = self.visual_rep(fmap, rois, rel_inds[:, 1:])
+                vr = _LateBackward.apply(vr_inner.detach().requires_grad_(True), [vr_inner]) if vr_inner.requires_grad else vr_inner
         subj_rep, obj_rep = edge_rep[:, 0], edge_rep[:, 1]
         prod_rep = subj_rep[rel_inds[:, 1]] * obj_rep[rel_inds[:, 2]]
 

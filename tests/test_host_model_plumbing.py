@@ -593,3 +593,47 @@ def test_forced_pool_routing_matches_max_pool():
         assert OM.TAPS['flips']['p'][0] == 1 and OM.TAPS['flips']['p'][1] > 0
     finally:
         OM.TAPS = None
+
+
+def test_late_backward_of_the_union_box_branch_gives_the_same_gradients(small_world):
+    import torch.nn.functional as F
+    """RelModel.late_vr_backward re-orders backward (the union-box branch's gradients are launched first, lib/rel_model.py:
+    _LateBackward): logits, loss and every gradient must equal the plain step (the re-ordered branch's bit for bit); the
+    re-ordered branch really runs first (its parameters have their gradients before any context parameter has one)."""
+    from lib import rng
+    ds, model, make_blob = small_world
+    model.train()
+    blob = make_blob(ds, [0, 1], is_train=True)
+    order = []
+    handles = [p.register_post_accumulate_grad_hook(lambda p, n=n: order.append(n)) for n, p in model.named_parameters() if p.requires_grad]
+
+    def step(mode):
+        model.late_vr_backward = mode
+        model.zero_grad(set_to_none=True)
+        del order[:]
+        model.sampler_rs = np.random.RandomState(3)
+        rng.use_host_rng(77)
+        res = model[blob]
+        rng.use_host_rng(None)
+        loss = F.cross_entropy(res.rm_obj_dists, res.rm_obj_labels) + F.cross_entropy(res.rel_dists, res.rel_labels[:, -1])
+        loss.backward()
+        return (res.rel_dists.detach().clone(), float(loss.detach()),
+                {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}, list(order))
+
+    try:
+        plain = step('0')
+        late = step('force')
+    finally:
+        model.late_vr_backward = '0'
+        for h in handles:
+            h.remove()
+    assert set(plain[2]) == set(late[2])
+    assert float((plain[0] - late[0]).abs().max()) <= 1e-5 * float(plain[0].abs().max()) and abs(plain[1] - late[1]) <= 1e-5 * abs(plain[1])
+    for n, g in plain[2].items():
+        if n.startswith(('roi_fmap.', 'union_boxes.')):       # the re-ordered branch: bit for bit
+            assert torch.equal(g, late[2][n]), n
+        else:                                                 # (the CPU shim's context branch is not bit-reproducible run to run: 1e-7)
+            assert float((g - late[2][n]).abs().max()) <= 1e-5 * float(g.abs().max()) + 1e-12, n
+    first_ctx = min(i for i, n in enumerate(late[3]) if n.startswith('context.'))
+    vis = [i for i, n in enumerate(late[3]) if n.startswith(('roi_fmap.', 'union_boxes.'))]
+    assert vis and max(vis) < first_ctx, 'the union-box branch did not finish its backward first: %s' % late[3][:12]

@@ -4,7 +4,9 @@
 
 Takes the LAST N steps of the trace (a step ends with the optimizer kernel `multi_sgd_kernel`), merges the kernel intervals of
 all queues, and prints per step: wall time, busy time (union of intervals), idle time, and the K largest idle gaps with the
-kernel before / after each -- the places where the host cannot keep the GPU fed."""
+kernel before / after each -- the places where the host cannot keep the GPU fed.  With more than one queue (HIP streams) it also
+prints, per step, how long ONLY each queue had a kernel running, how long several had, and what the queues ran: the branch that
+runs alone for long is the step's critical path (round 3: the context branch on the second stream, 4.3 ms per step)."""
 import csv
 import sys
 from collections import defaultdict
@@ -42,6 +44,23 @@ def main():
         print(f'step {s}: wall {(t1 - t0) / 1e6:.3f} ms, busy {busy / 1e6:.3f} ms, idle {(t1 - t0 - busy) / 1e6:.3f} ms, '
               f'{len(seg)} launches, sum of kernel durations {sum(b - a for a, b, _, _ in seg) / 1e6:.3f} ms, '
               f'queues {sorted(set(q for *_, q in seg))}')
+        queues = sorted(set(q for *_, q in seg))
+        if len(queues) > 1:
+            ev = sorted([(a, 1, q) for a, b, _, q in seg] + [(b, -1, q) for a, b, _, q in seg])
+            active, last, alone, several = defaultdict(int), t0, defaultdict(int), 0
+            for t, d, q in ev:
+                on = [k for k, v in active.items() if v > 0]
+                if len(on) == 1:
+                    alone[on[0]] += t - last
+                elif len(on) > 1:
+                    several += t - last
+                active[q] += d
+                last = t
+            per_q = defaultdict(float)
+            for a, b, _, q in seg:
+                per_q[q] += b - a
+            print('   ' + ', '.join(f'only queue {q}: {alone[q] / 1e6:.2f} ms (its kernels: {per_q[q] / 1e6:.2f} ms)' for q in queues)
+                  + f', several queues at once: {several / 1e6:.2f} ms')
         for g, p, n in gaps:
             k = (p[:48], n[:48])
             agg[k][0] += 1
