@@ -57,3 +57,32 @@ def test_committed_bench_line_follows_the_contract():
         assert k in c, k
     assert c['kind'] == 'port' and c['unit'] == 'img/s' and 0 < c['value'] < d['value']
     assert isinstance(base.get('metric', ''), str)
+
+
+def test_trace_gaps_splits_a_step_by_queue(tmp_path, capsys):
+    """tools/trace_gaps.py on a synthetic two-queue trace: 10 us only queue 1, 5 us both, 15 us only queue 2, 10 us idle"""
+    import importlib.util
+    import sys
+    rows = [('opt', 0, 1000, '1'),                                   # previous step's optimizer kernel ends at t = 1000
+            ('a', 1000, 16000, '1'), ('b', 11000, 31000, '2'), ('mh::multi_sgd_kernel', 41000, 42000, '1'),
+            ('c', 42000, 52000, '1'), ('mh::multi_sgd_kernel x', 60000, 61000, '1')]
+    path = tmp_path / 'trace.csv'
+    with open(path, 'w') as f:
+        f.write('Start_Timestamp,End_Timestamp,Kernel_Name,Queue_Id\n')
+        f.write('0,1000,mh::multi_sgd_kernel,1\n')
+        for n, a, b, q in rows[1:]:
+            f.write('%d,%d,%s,%s\n' % (a, b, n, q))
+    spec = importlib.util.spec_from_file_location('trace_gaps', os.path.join(ROOT, 'tools', 'trace_gaps.py'))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    argv = sys.argv
+    sys.argv = ['trace_gaps.py', str(path), '--steps', '2', '--top', '2']
+    try:
+        mod.main()
+    finally:
+        sys.argv = argv
+    out = capsys.readouterr().out
+    first = [l for l in out.split('\n') if l.startswith('step')][0]
+    assert 'wall 0.041 ms' in first and 'busy 0.031 ms' in first and "queues ['1', '2']" in first
+    line = [l for l in out.split('\n') if 'only queue' in l][0]
+    assert 'only queue 1: 0.01 ms' in line and 'only queue 2: 0.01 ms' in line and 'several queues at once: 0.01 ms' in line
