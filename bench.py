@@ -664,6 +664,10 @@ def main():
             'products_on_images': {'tflops': gpl['tflops'], 'frac': gpl['tflops'] / peak, 'ms_per_step': gpl['total_ms'] / args.steps,
                                    'launches': gpl['launches']},
             'note': 'HIP-event time of the calls; some run concurrently with the other HIP stream (context branch)'}
+        # which kernel class takes more of the step by HIP-event time (the verdict of round 2 noted that GEMM-class work exceeds
+        # the conv's: both rooflines are reported, this names the larger one)
+        line['dominant_by_time'] = {'class': 'gemm' if gm['total_ms'] > conv['total_ms'] else 'conv3x3',
+                                    'conv3x3_ms_per_step': conv['total_ms'] / args.steps, 'gemm_ms_per_step': gm['total_ms'] / args.steps}
         opt_ms = sum(a.elapsed_time(b) for a, b in opt_events) / max(len(opt_events), 1) if opt_events else None
         n_train = sum(p.numel() for p in model.parameters() if p.requires_grad)
         line['hbm_kernels'] = hbm_rows(meters, args.steps, opt_ms, 20.0 * n_train)
