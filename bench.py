@@ -5,8 +5,17 @@ grad-clip + SGD step) on synthetic 592x592 VG-shaped batches, `configs[1]`:
     SGCls MotifNet (order=leftright, 2-layer highway LSTMs, hidden 512) VGG16, batch 6 per GPU, 20 GT boxes/img.
 
     python bench.py --gpus N --steps K --warmup W
-For N > 1 launch with torchrun (one rank per GPU, RCCL): every rank trains on its own images (weak scaling), the only
-collective is the gradient all-reduce.  Rank 0 prints ONE JSON line.
+N > 1: one rank per GPU over RCCL; every rank trains on its own images (weak scaling), the only collective is the gradient
+all-reduce; rank 0 prints ONE JSON line.  Started either by torchrun (`python -m torch.distributed.run --nproc-per-node N
+bench.py --gpus N ...`: RANK / WORLD_SIZE in the environment) or plainly as `python bench.py --gpus N`, in which case
+bench.py starts the N ranks itself (`launch_ranks`: re-executes itself under torch.distributed.run on 127.0.0.1) -- as easy
+to start as the reference's single-process DataParallel (lib/rel_model.py:549-560).  Fewer than N visible devices, or a
+process group of another size, is an error, never a silent smaller run.
+
+Step-time distribution: every timed step is bracketed by HIP events on the main stream and by host timestamps;
+`ms_per_step` stays the wall-clock mean the driver expects, `step_ms` carries p50 / p90 / max / the per-step list.
+`h2d_inclusive` re-times a few steps with the batch uploaded from page-locked host memory INSIDE each step (what
+models/train_rels.py:137 + dataloaders/blob.py:155-180 do per step); `value` itself is quoted with inputs resident in HBM.
 
 Extra objects in the line:
   roofline     -- the dominant kernel class, the 3x3 convolutions as implicit GEMMs on the matrix cores (12 trunk layers on
@@ -253,6 +262,69 @@ def cpu_baseline(ds, model_sd, iters=3, eval_images=3, budget_s=150.0):
                                        eval_images, ', '.join('%.2f' % t for t in etimes[1:]))})
 
 
+def launch_ranks(args, argv):
+    """`python bench.py --gpus N` without torchrun's environment: start N ranks of this file under torch.distributed.run
+    (one process per GPU, rendezvous on 127.0.0.1 at a free port) and pass rank 0's JSON line through.  Returns the exit code."""
+    import socket
+    import subprocess
+    if not args.launch_selftest:
+        n_dev = torch.cuda.device_count() if torch.cuda.is_available() else 0
+        if n_dev < args.gpus:
+            raise SystemExit('bench.py --gpus %d: only %d HIP device(s) visible -- refusing to run a smaller job under that name'
+                             % (args.gpus, n_dev))
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')      # dmabuf IPC: RCCL's cross-process buffer sharing needs it on this driver
+    env.setdefault('OMP_NUM_THREADS', str(max(1, (os.cpu_count() or 8) // max(args.gpus, 1))))
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus),
+           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + list(argv)
+    return subprocess.call(cmd, env=env)
+
+
+def launch_selftest(args):
+    """the launcher path without the model (CPU + gloo when there is no HIP device): every rank joins the group, one
+    all-reduce, rank 0 prints a line.  tests/test_bench_launcher.py runs `python bench.py --gpus 2 --launch-selftest`."""
+    import torch.distributed as dist
+    from lib import dist as D
+    rank, world, local_rank = D.init_from_env()
+    if world != args.gpus or (world > 1 and dist.get_world_size() != args.gpus):
+        raise SystemExit('launch self-test: asked for %d ranks, the process group has %d' % (args.gpus, world))
+    t = torch.tensor([float(rank + 1)])
+    if torch.cuda.is_available():
+        t = t.cuda(local_rank)
+    if world > 1:
+        dist.all_reduce(t)
+    if rank == 0:
+        print(json.dumps({'launch_selftest': True, 'n_gpus': world, 'sum_of_ranks_plus_1': float(t.item()),
+                          'backend': dist.get_backend() if world > 1 else None}), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def pct(xs, q):
+    xs = sorted(xs)
+    if not xs:
+        return None
+    k = (len(xs) - 1) * q
+    lo, hi = int(k), min(int(k) + 1, len(xs) - 1)
+    return xs[lo] + (xs[hi] - xs[lo]) * (k - lo)
+
+
+def step_stats(events, host_t, t_end):
+    """per-step distribution of the timed region: `gpu` = HIP-event time between the starts of consecutive steps on the main
+    stream (the last step ends at the final event), `host` = the host's enqueue time per step (run-ahead: it can be
+    shorter than the GPU's)"""
+    gpu = [events[i].elapsed_time(events[i + 1]) for i in range(len(events) - 1)]
+    host = [1e3 * (b - a) for a, b in zip(host_t, host_t[1:] + [t_end])]
+    r = lambda v: None if v is None else round(v, 3)
+    return {'gpu_p50': r(pct(gpu, 0.5)), 'gpu_p90': r(pct(gpu, 0.9)), 'gpu_max': r(max(gpu)), 'gpu_min': r(min(gpu)),
+            'host_p50': r(pct(host, 0.5)), 'host_max': r(max(host)),
+            'gpu_per_step': [round(x, 2) for x in gpu] if len(gpu) <= 64 else None,
+            'what': 'ms; gpu = HIP events at the start of every step on the main stream, host = enqueue time per step'}
+
+
 def secondary(args, rank, world, dev):
     """Secondary rows (BASELINE.json configs other than the headline cfg2), each ONE JSON line with its own workload name:
       cfg1  PredCls evaluation, one 592x592 image with 20 GT boxes per step (380 candidate pairs)      -- eval img/s
@@ -470,12 +542,18 @@ def main():
                     help='BASELINE.json configs[i-1]; cfg2 (default) is the headline metric, the others are secondary rows; '
                          'recipe = cfg2 with the edge-context LSTM of the shipped training script (-nl_edge 4, '
                          'scripts/train_models_sgcls.sh:19-21; SURVEY.md 8d)')
+    ap.add_argument('--launch-selftest', action='store_true', help='only exercise the rank launcher / process group (no model)')
+    ap.add_argument('--h2d-steps', type=int, default=8, help='steps of the second, H2D-inclusive timing (0 = skip)')
     args = ap.parse_args()
 
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        raise SystemExit(launch_ranks(args, sys.argv[1:]))       # not started by torchrun: start the ranks ourselves
+    if args.launch_selftest:
+        return launch_selftest(args)
     from lib import dist as D
     rank, world, local_rank = D.init_from_env()
-    if world != args.gpus:
-        raise SystemExit('--gpus %d but WORLD_SIZE=%d: launch with torchrun --nproc-per-node %d' % (args.gpus, world, args.gpus))
+    if world != args.gpus or (world > 1 and torch.distributed.get_world_size() != args.gpus):
+        raise SystemExit('--gpus %d but the process group has %d rank(s): refusing to report a job of another size' % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs a HIP device (no CPU fallback for the hot path)')
     torch.cuda.set_device(local_rank)
@@ -505,7 +583,9 @@ def main():
     rest = [p for n, p in model.named_parameters() if not n.startswith('roi_fmap') and p.requires_grad]
     opt = FusedClipSGD([{'params': fc, 'lr': lr / 10.0}, {'params': rest}], lr=lr, momentum=0.9, weight_decay=1e-4)
     reducer = D.OverlappedGradReducer([p for p in model.parameters() if p.requires_grad])   # inert at world 1
-    blobs = [make_blob(ds, range(i * BATCH, (i + 1) * BATCH), is_train=True) for i in range(n_img // BATCH)]
+    import copy
+    host_blobs = [make_blob(ds, range(i * BATCH, (i + 1) * BATCH), is_train=True).pin_memory() for i in range(n_img // BATCH)]
+    blobs = [copy.copy(b) for b in host_blobs]                # shallow: the device copies below replace the tensor attributes
     for b in blobs:
         b.scatter()                                           # inputs resident in HBM before the timed region
     meters = install_meters(_hip)
@@ -514,8 +594,12 @@ def main():
     if world > 1:
         model.rows_hook = roww.start          # the row-count all-reduce starts inside the forward pass, asynchronously
 
-    def step(i):
-        res = model[blobs[i % len(blobs)]]
+    def step(i, upload=False):
+        blob = blobs[i % len(blobs)]
+        if upload:                           # the reference's per-step scatter (train_rels.py:137, blob.py:155-180): 25 MB of
+            blob = copy.copy(host_blobs[i % len(host_blobs)])      # page-locked batch -> HBM, asynchronous, ordered on the stream
+            blob.scatter()
+        res = model[blob]
         l_obj = F.cross_entropy(res.rm_obj_dists, res.rm_obj_labels)
         l_rel = F.cross_entropy(res.rel_dists, res.rel_labels[:, -1])
         if world > 1:
@@ -545,9 +629,15 @@ def main():
         step(i)
     barrier()
     set_meters(meters, True)
+    step_ev = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+    host_t = []
     t0 = time.time()
     for i in range(args.steps):
+        step_ev[i].record()
+        host_t.append(time.perf_counter())
         loss = step(args.warmup + i)
+    step_ev[args.steps].record()
+    t_enq = time.perf_counter()
     barrier()
     dt = time.time() - t0
     set_meters(meters, False)
@@ -555,6 +645,27 @@ def main():
     if world > 1:
         torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
     dt = float(tmax.item())
+    stats = step_stats(step_ev, host_t, t_enq)
+
+    # second timing, meters off: the same steps with the batch uploaded from page-locked host memory inside every step
+    h2d = None
+    if args.h2d_steps > 0:
+        for i in range(2):
+            step(i, upload=True)
+        barrier()
+        t1 = time.time()
+        for i in range(args.h2d_steps):
+            step(2 + i, upload=True)
+        barrier()
+        dth = torch.tensor([time.time() - t1], dtype=torch.float64, device=dev)
+        if world > 1:
+            torch.distributed.all_reduce(dth, op=torch.distributed.ReduceOp.MAX)
+        dth = float(dth.item())
+        nbytes = sum(getattr(host_blobs[0], n).numel() * getattr(host_blobs[0], n).element_size()
+                     for n in ('imgs', 'gt_boxes', 'gt_classes', 'gt_rels'))
+        h2d = {'value': world * BATCH * args.h2d_steps / dth, 'unit': 'img/s', 'ms_per_step': 1e3 * dth / args.h2d_steps,
+               'steps': args.h2d_steps, 'bytes_per_step': nbytes,
+               'what': 'same step with the batch uploaded (pinned host -> HBM, async on the main stream) inside every step, unmetered'}
 
     if args.host_profile and rank == 0:
         # where the HOST spends a step: enqueue time without synchronisation (the GPU queue is empty at the start, so this
@@ -635,6 +746,8 @@ def main():
             'value': world * BATCH * args.steps / dt, 'unit': 'img/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * dt / args.steps,
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'ms_per_step_p50': stats['gpu_p50'], 'ms_per_step_p90': stats['gpu_p90'], 'ms_per_step_max': stats['gpu_max'],
+            'step_ms': stats, 'h2d_inclusive': h2d,
             'config': {'workload': 'SGCls MotifNet VGG16 train step (fwd+bwd+clip+SGD), order=leftright, nl_obj=2, '
                                    'nl_edge=%d, hidden 512, batch 6/GPU, 20 GT boxes/img, <=256 rel rows/img, 592x592' % model_kw['nl_edge'],
                        'global_batch': world * BATCH, 'parallelism': 'dp%d' % world, 'final_loss': float(loss.item())},

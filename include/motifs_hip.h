@@ -33,15 +33,14 @@ extern "C" {
 #define MH_EPI_RELU6 2
 
 int mh_version(void);
-/* how the fp32 matrix products of mh_gemm_* / mh_conv3x3_* are evaluated in this build (MFMAs per fp32 product):
- * 3 with mh_split_f16() == 1 = f16x3, the DEFAULT: each operand row is scaled by a power of two (its largest magnitude
- *     lands in [2^14, 2^15)), every element splits into two f16 terms h1 + h2 (|remainder| <= 2^-24 |a|), three f16 MFMAs
- *     (h1*h1 + h1*h2 + h2*h1) accumulate in fp32, the scales come off exactly in the epilogue;
- * 6 = bf16x6 (build knob MH_SPLIT_F16=0): exact 3-way bf16 split of both operands, six bf16 MFMAs;
- * 0 = f32-input MFMA (exact fp32 fma chain; MH_MFMA_SPLIT=0);  3 with mh_split_f16() == 0 = bf16x3 (2^-17; experiments).
- * Measured error of all builds against float64: profiles/r02_split_check.jsonl (tools/split_check.cpp). */
+/* how the fp32 matrix products of mh_gemm_* / mh_conv3x3_* are evaluated (MFMAs per fp32 product): always 3, with
+ * mh_split_f16() == 1 = f16x3: each operand row is scaled by a power of two (its largest magnitude lands in
+ * [2^14, 2^15)), every element splits into two f16 terms h1 + h2 (|remainder| <= 2^-24 |a|), three f16 MFMAs
+ * (h1*h1 + h1*h2 + h2*h1) accumulate in fp32, the scales come off exactly in the epilogue.  (Rounds 1-2 also shipped a
+ * bf16x6 and an f32-input-MFMA build; their code is gone, their measured error against float64 is kept in
+ * profiles/r02_split_check.jsonl, tools/split_check.cpp.) */
 int mh_mfma_split(void);
-/* 1 when the bf16 split rounds to nearest even (build knob MH_SPLIT_RN=1, bf16x6 builds only) */
+/* always 0 (kept for ABI stability: the bf16x6 builds it described were removed in round 3) */
 int mh_split_rne(void);
 /* 1 in the f16x3 build (the default); workspaces of mh_gemm_f32 / mh_conv3x3_* then also hold the row exponents */
 int mh_split_f16(void);
@@ -113,8 +112,7 @@ int mh_triplet_match(const int *gt_triplets, const float *gt_boxes, int G, const
                      void *stream);
 
 /* ---------------------------------------------------------------------------------------------
- * FP32 GEMM on MFMA (f16x3 on v_mfma_f32_32x32x16_f16 by default; bf16x6 / v_mfma_f32_32x32x2_f32 in the MH_SPLIT_F16=0 /
- * MH_MFMA_SPLIT=0 builds; see mh_mfma_split).  Replaces the cuBLAS / nn.Linear
+ * FP32 GEMM on MFMA (f16x3 on v_mfma_f32_32x32x16_f16; see mh_mfma_split).  Replaces the cuBLAS / nn.Linear
  * calls on the path (lib/object_detector.py:80-104, lib/rel_model.py:367-390,
  * highway_lstm_kernel.cu:441-465).  Row-major:
  *     C[M,N] = epi( opA(A)[M,K] * opB(B)[K,N] + bias[N] )   (+ C if accumulate)

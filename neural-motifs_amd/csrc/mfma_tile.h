@@ -61,79 +61,6 @@ __device__ __forceinline__ void acc_zero(Acc &a)
             for (int r = 0; r < 16; ++r) a.v[i][j][r] = 0.f;
 }
 
-// Per-lane operand fragments of one k-tile.  WM: two float4 per phase of 4 k-steps (sub-tiles s = 0,1);
-// KM: one float2 per k-step (x = sub-tile 0, y = sub-tile 1).
-template <bool WM>
-struct FragBuf;
-template <>
-struct FragBuf<true> {
-    float4 v[2][2];   // [phase parity][sub-tile]
-};
-template <>
-struct FragBuf<false> {
-    float2 v[kBK / 2];   // one register pair per k-step (no reuse inside a k-tile: lets the waits be counted exactly)
-};
-
-// issue the LDS reads that provide k-step `kk`; returns the number of DS instructions issued (compile-time folded)
-template <int WD>
-__device__ __forceinline__ int frag_fetch(FragBuf<true> &f, const float *__restrict__ tile, int w0, int lane, int kk)
-{
-    if (kk % 4 != 0) return 0;
-    const float *p = tile + (w0 + (lane & 31)) * kLdW + 8 * (lane >> 5) + kk;
-    f.v[(kk / 4) & 1][0] = *reinterpret_cast<const float4 *>(p);
-    f.v[(kk / 4) & 1][1] = *reinterpret_cast<const float4 *>(p + 32 * kLdW);
-    return 2;
-}
-template <int WD>
-__device__ __forceinline__ int frag_fetch(FragBuf<false> &f, const float *__restrict__ tile, int w0, int lane, int kk)
-{
-    constexpr int ld = TileGeom<WD, false>::ld;
-    f.v[kk] = *reinterpret_cast<const float2 *>(tile + (8 * (lane >> 5) + kk) * ld + w0 + 2 * (lane & 31));
-    return 1;
-}
-__device__ __forceinline__ float frag_get(const FragBuf<true> &f, int kk, int s)
-{
-    const float4 &x = f.v[(kk / 4) & 1][s];
-    return (kk % 4 == 0) ? x.x : (kk % 4 == 1) ? x.y : (kk % 4 == 2) ? x.z : x.w;
-}
-__device__ __forceinline__ float frag_get(const FragBuf<false> &f, int kk, int s)
-{
-    return s == 0 ? f.v[kk].x : f.v[kk].y;
-}
-
-// All MFMAs of one k-tile for this wave.  wm/wn = the wave's row/col origin inside the block tile.
-// The LDS reads for k-step kk+1 are issued before the 4 MFMAs of step kk and the order is pinned with
-// sched_group_barrier, so the 4 x 64-cycle MFMA issue covers the LDS latency inside the SAME wave.
-template <bool AWM, bool BWM, int BM, int BN>
-__device__ __forceinline__ void mma_ktile_f32(const float *__restrict__ As, const float *__restrict__ Bs, int wm, int wn,
-                                          int lane, Acc &acc)
-{
-    FragBuf<AWM> a;
-    FragBuf<BWM> b;
-    frag_fetch<BM>(a, As, wm, lane, 0);
-    frag_fetch<BN>(b, Bs, wn, lane, 0);
-    __builtin_amdgcn_sched_group_barrier(0x100, (AWM ? 2 : 1) + (BWM ? 2 : 1), 0);   // the prologue reads form group 0
-#pragma unroll
-    for (int kk = 0; kk < kBK / 2; ++kk) {
-        int nreads = 0;
-        if (kk + 1 < kBK / 2) {
-            nreads += frag_fetch<BM>(a, As, wm, lane, kk + 1);
-            nreads += frag_fetch<BN>(b, Bs, wn, lane, kk + 1);
-        }
-        const float a0 = frag_get(a, kk, 0), a1 = frag_get(a, kk, 1);
-        const float b0 = frag_get(b, kk, 0), b1 = frag_get(b, kk, 1);
-        acc.v[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc.v[0][0], 0, 0, 0);
-        acc.v[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc.v[0][1], 0, 0, 0);
-        acc.v[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc.v[1][0], 0, 0, 0);
-        acc.v[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc.v[1][1], 0, 0, 0);
-        if (nreads == 1) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-        if (nreads == 2) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-        if (nreads == 3) __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
-        if (nreads == 4) __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
-        __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
-    }
-}
-
 // ---------------------------------------------------------------------------------------------------------------
 // FP32-accurate products on the f16 matrix cores ("f16x3").
 // gfx950's v_mfma_f32_32x32x16_f16 retires 16 k per 32 cycles, the f32-input MFMA 2 k per 64 cycles: 16x the rate.

@@ -11,6 +11,7 @@
 #include <cstdlib>
 
 #include "mfma_tile.h"     // launch_row_exponents / launch_splitk_reduce / makespan_units (gemm.hip)
+#include "pl_ring.h"
 #include "pl_tile.h"
 
 namespace mh {
@@ -276,28 +277,107 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_kernel(const GemmArgs p)
     });
 }
 
+
+// ------------------------------------------------------------------------------------------------- the ring GEMM kernel
+// Round 4: the same product on the ring loop of pl_ring.h (LDS-DMA staging, register double-buffered fragments, 64x128 wave
+// tiles).  Operand images, scales, epilogue and tile numbering are those of gemm_kernel above.
+template <class R>
+__global__ __launch_bounds__(R::threads, (R::threads == 512 || R::sm * R::sn <= 8) ? 2 : 1) void gemm_ring_kernel(const GemmArgs p)
+{
+    extern __shared__ __attribute__((aligned(1024))) char lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int wm0, wn0;
+    rwave_origin<R>(wave, wm0, wn0);
+    const int t = xcd_remap(blockIdx.x, p.tiles_m * p.tiles_n);
+    int tm, tn;
+    patch_tile(t, p.tiles_m, p.tiles_n, p.patch_h, p.patch_w, tm, tn);
+    const int m0 = tm * R::bm, n0 = tn * R::bn;
+    const int z = blockIdx.y;
+    const int kt_begin = z * p.kc_per_split, kt_end = min(p.Kc, kt_begin + p.kc_per_split);
+
+    const Src sa = make_src(p.A + (size_t)m0 * kCell), sb = make_src(p.B + (size_t)n0 * kCell);
+    const unsigned strideA = (unsigned)p.M * kCell, strideB = (unsigned)p.N * kCell;
+    DmaPlan<R> dp;
+    plan_dma<R>(dp, [&](int r) { return m0 + r < p.M; }, [&](int r) { return n0 + r < p.N; }, wave, lane);
+    FragPlan fp;
+    rplan_frags<R>(fp, wm0, wn0, lane);
+    auto issue = [&](int kt, char *stage) {
+        const bool live = kt < kt_end;                        // padding steps: A out of range (zeros), B = the last tile again
+        const int ktc = live ? kt : kt_end - 1;
+        unsigned va[R::na];
+#pragma unroll
+        for (int j = 0; j < R::na; ++j) va[j] = live ? dp.va[j] : kOob;
+        dma_stage<R>(sa, sb, va, dp.vb, (unsigned)ktc * strideA, (unsigned)ktc * strideB, stage, wave);
+    };
+    RAcc<R> acc;
+    racc_zero<R>(acc);
+    ring_loop<R>(issue, kt_begin, kt_end, lds, fp, acc);
+
+    // the ring is free after the loop's last barrier: this tile's row / column exponents go there
+    int *ex = reinterpret_cast<int *>(lds);
+    for (int i = tid; i < R::bm + R::bn; i += R::threads) {
+        const bool is_a = i < R::bm;
+        const int idx = is_a ? m0 + i : n0 + (i - R::bm);
+        const bool ok = is_a ? idx < p.M : idx < p.N;
+        ex[i] = ok ? row_exponent(is_a ? p.mbA[idx] : p.mbB[idx]) : 0;
+    }
+    __syncthreads();
+    int ecol[R::sn];
+    float bcol[R::sn];
+#pragma unroll
+    for (int sn = 0; sn < R::sn; ++sn) {
+        const int c = wn0 + 32 * sn + (lane & 31);
+        ecol[sn] = ex[R::bm + c];
+        bcol[sn] = (p.bias && p.splitk == 1 && n0 + c < p.N) ? p.bias[n0 + c] : 0.f;
+    }
+    if (p.splitk > 1) {
+        float *dst = p.partial + (size_t)z * p.M * p.N;
+        racc_foreach<R>(acc, wm0, wn0, lane, [&](int r, int c, int sn, float v) {
+            const int row = m0 + r, col = n0 + c;
+            if (row < p.M && col < p.N) dst[(size_t)row * p.N + col] = __builtin_ldexpf(v, -(ex[r] + ecol[sn]));
+        });
+        return;
+    }
+    racc_foreach<R>(acc, wm0, wn0, lane, [&](int r, int c, int sn, float v) {
+        const int row = m0 + r, col = n0 + c;
+        if (row >= p.M || col >= p.N) return;
+        v = epi(__builtin_ldexpf(v, -(ex[r] + ecol[sn])) + bcol[sn], p.epilogue);
+        float *q = p.C + (size_t)row * p.ldc + col;
+        if (p.accumulate) v += *q;
+        *q = v;
+    });
+}
+
+typedef Ring<4, 2, 2, 4, 4> R256x256;        // 8 waves, 64x128 wave tiles, 4 stages x 32 KB: one block per CU
+typedef Ring<4, 1, 2, 4, 3> R256x128;        // 4 waves, 3 stages x 24 KB: two blocks per CU
+typedef Ring<2, 2, 4, 4, 4> R256x256w4;      // 4 waves, 128x128 wave tiles (256 accumulator registers): one wave per SIMD
+
 typedef Shape<256, 128, 4, 2> S256x128;
 typedef Shape<128, 128, 2, 2> S128x128;
 typedef Shape<256, 64, 2, 2> S256x64;
 
 // ------------------------------------------------------------------------------------------------- host side
 struct Plan {
-    int shape;     // 0: 256x128, 1: 128x128, 2: 256x64
+    int shape;     // round-3 loop: 0: 256x128, 1: 128x128, 2: 256x64; ring loop: 3: 256x256 (8 waves), 4: 256x128 (4 waves, 2 / CU),
+                   // 5: 256x256 (4 waves of 128x128)
     int bm, bn, splitk;
 };
 static int g_force_shape = -1;      // mh_debug_pl_shape: A/B runs
 
 static Plan plan_gemm(int M, int N, int K, int want_splitk)
 {
-    static const int bms[3] = {256, 128, 256}, bns[3] = {128, 128, 64};
+    static const int bms[6] = {256, 128, 256, 256, 256, 256}, bns[6] = {128, 128, 64, 256, 128, 256};
     // fp32-equivalent FLOP/s one CU sustains with a full complement of blocks of the shape (measured: DESIGN.md 5)
-    static const double rate[3] = {365e12 / 256, 370e12 / 256, 300e12 / 256};      // gpurun r03_c1
+    static const double rate[6] = {365e12 / 256, 370e12 / 256, 300e12 / 256, 450e12 / 256, 430e12 / 256, 450e12 / 256};
+    static const int per_cu[6] = {2, 2, 2, 1, 2, 1};          // resident blocks per CU the makespan model assumes
+    (void)per_cu;
     const int ktiles = ceil_div(K, kBK);
     Plan best = {1, 128, 128, 1};
     double best_cost = 1e30;
-    for (int s = 0; s < 3; ++s) {
+    for (int s = 0; s < 6; ++s) {
         if (g_force_shape >= 0 && s != g_force_shape) continue;
         if (g_force_shape < 0) {
+            if (s >= 3) continue;                 // ring shapes: selected explicitly until measured (mh_debug_pl_shape / MH_PL_RING)
             if (s == 2 && N > 64) continue;
             if (s != 2 && N <= 64) continue;
             if (s == 0 && M <= 128) continue;
@@ -337,7 +417,10 @@ static int launch_gemm(const GemmArgs &p0, const Plan &pl, hipStream_t st)
     p.patch_h = std::max(ph, 1);
     p.patch_w = std::max(pw, 1);
     const dim3 grid((unsigned)(p.tiles_m * p.tiles_n), (unsigned)p.splitk);
-    if (pl.shape == 0) launch<gemm_kernel<S256x128>>(grid, S256x128::lds_bytes, st, p);
+    if (pl.shape == 3) launch<gemm_ring_kernel<R256x256>>(grid, R256x256::lds_bytes, st, p, 0, R256x256::threads);
+    else if (pl.shape == 4) launch<gemm_ring_kernel<R256x128>>(grid, R256x128::lds_bytes, st, p, 0, R256x128::threads);
+    else if (pl.shape == 5) launch<gemm_ring_kernel<R256x256w4>>(grid, R256x256w4::lds_bytes, st, p, 0, R256x256w4::threads);
+    else if (pl.shape == 0) launch<gemm_kernel<S256x128>>(grid, S256x128::lds_bytes, st, p);
     else if (pl.shape == 1) launch<gemm_kernel<S128x128>>(grid, S128x128::lds_bytes, st, p);
     else launch<gemm_kernel<S256x64>>(grid, S256x64::lds_bytes, st, p);
     return check_launch("pl::gemm_kernel");

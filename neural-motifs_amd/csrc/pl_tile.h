@@ -280,7 +280,7 @@ __device__ __forceinline__ void wave_atomic_max(unsigned *words, int key, unsign
 }
 
 template <auto Kern, typename Args>
-inline void launch(dim3 grid, size_t lds_bytes, hipStream_t st, const Args &p, size_t lds_max = 0)
+inline void launch(dim3 grid, size_t lds_bytes, hipStream_t st, const Args &p, size_t lds_max = 0, int threads = kThreads)
 {
     // lds_max: the largest dynamic LDS size ANY launch of this kernel may ask for (the attribute is set once per device)
     static bool raised[64] = {};
@@ -291,7 +291,7 @@ inline void launch(dim3 grid, size_t lds_bytes, hipStream_t st, const Args &p, s
                                   (int)(lds_max > lds_bytes ? lds_max : lds_bytes));
         raised[dev] = true;
     }
-    hipLaunchKernelGGL(Kern, grid, dim3(kThreads), lds_bytes, st, p);
+    hipLaunchKernelGGL(Kern, grid, dim3((unsigned)threads), lds_bytes, st, p);
 }
 
 }  // namespace pl

@@ -189,6 +189,8 @@ class OverlappedGradReducer(object):
         if not (self.enabled and self.overlap and self._armed):
             return None
         w = self._where.get(id(p))
+        if p.grad is not None:                      # a kept .grad (zero_grad(set_to_none=False), gradient accumulation) may BE
+            return None                             # this slot: writing the new gradient into it and then `grad += gw` would double it
         if w is None or id(p) in self._handed:      # a slot is handed out ONCE per backward: a parameter used twice gets its
             return None                             # second contribution as an ordinary tensor, which autograd adds on top
         self._handed.add(id(p))

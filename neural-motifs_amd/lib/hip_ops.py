@@ -101,7 +101,7 @@ class _LinearFn(torch.autograd.Function):
         x2, w2 = _rows2d(x), _rows2d(weight)
         epi = EPI_RELU if relu else EPI_NONE
         ctx.x_cols = None
-        ctx.x2 = None
+        x_keep = None
         need_wgrad, need_dgrad = ctx.needs_input_grad[1], ctx.needs_input_grad[0]      # (grad mode is off inside forward)
         M, K, N = x2.shape[0], x2.shape[1], w2.shape[0]
         # plane images pay for big, deep products (and for cached weights); small / thin ones and the skinny product against a
@@ -112,7 +112,7 @@ class _LinearFn(torch.autograd.Function):
             y = x2.new_zeros(0, N)
         elif not ctx.images:
             y = _hip.gemm_inloop(x2, w2, False, True, bias=bias, epilogue=epi)
-            ctx.x2 = x2 if need_wgrad else None
+            x_keep = x2 if need_wgrad else None
         else:
             if need_wgrad:
                 x_rows, ctx.x_cols = _hip.make_planes_both(x2)
@@ -123,12 +123,14 @@ class _LinearFn(torch.autograd.Function):
         ctx.has_bias = bias is not None
         ctx.weight = weight
         ctx.x_shape = tuple(x2.shape)
-        ctx.save_for_backward(y if relu else None)
+        # fp32 tensors go through save_for_backward (autograd's in-place-modification check); the plane image kept for the weight
+        # gradient is this function's own buffer
+        ctx.save_for_backward(y if relu else None, x_keep)
         return y
 
     @staticmethod
     def backward(ctx, gy):
-        (y,) = ctx.saved_tensors
+        y, x_keep = ctx.saved_tensors
         weight = ctx.weight
         gy = _rows2d(gy)
         if ctx.relu:
@@ -146,10 +148,10 @@ class _LinearFn(torch.autograd.Function):
                 M, K, N = ctx.x_shape[0], ctx.x_shape[1], gy.shape[1]
                 if 2.0 * M * N * K >= 20e9 and M >= 96:        # the skinny layer's weight gradient is a big product again
                     sink = GRAD_SINK(weight) if (GRAD_SINK is not None and weight.is_contiguous()) else None
-                    gw = _hip.gemm_planes(_hip.make_planes(gy, False), _hip.make_planes(ctx.x2, False), out=sink)
+                    gw = _hip.gemm_planes(_hip.make_planes(gy, False), _hip.make_planes(x_keep, False), out=sink)
                 else:
                     sink = GRAD_SINK(weight) if (GRAD_SINK is not None and weight.is_contiguous()) else None
-                    gw = _hip.gemm_inloop(gy, ctx.x2, True, False, out=sink)               # [M,N]^T . [M,K]
+                    gw = _hip.gemm_inloop(gy, x_keep, True, False, out=sink)               # [M,N]^T . [M,K]
         else:
             gy_rows = gy_cols = None
             if ctx.needs_input_grad[0] and ctx.needs_input_grad[1]:
@@ -163,7 +165,7 @@ class _LinearFn(torch.autograd.Function):
                 gw = _hip.gemm_planes(gy_cols, ctx.x_cols, out=sink)                       # gy^T [N,M] . (x^T [K,M])^T
         if ctx.has_bias and ctx.needs_input_grad[2]:
             gb = gy.sum(0)
-        ctx.x_cols = ctx.x2 = None
+        ctx.x_cols = None
         return gx, gw, gb, None
 
 
@@ -321,7 +323,13 @@ class VGG16Features(nn.Sequential):
         # MOTIFS_TRUNK=planes|v2 forces one engine.
         engine = os.environ.get('MOTIFS_TRUNK', 'auto')
         if engine == 'planes' or (engine == 'auto' and x.shape[0] >= 2):
-            return self._forward_planes(x)
+            # csrc/pl_conv.hip addresses an activation image with 32-bit byte offsets (image bytes = B*H*W*C*4 < 0x7ff00000,
+            # B <= 256): the widest layer (64 channels at full resolution) bounds the images of one pass -- 23 at 592x592.
+            # Larger batches run in chunks (the trunk is per-image arithmetic; per-image scales make chunking exact).
+            cap = max(1, min(256, (0x7ff00000 - 1) // (x.shape[2] * x.shape[3] * 64 * 4)))
+            if x.shape[0] <= cap:
+                return self._forward_planes(x)
+            return torch.cat([self._forward_planes(x[i:i + cap]) for i in range(0, x.shape[0], cap)], 0)
         with torch.no_grad():
             mods = list(self.children())
             first = mods[0]

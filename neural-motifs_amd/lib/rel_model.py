@@ -77,8 +77,10 @@ class _LateBackward(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
-        inner = ctx.holder.pop()
-        torch.autograd.backward(inner, g)
+        # the holder keeps its entry: a second backward (retain_graph) reaches the same inner graph and gets autograd's own
+        # error or result, not an IndexError.  Gradients of the inner graph's parameters are ACCUMULATED into .grad as a side
+        # effect -- torch.autograd.grad(loss, params) does not see them; only loss.backward() is supported in this mode
+        torch.autograd.backward(ctx.holder[0], g)
         return None, None
 
 

@@ -21,6 +21,7 @@ from lib.hip_ops import _c, _Conv3x3Fn, linear, EPI_NONE, EPI_RELU
 
 BN_EPS = 1e-5
 BN_MOMENTUM = 0.1            # torchvision's BatchNorm2d default (the detector uses torchvision.models.resnet)
+L4_BN_MOMENTUM = 0.01        # config.BATCHNORM_MOMENTUM: the relation model's resnet_l4 blocks (reference lib/resnet.py:14-19)
 
 
 class _Conv(nn.Module):
@@ -126,14 +127,14 @@ class _BN(nn.Module):
 class Bottleneck(nn.Module):
     expansion = 4
 
-    def __init__(self, inplanes, planes, stride=1, downsample=None):
+    def __init__(self, inplanes, planes, stride=1, downsample=None, momentum=BN_MOMENTUM):
         super(Bottleneck, self).__init__()
         self.conv1 = _Conv(inplanes, planes, 1)
-        self.bn1 = _BN(planes)
+        self.bn1 = _BN(planes, momentum)
         self.conv2 = _Conv(planes, planes, 3, stride=stride, pad=1)
-        self.bn2 = _BN(planes)
+        self.bn2 = _BN(planes, momentum)
         self.conv3 = _Conv(planes, planes * 4, 1)
-        self.bn3 = _BN(planes * 4)
+        self.bn3 = _BN(planes * 4, momentum)
         self.downsample = downsample
         self.stride = stride
         self.relu_end = True            # lib/resnet.py:126-131: the last block of the relation model's layer4 ends without ReLU
@@ -197,8 +198,11 @@ class Layer4Stack(nn.Sequential):
     NHWC on the HIP kernels, with autograd when the parameters train."""
 
     def __init__(self, relu_end=True):
-        down = nn.Sequential(_Conv(1024, 2048, 1), _BN(2048))
-        blocks = [Bottleneck(1024, 512, 1, down), Bottleneck(2048, 512), Bottleneck(2048, 512)]
+        # the reference's OWN lib/resnet.py builds these blocks with momentum=BATCHNORM_MOMENTUM = 0.01 (lib/resnet.py:14-19,
+        # config.py:57); only the detector trunk comes from torchvision (0.1)
+        m = L4_BN_MOMENTUM
+        down = nn.Sequential(_Conv(1024, 2048, 1), _BN(2048, m))
+        blocks = [Bottleneck(1024, 512, 1, down, momentum=m), Bottleneck(2048, 512, momentum=m), Bottleneck(2048, 512, momentum=m)]
         blocks[-1].relu_end = relu_end
         super(Layer4Stack, self).__init__(*blocks)
 

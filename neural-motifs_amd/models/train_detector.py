@@ -99,7 +99,7 @@ def train_epoch(epoch_num):
             print(mn)
             print('-----------', flush=True)
             start = time.time()
-    return pd.concat(tr, axis=1)
+    return pd.concat(tr, axis=1) if tr else pd.DataFrame()
 
 
 def val_epoch():

@@ -159,7 +159,7 @@ def train_epoch(epoch_num):
     if pending:
         frames.append(_loss_frame(pending))
     _device_health()
-    return pd.concat(frames, axis=1, ignore_index=True)
+    return pd.concat(frames, axis=1, ignore_index=True) if frames else pd.DataFrame()      # a loader that yields no batch
 
 
 def val_batch(batch_num, b, evaluator):

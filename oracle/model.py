@@ -191,14 +191,15 @@ def resnet_l4_head(sd, x, prefix, training, relu_end=False):
     nn.Sequential(resnet_l4(relu_end=False), nn.AvgPool2d(7), Flattener()) (lib/rel_model.py:360-365, lib/resnet.py:126-133):
     torchvision's layer4 with the stride removed from block 0, the last block without its final ReLU, then the 7x7 mean.
     x [n,1024,7,7] -> [n,2048]; `prefix` e.g. 'roi_fmap.0.'"""
+    m = BATCHNORM_MOMENTUM      # lib/resnet.py:14-19 (the reference's own Bottleneck), not torchvision's 0.1
     for b in range(3):
         p = '%s%d.' % (prefix, b)
         last = (b == 2) and not relu_end
-        out = F.relu(_bn(sd, F.conv2d(x, sd[p + 'conv1.weight']), p + 'bn1.', training))
-        out = F.relu(_bn(sd, F.conv2d(out, sd[p + 'conv2.weight'], None, stride=1, padding=1), p + 'bn2.', training))
-        out = _bn(sd, F.conv2d(out, sd[p + 'conv3.weight']), p + 'bn3.', training)
+        out = F.relu(_bn(sd, F.conv2d(x, sd[p + 'conv1.weight']), p + 'bn1.', training, m))
+        out = F.relu(_bn(sd, F.conv2d(out, sd[p + 'conv2.weight'], None, stride=1, padding=1), p + 'bn2.', training, m))
+        out = _bn(sd, F.conv2d(out, sd[p + 'conv3.weight']), p + 'bn3.', training, m)
         if p + 'downsample.0.weight' in sd:
-            x = _bn(sd, F.conv2d(x, sd[p + 'downsample.0.weight']), p + 'downsample.1.', training)
+            x = _bn(sd, F.conv2d(x, sd[p + 'downsample.0.weight']), p + 'downsample.1.', training, m)
         x = out + x if last else F.relu(out + x)
     return x.mean((2, 3))
 

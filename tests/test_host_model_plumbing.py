@@ -637,3 +637,26 @@ def test_late_backward_of_the_union_box_branch_gives_the_same_gradients(small_wo
     first_ctx = min(i for i, n in enumerate(late[3]) if n.startswith('context.'))
     vis = [i for i, n in enumerate(late[3]) if n.startswith(('roi_fmap.', 'union_boxes.'))]
     assert vis and max(vis) < first_ctx, 'the union-box branch did not finish its backward first: %s' % late[3][:12]
+
+
+def test_layer4_batchnorm_momentum_is_the_reference_models(shim):
+    """the relation model's resnet_l4 blocks come from the reference's OWN lib/resnet.py (Bottleneck with
+    momentum=BATCHNORM_MOMENTUM = 0.01, lib/resnet.py:14-19, config.py:57), the detector trunk from torchvision (0.1):
+    product modules, the oracle's constant, and one train-mode running-stat update of the oracle's restatement"""
+    import torch.nn.functional as F
+    from config import BATCHNORM_MOMENTUM
+    from lib import resnet as R
+    from oracle import model as OM
+    assert BATCHNORM_MOMENTUM == 0.01 == OM.BATCHNORM_MOMENTUM == R.L4_BN_MOMENTUM
+    l4 = R.Layer4Stack(relu_end=False)
+    bns = [m for m in l4.modules() if isinstance(m, R._BN)]
+    assert len(bns) == 10 and all(m.momentum == 0.01 for m in bns)            # 3 x (bn1, bn2, bn3) + downsample.1
+    trunk_bns = [m for m in R.ResNet101Trunk().modules() if isinstance(m, R._BN)]
+    assert trunk_bns and all(m.momentum == 0.1 for m in trunk_bns)
+    # oracle: after one train-mode pass the running mean of block 0's bn1 moved by 0.01 * (batch mean - 0)
+    torch.manual_seed(0)
+    sd = {'roi_fmap.0.' + k: v.detach().clone() for k, v in l4.state_dict().items()}
+    x = torch.randn(3, 1024, 7, 7)
+    y1 = F.conv2d(x, sd['roi_fmap.0.0.conv1.weight'])
+    OM.resnet_l4_head(sd, x, 'roi_fmap.0.', True)
+    assert torch.allclose(sd['roi_fmap.0.0.bn1.running_mean'], 0.01 * y1.mean((0, 2, 3)), atol=1e-7)

@@ -134,7 +134,7 @@ static int image_case(int M, int N, int K, unsigned seed)
     std::vector<double> R;
     ref_gemm(0, 0, M, N, K, A, K, B, N, nullptr, 0, nullptr, N, R);
     int bad = 0;
-    for (int shape = -1; shape <= 2; ++shape) {
+    for (int shape = -1; shape <= 5; ++shape) {
         set_shape(shape);
         for (int sk : {0, 1, 3}) {
             Dev ws(wspl(M, N, K, sk));
@@ -507,6 +507,31 @@ static void conv_speed(const char *name, int B, int H, int W, int Cin, int Cout,
     set_conv_shape(-1);
 }
 
+
+// --ring: the round-4 ring kernels (shapes 3..5) against the round-3 loop (shapes 0, 1) on ready images: accuracy on ragged
+// shapes, then speed on the step's big products
+static void ring_speed(const char *name, int M, int N, int K, int iters)
+{
+    Dev dA((size_t)M * K * 4), dB((size_t)N * K * 4), dC((size_t)M * N * 4), ia(pbytes(M, K)), ib(pbytes(N, K));
+    fill_dev(dA.f(), (size_t)M * K, 1); fill_dev(dB.f(), (size_t)N * K, 2);
+    mkplanes(dA.f(), 1, M, K, K, ia.p, nullptr);
+    mkplanes(dB.f(), 1, N, K, K, ib.p, nullptr);
+    const double flops = 2.0 * M * N * (double)K;
+    for (int shape : {1, 0, 3, 4, 5}) {
+        if (shape == 0 && M <= 128) continue;
+        set_shape(shape);
+        for (int sk : {1, 2, 3, 4, 8}) {
+            if (sk > 1 && K / 16 / sk < 8) continue;
+            Dev ws(wspl(M, N, K, sk));
+            const float ms = time_ms(iters, [&] { gemmpl(M, N, K, ia.p, ib.p, dC.f(), N, nullptr, 0, 0, sk, ws.p, ws.n, nullptr); });
+            printf("{\"check\": \"ring speed\", \"case\": \"%s\", \"M\": %d, \"N\": %d, \"K\": %d, \"shape\": %d, \"splitk\": %d, \"ms\": %.4f, \"tflops\": %.1f}\n", name, M, N, K,
+                   shape, sk, ms, flops / ms * 1e-9);
+            fflush(stdout);
+        }
+    }
+    set_shape(-1);
+}
+
 int main(int argc, char **argv)
 {
     if (argc < 2) { printf("usage: pl_check <libmotifs_hip.so> [--quick] [--speed-only]\n"); return 1; }
@@ -591,6 +616,20 @@ int main(int argc, char **argv)
         return badc ? 1 : 0;
     }
     int bad = 0;
+    if (argc > 2 && !strcmp(argv[2], "--ring")) {
+        bad += image_case(520, 300, 1040, 21);
+        bad += image_case(130, 60, 200, 22);
+        bad += image_case(257, 513, 16 * 37, 25);
+        bad += image_case(1000, 1000, 16 * 4 + 5, 26);
+        printf("{\"check\": \"ring accuracy summary\", \"failed\": %d}\n", bad);
+        if (argc > 3 && !strcmp(argv[3], "--accuracy")) return bad ? 1 : 0;
+        ring_speed("4096^3", 4096, 4096, 4096, 5);
+        ring_speed("fc6 forward", 1536, 4096, 25088, 5);
+        ring_speed("fc7 forward", 1536, 4096, 4096, 10);
+        ring_speed("fc6 weight gradient", 4096, 25088, 1536, 5);
+        ring_speed("fc6 input gradient", 1536, 25088, 4096, 5);
+        return bad ? 1 : 0;
+    }
     if (pmc) {      // a few launches of the product kernel on ready images, nothing else: the target of rocprofv3 --pmc
         const int M = 1536, N = 4096, K = 25088;
         Dev dA((size_t)M * K * 4), dB((size_t)N * K * 4), dC((size_t)M * N * 4), ia(pbytes(M, K)), ib(pbytes(N, K));
