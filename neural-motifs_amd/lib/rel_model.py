@@ -266,10 +266,11 @@ class RelModel(nn.Module):
         # (a handful of chip-filling MFMA GEMMs).  The two branches only meet at the subject/object product.
         self.overlap_streams = os.environ.get('MOTIFS_OVERLAP', '1') != '0'     # context branch on a second HIP stream
         self._side_stream = None
-        # Backward ORDER of the two branches (see _LateBackward): 'auto' (default) = the union-box branch's backward is issued
-        # first whenever the two-stream forward is used with a frozen trunk; '0' = autograd's own order (context branch
-        # first); 'force' = also on one stream / on the CPU (tests)
-        self.late_vr_backward = os.environ.get('MOTIFS_LATE_VR', 'auto')
+        # Backward ORDER of the two branches (see _LateBackward): '0' (default) = autograd's own order (context branch first);
+        # 'auto' = the union-box branch's backward is issued first whenever the two-stream forward is used with a frozen
+        # trunk; 'force' = also on one stream / on the CPU (tests).  Measured in round 4 on one box, alternating, unprofiled
+        # (profiles/r04_variance.jsonl): 18.75 ms per step with it, 18.80 without, both +-0.1 ms -- no gain, so it is off
+        self.late_vr_backward = os.environ.get('MOTIFS_LATE_VR', '0')
 
         self.detector = ObjectDetector(
             classes=classes,

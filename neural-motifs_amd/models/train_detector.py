@@ -139,6 +139,8 @@ def val_epoch():
 if __name__ == '__main__':
     if rank == 0:
         print("Training starts now!")
+    from lib.pytorch_misc import quiet_gc
+    quiet_gc()
     for epoch in range(start_epoch + 1, start_epoch + 1 + conf.num_epochs):
         rez = train_epoch(epoch)
         if rank == 0:

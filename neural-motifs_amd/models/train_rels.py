@@ -25,7 +25,7 @@ from dataloaders.visual_genome import VGDataLoader, VG
 from lib import dist as D
 from lib.evaluation.sg_eval import BasicSceneGraphEvaluator
 from lib.optim import FusedClipSGD
-from lib.pytorch_misc import restore_rel_checkpoint, clip_grad_norm, print_para
+from lib.pytorch_misc import restore_rel_checkpoint, clip_grad_norm, print_para, quiet_gc
 
 conf = ModelConfig()
 if conf.model == 'motifnet':
@@ -195,6 +195,7 @@ def val_epoch():
 if rank == 0:
     print("Training starts now!")
 optimizer, scheduler = get_optim(conf.lr * world * conf.batch_size)
+quiet_gc()        # model, optimizer and loaders are built: keep full garbage collections out of the steps (lib/pytorch_misc.py)
 for epoch in range(start_epoch + 1, start_epoch + 1 + conf.num_epochs):
     rez = train_epoch(epoch)
     if rank == 0:
