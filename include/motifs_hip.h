@@ -190,6 +190,7 @@ int mh_stem_to_image(const float *in_nchw, int B, int Cin, int H, int W, const f
                      int epilogue, void *out_image, unsigned *out_maxbits, void *stream);
 void mh_debug_plconv_shape(int shape);
 void mh_debug_plconv_splitk(int splitk);   /* 0 = the planner's schedule; > 0 = every tile in that many K slices (sweeps) */
+void mh_debug_plconv_flags(int flags);     /* measurement only; bit 1: the ring kernel returns without its epilogue (no output) */
 
 /* ---------------------------------------------------------------------------------------------
  * Convolution stack, NHWC internal layout (cuDNN replacement; lib/object_detector.py:110-118,

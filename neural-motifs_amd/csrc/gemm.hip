@@ -515,8 +515,12 @@ int launch_row_exponents(const float *X, bool k_contiguous, long long n_rows, lo
 //     floor(blocks / slots) * k  +  j / f(j),   j = ceil(remainder / 256) blocks per CU in the last round, f(k) = 1
 // (PMC: the 384-tile fc6 forward at S = 2 ran 1.5 rounds with an average of 1.2 waves per SIMD).  The partial-sum round
 // trip costs S*M*N*8 bytes of HBM traffic.
+static thread_local int g_slots_override = 0;
+void set_resident_slots_override(int slots) { g_slots_override = slots; }
+
 int resident_slots()
 {
+    if (g_slots_override > 0) return g_slots_override;      // a shape with another residency is being planned (pl_conv.hip: ring shapes)
     static const int slots = [] {
         const char *e = getenv("MH_SLOTS");
         const int v = e ? atoi(e) : 0;

@@ -581,6 +581,7 @@ struct ConvTilePlan {
 // LDS), but schedules built for 768 slots measured SLOWER on MI355X (trunk 6.11 ms vs 5.82 ms at 512, gpurun r02_c3);
 // MH_SLOTS overrides it for A/B runs.
 int resident_slots();
+void set_resident_slots_override(int slots);   // > 0: what resident_slots() returns on this thread until reset with 0
 double makespan_units(long long blocks);   // time of `blocks` equal blocks in units of (one block alone on a full CU)
 ConvTilePlan plan_conv_tiles(long long M, int Cin, int Cout, int bm, int bn);
 int launch_splitk_reduce(const float *partial, int splitk, long long M, int N, float *C, int ldc, const float *bias,

@@ -20,6 +20,7 @@
 #include <cstdlib>
 
 #include "mfma_tile.h"     // plan_conv_tiles, ConvTilePlan
+#include "pl_ring.h"
 #include "pl_tile.h"
 
 namespace mh {
@@ -176,6 +177,8 @@ struct ConvArgs {
     int tail_tiles, tail_slices, tail_ktiles;
     long long tail_row0;
     float *partial, *partial_tail;
+    int debug_flags;           // measurement only (mh_debug_plconv_flags): bit 1 = the ring kernel returns without its epilogue (no output):
+                               // what the K loop alone costs (gpurun r04_c5)
 };
 
 constexpr int kStageOff = 4096;       // LDS offset of the image epilogue's staging (behind the exponent tables)
@@ -395,6 +398,288 @@ __global__ __launch_bounds__(kThreads, (S::bm * S::bn <= 128 * 128) ? 3 : 2) voi
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------- the ring conv kernel
+// Round 4: the same implicit GEMM on the ring loop of pl_ring.h (LDS-DMA staging: no staging registers, no ds_write;
+// register double-buffered fragments; one barrier per k-tile with NS - 2 tiles in flight).  Images, scales, schedules and both
+// epilogues are those of conv3x3_kernel above; what changes is how a k-tile reaches LDS:
+//   * a lane owns R::na rows of the A tile (one per DMA piece) and keeps their 9-bit tap masks; for the k-tile of tap t a
+//     row whose tap leaves the image is fetched out of range (the DMA writes zeros), selected per piece with one v_cndmask;
+//   * the (A offset, B offset, tap bit) entry of a k-tile comes from the same per-block table in LDS, read one issue ahead;
+//     padding steps of the unrolled ring (and steps past a K slice's end) carry tap bit 0: A = zeros, acc += 0 * B.
+constexpr int kRingStageOff = 8192;   // LDS offset of the ring kernel's image staging (exponent tables of up to 512 + 256 rows in front)
+template <class R>
+constexpr int ring_conv_lds_bytes(bool img)
+{
+    const int epi = kRingStageOff + R::waves * (img ? 2 * 32 * 80 : 32 * 36 * 4);      // wave-private staging patches of the epilogue
+    return epi > R::lds_bytes ? epi : R::lds_bytes;
+}
+
+template <class R, bool IMG>
+__global__ __launch_bounds__(R::threads, (R::threads == 512 || R::sm * R::sn <= 8) ? 2 : 1) void conv3x3_ring_kernel(const ConvArgs p)
+{
+    extern __shared__ __attribute__((aligned(1024))) char lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int wm, wn;
+    rwave_origin<R>(wave, wm, wn);
+    const int tail_blocks = p.tail_tiles * p.tail_slices;
+    const bool is_tail = (int)blockIdx.x < tail_blocks;
+    int t, slice, kt_per_slice, nslices;
+    if (is_tail) {
+        t = p.body_tiles + (int)blockIdx.x / p.tail_slices;
+        slice = (int)blockIdx.x % p.tail_slices;
+        kt_per_slice = p.tail_ktiles;
+        nslices = p.tail_slices;
+    } else {
+        const int bb = (int)blockIdx.x - tail_blocks;
+        t = xcd_remap(bb % p.body_tiles, p.body_tiles);
+        slice = bb / p.body_tiles;
+        kt_per_slice = p.ktiles_per_split;
+        nslices = p.splitk;
+    }
+    const long long m0 = (long long)(t / p.tiles_n) * R::bm;
+    const int n0 = (t % p.tiles_n) * R::bn;
+    const long long HW = (long long)p.H * p.W, Mtot = (long long)p.B * HW;
+    const int G = p.Cin / kBK;
+    const int total_kt = 9 * G;
+    const int kt_begin = slice * kt_per_slice, kt_end = min(total_kt, kt_begin + kt_per_slice);
+
+    const int halo = p.W + 1;
+    const Src sa = make_src(p.in + (m0 - halo) * (long long)kCell), sb = make_src(p.wt + (size_t)n0 * kCell);
+    DmaPlan<R> dp;
+    plan_dma<R>(dp, [&](int) { return true; }, [&](int r) { return n0 + r < p.Cout; }, wave, lane);
+    unsigned a_taps[R::na];
+#pragma unroll
+    for (int j = 0; j < R::na; ++j) {
+        const long long pix = m0 + dma_row<R>(j, wave, lane);
+        const bool ok = pix < Mtot;
+        const int rem = (int)((ok ? pix : 0) % HW), py = rem / p.W, px = rem % p.W;
+        unsigned mask = 0;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int dy = tap / 3 - 1, dx = tap % 3 - 1;
+            if (ok && (unsigned)(py + dy) < (unsigned)p.H && (unsigned)(px + dx) < (unsigned)p.W) mask |= 1u << tap;
+        }
+        a_taps[j] = mask;
+    }
+    FragPlan fp;
+    rplan_frags<R>(fp, wm, wn, lane);
+    const unsigned strideA = (unsigned)(Mtot * kCell), strideB = (unsigned)p.Cout * kCell;
+    // Operand offsets of a k-tile WITHOUT a table: k-tiles run chunk-outer / tap-inner, K slices start at whole chunks
+    // (host: multiples of 9 k-tiles) and the loop body is unrolled over a multiple of 9 steps, so a tile's tap is a
+    // compile-time constant (`ui % 9`): the nine tap shifts and the nine per-tap weight offsets live in SGPRs, the chunk
+    // offsets advance by one scalar add per chunk.  (A table in LDS, as in the round-3 kernel, cannot be used here: hipcc
+    // orders any LDS read it cannot prove disjoint from an earlier `buffer_load ... lds` behind s_waitcnt vmcnt(0), so every
+    // step waited for the DMA it had just issued -- gpurun r04_c2: conv2_2 251 TF/s against 310 for the round-3 loop.)
+    unsigned tapoff[9], tapwt[9];
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+        tapoff[tap] = (unsigned)(halo + (tap / 3 - 1) * p.W + (tap % 3 - 1)) * kCell;
+        tapwt[tap] = (unsigned)(tap * G) * strideB;
+    }
+    const int g0 = kt_begin / 9;                   // kt_begin is a multiple of 9
+    unsigned ga = (unsigned)g0 * strideA - strideA, gb = (unsigned)g0 * strideB - strideB;      // advanced when a chunk's tap 0 is issued
+    auto issue = [&](int kt, int ui, char *stage) {
+        const int tap = ui % 9;                    // compile-time after unrolling (U % 9 == 0)
+        if (tap == 0) { ga += strideA; gb += strideB; }
+        const bool live = kt < kt_end;
+        const unsigned bit = live ? (1u << tap) : 0u;                 // padding steps: A out of range (zeros) ...
+        const unsigned ob = live ? gb + tapwt[tap] : 0u;              // ... and B = the first weight tile (finite values)
+        unsigned va[R::na];
+#pragma unroll
+        for (int j = 0; j < R::na; ++j) va[j] = (a_taps[j] & bit) ? dp.va[j] : kOob;
+        dma_stage<R>(sa, sb, va, dp.vb, ga + tapoff[tap], ob, stage, wave);
+    };
+    RAcc<R> acc;
+    racc_zero<R>(acc);
+    constexpr int U = (R::unroll % 9 == 0) ? R::unroll : ((R::unroll % 3 == 0) ? 3 * R::unroll : 9 * R::unroll);      // lcm(unroll, 9)
+    ring_loop<R, U, 9>(issue, kt_begin, kt_end, lds, fp, acc);
+    if (p.debug_flags & 2) {                    // measurement only: no epilogue (one store keeps the accumulators alive)
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < R::sm; ++i)
+#pragma unroll
+            for (int j = 0; j < R::sn; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) s += acc.v[i][j][r];
+        if (s == 123.456f && p.out) p.out[0] = s;
+        return;
+    }
+
+    // ---- epilogue.  The MFMAs ran with the operand roles SWAPPED (rmma: weights as the matrix-core A operand, pixels as B), so
+    // accumulator (sm, sn) of lane (j = lane & 31, g = lane >> 5) holds, in registers 4 q .. 4 q + 3, FOUR CONSECUTIVE CHANNELS
+    //     channel = wn + 32 sn + 8 q + 4 g + (0..3)     of pixel     wm + 32 sm + j
+    // -- 16 contiguous bytes of an NHWC row, or a quarter of a plane-image cell.  Round 3's epilogue had one channel of 16
+    // rows per lane: 128 four-byte global stores per lane and tile (fp32) or a shuffle + ds_write_b32 per ELEMENT (image), and
+    // measured as long as the whole K loop on the shallow layers (gpurun r04_c5: conv2_1 186 TF/s with it, 392 without).
+    // Now each 32 x 32 accumulator goes through a wave-private LDS patch (4 ds_write_b128 / 8 ds_write_b64 per lane) and leaves
+    // as four 16-byte stores per lane covering whole 128-byte lines.
+    float *chan_f = reinterpret_cast<float *>(lds);             // bias[bn]
+    int *chan_e = reinterpret_cast<int *>(lds) + R::bn;         // weight exponent per channel [bn]
+    for (int i = tid; i < R::bn; i += R::threads) {
+        const bool ok = n0 + i < p.Cout;
+        chan_f[i] = (ok && p.bias && nslices == 1) ? p.bias[n0 + i] : 0.f;
+        chan_e[i] = ok ? row_exponent(p.wt_bits[n0 + i]) : 0;
+    }
+    float bmax = 0.f;
+    if (IMG) {
+        unsigned m = 0;
+        if (p.bias)
+            for (int n = tid; n < p.Cout; n += R::threads) m = max(m, __float_as_uint(p.bias[n]) & 0x7fffffffu);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o));
+        unsigned *red = reinterpret_cast<unsigned *>(lds) + 2 * R::bn;
+        if (lane == 0) red[wave] = m;
+        __syncthreads();
+        unsigned mm = 0;
+#pragma unroll
+        for (int w = 0; w < R::waves; ++w) mm = max(mm, red[w]);
+        bmax = __uint_as_float(mm);
+    }
+    auto bound_bits = [&](int b) { return __float_as_uint(__uint_as_float(p.in_true_bits[b]) * p.wnorm[0] + bmax); };
+    if (IMG && blockIdx.x == 0 && tid < p.B) p.out_scale_bits[tid] = bound_bits(tid);
+    __syncthreads();
+    static_assert((2 * R::bn + 16) * 4 <= kRingStageOff, "channel tables must fit in front of the staging patches");
+    const int j = lane & 31, g = lane >> 5;
+    const unsigned uHW = (unsigned)HW;                                      // B*H*W < 2^25 (host-checked image size)
+    if (nslices > 1) {
+        // partial sums of this K slice (fp32, scales removed): rows numbered from the first row of the block's region
+        const long long region_row0 = is_tail ? p.tail_row0 : 0, region_rows = is_tail ? Mtot - p.tail_row0 : p.tail_row0;
+        float *dst = (is_tail ? p.partial_tail : p.partial) + (size_t)slice * region_rows * p.Cout;
+        float *stg = reinterpret_cast<float *>(lds + kRingStageOff) + wave * (32 * 36);
+#pragma unroll
+        for (int sm = 0; sm < R::sm; ++sm) {
+            const long long row = m0 + wm + 32 * sm + j;
+            const int ea = row < Mtot ? row_exponent(p.in_bits[(unsigned)row / uHW]) : 0;
+#pragma unroll
+            for (int sn = 0; sn < R::sn; ++sn) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int c = wn + 32 * sn + 8 * q + 4 * g;
+                    const int4 eb = *reinterpret_cast<const int4 *>(chan_e + c);
+                    float4 v;
+                    v.x = __builtin_ldexpf(acc.v[sm][sn][4 * q + 0], -(ea + eb.x));
+                    v.y = __builtin_ldexpf(acc.v[sm][sn][4 * q + 1], -(ea + eb.y));
+                    v.z = __builtin_ldexpf(acc.v[sm][sn][4 * q + 2], -(ea + eb.z));
+                    v.w = __builtin_ldexpf(acc.v[sm][sn][4 * q + 3], -(ea + eb.w));
+                    *reinterpret_cast<float4 *>(stg + j * 36 + 8 * q + 4 * g) = v;
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int rr = 8 * i + (lane >> 3), c4 = 4 * (lane & 7);
+                    const long long orow = m0 + wm + 32 * sm + rr;
+                    const int col = n0 + wn + 32 * sn + c4;
+                    const float4 v = *reinterpret_cast<const float4 *>(stg + rr * 36 + c4);
+                    if (orow < Mtot && col < p.Cout) *reinterpret_cast<float4 *>(dst + (size_t)(orow - region_row0) * p.Cout + col) = v;
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        return;
+    }
+    unsigned vmax[R::sm];
+    int img_of[R::sm];
+    if (!IMG) {
+        float *stg = reinterpret_cast<float *>(lds + kRingStageOff) + wave * (32 * 36);      // [32 pixels][32 channels + 4 pad]
+#pragma unroll
+        for (int sm = 0; sm < R::sm; ++sm) {
+            const long long row = m0 + wm + 32 * sm + j;
+            const bool rok = row < Mtot;
+            const int b = rok ? (int)((unsigned)row / uHW) : 0;
+            const int ea = rok ? row_exponent(p.in_bits[b]) : 0;
+            img_of[sm] = b;
+            unsigned vm = 0;
+#pragma unroll
+            for (int sn = 0; sn < R::sn; ++sn) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int c = wn + 32 * sn + 8 * q + 4 * g;
+                    const int4 eb = *reinterpret_cast<const int4 *>(chan_e + c);
+                    const float4 bs = *reinterpret_cast<const float4 *>(chan_f + c);
+                    float4 v;
+                    v.x = conv_epi(__builtin_ldexpf(acc.v[sm][sn][4 * q + 0], -(ea + eb.x)) + bs.x, p.epilogue);
+                    v.y = conv_epi(__builtin_ldexpf(acc.v[sm][sn][4 * q + 1], -(ea + eb.y)) + bs.y, p.epilogue);
+                    v.z = conv_epi(__builtin_ldexpf(acc.v[sm][sn][4 * q + 2], -(ea + eb.z)) + bs.z, p.epilogue);
+                    v.w = conv_epi(__builtin_ldexpf(acc.v[sm][sn][4 * q + 3], -(ea + eb.w)) + bs.w, p.epilogue);
+                    if (rok) {                      // channels >= Cout carry zero weights and zero bias: 0 after ReLU, |0| otherwise
+                        vm = max(vm, max(max(__float_as_uint(v.x) & 0x7fffffffu, __float_as_uint(v.y) & 0x7fffffffu),
+                                         max(__float_as_uint(v.z) & 0x7fffffffu, __float_as_uint(v.w) & 0x7fffffffu)));
+                    }
+                    *reinterpret_cast<float4 *>(stg + j * 36 + 8 * q + 4 * g) = v;
+                }
+                // the patch leaves row-major: lane -> row 8 i + lane / 8, channels 4 (lane % 8) .. + 3: eight 128-byte lines per store
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int rr = 8 * i + (lane >> 3), c4 = 4 * (lane & 7);
+                    const long long orow = m0 + wm + 32 * sm + rr;
+                    const int col = n0 + wn + 32 * sn + c4;
+                    const float4 v = *reinterpret_cast<const float4 *>(stg + rr * 36 + c4);
+                    if (orow < Mtot && col < p.Cout) *reinterpret_cast<float4 *>(p.out + (size_t)orow * p.Cout + col) = v;
+                }
+                __builtin_amdgcn_sched_barrier(0);       // one accumulator at a time: keeps the epilogue inside the loop's register budget
+            }
+            vmax[sm] = vm;
+        }
+    } else {
+        // image output: a lane's four channels are 8 bytes of the cell's h1 half and 8 bytes of its h2 half; the wave assembles the
+        // 2 chunks x 32 pixels of a 32 x 32 accumulator in an LDS patch with an 80-byte cell pitch (ds_write_b64 two-way instead of
+        // eight-way conflicts) and copies the cells out as 1 KiB runs (the 64-byte cells of consecutive pixels are adjacent)
+        constexpr int kPitch = 80;
+        char *stg = lds + kRingStageOff + wave * (2 * 32 * kPitch);
+        const long long chunk0 = (n0 + wn) / kBK;
+#pragma unroll
+        for (int sm = 0; sm < R::sm; ++sm) {
+            const long long row = m0 + wm + 32 * sm + j;
+            const bool rok = row < Mtot;
+            const int b = rok ? (int)((unsigned)row / uHW) : 0;
+            const int ea = rok ? row_exponent(p.in_bits[b]) : 0;
+            const int eo = rok ? row_exponent(bound_bits(b)) : 0;
+            img_of[sm] = b;
+            unsigned vm = 0;
+#pragma unroll
+            for (int sn = 0; sn < R::sn; ++sn) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int c = wn + 32 * sn + 8 * q + 4 * g;
+                    const int4 eb = *reinterpret_cast<const int4 *>(chan_e + c);
+                    const float4 bs = *reinterpret_cast<const float4 *>(chan_f + c);
+                    float v0 = conv_epi(__builtin_ldexpf(acc.v[sm][sn][4 * q + 0], -(ea + eb.x)) + bs.x, p.epilogue);
+                    float v1 = conv_epi(__builtin_ldexpf(acc.v[sm][sn][4 * q + 1], -(ea + eb.y)) + bs.y, p.epilogue);
+                    float v2 = conv_epi(__builtin_ldexpf(acc.v[sm][sn][4 * q + 2], -(ea + eb.z)) + bs.z, p.epilogue);
+                    float v3 = conv_epi(__builtin_ldexpf(acc.v[sm][sn][4 * q + 3], -(ea + eb.w)) + bs.w, p.epilogue);
+                    if (!rok) v0 = v1 = v2 = v3 = 0.f;
+                    if (n0 + c + 0 >= p.Cout) v0 = 0.f;
+                    if (n0 + c + 1 >= p.Cout) v1 = 0.f;
+                    if (n0 + c + 2 >= p.Cout) v2 = 0.f;
+                    if (n0 + c + 3 >= p.Cout) v3 = 0.f;
+                    vm = max(vm, max(max(__float_as_uint(v0) & 0x7fffffffu, __float_as_uint(v1) & 0x7fffffffu),
+                                     max(__float_as_uint(v2) & 0x7fffffffu, __float_as_uint(v3) & 0x7fffffffu)));
+                    unsigned a1, a2, b1, b2;
+                    split2(v0, v1, eo, a1, a2);
+                    split2(v2, v3, eo, b1, b2);
+                    char *cell = stg + ((q >> 1) * 32 + j) * kPitch + 16 * (q & 1) + 8 * g;
+                    *reinterpret_cast<u32x2 *>(cell) = (u32x2){a1, b1};
+                    *reinterpret_cast<u32x2 *>(cell + 32) = (u32x2){a2, b2};
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {       // instruction i: chunk i / 2, pixels 16 (i % 2) .. + 15: one contiguous KiB
+                    const int cc = i >> 1, rr = 16 * (i & 1) + (lane >> 2), c16 = lane & 3;
+                    const long long orow = m0 + wm + 32 * sm + rr, chunk = chunk0 + 2 * sn + cc;
+                    const u32x4 cellv = *reinterpret_cast<const u32x4 *>(stg + (cc * 32 + rr) * kPitch + 16 * c16);
+                    if (orow < Mtot && chunk * kBK < p.Cout)
+                        *reinterpret_cast<u32x4 *>(p.out_cells + ((size_t)chunk * Mtot + orow) * kCell + 16 * c16) = cellv;
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            vmax[sm] = vm;
+        }
+    }
+    if (p.out_bits) {
+#pragma unroll
+        for (int sm = 0; sm < R::sm; ++sm) wave_atomic_max(p.out_bits, img_of[sm], vmax[sm]);
+    }
+}
+
 // C[rows][N] = epi(sum_z partial[z] + bias), and the per-image maxima of what is written (rows start at row0 of the layer)
 __global__ __launch_bounds__(256) void reduce_kernel(const float *__restrict__ partial, int nslices, long long rows, int N, float *__restrict__ C,
                                                      const float *__restrict__ bias, int epilogue, long long row0, long long HW,
@@ -560,7 +845,12 @@ __global__ __launch_bounds__(256) void image_absmax_kernel(const float *__restri
 typedef Shape<256, 128, 4, 2> S256x128;
 typedef Shape<128, 128, 2, 2> S128x128;
 typedef Shape<256, 64, 2, 2> S256x64;
+typedef Ring<4, 2, 2, 4, 4> CR256x256;     // shape 3: 8 waves, 64x128 wave tiles, 4 stages x 32 KB, one block per CU
+typedef Ring<4, 1, 2, 4, 3> CR256x128;     // shape 4: 4 waves, 3 stages x 24 KB, two blocks per CU
+typedef Ring<4, 1, 2, 2, 3> CR256x64;      // shape 5: 4 waves of 64x64 (Cout 64), 3 stages x 20 KB, two blocks per CU
+typedef Ring<2, 2, 2, 2, 4> CR128x128;     // shape 6: 4 waves of 64x64, 4 stages x 16 KB, two blocks per CU (small maps: more tiles)
 static int g_conv_shape = -1;       // mh_debug_plconv_shape
+static int g_conv_flags = 0;        // mh_debug_plconv_flags
 static int g_conv_splitk = 0;       // mh_debug_plconv_splitk: > 0 = every tile cut into that many K slices (measurement sweeps)
 
 static inline size_t act_cells_bytes(long long M, int C) { return (size_t)(C / kBK) * M * kCell; }
@@ -583,14 +873,22 @@ static Sched schedule(long long M, int Cin, int Cout)
     Sched s;
     // MH_PLCONV_SHAPE=0|1: block tile of the Cout >= 128 layers for A/B runs of the whole step (0 = 256x128, 1 = 128x128)
     static const int env_shape = [] { const char *e = getenv("MH_PLCONV_SHAPE"); return e ? atoi(e) : -1; }();
-    s.shape = (g_conv_shape >= 0) ? g_conv_shape : (Cout <= 64 ? 2 : (env_shape >= 0 ? env_shape : 1));
-    s.bm = (s.shape == 1) ? 128 : 256;
-    s.bn = (s.shape == 2) ? 64 : 128;
+    // round 4 (gpurun r04_c6, TFLOP/s fp32 / image output at b = 6): the ring kernel's 256x128 tiles (shape 4) beat the round-3
+    // loop on every layer with Cout >= 128 -- conv2_1 277 / 249 vs 237 / 216, conv2_2 358 / 340 vs 313 / 301, conv3_2 381 / 369 vs
+    // 331 / 324, conv4_2 393 / 378 vs 329 / 324, conv5_1 223 / 217 vs 211 / 210; Cout 64 (conv1_2: 36 k-tiles per tile, the
+    // block count per CU decides) stays on the round-3 256x64 loop, whole tiles (228 vs 203 with the tail cut into slices)
+    s.shape = (g_conv_shape >= 0) ? g_conv_shape : (Cout <= 64 ? 2 : (env_shape >= 0 ? env_shape : 4));
+    if (Cout <= 64 && s.shape != 2 && s.shape != 5) s.shape = (s.shape >= 3) ? 5 : 2;       // 64 output channels: the 64-wide tiles only
+    static const int bms[7] = {256, 128, 256, 256, 256, 256, 128}, bns[7] = {128, 128, 64, 256, 128, 64, 128};
+    s.bm = bms[s.shape];
+    s.bn = bns[s.shape];
+    set_resident_slots_override(s.shape == 3 ? 256 : 0);       // the 8-wave ring shape: one block per CU
     s.pl = plan_conv_tiles(M, Cin, Cout, s.bm, s.bn);
     const long long tiles = (long long)s.pl.tiles_m * s.pl.tiles_n;
     const int slots = resident_slots();
+    set_resident_slots_override(0);
     const long long rounds = tiles / slots;
-    const bool whole = (rounds == 0) ? tiles > slots / 4 : rounds > 3;
+    const bool whole = (rounds == 0) ? tiles > slots / 4 : (rounds > 3 || s.shape == 2);
     if (whole) { s.pl.splitk = 1; s.pl.body_mtiles = s.pl.tiles_m; s.pl.tail_slices = 1; }
     if (g_conv_splitk > 0) { s.pl.splitk = std::min(g_conv_splitk, 9 * (Cin / kBK)); s.pl.body_mtiles = s.pl.tiles_m; s.pl.tail_slices = 1; }
     return s;
@@ -614,6 +912,7 @@ extern "C" {
 
 void mh_debug_plconv_shape(int shape) { pl::g_conv_shape = shape; }
 void mh_debug_plconv_splitk(int splitk) { pl::g_conv_splitk = splitk; }
+void mh_debug_plconv_flags(int flags) { pl::g_conv_flags = flags; }
 
 size_t mh_act_planes_bytes(int B, int H, int W, int C)
 {
@@ -699,6 +998,7 @@ static int plconv_impl(const void *in_image, const unsigned *in_true_maxbits, in
     p.wt_bits = reinterpret_cast<const unsigned *>(p.wt + align_up(pl::wt_cells_bytes(Cout, Cin), 256));
     p.wnorm = reinterpret_cast<const float *>(reinterpret_cast<const char *>(p.wt_bits) + align_up((size_t)Cout * 4, 256));
     p.Cout = Cout; p.bias = bias; p.epilogue = epilogue; p.out = out; p.out_bits = out_maxbits;
+    p.debug_flags = pl::g_conv_flags;
     p.out_cells = reinterpret_cast<char *>(out_image);
     p.out_scale_bits = out_image ? reinterpret_cast<unsigned *>(p.out_cells + align_up(pl::act_cells_bytes(M, Cout), 256)) : nullptr;
     pl::Sched sc = pl::schedule(M, Cin, Cout);
@@ -711,10 +1011,11 @@ static int plconv_impl(const void *in_image, const unsigned *in_true_maxbits, in
     const int total_kt = 9 * (Cin / pl::kBK);
     p.tiles_m = sc.pl.tiles_m; p.tiles_n = sc.pl.tiles_n;
     p.body_tiles = sc.pl.body_mtiles * sc.pl.tiles_n;
-    p.ktiles_per_split = ceil_div(total_kt, sc.pl.splitk);
+    const int kgran = (sc.shape >= 3) ? 9 : 1;          // ring shapes: K slices of whole 16-channel chunks (9 k-tiles)
+    p.ktiles_per_split = ceil_div(ceil_div(total_kt, sc.pl.splitk), kgran) * kgran;
     p.splitk = ceil_div(total_kt, p.ktiles_per_split);
     p.tail_tiles = (sc.pl.tiles_m - sc.pl.body_mtiles) * sc.pl.tiles_n;
-    p.tail_ktiles = ceil_div(total_kt, sc.pl.tail_slices);
+    p.tail_ktiles = ceil_div(ceil_div(total_kt, sc.pl.tail_slices), kgran) * kgran;
     p.tail_slices = ceil_div(total_kt, p.tail_ktiles);
     p.tail_row0 = std::min<long long>(M, (long long)sc.pl.body_mtiles * sc.bm);
     p.partial = reinterpret_cast<float *>(workspace);
@@ -726,6 +1027,16 @@ static int plconv_impl(const void *in_image, const unsigned *in_true_maxbits, in
     constexpr size_t kTabMax = 1024 * 16;                          // the per-k-tile offset table lives in LDS (16 B per k-tile)
     MH_REQUIRE(total_kt <= 1024);
     const size_t tab_bytes = (size_t)total_kt * 16;
+    auto ring = [&](auto tag) {
+        typedef decltype(tag) R;
+        if (out_image) pl::launch<pl::conv3x3_ring_kernel<R, true>>(grid, pl::ring_conv_lds_bytes<R>(true), st, p, 0, R::threads);
+        else pl::launch<pl::conv3x3_ring_kernel<R, false>>(grid, pl::ring_conv_lds_bytes<R>(false), st, p, 0, R::threads);
+    };
+    if (sc.shape == 3) ring(pl::CR256x256());
+    else if (sc.shape == 4) ring(pl::CR256x128());
+    else if (sc.shape == 5) ring(pl::CR256x64());
+    else if (sc.shape == 6) ring(pl::CR128x128());
+    else
     if (out_image) {
         if (sc.shape == 0) pl::launch<pl::conv3x3_kernel<pl::S256x128, true>>(grid, pl::conv_lds_bytes<pl::S256x128>() + tab_bytes, st, p, pl::conv_lds_bytes<pl::S256x128>() + kTabMax);
         else if (sc.shape == 1) pl::launch<pl::conv3x3_kernel<pl::S128x128, true>>(grid, pl::conv_lds_bytes<pl::S128x128>() + tab_bytes, st, p, pl::conv_lds_bytes<pl::S128x128>() + kTabMax);

@@ -301,7 +301,7 @@ __global__ __launch_bounds__(R::threads, (R::threads == 512 || R::sm * R::sn <= 
     plan_dma<R>(dp, [&](int r) { return m0 + r < p.M; }, [&](int r) { return n0 + r < p.N; }, wave, lane);
     FragPlan fp;
     rplan_frags<R>(fp, wm0, wn0, lane);
-    auto issue = [&](int kt, char *stage) {
+    auto issue = [&](int kt, int, char *stage) {
         const bool live = kt < kt_end;                        // padding steps: A out of range (zeros), B = the last tile again
         const int ktc = live ? kt : kt_end - 1;
         unsigned va[R::na];
@@ -313,40 +313,66 @@ __global__ __launch_bounds__(R::threads, (R::threads == 512 || R::sm * R::sn <= 
     racc_zero<R>(acc);
     ring_loop<R>(issue, kt_begin, kt_end, lds, fp, acc);
 
-    // the ring is free after the loop's last barrier: this tile's row / column exponents go there
-    int *ex = reinterpret_cast<int *>(lds);
+    // The ring is free after the loop's last barrier.  Epilogue (see pl_ring.h: rmma): the accumulators are TRANSPOSED -- a lane
+    // holds four consecutive columns of one row per register quad -- so every 32 x 32 accumulator is scaled, staged in a
+    // wave-private LDS patch with ds_write_b128 and leaves as 16-byte stores that cover whole 128-byte lines of C.
+    int *ex = reinterpret_cast<int *>(lds);                       // row exponents [bm], column exponents [bn]
+    float *bs = reinterpret_cast<float *>(lds) + R::bm + R::bn;   // bias [bn]
     for (int i = tid; i < R::bm + R::bn; i += R::threads) {
         const bool is_a = i < R::bm;
         const int idx = is_a ? m0 + i : n0 + (i - R::bm);
         const bool ok = is_a ? idx < p.M : idx < p.N;
         ex[i] = ok ? row_exponent(is_a ? p.mbA[idx] : p.mbB[idx]) : 0;
+        if (!is_a) bs[i - R::bm] = (ok && p.bias && p.splitk == 1) ? p.bias[idx] : 0.f;
     }
     __syncthreads();
-    int ecol[R::sn];
-    float bcol[R::sn];
+    static_assert((R::bm + 2 * R::bn) * 4 <= 8192, "tables in front of the staging patches");
+    const int j = lane & 31, g = lane >> 5;
+    float *stg = reinterpret_cast<float *>(lds + 8192) + wave * (32 * 36);
+    float *dst = (p.splitk > 1) ? p.partial + (size_t)z * p.M * p.N : p.C;
+    const size_t ldd = (p.splitk > 1) ? (size_t)p.N : (size_t)p.ldc;
+    const bool vec_ok = (ldd % 4 == 0) && ((reinterpret_cast<uintptr_t>(dst) & 15) == 0);
 #pragma unroll
-    for (int sn = 0; sn < R::sn; ++sn) {
-        const int c = wn0 + 32 * sn + (lane & 31);
-        ecol[sn] = ex[R::bm + c];
-        bcol[sn] = (p.bias && p.splitk == 1 && n0 + c < p.N) ? p.bias[n0 + c] : 0.f;
+    for (int sm = 0; sm < R::sm; ++sm) {
+        const int ea = ex[wm0 + 32 * sm + j];
+#pragma unroll
+        for (int sn = 0; sn < R::sn; ++sn) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int c = wn0 + 32 * sn + 8 * q + 4 * g;
+                const int4 eb = *reinterpret_cast<const int4 *>(ex + R::bm + c);
+                const float4 bb = *reinterpret_cast<const float4 *>(bs + c);
+                float4 v;
+                v.x = __builtin_ldexpf(acc.v[sm][sn][4 * q + 0], -(ea + eb.x)) + bb.x;
+                v.y = __builtin_ldexpf(acc.v[sm][sn][4 * q + 1], -(ea + eb.y)) + bb.y;
+                v.z = __builtin_ldexpf(acc.v[sm][sn][4 * q + 2], -(ea + eb.z)) + bb.z;
+                v.w = __builtin_ldexpf(acc.v[sm][sn][4 * q + 3], -(ea + eb.w)) + bb.w;
+                if (p.splitk == 1) { v.x = epi(v.x, p.epilogue); v.y = epi(v.y, p.epilogue); v.z = epi(v.z, p.epilogue); v.w = epi(v.w, p.epilogue); }
+                *reinterpret_cast<float4 *>(stg + j * 36 + 8 * q + 4 * g) = v;
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int rr = 8 * i + (lane >> 3), c4 = 4 * (lane & 7);
+                const int row = m0 + wm0 + 32 * sm + rr, col = n0 + wn0 + 32 * sn + c4;
+                float4 v = *reinterpret_cast<const float4 *>(stg + rr * 36 + c4);
+                if (row >= p.M || col >= p.N) continue;
+                float *q = dst + (size_t)row * ldd + col;
+                if (vec_ok && col + 3 < p.N) {
+                    if (p.accumulate && p.splitk == 1) { const float4 o = *reinterpret_cast<const float4 *>(q); v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
+                    *reinterpret_cast<float4 *>(q) = v;
+                } else {
+                    const float vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        if (col + k < p.N) q[k] = (p.accumulate && p.splitk == 1) ? q[k] + vv[k] : vv[k];
+                }
+            }
+        }
     }
-    if (p.splitk > 1) {
-        float *dst = p.partial + (size_t)z * p.M * p.N;
-        racc_foreach<R>(acc, wm0, wn0, lane, [&](int r, int c, int sn, float v) {
-            const int row = m0 + r, col = n0 + c;
-            if (row < p.M && col < p.N) dst[(size_t)row * p.N + col] = __builtin_ldexpf(v, -(ex[r] + ecol[sn]));
-        });
-        return;
-    }
-    racc_foreach<R>(acc, wm0, wn0, lane, [&](int r, int c, int sn, float v) {
-        const int row = m0 + r, col = n0 + c;
-        if (row >= p.M || col >= p.N) return;
-        v = epi(__builtin_ldexpf(v, -(ex[r] + ecol[sn])) + bcol[sn], p.epilogue);
-        float *q = p.C + (size_t)row * p.ldc + col;
-        if (p.accumulate) v += *q;
-        *q = v;
-    });
 }
+
+template <class R>
+constexpr size_t ring_gemm_lds() { return (size_t)(R::lds_bytes > 8192 + R::waves * 32 * 36 * 4 ? R::lds_bytes : 8192 + R::waves * 32 * 36 * 4); }
 
 typedef Ring<4, 2, 2, 4, 4> R256x256;        // 8 waves, 64x128 wave tiles, 4 stages x 32 KB: one block per CU
 typedef Ring<4, 1, 2, 4, 3> R256x128;        // 4 waves, 3 stages x 24 KB: two blocks per CU
@@ -370,14 +396,18 @@ static Plan plan_gemm(int M, int N, int K, int want_splitk)
     // fp32-equivalent FLOP/s one CU sustains with a full complement of blocks of the shape (measured: DESIGN.md 5)
     static const double rate[6] = {365e12 / 256, 370e12 / 256, 300e12 / 256, 450e12 / 256, 430e12 / 256, 450e12 / 256};
     static const int per_cu[6] = {2, 2, 2, 1, 2, 1};          // resident blocks per CU the makespan model assumes
-    (void)per_cu;
     const int ktiles = ceil_div(K, kBK);
     Plan best = {1, 128, 128, 1};
     double best_cost = 1e30;
     for (int s = 0; s < 6; ++s) {
         if (g_force_shape >= 0 && s != g_force_shape) continue;
         if (g_force_shape < 0) {
-            if (s >= 3) continue;                 // ring shapes: selected explicitly until measured (mh_debug_pl_shape / MH_PL_RING)
+            // ring shapes (gpurun r04_c6, TFLOP/s on ready images, ring vs the round-3 loop: 4096^3 436 vs 389, fc6 forward 389 vs
+            // 373, fc6 input gradient 386 vs 353, fc6 weight gradient 381 vs 333, fc7 forward 337 vs 302): 256x256 on eight waves
+            // for wide products, 256x128 two per CU otherwise; the 4-wave 128x128-wave-tile variant never won
+            if (s == 5) continue;
+            if (s == 3 && (N <= 128 || M <= 128)) continue;
+            if (s == 4 && (N <= 64 || M <= 128)) continue;
             if (s == 2 && N > 64) continue;
             if (s != 2 && N <= 64) continue;
             if (s == 0 && M <= 128) continue;
@@ -385,17 +415,19 @@ static Plan plan_gemm(int M, int N, int K, int want_splitk)
         const long long tiles = (long long)ceil_div(M, bms[s]) * ceil_div(N, bns[s]);
         const double t1 = 2.0 * bms[s] * bns[s] * (double)K / rate[s];      // one tile on a fully occupied CU
         static const int cand[] = {1, 2, 3, 4, 5, 6, 7, 8, 10, 12, 14, 16, 20, 24, 28, 32, 40, 48, 56, 64};
+        set_resident_slots_override(256 * per_cu[s]);
         auto consider = [&](int sk) {
             const double t_partial = (sk > 1) ? ((double)M * N * 8.0 * sk) / 4.0e12 + 4e-6 : 0.0;
             const double cost = makespan_units(tiles * sk) * t1 / sk + t_partial;
             if (cost < best_cost * 0.97) { best_cost = cost; best = {s, bms[s], bns[s], sk}; }
         };
-        if (want_splitk > 0) { consider(std::max(1, std::min(std::min(want_splitk, 64), ktiles))); continue; }
+        if (want_splitk > 0) { consider(std::max(1, std::min(std::min(want_splitk, 64), ktiles))); set_resident_slots_override(0); continue; }
         for (int sk : cand) {
             if (sk > 1 && ktiles / sk < 8) break;
             consider(sk);
         }
     }
+    set_resident_slots_override(0);
     return best;
 }
 
@@ -417,9 +449,9 @@ static int launch_gemm(const GemmArgs &p0, const Plan &pl, hipStream_t st)
     p.patch_h = std::max(ph, 1);
     p.patch_w = std::max(pw, 1);
     const dim3 grid((unsigned)(p.tiles_m * p.tiles_n), (unsigned)p.splitk);
-    if (pl.shape == 3) launch<gemm_ring_kernel<R256x256>>(grid, R256x256::lds_bytes, st, p, 0, R256x256::threads);
-    else if (pl.shape == 4) launch<gemm_ring_kernel<R256x128>>(grid, R256x128::lds_bytes, st, p, 0, R256x128::threads);
-    else if (pl.shape == 5) launch<gemm_ring_kernel<R256x256w4>>(grid, R256x256w4::lds_bytes, st, p, 0, R256x256w4::threads);
+    if (pl.shape == 3) launch<gemm_ring_kernel<R256x256>>(grid, ring_gemm_lds<R256x256>(), st, p, 0, R256x256::threads);
+    else if (pl.shape == 4) launch<gemm_ring_kernel<R256x128>>(grid, ring_gemm_lds<R256x128>(), st, p, 0, R256x128::threads);
+    else if (pl.shape == 5) launch<gemm_ring_kernel<R256x256w4>>(grid, ring_gemm_lds<R256x256w4>(), st, p, 0, R256x256w4::threads);
     else if (pl.shape == 0) launch<gemm_kernel<S256x128>>(grid, S256x128::lds_bytes, st, p);
     else if (pl.shape == 1) launch<gemm_kernel<S128x128>>(grid, S128x128::lds_bytes, st, p);
     else launch<gemm_kernel<S256x64>>(grid, S256x64::lds_bytes, st, p);

@@ -122,7 +122,12 @@ __device__ __forceinline__ void rfetch(RFrags<R> &f, const FragPlan &fp, const c
 #pragma unroll
     for (int s = 0; s < R::sm; ++s) f.a[s][0] = *reinterpret_cast<const f16x8 *>(stage + fp.a[0] + 2048 * s);
 }
-// three terms per accumulator, smallest first (h2a h1b, h1a h2b, h1a h1b); consecutive MFMAs are independent
+// three terms per accumulator, smallest first (h2a h1b, h1a h2b, h1a h1b); consecutive MFMAs are independent.
+// OPERAND ROLES ARE SWAPPED: the B fragment (columns of the product: output channels / N) is the matrix core's A operand and
+// the A fragment (rows: pixels / M) its B operand, so the 32x32 result arrives TRANSPOSED: lane (j, g) register r holds
+//     C[row = 32 sm + j][col = 32 sn + (r & 3) + 8 (r >> 2) + 4 g]
+// i.e. every group of four registers is four CONSECUTIVE columns of one row -- 16 contiguous bytes of a row-major C (or of
+// an NHWC pixel): what the epilogues' 16-byte stores want (racc_quads).
 template <class R>
 __device__ __forceinline__ void rmma(const RFrags<R> &f, RAcc<R> &acc)
 {
@@ -133,7 +138,7 @@ __device__ __forceinline__ void rmma(const RFrags<R> &f, RAcc<R> &acc)
         for (int sm = 0; sm < R::sm; ++sm)
 #pragma unroll
             for (int sn = 0; sn < R::sn; ++sn)
-                acc.v[sm][sn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.a[sm][kTermA[t]], f.b[sn][kTermB[t]], acc.v[sm][sn], 0, 0, 0);
+                acc.v[sm][sn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.b[sn][kTermB[t]], f.a[sm][kTermA[t]], acc.v[sm][sn], 0, 0, 0);
 }
 
 template <int N>
@@ -174,44 +179,52 @@ __device__ __forceinline__ void rwave_origin(int wave, int &wm0, int &wn0)
     wn0 = (wave % R::wn) * 32 * R::sn;
 }
 
+// visitor over the (transposed) accumulators: f(row, col0, sn, v0, v1, v2, v3) for every quad of four consecutive columns this
+// lane holds (row / col0 relative to the block tile; col0 is a multiple of 4)
 template <class R, typename F>
-__device__ __forceinline__ void racc_foreach(const RAcc<R> &acc, int wm0, int wn0, int lane, F f)
+__device__ __forceinline__ void racc_quads(const RAcc<R> &acc, int wm0, int wn0, int lane, F f)
 {
     const int j = lane & 31, g = lane >> 5;
 #pragma unroll
     for (int sm = 0; sm < R::sm; ++sm)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = wm0 + 32 * sm + (r & 3) + 8 * (r >> 2) + 4 * g;
+        for (int sn = 0; sn < R::sn; ++sn)
 #pragma unroll
-            for (int sn = 0; sn < R::sn; ++sn) f(row, wn0 + 32 * sn + j, sn, acc.v[sm][sn][r]);
-        }
+            for (int q = 0; q < 4; ++q)
+                f(wm0 + 32 * sm + j, wn0 + 32 * sn + 8 * q + 4 * g, sn, acc.v[sm][sn][4 * q], acc.v[sm][sn][4 * q + 1], acc.v[sm][sn][4 * q + 2],
+                  acc.v[sm][sn][4 * q + 3]);
 }
 
-// The whole K loop over tiles [kt_begin, kt_end): `issue(kt, stage_ptr)` must launch the R::nd DMA pieces of tile kt (for
-// kt >= kt_end: A pieces out of range -> zeros, B pieces any valid tile) into stage_ptr.  Ends with every wave past its last
-// fragment read (a trailing barrier makes the ring reusable as epilogue scratch).
-template <class R, typename Issue>
+// The whole K loop over tiles [kt_begin, kt_end): `issue(kt, ui, stage_ptr)` must launch the R::nd DMA pieces of tile kt (for
+// kt >= kt_end: A pieces out of range -> zeros, B pieces any valid tile) into stage_ptr.  Tiles are issued strictly in order;
+// `ui` is the tile's index relative to the start of the current unrolled body (kt - kt_begin modulo U for the first NS - 1
+// tiles, then u + NS - 1): a COMPILE-TIME constant after unrolling, which the conv uses to know a tile's tap without any
+// table (U a multiple of 9 there).  GRAN > 0: leave the unrolled body after any whole group of GRAN steps once the range is
+// exhausted (bounds the padding of a short K range to GRAN - 1 steps instead of U - 1).
+// Ends with every wave past its last fragment read and a barrier: the ring is reusable as epilogue scratch.
+template <class R, int U = R::unroll, int GRAN = 0, typename Issue>
 __device__ __forceinline__ void ring_loop(Issue issue, int kt_begin, int kt_end, char *lds, const FragPlan &fp, RAcc<R> &acc)
 {
     constexpr int NS = R::NS;
+    static_assert(U % R::unroll == 0, "the unrolled body must cover whole cycles of stages and fragment sets");
+    static_assert(GRAN == 0 || (U % GRAN == 0 && GRAN >= NS), "exit granule");
     // prologue: tiles kt_begin .. kt_begin + NS - 2 into stages 0 .. NS - 2
 #pragma unroll
-    for (int s = 0; s < NS - 1; ++s) issue(kt_begin + s, lds + s * R::stage_bytes);
+    for (int s = 0; s < NS - 1; ++s) issue(kt_begin + s, s, lds + s * R::stage_bytes);
     wait_vmcnt<R::nd * (NS - 2)>();                      // my pieces of tile kt_begin
     __builtin_amdgcn_s_barrier();
     RFrags<R> f0, f1;
     rfetch<R>(f0, fp, lds);
-    int kt = kt_begin;
-    for (; kt < kt_end; kt += R::unroll) {
+    for (int kt = kt_begin; kt < kt_end; kt += U) {
 #pragma unroll
-        for (int u = 0; u < R::unroll; ++u) {
+        for (int u = 0; u < U; ++u) {
+            if (GRAN > 0 && u > 0 && u % GRAN == 0 && kt + u >= kt_end) break;       // wave-uniform
             // step kt + u: consume set u % 2, read tile kt + u + 1 from stage (u + 1) % NS, DMA tile kt + u + NS - 1 into stage (u + NS - 1) % NS
             char *dst = lds + ((u + NS - 1) % NS) * R::stage_bytes;
             const char *rd = lds + ((u + 1) % NS) * R::stage_bytes;
             const int ktn = kt + u + NS - 1;
-            if (u % 2 == 0) ring_step<R>([&](char *st) { issue(ktn, st); }, dst, rd, fp, f0, f1, acc);
-            else ring_step<R>([&](char *st) { issue(ktn, st); }, dst, rd, fp, f1, f0, acc);
+            if (u % 2 == 0) ring_step<R>([&](char *st) { issue(ktn, u + NS - 1, st); }, dst, rd, fp, f0, f1, acc);
+            else ring_step<R>([&](char *st) { issue(ktn, u + NS - 1, st); }, dst, rd, fp, f1, f0, acc);
         }
     }
     wait_vmcnt<0>();

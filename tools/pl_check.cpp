@@ -278,7 +278,7 @@ static plpack_fn plpack;
 static plconv_fn plconv;
 static v2pack_fn v2pack;
 static v2conv_fn v2conv;
-static shape_fn set_conv_shape, set_conv_splitk;
+static shape_fn set_conv_shape, set_conv_splitk, set_conv_flags;
 
 static unsigned fbits(float v) { unsigned u; memcpy(&u, &v, 4); return u & 0x7fffffffu; }
 
@@ -331,7 +331,7 @@ static int conv_case(const char *name, int B, int H, int W, int Cin, int Cout, i
         HIP_OK(hipMemcpy(Rf.data(), dref.p, Rf.size() * 4, hipMemcpyDeviceToHost));
     }
     int bad = 0;
-    for (int shape = -1; shape <= 2; ++shape) {
+    for (int shape = -1; shape <= 6; ++shape) {
         set_conv_shape(shape);
         Dev ws3(plconv_ws(B, H, W, Cin, Cout));
         HIP_OK(hipMemset(dmbo.p, 0, B * 4));
@@ -419,7 +419,7 @@ static int chain_case(const char *name, int B, int H, int W, int C0, int C1, int
     const void *in2 = img0.p;
     if (with_stem) { rc |= stem_img(dx.f(), B, 3, H, W, dws.f(), C0, dbs.f(), 1, jmg0.p, n0_, nullptr); in2 = jmg0.p; }
     int bad = 0;
-    for (int shape = -1; shape <= 2; ++shape) {
+    for (int shape = -1; shape <= 6; ++shape) {
         set_conv_shape(shape);
         HIP_OK(hipMemset(n1, 0, B * 4)); HIP_OK(hipMemset(n2, 0, B * 4));
         Dev wsa2(plconv_ws(B, H, W, C0, C1)), wsb2(plconv_ws(B, H, W, C1, C2));
@@ -447,6 +447,7 @@ static int chain_case(const char *name, int B, int H, int W, int C0, int C1, int
     return bad;
 }
 
+static bool g_sweep_quick = false;
 // shape x split-K sweep of one layer (the planner's choice is the row with splitk 0)
 static void conv_sweep(const char *name, int B, int H, int W, int Cin, int Cout, int iters)
 {
@@ -459,9 +460,11 @@ static void conv_sweep(const char *name, int B, int H, int W, int Cin, int Cout,
     Dev img(act_bytes(B, H, W, Cin)), pk(plpacked_bytes(Cout, Cin)), oimg(act_bytes(B, H, W, Cout));
     plpack(dw.f(), Cout, Cin, 0, pk.p, nullptr);
     act_planes(dx.f(), (const unsigned *)dmb.p, B, H, W, Cin, 0, img.p, nullptr);
-    for (int shape = 0; shape <= 2; ++shape) {
-        if (shape == 2 && Cout > 64) continue;
+    for (int shape = 0; shape <= 6; ++shape) {
+        if ((shape == 2 || shape == 5) && Cout > 64) continue;
+        if (Cout <= 64 && shape != 2 && shape != 5) continue;
         for (int sk : {0, 1, 2, 3, 4, 6}) {
+            if (g_sweep_quick && sk != 0 && sk != 1 && !(H <= 74 && (sk == 2 || sk == 3 || sk == 4))) continue;
             set_conv_shape(shape); set_conv_splitk(sk);
             Dev ws3(plconv_ws(B, H, W, Cin, Cout));
             const float ms = time_ms(iters, [&] { plconv(img.p, B, H, W, Cin, pk.p, Cout, db.f(), 1, dout.f(), (unsigned *)dmbo.p, ws3.p, ws3.n, nullptr); });
@@ -552,6 +555,7 @@ int main(int argc, char **argv)
     plconv = (plconv_fn)dlsym(h, "mh_plconv3x3"); v2pack = (v2pack_fn)dlsym(h, "mh_conv3x3_pack_weight"); v2conv = (v2conv_fn)dlsym(h, "mh_conv3x3_nhwc");
     set_conv_shape = (shape_fn)dlsym(h, "mh_debug_plconv_shape");
     set_conv_splitk = (shape_fn)dlsym(h, "mh_debug_plconv_splitk");
+    set_conv_flags = (shape_fn)dlsym(h, "mh_debug_plconv_flags");
     plconv_img = (plconv_img_fn)dlsym(h, "mh_plconv3x3_to_image"); stem_img = (stem_img_fn)dlsym(h, "mh_stem_to_image"); stem_max = (stem_max_fn)dlsym(h, "mh_conv_first_nchw_max");
     if (!act_bytes || !plpacked_bytes || !v2packed_floats || !plconv_ws || !v2conv_ws || !act_planes || !plpack || !plconv || !v2pack || !v2conv || !set_conv_shape || !plconv_img || !stem_img || !stem_max) { printf("missing conv symbol\n"); return 2; }
     if (argc > 2 && !strcmp(argv[2], "--conv-replay")) {
@@ -581,10 +585,28 @@ int main(int argc, char **argv)
         }
         return 0;
     }
+    if (argc > 2 && !strcmp(argv[2], "--conv-noepi")) {
+        // what the K loop alone costs: debug flag 2 = the ring kernel returns without its epilogue (no output)
+        for (int fl : {0, 2}) {
+            set_conv_flags(fl);
+            printf("{\"debug_flags\": %d}\n", fl);
+            g_sweep_quick = true;
+            conv_sweep("conv1_2", 6, 592, 592, 64, 64, 5);
+            conv_sweep("conv2_1", 6, 296, 296, 64, 128, 5);
+            conv_sweep("conv2_2", 6, 296, 296, 128, 128, 5);
+            conv_sweep("conv3_2", 6, 148, 148, 256, 256, 5);
+        }
+        set_conv_flags(0);
+        return 0;
+    }
     if (argc > 2 && !strcmp(argv[2], "--conv-sweep")) {
+        g_sweep_quick = argc > 3 && !strcmp(argv[3], "--quick");
         conv_sweep("conv1_2", 6, 592, 592, 64, 64, 5);
         conv_sweep("conv2_1", 6, 296, 296, 64, 128, 5);
+        conv_sweep("conv2_2", 6, 296, 296, 128, 128, 5);
         conv_sweep("conv3_1", 6, 148, 148, 128, 256, 5);
+        conv_sweep("conv3_2", 6, 148, 148, 256, 256, 5);
+        conv_sweep("conv4_1", 6, 74, 74, 256, 512, 5);
         conv_sweep("conv4_2", 6, 74, 74, 512, 512, 5);
         conv_sweep("conv5_1", 6, 37, 37, 512, 512, 10);
         return 0;
