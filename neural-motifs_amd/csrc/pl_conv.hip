@@ -877,7 +877,8 @@ static Sched schedule(long long M, int Cin, int Cout)
     // loop on every layer with Cout >= 128 -- conv2_1 277 / 249 vs 237 / 216, conv2_2 358 / 340 vs 313 / 301, conv3_2 381 / 369 vs
     // 331 / 324, conv4_2 393 / 378 vs 329 / 324, conv5_1 223 / 217 vs 211 / 210; Cout 64 (conv1_2: 36 k-tiles per tile, the
     // block count per CU decides) stays on the round-3 256x64 loop, whole tiles (228 vs 203 with the tail cut into slices)
-    s.shape = (g_conv_shape >= 0) ? g_conv_shape : (Cout <= 64 ? 2 : (env_shape >= 0 ? env_shape : 4));
+    static const bool ring_off = [] { const char *e = getenv("MH_PL_RING"); return e && e[0] == '0'; }();      // A/B: MH_PL_RING=0 = round-3 loop
+    s.shape = (g_conv_shape >= 0) ? g_conv_shape : (Cout <= 64 ? 2 : (env_shape >= 0 ? env_shape : (ring_off ? 1 : 4)));
     if (Cout <= 64 && s.shape != 2 && s.shape != 5) s.shape = (s.shape >= 3) ? 5 : 2;       // 64 output channels: the 64-wide tiles only
     static const int bms[7] = {256, 128, 256, 256, 256, 256, 128}, bns[7] = {128, 128, 64, 256, 128, 64, 128};
     s.bm = bms[s.shape];

@@ -405,7 +405,8 @@ static Plan plan_gemm(int M, int N, int K, int want_splitk)
             // ring shapes (gpurun r04_c6, TFLOP/s on ready images, ring vs the round-3 loop: 4096^3 436 vs 389, fc6 forward 389 vs
             // 373, fc6 input gradient 386 vs 353, fc6 weight gradient 381 vs 333, fc7 forward 337 vs 302): 256x256 on eight waves
             // for wide products, 256x128 two per CU otherwise; the 4-wave 128x128-wave-tile variant never won
-            if (s == 5) continue;
+            static const bool ring_off = [] { const char *e = getenv("MH_PL_RING"); return e && e[0] == '0'; }();      // A/B: MH_PL_RING=0
+            if (s == 5 || (ring_off && s >= 3)) continue;
             if (s == 3 && (N <= 128 || M <= 128)) continue;
             if (s == 4 && (N <= 64 || M <= 128)) continue;
             if (s == 2 && N > 64) continue;

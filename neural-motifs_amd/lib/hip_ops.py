@@ -203,7 +203,10 @@ class ReLU(nn.Module):
     parent container runs the stack, plain clamp otherwise."""
 
     def forward(self, x):
-        return torch.clamp_min(x, 0.0)
+        # torch.relu, not clamp_min: its backward passes the gradient where the OUTPUT is > 0 (nn.ReLU / threshold_backward, what the
+        # reference runs); clamp_min passes it where the input is >= 0 -- a pre-activation that is exactly 0.0 then trains
+        # differently (found by the kink accounting of tests/test_gpu_sgdet.py: one such unit in 16384)
+        return torch.relu(x)
 
 
 class Dropout(nn.Module):

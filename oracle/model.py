@@ -195,12 +195,13 @@ def resnet_l4_head(sd, x, prefix, training, relu_end=False):
     for b in range(3):
         p = '%s%d.' % (prefix, b)
         last = (b == 2) and not relu_end
-        out = F.relu(_bn(sd, F.conv2d(x, sd[p + 'conv1.weight']), p + 'bn1.', training, m))
-        out = F.relu(_bn(sd, F.conv2d(out, sd[p + 'conv2.weight'], None, stride=1, padding=1), p + 'bn2.', training, m))
+        # ReLU sites are named after the BatchNorm in front of them (`<prefix><block>.bn1` ...): forceable through TAPS
+        out = _relu(_bn(sd, F.conv2d(x, sd[p + 'conv1.weight']), p + 'bn1.', training, m), p + 'bn1')
+        out = _relu(_bn(sd, F.conv2d(out, sd[p + 'conv2.weight'], None, stride=1, padding=1), p + 'bn2.', training, m), p + 'bn2')
         out = _bn(sd, F.conv2d(out, sd[p + 'conv3.weight']), p + 'bn3.', training, m)
         if p + 'downsample.0.weight' in sd:
             x = _bn(sd, F.conv2d(x, sd[p + 'downsample.0.weight']), p + 'downsample.1.', training, m)
-        x = out + x if last else F.relu(out + x)
+        x = out + x if last else _relu(out + x, p + 'bn3')
     return x.mean((2, 3))
 
 

@@ -256,3 +256,103 @@ def test_cfg4_resnet_relation_head_train_step():
                       ('post_lstm.weight', 2e-3), ('roi_fmap.0.0.conv1.weight', 3e-2), ('roi_fmap_obj.0.0.conv2.weight', 3e-2),
                       ('roi_fmap.0.0.downsample.1.bias', 3e-2)):
         report('cfg4 grad ' + name, params[name].grad.cpu().numpy(), osd[name].grad.numpy(), rel_tol=tol)
+
+
+def test_cfg4_resnet_sgcls_train_step_b6_1536_rows():
+    """BASELINE configs[3] AT ITS STATED SIZE: SGCls train step of the ResNet-101 MotifNet, b = 6, 592x592, 20 GT boxes and 30
+    GT relations per image -> 1536 relation rows through the relation head's layer4 stack (1.46 GFLOP per row), H = 512 --
+    RelModel(use_resnet=True) with the documented repair (resnet_obj_fmap='layer4'; the reference never builds roi_fmap_obj
+    for this configuration, lib/rel_model.py:360-365 vs :448).  The REAL random-weight conv1..layer3 trunk runs (train-mode
+    BatchNorm like the reference, models/train_rels.py:101); the oracle gets the product's detector stage through
+    `det_override` as the cfg3 test does (the trunk has its own parity test), so everything from RoIAlign on -- both layer4
+    stacks with batch statistics over 1536 x 7 x 7 positions, union tower, context LSTMs, decoder, relation tail -- is
+    compared: logits, loss, EVERY trainable gradient at 1e-4 of its own maximum with the product's ReLU decisions forced
+    (layer4's sixteen ReLU sites included), and the BatchNorm running statistics after the step (momentum 0.01:
+    lib/resnet.py:14-19)."""
+    from dataloaders.synthetic import SyntheticVG, make_blob
+    from lib import rng
+    from lib.rel_model import RelModel
+    from oracle import model as OM
+    from parity_util import ProductMasks, assert_genuine_kinks, grad_close, oracle_forced, rel_close
+    seed = 1234 + 400
+    torch.manual_seed(seed)
+    np.random.seed(seed)
+    ds = SyntheticVG(num_images=6, seed=seed, n_boxes=20, n_rels=30)
+    cfg = dict(MODEL_KW, pooling_dim=2048, mode='sgcls')
+    model = RelModel(classes=ds.ind_to_classes, rel_classes=ds.ind_to_predicates, num_gpus=1, use_resnet=True,
+                     resnet_obj_fmap='layer4', **cfg)
+    for _, p in model.detector.named_parameters():
+        p.requires_grad = False
+    with torch.no_grad():
+        model.post_lstm.weight.mul_(CAL)
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    model.cuda().train()
+    for m in model.detector.modules():                      # the frozen detector's RoI head: AlphaDropout off on both sides
+        if isinstance(m, torch.nn.AlphaDropout):
+            m.eval()
+    sites = {}
+    for stack in ('roi_fmap', 'roi_fmap_obj'):
+        l4 = getattr(model, stack)[0]
+        for b in range(3):
+            sites['%s.0.%d.bn1' % (stack, b)] = l4[b].bn1
+            sites['%s.0.%d.bn2' % (stack, b)] = l4[b].bn2
+            if b < 2:
+                sites['%s.0.%d.bn3' % (stack, b)] = l4[b].bn3          # the last block ends without ReLU (relu_end=False)
+    blob = make_blob(ds, range(6), is_train=True)
+    rng.use_host_rng(41)
+    model.sampler_rs = np.random.RandomState(seed)
+    with ProductMasks(model, nhwc_sites=sites) as pm:
+        res = model[blob]
+    rng.use_host_rng(None)
+    assert res.rel_labels.shape[0] == 1536 and res.rm_obj_labels.shape[0] == 120
+    loss = F.cross_entropy(res.rm_obj_dists, res.rm_obj_labels) + F.cross_entropy(res.rel_dists, res.rel_labels[:, -1])
+    loss.backward()
+
+    trainable = {n for n, p in model.named_parameters() if p.requires_grad}
+    osd = {k: v.clone().requires_grad_(k in trainable) for k, v in sd.items()}
+    cpu_blob = make_blob(ds, range(6), is_train=True)
+    x, im_sizes, off, gt_boxes, gt_classes, gt_rels = cpu_blob[0][:6]
+    det = dict(fmap=res.fmap.detach().float().cpu().contiguous(), im_inds=res.im_inds.cpu(), rm_box_priors=res.rm_box_priors.detach().cpu(),
+               rm_obj_dists=model.last_detector_obj_dists.cpu(), od_obj_dists=model.last_detector_obj_dists.cpu(),
+               rm_obj_labels=res.rm_obj_labels.cpu(), rel_labels=res.rel_labels.cpu(), boxes_all=None)
+    fm = det['fmap']
+    spatial = float((fm.std((2, 3)) / (fm.mean((2, 3)).abs() + 1e-9)).median())
+    print('cfg4 trunk feature map %s: mean %.3f, max %.3f, spatial std / |mean| per channel (median) %.3f' % (
+        tuple(fm.shape), float(fm.mean()), float(fm.max()), spatial))
+    assert tuple(fm.shape) == (6, 1024, 37, 37) and spatial > 0.1           # a lively map: layer4's batch statistics are well conditioned
+    with oracle_forced(pm.force) as taps:
+        ref = OM.relmodel_forward(osd, dict(cfg, use_resnet=True, use_vision=True), x, im_sizes, off, gt_boxes, gt_classes, True,
+                                  OM.HostRNG(41), rel_labels=res.rel_labels.cpu(), det_override=det)
+    assert_genuine_kinks(taps)
+    assert len([k for k in taps['flips'] if '.bn' in k]) == 16
+    np.testing.assert_array_equal(res.obj_preds.cpu().numpy(), ref['obj_preds'].numpy())
+    report('cfg4 relation logits', res.rel_dists.detach().cpu().numpy(), ref['rel_dists'].detach().numpy(), abs_tol=ABS_TOL)
+    report('cfg4 object logits', res.rm_obj_dists.detach().cpu().numpy(), ref['rm_obj_dists'].detach().numpy(), abs_tol=ABS_TOL)
+    oloss = F.cross_entropy(ref['rm_obj_dists'], ref['rm_obj_labels']) + F.cross_entropy(ref['rel_dists'], ref['rel_labels'][:, -1])
+    report('cfg4 loss', loss.item(), oloss.item(), abs_tol=ABS_TOL)
+    oloss.backward()
+    checked = 0
+    for name, p in model.named_parameters():
+        if not p.requires_grad:
+            assert p.grad is None
+            continue
+        assert osd[name].grad is not None and p.grad is not None, name
+        if name == 'union_boxes.conv.6.bias':
+            # the tower's last BatchNorm shift is a per-channel constant in front of layer4's conv1 + TRAIN-MODE BatchNorm, which
+            # removes it again: its gradient is analytically zero (both sides: rounding residue, 1e-6 of the weight's gradient)
+            wmax = float(osd['union_boxes.conv.6.weight'].grad.abs().max())
+            gp, go = float(p.grad.abs().max()), float(osd[name].grad.abs().max())
+            print('cfg4 grad union_boxes.conv.6.bias      analytically zero: product %.2e, oracle %.2e (conv.6.weight gradient: %.2e)' % (gp, go, wmax))
+            assert gp <= 1e-4 * wmax and go <= 1e-4 * wmax
+            continue
+        grad_close(p.grad.cpu().numpy(), osd[name].grad.numpy(), what='cfg4 grad ' + name[-30:])
+        checked += 1
+    assert checked >= 80                                   # 2 x 30 layer4 tensors + context + tower + tail
+    # running statistics after ONE training step: momentum 0.01 (the reference's own Bottleneck), unbiased variance
+    msd = model.state_dict()
+    for stack in ('roi_fmap', 'roi_fmap_obj'):
+        for b in range(3):
+            for bn in ('bn1', 'bn2', 'bn3') + (('downsample.1',) if b == 0 else ()):
+                for stat in ('running_mean', 'running_var'):
+                    k = '%s.0.%d.%s.%s' % (stack, b, bn, stat)
+                    rel_close(msd[k].cpu().numpy(), osd[k].detach().numpy(), rtol=1e-4, what='cfg4 ' + k[-34:], own_scale=True)
