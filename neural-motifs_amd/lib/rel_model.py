@@ -400,7 +400,11 @@ class RelModel(nn.Module):
         if overlap:
             main = torch.cuda.current_stream()
             if self._side_stream is None:
-                self._side_stream = torch.cuda.Stream(device=x.device)
+                # high priority: the context branch is a long chain of small, latency-bound launches (the step's critical path:
+                # profiles/r04_step_timeline_late0.txt); its workgroups should not queue behind the union-box branch's chip-filling
+                # GEMM / conv tiles.  MOTIFS_SIDE_PRIORITY=0 restores the default priority (A/B)
+                prio = -1 if os.environ.get('MOTIFS_SIDE_PRIORITY', '-1') != '0' else 0
+                self._side_stream = torch.cuda.Stream(device=x.device, priority=prio)
             side = self._side_stream
             side.wait_stream(main)                                   # fmap / rois / labels are ready
             late = self._late_ok(fmap) and self.late_vr_backward in ('auto', '1', 'force')

@@ -64,3 +64,73 @@ def test_rccl_world1_overlapped_reducer_and_fused_optimizer():
             np.testing.assert_allclose(a.detach().cpu().numpy(), b.detach().cpu().numpy(), atol=2e-6)
     finally:
         dist.destroy_process_group()
+
+
+def test_rccl_reducer_beside_the_two_compute_streams_of_the_real_backward():
+    """A THIRD stream next to the two compute streams: the overlapped reducer (forced on at world_size 1: RCCL's all-reduce
+    over one rank is the identity, but its kernels run on RCCL's own stream for the whole backward pass) while the real
+    RelModel backward runs its union-box branch and its context branch on two HIP streams.  Two hazards only this design has
+    (VERDICT r03): RCCL's reduction kernels co-resident with our MFMA kernels (the packed-FP32 fault of round 3 was a
+    co-residency fault) and the persistent LSTM launches, whose grid barrier needs every workgroup resident, next to RCCL's
+    channel blocks.  Gradients, logits and loss must be BITWISE those of the same step without the reducer."""
+    if not torch.cuda.is_available():
+        pytest.fail('needs a HIP device')
+    import torch.distributed as dist
+    from dataloaders.synthetic import SyntheticVG, make_blob
+    from lib import _hip
+    from lib import dist as D
+    from lib.rel_model import RelModel
+    torch.cuda.set_device(0)
+    dist.init_process_group('nccl', init_method='tcp://127.0.0.1:%d' % _free_port(), rank=0, world_size=1)
+    try:
+        torch.manual_seed(5)
+        ds = SyntheticVG(num_images=4, seed=23, n_boxes=12, n_rels=14)
+        model = RelModel(classes=ds.ind_to_classes, rel_classes=ds.ind_to_predicates, mode='sgcls', num_gpus=1,
+                         hidden_dim=512, pooling_dim=4096, nl_obj=2, nl_edge=2, order='leftright', rec_dropout=0.0,
+                         use_bias=True, pass_in_obj_feats_to_decoder=False, pass_in_obj_feats_to_edge=False,
+                         use_tanh=False, limit_vision=False)
+        for _, p in model.detector.named_parameters():
+            p.requires_grad = False
+        model.cuda().train()
+        for m in model.modules():
+            if m.__class__.__name__ in ('Dropout', 'AlphaDropout'):
+                m.eval()
+        model.overlap_streams = True
+        blob = make_blob(ds, [0, 1, 2, 3], is_train=True)
+        params = [p for p in model.parameters() if p.requires_grad]
+        red = D.OverlappedGradReducer(params, bucket_bytes=32 << 20, force=True)
+        assert red.enabled and len(red.buckets) >= 8                     # ~1.1 GB of gradients in 32 MB buckets
+
+        def step(with_reducer):
+            model.zero_grad(set_to_none=True)
+            model.sampler_rs = np.random.RandomState(9)
+            res = model[blob]
+            loss = F.cross_entropy(res.rm_obj_dists, res.rm_obj_labels) + F.cross_entropy(res.rel_dists, res.rel_labels[:, -1])
+            if with_reducer:
+                red.prepare()
+            loss.backward()
+            if with_reducer:
+                red.finish()
+            torch.cuda.synchronize()
+            _hip.check_faults()                                          # a timed-out grid barrier of the persistent LSTM raises here
+            return (res.rm_obj_dists.detach().clone(), res.rel_dists.detach().clone(), float(loss),
+                    {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None})
+
+        plain = step(False)
+        for trial in range(3):
+            got = step(True)
+            assert torch.equal(plain[0], got[0]) and torch.equal(plain[1], got[1]) and plain[2] == got[2]
+            assert set(plain[3]) == set(got[3])
+            for name, g in plain[3].items():
+                if 'embed' in name or 'obj_baseline' in name:
+                    # embedding / index_add gradients: torch accumulates them with atomics, their last bits differ from run to run
+                    # with or without the reducer -- rounding only
+                    err = float((g - got[3][name]).abs().max())
+                    assert err <= 1e-6 * float(g.abs().max()), '%s: %.3e' % (name, err)
+                    continue
+                assert torch.equal(g, got[3][name]), '%s: gradient differs with the reducer running (max %.3e)' % (
+                    name, float((g - got[3][name]).abs().max()))
+        assert red.stats['in_place_bytes'] > 0                           # fc6 / fc7 weight gradients were born inside the buckets
+        red.remove()
+    finally:
+        dist.destroy_process_group()

@@ -99,13 +99,17 @@ def test_sgdet_eval_end_to_end(det):
     # The detections themselves are compared stage by stage above (RPN, proposal NMS, filter_det: exact on identical inputs);
     # chained across devices a 1-ulp difference may re-rank two near-tied scores, so the end-to-end check hands the oracle
     # the PRODUCT's detections (det_override) and demands equality of everything the relation model makes of them.
-    _oracle_on_product_detections(model, sd, cfg, a, got, tag='sgdet e2e')
+    gt = dict(gt_classes=ds.gt_classes[2], gt_relations=ds.relationships[2], gt_boxes=ds.gt_boxes[2])
+    _oracle_on_product_detections(model, sd, cfg, a, got, tag='sgdet e2e', gt=gt)
     rb = ref[0]
     same = sum(1 for b in boxes if np.any(np.all(np.abs(rb - b[None]) < 1e-2, 1)))
     print('sgdet e2e: %d detections (oracle on its own detector: %d), %d coincide' % (boxes.shape[0], rb.shape[0], same))
+    # the oracle running its OWN detector (fp32 on the CPU) must find essentially the same boxes: a re-ranked near-tie may swap
+    # one or two detections at the max_per_img cut, more would mean the detector stages disagree
+    assert abs(boxes.shape[0] - rb.shape[0]) <= 2 and same >= min(boxes.shape[0], rb.shape[0]) - 2, (boxes.shape[0], rb.shape[0], same)
 
 
-def _oracle_on_product_detections(model, sd, cfg, a, got, tag, logits_tol=1e-4, fp64_floor=False):
+def _oracle_on_product_detections(model, sd, cfg, a, got, tag, logits_tol=1e-4, fp64_floor=False, gt=None, min_firm=None):
     """the oracle's relation model (eval mode) on the detections of the product's last forward: object labels, boxes and the
     set of candidate pairs EXACT; the ranked pair list exact wherever two ranking scores are separated by more than their
     rounding; object / relation logits and scores within `logits_tol` of scale"""
@@ -162,9 +166,45 @@ def _oracle_on_product_detections(model, sd, cfg, a, got, tag, logits_tol=1e-4, 
     eps = (1e-5 if ref_scores is None else 3.0 * logits_tol) * max(1.0, float(sr.max()))
     firm = np.concatenate(([True], gaps > eps)) & np.concatenate((gaps > eps, [True]))
     np.testing.assert_array_equal(rels[firm], rank_ref[3][firm])
+    # ... and the WHOLE ranked list, not only its firmly separated positions: walking the product's order, the reference
+    # scores must never rise by more than the rounding allowance (no pair is ranked below one that the reference scores more
+    # than `eps` lower) -- a statement about all N(N-1) pairs, however close their scores are
+    ref_score_of = dict(zip(key(rank_ref[3]).tolist(), sr.tolist()))
+    along = np.array([ref_score_of[k] for k in key(rels).tolist()])
+    later_max = np.maximum.accumulate(along[::-1])[::-1]
+    worst = float((later_max[1:] - along[:-1]).max()) if along.size > 1 else 0.0
+    assert worst <= eps, '%s: a pair is ranked %.3e (of reference score) too low; allowance %.3e' % (tag, worst, eps)
+    # the head of the list that Recall@K reads: the top-K triple SETS (subject, object, arg-max predicate) agree for the largest
+    # K <= 100 at which the reference ranking has a gap wider than the allowance (a tie AT the cut may swap members)
+    def triples(t, k):
+        return set(zip(t[3][:k, 0].tolist(), t[3][:k, 1].tolist(), (1 + np.asarray(t[4])[:k, 1:].argmax(1)).tolist()))
+    kmax = min(100, rels.shape[0])
+    cut = kmax
+    while 0 < cut < rels.shape[0] and sr[cut - 1] - sr[cut] <= eps:
+        cut -= 1
+    if cut > 0:
+        assert triples(got, cut) == triples(rank_ref, cut), '%s: top-%d triples differ' % (tag, cut)
     og, orr = np.argsort(key(rels), kind='stable'), np.argsort(key(sc_ref[3]), kind='stable')
     rel_close(pred_scores[og], np.asarray(sc_ref[4], dtype=np.float64)[orr], rtol=logits_tol, what=tag + ' predicate probabilities')
-    print('%s: %d detections, %d pairs, %d of them firmly ranked' % (tag, boxes.shape[0], rels.shape[0], int(firm.sum())))
+    nfirm = int(firm.sum())
+    print('%s: %d detections, %d pairs, %d of them firmly ranked, order violation %.2e (allowance %.2e), top-%d triple sets equal' % (
+        tag, boxes.shape[0], rels.shape[0], nfirm, worst, eps, cut))
+    if min_firm is not None:
+        assert nfirm >= min_firm, '%s: only %d firmly ranked pairs' % (tag, nfirm)
+    if gt is not None:
+        # Recall@20/50/100 through the pinned evaluator, product vs reference tuple: IDENTICAL (not "within 0.1")
+        from config import BOX_SCALE, IM_SCALE
+        from lib.evaluation.sg_eval import BasicSceneGraphEvaluator
+        recalls = {}
+        for name, tup in (('hip', got), ('oracle', rank_ref)):
+            ev = BasicSceneGraphEvaluator.all_modes()
+            ev['sgdet'].evaluate_scene_graph_entry(
+                dict(gt_classes=gt['gt_classes'], gt_relations=gt['gt_relations'], gt_boxes=gt['gt_boxes']),
+                dict(pred_boxes=np.asarray(tup[0]) * BOX_SCALE / IM_SCALE, pred_classes=np.asarray(tup[1]), pred_rel_inds=np.asarray(tup[3]),
+                     obj_scores=np.asarray(tup[2], dtype=np.float32), rel_scores=np.asarray(tup[4], dtype=np.float32)))
+            recalls[name] = [ev['sgdet'].result_dict['sgdet_recall'][k][0] for k in (20, 50, 100)]
+        print('%s R@20/50/100  hip %s  oracle %s' % (tag, recalls['hip'], recalls['oracle']))
+        assert recalls['hip'] == recalls['oracle']
     return ref
 
 
@@ -360,7 +400,8 @@ def test_cfg5_sgdet_eval_80_detections_all_pairs(det_big):
     n = got[0].shape[0]
     assert n == 80, 'the confident detector should fill max_per_img (got %d)' % n
     assert got[3].shape[0] == 80 * 79
-    _oracle_on_product_detections(model, sd, cfg, a, got, tag='cfg5', fp64_floor=True)
+    gt = dict(gt_classes=ds.gt_classes[0], gt_relations=ds.relationships[0], gt_boxes=ds.gt_boxes[0])
+    _oracle_on_product_detections(model, sd, cfg, a, got, tag='cfg5', fp64_floor=True, gt=gt, min_firm=40)
     model.require_overlap = True
 
 
