@@ -53,7 +53,7 @@ for p in (ROOT, os.path.join(ROOT, 'neural-motifs_amd')):
 
 PEAK_FP32_MFMA_TFLOPS = 157.3          # /opt/skills/guides/MI355X_MICROARCH.md chip table (f32-input MFMA)
 PEAK_BF16_MFMA_TFLOPS = 2500.0         # same table, dense bf16 MFMA
-TRAFFIC_SUMMARY = 'profiles/r03_conv_traffic_summary.json'   # tools/r03/traffic_summary.py (plane trunk, shipped schedule)
+TRAFFIC_SUMMARY = 'profiles/r04_conv_traffic_summary.json'   # tools/r04/traffic_summary.py (ring trunk, shipped schedule)
 PEAK_HBM_TBS = 8.0                     # same table, HBM3E
 MODEL_KW = dict(hidden_dim=512, pooling_dim=4096, nl_obj=2, nl_edge=2, order='leftright', rec_dropout=0.1,
                 use_bias=True, pass_in_obj_feats_to_decoder=False, pass_in_obj_feats_to_edge=False, use_tanh=False,

@@ -11,7 +11,7 @@ def test_cited_profile_files_exist():
     for md in ('DESIGN.md', 'BASELINE.md', 'README.md', 'INTEGRATION.md', os.path.join('profiles', 'README.md'),
                os.path.join('tools', 'README.md')):
         txt = open(os.path.join(ROOT, md)).read()
-        for m in re.finditer(r'`((?:profiles/)?r0[123]_[A-Za-z0-9_.*\-]+\.(?:json|jsonl|csv|txt))`', txt):
+        for m in re.finditer(r'`((?:profiles/)?r0[1234]_[A-Za-z0-9_.*\-]+\.(?:json|jsonl|csv|txt))`', txt):
             name = m.group(1).replace('1..5', '*')                      # "set1..5.csv" = the five counter-set files
             path = name if name.startswith('profiles/') else os.path.join('profiles', name)
             if not glob.glob(os.path.join(ROOT, path)):
@@ -34,11 +34,11 @@ def test_cited_tools_and_tests_exist():
 
 
 def test_committed_bench_line_follows_the_contract():
-    """the JSON line bench.py printed on the GPU box (profiles/r03_bench_n1.json) carries every field of the bench contract:
+    """the JSON line bench.py printed on the GPU box (profiles/r04_bench_n1.json) carries every field of the bench contract:
     the headline fields, config.workload (no model keys), roofline {bound, achieved, peak, unit, frac, traffic} with
     frac == achieved / peak, and cpu_baseline {value, unit, cores, kind, sample}"""
     import json
-    d = json.loads(open(os.path.join(ROOT, 'profiles', 'r03_bench_n1.json')).read().strip().split('\n')[-1])
+    d = json.loads(open(os.path.join(ROOT, 'profiles', 'r04_bench_n1.json')).read().strip().split('\n')[-1])
     for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline',
               'dtype', 'data', 'config', 'roofline', 'cpu_baseline'):
         assert k in d, k
@@ -57,6 +57,9 @@ def test_committed_bench_line_follows_the_contract():
         assert k in c, k
     assert c['kind'] == 'port' and c['unit'] == 'img/s' and 0 < c['value'] < d['value']
     assert isinstance(base.get('metric', ''), str)
+    # round 4: the distribution of the timed steps and the H2D-inclusive timing ride along
+    assert d['ms_per_step_p50'] <= d['ms_per_step_p90'] <= d['ms_per_step_max'] and d['ms_per_step_max'] < 1.25 * d['ms_per_step_p50']
+    assert d['h2d_inclusive']['value'] > 0 and d['meter_every'] >= 1
 
 
 def test_trace_gaps_splits_a_step_by_queue(tmp_path, capsys):
