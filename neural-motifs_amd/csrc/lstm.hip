@@ -10,6 +10,7 @@
 //   * sigmoid / cell expressions keep the reference's operation order (elementWise_fp :108-160), including the
 //     double-precision `(1. - r)` term.
 #include <algorithm>
+#include <cstdlib>
 
 #include "common.h"
 
@@ -192,9 +193,21 @@ __device__ __forceinline__ void load_resident(WResident<NR, NCH> &w, const float
 #pragma unroll
     for (int c = 0; c < NCH; ++c) load_w<NR>(w.c[c], wrow, ok_rows, vec, c * kChunk, K, wave, kq);
 }
+template <int NR, int NCH, typename Loader>
+__device__ __forceinline__ void block_gemv_resident_from(const WResident<NR, NCH> &w, Loader load_chunk, int K, float *vs, float *red,
+                                                         float (&tot)[NR]);
 template <int NR, int NCH>
 __device__ __forceinline__ void block_gemv_resident(const WResident<NR, NCH> &w, const float *v, int ldv, bool vvec,
                                                     int n, int b0, int K, float *vs, float *red, float (&tot)[NR])
+{
+    const int tid = threadIdx.x;
+    block_gemv_resident_from<NR, NCH>(w, [&](VStage &st, int k0) { load_vstage(st, v, ldv, vvec, n, b0, k0, K, tid); }, K, vs, red, tot);
+}
+// the same engine with the right-hand sides fetched by `load_chunk(stage, k0)` (plain rows of a state buffer, or the tagged
+// granules of the exchange buffer: hw_layer_fwd_kernel)
+template <int NR, int NCH, typename Loader>
+__device__ __forceinline__ void block_gemv_resident_from(const WResident<NR, NCH> &w, Loader load_chunk, int K, float *vs, float *red,
+                                                         float (&tot)[NR])
 {
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, grp = lane >> 4, kq = lane & 15;
     float acc[NR][kNB];
@@ -203,7 +216,7 @@ __device__ __forceinline__ void block_gemv_resident(const WResident<NR, NCH> &w,
 #pragma unroll
         for (int b = 0; b < kNB; ++b) acc[r][b] = 0.f;
     VStage st;
-    load_vstage(st, v, ldv, vvec, n, b0, 0, K, tid);
+    load_chunk(st, 0);
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
         const int k0 = c * kChunk;
@@ -211,7 +224,7 @@ __device__ __forceinline__ void block_gemv_resident(const WResident<NR, NCH> &w,
             __syncthreads();               // previous chunk's LDS reads are done
             store_vstage(st, vs, tid);
             __syncthreads();
-            if (k0 + kChunk < K) load_vstage(st, v, ldv, vvec, n, b0, k0 + kChunk, K, tid);
+            if (k0 + kChunk < K) load_chunk(st, k0 + kChunk);
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 const float *vp = vs + 128 * wave + 64 * h + 4 * kq;
@@ -308,6 +321,72 @@ __device__ __forceinline__ StepRows step_rows(const SeqSched &s, int t)
     r.after = (t + 1 < s.T) ? (size_t)s.B + start + r.n : 0;
     r.n_after = (t + 1 < s.T) ? covered_at(s, t + 1) : 0;
     return r;
+}
+
+
+// ---------------------------------------------------------------------------------------------------
+// Tagged-granule exchange (round 4): how the hidden state travels between the workgroups of a persistent layer WITHOUT a grid
+// barrier.  A granule is one naturally aligned 8-byte word {fp32 value, 32-bit tag} written by ONE agent-scope store
+// (`global_store_dwordx2 ... sc1`: write-through, single-copy atomic) and read by agent-scope loads that bypass the reader's L1 --
+// the "8-B agent atomics on both sides" form of MI355X_MICROARCH.md (workgroup dispatch / price list rows handoff-1to1, allgather),
+// valid for any placement of the workgroups.  A consumer sweeps the n x H granules of the previous step into its LDS stage and simply
+// re-reads a granule until its tag is the step's tag: data and "ready" arrive together, there is no counter, no release fence
+// (L2 write-back), no acquire (L1 invalidate), and nobody waits for workgroups whose data it already has.
+// Tags are unique per (call, layer, step) -- the buffer is zeroed once per call -- and two slots alternate by step parity: a producer
+// that writes slot s for step i + 2 has consumed every granule of step i + 1, which each workgroup publishes only after it is done
+// reading step i from slot s.  The sweep is bounded like the barrier's spin (same fault path).
+// ---------------------------------------------------------------------------------------------------
+constexpr size_t kXchFwdBytes = (size_t)2 * kSeqMaxB * kChunk * 8;      // 2 slots x <= 32 rows x <= 512 units x 8 B = 256 KiB
+constexpr size_t kXchBwdBytes = 5 * kXchFwdBytes;                       // the backward pass exchanges the 5 H gate gradients of every row
+
+__device__ __forceinline__ void gran_store(unsigned long long *p, float v, unsigned tag)
+{
+    __hip_atomic_store(p, ((unsigned long long)tag << 32) | (unsigned long long)__float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// rows b0 .. b0 + 7 x floats k0 .. k0 + 511 of the granule array g [rows][K] into a VStage (same element order as load_vstage);
+// rows >= n_pub were not published by the previous step (initial state / sequences that start here): zeros.  Returns false on a time-out.
+__device__ __forceinline__ bool load_vstage_gran(VStage &s, const unsigned long long *g, int n_pub, int b0, int k0, int K, int tid, unsigned tag,
+                                                 const unsigned *broken)
+{
+    unsigned long long w[4][4];
+    bool mine[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int f = tid + kGemvThreads * i, b = b0 + (f >> 7), k = k0 + 4 * (f & 127);
+        mine[i] = b < n_pub && k < K;                                     // K % 4 == 0 (persistent_ok)
+        s.v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    bool all_ok = false;
+    for (int spin = 0; spin < (1 << 16) && !all_ok; ++spin) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            if (!mine[i]) continue;
+            const int f = tid + kGemvThreads * i, b = b0 + (f >> 7), k = k0 + 4 * (f & 127);
+            const unsigned long long *q = g + (size_t)b * K + k;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) w[i][e] = __hip_atomic_load(q + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        all_ok = true;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            if (!mine[i]) continue;
+            bool ok = true;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) ok = ok && (unsigned)(w[i][e] >> 32) == tag;
+            if (ok) {
+                s.v[i] = make_float4(__uint_as_float((unsigned)w[i][0]), __uint_as_float((unsigned)w[i][1]), __uint_as_float((unsigned)w[i][2]),
+                                     __uint_as_float((unsigned)w[i][3]));
+                mine[i] = false;
+            } else {
+                all_ok = false;
+            }
+        }
+        if (!all_ok) {
+            if ((spin & 63) == 63 && __hip_atomic_load(broken, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return false;
+            __builtin_amdgcn_s_sleep(1);
+        }
+    }
+    return all_ok;
 }
 
 #ifndef MH_BAR_SLEEP
@@ -497,10 +576,15 @@ __global__ __launch_bounds__(kGemvThreads) void hw_layer_fwd_kernel(SeqSched s, 
                                                                    const float *__restrict__ wh_t,
                                                                    const float *__restrict__ bias,
                                                                    const float *__restrict__ dropout, float *gates,
-                                                                   unsigned *counters, int slot, FaultCtl fc)
+                                                                   unsigned *counters, int slot, FaultCtl fc,
+                                                                   unsigned long long *xch, unsigned tag_base)
 {
+    // xch != nullptr: the hidden state travels as tagged granules (see gran_store / load_vstage_gran), no grid barrier;
+    // xch == nullptr (MH_LSTM_GRAN=0, or no room in the workspace): every step ends with the grid barrier and reads h from `hl`
     __shared__ __attribute__((aligned(16))) float vs[kNB * kChunk];
     __shared__ float red[4 * 4 * 5 * kNB];
+    __shared__ int timed_out;
+    if (threadIdx.x == 0) timed_out = 0;
     const int lane = threadIdx.x & 63, grp = lane >> 4;
     const int ug = blockIdx.x * 4 + grp;
     const bool u_ok = ug < H;
@@ -518,11 +602,14 @@ __global__ __launch_bounds__(kGemvThreads) void hw_layer_fwd_kernel(SeqSched s, 
             for (int k = 0; k < 5; ++k) bias_u[k] = bias[k * H + u];
     }
     unsigned epoch = 0;
+    int n_pub = 0;                                   // rows the previous step published (0: the initial state is zero)
     for (int i = 0; i < s.T; ++i) {
         const int t = s.forward ? i : s.T - 1 - i;
         const StepRows rw = step_rows(s, t);
         const int n = rw.n;
         const float *h_prev = hl + rw.before * H, *c_prev = cl + rw.before * H;
+        const unsigned long long *g_prev = xch ? xch + (size_t)((i + 1) & 1) * kSeqMaxB * H : nullptr;     // slot of step i - 1
+        unsigned long long *g_out = xch ? xch + (size_t)(i & 1) * kSeqMaxB * H : nullptr;
         float *h_out = hl + rw.state * H, *c_out = cl + rw.state * H;
         const float *pi_t = pre_i + rw.io * 6 * H;
         float *g_t = gates ? gates + rw.io * 6 * H : nullptr;
@@ -541,7 +628,14 @@ __global__ __launch_bounds__(kGemvThreads) void hw_layer_fwd_kernel(SeqSched s, 
                 if (dropout) dm = dropout[o];
             }
             float th[5];
-            block_gemv_resident<5, 1>(w, h_prev, H, true, n, b0, H, vs, red, th);
+            if (xch) {
+                const unsigned tag = tag_base + (unsigned)i + fc.inflate;    // the tag step i - 1 published with (inflate: the test hook that makes it unreachable)
+                block_gemv_resident_from<5, 1>(w, [&](VStage &st, int k0) {
+                    if (!load_vstage_gran(st, g_prev, n_pub, b0, k0, H, threadIdx.x, tag, counters + kBrokenWord)) timed_out = 1;
+                }, H, vs, red, th);
+            } else {
+                block_gemv_resident<5, 1>(w, h_prev, H, true, n, b0, H, vs, red, th);
+            }
             if (mine) {
                 float g[5];
 #pragma unroll
@@ -558,6 +652,7 @@ __global__ __launch_bounds__(kGemvThreads) void hw_layer_fwd_kernel(SeqSched s, 
                 val = (float)((double)(val * r_gate) + (1. - (double)r_gate) * (double)lin_gate);
                 if (dropout) val = val * dm;
                 h_out[o] = val;
+                if (g_out) gran_store(g_out + o, val, tag_base + (unsigned)i + 1u);
                 if (g_t) {
                     float *go = g_t + (size_t)row * 6 * H + u;
                     go[0] = in_gate;
@@ -569,10 +664,23 @@ __global__ __launch_bounds__(kGemvThreads) void hw_layer_fwd_kernel(SeqSched s, 
                 }
             }
         }
-        if (i + 1 < s.T) grid_barrier(counters, slot, ++epoch * gridDim.x, fc);
+        n_pub = n;
+        if (xch) {
+            __syncthreads();                        // vs / red are reused by the next step; `timed_out` is complete
+            if (timed_out) {                        // bounded sweep ran out: raise the sticky word + the host-visible fault, stop
+                if (threadIdx.x == 0) {
+                    __hip_atomic_store(counters + kBrokenWord, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(fc.host_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                }
+                break;
+            }
+        } else if (i + 1 < s.T) {
+            grid_barrier(counters, slot, ++epoch * gridDim.x, fc);
+        }
     }
-    // a timed-out barrier means some step read a stale h_{t-1}: make the whole layer output unmistakably invalid
-    if (launch_broken(counters)) {
+    __syncthreads();
+    // a timed-out barrier / sweep means some step read a stale h_{t-1}: make the whole layer output unmistakably invalid
+    if (timed_out || launch_broken(counters)) {
         const float nan = __builtin_nanf("");
         for (int i = 0; i < s.T; ++i) {
             const StepRows rw = step_rows(s, i);
@@ -729,10 +837,13 @@ __global__ __launch_bounds__(kGemvThreads) void hw_layer_bwd_kernel(SeqSched s, 
                                                                    const float *__restrict__ gates,
                                                                    const float *__restrict__ dropout, float *dg_all,
                                                                    const float *__restrict__ wh, unsigned *counters, int slot,
-                                                                   FaultCtl fc)
+                                                                   FaultCtl fc, unsigned long long *xch, unsigned tag_base)
 {
+    // xch != nullptr: the gate gradients of a step travel as tagged granules ([slot][row][5 H], see hw_layer_fwd_kernel), no grid barrier
     __shared__ __attribute__((aligned(16))) float vs[kNB * kChunk];
     __shared__ float red[4 * 4 * 1 * kNB];
+    __shared__ int timed_out;
+    if (threadIdx.x == 0) timed_out = 0;
     const int lane = threadIdx.x & 63, grp = lane >> 4;
     const int ug = blockIdx.x * 4 + grp;
     const bool u_ok = ug < H;
@@ -783,27 +894,60 @@ __global__ __launch_bounds__(kGemvThreads) void hw_layer_bwd_kernel(SeqSched s, 
                 const float d_c = d_o * out_gate * (1.f - tc * tc) + (has_rec ? c_grad[rw.after * H + idx] : 0.f);
                 const float h_prime = out_gate * tc;
                 float *dgp = dg + (size_t)b * 6 * H + u;
-                dgp[0] = d_c * act_gate * in_gate * (1.f - in_gate);
-                dgp[(size_t)H] = d_c * in.c_p * forget_gate * (1.f - forget_gate);
-                dgp[(size_t)2 * H] = d_c * in_gate * (1.f - act_gate * act_gate);
-                dgp[(size_t)3 * H] = d_o * tc * out_gate * (1.f - out_gate);
-                dgp[(size_t)4 * H] = d_h * (h_prime - lin_gate) * r_gate * (1.f - r_gate);
+                const float d0 = d_c * act_gate * in_gate * (1.f - in_gate);
+                const float d1 = d_c * in.c_p * forget_gate * (1.f - forget_gate);
+                const float d2 = d_c * in_gate * (1.f - act_gate * act_gate);
+                const float d3 = d_o * tc * out_gate * (1.f - out_gate);
+                const float d4 = d_h * (h_prime - lin_gate) * r_gate * (1.f - r_gate);
+                dgp[0] = d0;
+                dgp[(size_t)H] = d1;
+                dgp[(size_t)2 * H] = d2;
+                dgp[(size_t)3 * H] = d3;
+                dgp[(size_t)4 * H] = d4;
                 dgp[(size_t)5 * H] = d_h * (1 - r_gate);
                 c_grad[rw.state * H + idx] = forget_gate * d_c;
+                if (xch) {
+                    unsigned long long *gp = xch + ((size_t)(i & 1) * kSeqMaxB + b) * 5 * H + u;
+                    const unsigned tg = tag_base + (unsigned)i + 1u;
+                    gran_store(gp, d0, tg);
+                    gran_store(gp + (size_t)H, d1, tg);
+                    gran_store(gp + (size_t)2 * H, d2, tg);
+                    gran_store(gp + (size_t)3 * H, d3, tg);
+                    gran_store(gp + (size_t)4 * H, d4, tg);
+                }
             }
         }
-        grid_barrier(counters, slot, ++epoch * gridDim.x, fc);
+        if (!xch) grid_barrier(counters, slot, ++epoch * gridDim.x, fc);
         if (i + 1 < s.T) fetch(i + 1, in);
         for (int b0 = 0; b0 < n; b0 += kNB) {
             float tot[1];
-            block_gemv_resident<1, 5>(w, dg, 6 * H, true, n, b0, 5 * H, vs, red, tot);
+            if (xch) {
+                const unsigned long long *g_cur = xch + (size_t)(i & 1) * kSeqMaxB * 5 * H;
+                const unsigned tag = tag_base + (unsigned)i + 1u + fc.inflate;
+                block_gemv_resident_from<1, 5>(w, [&](VStage &st, int k0) {
+                    if (!load_vstage_gran(st, g_cur, n, b0, k0, 5 * H, threadIdx.x, tag, counters + kBrokenWord)) timed_out = 1;
+                }, 5 * H, vs, red, tot);
+            } else {
+                block_gemv_resident<1, 5>(w, dg, 6 * H, true, n, b0, 5 * H, vs, red, tot);
+            }
             const int u = blockIdx.x * 4 + (threadIdx.x >> 3), row = b0 + (threadIdx.x & 7);
             if (threadIdx.x < 4 * kNB && u < H && row < n) h_grad[rw.state * H + (size_t)row * H + u] = tot[0];
         }
+        if (xch) {
+            __syncthreads();                        // this step's h_grad (other threads of the block read it next step); vs / red free
+            if (timed_out) {
+                if (threadIdx.x == 0) {
+                    __hip_atomic_store(counters + kBrokenWord, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(fc.host_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                }
+                break;
+            }
+        }
     }
+    __syncthreads();
     // see hw_layer_fwd_kernel: after a timed-out barrier the gate gradients (what the caller's dgrad / wgrad GEMMs read)
     // and the state gradients of this block's units become NaN
-    if (launch_broken(counters)) {
+    if (timed_out || launch_broken(counters)) {
         const float nan = __builtin_nanf("");
         for (int i = 0; i < s.T; ++i) {
             const StepRows rw = step_rows(s, i);
@@ -911,6 +1055,12 @@ static int fault_ctl(FaultCtl &fc)
 }
 
 constexpr size_t kCounterBytes = 256;   // grid-barrier counters of the persistent layer kernels (one per layer)
+// MH_LSTM_GRAN=0: the forward layers exchange h through `hl` + a grid barrier per step (rounds 2-3) instead of tagged granules (A/B)
+static bool gran_enabled()
+{
+    static const bool on = [] { const char *e = getenv("MH_LSTM_GRAN"); return !(e && e[0] == '0'); }();
+    return on;
+}
 static bool persistent_ok(int H, int B, int L)
 {
     return H <= kChunk && H % 4 == 0 && B <= kSeqMaxB && L <= kBrokenWord;
@@ -1016,7 +1166,7 @@ size_t mh_hwlstm_fwd_ws_bytes(int in_size, int H, int B, int L, int T)
     (void)L;
     size_t s = align_up((size_t)T * B * 6 * H * sizeof(float), 256) + align_up((size_t)5 * H * H * sizeof(float), 256);
     s += std::max(mh_gemm_ws_bytes(T * B, 6 * H, in_size, 0), mh_gemm_ws_bytes(T * B, 6 * H, H, 0));
-    return s + kCounterBytes + 256;
+    return s + kCounterBytes + kXchFwdBytes + 256;
 }
 
 int mh_hwlstm_fwd(int in_size, int H, int B, int L, int T, const float *x, const int *lengths_host, float *h_data,
@@ -1045,9 +1195,12 @@ int mh_hwlstm_fwd(int in_size, int H, int B, int L, int T, const float *x, const
     int ts[4096], ns[4096];
     unsigned *counters = reinterpret_cast<unsigned *>(ws);   // one barrier counter per layer
     ws += kCounterBytes;
+    unsigned long long *xch = reinterpret_cast<unsigned long long *>(ws);     // granule exchange of the forward layers (behind the counters)
+    ws += kXchFwdBytes;
     const bool persistent = persistent_ok(H, B, L) && al16(h_data) && al16(wh_t);
+    const bool gran = persistent && gran_enabled();
     if (persistent) {
-        hipError_t e = hipMemsetAsync(counters, 0, kCounterBytes, st);
+        hipError_t e = hipMemsetAsync(counters, 0, kCounterBytes + (gran ? kXchFwdBytes : 0), st);
         if (e != hipSuccess) return (int)e;
     }
     void *gws = ws;
@@ -1071,7 +1224,8 @@ int mh_hwlstm_fwd(int in_size, int H, int B, int L, int T, const float *x, const
             SeqSched sched = make_sched(lengths_host, T, B, fwd_dir);
             hipLaunchKernelGGL(hw_layer_fwd_kernel, dim3(ceil_div(H, 4)), dim3(kGemvThreads), 0, st, sched, H, tmp_i, hl, cl,
                                wh_t, bias + (size_t)5 * H * layer, dropout + (size_t)layer * numEl,
-                               is_training ? gates + (size_t)layer * T * 6 * numEl : nullptr, counters, layer, fc);
+                               is_training ? gates + (size_t)layer * T * 6 * numEl : nullptr, counters, layer, fc,
+                               gran ? xch : nullptr, 1u + 8192u * (unsigned)layer);
             MH_TRY(check_launch("hw_layer_fwd_kernel"));
             continue;
         }
@@ -1112,7 +1266,7 @@ static int sched_from_batch_sizes(const int *batch_sizes, int T, int B, SeqSched
     return MH_OK;
 }
 
-size_t mh_hwcell_seq_ws_bytes(void) { return kCounterBytes; }
+size_t mh_hwcell_seq_ws_bytes(void) { return kCounterBytes + kXchBwdBytes; }      // forward needs a fifth of it
 
 int mh_hwcell_seq_fwd(int H, int B, int T, const int *batch_sizes_host, const float *pre_i, const float *w_state,
                       const float *b_state, const float *dropout, float *h_buf, float *c_buf, float *gates,
@@ -1125,10 +1279,12 @@ int mh_hwcell_seq_fwd(int H, int B, int T, const int *batch_sizes_host, const fl
     FaultCtl fc;
     MH_TRY(fault_ctl(fc));
     hipStream_t st = as_stream(stream);
-    hipError_t e = hipMemsetAsync(workspace, 0, kCounterBytes, st);
+    const bool gran = gran_enabled() && ws_bytes >= kCounterBytes + kXchFwdBytes;
+    hipError_t e = hipMemsetAsync(workspace, 0, kCounterBytes + (gran ? kXchFwdBytes : 0), st);
     if (e != hipSuccess) return (int)e;
+    unsigned long long *xch = reinterpret_cast<unsigned long long *>(reinterpret_cast<char *>(workspace) + kCounterBytes);
     hipLaunchKernelGGL(hw_layer_fwd_kernel, dim3(ceil_div(H, 4)), dim3(kGemvThreads), 0, st, sched, H, pre_i, h_buf, c_buf,
-                       w_state, b_state, dropout, gates, reinterpret_cast<unsigned *>(workspace), 0, fc);
+                       w_state, b_state, dropout, gates, reinterpret_cast<unsigned *>(workspace), 0, fc, gran ? xch : nullptr, 1u);
     return check_launch("hw_layer_fwd_kernel");
 }
 
@@ -1145,10 +1301,13 @@ int mh_hwcell_seq_bwd(int H, int B, int T, const int *batch_sizes_host, const fl
     FaultCtl fc;
     MH_TRY(fault_ctl(fc));
     hipStream_t st = as_stream(stream);
-    hipError_t e = hipMemsetAsync(workspace, 0, kCounterBytes, st);
+    const bool gran = gran_enabled() && ws_bytes >= kCounterBytes + kXchBwdBytes;
+    hipError_t e = hipMemsetAsync(workspace, 0, kCounterBytes + (gran ? kXchBwdBytes : 0), st);
     if (e != hipSuccess) return (int)e;
+    unsigned long long *xch = reinterpret_cast<unsigned long long *>(reinterpret_cast<char *>(workspace) + kCounterBytes);
     hipLaunchKernelGGL(hw_layer_bwd_kernel, dim3(ceil_div(H, 4)), dim3(kGemvThreads), 0, st, sched, H, dh_all, hgrad_buf,
-                       cgrad_buf, c_buf, gates, dropout, d_pre, w_state_t, reinterpret_cast<unsigned *>(workspace), 0, fc);
+                       cgrad_buf, c_buf, gates, dropout, d_pre, w_state_t, reinterpret_cast<unsigned *>(workspace), 0, fc,
+                       gran ? xch : nullptr, 1u);
     return check_launch("hw_layer_bwd_kernel");
 }
 
@@ -1188,7 +1347,7 @@ size_t mh_hwlstm_bwd_ws_bytes(int in_size, int H, int B, int L, int T)
     size_t s = align_up((size_t)T * B * 6 * H * sizeof(float), 256);
     s += 2 * align_up((size_t)(T + 1) * numEl * sizeof(float), 256);
     s += 2 * align_up((size_t)T * numEl * sizeof(float), 256);
-    s += kCounterBytes;
+    s += kCounterBytes + kXchBwdBytes;
     size_t g = 0;
     const int ins[2] = {in_size, H};
     for (int i = 0; i < 2; ++i) {
@@ -1230,9 +1389,12 @@ int mh_hwlstm_bwd(int in_size, int H, int B, int L, int T, const float *out_grad
     ws += align_up((size_t)T * numEl * sizeof(float), 256);
     unsigned *counters = reinterpret_cast<unsigned *>(ws);
     ws += kCounterBytes;
+    unsigned long long *xch = reinterpret_cast<unsigned long long *>(ws);     // granule exchange of the backward layers
+    ws += kXchBwdBytes;
     const bool persistent = persistent_ok(H, B, L) && al16(weight) && al16(dg_all);
+    const bool gran = persistent && gran_enabled();
     if (persistent) {
-        hipError_t e = hipMemsetAsync(counters, 0, kCounterBytes, st);
+        hipError_t e = hipMemsetAsync(counters, 0, kCounterBytes + (gran ? kXchBwdBytes : 0), st);
         if (e != hipSuccess) return (int)e;
     }
     void *gws = ws;
@@ -1257,7 +1419,8 @@ int mh_hwlstm_bwd(int in_size, int H, int B, int L, int T, const float *out_grad
             SeqSched sched = make_sched(lengths_host, T, B, fwd_dir);
             hipLaunchKernelGGL(hw_layer_bwd_kernel, dim3(ceil_div(H, 4)), dim3(kGemvThreads), 0, st, sched, H, grad_in,
                                h_grad, c_grad, cl, gates + (size_t)layer * T * 6 * numEl,
-                               dropout + (size_t)layer * numEl, dg_all, weight + o.wh, counters, layer, fc);
+                               dropout + (size_t)layer * numEl, dg_all, weight + o.wh, counters, layer, fc, gran ? xch : nullptr,
+                               1u + 8192u * (unsigned)layer);
             MH_TRY(check_launch("hw_layer_bwd_kernel"));
         } else
         for (int i = 0; i < T; ++i) {
