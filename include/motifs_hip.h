@@ -145,7 +145,8 @@ size_t mh_gemm_planes_ws_bytes(int M, int N, int K, int splitk);
 int mh_gemm_planes_auto_splitk(int M, int N, int K);
 int mh_gemm_planes(int M, int N, int K, const void *A_image, const void *B_image, float *C, int ldc, const float *bias,
                    int epilogue, int accumulate, int splitk, void *workspace, size_t ws_bytes, void *stream);
-/* A/B hooks for measurements (tools/pl_check.cpp): force a block-tile shape (-1 auto, 0 256x128, 1 128x128, 2 256x64);
+/* A/B hooks for measurements (tools/pl_check.cpp): force a block-tile shape (-1 auto; round-3 loop: 0 256x128, 1 128x128, 2 256x64;
+ * ring loop: 3 256x256 on eight waves, 4 256x128);
  * the round-2 in-loop-split kernel (fp32 operands split inside the K loop) kept for comparison runs. */
 void mh_debug_pl_shape(int shape);
 size_t mh_gemm_ws_bytes_v2(int M, int N, int K, int splitk);
@@ -166,7 +167,8 @@ int mh_gemm_f32_v2(int transA, int transB, int M, int N, int K, const float *A, 
  *                     ZERO on entry) receives the largest |out| per image.  Workspace: mh_plconv3x3_ws_bytes (split-K
  *                     partial sums of the tile schedule).
  *   mh_conv_first_nchw_max = mh_conv_first_nchw that also reports those maxima (conv1_1 feeds the first image).
- * mh_debug_plconv_shape: A/B hook (-1 auto, 0 256x128, 1 128x128, 2 256x64 block tiles). */
+ * mh_debug_plconv_shape: A/B hook (-1 auto; round-3 loop: 0 256x128, 1 128x128, 2 256x64 block tiles; 4: the ring kernel's
+ * 256x128, what auto selects for Cout >= 128). */
 size_t mh_act_planes_bytes(int B, int H, int W, int C);
 int mh_act_planes(const float *x_nhwc, const unsigned *maxbits, int B, int H, int W, int C, int pool, void *image,
                   void *stream);

@@ -845,10 +845,9 @@ __global__ __launch_bounds__(256) void image_absmax_kernel(const float *__restri
 typedef Shape<256, 128, 4, 2> S256x128;
 typedef Shape<128, 128, 2, 2> S128x128;
 typedef Shape<256, 64, 2, 2> S256x64;
-typedef Ring<4, 2, 2, 4, 4> CR256x256;     // shape 3: 8 waves, 64x128 wave tiles, 4 stages x 32 KB, one block per CU
-typedef Ring<4, 1, 2, 4, 3> CR256x128;     // shape 4: 4 waves, 3 stages x 24 KB, two blocks per CU
-typedef Ring<4, 1, 2, 2, 3> CR256x64;      // shape 5: 4 waves of 64x64 (Cout 64), 3 stages x 20 KB, two blocks per CU
-typedef Ring<2, 2, 2, 2, 4> CR128x128;     // shape 6: 4 waves of 64x64, 4 stages x 16 KB, two blocks per CU (small maps: more tiles)
+// the ring shape that ships (shape 4).  Three more were built and measured in round 4 and removed again because they never won
+// (profiles/r04_ring_conv_sweep.jsonl: 256x256 on eight waves -- shape 3 there --, 256x64 and 128x128 with 64x64 wave tiles -- 5, 6)
+typedef Ring<4, 1, 2, 4, 3> CR256x128;     // shape 4: 4 waves, 64x128 wave tiles, 3 stages x 24 KB, two blocks per CU
 static int g_conv_shape = -1;       // mh_debug_plconv_shape
 static int g_conv_flags = 0;        // mh_debug_plconv_flags
 static int g_conv_splitk = 0;       // mh_debug_plconv_splitk: > 0 = every tile cut into that many K slices (measurement sweeps)
@@ -879,15 +878,13 @@ static Sched schedule(long long M, int Cin, int Cout)
     // block count per CU decides) stays on the round-3 256x64 loop, whole tiles (228 vs 203 with the tail cut into slices)
     static const bool ring_off = [] { const char *e = getenv("MH_PL_RING"); return e && e[0] == '0'; }();      // A/B: MH_PL_RING=0 = round-3 loop
     s.shape = (g_conv_shape >= 0) ? g_conv_shape : (Cout <= 64 ? 2 : (env_shape >= 0 ? env_shape : (ring_off ? 1 : 4)));
-    if (Cout <= 64 && s.shape != 2 && s.shape != 5) s.shape = (s.shape >= 3) ? 5 : 2;       // 64 output channels: the 64-wide tiles only
-    static const int bms[7] = {256, 128, 256, 256, 256, 256, 128}, bns[7] = {128, 128, 64, 256, 128, 64, 128};
+    if (Cout <= 64 || s.shape == 3 || s.shape > 4) s.shape = (Cout <= 64) ? 2 : 4;          // 64 output channels: the 64-wide round-3 tiles
+    static const int bms[5] = {256, 128, 256, 256, 256}, bns[5] = {128, 128, 64, 256, 128};
     s.bm = bms[s.shape];
     s.bn = bns[s.shape];
-    set_resident_slots_override(s.shape == 3 ? 256 : 0);       // the 8-wave ring shape: one block per CU
     s.pl = plan_conv_tiles(M, Cin, Cout, s.bm, s.bn);
     const long long tiles = (long long)s.pl.tiles_m * s.pl.tiles_n;
     const int slots = resident_slots();
-    set_resident_slots_override(0);
     const long long rounds = tiles / slots;
     const bool whole = (rounds == 0) ? tiles > slots / 4 : (rounds > 3 || s.shape == 2);
     if (whole) { s.pl.splitk = 1; s.pl.body_mtiles = s.pl.tiles_m; s.pl.tail_slices = 1; }
@@ -1033,10 +1030,7 @@ static int plconv_impl(const void *in_image, const unsigned *in_true_maxbits, in
         if (out_image) pl::launch<pl::conv3x3_ring_kernel<R, true>>(grid, pl::ring_conv_lds_bytes<R>(true), st, p, 0, R::threads);
         else pl::launch<pl::conv3x3_ring_kernel<R, false>>(grid, pl::ring_conv_lds_bytes<R>(false), st, p, 0, R::threads);
     };
-    if (sc.shape == 3) ring(pl::CR256x256());
-    else if (sc.shape == 4) ring(pl::CR256x128());
-    else if (sc.shape == 5) ring(pl::CR256x64());
-    else if (sc.shape == 6) ring(pl::CR128x128());
+    if (sc.shape == 4) ring(pl::CR256x128());
     else
     if (out_image) {
         if (sc.shape == 0) pl::launch<pl::conv3x3_kernel<pl::S256x128, true>>(grid, pl::conv_lds_bytes<pl::S256x128>() + tab_bytes, st, p, pl::conv_lds_bytes<pl::S256x128>() + kTabMax);

@@ -376,7 +376,6 @@ constexpr size_t ring_gemm_lds() { return (size_t)(R::lds_bytes > 8192 + R::wave
 
 typedef Ring<4, 2, 2, 4, 4> R256x256;        // 8 waves, 64x128 wave tiles, 4 stages x 32 KB: one block per CU
 typedef Ring<4, 1, 2, 4, 3> R256x128;        // 4 waves, 3 stages x 24 KB: two blocks per CU
-typedef Ring<2, 2, 4, 4, 4> R256x256w4;      // 4 waves, 128x128 wave tiles (256 accumulator registers): one wave per SIMD
 
 typedef Shape<256, 128, 4, 2> S256x128;
 typedef Shape<128, 128, 2, 2> S128x128;
@@ -384,29 +383,28 @@ typedef Shape<256, 64, 2, 2> S256x64;
 
 // ------------------------------------------------------------------------------------------------- host side
 struct Plan {
-    int shape;     // round-3 loop: 0: 256x128, 1: 128x128, 2: 256x64; ring loop: 3: 256x256 (8 waves), 4: 256x128 (4 waves, 2 / CU),
-                   // 5: 256x256 (4 waves of 128x128)
+    int shape;     // round-3 loop: 0: 256x128, 1: 128x128, 2: 256x64; ring loop: 3: 256x256 (8 waves), 4: 256x128 (4 waves, 2 / CU)
     int bm, bn, splitk;
 };
 static int g_force_shape = -1;      // mh_debug_pl_shape: A/B runs
 
 static Plan plan_gemm(int M, int N, int K, int want_splitk)
 {
-    static const int bms[6] = {256, 128, 256, 256, 256, 256}, bns[6] = {128, 128, 64, 256, 128, 256};
+    static const int bms[5] = {256, 128, 256, 256, 256}, bns[5] = {128, 128, 64, 256, 128};
     // fp32-equivalent FLOP/s one CU sustains with a full complement of blocks of the shape (measured: DESIGN.md 5)
-    static const double rate[6] = {365e12 / 256, 370e12 / 256, 300e12 / 256, 450e12 / 256, 430e12 / 256, 450e12 / 256};
-    static const int per_cu[6] = {2, 2, 2, 1, 2, 1};          // resident blocks per CU the makespan model assumes
+    static const double rate[5] = {365e12 / 256, 370e12 / 256, 300e12 / 256, 450e12 / 256, 430e12 / 256};
+    static const int per_cu[5] = {2, 2, 2, 1, 2};          // resident blocks per CU the makespan model assumes
     const int ktiles = ceil_div(K, kBK);
     Plan best = {1, 128, 128, 1};
     double best_cost = 1e30;
-    for (int s = 0; s < 6; ++s) {
+    for (int s = 0; s < 5; ++s) {
         if (g_force_shape >= 0 && s != g_force_shape) continue;
         if (g_force_shape < 0) {
             // ring shapes (gpurun r04_c6, TFLOP/s on ready images, ring vs the round-3 loop: 4096^3 436 vs 389, fc6 forward 389 vs
             // 373, fc6 input gradient 386 vs 353, fc6 weight gradient 381 vs 333, fc7 forward 337 vs 302): 256x256 on eight waves
-            // for wide products, 256x128 two per CU otherwise; the 4-wave 128x128-wave-tile variant never won
+            // for wide products, 256x128 two per CU otherwise (a 4-wave variant with 128x128 wave tiles was measured and removed: never won)
             static const bool ring_off = [] { const char *e = getenv("MH_PL_RING"); return e && e[0] == '0'; }();      // A/B: MH_PL_RING=0
-            if (s == 5 || (ring_off && s >= 3)) continue;
+            if (ring_off && s >= 3) continue;
             if (s == 3 && (N <= 128 || M <= 128)) continue;
             if (s == 4 && (N <= 64 || M <= 128)) continue;
             if (s == 2 && N > 64) continue;
@@ -452,7 +450,6 @@ static int launch_gemm(const GemmArgs &p0, const Plan &pl, hipStream_t st)
     const dim3 grid((unsigned)(p.tiles_m * p.tiles_n), (unsigned)p.splitk);
     if (pl.shape == 3) launch<gemm_ring_kernel<R256x256>>(grid, ring_gemm_lds<R256x256>(), st, p, 0, R256x256::threads);
     else if (pl.shape == 4) launch<gemm_ring_kernel<R256x128>>(grid, ring_gemm_lds<R256x128>(), st, p, 0, R256x128::threads);
-    else if (pl.shape == 5) launch<gemm_ring_kernel<R256x256w4>>(grid, ring_gemm_lds<R256x256w4>(), st, p, 0, R256x256w4::threads);
     else if (pl.shape == 0) launch<gemm_kernel<S256x128>>(grid, S256x128::lds_bytes, st, p);
     else if (pl.shape == 1) launch<gemm_kernel<S128x128>>(grid, S128x128::lds_bytes, st, p);
     else launch<gemm_kernel<S256x64>>(grid, S256x64::lds_bytes, st, p);

@@ -134,7 +134,7 @@ static int image_case(int M, int N, int K, unsigned seed)
     std::vector<double> R;
     ref_gemm(0, 0, M, N, K, A, K, B, N, nullptr, 0, nullptr, N, R);
     int bad = 0;
-    for (int shape = -1; shape <= 5; ++shape) {
+    for (int shape = -1; shape <= 4; ++shape) {
         set_shape(shape);
         for (int sk : {0, 1, 3}) {
             Dev ws(wspl(M, N, K, sk));
@@ -331,7 +331,8 @@ static int conv_case(const char *name, int B, int H, int W, int Cin, int Cout, i
         HIP_OK(hipMemcpy(Rf.data(), dref.p, Rf.size() * 4, hipMemcpyDeviceToHost));
     }
     int bad = 0;
-    for (int shape = -1; shape <= 6; ++shape) {
+    for (int shape = -1; shape <= 4; ++shape) {
+        if (shape == 3) continue;
         set_conv_shape(shape);
         Dev ws3(plconv_ws(B, H, W, Cin, Cout));
         HIP_OK(hipMemset(dmbo.p, 0, B * 4));
@@ -419,7 +420,8 @@ static int chain_case(const char *name, int B, int H, int W, int C0, int C1, int
     const void *in2 = img0.p;
     if (with_stem) { rc |= stem_img(dx.f(), B, 3, H, W, dws.f(), C0, dbs.f(), 1, jmg0.p, n0_, nullptr); in2 = jmg0.p; }
     int bad = 0;
-    for (int shape = -1; shape <= 6; ++shape) {
+    for (int shape = -1; shape <= 4; ++shape) {
+        if (shape == 3) continue;
         set_conv_shape(shape);
         HIP_OK(hipMemset(n1, 0, B * 4)); HIP_OK(hipMemset(n2, 0, B * 4));
         Dev wsa2(plconv_ws(B, H, W, C0, C1)), wsb2(plconv_ws(B, H, W, C1, C2));
@@ -460,9 +462,9 @@ static void conv_sweep(const char *name, int B, int H, int W, int Cin, int Cout,
     Dev img(act_bytes(B, H, W, Cin)), pk(plpacked_bytes(Cout, Cin)), oimg(act_bytes(B, H, W, Cout));
     plpack(dw.f(), Cout, Cin, 0, pk.p, nullptr);
     act_planes(dx.f(), (const unsigned *)dmb.p, B, H, W, Cin, 0, img.p, nullptr);
-    for (int shape = 0; shape <= 6; ++shape) {
-        if ((shape == 2 || shape == 5) && Cout > 64) continue;
-        if (Cout <= 64 && shape != 2 && shape != 5) continue;
+    for (int shape = 0; shape <= 4; ++shape) {
+        if (shape == 3 || (shape == 2 && Cout > 64)) continue;
+        if (Cout <= 64 && shape != 2) continue;
         for (int sk : {0, 1, 2, 3, 4, 6}) {
             if (g_sweep_quick && sk != 0 && sk != 1 && !(H <= 74 && (sk == 2 || sk == 3 || sk == 4))) continue;
             set_conv_shape(shape); set_conv_splitk(sk);
@@ -520,7 +522,7 @@ static void ring_speed(const char *name, int M, int N, int K, int iters)
     mkplanes(dA.f(), 1, M, K, K, ia.p, nullptr);
     mkplanes(dB.f(), 1, N, K, K, ib.p, nullptr);
     const double flops = 2.0 * M * N * (double)K;
-    for (int shape : {1, 0, 3, 4, 5}) {
+    for (int shape : {1, 0, 3, 4}) {
         if (shape == 0 && M <= 128) continue;
         set_shape(shape);
         for (int sk : {1, 2, 3, 4, 8}) {

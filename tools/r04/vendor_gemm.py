@@ -47,7 +47,7 @@ def main():
         b = torch.randn(N, K, device=dev)
         ia, ib = _hip.make_planes(a, True), _hip.make_planes(b, True)
         out = torch.empty(M, N, device=dev)
-        for shape in (-1, 3, 4, 5):
+        for shape in (-1, 0, 3, 4):
             _hip.lib().mh_debug_pl_shape(shape)
             ms = timed(lambda: _hip.gemm_planes(ia, ib, out=out), 10)
             print(json.dumps({'engine': 'plane GEMM on ready images', 'shape': shape, 'M': M, 'N': N, 'K': K, 'ms': round(ms, 4),
