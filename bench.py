@@ -776,7 +776,7 @@ def main():
                          'traffic_unit': 'bytes per launch (L2 fabric side: HBM + Infinity-Cache)',
                          'traffic_algorithmic': traffic['algorithmic_bytes_per_launch'] if traffic else None,
                          'traffic_source': TRAFFIC_SUMMARY + ' (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over one '
-                                           'launch per trunk layer of this step with the shipped library, tools/r03/traffic.sh; replayed offline: a '
+                                           'launch per trunk layer of this step with the shipped library, tools/r04/traffic.sh; replayed offline: a '
                                            'PMC pass over the whole step does not finish); covers the 12 pl::conv3x3_kernel launches',
                          'frac_of_f32_mfma_peak': conv['tflops'] / PEAK_FP32_MFMA_TFLOPS,
                          'frac_of_bf16x6_peak': conv['tflops'] / (PEAK_BF16_MFMA_TFLOPS / 6.0),
