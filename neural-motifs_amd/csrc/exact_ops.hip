@@ -72,13 +72,131 @@ __global__ __launch_bounds__(64) void nms_mask_kernel(const float4 *__restrict__
     if (row < n) mask[(size_t)(base + row) * cb_stride + col_blk] = t;
 }
 
-// Sequential greedy sweep, one 256-thread block per segment.  Wave 0 resolves one 64-box block-row
-// at a time from the diagonal words (uniform loop + readlane broadcast), then the whole block ORs
-// the kept rows' words into the running `removed` bitmap (LDS).
+// Sequential greedy sweep, one 256-thread block per segment (the chain over block-rows is serial by definition: whether box i
+// survives depends on every kept box before it; /root/reference lib/fpn/nms/src/cuda/nms_kernel.cu:96-131 does it on the host).
+// What bounds it is the latency of the mask reads, so none of them may depend on the chain:
+//   * the diagonal words of kSweepStage block-rows are staged in LDS at a time;
+//   * the words of block-row r right of the diagonal are fetched by ALL 256 threads into registers one block-row ahead
+//     (thread = row group tid>>4 x column lane tid&15: rows rg + 16p, columns jb + cl + 16t; 128 contiguous bytes per 16
+//     lanes), whether or not the row is going to be kept -- the whole upper triangle streams through once, 2.3 MB at 6000 boxes;
+//   * wave 0 resolves the 64 boxes of the block-row from the diagonal words by walking only the boxes still alive
+//     (s_ff1 over a scalar word + v_readlane), the block ORs the kept rows' registers into `removed` (ds_or_b64).
+// MH_NMS_SWEEP=chain (read once per process) selects round 3's kernel below, one dependent global read per kept row and
+// column: the A/B of tools/r04/nms_time.py.  Index model of this kernel without a GPU: tests/test_nms_sweep_model.py.
+constexpr int kSweepStage = 32;     // block-rows whose diagonal words are in LDS at a time (16 KiB)
+constexpr int kSweepP = 4;          // row passes: 4 x 16 row groups = the 64 rows of a block-row
+constexpr int kSweepT = 6;          // column steps: 6 x 16 lanes = 96 columns per chunk
+
+struct SweepRegs {
+    unsigned long long w[kSweepP][kSweepT];
+};
+
+__device__ __forceinline__ void sweep_fetch(SweepRegs &s, const unsigned long long *__restrict__ mask, int base, int n,
+                                            int cb_stride, int col_blocks, int r, int jb, int rg, int cl)
+{
+    // every read is issued unconditionally (24 in flight per thread); a row or column beyond the segment reads the last valid
+    // one instead (written by nms_mask_kernel: the last column is on or right of every row's diagonal).  Such a row is never
+    // kept and such a column is never folded (sweep_fold), so the values need no zeroing here -- a select on the loaded value
+    // makes the compiler branch around each read and wait for it inside the branch.
+#pragma unroll
+    for (int p = 0; p < kSweepP; ++p) {
+        const int row = min(r * 64 + rg + 16 * p, n - 1);
+        const unsigned long long *src = mask + (size_t)(base + row) * cb_stride;
+#pragma unroll
+        for (int t = 0; t < kSweepT; ++t) s.w[p][t] = src[min(jb + cl + 16 * t, col_blocks - 1)];
+    }
+}
+
+__device__ __forceinline__ void sweep_fold(const SweepRegs &s, unsigned long long kept, unsigned long long *removed, int jb,
+                                           int col_blocks, int rg, int cl)
+{
+#pragma unroll
+    for (int t = 0; t < kSweepT; ++t) {
+        unsigned long long acc = 0ULL;
+#pragma unroll
+        for (int p = 0; p < kSweepP; ++p) acc |= ((kept >> (rg + 16 * p)) & 1ULL) ? s.w[p][t] : 0ULL;
+        const int j = jb + cl + 16 * t;
+        if (acc != 0ULL && j < col_blocks) atomicOr(removed + j, acc);
+    }
+}
+
 __global__ __launch_bounds__(256) void nms_sweep_kernel(const unsigned long long *__restrict__ mask,
                                                         const int *__restrict__ seg_offsets, int n_single,
                                                         int cb_stride, int *__restrict__ keep,
                                                         int *__restrict__ num_keep)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned long long smem[];  // removed[cb_stride] | kept word | diag stage
+    const int seg = blockIdx.x;
+    const int base = seg_offsets ? seg_offsets[seg] : 0;
+    const int n = seg_offsets ? seg_offsets[seg + 1] - base : n_single;
+    const int col_blocks = (n + 63) / 64;
+    unsigned long long *removed = smem;
+    unsigned long long *kept_word = smem + cb_stride;
+    unsigned long long *diag = smem + cb_stride + 2;              // [kSweepStage][64]
+    const int tid = threadIdx.x, rg = tid >> 4, cl = tid & 15;
+    for (int j = tid; j < col_blocks; j += 256) removed[j] = 0ULL;
+
+    SweepRegs regs;
+    if (col_blocks > 0) sweep_fetch(regs, mask, base, n, cb_stride, col_blocks, 0, 1, rg, cl);
+    int total = 0;  // meaningful in wave 0 only (uniform)
+    for (int r = 0; r < col_blocks; ++r) {
+        if (r % kSweepStage == 0) {
+            unsigned long long dv[kSweepStage / 4];
+#pragma unroll
+            for (int s = 0; s < kSweepStage / 4; ++s) {           // all reads first, then the LDS writes
+                const int row = min(r * 64 + tid + 256 * s, n - 1);
+                dv[s] = mask[(size_t)(base + row) * cb_stride + (row >> 6)];
+            }
+#pragma unroll
+            for (int s = 0; s < kSweepStage / 4; ++s) diag[tid + 256 * s] = (r * 64 + tid + 256 * s < n) ? dv[s] : 0ULL;
+            __syncthreads();
+        }
+        if (tid < 64) {
+            const int lane = tid;
+            const int rows = min(n - r * 64, 64);
+            const unsigned long long d = diag[(r % kSweepStage) * 64 + lane];
+            const unsigned dlo = (unsigned)d, dhi = (unsigned)(d >> 32);
+            unsigned long long alive_v = ~removed[r];
+            if (rows < 64) alive_v &= (1ULL << rows) - 1ULL;
+            unsigned long long alive = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(alive_v >> 32)) << 32) |
+                                       (unsigned)__builtin_amdgcn_readfirstlane((int)alive_v);
+            unsigned long long kept = 0ULL;
+            while (alive) {                                       // uniform: one trip per KEPT box of this block-row
+                const int i = __builtin_ctzll(alive);
+                kept |= 1ULL << i;
+                const unsigned lo = __builtin_amdgcn_readlane(dlo, i), hi = __builtin_amdgcn_readlane(dhi, i);
+                alive &= ~((((unsigned long long)hi << 32) | lo) | (1ULL << i));     // row i's word holds bits j > i only
+            }
+            if ((kept >> lane) & 1ULL) {
+                const int rank = __popcll(kept & ((1ULL << lane) - 1ULL));
+                keep[base + total + rank] = r * 64 + lane;
+            }
+            total += __popcll(kept);
+            if (lane == 0) kept_word[0] = kept;
+        }
+        __syncthreads();
+        const unsigned long long kept = kept_word[0];
+        // `regs` holds the chunk (r, r + 1); the chunk fetched after each fold is the next one in the order the sweep needs
+        // them: the next 96 columns of this block-row (segments beyond 6208 boxes), else the first chunk of block-row r + 1
+        int jb = r + 1;
+        do {
+            if (kept) sweep_fold(regs, kept, removed, jb, col_blocks, rg, cl);
+            jb += 16 * kSweepT;
+            if (kept && jb < col_blocks) sweep_fetch(regs, mask, base, n, cb_stride, col_blocks, r, jb, rg, cl);
+            else if (r + 1 < col_blocks) sweep_fetch(regs, mask, base, n, cb_stride, col_blocks, r + 1, r + 2, rg, cl);
+        } while (kept && jb < col_blocks);
+        __syncthreads();                                          // removed[r + 1] is final; kept_word may be rewritten
+    }
+    if (tid == 0) num_keep[seg] = total;
+}
+static size_t sweep_lds_bytes(int cb) { return (size_t)(cb + 2 + kSweepStage * 64) * 8; }
+
+// Round 3's sweep (MH_NMS_SWEEP=chain): wave 0 resolves a block-row with a 64-trip loop, then each thread ORs the kept rows'
+// words of its columns one dependent global read after the other.
+__global__ __launch_bounds__(256) void nms_sweep_chain_kernel(const unsigned long long *__restrict__ mask,
+                                                              const int *__restrict__ seg_offsets, int n_single,
+                                                              int cb_stride, int *__restrict__ keep,
+                                                              int *__restrict__ num_keep)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned long long smem[];  // [cb_stride] removed + 2 words
     const int seg = blockIdx.x;
@@ -133,6 +251,20 @@ __global__ __launch_bounds__(256) void nms_sweep_kernel(const unsigned long long
         __syncthreads();
     }
     if (tid == 0) num_keep[seg] = total;
+}
+
+static bool sweep_chain() { static const bool v = [] { const char *e = getenv("MH_NMS_SWEEP"); return e && e[0] == 'c'; }(); return v; }
+static int launch_sweep(const unsigned long long *mask, const int *seg_offsets, int nseg, int n_single, int cb, int *keep,
+                        int *num_keep, hipStream_t st)
+{
+    if (sweep_chain()) {
+        hipLaunchKernelGGL(nms_sweep_chain_kernel, dim3(nseg), dim3(256), (size_t)(cb + 2) * 8, st, mask, seg_offsets, n_single, cb,
+                           keep, num_keep);
+        return check_launch("nms_sweep_chain_kernel");
+    }
+    hipLaunchKernelGGL(nms_sweep_kernel, dim3(nseg), dim3(256), sweep_lds_bytes(cb), st, mask, seg_offsets, n_single, cb, keep,
+                       num_keep);
+    return check_launch("nms_sweep_kernel");
 }
 
 // =====================================================================================
@@ -613,9 +745,7 @@ int mh_nms(const float *boxes_sorted, int n, float thresh, int *keep, int *num_k
                        reinterpret_cast<const float4 *>(boxes_sorted), (const int *)nullptr, n, thresh, mask, cb);
     int rc = check_launch("nms_mask_kernel");
     if (rc) return rc;
-    hipLaunchKernelGGL(nms_sweep_kernel, dim3(1), dim3(256), (size_t)(cb + 2) * 8, st, mask, (const int *)nullptr, n,
-                       cb, keep, num_keep);
-    return check_launch("nms_sweep_kernel");
+    return launch_sweep(mask, nullptr, 1, n, cb, keep, num_keep, st);
 }
 
 size_t mh_nms_batched_ws_bytes(int total_boxes, int nseg, int max_seg)
@@ -642,9 +772,7 @@ int mh_nms_batched(const float *boxes_sorted, const int *seg_offsets, int nseg, 
                        reinterpret_cast<const float4 *>(boxes_sorted), seg_offsets, 0, thresh, mask, cb);
     int rc = check_launch("nms_mask_kernel(batched)");
     if (rc) return rc;
-    hipLaunchKernelGGL(nms_sweep_kernel, dim3(nseg), dim3(256), (size_t)(cb + 2) * 8, st, mask, seg_offsets, 0, cb,
-                       keep, num_keep);
-    return check_launch("nms_sweep_kernel(batched)");
+    return launch_sweep(mask, seg_offsets, nseg, 0, cb, keep, num_keep, st);
 }
 
 static void roi_norm(int H, int W, float spatial_scale, float *width, float *height)

@@ -29,28 +29,12 @@ def rel_close(got, ref, rtol=1e-4, what='', own_scale=False):
     assert err <= rtol * scale, '%s: max abs err %.3e > %.1e * %.4e' % (what, err, rtol, scale)
 
 
-def grad_close(got, ref, what='', rtol=1e-4, max_flipped_rows=0, ref64=None):
+def grad_close(got, ref, what='', rtol=1e-4, max_flipped_rows=0):
     """|got - ref| <= rtol * max|ref| (the tensor's OWN largest magnitude, no clamp), element-wise.
     max_flipped_rows > 0 (only for paths whose kink decisions are NOT forced, e.g. the detector pre-training step):
-    that many rows (first index) may exceed the bound -- they are printed with their error; the rest must hold it.
-    ref64 (callable -> the same gradient from a FLOAT64 evaluation of the oracle, same forced decisions): consulted only if
-    the fp32 comparison fails.  An ill-conditioned gradient (a BatchNorm scale over a few boxes: a sum whose terms cancel
-    40-fold) can sit farther than rtol from the fp32 oracle while being as close to the exact value as the fp32 oracle is;
-    then the bound is the product's distance from the float64 result <= max(rtol, 2 x the fp32 oracle's own distance)."""
+    that many rows (first index) may exceed the bound -- they are printed with their error; the rest must hold it."""
     got, ref = np.asarray(got, dtype=np.float64), np.asarray(ref, dtype=np.float64)
     assert got.shape == ref.shape, what
-    if ref64 is not None:
-        try:
-            return grad_close(got, ref, what=what, rtol=rtol, max_flipped_rows=max_flipped_rows)
-        except AssertionError:
-            r64 = np.asarray(ref64(), dtype=np.float64)
-            mag = float(np.abs(r64).max())
-            e_prod, e_o32 = float(np.abs(got - r64).max()), float(np.abs(ref - r64).max())
-            print('%-34s beyond %.0e of the fp32 oracle; vs the FLOAT64 oracle: product %.3e, fp32 oracle %.3e (of own max %.3e)' % (
-                what, rtol, e_prod / mag, e_o32 / mag, mag))
-            assert e_prod <= max(rtol * mag, 2.0 * e_o32), '%s: product %.3e from the float64 gradient, fp32 oracle %.3e (own max %.3e)' % (
-                what, e_prod, e_o32, mag)
-            return
     mag = float(np.abs(ref).max()) if ref.size else 0.0
     if mag == 0.0:
         assert float(np.abs(got).max() if got.size else 0.0) == 0.0, '%s: reference gradient is identically 0, got is not' % what

@@ -36,11 +36,15 @@ def rand_boxes(rs, n, hi=591.0):
 
 # ----------------------------------------------------------------------------------------------- NMS
 @pytest.mark.parametrize('n,thresh', [(0, 0.5), (1, 0.5), (2, 0.3), (63, 0.3), (64, 0.7), (65, 0.5), (129, 0.3),
-                                      (1000, 0.3), (2500, 0.5), (6000, 0.7)])
+                                      (1000, 0.3), (2500, 0.5), (6000, 0.7), (6300, 0.7), (12000, 0.7), (6000, -0.7), (6300, -0.3)])
 def test_nms_bit_exact(hip, n, thresh):
+    """sizes around every boundary of the sweep (csrc/exact_ops.hip nms_sweep_kernel): 64-box block-rows, the 32-block-row stages of
+    the diagonal words (2048 boxes), the 96-column register chunks (6208 boxes); a negative threshold = the same test on a
+    CROWDED scene (boxes within 120 px: whole block-rows without a kept box)"""
     from oracle import native
     rs = np.random.RandomState(100 + n)
-    boxes = rand_boxes(rs, n)
+    boxes = rand_boxes(rs, n) if thresh > 0 else rand_boxes(rs, n, hi=120.0)
+    thresh = abs(thresh)
     if n >= 64:
         boxes[5] = boxes[3]                 # exact duplicates (IoU == 1)
         boxes[40:44] = boxes[40] + np.float32(0.5)
