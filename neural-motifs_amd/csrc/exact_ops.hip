@@ -53,21 +53,19 @@ __global__ __launch_bounds__(64) void nms_mask_kernel(const float4 *__restrict__
     const int col_size = min(n - col_blk * 64, 64);
     const int row = row_blk * 64 + lane;
 
-    // the 64 column boxes live one per lane; lane j's box is broadcast with readlane
-    float4 cbox = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (lane < col_size) cbox = boxes[base + col_blk * 64 + lane];
+    // the column boxes are read through the scalar cache (wave-uniform address: s_load_dwordx4, eight in flight), the row box
+    // lives in the lane.  Round 3 kept the column boxes one per lane and broadcast them with four v_readlane per column.
     float4 rbox = make_float4(0.f, 0.f, 0.f, 0.f);
     if (row < n) rbox = boxes[base + row];
+    const float4 *__restrict__ cbox = boxes + base + col_blk * 64;
 
     unsigned long long t = 0;
     const int start = (row_blk == col_blk) ? lane + 1 : 0;
+#pragma unroll 8
     for (int j = 0; j < col_size; ++j) {
-        float4 cb;
-        cb.x = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, cbox.x), j));
-        cb.y = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, cbox.y), j));
-        cb.z = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, cbox.z), j));
-        cb.w = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, cbox.w), j));
-        if (j >= start && iou_p1(rbox, cb) > thresh) t |= 1ULL << j;
+        const float4 cb = cbox[j];
+        const unsigned long long hit = iou_p1(rbox, cb) > thresh;      // evaluated for every column: no branch around the read
+        t |= (hit & (unsigned long long)(j >= start)) << j;
     }
     if (row < n) mask[(size_t)(base + row) * cb_stride + col_blk] = t;
 }
