@@ -556,6 +556,8 @@ def main():
     ap.add_argument('--launch-selftest', action='store_true', help='only exercise the rank launcher / process group (no model)')
     ap.add_argument('--meter-every', type=int, default=4, help='kernel meters (HIP event pairs) record on every n-th timed step')
     ap.add_argument('--h2d-steps', type=int, default=8, help='steps of the second, H2D-inclusive timing (0 = skip)')
+    ap.add_argument('--gemm-shapes', default='', help='after the timed region: one more cfg2 step with every matrix-product call '
+                    'logged (binding, M, N, K, transposes, HIP-event time, stream) as JSON lines into this file')
     args = ap.parse_args()
 
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
@@ -683,6 +685,38 @@ def main():
         h2d = {'value': world * BATCH * args.h2d_steps / dth, 'unit': 'img/s', 'ms_per_step': 1e3 * dth / args.h2d_steps,
                'steps': args.h2d_steps, 'bytes_per_step': nbytes,
                'what': 'same step with the batch uploaded (pinned host -> HBM, async on the main stream) inside every step, unmetered'}
+
+    if args.gemm_shapes and rank == 0:
+        log = []
+
+        def logged(name, shape_of):
+            orig = getattr(_hip, name)
+
+            def call(*a, **k):
+                s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                s.record()
+                y = orig(*a, **k)
+                e.record()
+                log.append((name, shape_of(a, k, y), s, e, int(torch.cuda.current_stream().cuda_stream)))
+                return y
+            setattr(_hip, name, call)
+            return orig
+
+        def dense_shape(a, k, y):
+            ta = bool(a[2] if len(a) > 2 else k.get('trans_a', False))
+            tb = bool(a[3] if len(a) > 3 else k.get('trans_b', False))
+            return dict(M=int(y.shape[0]), N=int(y.shape[1]), K=int(a[0].shape[0] if ta else a[0].shape[1]), trans_a=ta, trans_b=tb)
+        saved = {n: logged(n, dense_shape) for n in ('gemm', 'gemm_inloop')}
+        saved['gemm_planes'] = logged('gemm_planes', lambda a, k, y: dict(M=a[0].rows, N=a[1].rows, K=a[0].K, trans_a=False, trans_b=True))
+        step(0)
+        barrier()
+        for n, f in saved.items():
+            setattr(_hip, n, f)
+        streams = sorted({r[4] for r in log})
+        with open(args.gemm_shapes, 'w') as f:
+            for name, shp, s, e, st in log:
+                f.write(json.dumps(dict(shp, binding=name, us=round(1e3 * s.elapsed_time(e), 1), stream=streams.index(st),
+                                        gflop=round(2e-9 * shp['M'] * shp['N'] * shp['K'], 2))) + '\n')
 
     if args.host_profile and rank == 0:
         # where the HOST spends a step: enqueue time without synchronisation (the GPU queue is empty at the start, so this
