@@ -404,6 +404,25 @@ int mh_bn_bwd(const float *x, const float *g, const unsigned char *argmax, long 
               const float *mean, const float *invstd, const float *gamma, int pooled, int relu_mask, float *dx,
               float *dgamma, float *dbeta, void *workspace, size_t ws_bytes, void *stream);
 
+/* The tower's FIRST convolution, direct (replaces nn.Conv2d(2, dim/2, kernel_size=7, stride=2, padding=3) + ReLU of
+ * /root/reference lib/get_union_boxes.py:31-32 on the [N,S,S,2] NHWC masks of draw_union_boxes, S = 27): thread = output
+ * channel with its 98 weights in registers, mask values through the scalar cache, exact fp32 FMAs; no column matrix.
+ *   mh_tower_conv1_out_size      : output height = width for mask size S (27 -> 14)
+ *   mh_tower_conv1_padded_bytes  : bytes of the zero-padded mask copy [N, S+6, S+6, 2] (kept for the weight gradient)
+ *   mh_tower_conv1_pad           : rects [N,S,S,2] -> padded
+ *   mh_tower_conv1_fwd           : y[N,Ho,Wo,C0] = relu(conv(padded, w) + bias); w_kc[98][C0], k = (ky*7 + kx)*2 + ci
+ *   mh_tower_conv1_wgrad         : dw_kc[99][C0]: rows 0..97 = weight gradient in w_kc's layout, row 98 = bias gradient
+ *                                  (sum of dy), from dy[N,Ho,Wo,C0]; deterministic two-stage sum; workspace >= _ws_bytes
+ * C0 a multiple of 256; Ho even and <= 16.  MH_ERR_BAD_ARG otherwise (the caller then uses mh_im2col_nhwc + mh_gemm_f32). */
+int mh_tower_conv1_out_size(int S);
+size_t mh_tower_conv1_padded_bytes(long long N, int S);
+size_t mh_tower_conv1_wgrad_ws_bytes(long long N, int C0);
+int mh_tower_conv1_pad(const float *rects_nhwc, long long N, int S, float *padded, void *stream);
+int mh_tower_conv1_fwd(const float *padded, long long N, int S, const float *w_kc, const float *bias, int C0, float *y_nhwc,
+                       void *stream);
+int mh_tower_conv1_wgrad(const float *padded, const float *dy_nhwc, long long N, int S, int C0, float *dw_kc, void *workspace,
+                         size_t ws_bytes, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -321,6 +321,138 @@ __global__ void bn_bwd_apply_kernel(const float *__restrict__ x, const float *__
     }
 }
 
+
+// ---- the tower's first convolution, direct (lib/get_union_boxes.py:31: Conv2d(2, dim/2, kernel 7, stride 2, padding 3) + ReLU) ----
+// As a column matrix + GEMM this layer wrote 120 MB of patches, read them back and ran a 301056 x 256 x 100 product at 48 TFLOP/s
+// (K = 98 does not feed a 16-deep MFMA loop; profiles/r04_gemm_shapes.jsonl: 0.14 + 0.32 ms forward, 0.39 ms weight gradient).
+// Direct form: thread = output channel (its 98 weights live in VGPRs), block = one pair's mask; the mask is read from a zero-
+// padded copy [N, S+6, S+6, 2] so that a tap needs no bounds test, and every tap address is wave-uniform: the values arrive
+// through the scalar cache (s_load_dwordxN) and enter v_fmac_f32 as SGPR operands -- no LDS, no per-lane address arithmetic.
+// Exact fp32 FMAs (no f16 split).  VALU-bound: 98 FMA per output, 7.5 G FMA per step at b = 6.
+constexpr int kT1K = 7, kT1C = 2, kT1Stride = 2, kT1Pad = 3;
+constexpr int kT1Row = kT1K * kT1C;            // 14 contiguous floats of one kernel row in the NHWC mask
+constexpr int kT1Taps = kT1K * kT1Row;         // 98
+
+__global__ __launch_bounds__(256) void tower_pad_kernel(const float2 *__restrict__ in, long long N, int S, float2 *__restrict__ out)
+{
+    const int Sp = S + 2 * kT1Pad;
+    const long long total = N * Sp * Sp;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int x = (int)(i % Sp) - kT1Pad, y = (int)((i / Sp) % Sp) - kT1Pad;
+        const long long n = i / ((long long)Sp * Sp);
+        out[i] = (x >= 0 && x < S && y >= 0 && y < S) ? in[(n * S + y) * S + x] : make_float2(0.f, 0.f);
+    }
+}
+
+// y[n, oy, ox, c] = relu(bias[c] + sum_k xp[n, 2 oy + ky, 2 ox + kx, ci] * wk[k, c]),  k = (ky * 7 + kx) * 2 + ci.
+// Two neighbouring outputs per trip: their windows share 5 of 9 columns, so one kernel row is ONE run of 18 scalar-loaded
+// floats for 28 FMAs (two independent chains) -- half the scalar-cache waits per FMA of the one-output form.
+constexpr int kT1Pair = kT1Row + kT1Stride * kT1C;       // 18 floats: the union of two windows' kernel row
+__global__ __launch_bounds__(256) void tower_conv1_fwd_kernel(const float *__restrict__ xp, int Sp, int Ho, int Wo,
+                                                              const float *__restrict__ wk, const float *__restrict__ bias, int C0,
+                                                              float *__restrict__ y)
+{
+    const int c = (int)blockIdx.y * 256 + (int)threadIdx.x;
+    float w[kT1Taps];
+#pragma unroll
+    for (int k = 0; k < kT1Taps; ++k) w[k] = wk[(size_t)k * C0 + c];
+    const float b = bias ? bias[c] : 0.f;
+    const float *__restrict__ xn = xp + (size_t)blockIdx.x * Sp * Sp * kT1C;          // wave-uniform from here on
+    float *yn = y + (size_t)blockIdx.x * Ho * Wo * C0 + c;
+    for (int oy = 0; oy < Ho; ++oy)
+        for (int ox = 0; ox < Wo; ox += 2) {                                          // Wo is even (host check)
+            const float *__restrict__ win = xn + ((size_t)(oy * kT1Stride) * Sp + ox * kT1Stride) * kT1C;
+            float a0 = b, a1 = b;
+#pragma unroll
+            for (int ky = 0; ky < kT1K; ++ky) {
+                float r[kT1Pair];
+#pragma unroll
+                for (int t = 0; t < kT1Pair; ++t) r[t] = win[(size_t)ky * Sp * kT1C + t];
+#pragma unroll
+                for (int t = 0; t < kT1Row; ++t) {
+                    a0 = fmaf(r[t], w[ky * kT1Row + t], a0);
+                    a1 = fmaf(r[t + kT1Stride * kT1C], w[ky * kT1Row + t], a1);
+                }
+            }
+            yn[(size_t)(oy * Wo + ox) * C0] = fmaxf(a0, 0.f);
+            yn[(size_t)(oy * Wo + ox + 1) * C0] = fmaxf(a1, 0.f);
+        }
+}
+
+// partial[b][k][c] = sum over the block's pairs and their Ho*Wo positions of dy[n, p, c] * xp[n, window(p), k]  (k < 98),
+// partial[b][98][c] = sum of dy[n, p, c]  (the bias gradient rides along: dy is read once).
+// The gradients of one output ROW (Wo <= 16 values per thread) are fetched while the previous row's 98 x Wo FMAs run.
+constexpr int kT1MaxW = 16;
+__global__ __launch_bounds__(256) void tower_conv1_wgrad_kernel(const float *__restrict__ xp, int Sp, int Ho, int Wo,
+                                                                const float *__restrict__ dy, long long N, int C0, int pairs_per_block,
+                                                                float *__restrict__ partial)
+{
+    const int c = (int)blockIdx.y * 256 + (int)threadIdx.x;
+    float acc[kT1Taps], accb = 0.f;
+#pragma unroll
+    for (int k = 0; k < kT1Taps; ++k) acc[k] = 0.f;
+    const long long n0 = (long long)blockIdx.x * pairs_per_block, n1 = min(N, n0 + pairs_per_block);
+    const int rows = (int)(n1 - n0) * Ho;                                  // output rows of this block, all pairs
+    const float *__restrict__ d0 = dy + (size_t)n0 * Ho * Wo * C0 + c;     // row r of the block: d0 + r * Wo * C0
+    float cur[kT1MaxW], nxt[kT1MaxW];
+#pragma unroll
+    for (int j = 0; j < kT1MaxW; ++j) cur[j] = d0[(size_t)min(j, Wo - 1) * C0];          // rows >= 1: the grid covers N exactly
+    for (int r = 0; r < rows; ++r) {
+        // every read is issued (columns beyond Wo and the row after the last re-read a valid address and are never used): with
+        // reads under a branch the compiler cannot count what is in flight and waits for ALL of it before the first FMA
+        const int rn = min(r + 1, rows - 1);
+#pragma unroll
+        for (int j = 0; j < kT1MaxW; ++j) nxt[j] = d0[((size_t)rn * Wo + min(j, Wo - 1)) * C0];
+        __builtin_amdgcn_sched_barrier(0);         // the reads stay HERE: the scheduler otherwise sinks them below the FMAs, next to their use
+        const int n = r / Ho, oy = r - n * Ho;
+        const float *__restrict__ xrow = xp + ((size_t)(n0 + n) * Sp + (size_t)oy * kT1Stride) * Sp * kT1C;
+#pragma unroll
+        for (int j = 0; j < kT1MaxW; j += 2) {
+            if (j < Wo) {                                                  // wave-uniform; Wo is even (host check)
+                const float *__restrict__ win = xrow + (size_t)j * kT1Stride * kT1C;
+                const float v0 = cur[j], v1 = cur[j + 1];
+                accb += v0 + v1;
+#pragma unroll
+                for (int ky = 0; ky < kT1K; ++ky) {
+                    float x[kT1Pair];
+#pragma unroll
+                    for (int t = 0; t < kT1Pair; ++t) x[t] = win[(size_t)ky * Sp * kT1C + t];
+#pragma unroll
+                    for (int t = 0; t < kT1Row; ++t) {
+                        acc[ky * kT1Row + t] = fmaf(x[t], v0, acc[ky * kT1Row + t]);
+                        acc[ky * kT1Row + t] = fmaf(x[t + kT1Stride * kT1C], v1, acc[ky * kT1Row + t]);
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < kT1MaxW; ++j) cur[j] = nxt[j];
+    }
+    float *out = partial + (size_t)blockIdx.x * (kT1Taps + 1) * C0 + c;
+#pragma unroll
+    for (int k = 0; k < kT1Taps; ++k) out[(size_t)k * C0] = acc[k];
+    out[(size_t)kT1Taps * C0] = accb;
+}
+
+// dwk[k][c] = sum_b partial[b][k][c]: fixed order, deterministic
+__global__ __launch_bounds__(256) void tower_conv1_wgrad_reduce_kernel(const float *__restrict__ partial, int nblk, int rows_c0,
+                                                                       float *__restrict__ dwk)
+{
+    const int i = (int)blockIdx.x * 256 + (int)threadIdx.x;
+    if (i >= rows_c0) return;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int b = 0;
+    for (; b + 3 < nblk; b += 4) {
+        s0 += partial[(size_t)b * rows_c0 + i];
+        s1 += partial[(size_t)(b + 1) * rows_c0 + i];
+        s2 += partial[(size_t)(b + 2) * rows_c0 + i];
+        s3 += partial[(size_t)(b + 3) * rows_c0 + i];
+    }
+    for (; b < nblk; ++b) s0 += partial[(size_t)b * rows_c0 + i];
+    dwk[i] = (s0 + s1) + (s2 + s3);
+}
+constexpr int kT1PairsPerBlock = 3;
+
 static int grid_for(long long total) { return (int)std::min<long long>((total + 255) / 256, 256 * 16); }
 
 }  // namespace mh
@@ -444,6 +576,68 @@ int mh_bn_bwd(const float *x, const float *g, const unsigned char *argmax, long 
         hipLaunchKernelGGL((bn_bwd_apply_kernel<false>), dim3(grid_for(M * (C / 4))), dim3(256), 0, st, x, g, argmax, mean,
                            invstd, gamma, dgamma, dbeta, N, H, W, C, relu_mask, dx);
     return check_launch("bn_bwd_apply_kernel");
+}
+
+// ---- the tower's first convolution, direct: see tower_conv1_fwd_kernel ----
+static int check_t1(long long N, int S, int C0)
+{
+    MH_REQUIRE(N > 0 && N <= 0x7fffffffLL / 4 && S >= kT1K - 2 * kT1Pad && S <= 4096 && C0 > 0 && C0 % 256 == 0 && C0 <= 256 * 65535);
+    MH_REQUIRE((S + 2 * kT1Pad - kT1K) % kT1Stride == 0);      // the last window ends on the last padded column (S = 27: 14 x 14 outputs)
+    const int Ho = (S + 2 * kT1Pad - kT1K) / kT1Stride + 1;
+    MH_REQUIRE(Ho % 2 == 0 && Ho <= kT1MaxW);                   // outputs are produced in pairs; a row of gradients lives in registers
+    return MH_OK;
+}
+int mh_tower_conv1_out_size(int S) { return (S + 2 * kT1Pad - kT1K) / kT1Stride + 1; }
+size_t mh_tower_conv1_padded_bytes(long long N, int S)
+{
+    if (N <= 0 || S <= 0) return 0;
+    const size_t Sp = (size_t)S + 2 * kT1Pad;
+    return align_up((size_t)N * Sp * Sp * kT1C * sizeof(float), 256);
+}
+size_t mh_tower_conv1_wgrad_ws_bytes(long long N, int C0)
+{
+    if (N <= 0 || C0 <= 0) return 0;
+    const size_t nblk = (size_t)ceil_div(N, (long long)kT1PairsPerBlock);
+    return align_up(nblk * (kT1Taps + 1) * (size_t)C0 * sizeof(float), 256);
+}
+int mh_tower_conv1_pad(const float *rects_nhwc, long long N, int S, float *padded, void *stream)
+{
+    int rc = check_t1(N, S, 256);
+    if (rc) return rc;
+    MH_REQUIRE(rects_nhwc && padded && ((reinterpret_cast<uintptr_t>(rects_nhwc) | reinterpret_cast<uintptr_t>(padded)) & 7) == 0);
+    const long long Sp = S + 2 * kT1Pad;
+    hipLaunchKernelGGL(tower_pad_kernel, dim3(grid_for(N * Sp * Sp)), dim3(256), 0, as_stream(stream),
+                       reinterpret_cast<const float2 *>(rects_nhwc), N, S, reinterpret_cast<float2 *>(padded));
+    return check_launch("tower_pad_kernel");
+}
+int mh_tower_conv1_fwd(const float *padded, long long N, int S, const float *w_kc, const float *bias, int C0, float *y_nhwc,
+                       void *stream)
+{
+    int rc = check_t1(N, S, C0);
+    if (rc) return rc;
+    MH_REQUIRE(padded && w_kc && y_nhwc);
+    const int Ho = mh_tower_conv1_out_size(S);
+    hipLaunchKernelGGL(tower_conv1_fwd_kernel, dim3((unsigned)N, (unsigned)(C0 / 256)), dim3(256), 0, as_stream(stream), padded,
+                       S + 2 * kT1Pad, Ho, Ho, w_kc, bias, C0, y_nhwc);
+    return check_launch("tower_conv1_fwd_kernel");
+}
+int mh_tower_conv1_wgrad(const float *padded, const float *dy_nhwc, long long N, int S, int C0, float *dw_kc, void *workspace,
+                         size_t ws_bytes, void *stream)
+{
+    int rc = check_t1(N, S, C0);
+    if (rc) return rc;
+    MH_REQUIRE(padded && dy_nhwc && dw_kc && workspace && ws_bytes >= mh_tower_conv1_wgrad_ws_bytes(N, C0));
+    hipStream_t st = as_stream(stream);
+    const int Ho = mh_tower_conv1_out_size(S);
+    const int nblk = (int)ceil_div(N, (long long)kT1PairsPerBlock);
+    float *partial = reinterpret_cast<float *>(workspace);
+    hipLaunchKernelGGL(tower_conv1_wgrad_kernel, dim3((unsigned)nblk, (unsigned)(C0 / 256)), dim3(256), 0, st, padded, S + 2 * kT1Pad, Ho,
+                       Ho, dy_nhwc, N, C0, kT1PairsPerBlock, partial);
+    rc = check_launch("tower_conv1_wgrad_kernel");
+    if (rc) return rc;
+    const int rows_c0 = (kT1Taps + 1) * C0;
+    hipLaunchKernelGGL(tower_conv1_wgrad_reduce_kernel, dim3(ceil_div(rows_c0, 256)), dim3(256), 0, st, partial, nblk, rows_c0, dw_kc);
+    return check_launch("tower_conv1_wgrad_reduce_kernel");
 }
 
 }  // extern "C"

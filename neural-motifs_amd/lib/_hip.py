@@ -37,6 +37,8 @@ SYMBOLS = (
     'mh_fault_pending', 'mh_fault_clear', 'mh_debug_lstm_barrier_fault',
     'mh_opt_chunk_elems', 'mh_opt_skipped_steps', 'mh_opt_skipped_clear', 'mh_opt_build_chunks', 'mh_multi_sumsq', 'mh_multi_sgd_step',
     'mh_bn_ws_bytes', 'mh_bn_stats', 'mh_bn_pool_fwd', 'mh_bn_residual_nchw', 'mh_bn_apply_nhwc', 'mh_nchw_to_nhwc_small', 'mh_bn_bwd',
+    'mh_tower_conv1_out_size', 'mh_tower_conv1_padded_bytes', 'mh_tower_conv1_wgrad_ws_bytes', 'mh_tower_conv1_pad', 'mh_tower_conv1_fwd',
+    'mh_tower_conv1_wgrad',
 )
 
 _lib = None
@@ -63,7 +65,8 @@ def lib():
                      'mh_plconv3x3_ws_bytes', 'mh_conv3x3_ws_bytes', 'mh_bn_ws_bytes',
                      'mh_conv3x3_packed_floats', 'mh_hwcell_seq_ws_bytes', 'mh_conv3x3_wgrad_ws_bytes',
                      'mh_hwlstm_fwd_ws_bytes', 'mh_hwlstm_bwd_ws_bytes',
-                     'mh_decoder_greedy_ws_bytes', 'mh_decoder_nms_commit_max_bytes'):
+                     'mh_decoder_greedy_ws_bytes', 'mh_decoder_nms_commit_max_bytes', 'mh_tower_conv1_padded_bytes',
+                     'mh_tower_conv1_wgrad_ws_bytes'):
             getattr(L, name).restype = ctypes.c_size_t
         _lib = L
     return _lib
@@ -764,3 +767,44 @@ def bn_bwd(x, g, argmax, mean, invstd, gamma, relu_mask):
                            c_int(int(argmax is not None)), c_int(int(relu_mask)), f32(dx), f32(dgamma), f32(dbeta),
                            ptr(ws), c_size_t(ws.numel()), stream()), 'mh_bn_bwd')
     return dx, dgamma, dbeta
+
+
+# ----------------------------------------------------------------------------------------------- tower conv 1, direct
+def tower_conv1_supported(rects_nhwc, weight):
+    """the direct kernels cover the reference's layer (7x7, stride 2, padding 3, 2 input channels) for C0 % 256 == 0 and an
+    even output size <= 16 (S = 27 -> 14)"""
+    C0, Ci, kh, kw = weight.shape
+    S = rects_nhwc.shape[1]
+    if not (Ci == 2 and kh == 7 and kw == 7 and rects_nhwc.shape[2] == S and rects_nhwc.shape[3] == 2 and C0 % 256 == 0
+            and rects_nhwc.shape[0] > 0 and rects_nhwc.dtype == torch.float32):
+        return False
+    Ho = (S + 6 - 7) // 2 + 1
+    return (S + 6 - 7) % 2 == 0 and Ho % 2 == 0 and Ho <= 16
+
+
+def tower_conv1_pad(rects_nhwc):
+    """[N,S,S,2] fp32 -> the zero-padded copy [N,S+6,S+6,2] both direct kernels read"""
+    N, S = rects_nhwc.shape[0], rects_nhwc.shape[1]
+    xp = torch.empty(N, S + 6, S + 6, 2, dtype=torch.float32, device=rects_nhwc.device)
+    _check(lib().mh_tower_conv1_pad(f32(rects_nhwc), c_ll(N), S, f32(xp), stream()), 'mh_tower_conv1_pad')
+    return xp
+
+
+def tower_conv1_fwd(xp, w_kc, bias):
+    """relu(conv7x7/2(xp) + bias): xp from tower_conv1_pad, w_kc [98, C0] (k = (ky*7 + kx)*2 + ci) -> y [N,Ho,Wo,C0]"""
+    N, S, C0 = xp.shape[0], xp.shape[1] - 6, w_kc.shape[1]
+    Ho = lib().mh_tower_conv1_out_size(S)
+    y = torch.empty(N, Ho, Ho, C0, dtype=torch.float32, device=xp.device)
+    _check(lib().mh_tower_conv1_fwd(f32(xp), c_ll(N), S, f32(w_kc), f32(bias), C0, f32(y), stream()), 'mh_tower_conv1_fwd')
+    return y
+
+
+def tower_conv1_wgrad(xp, dy):
+    """dy [N,Ho,Wo,C0] -> (dw_kc [98,C0], db [C0])"""
+    N, S, C0 = xp.shape[0], xp.shape[1] - 6, dy.shape[3]
+    L = lib()
+    out = torch.empty(99, C0, dtype=torch.float32, device=xp.device)
+    ws = workspace(L.mh_tower_conv1_wgrad_ws_bytes(c_ll(N), C0), xp.device, 'tower')
+    _check(L.mh_tower_conv1_wgrad(f32(xp), f32(dy), c_ll(N), S, C0, f32(out), ptr(ws), c_size_t(ws.numel()), stream()),
+           'mh_tower_conv1_wgrad')
+    return out[:98], out[98]

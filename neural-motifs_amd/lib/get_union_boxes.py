@@ -7,6 +7,8 @@ reference :47-50), the tower runs in NHWC on the MFMA GEMM / implicit-GEMM conv 
 as a logical [N,C,7,7] tensor (channels_last memory) so that `Flattener` + fc6 see the reference's (c,y,x) order.
 State-dict keys are the reference's: conv.{0,2,4,6}.*
 """
+import os
+
 import torch
 from torch import nn
 from torch.nn import functional as F
@@ -32,6 +34,12 @@ class _MaxPoolNHWC(nn.MaxPool2d):
         return y.permute(0, 2, 3, 1)
 
 
+# the tower's first convolution: 'direct' = csrc/tower.hip tower_conv1_* (mask values through the scalar cache, exact fp32 FMAs, no
+# column matrix; shapes the kernels do not cover fall through to the other path), 'gemm' = im2col + the in-loop-split GEMM of
+# rounds 1-3.  MOTIFS_TOWER_CONV1=gemm for A/B runs (gpurun r04_c21: 17.12 vs 17.26 ms per cfg2 step, p50 16.67 vs 16.98).
+TOWER_CONV1 = os.environ.get('MOTIFS_TOWER_CONV1', 'direct')
+
+
 # test hook (tests/parity_util.py): a dict here receives the tower's ReLU masks and pool arg-max table of the next forward,
 # so that the parity tests can hand the oracle the product's own kink decisions (oracle/model.py: TAPS)
 TAPS = None
@@ -47,11 +55,17 @@ class _TowerFn(torch.autograd.Function):
         N = rects.shape[0]
         C0, C1 = w0.shape[0], w4.shape[0]
         K0 = w0.shape[1] * w0.shape[2] * w0.shape[3]
-        ld0 = (K0 + 3) // 4 * 4
-        cols0, Ho, Wo = _hip.im2col_nhwc(rects.contiguous(), w0.shape[2], w0.shape[3], 2, 3, ldo=ld0)
-        wmat = w0.new_zeros(C0, ld0)
-        wmat[:, :K0] = w0.permute(0, 2, 3, 1).reshape(C0, K0)
-        y0 = _hip.gemm(cols0, wmat, False, True, bias=b0, epilogue=EPI_RELU).view(N, Ho, Wo, C0)
+        rects = rects.contiguous()
+        ctx.direct = TOWER_CONV1 == 'direct' and _hip.tower_conv1_supported(rects, w0)
+        if ctx.direct:
+            cols0 = _hip.tower_conv1_pad(rects)                  # zero-padded masks (13 MB at 1536 pairs), kept for the weight gradient
+            y0 = _hip.tower_conv1_fwd(cols0, w0.permute(2, 3, 1, 0).reshape(K0, C0).contiguous(), b0)
+        else:
+            ld0 = (K0 + 3) // 4 * 4
+            cols0, Ho, Wo = _hip.im2col_nhwc(rects, w0.shape[2], w0.shape[3], 2, 3, ldo=ld0)
+            wmat = w0.new_zeros(C0, ld0)
+            wmat[:, :K0] = w0.permute(0, 2, 3, 1).reshape(C0, K0)
+            y0 = _hip.gemm(cols0, wmat, False, True, bias=b0, epilogue=EPI_RELU).view(N, Ho, Wo, C0)
 
         def stats(x2d, bn):
             if training:
@@ -88,9 +102,14 @@ class _TowerFn(torch.autograd.Function):
         dw4 = dw4.view(C1, 3, 3, w4.shape[1]).permute(0, 3, 1, 2).contiguous()
         db4 = dx2.view(-1, C1).sum(0)
         dx1, dg1, db1 = _hip.bn_bwd(y0, dz, arg, mean1, invstd1, g1, True)               # pool + BN1 + conv.0's ReLU
-        dwm = _hip.gemm(dx1.view(-1, C0), cols0, True, False)
-        dw0 = dwm[:, :K0].reshape(C0, w0.shape[2], w0.shape[3], w0.shape[1]).permute(0, 3, 1, 2).contiguous()
-        db0 = dx1.view(-1, C0).sum(0)
+        if ctx.direct:
+            dwk, db0 = _hip.tower_conv1_wgrad(cols0, dx1)                    # [K0, C0] in (ky, kx, ci) order + the bias gradient
+            dw0 = dwk.view(w0.shape[2], w0.shape[3], w0.shape[1], C0).permute(3, 2, 0, 1).contiguous()
+            db0 = db0.clone()
+        else:
+            dwm = _hip.gemm(dx1.view(-1, C0), cols0, True, False)
+            dw0 = dwm[:, :K0].reshape(C0, w0.shape[2], w0.shape[3], w0.shape[1]).permute(0, 3, 1, 2).contiguous()
+            db0 = dx1.view(-1, C0).sum(0)
         d_up = dout if ctx.needs_input_grad[1] else None
         return None, d_up, dw0, db0, dg1, db1, dw4, db4, dg2, db2, None, None, None
 

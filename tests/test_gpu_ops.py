@@ -343,6 +343,61 @@ def test_im2col_conv7x7_stride2(hip):
     np.testing.assert_allclose(out.cpu().numpy(), ref.numpy(), atol=1e-4)
 
 
+@pytest.mark.parametrize('N,C0', [(1, 256), (37, 256), (200, 512)])
+def test_tower_conv1_direct_forward_and_weight_gradient(hip, N, C0):
+    """csrc/tower.hip tower_conv1_*: the mask tower's 7x7 / stride 2 convolution without a column matrix (mask values through
+    the scalar cache, exact fp32 FMAs) against torch's conv2d in float64; N = 37 and 200 leave a partial last block of the
+    weight-gradient grid (3 pairs per block), C0 = 512 is the ResNet tower (two channel groups)."""
+    g = torch.Generator().manual_seed(N)
+    rects = torch.rand(N, 27, 27, 2, generator=g)
+    rects[:, :5] = 0                                               # masks are exactly zero outside their box
+    w = (torch.randn(C0, 2, 7, 7, generator=g) * 0.1).requires_grad_(True)
+    b = (torch.randn(C0, generator=g) * 0.1).requires_grad_(True)
+    dy = torch.randn(N, 14, 14, C0, generator=g)
+    pre = F.conv2d(rects.permute(0, 3, 1, 2).double(), w.double(), b.double(), stride=2, padding=3)
+    pre.backward(dy.permute(0, 3, 1, 2).double())
+    assert hip.tower_conv1_supported(rects, w)
+    xp = hip.tower_conv1_pad(rects.cuda())
+    assert tuple(xp.shape) == (N, 33, 33, 2)
+    np.testing.assert_array_equal(xp[:, 3:30, 3:30].cpu().numpy(), rects.numpy())
+    assert float(xp[:, :3].abs().max()) == 0.0 and float(xp[:, :, 30:].abs().max()) == 0.0
+    y = hip.tower_conv1_fwd(xp, w.detach().permute(2, 3, 1, 0).reshape(98, C0).contiguous().cuda(), b.detach().cuda())
+    ref = F.relu(pre).detach().permute(0, 2, 3, 1).float().numpy()
+    np.testing.assert_allclose(y.cpu().numpy(), ref, atol=2e-6 * max(1.0, float(np.abs(ref).max())))
+    dwk, db = hip.tower_conv1_wgrad(xp, dy.cuda())
+    dw0 = dwk.view(7, 7, 2, C0).permute(3, 2, 0, 1).cpu().numpy()
+    np.testing.assert_allclose(dw0, w.grad.numpy(), atol=3e-6 * float(w.grad.abs().max()))
+    np.testing.assert_allclose(db.cpu().numpy(), b.grad.numpy(), atol=3e-6 * float(b.grad.abs().max()))
+
+
+def test_mask_tower_direct_and_gemm_first_convolution_agree(hip, monkeypatch):
+    """the whole tower node (forward + every gradient) with its first convolution on the direct kernels and on im2col + GEMM"""
+    import lib.get_union_boxes as GUB
+    torch.manual_seed(5)
+    N = 96
+    tower = GUB.UnionBoxesAndFeats(pooling_size=7, stride=16, dim=512).cuda().train()
+    rects = torch.rand(N, 27, 27, 2).cuda()
+    pools = torch.randn(N, 512, 7, 7).cuda()
+    gout = torch.randn(N, 512, 7, 7).cuda()
+    res = {}
+    for mode in ('gemm', 'direct'):
+        monkeypatch.setattr(GUB, 'TOWER_CONV1', mode)
+        for bn in (tower.conv[2], tower.conv[6]):
+            bn.reset_running_stats()
+        tower.zero_grad(set_to_none=True)
+        c = tower.conv
+        out = GUB._TowerFn.apply(rects, pools, c[0].weight, c[0].bias, c[2].weight, c[2].bias, c[4].weight, c[4].bias,
+                                 c[6].weight, c[6].bias, c[2], c[6], True)
+        out.backward(gout)
+        res[mode] = [out.detach().clone()] + [p.grad.detach().clone() for p in tower.parameters()]
+    # the two paths round differently (f16x3 product vs exact fp32 FMAs): a unit within rounding of a ReLU kink may take the other
+    # branch in the backward mask, which moves ONE channel row of the first convolution's gradients -- a few such rows are allowed
+    from parity_util import grad_close
+    names = ['output'] + [n for n, _ in tower.named_parameters()]
+    for name, a, d in zip(names, res['gemm'], res['direct']):
+        grad_close(d.cpu().numpy(), a.cpu().numpy(), what='tower ' + name, rtol=2e-4, max_flipped_rows=3)
+
+
 # ----------------------------------------------------------------------------------------------- LSTM
 def _lstm_problem(lengths, in_size, H, nl, seed, p=0.0):
     from oracle import lstm as OL
