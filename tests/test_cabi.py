@@ -113,3 +113,45 @@ def test_no_packed_fp32_valu_outside_the_tile_engines(tmp_path):
     asm = open(out).read()
     assert 'roi_align_fwd_nhwc' in asm
     assert not re.search(r'\bv_pk_(add|mul|fma)_f32\b', asm)
+
+
+def _device_asm(mod, src, tmp_path):
+    import subprocess
+    out = str(tmp_path / (src + '.s'))
+    subprocess.check_call([mod.HIPCC] + mod.compile_flags(src) + ['-S', '--cuda-device-only', '-w', '-o', out, os.path.join(mod.HERE, src)],
+                          stderr=subprocess.DEVNULL)
+    return open(out).read()
+
+
+def _kernel_body(asm, mangled_fragment):
+    """text of the first kernel whose symbol contains `mangled_fragment`, from its label to s_endpgm"""
+    m = re.search(r'^(_Z\w*%s\w*):[^\n]*\n(.*?)s_endpgm' % re.escape(mangled_fragment), asm, flags=re.S | re.M)
+    assert m, mangled_fragment
+    return m.group(2)
+
+
+def test_latency_critical_kernels_keep_their_load_structure(tmp_path):
+    """What the measured speed of three kernels rests on is decided by the compiler, not by the source alone (DESIGN.md 5.3,
+    7.4): the NMS sweep must issue its 24 mask reads per thread back to back (no branch / wait between them), the direct tower
+    convolution must take its mask values through the scalar cache into SGPR operands and keep its 98 weights in registers
+    (no scratch).  A compiler that decides otherwise makes them several times slower without failing a single numerics test."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location('mh_build_flags2', os.path.join(ROOT, 'neural-motifs_amd', 'csrc', 'build.py'))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    asm = _device_asm(mod, 'exact_ops.hip', tmp_path)
+    sweep = _kernel_body(asm, 'nms_sweep_kernel')
+    runs = [len(r.split('global_load_dwordx2')) - 1 for r in re.split(r's_waitcnt vmcnt|s_cbranch|s_barrier', sweep)]
+    assert max(runs) >= 24, 'the sweep no longer fetches a whole chunk (24 reads per thread) without a wait or branch in between: %s' % runs
+    assert 'ds_or_b64' in sweep and 's_ff1_i32_b64' in sweep
+    mask = _kernel_body(asm, 'nms_mask_kernel')
+    assert 'v_readlane' not in mask and re.search(r's_load_dwordx(8|16)', mask)
+    asm = _device_asm(mod, 'tower.hip', tmp_path)
+    for frag, fmas in (('tower_conv1_fwd_kernel', 196), ('tower_conv1_wgrad_kernel', 196)):
+        body = _kernel_body(asm, frag)
+        assert len(re.findall(r'\bv_fma(c)?_f32', body)) >= fmas, frag
+        assert re.search(r's_load_dwordx16', body), frag + ': mask values no longer come through the scalar cache'
+        assert re.search(r'v_fmac_f32_e32 v\d+, s\d+, v\d+', body), frag + ': no SGPR operand in the FMAs'
+    for name in ('tower_conv1_fwd_kernel', 'tower_conv1_wgrad_kernel'):
+        m = re.search(r'\.amdhsa_kernel \w*%s\w*\n(.*?)\.end_amdhsa_kernel' % name, asm, flags=re.S)
+        assert m and re.search(r'\.amdhsa_private_segment_fixed_size 0\b', m.group(1)), name + ' spills to scratch'
