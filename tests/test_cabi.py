@@ -80,6 +80,33 @@ def test_argument_validation_needs_no_device(so_path):
     rec = (ctypes.c_uint64 * 4)(0, 0, 0, 0)                    # {p, g, buf} = NULL, n = 0: rejected before any launch
     assert lib.mh_opt_build_chunks(rec, 1, ctypes.c_void_p(1 << 20), 1, None) == -1
     assert lib.mh_roi_align_bwd_det(None, 1, 2048, 4, 4, 1, None, 1, 7, 7, ctypes.c_float(1.0), None, None) == -1
+    # the direct first convolution of the mask tower: sizes, and the shapes it refuses (the caller then takes im2col + GEMM)
+    ll = ctypes.c_longlong
+    lib.mh_tower_conv1_padded_bytes.restype = ctypes.c_size_t
+    lib.mh_tower_conv1_wgrad_ws_bytes.restype = ctypes.c_size_t
+    assert lib.mh_tower_conv1_out_size(27) == 14
+    assert lib.mh_tower_conv1_padded_bytes(ll(1536), 27) >= 1536 * 33 * 33 * 2 * 4
+    assert lib.mh_tower_conv1_wgrad_ws_bytes(ll(1536), 256) >= 512 * 99 * 256 * 4
+    one = ctypes.c_void_p(1 << 20)
+    assert lib.mh_tower_conv1_fwd(one, ll(4), 27, one, None, 128, one, None) == -1          # C0 not a multiple of 256
+    assert lib.mh_tower_conv1_fwd(one, ll(4), 28, one, None, 256, one, None) == -1          # windows do not tile the padded mask
+    assert lib.mh_tower_conv1_fwd(one, ll(4), 39, one, None, 256, one, None) == -1          # 20 outputs per row: beyond the register row
+    assert lib.mh_tower_conv1_fwd(None, ll(4), 27, one, None, 256, one, None) == -1
+    assert lib.mh_tower_conv1_wgrad(one, one, ll(4), 27, 256, one, one, ctypes.c_size_t(16), None) == -1      # workspace too small
+    assert lib.mh_tower_conv1_pad(one, ll(0), 27, one, None) == -1
+
+
+def test_direct_tower_convolution_is_chosen_only_for_the_shapes_it_covers():
+    from lib import _hip
+    w = torch.zeros(256, 2, 7, 7)
+    assert _hip.tower_conv1_supported(torch.zeros(5, 27, 27, 2), w)
+    assert _hip.tower_conv1_supported(torch.zeros(5, 27, 27, 2), torch.zeros(512, 2, 7, 7))       # the ResNet tower
+    assert not _hip.tower_conv1_supported(torch.zeros(0, 27, 27, 2), w)                           # no pairs: the old path handles it
+    assert not _hip.tower_conv1_supported(torch.zeros(5, 27, 27, 2), torch.zeros(128, 2, 7, 7))   # default dim = 256 -> 128 channels
+    assert not _hip.tower_conv1_supported(torch.zeros(5, 27, 27, 2), torch.zeros(256, 2, 3, 3))
+    assert not _hip.tower_conv1_supported(torch.zeros(5, 28, 28, 2), w)
+    assert not _hip.tower_conv1_supported(torch.zeros(5, 39, 39, 2), w)
+    assert not _hip.tower_conv1_supported(torch.zeros(5, 27, 27, 2, dtype=torch.float64), w)
 
 
 @pytest.mark.skipif(torch.cuda.is_available(), reason='checks the no-GPU failure mode')
