@@ -154,6 +154,24 @@ int mh_gemm_auto_splitk_v2(int M, int N, int K);
 int mh_gemm_f32_v2(int transA, int transB, int M, int N, int K, const float *A, int lda,
                    const float *B, int ldb, float *C, int ldc, const float *bias, int epilogue,
                    int accumulate, int splitk, void *workspace, size_t ws_bytes, void *stream);
+/* The small-product engine (round 5; csrc/gemm.hip): ONE launch per product for everything mh_gemm_f32 does not put on plane
+ * images -- the ~40 small / skinny nn.Linear-shaped products of a step (lib/rel_model.py:171-296,500-524: obj_embed, pos_embed,
+ * post_lstm, rel_compress, the trainable object fc6/fc7; lib/lstm/decoder_rnn.py:96-131; their input and weight gradients).
+ * Same contract as mh_gemm_f32 (fp32 operands in any of the four orientations, bias / activation / accumulate), evaluated as
+ * "bf16x6": each fp32 operand element is the exact sum of three bf16 terms (round to nearest), six v_mfma_f32_32x32x16_bf16
+ * per accumulator and k-tile, fp32 accumulate -- no power-of-two row scales, hence no pass over the operands for their row
+ * maxima in front of the product (what f16x3 needs: mh_gemm_f32_v2 = the same kernel family behind MH_SMALL_GEMM=f16x3).
+ *   counters / n_counters   split-K arrival counters, one int per 128x128 (N <= 64: 256x64) output tile: ZERO on entry, left
+ *                           ZERO on return; the last K slice of a tile to finish adds the slices in slice order (bit-identical
+ *                           for any arrival order) and applies the epilogue inside the GEMM launch.  One array per HIP stream
+ *                           (products on different streams may run concurrently).  NULL / too few: the reduction is a second
+ *                           launch.  mh_gemm_small_max_counters() = the largest number ever used.
+ *   workspace               >= mh_gemm_ws_bytes_v2(M, N, K, splitk) (split-K partial sums), 256-byte aligned */
+int mh_gemm_small_max_counters(void);
+int mh_gemm_small_f32(int transA, int transB, int M, int N, int K, const float *A, int lda,
+                      const float *B, int ldb, float *C, int ldc, const float *bias, int epilogue,
+                      int accumulate, int splitk, void *workspace, size_t ws_bytes, int *counters,
+                      int n_counters, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
  * The trunk's 3x3 convolutions on the plane engine (round 3; csrc/pl_conv.hip).  Replaces cuDNN for

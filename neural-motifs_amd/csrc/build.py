@@ -16,9 +16,12 @@ SO = os.path.join(HERE, 'libmotifs_hip.so')
 ARCH = 'gfx950'
 EXACT = ('exact_ops.hip',)
 SOURCES = ('exact_ops.hip', 'gemm.hip', 'pl_gemm.hip', 'pl_conv.hip', 'conv.hip', 'lstm.hip', 'optim.hip', 'tower.hip')
-HEADERS = ('common.h', 'mfma_tile.h', 'pl_tile.h', os.path.join('..', '..', 'include', 'motifs_hip.h'))
+HEADERS = ('common.h', 'mfma_tile.h', 'pl_tile.h', 'pl_ring.h', os.path.join('..', '..', 'include', 'motifs_hip.h'))
 HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
-PACKED_OK = ('gemm.hip', 'conv.hip', 'pl_gemm.hip', 'pl_conv.hip')     # see build(): packed FP32 VALU ops only here
+PACKED_OK = ('conv.hip', 'pl_gemm.hip', 'pl_conv.hip')     # see build(): packed FP32 VALU ops only here
+# (gemm.hip left this list in round 5: its bf16x6 split is subtractions of a widened bf16 from the fp32 value -- the compiler
+# pairs them into v_pk_add_f32 with a neg modifier, the very instruction class that went wrong under MFMA co-residency, and
+# the small products run on the side stream next to the main stream's chip-filling MFMA kernels all the time)
 
 
 def _stale(target, deps):

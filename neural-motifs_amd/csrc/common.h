@@ -30,6 +30,16 @@ inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
 constexpr int kWave = 64;  // CDNA wavefront
 
+// the small-product engine (gemm.hip; include/motifs_hip.h: mh_gemm_small_f32) and the library-internal form of mh_gemm_f32
+// (pl_gemm.hip) that hands split-K arrival counters (zero on entry, left zero) to it when the product is a small one
+constexpr int kGemmCounters = 4096;
+int gemm_small(int transA, int transB, int M, int N, int K, const float *A, int lda, const float *B, int ldb, float *C, int ldc,
+               const float *bias, int epilogue, int accumulate, void *workspace, size_t ws_bytes, int *counters, int n_counters,
+               void *stream);
+int gemm_f32_ctr(int transA, int transB, int M, int N, int K, const float *A, int lda, const float *B, int ldb, float *C, int ldc,
+                 const float *bias, int epilogue, int accumulate, void *workspace, size_t ws_bytes, int *counters, int n_counters,
+                 void *stream);
+
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 

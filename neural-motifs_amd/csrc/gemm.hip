@@ -27,6 +27,8 @@ struct GemmArgs {
     int tiles_m, tiles_n;
     int patch_h, patch_w;     // patch-major tile order (mfma_tile.h: patch_tile)
     const int *expA, *expB;   // f16x3: power-of-two exponent per row of op(A) [M] and per column of op(B) [N]
+    int *counters;            // split-K, fused reduction: one arrival counter per output tile (zero on entry, left zero), or NULL
+    int vecC4;                // C rows 16-byte aligned (fused reduction: float4 stores)
 };
 
 __device__ __forceinline__ float apply_epi(float v, int epilogue)
@@ -36,7 +38,11 @@ __device__ __forceinline__ float apply_epi(float v, int epilogue)
     return v;
 }
 
-template <bool TA, bool TB, int BM, int BN, bool FAST>
+// SP = kSplitF16x3: the operands' row maxima (expA / expB) must have been computed by a pass in front of this kernel;
+// SP = kSplitBf16x6: no scales, the kernel is the whole product (mfma_tile.h).
+// Split-K (blockIdx.y = K slice) with p.counters: the LAST block to finish a tile adds the slices' partial sums in slice
+// order (bit-identical to splitk_reduce_kernel, whatever the arrival order) and applies bias / activation -- no reduce launch.
+template <bool TA, bool TB, int BM, int BN, bool FAST, int SP = kSplitF16x3>
 __global__ __launch_bounds__(kThreads, MH_MINW) void gemm_kernel(const GemmArgs p)
 {
     constexpr bool AWM = !TA, BWM = TB;          // K-contiguous global storage -> width-major LDS tile
@@ -101,14 +107,17 @@ __global__ __launch_bounds__(kThreads, MH_MINW) void gemm_kernel(const GemmArgs 
     };
     StageExp<BM> ea;
     StageExp<BN> eb;
-    load_stage_exp<BM>(ea, p.expA, m0, p.M, AWM, tid, true);     // the arrays hold |x| maxima as bit patterns
-    load_stage_exp<BN>(eb, p.expB, n0, p.N, BWM, tid, true);
+    if (SP == kSplitF16x3) {
+        load_stage_exp<BM>(ea, p.expA, m0, p.M, AWM, tid, true);     // the arrays hold |x| maxima as bit patterns
+        load_stage_exp<BN>(eb, p.expB, n0, p.N, BWM, tid, true);
+    }
     auto store_tiles = [&](const Stage<BM> &sa, const Stage<BN> &sb, int buf) {
-        if (TA) store_km<BM>(sa, As(buf), tid, ea); else store_wm<BM>(sa, As(buf), tid, ea);
-        if (TB) store_wm<BN>(sb, Bs(buf), tid, eb); else store_km<BN>(sb, Bs(buf), tid, eb);
+        if (TA) store_km<BM, SP>(sa, As(buf), tid, ea); else store_wm<BM, SP>(sa, As(buf), tid, ea);
+        if (TB) store_wm<BN, SP>(sb, Bs(buf), tid, eb); else store_km<BN, SP>(sb, Bs(buf), tid, eb);
     };
-    // the accumulators hold sum (a 2^ea[row]) (b 2^eb[col]): the exact inverse power of two goes on before anything else
+    // f16x3: the accumulators hold sum (a 2^ea[row]) (b 2^eb[col]): the exact inverse power of two goes on before anything else
     auto unscale = [&](int row, int col, float v) {
+        if (SP != kSplitF16x3) return v;
         return __builtin_ldexpf(v, -(row_exponent((unsigned)p.expA[row]) + row_exponent((unsigned)p.expB[col])));
     };
 
@@ -130,7 +139,7 @@ __global__ __launch_bounds__(kThreads, MH_MINW) void gemm_kernel(const GemmArgs 
         Stage<BN> &sb_next = cur ? sb0 : sb1, &sb_far = cur ? sb1 : sb0;
         auto load_far = [&]() { load_tiles(sa_far, sb_far, kt + 2, kt + 2 < kt_end); };
         auto store_next = [&]() { store_tiles(sa_next, sb_next, cur ^ 1); };
-        half_step<BM, BN>(load_far, store_next, As(cur), Bs(cur), wm, wn, lane, acc);
+        half_step<BM, BN, SP>(load_far, store_next, As(cur), Bs(cur), wm, wn, lane, acc);
     };
     for (int kt = kt_begin; kt < kt_end; kt += 2) {
         step(std::integral_constant<int, 0>{}, kt);
@@ -149,6 +158,57 @@ __global__ __launch_bounds__(kThreads, MH_MINW) void gemm_kernel(const GemmArgs 
             if (vec && col1 < p.N) *reinterpret_cast<float2 *>(q + col0) = make_float2(v0, v1);
             else { if (col0 < p.N) q[col0] = v0; if (col1 < p.N) q[col1] = v1; }
         });
+        if (p.counters == nullptr) return;             // the caller launches splitk_reduce_kernel
+        // ---- fused reduction.  Release: every thread's partial-sum stores are ordered before the barrier, thread 0's
+        // agent-scope release-increment publishes them (the grid barrier of lstm.hip uses the same idiom across XCDs);
+        // the block that draws the last ticket acquires and owns the tile.
+        __shared__ int s_last;
+        __syncthreads();
+        if (tid == 0) {
+            const int old = __hip_atomic_fetch_add(p.counters + t, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+            s_last = (old == p.splitk - 1) ? 1 : 0;
+            if (s_last) p.counters[t] = 0;             // re-armed for the next product on this stream (kernel boundary orders it)
+        }
+        __syncthreads();
+        if (!s_last) return;
+        __atomic_thread_fence(__ATOMIC_ACQUIRE);       // agent scope: the other blocks' partial sums (any XCD) are visible
+        const size_t plane = (size_t)p.M * p.N;
+        const int rows = min(BM, p.M - m0), cols = min(BN, p.N - n0);
+        auto finish = [&](float v, int row, int col) {
+            if (p.bias) v += p.bias[col];
+            v = apply_epi(v, p.epilogue);
+            if (p.accumulate) v += p.C[(size_t)row * p.ldc + col];
+            return v;
+        };
+        if ((p.N & 3) == 0) {                          // n0 and cols are multiples of 4 then
+            const int c4 = cols >> 2;
+            for (int idx = tid; idx < rows * c4; idx += kThreads) {
+                const int r = idx / c4, c = (idx - r * c4) * 4;
+                const int row = m0 + r, col = n0 + c;
+                const float *src = p.partial + (size_t)row * p.N + col;
+                float4 v = *reinterpret_cast<const float4 *>(src);
+#pragma unroll 4
+                for (int zz = 1; zz < p.splitk; ++zz) {
+                    const float4 w = *reinterpret_cast<const float4 *>(src + (size_t)zz * plane);
+                    v.x += w.x; v.y += w.y; v.z += w.z; v.w += w.w;
+                }
+                v.x = finish(v.x, row, col); v.y = finish(v.y, row, col + 1);
+                v.z = finish(v.z, row, col + 2); v.w = finish(v.w, row, col + 3);
+                float *q = p.C + (size_t)row * p.ldc + col;
+                if (p.vecC4) *reinterpret_cast<float4 *>(q) = v;
+                else { q[0] = v.x; q[1] = v.y; q[2] = v.z; q[3] = v.w; }
+            }
+        } else {
+            for (int idx = tid; idx < rows * cols; idx += kThreads) {
+                const int r = idx / cols, c = idx - r * cols;
+                const int row = m0 + r, col = n0 + c;
+                const float *src = p.partial + (size_t)row * p.N + col;
+                float v = *src;
+#pragma unroll 4
+                for (int zz = 1; zz < p.splitk; ++zz) v += src[(size_t)zz * plane];
+                p.C[(size_t)row * p.ldc + col] = finish(v, row, col);
+            }
+        }
         return;
     }
     acc_foreach_pair<AWM, BWM>(acc, wm, wn, lane, [&](int r, int c0, int c1, float v0, float v1) {
@@ -596,9 +656,25 @@ size_t mh_gemm_ws_bytes_v2(int M, int N, int K, int splitk)
     return exps + align_up((size_t)splitk * M * N * sizeof(float), 256);
 }
 
-int mh_gemm_f32_v2(int transA, int transB, int M, int N, int K, const float *A, int lda, const float *B, int ldb,
-                float *C, int ldc, const float *bias, int epilogue, int accumulate, int splitk, void *workspace,
-                size_t ws_bytes, void *stream)
+}  // extern "C"
+
+namespace mh {
+
+// which split the small-product engine runs: bf16x6 (no row maxima, one launch per product) unless MH_SMALL_GEMM=f16x3 asks
+// for round 2's f16x3 evaluation (a pass over both operands for their row maxima in front of every product) -- A/B only
+static int small_gemm_split()
+{
+    static const int sp = [] { const char *e = getenv("MH_SMALL_GEMM"); return (e && e[0] == 'f') ? kSplitF16x3 : kSplitBf16x6; }();
+    return sp;
+}
+
+// The in-loop-split product: fp32 operands are read once and split by the threads that stage them.
+//   sp           kSplitF16x3 (row maxima first: launch_operand_absmax, exponents at the head of the workspace) or kSplitBf16x6
+//   counters     split-K arrival counters (>= one int per output tile, ZERO on entry, left zero): the last block of a tile
+//                reduces its slices inside the GEMM launch; NULL (or too few): a separate splitk_reduce_kernel launch
+static int gemm_inloop_impl(int sp, int transA, int transB, int M, int N, int K, const float *A, int lda, const float *B, int ldb,
+                            float *C, int ldc, const float *bias, int epilogue, int accumulate, int splitk, void *workspace,
+                            size_t ws_bytes, int *counters, int n_counters, void *stream)
 {
     MH_REQUIRE(M >= 0 && N >= 0 && K >= 0);
     if (M == 0 || N == 0) return MH_OK;
@@ -610,7 +686,8 @@ int mh_gemm_f32_v2(int transA, int transB, int M, int N, int K, const float *A, 
     splitk = std::min(std::min(splitk, total_kt), 64);
     hipStream_t st = as_stream(stream);
     GemmArgs p;
-    {   // the row exponents live at the head of the workspace (mh_gemm_ws_bytes counts them): mandatory in this build
+    p.expA = p.expB = nullptr;
+    if (sp == kSplitF16x3) {   // the row exponents live at the head of the workspace (mh_gemm_ws_bytes counts them)
         const size_t ea = align_up((size_t)M * sizeof(int), 256), eb = align_up((size_t)N * sizeof(int), 256);
         MH_REQUIRE(workspace && ws_bytes >= ea + eb);
         int *expA = reinterpret_cast<int *>(workspace), *expB = reinterpret_cast<int *>(reinterpret_cast<char *>(workspace) + ea);
@@ -632,11 +709,13 @@ int mh_gemm_f32_v2(int transA, int transB, int M, int N, int K, const float *A, 
     p.vecA = al16(A) && (lda % 4 == 0);
     p.vecB = al16(B) && (ldb % 4 == 0);
     p.vecC = ((reinterpret_cast<uintptr_t>(C) & 7) == 0) && (ldc % 2 == 0);
+    p.vecC4 = al16(C) && (ldc % 4 == 0);
     const bool narrow = (N <= 64);
     p.tiles_m = ceil_div(M, narrow ? 256 : 128);
     p.tiles_n = ceil_div(N, narrow ? 64 : 128);
     const long long ntiles = (long long)p.tiles_m * p.tiles_n;
     MH_REQUIRE(ntiles < (1LL << 31) && splitk <= 65535);
+    p.counters = (splitk > 1 && counters != nullptr && ntiles <= (long long)n_counters) ? counters : nullptr;
     {   // patch-major tile order: ~64 tiles per patch (what one XCD runs at a time); the operand whose panel is the
         // more expensive to re-fetch gets the longer patch side.  MH_GEMM_PATCH=rows restores the round-1 order (A/B runs).
         static const bool rows_order = [] { const char *e = getenv("MH_GEMM_PATCH"); return e && e[0] == 'r'; }();
@@ -656,12 +735,17 @@ int mh_gemm_f32_v2(int transA, int transB, int M, int N, int K, const float *A, 
     const unsigned long long spanB = (unsigned long long)(transB ? N : K) * ldb * sizeof(float);
     const bool fast = p.vecA && p.vecB && ((transA ? M : K) % 4 == 0) && ((transB ? K : N) % 4 == 0) &&
                       spanA < (1ull << 30) && spanB < (1ull << 30);
-#define MH_LAUNCH_GEMM2(TA_, TB_, F_)                                                                           \
+#define MH_LAUNCH_GEMM3(TA_, TB_, F_, SP_)                                                                      \
     do {                                                                                                        \
-        if (narrow) launch_tile_kernel<gemm_kernel<TA_, TB_, 256, 64, F_>>(                                     \
+        if (narrow) launch_tile_kernel<gemm_kernel<TA_, TB_, 256, 64, F_, SP_>>(                                \
                 grid, tile_lds_bytes<256, 64, !TA_, TB_>(), st, p);                                             \
-        else launch_tile_kernel<gemm_kernel<TA_, TB_, 128, 128, F_>>(                                           \
+        else launch_tile_kernel<gemm_kernel<TA_, TB_, 128, 128, F_, SP_>>(                                      \
                 grid, tile_lds_bytes<128, 128, !TA_, TB_>(), st, p);                                            \
+    } while (0)
+#define MH_LAUNCH_GEMM2(TA_, TB_, F_)                                   \
+    do {                                                                \
+        if (sp == kSplitF16x3) MH_LAUNCH_GEMM3(TA_, TB_, F_, kSplitF16x3); \
+        else MH_LAUNCH_GEMM3(TA_, TB_, F_, kSplitBf16x6);               \
     } while (0)
 #define MH_LAUNCH_GEMM(TA_, TB_)                          \
     do {                                                  \
@@ -674,16 +758,45 @@ int mh_gemm_f32_v2(int transA, int transB, int M, int N, int K, const float *A, 
     else MH_LAUNCH_GEMM(true, true);
 #undef MH_LAUNCH_GEMM
 #undef MH_LAUNCH_GEMM2
+#undef MH_LAUNCH_GEMM3
     int rc = check_launch("gemm_kernel");
     if (rc) return rc;
-    if (splitk > 1) {
-        const long long total = (long long)M * N;
-        const int blocks = (int)std::min<long long>((total + 255) / 256, 256 * 16);
-        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, p.partial, splitk, M, N, C, ldc, bias,
-                           epilogue, accumulate);
-        rc = check_launch("splitk_reduce_kernel");
-    }
+    if (splitk > 1 && p.counters == nullptr)
+        rc = launch_splitk_reduce(p.partial, splitk, M, N, C, ldc, bias, epilogue, accumulate, st);
     return rc;
+}
+
+// for the C++ callers inside the library (lstm.hip through gemm_f32_ctr)
+int gemm_small(int transA, int transB, int M, int N, int K, const float *A, int lda, const float *B, int ldb, float *C, int ldc,
+               const float *bias, int epilogue, int accumulate, void *workspace, size_t ws_bytes, int *counters, int n_counters,
+               void *stream)
+{
+    return gemm_inloop_impl(small_gemm_split(), transA, transB, M, N, K, A, lda, B, ldb, C, ldc, bias, epilogue, accumulate, 0,
+                            workspace, ws_bytes, counters, n_counters, stream);
+}
+
+}  // namespace mh
+
+extern "C" {
+
+// the round-2 entry point: the engine chosen by small_gemm_split(), the split-K reduction as a separate launch
+int mh_gemm_f32_v2(int transA, int transB, int M, int N, int K, const float *A, int lda, const float *B, int ldb,
+                float *C, int ldc, const float *bias, int epilogue, int accumulate, int splitk, void *workspace,
+                size_t ws_bytes, void *stream)
+{
+    return gemm_inloop_impl(small_gemm_split(), transA, transB, M, N, K, A, lda, B, ldb, C, ldc, bias, epilogue, accumulate,
+                            splitk, workspace, ws_bytes, nullptr, 0, stream);
+}
+
+int mh_gemm_small_max_counters(void) { return kGemmCounters; }      /* choose_splitk_tiles never splits a product of >= 4096 tiles */
+
+int mh_gemm_small_f32(int transA, int transB, int M, int N, int K, const float *A, int lda, const float *B, int ldb,
+                      float *C, int ldc, const float *bias, int epilogue, int accumulate, int splitk, void *workspace,
+                      size_t ws_bytes, int *counters, int n_counters, void *stream)
+{
+    MH_REQUIRE(n_counters >= 0 && (counters != nullptr || n_counters == 0));
+    return gemm_inloop_impl(small_gemm_split(), transA, transB, M, N, K, A, lda, B, ldb, C, ldc, bias, epilogue, accumulate,
+                            splitk, workspace, ws_bytes, counters, n_counters, stream);
 }
 
 }  // extern "C"

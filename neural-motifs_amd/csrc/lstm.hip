@@ -1055,6 +1055,8 @@ static int fault_ctl(FaultCtl &fc)
 }
 
 constexpr size_t kCounterBytes = 256;   // grid-barrier counters of the persistent layer kernels (one per layer)
+constexpr size_t kGemmCtrBytes = (size_t)kGemmCounters * sizeof(int);   // split-K arrival counters of the projections' small products
+                                                                        // (gemm.hip: zero on entry, left zero), behind the barrier counters
 // MH_LSTM_GRAN=0: the forward layers exchange h through `hl` + a grid barrier per step (rounds 2-3) instead of tagged granules (A/B)
 static bool gran_enabled()
 {
@@ -1166,7 +1168,7 @@ size_t mh_hwlstm_fwd_ws_bytes(int in_size, int H, int B, int L, int T)
     (void)L;
     size_t s = align_up((size_t)T * B * 6 * H * sizeof(float), 256) + align_up((size_t)5 * H * H * sizeof(float), 256);
     s += std::max(mh_gemm_ws_bytes(T * B, 6 * H, in_size, 0), mh_gemm_ws_bytes(T * B, 6 * H, H, 0));
-    return s + kCounterBytes + kXchFwdBytes + 256;
+    return s + kCounterBytes + kGemmCtrBytes + kXchFwdBytes + 256;
 }
 
 int mh_hwlstm_fwd(int in_size, int H, int B, int L, int T, const float *x, const int *lengths_host, float *h_data,
@@ -1195,12 +1197,14 @@ int mh_hwlstm_fwd(int in_size, int H, int B, int L, int T, const float *x, const
     int ts[4096], ns[4096];
     unsigned *counters = reinterpret_cast<unsigned *>(ws);   // one barrier counter per layer
     ws += kCounterBytes;
+    int *gemm_ctr = reinterpret_cast<int *>(ws);
+    ws += kGemmCtrBytes;
     unsigned long long *xch = reinterpret_cast<unsigned long long *>(ws);     // granule exchange of the forward layers (behind the counters)
     ws += kXchFwdBytes;
     const bool persistent = persistent_ok(H, B, L) && al16(h_data) && al16(wh_t);
     const bool gran = persistent && gran_enabled();
-    if (persistent) {
-        hipError_t e = hipMemsetAsync(counters, 0, kCounterBytes + (gran ? kXchFwdBytes : 0), st);
+    {   // ONE memset: barrier counters | GEMM arrival counters | (granule exchange)
+        hipError_t e = hipMemsetAsync(counters, 0, kCounterBytes + kGemmCtrBytes + (gran ? kXchFwdBytes : 0), st);
         if (e != hipSuccess) return (int)e;
     }
     void *gws = ws;
@@ -1211,8 +1215,8 @@ int mh_hwlstm_fwd(int in_size, int H, int B, int L, int T, const float *x, const
         const bool fwd_dir = (layer % 2 == 0);
         const float *inp = (layer == 0) ? x : h_data + ((size_t)(layer - 1) * (T + 1) + 1) * numEl;
         // tmp_i[T*B, 6H] = inp[T*B, in] * Wx[in, 6H]
-        MH_TRY(mh_gemm_f32(0, 0, T * B, 6 * H, o.in_size, inp, o.in_size, weight + o.wx, 6 * H, tmp_i, 6 * H, nullptr,
-                           MH_EPI_NONE, 0, 0, gws, gws_bytes, stream));
+        MH_TRY(gemm_f32_ctr(0, 0, T * B, 6 * H, o.in_size, inp, o.in_size, weight + o.wx, 6 * H, tmp_i, 6 * H, nullptr,
+                            MH_EPI_NONE, 0, gws, gws_bytes, gemm_ctr, kGemmCounters, stream));
         // wh_t[5H,H] = Wh[H,5H]^T so that every output column's K weights are contiguous
         hipLaunchKernelGGL(transpose2d_kernel, dim3(ceil_div(5 * H, 32), ceil_div(H, 32)), dim3(256), 0, st,
                            weight + o.wh, H, 5 * H, wh_t);
@@ -1347,7 +1351,7 @@ size_t mh_hwlstm_bwd_ws_bytes(int in_size, int H, int B, int L, int T)
     size_t s = align_up((size_t)T * B * 6 * H * sizeof(float), 256);
     s += 2 * align_up((size_t)(T + 1) * numEl * sizeof(float), 256);
     s += 2 * align_up((size_t)T * numEl * sizeof(float), 256);
-    s += kCounterBytes + kXchBwdBytes;
+    s += kCounterBytes + kGemmCtrBytes + kXchBwdBytes;
     size_t g = 0;
     const int ins[2] = {in_size, H};
     for (int i = 0; i < 2; ++i) {
@@ -1389,12 +1393,14 @@ int mh_hwlstm_bwd(int in_size, int H, int B, int L, int T, const float *out_grad
     ws += align_up((size_t)T * numEl * sizeof(float), 256);
     unsigned *counters = reinterpret_cast<unsigned *>(ws);
     ws += kCounterBytes;
+    int *gemm_ctr = reinterpret_cast<int *>(ws);
+    ws += kGemmCtrBytes;
     unsigned long long *xch = reinterpret_cast<unsigned long long *>(ws);     // granule exchange of the backward layers
     ws += kXchBwdBytes;
     const bool persistent = persistent_ok(H, B, L) && al16(weight) && al16(dg_all);
     const bool gran = persistent && gran_enabled();
-    if (persistent) {
-        hipError_t e = hipMemsetAsync(counters, 0, kCounterBytes + (gran ? kXchBwdBytes : 0), st);
+    {   // ONE memset: barrier counters | GEMM arrival counters | (granule exchange)
+        hipError_t e = hipMemsetAsync(counters, 0, kCounterBytes + kGemmCtrBytes + (gran ? kXchBwdBytes : 0), st);
         if (e != hipSuccess) return (int)e;
     }
     void *gws = ws;
@@ -1405,9 +1411,8 @@ int mh_hwlstm_bwd(int in_size, int H, int B, int L, int T, const float *out_grad
     for (int layer = L - 1; layer >= 0; --layer) {
         const LayerOffsets o = layer_offsets(in_size, H, layer);
         const bool fwd_dir = (layer % 2 == 0);
-        hipError_t e = hipMemsetAsync(dg_all, 0, (size_t)T * B * 6 * H * sizeof(float), st);
-        if (e == hipSuccess) e = hipMemsetAsync(h_grad, 0, (size_t)(T + 1) * numEl * sizeof(float), st);
-        if (e == hipSuccess) e = hipMemsetAsync(c_grad, 0, (size_t)(T + 1) * numEl * sizeof(float), st);
+        // dg_all | h_grad | c_grad are adjacent in the workspace: one memset instead of three
+        hipError_t e = hipMemsetAsync(dg_all, 0, (size_t)(reinterpret_cast<char *>(below[0]) - reinterpret_cast<char *>(dg_all)), st);
         if (e != hipSuccess) return (int)e;
         const float *hl = h_data + (size_t)layer * (T + 1) * numEl;
         const float *cl = c_data + (size_t)layer * (T + 1) * numEl;
@@ -1442,20 +1447,20 @@ int mh_hwlstm_bwd(int in_size, int H, int B, int L, int T, const float *out_grad
         const float *inp = (layer == 0) ? x : h_data + ((size_t)(layer - 1) * (T + 1) + 1) * numEl;
         float *inp_grad = (layer == 0) ? x_grad : below[layer & 1];
         // d(inp)[T*B, in] = dg_all[T*B, 6H] * Wx[in, 6H]^T
-        MH_TRY(mh_gemm_f32(0, 1, T * B, o.in_size, 6 * H, dg_all, 6 * H, weight + o.wx, 6 * H, inp_grad, o.in_size,
-                           nullptr, MH_EPI_NONE, 0, 0, gws, gws_bytes, stream));
+        MH_TRY(gemm_f32_ctr(0, 1, T * B, o.in_size, 6 * H, dg_all, 6 * H, weight + o.wx, 6 * H, inp_grad, o.in_size,
+                            nullptr, MH_EPI_NONE, 0, gws, gws_bytes, gemm_ctr, kGemmCounters, stream));
         if (do_weight_grad) {
             // dWx[in, 6H] += inp[T*B, in]^T * dg_all[T*B, 6H]
-            MH_TRY(mh_gemm_f32(1, 0, o.in_size, 6 * H, T * B, inp, o.in_size, dg_all, 6 * H, weight_grad + o.wx, 6 * H,
-                               nullptr, MH_EPI_NONE, 1, 0, gws, gws_bytes, stream));
+            MH_TRY(gemm_f32_ctr(1, 0, o.in_size, 6 * H, T * B, inp, o.in_size, dg_all, 6 * H, weight_grad + o.wx, 6 * H,
+                                nullptr, MH_EPI_NONE, 1, gws, gws_bytes, gemm_ctr, kGemmCounters, stream));
             // dWh[H, 5H] += h_prev^T * dg_all[:, :5H];  h_prev(t) = slot t (forward layers) or slot t+2
             // (backward layers; t = T-1 reads the all-zero slot 0 and contributes nothing)
             if (fwd_dir) {
-                MH_TRY(mh_gemm_f32(1, 0, H, 5 * H, T * B, hl, H, dg_all, 6 * H, weight_grad + o.wh, 5 * H, nullptr,
-                                   MH_EPI_NONE, 1, 0, gws, gws_bytes, stream));
+                MH_TRY(gemm_f32_ctr(1, 0, H, 5 * H, T * B, hl, H, dg_all, 6 * H, weight_grad + o.wh, 5 * H, nullptr,
+                                    MH_EPI_NONE, 1, gws, gws_bytes, gemm_ctr, kGemmCounters, stream));
             } else if (T > 1) {
-                MH_TRY(mh_gemm_f32(1, 0, H, 5 * H, (T - 1) * B, hl + 2 * numEl, H, dg_all, 6 * H, weight_grad + o.wh,
-                                   5 * H, nullptr, MH_EPI_NONE, 1, 0, gws, gws_bytes, stream));
+                MH_TRY(gemm_f32_ctr(1, 0, H, 5 * H, (T - 1) * B, hl + 2 * numEl, H, dg_all, 6 * H, weight_grad + o.wh,
+                                    5 * H, nullptr, MH_EPI_NONE, 1, gws, gws_bytes, gemm_ctr, kGemmCounters, stream));
             }
             hipLaunchKernelGGL(colsum_accum_kernel, dim3(ceil_div(5 * H, 64)), dim3(256), 0, st, dg_all, T * B, 5 * H,
                                6 * H, bias_grad + (size_t)5 * H * layer);

@@ -181,6 +181,41 @@ __device__ __forceinline__ void split_pair_f16(float x0, float x1, int e0, int e
     p1 = __builtin_bit_cast(unsigned, h1);
     p2 = __builtin_bit_cast(unsigned, __builtin_convertvector(r, f16x2_t));
 }
+// ---- the second split of this header: "bf16x6" (round 5, small products: gemm.hip) ------------------------------------
+// An fp32 number is the EXACT sum of three bf16 terms (8 + 8 + 8 significant bits), each rounded to nearest even
+// (v_cvt_pk_bf16_f32): x = b1 + b2 + b3, |b2| <= 2^-8 |x|, |b3| <= 2^-16 |x|.  bf16 has fp32's exponent range, so NO scale and
+// therefore NO pass over the operands for their row maxima is needed: a product is one launch.  Six MFMAs per accumulator and
+// k-tile (b3*b1', b1*b3', b2*b2', b2*b1', b1*b2', b1*b1', smallest first); the three dropped cross terms are below 2^-24 |ab|.
+// Measured against float64 on MI355X in round 1 (profiles/r01_split_check.jsonl, "split_rne": 1): rms 7.9e-7 of rms(C) on
+// mixed-sign operands, 6.3e-7 on all-positive ones (mean signed error -1.9e-7), 24-bit operands copied exactly through a
+// permutation matrix.  Twice the matrix-core work of f16x3 -- used where a product is latency- or bandwidth-bound anyway.
+constexpr int kSplitF16x3 = 0, kSplitBf16x6 = 1;
+typedef __bf16 bf16pair_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned pack_bf16_rne(float lo16, float hi16)
+{
+    const f32x2_t v = {lo16, hi16};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16pair_t));
+}
+// (x0, x1) = values at k even / k odd -> packed dwords of the three planes
+__device__ __forceinline__ void split_pair_bf16(float x0, float x1, unsigned &p1, unsigned &p2, unsigned &p3)
+{
+    p1 = pack_bf16_rne(x0, x1);
+    const float r0 = x0 - __builtin_bit_cast(float, p1 << 16);               // exact
+    const float r1 = x1 - __builtin_bit_cast(float, p1 & 0xffff0000u);
+    p2 = pack_bf16_rne(r0, r1);
+    const float s0 = r0 - __builtin_bit_cast(float, p2 << 16);               // exact
+    const float s1 = r1 - __builtin_bit_cast(float, p2 & 0xffff0000u);
+    p3 = pack_bf16_rne(s0, s1);                                              // exact: at most 8 significant bits are left
+}
+template <int SP>
+__device__ __forceinline__ void split_pair_any(float x0, float x1, int e0, int e1, unsigned (&pl)[3])
+{
+    if (SP == kSplitBf16x6) split_pair_bf16(x0, x1, pl[0], pl[1], pl[2]);
+    else split_pair_f16(x0, x1, e0, e1, pl[0], pl[1]);
+}
+template <int SP>
+struct SplitPlanes { static constexpr int n = (SP == kSplitBf16x6) ? 3 : kNumPlanes; };
+
 // exponent e with max * 2^e in [2^14, 2^15) from the bit pattern of max = the largest |x| of a row (0 for an all-zero,
 // inf or nan row: nothing to scale / nothing to save)
 __host__ __device__ __forceinline__ int row_exponent(unsigned absmax_bits)
@@ -246,7 +281,7 @@ __device__ __forceinline__ void load_stage_exp(StageExp<WD> &se, const int *__re
     }
 }
 
-template <int WD>
+template <int WD, int SP = kSplitF16x3>
 __device__ __forceinline__ void store_km(const Stage<WD> &s, float *tile, int tid, const StageExp<WD> &se = StageExp<WD>())
 {
     constexpr int ntask = (2 * WD + kThreads - 1) / kThreads;
@@ -263,15 +298,15 @@ __device__ __forceinline__ void store_km(const Stage<WD> &s, float *tile, int ti
             const int r = 64 * (w >> 6) + 32 * (w & 1) + ((w & 63) >> 1);
             const int sw = plane_swz(r);
             unsigned pl[3];
-            split_pair_f16(e[j], o[j], se.km[jt][j], se.km[jt][j], pl[0], pl[1]);     // k, k+1 of the same column
+            split_pair_any<SP>(e[j], o[j], se.km[jt][j], se.km[jt][j], pl);     // k, k+1 of the same column
 #pragma unroll
-            for (int pidx = 0; pidx < kNumPlanes; ++pidx)
+            for (int pidx = 0; pidx < SplitPlanes<SP>::n; ++pidx)
                 t32[r * kRowDw + 4 * ((2 * pidx + (kp >> 2)) ^ sw) + (kp & 3)] = pl[pidx];
         }
     }
 }
 
-template <int WD>
+template <int WD, int SP = kSplitF16x3>
 __device__ __forceinline__ void store_wm(const Stage<WD> &s, float *tile, int tid, const StageExp<WD> &se = StageExp<WD>())
 {
     unsigned *t32 = reinterpret_cast<unsigned *>(tile);
@@ -280,10 +315,10 @@ __device__ __forceinline__ void store_wm(const Stage<WD> &s, float *tile, int ti
         const int f = tid + kThreads * j;
         const int r = f >> 2, kq = f & 3, sw = plane_swz(r);
         unsigned a[3], b[3];
-        split_pair_f16(s.v[j].x, s.v[j].y, se.wm[j], se.wm[j], a[0], a[1]);
-        split_pair_f16(s.v[j].z, s.v[j].w, se.wm[j], se.wm[j], b[0], b[1]);
+        split_pair_any<SP>(s.v[j].x, s.v[j].y, se.wm[j], se.wm[j], a);
+        split_pair_any<SP>(s.v[j].z, s.v[j].w, se.wm[j], se.wm[j], b);
 #pragma unroll
-        for (int pidx = 0; pidx < kNumPlanes; ++pidx) {
+        for (int pidx = 0; pidx < SplitPlanes<SP>::n; ++pidx) {
             typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
             *reinterpret_cast<u32x2 *>(t32 + r * kRowDw + 4 * ((2 * pidx + (kq >> 1)) ^ sw) + 2 * (kq & 1)) =
                 (u32x2){a[pidx], b[pidx]};
@@ -295,7 +330,7 @@ __device__ __forceinline__ void store_wm(const Stage<WD> &s, float *tile, int ti
 struct PlaneFrags {
     bf16x8 a[2][3], b[2][3];
 };
-template <int BM, int BN>
+template <int BM, int BN, int SP = kSplitF16x3>
 __device__ __forceinline__ void fetch_frags(PlaneFrags &f, const float *__restrict__ As, const float *__restrict__ Bs,
                                             int wm, int wn, int lane)
 {
@@ -303,6 +338,18 @@ __device__ __forceinline__ void fetch_frags(PlaneFrags &f, const float *__restri
     auto fetch = [&](const float *tile, int row, int pidx) -> bf16x8 {
         return *reinterpret_cast<const bf16x8 *>(tile + row * kRowDw + 4 * ((2 * pidx + g) ^ plane_swz(row)));
     };
+    if (SP == kSplitBf16x6) {
+        constexpr int kOrderA[3] = {2, 0, 1}, kOrderB[3] = {0, 2, 1};   // planes in order of first use: 12 ds_read_b128
+#pragma unroll
+        for (int o = 0; o < 3; ++o) {
+#pragma unroll
+            for (int sidx = 0; sidx < 2; ++sidx) {
+                f.a[sidx][kOrderA[o]] = fetch(As, wm + 32 * sidx + i, kOrderA[o]);
+                f.b[sidx][kOrderB[o]] = fetch(Bs, wn + 32 * sidx + i, kOrderB[o]);
+            }
+        }
+        return;
+    }
     constexpr int kOrderA[2] = {1, 0}, kOrderB[2] = {0, 1};         // planes in order of first use: 8 ds_read_b128
 #pragma unroll
     for (int o = 0; o < 2; ++o) {
@@ -313,11 +360,26 @@ __device__ __forceinline__ void fetch_frags(PlaneFrags &f, const float *__restri
         }
     }
 }
-// All MFMAs of one k-tile.  Per accumulator the six terms are added smallest first (lo*hi, hi*lo, mid*mid, mid*hi,
-// hi*mid, hi*hi); the four accumulators are interleaved so that consecutive MFMAs are independent.
+// All MFMAs of one k-tile; the four accumulators are interleaved so that consecutive MFMAs are independent.
 // f16x3: h2*h1, h1*h2, h1*h1 (smallest first); h2*h2 <= 2^-24 |ab| is dropped
+// bf16x6: b3*b1, b1*b3, b2*b2, b2*b1, b1*b2, b1*b1 (smallest first); b2*b3, b3*b2, b3*b3 <= 2^-24 |ab| are dropped
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+template <int SP = kSplitF16x3>
 __device__ __forceinline__ void mma_frags(const PlaneFrags &f, Acc &acc)
 {
+    if (SP == kSplitBf16x6) {
+        constexpr int kTermA[6] = {2, 0, 1, 1, 0, 0}, kTermB[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+        for (int t = 0; t < 6; ++t)
+#pragma unroll
+            for (int sm = 0; sm < 2; ++sm)
+#pragma unroll
+                for (int sn = 0; sn < 2; ++sn)
+                    acc.v[sm][sn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, f.a[sm][kTermA[t]]),
+                                                                            __builtin_bit_cast(bf16x8_t, f.b[sn][kTermB[t]]),
+                                                                            acc.v[sm][sn], 0, 0, 0);
+        return;
+    }
     constexpr int kTermA[3] = {1, 0, 0}, kTermB[3] = {0, 1, 0};
 #pragma unroll
     for (int t = 0; t < 3; ++t)
@@ -530,36 +592,37 @@ constexpr size_t tile_lds_bytes() { return 2 * (size_t)(TileGeom<BM, AWM>::float
 // Tiles beyond the last one are loaded as zeros (masked buffer loads), which makes the phantom half-step of an odd
 // tile count harmless (acc += 0) and keeps the loop free of branches -- the load count per step is static, so the
 // compiler waits with vmcnt(N > 0) and tile kt+2 stays in flight while tile kt+1 is consumed.
-template <int BM, int BN, typename LoadFn, typename StoreFn>
+template <int BM, int BN, int SP = kSplitF16x3, typename LoadFn, typename StoreFn>
 __device__ __forceinline__ void half_step(LoadFn load_far, StoreFn store_next, const float *As, const float *Bs, int wm,
                                           int wn, int lane, Acc &acc)
 {
     load_far();
     __builtin_amdgcn_sched_barrier(0);
     PlaneFrags f;
-    fetch_frags<BM, BN>(f, As, Bs, wm, wn, lane);
+    fetch_frags<BM, BN, SP>(f, As, Bs, wm, wn, lane);
     store_next();
-    mma_frags(f, acc);
-    __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);        // fragment reads (two planes)
-    __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);
+    mma_frags<SP>(f, acc);
 #ifndef MH_F16_VALU
 #define MH_F16_VALU 7     /* split / address VALU instructions the scheduler may place behind each MFMA (build knob for A/B) */
 #endif
+    if (SP == kSplitBf16x6) {
+        __builtin_amdgcn_sched_group_barrier(0x100, 12, 0);       // fragment reads (three planes)
+        __builtin_amdgcn_sched_group_barrier(0x002, 12, 0);       // first split ops while the reads land
 #pragma unroll
-    for (int i = 0; i < 12; ++i) {                            // same recipe as the bf16x6 loop below at half the MFMA count
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x002, MH_F16_VALU, 0);
-        __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
-    }
-    __syncthreads();
-    return;
-    __builtin_amdgcn_sched_group_barrier(0x100, 12, 0);       // fragment reads
-    __builtin_amdgcn_sched_group_barrier(0x002, 12, 0);       // first split ops while the reads land
+        for (int i = 0; i < 24; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);    // 1 MFMA
+            __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);    // split / address VALU
+            __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);    // LDS write of the next tile
+        }
+    } else {
+        __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);        // fragment reads (two planes)
+        __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);
 #pragma unroll
-    for (int i = 0; i < 24; ++i) {
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);    // 1 MFMA
-        __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);    // split / address VALU
-        __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);    // LDS write of the next tile
+        for (int i = 0; i < 12; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, MH_F16_VALU, 0);
+            __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+        }
     }
     __syncthreads();
 }

@@ -430,6 +430,9 @@ static Plan plan_gemm(int M, int N, int K, int want_splitk)
     return best;
 }
 
+// the dispatch rule of mh_gemm_f32: below 20 GFLOP, or with a shallow K, a one-shot product is not worth two plane images
+static inline bool small_product(int M, int N, int K) { return 2.0 * M * N * (double)K < 20e9 || K < 512; }
+
 static inline size_t cells_bytes(long long rows, long long K) { return (size_t)ceil_div(K, (long long)kBK) * rows * kCell; }
 static inline size_t image_bytes(long long rows, long long K) { return align_up(cells_bytes(rows, K), 256) + align_up((size_t)rows * 4, 256); }
 static inline unsigned *image_maxbits(void *image, long long rows, long long K)
@@ -457,6 +460,18 @@ static int launch_gemm(const GemmArgs &p0, const Plan &pl, hipStream_t st)
 }
 
 }  // namespace pl
+}  // namespace mh
+
+namespace mh {
+int gemm_f32_ctr(int transA, int transB, int M, int N, int K, const float *A, int lda, const float *B, int ldb, float *C, int ldc,
+                 const float *bias, int epilogue, int accumulate, void *workspace, size_t ws_bytes, int *counters, int n_counters,
+                 void *stream)
+{
+    if (pl::g_force_shape < 0 && M > 0 && N > 0 && K > 0 && pl::small_product(M, N, K))
+        return gemm_small(transA, transB, M, N, K, A, lda, B, ldb, C, ldc, bias, epilogue, accumulate, workspace, ws_bytes, counters,
+                          n_counters, stream);
+    return mh_gemm_f32(transA, transB, M, N, K, A, lda, B, ldb, C, ldc, bias, epilogue, accumulate, 0, workspace, ws_bytes, stream);
+}
 }  // namespace mh
 
 using namespace mh;
@@ -586,7 +601,7 @@ int mh_gemm_f32(int transA, int transB, int M, int N, int K, const float *A, int
     // One-shot operands of a SMALL or thin product are not worth an image each (two extra passes + launches per operand,
     // gpurun r03_c6: 50 such calls per step cost 1.0 ms of preparation for 0.3 ms of products): those go to the in-loop-split
     // kernel, which reads the fp32 operands once.  Images pay where the product is big (>= 20 GFLOP) and K is deep.
-    if (pl::g_force_shape < 0 && (2.0 * M * N * (double)K < 20e9 || K < 512))
+    if (pl::g_force_shape < 0 && pl::small_product(M, N, K))
         return mh_gemm_f32_v2(transA, transB, M, N, K, A, lda, B, ldb, C, ldc, bias, epilogue, accumulate, splitk, workspace, ws_bytes, stream);
     // workspace: maxbits A | maxbits B (adjacent: the k-major pass zeroes them with one memset) | cells A | cells B | partials
     const size_t ma = align_up((size_t)M * 4, 256), mb = align_up((size_t)N * 4, 256);

@@ -26,6 +26,7 @@ SYMBOLS = (
     'mh_act_planes_bytes', 'mh_act_planes', 'mh_plconv_packed_bytes', 'mh_plconv_pack_weight', 'mh_plconv3x3_ws_bytes',
     'mh_plconv3x3', 'mh_plconv3x3_to_image', 'mh_stem_to_image', 'mh_conv_first_nchw_max', 'mh_debug_plconv_shape', 'mh_debug_plconv_splitk', 'mh_debug_plconv_flags', 'mh_decoder_nms_commit_max_bytes',
     'mh_debug_pl_shape', 'mh_gemm_ws_bytes_v2', 'mh_gemm_auto_splitk_v2', 'mh_gemm_f32_v2',
+    'mh_gemm_small_max_counters', 'mh_gemm_small_f32',
     'mh_conv3x3_packed_floats', 'mh_conv3x3_pack_weight', 'mh_conv3x3_ws_bytes', 'mh_conv3x3_schedule', 'mh_conv3x3_nhwc',
     'mh_conv3x3_wgrad_ws_bytes', 'mh_conv3x3_wgrad', 'mh_conv_first_nchw', 'mh_maxpool2x2_nhwc',
     'mh_maxpool2x2_bwd_nhwc', 'mh_act_bwd',
@@ -155,6 +156,18 @@ def workspace(nbytes, device, tag='default'):
     return buf
 
 
+def zeroed_workspace(nbytes, device, tag):
+    """like workspace(), but zero-filled when it is (re)allocated: for kernels that need zeroed scratch on entry and leave it
+    zeroed (the split-K arrival counters of mh_gemm_small_f32) -- no memset per call"""
+    nbytes = max(int(nbytes), 256)
+    key = (str(device), tag, torch.cuda.current_stream().cuda_stream if torch.cuda.is_available() else 0)
+    buf = _ws_cache.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.zeros(nbytes, dtype=torch.uint8, device=device)
+        _ws_cache[key] = buf
+    return buf
+
+
 c_int = ctypes.c_int
 c_ll = ctypes.c_longlong
 c_float = ctypes.c_float
@@ -186,6 +199,8 @@ def gemm(a, b, trans_a=False, trans_b=False, bias=None, epilogue=0, out=None, ac
         if not accumulate:
             out.zero_()
         return out
+    if splitk <= 0 and is_small_product(M, N, K):
+        return _gemm_small(a, b, trans_a, trans_b, bias, epilogue, out, accumulate)
     if splitk <= 0:
         splitk = L.mh_gemm_auto_splitk(M, N, K)
     wsb = L.mh_gemm_ws_bytes(M, N, K, splitk)
@@ -261,26 +276,42 @@ def gemm_planes(a, b, bias=None, epilogue=0, out=None, accumulate=False, splitk=
     return out
 
 
-def gemm_inloop(a, b, trans_a=False, trans_b=False, bias=None, epilogue=0, out=None):
-    """the round-2 kernel (fp32 operands split inside the K loop): kept for ONE case -- a skinny product (<= 128 rows)
-    against a big weight matrix that changes every step and is read exactly once (the trainable object fc6), where
-    writing a plane image first would cost more than the product (profiles/r03_pl_check.jsonl)"""
+def is_small_product(M, N, K):
+    """the dispatch rule of mh_gemm_f32 (csrc/pl_gemm.hip): products below 20 GFLOP or with K < 512 are not worth plane images"""
+    return 2.0 * M * N * K < 20e9 or K < 512
+
+
+def gemm_inloop(a, b, trans_a=False, trans_b=False, bias=None, epilogue=0, out=None, accumulate=False):
+    """see _gemm_small (the name is round 2's: the product whose operands are split inside the K loop)"""
+    return _gemm_small(a, b, trans_a, trans_b, bias, epilogue, out, accumulate)
+
+
+def _gemm_small(a, b, trans_a=False, trans_b=False, bias=None, epilogue=0, out=None, accumulate=False):
+    """the small-product engine (csrc/gemm.hip, mh_gemm_small_f32): fp32 operands read once and split into three bf16 terms
+    inside the K loop, no pass for row maxima, the split-K reduction fused into the same launch -- ONE launch per product.
+    For everything that is not worth plane images: the ~40 small products of a step and the skinny product (<= 128 rows)
+    against a big weight matrix that changes every step and is read exactly once (the trainable object fc6)."""
     L = lib()
     M = a.shape[1] if trans_a else a.shape[0]
     K = a.shape[0] if trans_a else a.shape[1]
     N = b.shape[0] if trans_b else b.shape[1]
     if out is None:
         out = torch.empty(M, N, dtype=torch.float32, device=a.device)
+        accumulate = False
     elif tuple(out.shape) != (M, N) or out.stride(1) != 1 or out.dtype != torch.float32:
         raise HipKernelError('bad output tensor for gemm_inloop')
+    if M == 0 or N == 0:
+        return out
     splitk = L.mh_gemm_auto_splitk_v2(M, N, K)
     wsb = L.mh_gemm_ws_bytes_v2(M, N, K, splitk)
     ws = workspace(wsb, a.device, 'gemm') if wsb else None
-    rc = L.mh_gemm_f32_v2(c_int(int(trans_a)), c_int(int(trans_b)), M, N, K, ctypes.c_void_p(a.data_ptr()), c_int(a.stride(0)),
-                          ctypes.c_void_p(b.data_ptr()), c_int(b.stride(0)), ctypes.c_void_p(out.data_ptr()), c_int(out.stride(0)),
-                          f32(bias), c_int(epilogue), c_int(0), c_int(splitk), ptr(ws),
-                          c_size_t(ws.numel() if ws is not None else 0), stream())
-    _check(rc, 'mh_gemm_f32_v2')
+    nctr = L.mh_gemm_small_max_counters()
+    ctr = zeroed_workspace(4 * nctr, a.device, 'gemm_counters')
+    rc = L.mh_gemm_small_f32(c_int(int(trans_a)), c_int(int(trans_b)), M, N, K, ctypes.c_void_p(a.data_ptr()), c_int(a.stride(0)),
+                             ctypes.c_void_p(b.data_ptr()), c_int(b.stride(0)), ctypes.c_void_p(out.data_ptr()), c_int(out.stride(0)),
+                             f32(bias), c_int(epilogue), c_int(int(accumulate)), c_int(splitk), ptr(ws),
+                             c_size_t(ws.numel() if ws is not None else 0), ptr(ctr), c_int(nctr), stream())
+    _check(rc, 'mh_gemm_small_f32')
     return out
 
 

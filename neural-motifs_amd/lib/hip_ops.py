@@ -134,7 +134,12 @@ class _LinearFn(torch.autograd.Function):
         weight = ctx.weight
         gy = _rows2d(gy)
         if ctx.relu:
-            gy = gy * (y > 0).to(gy.dtype)
+            # gradient where the OUTPUT is > 0 (nn.ReLU's rule): one kernel instead of compare + cast + multiply
+            if (gy.is_cuda and gy.is_contiguous() and y.is_contiguous() and gy.numel() % 4 == 0 and gy.numel() > 0
+                    and (gy.data_ptr() | y.data_ptr()) % 16 == 0):
+                gy = _hip.act_bwd(gy, y, EPI_RELU)
+            else:
+                gy = gy * (y > 0).to(gy.dtype)
         gx = gw = gb = None
         if gy.shape[0] == 0:
             return (gy.new_zeros(ctx.x_shape) if ctx.needs_input_grad[0] else None,

@@ -251,6 +251,8 @@ class ObjectDetector(nn.Module):
                 set_host(im_inds, host_np(rois)[:, 0].astype(np.int64) + image_offset)
             nms_scores = nms_preds = nms_boxes_assign = nms_boxes = None
             box_priors = rois[:, 1:]
+            if has_host(rois):
+                set_host(box_priors, host_np(rois)[:, 1:])      # the context's packing order is box geometry: computed on the host
             rm_obj_labels = obj_labels
             box_deltas = od_box_deltas
             obj_dists = od_obj_dists

@@ -38,10 +38,9 @@ from lib.word_vectors import obj_edge_vectors
 MODES = ('sgdet', 'sgcls', 'predcls')
 
 
-def _sort_by_score(im_inds, scores):
-    """Permutation that orders rois for the LSTMs (reference :31-61): inside an image by descending score, images by
-    decreasing object count, then time-major (TxB packed).  Returns (perm, inv_perm, batch size per timestep)."""
-    im_host = host_np(im_inds)           # the mirror of GT-derived indices (no D2H synchronisation), else a copy
+def _packing_plan(im_host):
+    """host part of the LSTM packing order: per-image sort key offsets, and the time-major (TxB) gather of the image-sorted
+    rois (reference :31-61, lib/pytorch_misc.py:365-384)"""
     num_im = int(im_host[-1]) + 1
     im_key = np.zeros(num_im, dtype=np.float32)
     lengths = []
@@ -50,12 +49,37 @@ def _sort_by_score(im_inds, scores):
         lengths.append(e - s)
     lengths = sorted(lengths, reverse=True)
     inds, ls_transposed = transpose_packed_sequence_inds(lengths)
-    inds = h2d(np.asarray(inds, dtype=np.int64), im_inds.device)
+    return im_key, np.asarray(inds, dtype=np.int64), ls_transposed
+
+
+def _sort_by_score(im_inds, scores):
+    """Permutation that orders rois for the LSTMs (reference :31-61): inside an image by descending score, images by
+    decreasing object count, then time-major (TxB packed).  Returns (perm, inv_perm, batch size per timestep)."""
+    im_host = host_np(im_inds)           # the mirror of GT-derived indices (no D2H synchronisation), else a copy
+    im_key, inds, ls_transposed = _packing_plan(im_host)
+    inds = h2d(inds, im_inds.device)
     roi_order = scores - 2 * h2d(im_key, scores.device)[im_inds]
     _, perm = torch.sort(roi_order, dim=0, descending=True, stable=True)
     perm = perm[inds]
     _, inv_perm = torch.sort(perm)
     return perm, inv_perm, ls_transposed
+
+
+def _sort_by_score_host(im_inds, scores_host, device):
+    """_sort_by_score for scores that are known on the HOST (box geometry of ground-truth boxes: their Blob mirror): the
+    same fp32 arithmetic and the same stable sorts on CPU tensors, ONE upload of (perm | inv_perm) -- none of the ~22 small
+    launches of the device version (two sorts, gathers, key arithmetic) on the context branch's critical path."""
+    im_host = host_np(im_inds)
+    im_key, inds, ls_transposed = _packing_plan(im_host)
+    roi_order = scores_host - 2 * torch.from_numpy(im_key)[torch.from_numpy(np.ascontiguousarray(im_host, dtype=np.int64))]
+    _, perm = torch.sort(roi_order, dim=0, descending=True, stable=True)
+    perm = perm[torch.from_numpy(inds)]
+    _, inv_perm = torch.sort(perm)
+    both = h2d(torch.stack((perm, inv_perm)).numpy(), device)
+    perm_d, inv_d = both[0], both[1]
+    set_host(perm_d, perm.numpy())
+    set_host(inv_d, inv_perm.numpy())
+    return perm_d, inv_d, ls_transposed
 
 
 class _LateBackward(torch.autograd.Function):
@@ -145,12 +169,29 @@ class LinearizedContext(nn.Module):
         return len(self.rel_classes)
 
     def sort_rois(self, batch_idx, confidence, box_priors):
+        """`confidence` may be a callable: it is evaluated only for order == 'confidence' (three to five launches saved per
+        call in the other orders).  Orders that depend on the box geometry alone ('size', 'leftright') are computed on the
+        host when the boxes carry their Blob mirror (GT-box modes), once per forward: the object and the edge context use
+        the same order."""
+        geometric = self.order in ('size', 'leftright')
+        if geometric and has_host(box_priors) and has_host(batch_idx):
+            cache = getattr(self, '_order_cache', None)
+            if cache is not None and cache[0] is box_priors and cache[1] is batch_idx:
+                return cache[2]
+            cxcywh = center_size(torch.from_numpy(np.ascontiguousarray(host_np(box_priors), dtype=np.float32)))
+            if self.order == 'size':
+                key = cxcywh[:, 2] * cxcywh[:, 3]
+            else:
+                key = cxcywh[:, 0]
+            out = _sort_by_score_host(batch_idx, key / (key.max() + 1), box_priors.device)
+            self._order_cache = (box_priors, batch_idx, out)
+            return out
         cxcywh = center_size(box_priors)
         if self.order == 'size':
             sizes = cxcywh[:, 2] * cxcywh[:, 3]
             scores = sizes / (sizes.max() + 1)
         elif self.order == 'confidence':
-            scores = confidence
+            scores = confidence() if callable(confidence) else confidence
         elif self.order == 'random':
             scores = h2d(np.random.rand(batch_idx.size(0)).astype(np.float32), batch_idx.device)
         elif self.order == 'leftright':
@@ -163,14 +204,14 @@ class LinearizedContext(nn.Module):
     def edge_ctx(self, obj_feats, obj_dists, im_inds, obj_preds, box_priors=None):
         obj_embed2 = self.obj_embed2(obj_preds)
         inp_feats = torch.cat((obj_embed2, obj_feats), 1)
-        confidence = F.softmax(obj_dists, dim=1).detach().view(-1)[obj_preds.detach() + arange(obj_preds) * self.num_classes]
+        confidence = lambda: F.softmax(obj_dists, dim=1).detach().view(-1)[obj_preds.detach() + arange(obj_preds) * self.num_classes]
         perm, inv_perm, ls_transposed = self.sort_rois(im_inds, confidence, box_priors)
         edge_input_packed = PackedSequence(inp_feats[perm], torch.tensor(ls_transposed))
         edge_reps = self.edge_ctx_rnn(edge_input_packed)[0][0]
         return edge_reps[inv_perm]
 
     def obj_ctx(self, obj_feats, obj_dists, im_inds, obj_labels=None, box_priors=None, boxes_per_cls=None):
-        confidence = F.softmax(obj_dists, dim=1).detach()[:, 1:].max(1)[0]
+        confidence = lambda: F.softmax(obj_dists, dim=1).detach()[:, 1:].max(1)[0]
         perm, inv_perm, ls_transposed = self.sort_rois(im_inds, confidence, box_priors)
         obj_inp_rep = obj_feats[perm].contiguous()
         bs = torch.tensor(ls_transposed)
@@ -389,7 +430,8 @@ class RelModel(nn.Module):
             result.rm_obj_dists, result.obj_preds, edge_ctx = self.context(
                 result.obj_fmap, result.rm_obj_dists.detach(), im_inds,
                 result.rm_obj_labels if self.training or self.mode == 'predcls' else None,
-                boxes.detach(), result.boxes_all)
+                boxes if not boxes.requires_grad else boxes.detach(),      # (a detached copy would drop the host mirror)
+                result.boxes_all)
             er = self.post_emb(result.obj_preds) if edge_ctx is None else self.post_lstm(edge_ctx)
             return er.view(er.size(0), 2, self.pooling_dim)
 

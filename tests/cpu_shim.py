@@ -46,8 +46,8 @@ def install():
     def gemm_planes(a, b, bias=None, epilogue=0, out=None, accumulate=False, splitk=0):
         return gemm(a.buf, b.buf, False, True, bias=bias, epilogue=epilogue, out=out, accumulate=accumulate)
 
-    def gemm_inloop(a, b, trans_a=False, trans_b=False, bias=None, epilogue=0, out=None):
-        return gemm(a, b, trans_a, trans_b, bias=bias, epilogue=epilogue, out=out)
+    def gemm_inloop(a, b, trans_a=False, trans_b=False, bias=None, epilogue=0, out=None, accumulate=False):
+        return gemm(a, b, trans_a, trans_b, bias=bias, epilogue=epilogue, out=out, accumulate=accumulate)
 
     def nms(boxes_sorted, thresh):
         keep = native.nms(_np(boxes_sorted), thresh)

@@ -254,6 +254,104 @@ def test_gemm_strided_rows(hip):
     np.testing.assert_allclose(out.cpu().numpy(), (a.cpu().double() @ w.cpu().double().t()).float().numpy(), atol=2e-4)
 
 
+# ----------------------------------------------------------------------------------------------- small-product engine
+# (csrc/gemm.hip, mh_gemm_small_f32: bf16x6, no row-maxima pass, split-K reduced by the last block of a tile inside the launch)
+SMALL_CASES = [
+    # M, N, K, ta, tb -- the small products of a cfg2 step (profiles/r04_gemm_shapes.jsonl) + ragged / unaligned ones
+    (120, 4096, 4096, 0, 1), (120, 512, 8192, 0, 0), (8192, 512, 120, 1, 0), (120, 151, 512, 0, 1), (152, 100, 3072, 0, 0),
+    (1536, 51, 4096, 0, 1), (51, 4096, 1536, 1, 0), (120, 4, 128, 0, 0), (120, 200, 151, 0, 1), (130, 129, 1003, 1, 1),
+    (120, 3072, 4424, 0, 0), (4424, 3072, 120, 1, 0), (37, 51, 4099, 0, 1),
+]
+
+
+def _counters_of(hip, device):
+    key = (str(device), 'gemm_counters', torch.cuda.current_stream().cuda_stream)
+    return hip._ws_cache[key].view(torch.int32)
+
+
+@pytest.mark.parametrize('M,N,K,ta,tb', SMALL_CASES)
+def test_small_product_engine_is_one_launch_and_equals_the_two_launch_form(hip, M, N, K, ta, tb):
+    g = torch.Generator().manual_seed(M * 5 + N * 11 + K)
+    a = torch.randn((K, M) if ta else (M, K), generator=g).cuda()
+    b = torch.randn((N, K) if tb else (K, N), generator=g).cuda()
+    bias = torch.randn(N, generator=g).cuda()
+    ref = ((a.t() if ta else a).double() @ (b.t() if tb else b).double()).cpu()
+    tol = 2e-5 * K ** 0.5 + 1e-5
+    out = hip.gemm_inloop(a, b, bool(ta), bool(tb), bias=bias, epilogue=1)
+    np.testing.assert_allclose(out.cpu().numpy(), torch.relu(ref + bias.cpu().double()).float().numpy(), atol=tol)
+    assert int(_counters_of(hip, a.device).abs().sum()) == 0, 'the arrival counters were not left zero'
+    # the fused reduction adds the K slices in slice order: bit-identical to the separate reduce launch over the same split
+    sk = hip.lib().mh_gemm_auto_splitk_v2(M, N, K)
+    sep = hip.gemm(a, b, bool(ta), bool(tb), bias=bias, epilogue=1, splitk=sk)       # mh_gemm_f32 -> mh_gemm_f32_v2: no counters
+    assert torch.equal(out, sep), 'fused and separate split-K reductions differ (split %d)' % sk
+    # ... and reproducible whatever order the slices arrive in
+    for _ in range(3):
+        assert torch.equal(hip.gemm_inloop(a, b, bool(ta), bool(tb), bias=bias, epilogue=1), out)
+    # accumulate into an existing C (the LSTM weight gradients): C += A.B
+    acc = torch.randn(M, N, generator=g).cuda()
+    out2 = acc.clone()
+    hip.gemm_inloop(a, b, bool(ta), bool(tb), out=out2, accumulate=True)
+    np.testing.assert_allclose(out2.cpu().numpy(), (ref + acc.cpu().double()).float().numpy(), atol=tol)
+    assert int(_counters_of(hip, a.device).abs().sum()) == 0
+
+
+def test_small_product_engine_copies_24_bit_operands_exactly(hip):
+    """three bf16 terms carry all 24 significant bits of an fp32 number: a selection matrix copies operand values through the
+    matrix cores bit for bit, from either side (the f16x3 engine of the big products carries 22-23)"""
+    g = torch.Generator().manual_seed(5)
+    a = (torch.randint(-2 ** 24 + 1, 2 ** 24, (200, 150), generator=g) | 1).float() * 2.0 ** -11
+    sel = torch.zeros(150, 90)
+    cols = torch.randint(0, 150, (90,), generator=g)
+    pw = 2.0 ** torch.randint(-6, 7, (90,), generator=g).float()
+    sel[cols, torch.arange(90)] = pw
+    out = hip.gemm_inloop(a.cuda(), sel.cuda(), False, False)
+    np.testing.assert_array_equal(out.cpu().numpy(), (a[:, cols] * pw).numpy())
+    out = hip.gemm_inloop(sel.cuda(), a.cuda(), True, True)
+    np.testing.assert_array_equal(out.cpu().numpy(), (a[:, cols] * pw).t().numpy())
+    # a wide dynamic range inside a row needs no scale: rows of 1e-20 .. 1e+10 magnitudes multiply like fp32
+    x = torch.randn(64, 256, generator=g) * (10.0 ** torch.randint(-20, 10, (64, 1), generator=g).float())
+    w = torch.randn(96, 256, generator=g) * (10.0 ** torch.randint(-10, 10, (96, 1), generator=g).float())
+    ref = x.double() @ w.double().t()
+    got = hip.gemm_inloop(x.cuda(), w.cuda(), False, True).cpu().double()
+    scale = (x.double().abs() @ w.double().abs().t())
+    assert ((got - ref).abs() / scale).max().item() < 2e-6
+
+
+def test_small_product_engine_error_is_fp32_rounding(hip):
+    g = torch.Generator().manual_seed(2)
+    a = torch.randn(120, 4096, generator=g)
+    b = torch.randn(3072, 4096, generator=g)
+    a[:, ::7] *= 1e-3
+    b[:, ::5] *= 1e4
+    ref = a.double() @ b.double().t()
+    err = hip.gemm_inloop(a.cuda(), b.cuda(), False, True).cpu().double() - ref
+    rms = ref.pow(2).mean().sqrt().item()
+    assert err.abs().max().item() / rms < 6e-6
+    assert err.pow(2).mean().sqrt().item() / rms < 8e-7
+    pos = hip.gemm_inloop(a.abs().cuda(), b.abs().cuda(), False, True).cpu().double() - a.abs().double() @ b.abs().double().t()
+    rel = pos / (a.abs().double() @ b.abs().double().t())
+    assert abs(rel.mean().item()) < 1e-6 and rel.abs().max().item() < 6e-6       # no one-sided bias (round to nearest split)
+
+
+def test_small_products_on_two_streams_keep_their_own_counters(hip):
+    """products of the two branches of a step run concurrently on two HIP streams: each stream has its own arrival counters
+    and partial-sum workspace, results are bit-identical to the sequential ones"""
+    g = torch.Generator().manual_seed(9)
+    a1, b1 = torch.randn(120, 4096, generator=g).cuda(), torch.randn(4096, 4096, generator=g).cuda()
+    a2, b2 = torch.randn(152, 3072, generator=g).cuda(), torch.randn(3072, 100, generator=g).cuda()
+    r1, r2 = hip.gemm_inloop(a1, b1, False, True), hip.gemm_inloop(a2, b2, False, False)
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    for _ in range(20):
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            o2 = [hip.gemm_inloop(a2, b2, False, False) for _ in range(4)]
+        o1 = [hip.gemm_inloop(a1, b1, False, True) for _ in range(4)]
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        assert all(torch.equal(o, r1) for o in o1) and all(torch.equal(o, r2) for o in o2)
+
+
 # ----------------------------------------------------------------------------------------------- conv stack
 @pytest.mark.parametrize('B,H,W,Cin,Cout,epi', [(2, 9, 11, 16, 32, 1), (1, 37, 37, 64, 128, 1), (2, 14, 14, 64, 64, 0),
                                                 (1, 20, 23, 128, 120, 2), (3, 7, 7, 256, 512, 1)])

@@ -662,3 +662,38 @@ def test_layer4_batchnorm_momentum_is_the_reference_models(shim):
     y1 = F.conv2d(x, sd['roi_fmap.0.0.conv1.weight'])
     OM.resnet_l4_head(sd, x, 'roi_fmap.0.', True)
     assert torch.allclose(sd['roi_fmap.0.0.bn1.running_mean'], 0.01 * y1.mean((0, 2, 3)), atol=1e-7)
+
+
+def test_host_side_packing_order_equals_the_device_arithmetic(shim):
+    """LinearizedContext.sort_rois: for the box-geometry orders the permutation is computed on the host from the boxes' Blob
+    mirror (no sort / gather launches on the context branch); it must be the permutation the tensor arithmetic gives --
+    ties (equal centres: stable, by index), ragged images, one image -- and it is computed once per forward."""
+    from lib.pytorch_misc import set_host
+    from lib.rel_model import LinearizedContext
+    rs = np.random.RandomState(11)
+    for order in ('leftright', 'size'):
+        ctx = LinearizedContext(['bg'] + ['c%d' % i for i in range(5)], ['bgr', 'r1'], mode='sgcls', embed_dim=8, hidden_dim=8,
+                                obj_dim=16, nl_obj=1, nl_edge=1, order=order)
+        for counts in ([5, 3, 7, 7, 1], [4], [2, 2, 2], [20, 20, 19, 20, 20, 20]):
+            im = np.repeat(np.arange(len(counts)), counts).astype(np.int64)
+            x1 = rs.randint(0, 500, im.size).astype(np.float32)
+            y1 = rs.randint(0, 500, im.size).astype(np.float32)
+            boxes = np.stack([x1, y1, x1 + rs.randint(10, 90, im.size), y1 + rs.randint(10, 90, im.size)], 1).astype(np.float32)
+            boxes[1::3] = boxes[0::3][:boxes[1::3].shape[0]]                    # exact ties inside and across images
+            b_plain, i_plain = torch.from_numpy(boxes.copy()), torch.from_numpy(im.copy())
+            ref = ctx.sort_rois(i_plain, None, b_plain)                        # no mirrors: the tensor path
+            b_host, i_host = set_host(torch.from_numpy(boxes.copy()), boxes), set_host(torch.from_numpy(im.copy()), im)
+            got = ctx.sort_rois(i_host, None, b_host)
+            assert torch.equal(got[0], ref[0]) and torch.equal(got[1], ref[1]) and list(got[2]) == list(ref[2])
+            assert torch.equal(got[0][got[1]], torch.arange(im.size))
+            assert ctx.sort_rois(i_host, None, b_host) is got                   # second call of the forward: cached
+    # 'confidence' never takes the host path, and its score is evaluated lazily
+    ctx = LinearizedContext(['bg', 'a', 'b'], ['bgr', 'r1'], mode='sgcls', embed_dim=8, hidden_dim=8, obj_dim=16, nl_obj=1,
+                            nl_edge=1, order='confidence')
+    calls = []
+    conf = torch.rand(im.size)
+    ctx.sort_rois(i_host, lambda: calls.append(1) or conf, b_host)
+    assert calls == [1]
+    ctx.order = 'leftright'
+    ctx.sort_rois(i_plain, lambda: calls.append(1) or conf, b_plain)
+    assert calls == [1]
