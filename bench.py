@@ -55,6 +55,10 @@ PEAK_FP32_MFMA_TFLOPS = 157.3          # /opt/skills/guides/MI355X_MICROARCH.md 
 PEAK_BF16_MFMA_TFLOPS = 2500.0         # same table, dense bf16 MFMA
 TRAFFIC_SUMMARY = 'profiles/r04_conv_traffic_summary.json'   # tools/r04/traffic_summary.py (ring trunk, shipped schedule)
 PEAK_HBM_TBS = 8.0                     # same table, HBM3E
+# every product is an fp32 product (operands, accumulation and results fp32, 1e-4 parity against the fp32 oracle); the matrix cores
+# evaluate it from 16-bit terms: big products as f16x3 (two f16 terms of row-scaled operands, 3 MFMAs), small ones as bf16x6
+# (three bf16 terms, 6 MFMAs) -- DESIGN.md section 3.1
+DTYPE = 'f32 (f16x3 / bf16x6 on the 16-bit matrix cores, fp32 accumulate)'
 MODEL_KW = dict(hidden_dim=512, pooling_dim=4096, nl_obj=2, nl_edge=2, order='leftright', rec_dropout=0.1,
                 use_bias=True, pass_in_obj_feats_to_decoder=False, pass_in_obj_feats_to_edge=False, use_tanh=False,
                 limit_vision=False)
@@ -189,7 +193,7 @@ def hbm_rows(meters, steps, opt_ms=None, opt_bytes=None):
         rows['fused_clip_sgd'] = {'bound': 'hbm', 'what': 'global-norm clip + SGD(momentum, wd) over all trainable parameters: 20 B/param',
                                   'achieved': opt_bytes / (opt_ms * 1e-3) / 1e9, 'peak': PEAK_HBM_TBS * 1e3, 'unit': 'GB/s',
                                   'frac': opt_bytes / (opt_ms * 1e-3) / 1e9 / (PEAK_HBM_TBS * 1e3), 'ms_per_step': opt_ms}
-    for k, what in (('lstm_fwd', 'persistent highway-LSTM forward (all layers of one context LSTM, grid barrier per step)'),
+    for k, what in (('lstm_fwd', 'persistent highway-LSTM forward (all layers of one context LSTM; state exchanged as tagged 8-byte granules, one launch per layer)'),
                     ('lstm_bwd', 'persistent highway-LSTM backward')):
         sm = meters[k].summary()
         if sm['launches']:
@@ -526,7 +530,7 @@ def secondary(args, rank, world, dev):
             (c, 'conv3x3_nhwc_kernel (implicit GEMM)')
         line = {'metric': unit_name, 'value': world * per_step * args.steps / dt, 'unit': 'img/s', 'n_gpus': world,
                 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * dt / args.steps, 'higher_is_better': True,
-                'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+                'scaling': 'weak', 'vs_baseline': None, 'dtype': DTYPE, 'data': 'synthetic',
                 'config': dict({'workload': workload, 'baseline_config': cfg, 'global_batch': world * per_step,
                                 'parallelism': 'dp%d' % world}, **extra),
                 'roofline': {'bound': 'mfma', 'kernel': dom_name, 'achieved': dom['tflops'], 'peak': peak, 'unit': 'TFLOP/s',
@@ -625,11 +629,14 @@ def main():
         reducer.prepare()
         loss.backward()                  # N > 1: each 32 MB gradient bucket is all-reduced (RCCL) as soon as it is complete
         reducer.finish()
-        if meters['roi'].enabled and KernelMeter.sampling:
+        timed = meters['roi'].enabled and KernelMeter.sampling
+        if opt.overlap_next_forward:
+            opt.meter_events = opt_events if timed else None      # events on the optimizer's own stream (lib/optim.py)
+        elif timed:
             ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
             ev[0].record()
         opt.step(max_norm=5.0)           # global-norm clip (5.0) + SGD(momentum, wd) in three multi-tensor launches
-        if meters['roi'].enabled and KernelMeter.sampling:
+        if timed and not opt.overlap_next_forward:
             ev[1].record()
             opt_events.append(ev)
         return loss
@@ -658,6 +665,7 @@ def main():
     t_enq = time.perf_counter()
     barrier()
     dt = time.time() - t0
+    dt_local = dt
     KernelMeter.sampling = True
     set_meters(meters, False)
     tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
@@ -768,6 +776,8 @@ def main():
                          % (['%.2f' % h for h in hs], 1e3 * dt / args.steps, buf.getvalue()))
 
     msteps = max(metered_steps, 1)              # the steps the kernel meters recorded (sample_step)
+    # what a first N > 1 run needs to be readable (lib/dist.py: scaling_diagnostics): gathered through the process group
+    diag = D.scaling_diagnostics(reducer, dev, 1e3 * dt_local / args.steps)
     if rank == 0:
         plc, c2 = merge(meters['plconv'].summary(), meters['plconv_img'].summary()), meters['conv'].summary()
         conv = merge(plc, c2)
@@ -797,21 +807,21 @@ def main():
             'metric': 'images/sec MotifNet-SGCls fwd+bwd' + (' (shipped recipe: nl_edge 4)' if args.config == 'recipe' else ''),
             'value': world * BATCH * args.steps / dt, 'unit': 'img/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * dt / args.steps,
-            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': DTYPE, 'data': 'synthetic',
             'ms_per_step_p50': stats['gpu_p50'], 'ms_per_step_p90': stats['gpu_p90'], 'ms_per_step_max': stats['gpu_max'],
             'step_ms': stats, 'h2d_inclusive': h2d, 'meter_every': args.meter_every, 'metered_steps': metered_steps,
             'config': {'workload': 'SGCls MotifNet VGG16 train step (fwd+bwd+clip+SGD), order=leftright, nl_obj=2, '
                                    'nl_edge=%d, hidden 512, batch 6/GPU, 20 GT boxes/img, <=256 rel rows/img, 592x592' % model_kw['nl_edge'],
                        'global_batch': world * BATCH, 'parallelism': 'dp%d' % world, 'final_loss': float(loss.item())},
-            'roofline': {'bound': 'mfma', 'kernel': 'pl::conv3x3_kernel (implicit GEMM on pre-split plane images: the 12 VGG trunk layers) + conv3x3_nhwc_kernel '
-                                                    '(union tower fwd / dgrad); ' + how,
+            'roofline': {'bound': 'mfma', 'kernel': 'pl::conv3x3_ring_kernel (implicit GEMM on pre-split plane images, LDS-DMA ring K loop: 11 VGG trunk layers; '
+                                                    'conv1_2 on pl::conv3x3_kernel) + conv3x3_nhwc_kernel (union tower fwd / dgrad); ' + how,
                          'achieved': conv['tflops'], 'peak': peak, 'unit': 'TFLOP/s',
                          'frac': conv['tflops'] / peak, 'traffic': traffic['bytes_per_launch'] if traffic else None,
                          'traffic_unit': 'bytes per launch (L2 fabric side: HBM + Infinity-Cache)',
                          'traffic_algorithmic': traffic['algorithmic_bytes_per_launch'] if traffic else None,
                          'traffic_source': TRAFFIC_SUMMARY + ' (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over one '
                                            'launch per trunk layer of this step with the shipped library, tools/r04/traffic.sh; replayed offline: a '
-                                           'PMC pass over the whole step does not finish); covers the 12 pl::conv3x3_kernel launches',
+                                           'PMC pass over the whole step does not finish); covers the 12 plane-trunk launches',
                          'frac_of_f32_mfma_peak': conv['tflops'] / PEAK_FP32_MFMA_TFLOPS,
                          'frac_of_bf16x6_peak': conv['tflops'] / (PEAK_BF16_MFMA_TFLOPS / 6.0),
                          'launches': conv['launches'], 'avg_launch_ms': conv['avg_ms'],
@@ -820,9 +830,9 @@ def main():
                                         'launches': plc['launches']}},
         }
         line['roofline_gemm'] = {
-            'bound': 'mfma', 'kernel': 'pl::gemm_kernel: every matrix product of the step -- mh_gemm_planes on ready plane images (fc6/fc7 of the '
-                                       'RoI heads: fwd, dgrad, wgrad), generic mh_gemm_f32 calls (operand preparation inside the call), the skinny '
-                                       'in-loop-split product; split-K reduces included',
+            'bound': 'mfma', 'kernel': 'every matrix product of the step: pl::gemm_ring_kernel / pl::gemm_kernel on ready plane images (mh_gemm_planes: fc6/fc7 '
+                                       'of the RoI heads fwd, dgrad, wgrad) + the small-product engine (mh_gemm_small_f32: bf16x6, one launch per product, '
+                                       'split-K reduced inside the launch); priced against the f16x3 peak',
             'achieved': gm['tflops'], 'peak': peak, 'unit': 'TFLOP/s', 'frac': gm['tflops'] / peak,
             'launches': gm['launches'], 'ms_per_step': gm['total_ms'] / msteps,
             'flops_per_step': gm['flops_per_launch'] * gm['launches'] / msteps,
@@ -833,10 +843,21 @@ def main():
         # the conv's: both rooflines are reported, this names the larger one)
         line['dominant_by_time'] = {'class': 'gemm' if gm['total_ms'] > conv['total_ms'] else 'conv3x3',
                                     'conv3x3_ms_per_step': conv['total_ms'] / msteps, 'gemm_ms_per_step': gm['total_ms'] / msteps}
+        # `roofline` headlines the class that takes more of the step; the other class's object stays beside it and both fractions
+        # are repeated in the headline object
+        line['roofline_conv'] = line['roofline']
+        if line['dominant_by_time']['class'] == 'gemm':
+            line['roofline'] = dict(line['roofline_gemm'], traffic=None, avg_launch_ms=gm['avg_ms'], flops_per_launch=gm['flops_per_launch'])
+        line['roofline'] = dict(line['roofline'], dominant_class=line['dominant_by_time']['class'],
+                                frac_conv3x3=conv['tflops'] / peak, frac_gemm=gm['tflops'] / peak, frac_trunk_only=plc['tflops'] / peak)
         opt_ms = sum(a.elapsed_time(b) for a, b in opt_events) / max(len(opt_events), 1) if opt_events else None
         n_train = sum(p.numel() for p in model.parameters() if p.requires_grad)
         line['hbm_kernels'] = hbm_rows(meters, msteps, opt_ms, 20.0 * n_train)
-        line['roofline']['ms_per_step'] = conv['total_ms'] / msteps
+        line['roofline_conv']['ms_per_step'] = conv['total_ms'] / msteps
+        line['scaling_diagnostics'] = diag
+        line['optimizer'] = {'deferred_to_own_stream': bool(opt.overlap_next_forward),
+                             'what': 'norm + update enqueued on the optimizer stream, beside the next step\'s frozen trunk' if opt.overlap_next_forward
+                                     else 'norm + update on the compute stream'}
         line['calibration'] = calibration()
         if sd_cpu is not None:
             try:

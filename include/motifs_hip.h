@@ -168,6 +168,7 @@ int mh_gemm_f32_v2(int transA, int transB, int M, int N, int K, const float *A, 
  *                           launch.  mh_gemm_small_max_counters() = the largest number ever used.
  *   workspace               >= mh_gemm_ws_bytes_v2(M, N, K, splitk) (split-K partial sums), 256-byte aligned */
 int mh_gemm_small_max_counters(void);
+int mh_debug_small_plan(int M, int N, int K);   /* tests / tools: K slices | (1 << 16 if the reduction is fused) for an auto split */
 int mh_gemm_small_f32(int transA, int transB, int M, int N, int K, const float *A, int lda,
                       const float *B, int ldb, float *C, int ldc, const float *bias, int epilogue,
                       int accumulate, int splitk, void *workspace, size_t ws_bytes, int *counters,

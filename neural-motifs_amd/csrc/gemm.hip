@@ -180,33 +180,91 @@ __global__ __launch_bounds__(kThreads, MH_MINW) void gemm_kernel(const GemmArgs 
             if (p.accumulate) v += p.C[(size_t)row * p.ldc + col];
             return v;
         };
+        // One block pulls the s slices of its tile: what bounds it is the number of loads it keeps in flight (a serial
+        // "one output, four slices at a time" loop ran at 15 GB/s: 190 us for the 40 slices of a 120 x 151 tile, gpurun
+        // r05_c1).  Here a thread owns kU outputs per pass and issues kU x 4 unconditional 16-byte loads before the first add
+        // (64 KB in flight per block); the slice order of every sum stays 0, 1, 2, ...
+        constexpr int kU = 4;
         if ((p.N & 3) == 0) {                          // n0 and cols are multiples of 4 then
-            const int c4 = cols >> 2;
-            for (int idx = tid; idx < rows * c4; idx += kThreads) {
-                const int r = idx / c4, c = (idx - r * c4) * 4;
-                const int row = m0 + r, col = n0 + c;
-                const float *src = p.partial + (size_t)row * p.N + col;
-                float4 v = *reinterpret_cast<const float4 *>(src);
-#pragma unroll 4
-                for (int zz = 1; zz < p.splitk; ++zz) {
-                    const float4 w = *reinterpret_cast<const float4 *>(src + (size_t)zz * plane);
-                    v.x += w.x; v.y += w.y; v.z += w.z; v.w += w.w;
+            const int c4 = cols >> 2, W = rows * c4;
+            for (int base = tid; base < W; base += kThreads * kU) {
+                const float *src[kU];
+                float4 v[kU];
+#pragma unroll
+                for (int u = 0; u < kU; ++u) {
+                    const int idx = min(base + u * kThreads, W - 1);       // the tail re-reads the last output (never stored)
+                    const int r = idx / c4, c = (idx - r * c4) * 4;
+                    src[u] = p.partial + (size_t)(m0 + r) * p.N + n0 + c;
+                    v[u] = *reinterpret_cast<const float4 *>(src[u]);
                 }
-                v.x = finish(v.x, row, col); v.y = finish(v.y, row, col + 1);
-                v.z = finish(v.z, row, col + 2); v.w = finish(v.w, row, col + 3);
-                float *q = p.C + (size_t)row * p.ldc + col;
-                if (p.vecC4) *reinterpret_cast<float4 *>(q) = v;
-                else { q[0] = v.x; q[1] = v.y; q[2] = v.z; q[3] = v.w; }
+                int zz = 1;
+                for (; zz + 3 < p.splitk; zz += 4) {
+                    float4 w[kU][4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+#pragma unroll
+                        for (int u = 0; u < kU; ++u) w[u][q] = *reinterpret_cast<const float4 *>(src[u] + (size_t)(zz + q) * plane);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+#pragma unroll
+                        for (int u = 0; u < kU; ++u) { v[u].x += w[u][q].x; v[u].y += w[u][q].y; v[u].z += w[u][q].z; v[u].w += w[u][q].w; }
+                }
+                for (; zz < p.splitk; ++zz) {
+                    float4 w[kU];
+#pragma unroll
+                    for (int u = 0; u < kU; ++u) w[u] = *reinterpret_cast<const float4 *>(src[u] + (size_t)zz * plane);
+#pragma unroll
+                    for (int u = 0; u < kU; ++u) { v[u].x += w[u].x; v[u].y += w[u].y; v[u].z += w[u].z; v[u].w += w[u].w; }
+                }
+#pragma unroll
+                for (int u = 0; u < kU; ++u) {
+                    const int idx = base + u * kThreads;
+                    if (idx >= W) break;
+                    const int r = idx / c4, c = (idx - r * c4) * 4;
+                    const int row = m0 + r, col = n0 + c;
+                    float4 o = v[u];
+                    o.x = finish(o.x, row, col); o.y = finish(o.y, row, col + 1);
+                    o.z = finish(o.z, row, col + 2); o.w = finish(o.w, row, col + 3);
+                    float *q = p.C + (size_t)row * p.ldc + col;
+                    if (p.vecC4) *reinterpret_cast<float4 *>(q) = o;
+                    else { q[0] = o.x; q[1] = o.y; q[2] = o.z; q[3] = o.w; }
+                }
             }
         } else {
-            for (int idx = tid; idx < rows * cols; idx += kThreads) {
-                const int r = idx / cols, c = idx - r * cols;
-                const int row = m0 + r, col = n0 + c;
-                const float *src = p.partial + (size_t)row * p.N + col;
-                float v = *src;
-#pragma unroll 4
-                for (int zz = 1; zz < p.splitk; ++zz) v += src[(size_t)zz * plane];
-                p.C[(size_t)row * p.ldc + col] = finish(v, row, col);
+            const int W = rows * cols;
+            for (int base = tid; base < W; base += kThreads * kU) {
+                const float *src[kU];
+                float v[kU];
+#pragma unroll
+                for (int u = 0; u < kU; ++u) {
+                    const int idx = min(base + u * kThreads, W - 1);
+                    const int r = idx / cols, c = idx - r * cols;
+                    src[u] = p.partial + (size_t)(m0 + r) * p.N + n0 + c;
+                    v[u] = *src[u];
+                }
+                int zz = 1;
+                for (; zz + 3 < p.splitk; zz += 4) {
+                    float w[kU][4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+#pragma unroll
+                        for (int u = 0; u < kU; ++u) w[u][q] = src[u][(size_t)(zz + q) * plane];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+#pragma unroll
+                        for (int u = 0; u < kU; ++u) v[u] += w[u][q];
+                }
+                for (; zz < p.splitk; ++zz) {
+#pragma unroll
+                    for (int u = 0; u < kU; ++u) v[u] += src[u][(size_t)zz * plane];
+                }
+#pragma unroll
+                for (int u = 0; u < kU; ++u) {
+                    const int idx = base + u * kThreads;
+                    if (idx >= W) break;
+                    const int r = idx / cols, c = idx - r * cols;
+                    p.C[(size_t)(m0 + r) * p.ldc + n0 + c] = finish(v[u], m0 + r, n0 + c);
+                }
             }
         }
         return;
@@ -618,11 +676,49 @@ int choose_splitk_tiles(long long tiles, int ktiles, double out_elems, double fl
     return best_s;
 }
 
-static int choose_splitk(int M, int N, int K)
+// ---- the schedule of the small-product engine (round 5).  choose_splitk_tiles prices a tile by its flops, which is right for
+// chip-filling products and wrong here: a 120 x 151 x 4096 product is two tiles whose 256 k-steps each cost what a k-step
+// of the in-loop engine costs whatever the tile holds -- ~0.75 us alone on a CU, ~0.9 us next to a second block (measured:
+// 194 us for 256 k-steps of one block, gpurun r05_c1) -- so the products of a step are latency chains that only more K
+// slices shorten, until the reduction of the slices costs more than the loop saves.  The reduction is either FUSED (the last
+// block of a tile adds its s slices: one block sustains ~50 GB/s, fine up to ~1 MB per tile) or a second launch
+// (splitk_reduce_kernel: chip-wide, ~2 TB/s on these sizes, + ~10 us for the launch and its gap).
+struct SmallPlan {
+    int splitk;
+    bool fused;
+};
+constexpr double kFusedBytesMax = 1.5e6;       // slices x tile bytes one block is asked to add up
+static SmallPlan plan_small(int M, int N, int K, int want_splitk, bool counters_ok)
 {
     const int bm = (N <= 64) ? 256 : 128, bn = (N <= 64) ? 64 : 128;
     const long long tiles = (long long)ceil_div(M, bm) * ceil_div(N, bn);
-    return choose_splitk_tiles(tiles, ceil_div(K, kBK), (double)M * N, 2.0 * M * N * K);
+    const int ktiles = ceil_div(K, kBK);
+    const double tile_bytes = 4.0 * std::min(M, bm) * std::min(N, bn);
+    auto fused_ok = [&](int sk) { return counters_ok && sk > 1 && sk * tile_bytes <= kFusedBytesMax && tiles <= kGemmCounters; };
+    if (want_splitk > 0) {
+        const int sk = std::max(1, std::min(std::min(want_splitk, ktiles), 64));
+        return {sk, fused_ok(sk)};
+    }
+    if (tiles >= 4096 || ktiles < 4) return {1, false};
+    static const int cand[] = {1, 2, 3, 4, 5, 6, 7, 8, 10, 12, 14, 16, 20, 24, 28, 32, 40, 48, 56, 64};
+    SmallPlan best = {1, false};
+    double best_cost = 1e30;
+    for (int sk : cand) {
+        if (sk > 1 && ktiles / sk < 2) break;
+        const long long blocks = tiles * sk;
+        const double kt = (double)ceil_div(ktiles, sk);
+        const double rounds = (double)ceil_div(blocks, 512LL);
+        const double loop = rounds * kt * (blocks <= 256 ? 0.75e-6 : 0.9e-6);
+        const double fixed = 4e-6;
+        for (int f = 0; f < 2; ++f) {
+            if (sk == 1 && f) continue;
+            if (f && !fused_ok(sk)) continue;
+            const double red = (sk == 1) ? 0.0 : f ? (sk * tile_bytes / 50e9 + 1e-6) : ((double)sk * M * N * 8.0 / 2e12 + 10e-6);
+            const double cost = loop + fixed + red;
+            if (cost < best_cost * 0.97) { best_cost = cost; best = {sk, f != 0}; }
+        }
+    }
+    return best;
 }
 
 int launch_splitk_reduce(const float *partial, int splitk, long long M, int N, float *C, int ldc, const float *bias,
@@ -645,12 +741,12 @@ int mh_mfma_split(void) { return MH_MFMA_SPLIT; }
 int mh_split_f16(void) { return MH_SPLIT_F16; }
 int mh_split_rne(void) { return 0; }      /* the bf16 round-to-nearest split variant is gone (round 3); kept for ABI stability */
 
-int mh_gemm_auto_splitk_v2(int M, int N, int K) { return (M > 0 && N > 0 && K > 0) ? choose_splitk(M, N, K) : 1; }
+int mh_gemm_auto_splitk_v2(int M, int N, int K) { return (M > 0 && N > 0 && K > 0) ? plan_small(M, N, K, 0, true).splitk : 1; }
 
 size_t mh_gemm_ws_bytes_v2(int M, int N, int K, int splitk)
 {
     if (M <= 0 || N <= 0 || K <= 0) return 0;
-    if (splitk <= 0) splitk = choose_splitk(M, N, K);
+    if (splitk <= 0) splitk = plan_small(M, N, K, 0, true).splitk;
     const size_t exps = align_up((size_t)M * sizeof(int), 256) + align_up((size_t)N * sizeof(int), 256);
     if (splitk <= 1) return exps;
     return exps + align_up((size_t)splitk * M * N * sizeof(float), 256);
@@ -681,9 +777,9 @@ static int gemm_inloop_impl(int sp, int transA, int transB, int M, int N, int K,
     MH_REQUIRE(A && B && C && K > 0);
     MH_REQUIRE(lda >= (transA ? M : K) && ldb >= (transB ? K : N) && ldc >= N);
     MH_REQUIRE(epilogue >= MH_EPI_NONE && epilogue <= MH_EPI_RELU6);
-    if (splitk <= 0) splitk = choose_splitk(M, N, K);
+    const SmallPlan pln = plan_small(M, N, K, splitk, counters != nullptr && n_counters > 0);
+    splitk = pln.splitk;
     const int total_kt = ceil_div(K, kBK);
-    splitk = std::min(std::min(splitk, total_kt), 64);
     hipStream_t st = as_stream(stream);
     GemmArgs p;
     p.expA = p.expB = nullptr;
@@ -715,7 +811,7 @@ static int gemm_inloop_impl(int sp, int transA, int transB, int M, int N, int K,
     p.tiles_n = ceil_div(N, narrow ? 64 : 128);
     const long long ntiles = (long long)p.tiles_m * p.tiles_n;
     MH_REQUIRE(ntiles < (1LL << 31) && splitk <= 65535);
-    p.counters = (splitk > 1 && counters != nullptr && ntiles <= (long long)n_counters) ? counters : nullptr;
+    p.counters = (splitk > 1 && pln.fused && ntiles <= (long long)n_counters) ? counters : nullptr;
     {   // patch-major tile order: ~64 tiles per patch (what one XCD runs at a time); the operand whose panel is the
         // more expensive to re-fetch gets the longer patch side.  MH_GEMM_PATCH=rows restores the round-1 order (A/B runs).
         static const bool rows_order = [] { const char *e = getenv("MH_GEMM_PATCH"); return e && e[0] == 'r'; }();
@@ -788,7 +884,14 @@ int mh_gemm_f32_v2(int transA, int transB, int M, int N, int K, const float *A, 
                             splitk, workspace, ws_bytes, nullptr, 0, stream);
 }
 
-int mh_gemm_small_max_counters(void) { return kGemmCounters; }      /* choose_splitk_tiles never splits a product of >= 4096 tiles */
+int mh_gemm_small_max_counters(void) { return kGemmCounters; }
+/* the plan of an auto-split small product: K slices | (1 << 16 when their reduction is fused into the launch) */
+int mh_debug_small_plan(int M, int N, int K)
+{
+    if (M <= 0 || N <= 0 || K <= 0) return 1;
+    const SmallPlan pl = plan_small(M, N, K, 0, true);
+    return pl.splitk | (pl.fused ? (1 << 16) : 0);
+}      /* choose_splitk_tiles never splits a product of >= 4096 tiles */
 
 int mh_gemm_small_f32(int transA, int transB, int M, int N, int K, const float *A, int lda, const float *B, int ldb,
                       float *C, int ldc, const float *bias, int epilogue, int accumulate, int splitk, void *workspace,

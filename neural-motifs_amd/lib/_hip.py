@@ -26,7 +26,7 @@ SYMBOLS = (
     'mh_act_planes_bytes', 'mh_act_planes', 'mh_plconv_packed_bytes', 'mh_plconv_pack_weight', 'mh_plconv3x3_ws_bytes',
     'mh_plconv3x3', 'mh_plconv3x3_to_image', 'mh_stem_to_image', 'mh_conv_first_nchw_max', 'mh_debug_plconv_shape', 'mh_debug_plconv_splitk', 'mh_debug_plconv_flags', 'mh_decoder_nms_commit_max_bytes',
     'mh_debug_pl_shape', 'mh_gemm_ws_bytes_v2', 'mh_gemm_auto_splitk_v2', 'mh_gemm_f32_v2',
-    'mh_gemm_small_max_counters', 'mh_gemm_small_f32',
+    'mh_gemm_small_max_counters', 'mh_gemm_small_f32', 'mh_debug_small_plan',
     'mh_conv3x3_packed_floats', 'mh_conv3x3_pack_weight', 'mh_conv3x3_ws_bytes', 'mh_conv3x3_schedule', 'mh_conv3x3_nhwc',
     'mh_conv3x3_wgrad_ws_bytes', 'mh_conv3x3_wgrad', 'mh_conv_first_nchw', 'mh_maxpool2x2_nhwc',
     'mh_maxpool2x2_bwd_nhwc', 'mh_act_bwd',
@@ -106,6 +106,26 @@ _raw_updates = {}
 def note_raw_update(p):
     k = p.data_ptr()
     _raw_updates[k] = _raw_updates.get(k, 0) + 1
+
+
+# A FusedClipSGD step enqueued on the optimizer's own stream (lib/optim.py: overlap_next_forward) leaves this event; whoever
+# touches a trainable parameter or a gradient next makes ITS stream wait for it first (RelModel.forward after the frozen
+# detector stage, FusedClipSGD.zero_grad / synchronize).  None: nothing pending.
+_pending_param_update = None
+
+
+def set_pending_param_update(event):
+    global _pending_param_update
+    _pending_param_update = event
+
+
+def wait_param_update():
+    """make the current stream wait for a deferred optimizer step, if one is in flight (no host synchronisation)"""
+    global _pending_param_update
+    ev = _pending_param_update
+    if ev is not None:
+        torch.cuda.current_stream().wait_event(ev)
+        _pending_param_update = None
 
 
 def version_of(p):
@@ -302,7 +322,7 @@ def _gemm_small(a, b, trans_a=False, trans_b=False, bias=None, epilogue=0, out=N
         raise HipKernelError('bad output tensor for gemm_inloop')
     if M == 0 or N == 0:
         return out
-    splitk = L.mh_gemm_auto_splitk_v2(M, N, K)
+    splitk = 0                     # the library plans the K split and whether its reduction is fused (csrc/gemm.hip: plan_small)
     wsb = L.mh_gemm_ws_bytes_v2(M, N, K, splitk)
     ws = workspace(wsb, a.device, 'gemm') if wsb else None
     nctr = L.mh_gemm_small_max_counters()

@@ -88,6 +88,23 @@ _LINEAR_ENGINE = os.environ.get('MOTIFS_LINEAR', 'auto')      # 'inloop': every 
 # multi-GPU: while a backward pass runs under lib.dist.OverlappedGradReducer this is its `grad_view`: a weight-gradient GEMM
 # writes its result straight into the parameter's slot of the gradient bucket (no copy into the bucket afterwards)
 GRAD_SINK = None
+# ... and the reducer itself: for a weight it reduces in row ranges (fc6: 411 MB in ranges of <= 64 MB) the weight gradient is
+# produced range by range, each range reported as soon as its GEMM is enqueued, so that its all-reduce runs under the next one
+GRAD_REDUCER = None
+
+
+def _wgrad_planes(gy, x_cols, weight):
+    """gw [N, K] = gy^T [N, M] . x [M, K] on plane images; `x_cols` = image of x with operand rows = x columns.  Written into
+    the parameter's gradient bucket when a reducer is armed (GRAD_SINK), in the reducer's row ranges when it has any."""
+    sink = GRAD_SINK(weight) if (GRAD_SINK is not None and weight.is_contiguous()) else None
+    segs = GRAD_REDUCER.segments(weight) if (sink is not None and GRAD_REDUCER is not None) else None
+    if segs is None or len(segs) < 2:
+        return _hip.gemm_planes(_hip.make_planes(gy, False), x_cols, out=sink)
+    red = GRAD_REDUCER
+    for i, (r0, r1) in enumerate(segs):
+        _hip.gemm_planes(_hip.make_planes(gy[:, r0:r1], False), x_cols, out=sink[r0:r1])
+        red.segment_done(weight, i)
+    return sink
 
 
 class _LinearFn(torch.autograd.Function):
@@ -152,8 +169,7 @@ class _LinearFn(torch.autograd.Function):
             if ctx.needs_input_grad[1]:
                 M, K, N = ctx.x_shape[0], ctx.x_shape[1], gy.shape[1]
                 if 2.0 * M * N * K >= 20e9 and M >= 96:        # the skinny layer's weight gradient is a big product again
-                    sink = GRAD_SINK(weight) if (GRAD_SINK is not None and weight.is_contiguous()) else None
-                    gw = _hip.gemm_planes(_hip.make_planes(gy, False), _hip.make_planes(x_keep, False), out=sink)
+                    gw = _wgrad_planes(gy, _hip.make_planes(x_keep, False), weight)
                 else:
                     sink = GRAD_SINK(weight) if (GRAD_SINK is not None and weight.is_contiguous()) else None
                     gw = _hip.gemm_inloop(gy, x_keep, True, False, out=sink)               # [M,N]^T . [M,K]
@@ -165,9 +181,12 @@ class _LinearFn(torch.autograd.Function):
                 gy_rows = gy_rows if gy_rows is not None else _hip.make_planes(gy, True)
                 gx = _hip.gemm_planes(gy_rows, _weight_image(weight, True))                 # [M,N] . (W^T image [K,N])^T
             if ctx.needs_input_grad[1]:
-                gy_cols = gy_cols if gy_cols is not None else _hip.make_planes(gy, False)
-                sink = GRAD_SINK(weight) if (GRAD_SINK is not None and weight.is_contiguous()) else None
-                gw = _hip.gemm_planes(gy_cols, ctx.x_cols, out=sink)                       # gy^T [N,M] . (x^T [K,M])^T
+                if GRAD_REDUCER is not None and GRAD_REDUCER.segments(weight) is not None:
+                    gw = _wgrad_planes(gy, ctx.x_cols, weight)                              # row ranges, reduced as they complete
+                else:
+                    gy_cols = gy_cols if gy_cols is not None else _hip.make_planes(gy, False)
+                    sink = GRAD_SINK(weight) if (GRAD_SINK is not None and weight.is_contiguous()) else None
+                    gw = _hip.gemm_planes(gy_cols, ctx.x_cols, out=sink)                   # gy^T [N,M] . (x^T [K,M])^T
         if ctx.has_bias and ctx.needs_input_grad[2]:
             gb = gy.sum(0)
         ctx.x_cols = None

@@ -18,8 +18,20 @@ from lib import _hip
 
 
 class FusedClipSGD(torch.optim.Optimizer):
-    def __init__(self, params, lr, momentum=0.9, weight_decay=0.0):
+    def __init__(self, params, lr, momentum=0.9, weight_decay=0.0, overlap_next_forward=None):
+        """overlap_next_forward: enqueue the step (norm + update: 20 B per parameter, HBM-bound, ~1.2 ms for MotifNet's 279 M
+        trainable parameters) on the optimizer's OWN stream, behind the gradients, instead of the compute stream.  The
+        next forward pass starts with the frozen detector trunk (matrix-core-bound, reads no trainable parameter):
+        the two run side by side, and the compute stream waits for the update only where RelModel.forward leaves the
+        detector stage (lib/_hip.py: wait_param_update).  Only for models whose first stage is frozen (the relation
+        drivers: models/train_rels.py:50-52); zero_grad() / synchronize() / state_dict() wait as well.  Default: the
+        environment variable MOTIFS_OPT_DEFER (unset = off)."""
         super(FusedClipSGD, self).__init__(params, dict(lr=lr, momentum=momentum, weight_decay=weight_decay))
+        if overlap_next_forward is None:
+            overlap_next_forward = os.environ.get('MOTIFS_OPT_DEFER', '0') == '1'
+        self.overlap_next_forward = bool(overlap_next_forward)
+        self._opt_stream = None
+        self.meter_events = None          # a list here receives (start, end) timing events of every deferred step (bench.py)
         mom = {g['momentum'] for g in self.param_groups}
         wd = {g['weight_decay'] for g in self.param_groups}
         if len(mom) != 1 or len(wd) != 1:
@@ -83,8 +95,57 @@ class FusedClipSGD(torch.optim.Optimizer):
         """host value of the gradient norm measured by the last step (forces a sync; for logging only)"""
         return float(self._sumsq.sqrt().item()) if self._sumsq is not None else 0.0
 
+    def zero_grad(self, set_to_none=True):
+        # the gradients a deferred step is still reading must not be released (or overwritten) under it
+        if torch.cuda.is_available():
+            _hip.wait_param_update()
+        return super(FusedClipSGD, self).zero_grad(set_to_none=set_to_none)
+
+    def synchronize(self):
+        """make the current stream wait for a deferred step (before parameters are read outside RelModel.forward:
+        checkpoints, evaluation code that bypasses it)"""
+        if torch.cuda.is_available():
+            _hip.wait_param_update()
+
+    def state_dict(self):
+        self.synchronize()
+        return super(FusedClipSGD, self).state_dict()
+
     @torch.no_grad()
     def step(self, max_norm=0.0, closure=None):
+        if not (self.overlap_next_forward and torch.cuda.is_available()):
+            return self._step(max_norm)
+        dev = None
+        for grp in self.param_groups:
+            for p in grp['params']:
+                if p.grad is not None:
+                    dev = p.device
+                    break
+            if dev is not None:
+                break
+        if dev is None or dev.type != 'cuda':
+            return self._step(max_norm)
+        main = torch.cuda.current_stream(dev)
+        if self._opt_stream is None:
+            self._opt_stream = torch.cuda.Stream(device=dev)
+        side = self._opt_stream
+        _hip.wait_param_update()                   # (a previous deferred step nobody waited for: keep the order on `main` too)
+        side.wait_stream(main)                     # every gradient of this backward pass is complete
+        with torch.cuda.stream(side):
+            timed = self.meter_events is not None
+            if timed:
+                e0 = torch.cuda.Event(enable_timing=True)
+                e0.record(side)
+            out = self._step(max_norm, bound_stream=main)
+            ev = torch.cuda.Event(enable_timing=timed)
+            ev.record(side)
+            if timed:
+                self.meter_events.append((e0, ev))
+        _hip.set_pending_param_update(ev)
+        return out
+
+    @torch.no_grad()
+    def _step(self, max_norm=0.0, bound_stream=None):
         # Host reads, no synchronisation: they see launches that have COMPLETED, i.e. steps the host enqueued up to
         # max_ahead steps ago.  What protects the weights of the steps in between is on the device: a timed-out
         # persistent launch NaN-poisons its outputs, the gradients and their norm become NaN, and multi_sgd_kernel
@@ -126,7 +187,7 @@ class FusedClipSGD(torch.optim.Optimizer):
                     self._done_events = [torch.cuda.Event() for _ in range(2 if self.max_ahead > 1 else 1)]
                 ev = self._done_events[(self._steps // period) % len(self._done_events)]
                 ev.synchronize()                 # recorded max_ahead steps ago (a never-recorded event returns at once)
-                ev.record()
+                ev.record(bound_stream) if bound_stream is not None else ev.record()
                 if self.max_ahead == 0:
                     ev.synchronize()
         return None

@@ -400,8 +400,15 @@ class RelModel(nn.Module):
     def forward(self, x, im_sizes, image_offset, gt_boxes=None, gt_classes=None, gt_rels=None, proposals=None,
                 train_anchor_inds=None, return_fmap=False):
         self.detector.sampler_rs = self.sampler_rs
+        # a FusedClipSGD step deferred to its own stream (lib/optim.py: overlap_next_forward) may still be updating the trainable
+        # parameters: the frozen detector stage runs beside it, everything after it waits
+        detector_trains = x.is_cuda and any(p.requires_grad for p in self.detector.parameters())
+        if detector_trains:
+            _hip.wait_param_update()
         result = self.detector(x, im_sizes, image_offset, gt_boxes, gt_classes, gt_rels, proposals,
                                train_anchor_inds, return_fmap=True)
+        if x.is_cuda and not detector_trains:
+            _hip.wait_param_update()
         if result.is_none():
             return ValueError("heck")            # the reference returns (not raises) this, :474-475
 

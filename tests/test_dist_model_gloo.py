@@ -67,6 +67,10 @@ def _losses(model, ds, idx, step):
             res.rm_obj_labels.shape[0], res.rel_labels.shape[0])
 
 
+def _pids(world):
+    return []          # (the ranks' pids are not known to each other: the identity strings are only checked for distinctness)
+
+
 def _worker(rank, world, port, out_dir):
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR='127.0.0.1',
                       MASTER_PORT=str(port))
@@ -76,8 +80,13 @@ def _worker(rank, world, port, out_dir):
     from lib import dist as D
     D.init_from_env(backend='gloo')
     opt = _optimizer(model, world)
-    red = D.OverlappedGradReducer([p for p in model.parameters() if p.requires_grad], bucket_bytes=8 << 20)
+    # split_bytes 16 MB: the three fc6 weights (411 MB each) are reduced in 26 row ranges each, produced range by range by the
+    # weight-gradient GEMM (lib/hip_ops.py: _wgrad_planes); fc7 (67 MB) in 4
+    red = D.OverlappedGradReducer([p for p in model.parameters() if p.requires_grad], bucket_bytes=8 << 20, split_bytes=16 << 20)
     assert red.enabled and len(red.buckets) >= 3
+    big = [p for p in red.params if p.numel() * 4 > red.split_bytes]
+    assert len(big) >= 4 and all(red.segments(p) is not None and len(red.segments(p)) >= 4 for p in big)
+    assert len(red.units) > len(red.buckets) + 40 and max(red.bucket_mb) <= 16.0 + 1e-6
     ptrs = None
     roww = D.RowWeights('cpu')
     model.rows_hook = roww.start              # the row-count all-reduce is launched inside the forward pass, asynchronously
@@ -89,12 +98,20 @@ def _worker(rank, world, port, out_dir):
         red.prepare()
         (l_obj * w[0] + l_rel * w[1]).backward()
         red.finish()
+        assert red.launch_log == list(range(len(red.units))), 'collectives were not issued in unit order'
         now = [p.grad.data_ptr() for p in red.params]
         assert ptrs is None or ptrs == now, 'reduced gradients must keep their addresses (fused optimizer pointer table)'
         ptrs = now
         opt.step(max_norm=5.0)
     # the big weight gradients (fc6 / fc7 / post_lstm ...) were written straight into their buckets by the GEMMs
     assert red.stats['in_place_bytes'] > 0.8 * (red.stats['in_place_bytes'] + red.stats['copied_bytes']), red.stats
+    # what bench.py adds to rank 0's line at N > 1 (lib/dist.py: scaling_diagnostics; every rank takes part)
+    diag = D.scaling_diagnostics(red, 'cpu', 12.5 + rank)
+    assert diag['ranks_seen'] == ['cpu:pid%d' % pid for pid in _pids(world)] or len(diag['ranks_seen']) == world
+    assert diag['distinct_devices'] == world and diag['collective_order_identical'] is True
+    assert diag['ms_per_step_per_rank'] == [12.5, 13.5] and len(diag['allreduce_exposed_ms']) == world
+    assert all(v >= 0.0 for v in diag['allreduce_exposed_ms']) and diag['bucket_mb'] == red.bucket_mb
+    assert diag['grad_bytes_in_place_frac'] > 0.8
     torch.save({n: p.detach().clone() for n, p in model.named_parameters() if p.requires_grad},
                os.path.join(out_dir, 'params%d.pt' % rank))
     dist.barrier()

@@ -317,3 +317,57 @@ def test_two_stream_train_step_equals_the_one_stream_step():
             err = float((g - two[3][name]).abs().max())
             assert err <= 1e-6 * float(g.abs().max()) + 1e-30, '%s: gradient differs by %.3e (max %.3e)' % (name, err, float(g.abs().max()))
     model.overlap_streams = True
+
+
+def test_deferred_optimizer_step_equals_the_in_order_step():
+    """FusedClipSGD(overlap_next_forward=True) runs norm + update on the optimizer's own stream, beside the frozen detector
+    stage of the NEXT forward pass; RelModel.forward waits for it where it leaves that stage.  Three training steps must leave
+    every parameter and momentum buffer bit-identical to the in-order optimizer's."""
+    if not torch.cuda.is_available():
+        pytest.fail('needs a HIP device')
+    from dataloaders.synthetic import SyntheticVG, make_blob
+    from lib import _hip
+    from lib.optim import FusedClipSGD
+    from lib.rel_model import RelModel
+    torch.manual_seed(5)
+    ds = SyntheticVG(num_images=4, seed=23, n_boxes=10, n_rels=12)
+    model = RelModel(classes=ds.ind_to_classes, rel_classes=ds.ind_to_predicates, mode='sgcls', num_gpus=1,
+                     hidden_dim=512, pooling_dim=4096, nl_obj=2, nl_edge=2, order='leftright', rec_dropout=0.0,
+                     use_bias=True, pass_in_obj_feats_to_decoder=False, pass_in_obj_feats_to_edge=False,
+                     use_tanh=False, limit_vision=False)
+    for _, p in model.detector.named_parameters():
+        p.requires_grad = False
+    model.cuda().train()
+    for m in model.modules():
+        if m.__class__.__name__ in ('Dropout', 'AlphaDropout'):
+            m.eval()
+    init = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    blobs = [make_blob(ds, [0, 1], is_train=True), make_blob(ds, [2, 3], is_train=True)]
+
+    def run(defer):
+        model.load_state_dict(init)
+        params = [p for p in model.parameters() if p.requires_grad]
+        opt = FusedClipSGD(params, lr=1e-2, momentum=0.9, weight_decay=1e-4, overlap_next_forward=defer)
+        for step in range(3):
+            model.sampler_rs = np.random.RandomState(40 + step)
+            res = model[blobs[step % 2]]
+            loss = F.cross_entropy(res.rm_obj_dists, res.rm_obj_labels) + F.cross_entropy(res.rel_dists, res.rel_labels[:, -1])
+            opt.zero_grad(set_to_none=True)
+            loss.backward()
+            opt.step(max_norm=5.0)
+            assert (_hip._pending_param_update is not None) == defer
+        opt.synchronize()
+        torch.cuda.synchronize()
+        assert _hip._pending_param_update is None
+        return ({n: p.detach().clone() for n, p in model.named_parameters() if p.requires_grad},
+                [opt.state[p]['momentum_buffer'].clone() for p in params], float(loss))
+
+    a, b = run(False), run(True)
+    assert a[2] == b[2]
+    moved = 0
+    for n in a[0]:
+        assert torch.equal(a[0][n], b[0][n]), n
+        moved += int(not torch.equal(a[0][n], init[n].to(a[0][n].device)))
+    assert moved >= 25
+    for x, y in zip(a[1], b[1]):
+        assert torch.equal(x, y)
