@@ -279,22 +279,20 @@ def cpu_baseline(ds, model_sd, iters=3, eval_images=3, budget_s=150.0):
 
 def launch_ranks(args, argv):
     """`python bench.py --gpus N` without torchrun's environment: start N ranks of this file under torch.distributed.run
-    (one process per GPU, rendezvous on 127.0.0.1 at a free port) and pass rank 0's JSON line through.  Returns the exit code."""
-    import socket
+    (one process per GPU, standalone c10d rendezvous on 127.0.0.1) and pass rank 0's JSON line through.  Returns the exit code."""
     import subprocess
     if not args.launch_selftest:
         n_dev = torch.cuda.device_count() if torch.cuda.is_available() else 0
         if n_dev < args.gpus:
             raise SystemExit('bench.py --gpus %d: only %d HIP device(s) visible -- refusing to run a smaller job under that name'
                              % (args.gpus, n_dev))
-    with socket.socket() as s:
-        s.bind(('127.0.0.1', 0))
-        port = s.getsockname()[1]
     env = dict(os.environ)
     env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')      # dmabuf IPC: RCCL's cross-process buffer sharing needs it on this driver
     env.setdefault('OMP_NUM_THREADS', str(max(1, (os.cpu_count() or 8) // max(args.gpus, 1))))
-    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus),
-           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + list(argv)
+    # --standalone: the c10d rendezvous binds a free port ITSELF (no bind-close-rebind window in which another process could
+    # take a port picked here, ADVICE r04); --local-addr: the container's hostname may not resolve
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--standalone', '--local-addr', '127.0.0.1', '--nnodes=1',
+           '--nproc-per-node', str(args.gpus), os.path.abspath(__file__)] + list(argv)
     return subprocess.call(cmd, env=env)
 
 
@@ -694,6 +692,21 @@ def main():
                'steps': args.h2d_steps, 'bytes_per_step': nbytes,
                'what': 'same step with the batch uploaded (pinned host -> HBM, async on the main stream) inside every step, unmetered'}
 
+    # third timing, meters off, inputs resident: what the headline would be without the sampled HIP-event pairs
+    unmetered = None
+    if args.h2d_steps > 0:
+        barrier()
+        t2 = time.time()
+        for i in range(args.h2d_steps):
+            step(i)
+        barrier()
+        dtu = torch.tensor([time.time() - t2], dtype=torch.float64, device=dev)
+        if world > 1:
+            torch.distributed.all_reduce(dtu, op=torch.distributed.ReduceOp.MAX)
+        dtu = float(dtu.item())
+        unmetered = {'value': world * BATCH * args.h2d_steps / dtu, 'unit': 'img/s', 'ms_per_step': 1e3 * dtu / args.h2d_steps,
+                     'steps': args.h2d_steps, 'what': 'the same step, inputs resident, kernel meters off'}
+
     if args.gemm_shapes and rank == 0:
         log = []
 
@@ -809,7 +822,7 @@ def main():
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * dt / args.steps,
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': DTYPE, 'data': 'synthetic',
             'ms_per_step_p50': stats['gpu_p50'], 'ms_per_step_p90': stats['gpu_p90'], 'ms_per_step_max': stats['gpu_max'],
-            'step_ms': stats, 'h2d_inclusive': h2d, 'meter_every': args.meter_every, 'metered_steps': metered_steps,
+            'step_ms': stats, 'h2d_inclusive': h2d, 'unmetered': unmetered, 'meter_every': args.meter_every, 'metered_steps': metered_steps,
             'config': {'workload': 'SGCls MotifNet VGG16 train step (fwd+bwd+clip+SGD), order=leftright, nl_obj=2, '
                                    'nl_edge=%d, hidden 512, batch 6/GPU, 20 GT boxes/img, <=256 rel rows/img, 592x592' % model_kw['nl_edge'],
                        'global_batch': world * BATCH, 'parallelism': 'dp%d' % world, 'final_loss': float(loss.item())},

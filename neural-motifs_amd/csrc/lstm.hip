@@ -334,8 +334,10 @@ __device__ __forceinline__ StepRows step_rows(const SeqSched &s, int t)
 // (L2 write-back), no acquire (L1 invalidate), and nobody waits for workgroups whose data it already has.
 // Tags are unique per (call, layer, step) -- the buffer is zeroed once per call -- and two slots alternate by step parity: a producer
 // that writes slot s for step i + 2 has consumed every granule of step i + 1, which each workgroup publishes only after it is done
-// reading step i from slot s.  The sweep is bounded like the barrier's spin (same fault path).
+// reading step i from slot s.  The sweep is bounded in TIME (400 ms of the device's wall clock) and raises the same fault word as the
+// barrier's spin when it expires.
 // ---------------------------------------------------------------------------------------------------
+constexpr unsigned long long kSweepBudgetTicks = 40000000ull;           // wall_clock64() runs at 100 MHz on gfx950: 400 ms
 constexpr size_t kXchFwdBytes = (size_t)2 * kSeqMaxB * kChunk * 8;      // 2 slots x <= 32 rows x <= 512 units x 8 B = 256 KiB
 constexpr size_t kXchBwdBytes = 5 * kXchFwdBytes;                       // the backward pass exchanges the 5 H gate gradients of every row
 
@@ -357,7 +359,11 @@ __device__ __forceinline__ bool load_vstage_gran(VStage &s, const unsigned long 
         s.v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
     bool all_ok = false;
-    for (int spin = 0; spin < (1 << 16) && !all_ok; ++spin) {
+    // Bounded by TIME, not by a spin count: a workgroup whose producers are not co-resident yet -- chip-filling conv /
+    // GEMM blocks of the other stream, a profiler -- may legitimately wait for many dispatch slots; 2^16 polls were 65-130 ms.
+    // kSweepBudgetTicks of the 100 MHz wall clock = 400 ms, checked (with the sticky `broken` word) every 64 polls.
+    const unsigned long long t_start = wall_clock64();
+    for (unsigned spin = 0; !all_ok; ++spin) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             if (!mine[i]) continue;
@@ -382,7 +388,10 @@ __device__ __forceinline__ bool load_vstage_gran(VStage &s, const unsigned long 
             }
         }
         if (!all_ok) {
-            if ((spin & 63) == 63 && __hip_atomic_load(broken, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return false;
+            if ((spin & 63) == 63) {
+                if (__hip_atomic_load(broken, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return false;
+                if (wall_clock64() - t_start > kSweepBudgetTicks) return false;
+            }
             __builtin_amdgcn_s_sleep(1);
         }
     }
@@ -1054,6 +1063,11 @@ static int fault_ctl(FaultCtl &fc)
     return MH_OK;
 }
 
+// Tags of the granule exchange are unique per (layer, step) of a call: layer l uses tag_base = 1 + kTagStride * l and step i the
+// tag tag_base + i (+ the fault hook's inflate, 1 at most), so the stride must exceed the longest sequence (+ 2)
+constexpr int kSeqMaxT = 4096;
+constexpr unsigned kTagStride = 2u * kSeqMaxT;
+static_assert(kTagStride > (unsigned)kSeqMaxT + 2u, "granule tags of neighbouring layers would alias");
 constexpr size_t kCounterBytes = 256;   // grid-barrier counters of the persistent layer kernels (one per layer)
 constexpr size_t kGemmCtrBytes = (size_t)kGemmCounters * sizeof(int);   // split-K arrival counters of the projections' small products
                                                                         // (gemm.hip: zero on entry, left zero), behind the barrier counters
@@ -1179,7 +1193,7 @@ int mh_hwlstm_fwd(int in_size, int H, int B, int L, int T, const float *x, const
     MH_REQUIRE(x && lengths_host && h_data && c_data && weight && bias && dropout && workspace);
     MH_REQUIRE(!is_training || gates);
     MH_REQUIRE(ws_bytes >= mh_hwlstm_fwd_ws_bytes(in_size, H, B, L, T));
-    MH_REQUIRE(T <= 4096);
+    MH_REQUIRE(T <= kSeqMaxT);
     for (int b = 0; b < B; ++b) {
         MH_REQUIRE(lengths_host[b] >= 1 && lengths_host[b] <= T);
         MH_REQUIRE(b == 0 || lengths_host[b] <= lengths_host[b - 1]);
@@ -1194,7 +1208,7 @@ int mh_hwlstm_fwd(int in_size, int H, int B, int L, int T, const float *x, const
     float *wh_t = reinterpret_cast<float *>(ws);
     ws += align_up((size_t)5 * H * H * sizeof(float), 256);
     const size_t numEl = (size_t)B * H;
-    int ts[4096], ns[4096];
+    int ts[kSeqMaxT], ns[kSeqMaxT];
     unsigned *counters = reinterpret_cast<unsigned *>(ws);   // one barrier counter per layer
     ws += kCounterBytes;
     int *gemm_ctr = reinterpret_cast<int *>(ws);
@@ -1229,7 +1243,7 @@ int mh_hwlstm_fwd(int in_size, int H, int B, int L, int T, const float *x, const
             hipLaunchKernelGGL(hw_layer_fwd_kernel, dim3(ceil_div(H, 4)), dim3(kGemvThreads), 0, st, sched, H, tmp_i, hl, cl,
                                wh_t, bias + (size_t)5 * H * layer, dropout + (size_t)layer * numEl,
                                is_training ? gates + (size_t)layer * T * 6 * numEl : nullptr, counters, layer, fc,
-                               gran ? xch : nullptr, 1u + 8192u * (unsigned)layer);
+                               gran ? xch : nullptr, 1u + kTagStride * (unsigned)layer);
             MH_TRY(check_launch("hw_layer_fwd_kernel"));
             continue;
         }
@@ -1367,7 +1381,7 @@ int mh_hwlstm_bwd(int in_size, int H, int B, int L, int T, const float *out_grad
                   const float *dropout, float *x_grad, float *weight_grad, float *bias_grad, int do_weight_grad,
                   void *workspace, size_t ws_bytes, void *stream)
 {
-    MH_REQUIRE(in_size > 0 && H > 0 && B > 0 && L > 0 && T > 0 && T <= 4096);
+    MH_REQUIRE(in_size > 0 && H > 0 && B > 0 && L > 0 && T > 0 && T <= kSeqMaxT);
     MH_REQUIRE(out_grad && lengths_host && x && h_data && c_data && weight && gates && dropout && x_grad && workspace);
     MH_REQUIRE(!do_weight_grad || (weight_grad && bias_grad));
     MH_REQUIRE(ws_bytes >= mh_hwlstm_bwd_ws_bytes(in_size, H, B, L, T));
@@ -1405,7 +1419,7 @@ int mh_hwlstm_bwd(int in_size, int H, int B, int L, int T, const float *out_grad
     }
     void *gws = ws;
     const size_t gws_bytes = ws_bytes - (size_t)(ws - reinterpret_cast<char *>(workspace));
-    int ts[4096], ns[4096];
+    int ts[kSeqMaxT], ns[kSeqMaxT];
 
     const float *grad_in = out_grad;  // gradient arriving at the current layer's outputs [T,B,H]
     for (int layer = L - 1; layer >= 0; --layer) {
@@ -1425,7 +1439,7 @@ int mh_hwlstm_bwd(int in_size, int H, int B, int L, int T, const float *out_grad
             hipLaunchKernelGGL(hw_layer_bwd_kernel, dim3(ceil_div(H, 4)), dim3(kGemvThreads), 0, st, sched, H, grad_in,
                                h_grad, c_grad, cl, gates + (size_t)layer * T * 6 * numEl,
                                dropout + (size_t)layer * numEl, dg_all, weight + o.wh, counters, layer, fc, gran ? xch : nullptr,
-                               1u + 8192u * (unsigned)layer);
+                               1u + kTagStride * (unsigned)layer);
             MH_TRY(check_launch("hw_layer_bwd_kernel"));
         } else
         for (int i = 0; i < T; ++i) {

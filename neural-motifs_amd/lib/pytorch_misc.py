@@ -146,10 +146,13 @@ def quiet_gc():
     gen-2 collection, none with the collector off, spread 0.01 %).  `gc.freeze()` moves everything alive NOW (the model,
     optimizer state, datasets -- built once, alive for the whole run) into the permanent generation that collections skip;
     the garbage of the steps themselves (autograd graphs are freed by reference counting) stays collectable and cheap.
-    Call once after the model, optimizer and data pipeline are built (and again after an evaluation pass if you like)."""
+    Call after the model, optimizer and data pipeline are built, and again at every epoch boundary (after the validation pass:
+    models/train_rels.py, train_detector.py) -- objects frozen once are never reclaimed otherwise, and what validation allocates
+    would bring the generation-2 pauses back."""
     import gc
-    gc.collect()
-    gc.freeze()
+    gc.unfreeze()        # a repeated call (epoch boundary): what was frozen and has died since becomes collectable again ...
+    gc.collect()         # ... is collected here, outside any step ...
+    gc.freeze()          # ... and what is alive now (incl. what an evaluation pass left behind) joins the permanent generation
 
 
 def restore_rel_checkpoint(rel_model, ckpt, ckpt_name):

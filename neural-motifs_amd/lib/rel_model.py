@@ -36,6 +36,10 @@ from lib.surgery import filter_dets
 from lib.word_vectors import obj_edge_vectors
 
 MODES = ('sgdet', 'sgcls', 'predcls')
+# SGDet training, two-stream mode: the object-context branch is enqueued BEFORE the host-side relation sampling (rel_assignments:
+# 3.5 ms during which the GPU queue used to run dry, profiles/r04_cfg3_trace_gaps_final.txt); MOTIFS_SGDET_CONTEXT_FIRST=0 = the
+# old order (A/B)
+SGDET_CONTEXT_FIRST = os.environ.get('MOTIFS_SGDET_CONTEXT_FIRST', '1') == '1'
 
 
 def _packing_plan(im_host):
@@ -368,6 +372,15 @@ class RelModel(nn.Module):
         uboxes = self.union_boxes(features, rois, pair_inds)
         return self.roi_fmap(uboxes)
 
+    def _side(self, device):
+        """the context branch's stream.  High priority: that branch is a long chain of small, latency-bound launches; its
+        workgroups should not queue behind the union-box branch's chip-filling GEMM / conv tiles.  MOTIFS_SIDE_PRIORITY=0
+        restores the default priority (A/B)"""
+        if self._side_stream is None:
+            prio = -1 if os.environ.get('MOTIFS_SIDE_PRIORITY', '-1') != '0' else 0
+            self._side_stream = torch.cuda.Stream(device=device, priority=prio)
+        return self._side_stream
+
     def get_rel_inds(self, rel_labels, im_inds, box_priors):
         """candidate (image, subject, object) rows: the sampled labels in training, every ordered pair of distinct
         boxes of an image in eval (overlapping ones only for sgdet)"""
@@ -416,18 +429,6 @@ class RelModel(nn.Module):
         if has_host(result.im_inds):
             set_host(im_inds, host_np(result.im_inds) - image_offset)
         boxes = result.rm_box_priors
-        if self.training and result.rel_labels is None:
-            assert self.mode == 'sgdet'
-            # index / ground-truth tensors are passed as they are (no .detach(): a new tensor object would drop the host mirror)
-            result.rel_labels = rel_assignments(im_inds, boxes.detach(), result.rm_obj_labels.detach(),
-                                                gt_boxes, gt_classes, gt_rels, image_offset,
-                                                filter_non_overlap=True, num_sample_per_gt=1, rs=self.sampler_rs)
-
-        rel_inds = self.get_rel_inds(result.rel_labels, im_inds, boxes)
-        if self.training and getattr(self, 'rows_hook', None) is not None:
-            # multi-GPU: both loss terms' row counts are known here, long before the losses: lib.dist.RowWeights launches
-            # its (tiny, asynchronous) all-reduce now instead of blocking in front of backward
-            self.rows_hook(int(result.rm_obj_labels.shape[0]), int(result.rel_labels.shape[0]))
         self.last_detector_obj_dists = result.rm_obj_dists.detach()   # the detector's logits of the kept boxes (the
         rois = torch.cat((im_inds[:, None].float(), boxes), 1)        # field is overwritten by the context's below)
         fmap = result.fmap.detach()
@@ -445,23 +446,42 @@ class RelModel(nn.Module):
         # Two-stream overlap only with device-side randomness: the seeded host mask stream used by the parity tests
         # fixes the draw ORDER (context before vision, as in the reference), which sequential issue preserves.
         overlap = (self.overlap_streams and self.use_vision and x.is_cuda and rng_mod._host_rng is None)
-        vr = None
-        if overlap:
-            main = torch.cuda.current_stream()
-            if self._side_stream is None:
-                # high priority: the context branch is a long chain of small, latency-bound launches (the step's critical path:
-                # profiles/r04_step_timeline_late0.txt); its workgroups should not queue behind the union-box branch's chip-filling
-                # GEMM / conv tiles.  MOTIFS_SIDE_PRIORITY=0 restores the default priority (A/B)
-                prio = -1 if os.environ.get('MOTIFS_SIDE_PRIORITY', '-1') != '0' else 0
-                self._side_stream = torch.cuda.Stream(device=x.device, priority=prio)
-            side = self._side_stream
-            side.wait_stream(main)                                   # fmap / rois / labels are ready
-            late = self._late_ok(fmap) and self.late_vr_backward in ('auto', '1', 'force')
-            vr = self.visual_rep(fmap, rois, rel_inds[:, 1:])         # big kernels first: the GPU is busy while
-            with torch.cuda.stream(side):                             # the host enqueues the small ones
+        early_edge_rep = None
+        if overlap and self.training and result.rel_labels is None and SGDET_CONTEXT_FIRST:
+            # SGDet training samples its relations on the HOST below; the context branch needs none of that, so its kernels go
+            # to the side stream first and run under the sampling
+            main, side = torch.cuda.current_stream(), self._side(x.device)
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
                 for t in (fmap, rois, im_inds, boxes, result.rm_obj_dists):
                     t.record_stream(side)
-                edge_rep = context_branch()
+                early_edge_rep = context_branch()
+        if self.training and result.rel_labels is None:
+            assert self.mode == 'sgdet'
+            # index / ground-truth tensors are passed as they are (no .detach(): a new tensor object would drop the host mirror)
+            result.rel_labels = rel_assignments(im_inds, boxes.detach(), result.rm_obj_labels.detach(),
+                                                gt_boxes, gt_classes, gt_rels, image_offset,
+                                                filter_non_overlap=True, num_sample_per_gt=1, rs=self.sampler_rs)
+
+        rel_inds = self.get_rel_inds(result.rel_labels, im_inds, boxes)
+        if self.training and getattr(self, 'rows_hook', None) is not None:
+            # multi-GPU: both loss terms' row counts are known here, long before the losses: lib.dist.RowWeights launches
+            # its (tiny, asynchronous) all-reduce now instead of blocking in front of backward
+            self.rows_hook(int(result.rm_obj_labels.shape[0]), int(result.rel_labels.shape[0]))
+        vr = None
+        if overlap:
+            main, side = torch.cuda.current_stream(), self._side(x.device)
+            late = self._late_ok(fmap) and self.late_vr_backward in ('auto', '1', 'force')
+            if early_edge_rep is None:
+                side.wait_stream(main)                               # fmap / rois / labels are ready
+                vr = self.visual_rep(fmap, rois, rel_inds[:, 1:])     # big kernels first: the GPU is busy while
+                with torch.cuda.stream(side):                         # the host enqueues the small ones
+                    for t in (fmap, rois, im_inds, boxes, result.rm_obj_dists):
+                        t.record_stream(side)
+                    edge_rep = context_branch()
+            else:
+                vr = self.visual_rep(fmap, rois, rel_inds[:, 1:])
+                edge_rep = early_edge_rep
             main.wait_stream(side)
             for t in (edge_rep, result.obj_fmap, result.rm_obj_dists, result.obj_preds):
                 if torch.is_tensor(t):

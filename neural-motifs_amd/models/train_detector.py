@@ -146,6 +146,7 @@ if __name__ == '__main__':
         if rank == 0:
             print("overall{:2d}: ({:.3f})\n{}".format(epoch, rez.mean(1)['total'], rez.mean(1)), flush=True)
         mAp = val_epoch()
+        quiet_gc()
         scheduler.step(mAp)
         if rank == 0 and conf.save_dir is not None:
             os.makedirs(conf.save_dir, exist_ok=True)

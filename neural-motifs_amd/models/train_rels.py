@@ -201,9 +201,12 @@ for epoch in range(start_epoch + 1, start_epoch + 1 + conf.num_epochs):
     if rank == 0:
         print("overall{:2d}: ({:.3f})\n{}".format(epoch, rez.mean(1)['total'], rez.mean(1)), flush=True)
         if conf.save_dir is not None:
+            if isinstance(optimizer, FusedClipSGD):
+                optimizer.synchronize()          # (a step deferred to the optimizer's own stream must have landed)
             torch.save({'epoch': epoch, 'state_dict': detector.state_dict()},
                        os.path.join(conf.save_dir, '{}-{}.tar'.format('vgrel', epoch)))
     mAp = val_epoch()
+    quiet_gc()        # what the validation pass left behind joins the permanent generation; what died is collected here
     scheduler.step(mAp)
     if any(pg['lr'] <= (conf.lr * world * conf.batch_size) / 99.0 for pg in optimizer.param_groups):
         print("exiting training early", flush=True)
