@@ -160,7 +160,7 @@ int mh_gemm_f32_v2(int transA, int transB, int M, int N, int K, const float *A, 
  * Same contract as mh_gemm_f32 (fp32 operands in any of the four orientations, bias / activation / accumulate), evaluated as
  * "bf16x6": each fp32 operand element is the exact sum of three bf16 terms (round to nearest), six v_mfma_f32_32x32x16_bf16
  * per accumulator and k-tile, fp32 accumulate -- no power-of-two row scales, hence no pass over the operands for their row
- * maxima in front of the product (what f16x3 needs: mh_gemm_f32_v2 = the same kernel family behind MH_SMALL_GEMM=f16x3).
+ * maxima in front of the product (what f16x3 needs).  mh_gemm_f32_v2 = the same engine without arrival counters.
  *   counters / n_counters   split-K arrival counters, one int per 128x128 (N <= 64: 256x64) output tile: ZERO on entry, left
  *                           ZERO on return; the last K slice of a tile to finish adds the slices in slice order (bit-identical
  *                           for any arrival order) and applies the epilogue inside the GEMM launch.  One array per HIP stream

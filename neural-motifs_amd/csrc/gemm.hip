@@ -1,8 +1,15 @@
-// gemm.hip -- fp32-accurate GEMM on the gfx950 matrix cores (f16x3 by default: three v_mfma_f32_32x32x16_f16 per product,
-// mfma_tile.h) for every nn.Linear-shaped
-// contraction on the path (fc6/fc7 x3, score/bbox heads, LSTM input projections, post_lstm, rel_compress and
-// their dgrad/wgrad).  Block tile 128x128x16, LDS double-buffered with register prefetch (one barrier per
-// k-tile), optional split-K with a fused bias/activation reduction.  See mfma_tile.h for the tile engine.
+// gemm.hip -- the SMALL-PRODUCT engine (round 5) and the helpers the other tile engines share.
+//   * mh_gemm_small_f32 / mh_gemm_f32_v2: every nn.Linear-shaped product that is not worth plane images (pl_gemm.hip routes
+//     products below 20 GFLOP or with K < 512 here): the ~40 small / skinny products of a step -- obj_embed, pos_embed, the LSTM
+//     and decoder projections, post_lstm, rel_compress, the object RoI head's fc6 / fc7 on ~120 rows, and their input / weight
+//     gradients.  fp32 operands are read ONCE and split into three bf16 terms by the threads that stage them ("bf16x6": six
+//     v_mfma_f32_32x32x16_bf16 per accumulator and k-tile, fp32 accumulate; mfma_tile.h); no power-of-two scales, so no pass
+//     over the operands in front of the product.  Block tile 128x128x16 (256x64 for N <= 64), LDS double-buffered, prefetch
+//     distance 2.  These products are latency chains, not throughput problems: plan_small() cuts K into as many slices as pays,
+//     and the last block of a tile to finish adds the slices in slice order inside the same launch (arrival counters): ONE launch
+//     per product where round 4 issued three (row maxima, product, reduction).
+//   * absmax_dual_kernel & co.: row maxima of operands for the f16x3 engines (plane images: pl_gemm.hip; conv.hip's weight
+//     gradient), the work-distribution model shared with the conv schedules, splitk_reduce_kernel.
 #include <algorithm>
 #include <cstdlib>
 
@@ -756,16 +763,13 @@ size_t mh_gemm_ws_bytes_v2(int M, int N, int K, int splitk)
 
 namespace mh {
 
-// which split the small-product engine runs: bf16x6 (no row maxima, one launch per product) unless MH_SMALL_GEMM=f16x3 asks
-// for round 2's f16x3 evaluation (a pass over both operands for their row maxima in front of every product) -- A/B only
-static int small_gemm_split()
-{
-    static const int sp = [] { const char *e = getenv("MH_SMALL_GEMM"); return (e && e[0] == 'f') ? kSplitF16x3 : kSplitBf16x6; }();
-    return sp;
-}
+// The small-product engine runs bf16x6 only.  Round 2's f16x3 evaluation of the same kernel family (a pass over both operands
+// for their row maxima in front of every product, then three f16 MFMAs) was kept as an A/B arm for one measurement and removed:
+// same box, cfg2 step, 330.7 img/s against 348.3 / 351.3 with bf16x6 (profiles/r05_bench_c1_*.json).
+static int small_gemm_split() { return kSplitBf16x6; }
 
 // The in-loop-split product: fp32 operands are read once and split by the threads that stage them.
-//   sp           kSplitF16x3 (row maxima first: launch_operand_absmax, exponents at the head of the workspace) or kSplitBf16x6
+//   sp           kSplitBf16x6
 //   counters     split-K arrival counters (>= one int per output tile, ZERO on entry, left zero): the last block of a tile
 //                reduces its slices inside the GEMM launch; NULL (or too few): a separate splitk_reduce_kernel launch
 static int gemm_inloop_impl(int sp, int transA, int transB, int M, int N, int K, const float *A, int lda, const float *B, int ldb,
@@ -783,16 +787,7 @@ static int gemm_inloop_impl(int sp, int transA, int transB, int M, int N, int K,
     hipStream_t st = as_stream(stream);
     GemmArgs p;
     p.expA = p.expB = nullptr;
-    if (sp == kSplitF16x3) {   // the row exponents live at the head of the workspace (mh_gemm_ws_bytes counts them)
-        const size_t ea = align_up((size_t)M * sizeof(int), 256), eb = align_up((size_t)N * sizeof(int), 256);
-        MH_REQUIRE(workspace && ws_bytes >= ea + eb);
-        int *expA = reinterpret_cast<int *>(workspace), *expB = reinterpret_cast<int *>(reinterpret_cast<char *>(workspace) + ea);
-        int rc_e = launch_operand_absmax(A, !transA, M, K, lda, expA, B, transB != 0, N, K, ldb, expB, st);
-        if (rc_e) return rc_e;
-        p.expA = expA; p.expB = expB;
-        workspace = reinterpret_cast<char *>(workspace) + ea + eb;
-        ws_bytes -= ea + eb;
-    }
+    MH_REQUIRE(sp == kSplitBf16x6);       // (the f16x3 form of this kernel needs row exponents: conv.hip still uses that half of mfma_tile.h)
     if (splitk > 1 && (workspace == nullptr || ws_bytes < (size_t)splitk * M * N * sizeof(float))) splitk = 1;
     p.M = M; p.N = N; p.K = K;
     p.A = A; p.lda = lda; p.B = B; p.ldb = ldb; p.C = C; p.ldc = ldc;
@@ -838,11 +833,7 @@ static int gemm_inloop_impl(int sp, int transA, int transB, int M, int N, int K,
         else launch_tile_kernel<gemm_kernel<TA_, TB_, 128, 128, F_, SP_>>(                                      \
                 grid, tile_lds_bytes<128, 128, !TA_, TB_>(), st, p);                                            \
     } while (0)
-#define MH_LAUNCH_GEMM2(TA_, TB_, F_)                                   \
-    do {                                                                \
-        if (sp == kSplitF16x3) MH_LAUNCH_GEMM3(TA_, TB_, F_, kSplitF16x3); \
-        else MH_LAUNCH_GEMM3(TA_, TB_, F_, kSplitBf16x6);               \
-    } while (0)
+#define MH_LAUNCH_GEMM2(TA_, TB_, F_) MH_LAUNCH_GEMM3(TA_, TB_, F_, kSplitBf16x6)
 #define MH_LAUNCH_GEMM(TA_, TB_)                          \
     do {                                                  \
         if (fast) MH_LAUNCH_GEMM2(TA_, TB_, true);        \
@@ -875,7 +866,8 @@ int gemm_small(int transA, int transB, int M, int N, int K, const float *A, int 
 
 extern "C" {
 
-// the round-2 entry point: the engine chosen by small_gemm_split(), the split-K reduction as a separate launch
+// the round-2 entry point (fp32 operands split inside the K loop), now the small-product engine without arrival counters:
+// the split-K reduction is a separate launch
 int mh_gemm_f32_v2(int transA, int transB, int M, int N, int K, const float *A, int lda, const float *B, int ldb,
                 float *C, int ldc, const float *bias, int epilogue, int accumulate, int splitk, void *workspace,
                 size_t ws_bytes, void *stream)

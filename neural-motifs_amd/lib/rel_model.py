@@ -36,10 +36,11 @@ from lib.surgery import filter_dets
 from lib.word_vectors import obj_edge_vectors
 
 MODES = ('sgdet', 'sgcls', 'predcls')
-# SGDet training, two-stream mode: the object-context branch is enqueued BEFORE the host-side relation sampling (rel_assignments:
-# 3.5 ms during which the GPU queue used to run dry, profiles/r04_cfg3_trace_gaps_final.txt); MOTIFS_SGDET_CONTEXT_FIRST=0 = the
-# old order (A/B)
-SGDET_CONTEXT_FIRST = os.environ.get('MOTIFS_SGDET_CONTEXT_FIRST', '1') == '1'
+# SGDet training, two-stream mode: MOTIFS_SGDET_CONTEXT_FIRST=1 enqueues the object-context branch BEFORE the host-side relation
+# sampling (rel_assignments: 3.5 ms during which the GPU queue runs dry, profiles/r04_cfg3_trace_gaps_final.txt).  Measured in
+# round 5 (gpurun r05_c3, cfg3, one box): 142.0 / 139.7 img/s with it, 146.6 without -- the SGDet step is bound by the HOST's
+# enqueue time (~1000 launches per step), and the order of two pieces of host work does not change their sum.  Off.
+SGDET_CONTEXT_FIRST = os.environ.get('MOTIFS_SGDET_CONTEXT_FIRST', '0') == '1'
 
 
 def _packing_plan(im_host):

@@ -100,7 +100,8 @@ def test_sgdet_eval_end_to_end(det):
     # chained across devices a 1-ulp difference may re-rank two near-tied scores, so the end-to-end check hands the oracle
     # the PRODUCT's detections (det_override) and demands equality of everything the relation model makes of them.
     gt = dict(gt_classes=ds.gt_classes[2], gt_relations=ds.relationships[2], gt_boxes=ds.gt_boxes[2])
-    _oracle_on_product_detections(model, sd, cfg, a, got, tag='sgdet e2e', gt=gt)
+    # fp64_prob_floor: the relation logits of this (reference-initialised) model are O(1e3); see the probability bound in the helper
+    _oracle_on_product_detections(model, sd, cfg, a, got, tag='sgdet e2e', gt=gt, fp64_prob_floor=True)
     rb = ref[0]
     same = sum(1 for b in boxes if np.any(np.all(np.abs(rb - b[None]) < 1e-2, 1)))
     print('sgdet e2e: %d detections (oracle on its own detector: %d), %d coincide' % (boxes.shape[0], rb.shape[0], same))
@@ -109,7 +110,8 @@ def test_sgdet_eval_end_to_end(det):
     assert abs(boxes.shape[0] - rb.shape[0]) <= 2 and same >= min(boxes.shape[0], rb.shape[0]) - 2, (boxes.shape[0], rb.shape[0], same)
 
 
-def _oracle_on_product_detections(model, sd, cfg, a, got, tag, logits_tol=1e-4, fp64_floor=False, gt=None, min_firm=None):
+def _oracle_on_product_detections(model, sd, cfg, a, got, tag, logits_tol=1e-4, fp64_floor=False, gt=None, min_firm=None,
+                                  fp64_prob_floor=False):
     """the oracle's relation model (eval mode) on the detections of the product's last forward: object labels, boxes and the
     set of candidate pairs EXACT; the ranked pair list exact wherever two ranking scores are separated by more than their
     rounding; object / relation logits and scores within `logits_tol` of scale"""
@@ -125,6 +127,12 @@ def _oracle_on_product_detections(model, sd, cfg, a, got, tag, logits_tol=1e-4, 
                                       False, OM.HostRNG(0), det_override=override)
     floor, ref_scores = {}, None
     key2 = lambda r: r[:, 0] * 1000 + r[:, 1]
+    ref64_scores = None
+    if fp64_prob_floor and not fp64_floor:
+        dbl = lambda t: t.double() if torch.is_tensor(t) and t.is_floating_point() else t
+        with torch.no_grad():
+            ref64_scores, _ = OM.relmodel_forward({k: dbl(v.clone()) for k, v in sd.items()}, dict(cfg, return_logits=True), a[0].double(), a[1], 0,
+                                                  dbl(a[3]), a[4], False, OM.HostRNG(0), det_override={k: dbl(v) for k, v in override.items()})
     if fp64_floor:
         # The fp32 rounding floor of these tensors: the same oracle evaluated in float64 on the same detections.  At cfg5's
         # size (80-step recurrences, 6320 pairs) two correct fp32 evaluations differ by more than 1e-4 of scale: the fp32
@@ -185,7 +193,23 @@ def _oracle_on_product_detections(model, sd, cfg, a, got, tag, logits_tol=1e-4, 
     if cut > 0:
         assert triples(got, cut) == triples(rank_ref, cut), '%s: top-%d triples differ' % (tag, cut)
     og, orr = np.argsort(key(rels), kind='stable'), np.argsort(key(sc_ref[3]), kind='stable')
-    rel_close(pred_scores[og], np.asarray(sc_ref[4], dtype=np.float64)[orr], rtol=logits_tol, what=tag + ' predicate probabilities')
+    prob_tol = logits_tol
+    p64 = ref_scores if ref_scores is not None else ref64_scores
+    if p64 is not None:
+        # A probability is a softmax over logits of the size the test runs at: |dp| = p (1 - p) |dlogit|.  At the reference's own
+        # initialisation the relation logits are O(1e3) (an fp32 ulp there is 1.2e-4), so two correct fp32 evaluations differ by
+        # about 1e-4 in a PROBABILITY although their logits agree to 3e-6 of scale (measured: 0.9e-4 .. 1.02e-4 between the product
+        # and the fp32 oracle, whichever engine evaluates rel_compress).  The fp32 oracle's own distance from the float64
+        # evaluation of the same detections is the floor; the product may be at most twice as far from the float64 result.
+        o32, o64 = np.argsort(key(ref[3]), kind='stable'), np.argsort(key(np.asarray(p64[3])), kind='stable')
+        assert np.array_equal(key(ref[3])[o32], key(np.asarray(p64[3]))[o64])
+        p_64 = np.asarray(p64[4], dtype=np.float64)[o64]
+        e_o32 = float(np.abs(np.asarray(ref[4], dtype=np.float64)[o32] - p_64).max())
+        e_prod = float(np.abs(np.asarray(pred_scores, dtype=np.float64)[og] - p_64).max())
+        print('%s predicate probabilities vs the float64 oracle: product %.3e, float32 oracle %.3e' % (tag, e_prod, e_o32))
+        assert e_prod <= max(logits_tol, 2.0 * e_o32 + 1e-6), '%s: probabilities %.3e from the float64 evaluation (fp32 oracle: %.3e)' % (tag, e_prod, e_o32)
+        prob_tol = max(logits_tol, e_prod + e_o32 + 1e-6) if ref_scores is None else max(logits_tol, 2.0 * e_o32 + 1e-6)
+    rel_close(pred_scores[og], np.asarray(sc_ref[4], dtype=np.float64)[orr], rtol=prob_tol, what=tag + ' predicate probabilities')
     nfirm = int(firm.sum())
     print('%s: %d detections, %d pairs, %d of them firmly ranked, order violation %.2e (allowance %.2e), top-%d triple sets equal' % (
         tag, boxes.shape[0], rels.shape[0], nfirm, worst, eps, cut))
