@@ -14,7 +14,7 @@ import torch
 import torch.nn as nn
 
 from lib import _hip
-from lib.rng import dropout as rng_dropout
+from lib.rng import alpha_dropout as rng_alpha_dropout, dropout as rng_dropout
 
 EPI_NONE, EPI_RELU, EPI_RELU6 = 0, 1, 2
 
@@ -242,6 +242,14 @@ class Dropout(nn.Module):
 
     def forward(self, x):
         return rng_dropout(x, self.p, self.training)
+
+
+class AlphaDropout(nn.AlphaDropout):
+    """nn.AlphaDropout whose mask source can be switched to the seeded host stream (lib/rng.py): the SELU RoI head of the ResNet
+    detector branch in train mode is then comparable with the oracle draw for draw."""
+
+    def forward(self, x):
+        return rng_alpha_dropout(x, self.p, self.training)
 
 
 class FCStack(nn.Sequential):

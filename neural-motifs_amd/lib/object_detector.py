@@ -21,7 +21,7 @@ from lib.fpn.nms.functions.nms import apply_nms, nms_mask_per_class
 from lib.fpn.proposal_assignments.proposal_assignments_gtbox import proposal_assignments_gtbox
 from lib.fpn.proposal_assignments.proposal_assignments_det import proposal_assignments_det
 from lib.fpn.roi_align.functions.roi_align import RoIAlignFunction
-from lib.hip_ops import (Conv3x3, Dropout, FCStack, Linear, ReLU, VGG16Features, EPI_NONE, EPI_RELU6, _is_nhwc,
+from lib.hip_ops import (AlphaDropout, Conv3x3, Dropout, FCStack, Linear, ReLU, VGG16Features, EPI_NONE, EPI_RELU6, _is_nhwc,
                          _Conv3x3Fn, linear)
 from lib.pytorch_misc import enumerate_by_image, gather_nd, has_host, host_np, set_host
 
@@ -134,8 +134,8 @@ class ObjectDetector(nn.Module):
             self.features = load_resnet()
             self.compress = ResNetCompress()
             self.roi_fmap = nn.Sequential(
-                Linear(256 * 7 * 7, 2048), nn.SELU(inplace=True), nn.AlphaDropout(p=0.05),
-                Linear(2048, 2048), nn.SELU(inplace=True), nn.AlphaDropout(p=0.05))
+                Linear(256 * 7 * 7, 2048), nn.SELU(inplace=True), AlphaDropout(p=0.05),
+                Linear(2048, 2048), nn.SELU(inplace=True), AlphaDropout(p=0.05))
             rpn_input_dim, output_dim = 1024, 2048
         self.score_fc = Linear(output_dim, self.num_classes)
         self.bbox_fc = Linear(output_dim, self.num_classes * 4)

@@ -44,3 +44,24 @@ def dropout(x, p, training):
     if _host_rng is None:
         return torch.nn.functional.dropout(x, p, True)       # fused mask + scale: one launch forward, one backward
     return x * keep_mask(x.shape, 1.0 - p, x.device) / (1.0 - p)
+
+
+# torch.nn.AlphaDropout (the SELU RoI head of the ResNet detector branch, reference lib/object_detector.py:89-96):
+# dropped units take the SELU saturation value alpha' = -scale * alpha, then the affine (a, b) restores zero mean / unit variance
+_ALPHA_PRIME = -1.7580993408473766
+
+
+def alpha_dropout_coeffs(p):
+    a = ((1.0 - p) * (1.0 + p * _ALPHA_PRIME ** 2)) ** -0.5
+    return a, -a * _ALPHA_PRIME * p
+
+
+def alpha_dropout(x, p, training):
+    """torch.nn.functional.alpha_dropout with a switchable mask source: y = a (x m + alpha' (1 - m)) + b"""
+    if not training or p == 0.0:
+        return x
+    if _host_rng is None:
+        return torch.nn.functional.alpha_dropout(x, p, True)
+    m = keep_mask(x.shape, 1.0 - p, x.device)
+    a, b = alpha_dropout_coeffs(p)
+    return a * (x * m + _ALPHA_PRIME * (1.0 - m)) + b

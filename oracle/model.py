@@ -205,10 +205,24 @@ def resnet_l4_head(sd, x, prefix, training, relu_end=False):
     return x.mean((2, 3))
 
 
-def resnet_roi_head(sd, pooled, prefix='detector.roi_fmap.'):
-    """Linear -> SELU -> AlphaDropout -> Linear -> SELU -> AlphaDropout (:89-96), eval mode (dropout = identity)"""
-    y = F.selu(F.linear(pooled, sd[prefix + '0.weight'], sd[prefix + '0.bias']))
-    return F.selu(F.linear(y, sd[prefix + '3.weight'], sd[prefix + '3.bias']))
+_ALPHA_PRIME = -1.7580993408473766      # -selu_scale * selu_alpha: the value a dropped unit takes (torch.nn.AlphaDropout)
+
+
+def alpha_dropout(x, p, training, rng):
+    """torch.nn.functional.alpha_dropout with the mask drawn from `rng` (reference: nn.AlphaDropout(p=0.05),
+    lib/object_detector.py:92,95): y = a (x m + alpha' (1 - m)) + b, a = ((1-p)(1 + p alpha'^2))^-1/2, b = -a alpha' p"""
+    if not training or p == 0.0 or rng is None:
+        return x
+    m = rng.keep_mask(x.shape, 1.0 - p).to(x.dtype)
+    a = ((1.0 - p) * (1.0 + p * _ALPHA_PRIME ** 2)) ** -0.5
+    return a * (x * m + _ALPHA_PRIME * (1.0 - m)) + (-a * _ALPHA_PRIME * p)
+
+
+def resnet_roi_head(sd, pooled, prefix='detector.roi_fmap.', training=False, rng=None):
+    """Linear -> SELU -> AlphaDropout -> Linear -> SELU -> AlphaDropout (:89-96); the dropout masks are drawn from `rng` in
+    train mode (identity without one: eval mode)"""
+    y = alpha_dropout(F.selu(F.linear(pooled, sd[prefix + '0.weight'], sd[prefix + '0.bias'])), 0.05, training, rng)
+    return alpha_dropout(F.selu(F.linear(y, sd[prefix + '3.weight'], sd[prefix + '3.bias'])), 0.05, training, rng)
 
 
 class _RoIAlignFn(torch.autograd.Function):
@@ -266,8 +280,11 @@ def detector_forward(sd, cfg, x, im_sizes, image_offset, gt_boxes, gt_classes, t
     if cfg['mode'] in ('sgcls', 'predcls'):
         im_inds = gt_classes[:, 0] - image_offset
         rois = torch.cat((im_inds.to(gt_boxes.dtype)[:, None], gt_boxes), 1)
-        if resnet:      # lib/object_detector.py:129-138 with the compress conv in front of RoIAlign (:84-96), dropout = identity
-            obj_fmap = resnet_roi_head(sd, roi_align(resnet_compress(sd, fmap, training), rois).view(rois.size(0), -1))
+        if resnet:      # lib/object_detector.py:129-138 with the compress conv in front of RoIAlign (:84-96); the AlphaDropout of
+            # the SELU head draws from `rng` only with cfg['resnet_alpha_dropout'] (the parity tests of the relation model run the
+            # frozen detector's dropout off on both sides)
+            obj_fmap = resnet_roi_head(sd, roi_align(resnet_compress(sd, fmap, training), rois).view(rois.size(0), -1),
+                                       training=training and cfg.get('resnet_alpha_dropout', False), rng=rng)
         else:
             obj_fmap = vgg_classifier(sd, roi_align(fmap, rois).view(rois.size(0), -1),
                                       'detector.roi_fmap.', training, rng)
