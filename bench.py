@@ -644,11 +644,14 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
+    from lib.pytorch_misc import quiet_gc
+    quiet_gc()                 # what models/train_rels.py does before its first epoch: no full garbage collection inside a step.
+                               # BEFORE the warm-up (round 5): the collection takes ~0.2 s with the GPU idle, and the first dozen steps
+                               # after such a pause run ~6 % slower than the steady state (17.0 against 16.1 ms, gpurun r05_c4: the
+                               # part's power management ramping up again) -- the warm-up steps are there to absorb exactly that
     for i in range(args.warmup):
         step(i)
     barrier()
-    from lib.pytorch_misc import quiet_gc
-    quiet_gc()                 # what models/train_rels.py does before its first epoch: no full garbage collection inside a step
     set_meters(meters, True)
     step_ev = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     host_t = []

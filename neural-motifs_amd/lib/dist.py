@@ -421,4 +421,5 @@ def scaling_diagnostics(reducer, device, ms_per_step_local):
             'bucket_mb': reducer.bucket_mb if reducer is not None else [],
             'collective_order_identical': all(v['order'] == allv[0]['order'] for v in allv),
             'grad_bytes_in_place_frac': (reducer.stats['in_place_bytes'] /
-                                         max(1, reducer.stats['in_place_bytes'] + reducer.stats['copied_bytes'])) if reducer is not None else None}
+                                         max(1, reducer.stats['in_place_bytes'] + reducer.stats['copied_bytes']))
+                                        if (reducer is not None and reducer.enabled) else None}
