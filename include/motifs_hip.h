@@ -209,6 +209,13 @@ int mh_plconv3x3_to_image(const void *in_image, const unsigned *in_true_maxbits,
                           unsigned *out_maxbits, void *workspace, size_t ws_bytes, void *stream);
 int mh_stem_to_image(const float *in_nchw, int B, int Cin, int H, int W, const float *w, int Cout, const float *bias,
                      int epilogue, void *out_image, unsigned *out_maxbits, void *stream);
+/* conv1_1 with its weights through the scalar cache (round 5; Cin = 3, Cout = 64: the VGG stem): `packed` = the weights as a
+ * [27][64] table + bias + the two scalars of the output bound, written by mh_stem_pack_weight once per parameter version
+ * (mh_stem_packed_bytes, 256-byte aligned; 0 = shape not supported, use mh_stem_to_image).  Bit-identical to mh_stem_to_image. */
+size_t mh_stem_packed_bytes(int Cin, int Cout);
+int mh_stem_pack_weight(const float *w, int Cin, int Cout, const float *bias, void *packed, void *stream);
+int mh_stem_to_image_packed(const float *in_nchw, int B, int Cin, int H, int W, const void *packed, int Cout, int epilogue,
+                            void *out_image, unsigned *out_maxbits, void *stream);
 void mh_debug_plconv_shape(int shape);
 void mh_debug_plconv_splitk(int splitk);   /* 0 = the planner's schedule; > 0 = every tile in that many K slices (sweeps) */
 void mh_debug_plconv_flags(int flags);     /* measurement only; bit 1: the ring kernel returns without its epilogue (no output) */
@@ -283,8 +290,9 @@ int mh_nhwc_to_nchw(const float *in, int B, int C, int H, int W, float *out, voi
  * the barrier spin is bounded; a block that times out stores 1 into a host-pinned fault word, the launch poisons its
  * outputs (h / gate gradients) with NaN, and EVERY later mh_hwlstm_* / mh_hwcell_seq_* call on that device returns
  * MH_EFAULT until mh_fault_clear().  mh_fault_pending() is a host read (no synchronisation): poll it at step end.
- * Backward: out_grad [T,B,H]; outputs x_grad [T,B,in] (overwritten), weight_grad / bias_grad
- * (ACCUMULATED into, caller zero-fills) when do_weight_grad.
+ * Backward: out_grad [T,B,H]; outputs x_grad [T,B,in] (overwritten); when do_weight_grad: weight_grad (OVERWRITTEN since
+ * round 5: every region of the flat vector is written exactly once per call -- no 64 MB zero fill in front) and bias_grad
+ * (ACCUMULATED into, the caller zero-fills its 5*H*L floats).
  * ------------------------------------------------------------------------------------------- */
 size_t mh_hwlstm_fwd_ws_bytes(int in_size, int H, int B, int L, int T);
 int mh_hwlstm_fwd(int in_size, int H, int B, int L, int T, const float *x,

@@ -1465,16 +1465,20 @@ int mh_hwlstm_bwd(int in_size, int H, int B, int L, int T, const float *out_grad
                             nullptr, MH_EPI_NONE, 0, gws, gws_bytes, gemm_ctr, kGemmCounters, stream));
         if (do_weight_grad) {
             // dWx[in, 6H] += inp[T*B, in]^T * dg_all[T*B, 6H]
+            // (every region of weight_grad is written exactly once per call: plain stores, the caller need not zero 64 MB first)
             MH_TRY(gemm_f32_ctr(1, 0, o.in_size, 6 * H, T * B, inp, o.in_size, dg_all, 6 * H, weight_grad + o.wx, 6 * H,
-                                nullptr, MH_EPI_NONE, 1, gws, gws_bytes, gemm_ctr, kGemmCounters, stream));
+                                nullptr, MH_EPI_NONE, 0, gws, gws_bytes, gemm_ctr, kGemmCounters, stream));
             // dWh[H, 5H] += h_prev^T * dg_all[:, :5H];  h_prev(t) = slot t (forward layers) or slot t+2
             // (backward layers; t = T-1 reads the all-zero slot 0 and contributes nothing)
             if (fwd_dir) {
                 MH_TRY(gemm_f32_ctr(1, 0, H, 5 * H, T * B, hl, H, dg_all, 6 * H, weight_grad + o.wh, 5 * H, nullptr,
-                                    MH_EPI_NONE, 1, gws, gws_bytes, gemm_ctr, kGemmCounters, stream));
+                                    MH_EPI_NONE, 0, gws, gws_bytes, gemm_ctr, kGemmCounters, stream));
             } else if (T > 1) {
                 MH_TRY(gemm_f32_ctr(1, 0, H, 5 * H, (T - 1) * B, hl + 2 * numEl, H, dg_all, 6 * H, weight_grad + o.wh,
-                                    5 * H, nullptr, MH_EPI_NONE, 1, gws, gws_bytes, gemm_ctr, kGemmCounters, stream));
+                                    5 * H, nullptr, MH_EPI_NONE, 0, gws, gws_bytes, gemm_ctr, kGemmCounters, stream));
+            } else {                    // a one-step backward-direction layer has no previous state: dWh = 0
+                hipError_t ez = hipMemsetAsync(weight_grad + o.wh, 0, (size_t)H * 5 * H * sizeof(float), st);
+                if (ez != hipSuccess) return (int)ez;
             }
             hipLaunchKernelGGL(colsum_accum_kernel, dim3(ceil_div(5 * H, 64)), dim3(256), 0, st, dg_all, T * B, 5 * H,
                                6 * H, bias_grad + (size_t)5 * H * layer);
