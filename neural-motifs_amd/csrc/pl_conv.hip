@@ -841,7 +841,7 @@ __global__ __launch_bounds__(256) void stem_kernel(const float *__restrict__ in,
 // (the idiom of tower_conv1_fwd_kernel, with the roles of data and weights swapped) -- no LDS at all; a thread keeps the 27 inputs
 // of TWO pixels in registers and runs the four chunks over them, so every scalar load feeds 32 FMAs.  Same FMA order per output as
 // stem_kernel (bias, then ci outer / tap inner): the two kernels are bit-identical (tests/test_gpu_ops.py).
-constexpr int kStemCin = 3, kStemCout = 64, kStemK = 9 * kStemCin, kStemPx = 2;
+constexpr int kStemCin = 3, kStemCout = 64, kStemK = 9 * kStemCin, kStemPx = 1;
 constexpr int kStemPackFloats = kStemK * kStemCout + kStemCout + 2;      // wt[k = tap * Cin + ci][co] | bias[co] | wnorm | bmax
 
 __global__ __launch_bounds__(64) void stem_pack_kernel(const float *__restrict__ w, const float *__restrict__ bias, float *__restrict__ pk)
