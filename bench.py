@@ -153,7 +153,6 @@ def install_meters(_hip):
         plconv=KernelMeter(_hip, 'plconv3x3', _plconv_flops), conv=KernelMeter(_hip, 'conv3x3_nhwc', _conv_flops),
         plconv_img=KernelMeter(_hip, 'plconv3x3_to_image', lambda a, k, y: 2.0 * a[0].B * a[0].H * a[0].W * a[0].C * a[3] * 9),
         stem=KernelMeter(_hip, 'stem_to_image', lambda a, k, y: (0.0, 4.0 * a[0].numel() + float(y.buf.numel()))),
-        stem_pk=KernelMeter(_hip, 'stem_to_image_packed', lambda a, k, y: (0.0, 4.0 * a[0].numel() + float(y.buf.numel()))),
         gemm_planes=KernelMeter(_hip, 'gemm_planes', _gemm_planes_flops), gemm=KernelMeter(_hip, 'gemm', _gemm_flops),
         gemm_inloop=KernelMeter(_hip, 'gemm_inloop', _gemm_flops),
         roi=KernelMeter(_hip, 'roi_align_fwd', _roi_bytes), act=KernelMeter(_hip, 'act_planes', _act_planes_bytes),
@@ -186,8 +185,7 @@ def hbm_rows(meters, steps, opt_ms=None, opt_bytes=None):
                           'frac': summ['gbps'] / (PEAK_HBM_TBS * 1e3), 'launches_per_step': summ['launches'] / steps,
                           'ms_per_step': summ['total_ms'] / steps, 'bytes_per_step': summ['bytes'] / steps}
     row('roi_align_fwd', meters['roi'].summary(), 'RoIAlign 7x7 forward (objects + union boxes): output bytes + feature map once')
-    row('stem_to_image', merge(meters['stem'].summary(), meters['stem_pk'].summary()),
-        'conv1_1 (3 -> 64 channels, VALU; weights through the scalar cache) writing its output as a plane image: NCHW input + image bytes')
+    row('stem_to_image', meters['stem'].summary(), 'conv1_1 (3 -> 64 channels, VALU) writing its output as a plane image: NCHW input + image bytes')
     row('act_planes', meters['act'].summary(), 'fp32 NHWC -> plane image (2x2 pool fused where the trunk has one): bytes in + bytes out')
     row('make_planes', merge(meters['planes'].summary(), meters['planes_both'].summary()),
         'GEMM operand preparation (row maxima + split, both orientations from one read where both are needed): read once + images written')

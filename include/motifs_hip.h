@@ -209,13 +209,7 @@ int mh_plconv3x3_to_image(const void *in_image, const unsigned *in_true_maxbits,
                           unsigned *out_maxbits, void *workspace, size_t ws_bytes, void *stream);
 int mh_stem_to_image(const float *in_nchw, int B, int Cin, int H, int W, const float *w, int Cout, const float *bias,
                      int epilogue, void *out_image, unsigned *out_maxbits, void *stream);
-/* conv1_1 with its weights through the scalar cache (round 5; Cin = 3, Cout = 64: the VGG stem): `packed` = the weights as a
- * [27][64] table + bias + the two scalars of the output bound, written by mh_stem_pack_weight once per parameter version
- * (mh_stem_packed_bytes, 256-byte aligned; 0 = shape not supported, use mh_stem_to_image).  Bit-identical to mh_stem_to_image. */
-size_t mh_stem_packed_bytes(int Cin, int Cout);
-int mh_stem_pack_weight(const float *w, int Cin, int Cout, const float *bias, void *packed, void *stream);
-int mh_stem_to_image_packed(const float *in_nchw, int B, int Cin, int H, int W, const void *packed, int Cout, int epilogue,
-                            void *out_image, unsigned *out_maxbits, void *stream);
+
 void mh_debug_plconv_shape(int shape);
 void mh_debug_plconv_splitk(int splitk);   /* 0 = the planner's schedule; > 0 = every tile in that many K slices (sweeps) */
 void mh_debug_plconv_flags(int flags);     /* measurement only; bit 1: the ring kernel returns without its epilogue (no output) */

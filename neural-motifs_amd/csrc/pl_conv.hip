@@ -833,131 +833,10 @@ __global__ __launch_bounds__(256) void stem_kernel(const float *__restrict__ in,
     if (out_bits) wave_atomic_max(out_bits, cur < 0 ? 0 : cur, cur < 0 ? 0u : vmax);
 }
 
-// ---- conv1_1, second form (round 5): the weights through the SCALAR cache --------------------------------------------------
-// stem_kernel above reads its 27 x 16 weights per (pixel, 16-channel chunk) from LDS: 108 broadcast ds_read_b128 per 432 FMAs, and
-// re-fetches the pixel's 27 inputs for each of the four chunks -- 0.40 ms per step for a layer whose output write is 0.11 ms
-// (profiles/r05_bench_n1_kernel_stats_c1.csv).  Here the weights are wave-uniform operands: a packed table wt[k][64] (+ bias, + the
-// two scalars of the output bound) prepared once per parameter version, read with s_load_dwordx16 and fed to v_fmac_f32 as SGPRs
-// (the idiom of tower_conv1_fwd_kernel, with the roles of data and weights swapped) -- no LDS at all; a thread keeps the 27 inputs
-// of TWO pixels in registers and runs the four chunks over them, so every scalar load feeds 32 FMAs.  Same FMA order per output as
-// stem_kernel (bias, then ci outer / tap inner): the two kernels are bit-identical (tests/test_gpu_ops.py).
-constexpr int kStemCin = 3, kStemCout = 64, kStemK = 9 * kStemCin, kStemPx = 1;
-constexpr int kStemPackFloats = kStemK * kStemCout + kStemCout + 2;      // wt[k = tap * Cin + ci][co] | bias[co] | wnorm | bmax
-
-__global__ __launch_bounds__(64) void stem_pack_kernel(const float *__restrict__ w, const float *__restrict__ bias, float *__restrict__ pk)
-{
-    __shared__ float sa[kStemCout], sb[kStemCout];
-    const int co = threadIdx.x;
-    float a = 0.f;
-    for (int k = 0; k < kStemK; ++k) {
-        const int tap = k / kStemCin, ci = k % kStemCin;
-        const float v = w[((size_t)co * kStemCin + ci) * 9 + tap];
-        pk[k * kStemCout + co] = v;
-        a += fabsf(v);
-    }
-    const float b = bias ? bias[co] : 0.f;
-    pk[kStemK * kStemCout + co] = b;
-    sa[co] = a;
-    sb[co] = fabsf(b);
-    __syncthreads();
-    if (co == 0) {
-        float wn = 0.f, bm = 0.f;
-        for (int i = 0; i < kStemCout; ++i) { wn = fmaxf(wn, sa[i]); bm = fmaxf(bm, sb[i]); }
-        pk[kStemK * kStemCout + kStemCout] = wn;
-        pk[kStemK * kStemCout + kStemCout + 1] = bm;
-    }
-}
-
-__global__ __launch_bounds__(256) void stem_packed_kernel(const float *__restrict__ in, int B, int H, int W, const float *__restrict__ pk,
-                                                          int epilogue, const unsigned *__restrict__ in_bits, char *__restrict__ out_cells,
-                                                          unsigned *__restrict__ scale_bits, unsigned *__restrict__ out_bits)
-{
-    // the thread's 2 x 27 inputs, [k][pixel slot][thread]: private to the thread (no barrier), conflict-free, and -- unlike a register
-    // array -- indexable by the RUNTIME tap loop below.  (Fully unrolled, with the inputs in registers, the compiler loads all 432
-    // weight scalars of a chunk up front and spills them through v_writelane / v_readlane: 14 readlanes per FMA in the first build.)
-    __shared__ float vs[kStemK][kStemPx][256];
-    const int tid = threadIdx.x;
-    const float wnorm = pk[kStemK * kStemCout + kStemCout], bmax = pk[kStemK * kStemCout + kStemCout + 1];
-    auto bound_bits = [&](int b) { return __float_as_uint(__uint_as_float(in_bits[b]) * wnorm + bmax); };
-    if (blockIdx.x == 0 && tid < B) scale_bits[tid] = bound_bits(tid);
-    const long long HW = (long long)H * W, M = (long long)B * HW;
-    int cur[kStemPx], e[kStemPx];
-    unsigned vmax[kStemPx];
-#pragma unroll
-    for (int p = 0; p < kStemPx; ++p) { cur[p] = -1; e[p] = 0; vmax[p] = 0; }
-    for (long long base = ((long long)blockIdx.x * 256 + tid) * kStemPx; base < M; base += (long long)gridDim.x * 256 * kStemPx) {
-        bool ok[kStemPx];
-        long long pix[kStemPx];
-#pragma unroll
-        for (int p = 0; p < kStemPx; ++p) {
-            ok[p] = base + p < M;
-            pix[p] = ok[p] ? base + p : M - 1;
-            const int b = (int)(pix[p] / HW), rem = (int)(pix[p] - (long long)b * HW), y = rem / W, x = rem - y * W;
-            if (b != cur[p]) {                  // a slot sees its pixels in increasing order: image indices never go back
-                if (cur[p] >= 0 && vmax[p] && out_bits) atomicMax(out_bits + cur[p], vmax[p]);
-                cur[p] = b;
-                vmax[p] = 0;
-                e[p] = row_exponent(bound_bits(b));
-            }
-#pragma unroll
-            for (int ci = 0; ci < kStemCin; ++ci) {
-                const float *plane = in + ((size_t)b * kStemCin + ci) * HW;
-#pragma unroll
-                for (int tap = 0; tap < 9; ++tap) {
-                    const int yy = y + tap / 3 - 1, xx = x + tap % 3 - 1;
-                    float t = 0.f;
-                    if ((unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W) t = plane[(size_t)yy * W + xx];
-                    vs[ci * 9 + tap][p][tid] = t;
-                }
-            }
-        }
-#pragma unroll 1
-        for (int g = 0; g < kStemCout / kBK; ++g) {
-            const float *__restrict__ wg = pk + g * kBK;                         // wave-uniform: scalar loads
-            float acc[kStemPx][16];
-#pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                const float bj = wg[kStemK * kStemCout + j];
-#pragma unroll
-                for (int p = 0; p < kStemPx; ++p) acc[p][j] = bj;
-            }
-#pragma unroll 1
-            for (int ci = 0; ci < kStemCin; ++ci) {                              // stem_kernel's FMA order: ci outer, tap inner
-#pragma unroll 3
-                for (int tap = 0; tap < 9; ++tap) {
-                    const float *__restrict__ wr = wg + (tap * kStemCin + ci) * kStemCout;
-                    float xv[kStemPx];
-#pragma unroll
-                    for (int p = 0; p < kStemPx; ++p) xv[p] = vs[ci * 9 + tap][p][tid];
-#pragma unroll
-                    for (int j = 0; j < 16; ++j) {
-                        const float wj = wr[j];
-#pragma unroll
-                        for (int p = 0; p < kStemPx; ++p) acc[p][j] = fmaf(xv[p], wj, acc[p][j]);
-                    }
-                }
-            }
-#pragma unroll
-            for (int p = 0; p < kStemPx; ++p) {
-                if (!ok[p]) continue;
-                unsigned h1[8], h2[8];
-#pragma unroll
-                for (int j = 0; j < 16; ++j) { acc[p][j] = conv_epi(acc[p][j], epilogue); vmax[p] = max(vmax[p], __float_as_uint(acc[p][j]) & 0x7fffffffu); }
-#pragma unroll
-                for (int j = 0; j < 8; ++j) split2(acc[p][2 * j], acc[p][2 * j + 1], e[p], h1[j], h2[j]);
-                u32x4 *dst = reinterpret_cast<u32x4 *>(out_cells + ((size_t)g * M + pix[p]) * kCell);
-                dst[0] = (u32x4){h1[0], h1[1], h1[2], h1[3]};
-                dst[1] = (u32x4){h1[4], h1[5], h1[6], h1[7]};
-                dst[2] = (u32x4){h2[0], h2[1], h2[2], h2[3]};
-                dst[3] = (u32x4){h2[4], h2[5], h2[6], h2[7]};
-            }
-        }
-    }
-    if (out_bits) {
-#pragma unroll
-        for (int p = 0; p < kStemPx; ++p) wave_atomic_max(out_bits, cur[p] < 0 ? 0 : cur[p], cur[p] < 0 ? 0u : vmax[p]);
-    }
-}
+// (Round 5 built a second form of this kernel -- weights as SGPR operands from a packed table read with s_load_dwordx16, inputs
+// in a per-thread LDS column, v_pk_fma_f32 with an SGPR pair, no LDS weight reads: bit-identical output -- and measured it in the
+// step against this one on the same boxes: 0.51 / 0.54 ms (two / one pixel per thread) against 0.42-0.43 ms.  Removed;
+// profiles/r05_bench_c5_*.json, r05_bench_c6_*.json.)
 
 // largest |x| per image of a [B][n] fp32 tensor (bits[B] zero on entry): grid (chunks, B)
 __global__ __launch_bounds__(256) void image_absmax_kernel(const float *__restrict__ x, long long n, unsigned *__restrict__ bits)
@@ -1232,41 +1111,6 @@ int mh_stem_to_image(const float *in_nchw, int B, int Cin, int H, int W, const f
     hipLaunchKernelGGL(pl::stem_kernel, dim3((unsigned)std::min<long long>(nblk, 256 * 16)), dim3(256), lds, st, in_nchw, B, Cin, H, W, w, Cout,
                        bias, epilogue, in_bits, cells, scale, out_maxbits);
     return check_launch("pl::stem_kernel");
-}
-
-
-// conv1_1 through the scalar cache (stem_packed_kernel): Cin = 3, Cout = 64 only -- the VGG stem.  `packed` = mh_stem_pack_weight's
-// output for these weights (mh_stem_packed_bytes; once per parameter version), the rest as mh_stem_to_image.
-size_t mh_stem_packed_bytes(int Cin, int Cout)
-{
-    return (Cin == pl::kStemCin && Cout == pl::kStemCout) ? align_up((size_t)pl::kStemPackFloats * sizeof(float), 256) : 0;
-}
-int mh_stem_pack_weight(const float *w, int Cin, int Cout, const float *bias, void *packed, void *stream)
-{
-    MH_REQUIRE(w && packed && Cin == pl::kStemCin && Cout == pl::kStemCout && (reinterpret_cast<uintptr_t>(packed) & 255) == 0);
-    hipLaunchKernelGGL(pl::stem_pack_kernel, dim3(1), dim3(64), 0, as_stream(stream), w, bias, reinterpret_cast<float *>(packed));
-    return check_launch("pl::stem_pack_kernel");
-}
-int mh_stem_to_image_packed(const float *in_nchw, int B, int Cin, int H, int W, const void *packed, int Cout, int epilogue,
-                            void *out_image, unsigned *out_maxbits, void *stream)
-{
-    MH_REQUIRE(in_nchw && packed && out_image && B > 0 && B <= 32 && Cin == pl::kStemCin && Cout == pl::kStemCout && H > 0 && W > 0);
-    MH_REQUIRE(((reinterpret_cast<uintptr_t>(out_image) | reinterpret_cast<uintptr_t>(packed)) & 255) == 0);
-    const long long M = (long long)B * H * W;
-    MH_REQUIRE(pl::act_cells_bytes(M, Cout) < (size_t)0x7ff00000u);
-    hipStream_t st = as_stream(stream);
-    char *cells = reinterpret_cast<char *>(out_image);
-    unsigned *scale = reinterpret_cast<unsigned *>(cells + align_up(pl::act_cells_bytes(M, Cout), 256));
-    unsigned *in_bits = scale + 32;                       // scratch behind the B scale words (the tail is >= 256 bytes)
-    hipError_t e = hipMemsetAsync(in_bits, 0, 32 * sizeof(unsigned), st);
-    if (e != hipSuccess) { set_last_error("hipMemsetAsync(stem maxima)", e); return (int)e; }
-    hipLaunchKernelGGL(pl::image_absmax_kernel, dim3(64, (unsigned)B), dim3(256), 0, st, in_nchw, (long long)Cin * H * W, in_bits);
-    int rc = check_launch("pl::image_absmax_kernel");
-    if (rc) return rc;
-    const long long nblk = (M + 256 * pl::kStemPx - 1) / (256 * pl::kStemPx);
-    hipLaunchKernelGGL(pl::stem_packed_kernel, dim3((unsigned)std::min<long long>(nblk, 256 * 32)), dim3(256), 0, st, in_nchw, B, H, W,
-                       reinterpret_cast<const float *>(packed), epilogue, in_bits, cells, scale, out_maxbits);
-    return check_launch("pl::stem_packed_kernel");
 }
 
 }  // extern "C"

@@ -24,7 +24,7 @@ SYMBOLS = (
     'mh_gemm_ws_bytes', 'mh_gemm_auto_splitk', 'mh_gemm_f32',
     'mh_planes_bytes', 'mh_make_planes', 'mh_make_planes_both', 'mh_gemm_planes_ws_bytes', 'mh_gemm_planes_auto_splitk', 'mh_gemm_planes',
     'mh_act_planes_bytes', 'mh_act_planes', 'mh_plconv_packed_bytes', 'mh_plconv_pack_weight', 'mh_plconv3x3_ws_bytes',
-    'mh_plconv3x3', 'mh_plconv3x3_to_image', 'mh_stem_to_image', 'mh_stem_packed_bytes', 'mh_stem_pack_weight', 'mh_stem_to_image_packed', 'mh_conv_first_nchw_max', 'mh_debug_plconv_shape', 'mh_debug_plconv_splitk', 'mh_debug_plconv_flags', 'mh_decoder_nms_commit_max_bytes',
+    'mh_plconv3x3', 'mh_plconv3x3_to_image', 'mh_stem_to_image', 'mh_conv_first_nchw_max', 'mh_debug_plconv_shape', 'mh_debug_plconv_splitk', 'mh_debug_plconv_flags', 'mh_decoder_nms_commit_max_bytes',
     'mh_debug_pl_shape', 'mh_gemm_ws_bytes_v2', 'mh_gemm_auto_splitk_v2', 'mh_gemm_f32_v2',
     'mh_gemm_small_max_counters', 'mh_gemm_small_f32', 'mh_debug_small_plan',
     'mh_conv3x3_packed_floats', 'mh_conv3x3_pack_weight', 'mh_conv3x3_ws_bytes', 'mh_conv3x3_schedule', 'mh_conv3x3_nhwc',
@@ -67,7 +67,7 @@ def lib():
                      'mh_conv3x3_packed_floats', 'mh_hwcell_seq_ws_bytes', 'mh_conv3x3_wgrad_ws_bytes',
                      'mh_hwlstm_fwd_ws_bytes', 'mh_hwlstm_bwd_ws_bytes',
                      'mh_decoder_greedy_ws_bytes', 'mh_decoder_nms_commit_max_bytes', 'mh_tower_conv1_padded_bytes',
-                     'mh_tower_conv1_wgrad_ws_bytes', 'mh_stem_packed_bytes'):
+                     'mh_tower_conv1_wgrad_ws_bytes'):
             getattr(L, name).restype = ctypes.c_size_t
         _lib = L
     return _lib
@@ -538,29 +538,6 @@ def stem_to_image(x, w, bias, epilogue, out_maxbits):
     rc = L.mh_stem_to_image(f32(x), B, Cin, H, W, f32(w), Cout, f32(bias), c_int(epilogue), ctypes.c_void_p(buf.data_ptr()),
                             i32(out_maxbits), stream())
     _check(rc, 'mh_stem_to_image')
-    return ActImage(buf, B, H, W, Cout)
-
-
-def stem_pack_weight(w, bias):
-    """conv1_1's weights as the scalar-cache table of mh_stem_to_image_packed (None: shape not supported)"""
-    L = lib()
-    Cout, Cin = w.shape[0], w.shape[1]
-    nbytes = L.mh_stem_packed_bytes(Cin, Cout)
-    if not nbytes or tuple(w.shape[2:]) != (3, 3):
-        return None
-    buf = torch.empty(nbytes, dtype=torch.uint8, device=w.device)
-    _check(L.mh_stem_pack_weight(f32(w), Cin, Cout, f32(bias), ctypes.c_void_p(buf.data_ptr()), stream()), 'mh_stem_pack_weight')
-    return buf
-
-
-def stem_to_image_packed(x, packed, Cout, epilogue, out_maxbits):
-    """stem_to_image with the weights as a packed scalar-cache table (stem_pack_weight): same image, bit for bit"""
-    L = lib()
-    B, Cin, H, W = x.shape
-    buf = torch.empty(L.mh_act_planes_bytes(B, H, W, Cout), dtype=torch.uint8, device=x.device)
-    rc = L.mh_stem_to_image_packed(f32(x), B, Cin, H, W, ctypes.c_void_p(packed.data_ptr()), Cout, c_int(epilogue),
-                                   ctypes.c_void_p(buf.data_ptr()), i32(out_maxbits), stream())
-    _check(rc, 'mh_stem_to_image_packed')
     return ActImage(buf, B, H, W, Cout)
 
 

@@ -300,17 +300,6 @@ class Conv3x3(nn.Module):
             self._plane_key = key
         return self._plane
 
-    def stem_weight(self):
-        """conv1_1 only: the weights as the scalar-cache table of mh_stem_to_image_packed, cached per parameter value (None when
-        the shape is not the VGG stem's or MOTIFS_STEM=lds asks for the round-3 kernel)"""
-        if os.environ.get('MOTIFS_STEM', 'scalar') == 'lds':
-            return None
-        key = (_hip.version_of(self.weight), _hip.version_of(self.bias), self.weight.device)
-        if getattr(self, '_stem_key', None) != key:
-            self._stem = _hip.stem_pack_weight(_c(self.weight.detach()), self.bias.detach())
-            self._stem_key = key
-        return self._stem
-
     def packed_weight(self, flip_transpose=False):
         key = (_hip.version_of(self.weight), flip_transpose, self.weight.device)
         if self._packed_key != key:
@@ -413,11 +402,7 @@ class VGG16Features(nn.Sequential):
             is_last = lambda idx: idx + 2 >= len(mods)
             y = img = None
             if direct and not pool_follows(0):
-                stem = first.stem_weight()
-                if stem is not None:
-                    img = _hip.stem_to_image_packed(_c(x), stem, first.out_channels, EPI_RELU, mb[0])
-                else:
-                    img = _hip.stem_to_image(_c(x), _c(first.weight), first.bias, EPI_RELU, mb[0])
+                img = _hip.stem_to_image(_c(x), _c(first.weight), first.bias, EPI_RELU, mb[0])
             else:
                 y = _hip.conv_first_nchw_max(_c(x), _c(first.weight), first.bias, EPI_RELU, mb[0])
             i, layer, pool = 2, 0, False

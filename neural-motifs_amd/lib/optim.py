@@ -43,7 +43,10 @@ class FusedClipSGD(torch.optim.Optimizer):
         # Ctrl-C stay responsive).  Measured on one MI355X (gpurun r02_c13, img/s of the SGCls step): unbounded 292.7,
         # bound 3 / 2 / 1 with an event EVERY step 283.5 / 281.6 / 268.8 -- the per-step event costs more than the wait,
         # hence the sparse events.  MOTIFS_MAX_AHEAD: -1 = unbounded, 0 = synchronise every step.
-        self.max_ahead = int(os.environ.get('MOTIFS_MAX_AHEAD', '8'))
+        # Round 5 re-measured the bound on the lighter step (gpurun r05_c6, one box, first 12 / last 8 of 20 timed steps after 5
+        # warm-up steps): bound 8: 16.5-16.7 / 16.0 ms -- while the host is still racing ahead about every second step takes 17+ ms;
+        # bound 4: 16.17 / 16.01; bound 2: 16.16 / 16.00 (365.8-368.2 -> 372.5 / 372.7 img/s).  Default 4.
+        self.max_ahead = int(os.environ.get('MOTIFS_MAX_AHEAD', '4'))
         self._done_events = []
         self._table = None
         self._table_key = None

@@ -980,31 +980,6 @@ def test_linear_on_plane_images_forward_backward_and_cache(hip):
     assert float((y2.double() - ref2).abs().max()) <= 2e-6 * float(ref2.abs().max())
 
 
-@pytest.mark.parametrize('B,H,W', [(1, 5, 7), (2, 37, 50), (3, 64, 130), (6, 592, 592)])
-def test_stem_with_weights_through_the_scalar_cache_equals_the_lds_stem(hip, B, H, W):
-    """conv1_1 -> activation image: mh_stem_to_image_packed (weights as SGPR operands from a packed table, two pixels per
-    thread) against mh_stem_to_image (weights in LDS), same FMA order per output: cells, scale words and true maxima bit for
-    bit -- incl. pixel pairs that straddle an image boundary (odd H*W) and a last block that is not full"""
-    g = torch.Generator().manual_seed(B * 100 + H)
-    x = torch.randn(B, 3, H, W, generator=g).cuda()
-    w = (torch.randn(64, 3, 3, 3, generator=g) * 0.2).cuda()
-    bias = (torch.randn(64, generator=g) * 0.1).cuda()
-    pk = hip.stem_pack_weight(w, bias)
-    assert pk is not None and hip.stem_pack_weight(torch.zeros(32, 3, 3, 3).cuda(), None) is None
-    mb_a = torch.zeros(B, dtype=torch.int32, device='cuda')
-    mb_b = torch.zeros(B, dtype=torch.int32, device='cuda')
-    a = hip.stem_to_image(x, w, bias, 1, mb_a)
-    b = hip.stem_to_image_packed(x, pk, 64, 1, mb_b)
-    n = B * H * W * 64 * 4
-    assert torch.equal(a.buf[:n], b.buf[:n]), 'image cells differ'
-    tail = (n + 255) // 256 * 256
-    assert torch.equal(a.buf[tail:tail + 4 * B], b.buf[tail:tail + 4 * B]), 'scale words differ'
-    assert torch.equal(mb_a, mb_b) and int(mb_a.min()) > 0
-    # ... and the value: relu(conv) of the first image against float64
-    ref = torch.relu(F.conv2d(x[:1].double().cpu(), w.double().cpu(), bias.double().cpu(), padding=1))
-    assert abs(float(torch.from_numpy(np.frombuffer(np.int32(mb_b[0].item()).tobytes(), dtype=np.float32).copy())[0]) - float(ref.max())) < 1e-4 * float(ref.max())
-
-
 @pytest.mark.parametrize('direct', ['1', '0'])
 def test_vgg_trunk_on_the_plane_engine_matches_the_in_loop_engine(hip, direct, monkeypatch):
     """VGG16Features frozen forward: plane engine (image-output epilogues / converter passes) vs the round-2 kernels vs a
