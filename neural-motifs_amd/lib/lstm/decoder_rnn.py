@@ -141,8 +141,6 @@ class DecoderRNN(torch.nn.Module):
     def __init__(self, classes, embed_dim, inputs_dim, hidden_dim, recurrent_dropout_probability=0.2,
                  use_highway=True, use_input_projection_bias=True):
         super(DecoderRNN, self).__init__()
-        if not use_highway:
-            raise NotImplementedError('only the highway variant is on the path (reference default)')
         self.classes = classes
         embed_vecs = obj_edge_vectors(['start'] + self.classes, wv_dim=100)       # [152,100] (reference :56-58)
         self.obj_embed = nn.Embedding(len(self.classes), embed_dim)
@@ -152,8 +150,10 @@ class DecoderRNN(torch.nn.Module):
         self.nms_thresh = 0.3
         self.recurrent_dropout_probability = recurrent_dropout_probability
         self.use_highway = use_highway
-        self.input_linearity = Linear(self.input_size, 6 * self.hidden_size, bias=use_input_projection_bias)
-        self.state_linearity = Linear(self.hidden_size, 5 * self.hidden_size, bias=True)
+        # reference :68-81: the plain LSTM cell (use_highway=False) has four gate blocks, the highway cell six / five
+        ng_in, ng_state = (6, 5) if use_highway else (4, 4)
+        self.input_linearity = Linear(self.input_size, ng_in * self.hidden_size, bias=use_input_projection_bias)
+        self.state_linearity = Linear(self.hidden_size, ng_state * self.hidden_size, bias=True)
         self.out = Linear(self.hidden_size, len(self.classes))
         self.reset_parameters()
 
@@ -168,10 +168,31 @@ class DecoderRNN(torch.nn.Module):
         self.state_linearity.bias.data[self.hidden_size:2 * self.hidden_size].fill_(1.0)
 
     # ------------------------------------------------------------------------------------------
+    _OPEN_GATE = 40.0       # sigmoid(40) == 1.0f
+
+    def _cell_params(self):
+        """(w_in [6H,in], b_in [6H] or None, w_state [5H,H], b_state [5H]) as the highway-cell kernels read them.  The plain
+        LSTM cell of use_highway=False (reference :96-131 without :122-127) IS the highway cell with its highway gate held
+        open: the four gate blocks are padded with a highway-gate block whose pre-activation is the constant 40 (sigmoid = 1.0f
+        exactly, so (1 - gate) * projection == 0) and a zero projection block -- same kernels, the reference's parameter shapes
+        ([4H,in], [4H,H]) and state-dict keys; gradients reach the four real blocks through the concatenation."""
+        w_in, b_in = self.input_linearity.weight, self.input_linearity.bias
+        w_state, b_state = self.state_linearity.weight, self.state_linearity.bias
+        if self.use_highway:
+            return w_in, b_in, w_state, b_state
+        H = self.hidden_size
+        w_in6 = torch.cat((w_in, w_in.new_zeros(2 * H, w_in.shape[1])), 0)
+        b4 = b_in if b_in is not None else w_in.new_zeros(4 * H)
+        b_in6 = torch.cat((b4, b4.new_full((H,), self._OPEN_GATE), b4.new_zeros(H)), 0)
+        w_state5 = torch.cat((w_state, w_state.new_zeros(H, H)), 0)
+        b_state5 = torch.cat((b_state, b_state.new_zeros(H)), 0)
+        return w_in6, b_in6, w_state5, b_state5
+
     def _projections(self, sequence_tensor):
         D = self.inputs_dim
-        w_in = self.input_linearity.weight
-        enc_proj = linear(sequence_tensor, w_in[:, :D], self.input_linearity.bias)          # [N,6H]
+        w_in, b_in, w_state, b_state = self._cell_params()
+        self._cell = (w_state, b_state)        # (a tuple: a Parameter assigned to a module attribute would register under that name)
+        enc_proj = linear(sequence_tensor, w_in[:, :D], b_in)          # [N,6H]
         emb_proj = linear(self.obj_embed.weight, w_in[:, D:], None)                         # [152,6H]
         return enc_proj, emb_proj
 
@@ -182,8 +203,8 @@ class DecoderRNN(torch.nn.Module):
         if enc_proj.is_cuda and _hip.hwcell_seq_supported(H, int(batch_sizes[0])):
             with torch.no_grad():                     # one persistent launch (mh_decoder_greedy)
                 h_all, logits, fed, commits = _hip.decoder_greedy(
-                    enc_proj.contiguous(), emb_proj.contiguous(), batch_sizes, self.state_linearity.weight.contiguous(),
-                    self.state_linearity.bias, dropout_mask, self.out.weight.contiguous(), self.out.bias,
+                    enc_proj.contiguous(), emb_proj.contiguous(), batch_sizes, self._cell[0].detach().contiguous(),
+                    self._cell[1].detach(), dropout_mask, self.out.weight.contiguous(), self.out.bias,
                     None if labels is None else labels.contiguous())
             self._greedy_states = (h_all, logits)
             return fed, commits
@@ -193,7 +214,7 @@ class DecoderRNN(torch.nn.Module):
             h_prev = c_prev = enc_proj.new_zeros(B, H)
             prev = torch.zeros(B, dtype=torch.long, device=enc_proj.device)      # 'start'
             fed, commits = [], []
-            w_state, b_state = self.state_linearity.weight.contiguous(), self.state_linearity.bias
+            w_state, b_state = self._cell[0].detach().contiguous(), self._cell[1].detach()
             for s, e, n in _step_bounds(batch_sizes):
                 fed.append(prev[:n])
                 pre_i = enc_proj[s:e] + emb_proj.index_select(0, prev[:n])
@@ -252,7 +273,7 @@ class DecoderRNN(torch.nn.Module):
                 return out_dists, commits
 
         pre_i_all = enc_proj + emb_proj.index_select(0, fed)
-        h_all = _DecoderRecurrenceFn.apply(pre_i_all, self.state_linearity.weight, self.state_linearity.bias,
+        h_all = _DecoderRecurrenceFn.apply(pre_i_all, self._cell[0], self._cell[1],
                                            dropout_mask, batch_sizes)
         out_dists = self.out(h_all)
 

@@ -226,9 +226,10 @@ def decoder_lstm_equations(p, timestep_input, previous_state, previous_memory, H
     output_gate = torch.sigmoid(pi[:, 3 * H:4 * H] + ps[:, 3 * H:4 * H])
     memory = input_gate * memory_init + forget_gate * previous_memory
     timestep_output = output_gate * torch.tanh(memory)
-    highway_gate = torch.sigmoid(pi[:, 4 * H:5 * H] + ps[:, 4 * H:5 * H])
-    highway_input_projection = pi[:, 5 * H:6 * H]
-    timestep_output = highway_gate * timestep_output + (1 - highway_gate) * highway_input_projection
+    if p['input_linearity.weight'].shape[0] == 6 * H:      # use_highway (the reference default, :122-127); four blocks: plain LSTM cell
+        highway_gate = torch.sigmoid(pi[:, 4 * H:5 * H] + ps[:, 4 * H:5 * H])
+        highway_input_projection = pi[:, 5 * H:6 * H]
+        timestep_output = highway_gate * timestep_output + (1 - highway_gate) * highway_input_projection
     if dropout_mask is not None and training:
         timestep_output = timestep_output * dropout_mask
     return timestep_output, memory

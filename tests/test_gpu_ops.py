@@ -686,6 +686,39 @@ def test_fused_greedy_decoder_equals_the_step_loop(hip, monkeypatch, H, batch_si
     np.testing.assert_allclose(logits.cpu().numpy(), (h_all @ dec.out.weight.t() + dec.out.bias).detach().cpu().numpy(), atol=1e-5)
 
 
+@pytest.mark.parametrize('H,bs,train', [(64, [3, 3, 2, 1], True), (512, [6] * 5 + [4, 2], True), (128, [1] * 9, False)])
+def test_plain_lstm_decoder_cell_on_the_highway_kernels(hip, H, bs, train):
+    """DecoderRNN(use_highway=False): the reference's four-block parameters, evaluated by the highway-cell kernels with the
+    highway gate held open (lib/lstm/decoder_rnn.py: _cell_params) -- logits, commitments and parameter gradients against the
+    oracle's plain LSTM cell (persistent launch for H = 512 / 128, step kernels otherwise)"""
+    from lib.lstm.decoder_rnn import DecoderRNN
+    from oracle import lstm as OL
+    from torch.nn.utils.rnn import PackedSequence
+    torch.manual_seed(H + len(bs))
+    D = 40
+    classes = ['bg'] + ['c%d' % i for i in range(1, 12)]
+    dec = DecoderRNN(classes, embed_dim=100, inputs_dim=D, hidden_dim=H, recurrent_dropout_probability=0.0, use_highway=False)
+    with torch.no_grad():
+        dec.out.weight.mul_(3.0)
+    p = {k: v.detach().clone().requires_grad_(True) for k, v in dec.state_dict().items()}
+    dec.cuda().train(train)
+    n = sum(bs)
+    x = torch.randn(n, D)
+    labels = torch.randint(0, len(classes), (n,))
+    labels[1] = 0
+    out, commits = dec(PackedSequence(x.cuda(), torch.tensor(bs)), labels=labels.cuda() if train else None)
+    ref_out, ref_commits = OL.decoder_forward(p, x, bs, H, train, labels=labels if train else None)
+    np.testing.assert_array_equal(commits.cpu().numpy(), ref_commits.numpy())
+    np.testing.assert_allclose(out.detach().cpu().numpy(), ref_out.detach().numpy(), atol=1e-4)
+    if train:
+        g = torch.randn(out.shape)
+        (out * g.cuda()).sum().backward()
+        (ref_out * g).sum().backward()
+        for k, v in dec.named_parameters():
+            ref = p[k].grad
+            np.testing.assert_allclose(v.grad.cpu().numpy(), ref.numpy(), atol=1e-4 * max(1e-3, float(ref.abs().max())), err_msg=k)
+
+
 @pytest.mark.parametrize('N', [1, 7, 64, 80])
 def test_decoder_nms_commitments_on_device_equal_the_host_loop(hip, N):
     """mh_decoder_nms_commit == the reference's host loop (decoder_rnn.py:230-247) on the same probabilities and class

@@ -697,3 +697,46 @@ def test_host_side_packing_order_equals_the_device_arithmetic(shim):
     ctx.order = 'leftright'
     ctx.sort_rois(i_plain, lambda: calls.append(1) or conf, b_plain)
     assert calls == [1]
+
+
+def test_plain_lstm_decoder_cell_runs_on_the_highway_kernels(shim):
+    """DecoderRNN(use_highway=False) (reference lib/lstm/decoder_rnn.py:68-81,96-121: four gate blocks, no highway mix) keeps the
+    reference's parameter shapes and runs on the highway-cell path with the highway gate held open (pre-activation 40:
+    sigmoid == 1.0f, zero projection block).  Logits, commitments and every parameter gradient against the oracle's plain cell,
+    teacher forcing with background labels and greedy evaluation."""
+    from lib.lstm.decoder_rnn import DecoderRNN
+    from oracle import lstm as OL
+    from torch.nn.utils.rnn import PackedSequence
+    torch.manual_seed(12)
+    H, D = 16, 24
+    classes = ['bg'] + ['c%d' % i for i in range(1, 9)]
+    dec = DecoderRNN(classes, embed_dim=100, inputs_dim=D, hidden_dim=H, recurrent_dropout_probability=0.0, use_highway=False)
+    sd = dec.state_dict()
+    assert tuple(sd['input_linearity.weight'].shape) == (4 * H, D + 100) and tuple(sd['state_linearity.weight'].shape) == (4 * H, H)
+    assert set(sd) == {'obj_embed.weight', 'input_linearity.weight', 'input_linearity.bias', 'state_linearity.weight',
+                       'state_linearity.bias', 'out.weight', 'out.bias'}
+    with torch.no_grad():
+        dec.out.weight.mul_(3.0)
+    for bs, train in (([3, 3, 2, 1], True), ([1, 1, 1, 1, 1], False)):
+        n = sum(bs)
+        x = torch.randn(n, D)
+        labels = torch.randint(0, len(classes), (n,))
+        labels[1] = 0                                              # a background label: the step's non-bg arg-max is fed back
+        dec.train(train)
+        for p_ in dec.parameters():
+            p_.grad = None
+        out, commits = dec(PackedSequence(x, torch.tensor(bs)), labels=labels if train else None)
+        p = {k: v.detach().clone().requires_grad_(True) for k, v in dec.state_dict().items()}
+        ref_out, ref_commits = OL.decoder_forward(p, x, bs, H, train, labels=labels if train else None)
+        np.testing.assert_array_equal(commits.numpy(), ref_commits.numpy())
+        np.testing.assert_allclose(out.detach().numpy(), ref_out.detach().numpy(), atol=2e-5)
+        if train:
+            g = torch.randn(out.shape)
+            (out * g).sum().backward()
+            (ref_out * g).sum().backward()
+            for k, v in dec.named_parameters():
+                if k == 'obj_embed.weight':
+                    continue                                       # (reaches the loss through the projection of all 152 rows here)
+                np.testing.assert_allclose(v.grad.numpy(), p[k].grad.numpy(), atol=5e-5 * max(1.0, float(p[k].grad.abs().max())), err_msg=k)
+            np.testing.assert_allclose(dec.obj_embed.weight.grad.numpy(), p['obj_embed.weight'].grad.numpy(),
+                                       atol=5e-5 * max(1.0, float(p['obj_embed.weight'].grad.abs().max())))
