@@ -556,7 +556,8 @@ def main():
                          'recipe = cfg2 with the edge-context LSTM of the shipped training script (-nl_edge 4, '
                          'scripts/train_models_sgcls.sh:19-21; SURVEY.md 8d)')
     ap.add_argument('--launch-selftest', action='store_true', help='only exercise the rank launcher / process group (no model)')
-    ap.add_argument('--meter-every', type=int, default=4, help='kernel meters (HIP event pairs) record on every n-th timed step')
+    ap.add_argument('--meter-every', type=int, default=10, help='kernel meters (HIP event pairs) record on every n-th timed step '
+                    '(a metered step is 0.4-0.5 ms longer: gpurun r05_c5; every 10th keeps the headline within 0.3 %% of the unmetered step)')
     ap.add_argument('--h2d-steps', type=int, default=8, help='steps of the second, H2D-inclusive timing (0 = skip)')
     ap.add_argument('--gemm-shapes', default='', help='after the timed region: one more cfg2 step with every matrix-product call '
                     'logged (binding, M, N, K, transposes, HIP-event time, stream) as JSON lines into this file')
