@@ -711,6 +711,42 @@ def main():
         unmetered = {'value': world * BATCH * args.h2d_steps / dtu, 'unit': 'img/s', 'ms_per_step': 1e3 * dtu / args.h2d_steps,
                      'steps': args.h2d_steps, 'what': 'the same step, inputs resident, kernel meters off'}
 
+    # where the UNPROFILED step spends its time on the main stream: five events per step (start, detector stage done, forward done,
+    # backward done, optimizer done) over a few extra steps -- under rocprofv3 the host becomes the bottleneck and the queues'
+    # overlap in its traces is not the production one
+    segments = None
+    if args.h2d_steps > 0 and world == 1:
+        marks = []
+        hook = model.detector.register_forward_hook(lambda m, i, o: marks[-1].__setitem__(1, _ev()))
+
+        def _ev():
+            e = torch.cuda.Event(enable_timing=True)
+            e.record()
+            return e
+        for i in range(args.h2d_steps):
+            marks.append([_ev(), None, None, None, None])
+            blob = blobs[i % len(blobs)]
+            res = model[blob]
+            loss_i = F.cross_entropy(res.rm_obj_dists, res.rm_obj_labels) + F.cross_entropy(res.rel_dists, res.rel_labels[:, -1])
+            marks[-1][2] = _ev()
+            opt.zero_grad(set_to_none=True)
+            reducer.prepare()
+            loss_i.backward()
+            reducer.finish()
+            marks[-1][3] = _ev()
+            opt.step(max_norm=5.0)
+            opt.synchronize()
+            marks[-1][4] = _ev()
+        hook.remove()
+        torch.cuda.synchronize()
+        seg = [[a.elapsed_time(b) for a, b in zip(m[:-1], m[1:])] for m in marks[1:]]
+        n = max(len(seg), 1)
+        segments = {'detector_stage_ms': sum(x[0] for x in seg) / n, 'rest_of_forward_ms': sum(x[1] for x in seg) / n,
+                    'backward_ms': sum(x[2] for x in seg) / n, 'optimizer_ms': sum(x[3] for x in seg) / n, 'steps': len(seg),
+                    'what': 'HIP events on the main stream, unprofiled, meters off; the detector stage = frozen trunk + RoI head of the GT boxes'}
+    if world > 1:
+        torch.distributed.barrier()
+
     if args.gemm_shapes and rank == 0:
         log = []
 
@@ -826,7 +862,7 @@ def main():
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * dt / args.steps,
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': DTYPE, 'data': 'synthetic',
             'ms_per_step_p50': stats['gpu_p50'], 'ms_per_step_p90': stats['gpu_p90'], 'ms_per_step_max': stats['gpu_max'],
-            'step_ms': stats, 'h2d_inclusive': h2d, 'unmetered': unmetered, 'meter_every': args.meter_every, 'metered_steps': metered_steps,
+            'step_ms': stats, 'h2d_inclusive': h2d, 'unmetered': unmetered, 'main_stream_segments': segments, 'meter_every': args.meter_every, 'metered_steps': metered_steps,
             'config': {'workload': 'SGCls MotifNet VGG16 train step (fwd+bwd+clip+SGD), order=leftright, nl_obj=2, '
                                    'nl_edge=%d, hidden 512, batch 6/GPU, 20 GT boxes/img, <=256 rel rows/img, 592x592' % model_kw['nl_edge'],
                        'global_batch': world * BATCH, 'parallelism': 'dp%d' % world, 'final_loss': float(loss.item())},
