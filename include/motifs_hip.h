@@ -278,10 +278,12 @@ int mh_nhwc_to_nchw(const float *in, int B, int C, int H, int W, float *out, voi
  *   gates    [L,T,B,6H] written when is_training (may be NULL otherwise)
  * The input projection x_t*Wx is hoisted out of the time loop into one MFMA GEMM per layer; the
  * recurrence of a whole layer is ONE persistent launch (a block owns 4 hidden units for all timesteps, Wh slice in
- * registers, one agent-scope grid barrier per step) when H <= 512, H % 4 == 0, B <= 32; other shapes run one fused
- * GEMV+gate kernel per (layer,t).
+ * registers; the state travels between the workgroups as tagged 8-byte granules swept straight into LDS -- no grid
+ * barrier; MH_LSTM_GRAN=0 selects the agent-scope barrier per step of rounds 2-3) when H <= 512, H % 4 == 0, B <= 32;
+ * other shapes run one fused GEMV+gate kernel per (layer,t).
  * Fault behaviour of the persistent launches (the reference only fprintf's CUDA errors, highway_lstm_kernel.cu:17-29):
- * the barrier spin is bounded; a block that times out stores 1 into a host-pinned fault word, the launch poisons its
+ * every wait is bounded (the granule sweep by 400 ms of the device's wall clock, the barrier spin by its count); a block
+ * whose wait expires stores 1 into a host-pinned fault word, the launch poisons its
  * outputs (h / gate gradients) with NaN, and EVERY later mh_hwlstm_* / mh_hwcell_seq_* call on that device returns
  * MH_EFAULT until mh_fault_clear().  mh_fault_pending() is a host read (no synchronisation): poll it at step end.
  * Backward: out_grad [T,B,H]; outputs x_grad [T,B,in] (overwritten); when do_weight_grad: weight_grad (OVERWRITTEN since
