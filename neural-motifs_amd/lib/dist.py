@@ -143,8 +143,9 @@ class OverlappedGradReducer(object):
     `.grad` at its slice of the reduced flat buffer -- no unpack copy, and stable gradient addresses for the fused
     optimizer's pointer table.
 
-    Collective UNITS (round 5).  A parameter larger than `split_bytes` (fc6: 411 MB) sits in a bucket of its own whose flat
-    buffer is reduced in row ranges of <= split_bytes, one all-reduce per range.  A producer that writes the gradient range
+    Collective UNITS (round 5).  A parameter larger than `split_bytes` (fc6: 411 MB; the flat 68 MB weight vector of the object
+    context LSTM: "rows" of one element) sits in a bucket of its own whose flat buffer is reduced in row ranges of <= split_bytes,
+    one all-reduce per range.  A producer that writes the gradient range
     by range (lib/hip_ops.py: the weight-gradient GEMM issued per row range, straight into `grad_view`) reports each range
     with `segment_done`, and that range's all-reduce starts while the GEMM of the next one runs -- the reduction of the
     step's largest gradient no longer waits for its last row.  A gradient that arrives whole (hook) releases all of its
@@ -187,7 +188,7 @@ class OverlappedGradReducer(object):
                 off += p.numel()
             first = len(self.units)
             p0 = bucket[0]
-            if len(bucket) == 1 and p0.dim() >= 2 and p0.numel() * p0.element_size() > self.split_bytes and p0.shape[0] > 1:
+            if len(bucket) == 1 and p0.dim() >= 1 and p0.numel() * p0.element_size() > self.split_bytes and p0.shape[0] > 1:
                 row = p0.numel() // p0.shape[0]
                 step = max(1, self.split_bytes // (row * p0.element_size()))
                 rows = [(r, min(r + step, p0.shape[0])) for r in range(0, p0.shape[0], step)]

@@ -11,7 +11,7 @@ def test_cited_profile_files_exist():
     for md in ('DESIGN.md', 'BASELINE.md', 'README.md', 'INTEGRATION.md', os.path.join('profiles', 'README.md'),
                os.path.join('tools', 'README.md')):
         txt = open(os.path.join(ROOT, md)).read()
-        for m in re.finditer(r'`((?:profiles/)?r0[1234]_[A-Za-z0-9_.*\-]+\.(?:json|jsonl|csv|txt))`', txt):
+        for m in re.finditer(r'`((?:profiles/)?r0[12345]_[A-Za-z0-9_.*\-]+\.(?:json|jsonl|csv|txt))`', txt):
             name = m.group(1).replace('1..5', '*')                      # "set1..5.csv" = the five counter-set files
             path = name if name.startswith('profiles/') else os.path.join('profiles', name)
             if not glob.glob(os.path.join(ROOT, path)):
@@ -89,3 +89,31 @@ def test_trace_gaps_splits_a_step_by_queue(tmp_path, capsys):
     assert 'wall 0.041 ms' in first and 'busy 0.031 ms' in first and "queues ['1', '2']" in first
     line = [l for l in out.split('\n') if 'only queue' in l][0]
     assert 'only queue 1: 0.01 ms' in line and 'only queue 2: 0.01 ms' in line and 'several queues at once: 0.01 ms' in line
+
+
+def test_round5_bench_line_follows_the_contract():
+    """the recorded line of round 5 (profiles/r05_bench_n1.json): contract fields, `roofline` headlines the class that takes more
+    of the step and repeats both fractions, `dtype` names the evaluation, the multi-GPU diagnostics are present at N = 1 with
+    nothing exposed, the CPU baseline is the oracle ("port") on a bounded sample"""
+    import json
+    d = json.loads(open(os.path.join(ROOT, 'profiles', 'r05_bench_n1.json')).read().strip().split('\n')[-1])
+    for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline',
+              'dtype', 'data', 'config', 'roofline', 'roofline_conv', 'roofline_gemm', 'cpu_baseline', 'scaling_diagnostics', 'unmetered'):
+        assert k in d, k
+    assert d['unit'] == 'img/s' and d['higher_is_better'] is True and d['scaling'] == 'weak' and d['n_gpus'] == 1 and d['vs_baseline'] is None
+    assert d['dtype'].startswith('f32') and 'f16x3' in d['dtype'] and 'bf16x6' in d['dtype']
+    assert 'workload' in d['config'] and 'model' not in d['config']
+    assert abs(d['value'] - 6.0 / (d['ms_per_step'] * 1e-3)) < 1e-6 * d['value']
+    r = d['roofline']
+    for k in ('bound', 'achieved', 'peak', 'unit', 'frac', 'traffic', 'dominant_class', 'frac_conv3x3', 'frac_gemm'):
+        assert k in r, k
+    assert r['bound'] == 'mfma' and abs(r['frac'] - r['achieved'] / r['peak']) < 1e-9 and abs(r['peak'] - 2500.0 / 3.0) < 1e-6
+    assert r['dominant_class'] == d['dominant_by_time']['class']
+    assert abs(r['frac'] - (r['frac_gemm'] if r['dominant_class'] == 'gemm' else r['frac_conv3x3'])) < 1e-9
+    assert 0 < r['frac'] < 1 and r['avg_launch_ms'] * r['launches'] <= d['ms_per_step'] * d['metered_steps'] * 1.05
+    c = d['cpu_baseline']
+    assert c['kind'] == 'port' and c['unit'] == 'img/s' and 0 < c['value'] < d['value'] and c['cores'] >= c['threads'] >= 1
+    g = d['scaling_diagnostics']
+    assert len(g['ranks_seen']) == 1 and g['distinct_devices'] == 1 and g['allreduce_exposed_ms'] == [0.0]
+    assert g['collective_order_identical'] is True and max(g['bucket_mb']) <= 64.0 + 1e-6 and len(g['bucket_mb']) >= 20
+    assert d['unmetered']['value'] >= 0.97 * d['value']
