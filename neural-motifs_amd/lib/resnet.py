@@ -13,6 +13,8 @@ reference's state dicts load.  Everything runs NHWC on the HIP kernels of libmot
                           the residual add and the ReLU in mh_bn_apply_nhwc; the stem's BN is fused with its 3x3/2 max-pool
 The trunk is forward-only (models/train_rels.py freezes the detector); its backward belongs to detector pre-training
 (SURVEY.md §8f)."""
+import os
+
 import torch
 import torch.nn as nn
 
@@ -43,6 +45,14 @@ class _Conv(nn.Module):
             cout, cin, k = w.shape[0], w.shape[1], self.k
             if k == 1:
                 d = _c(w.view(cout, cin))
+                # frozen 1x1 convs (the detector trunk): the weight's plane image is made ONCE and the product runs on the ring /
+                # plane engine whatever its size -- what keeps a 4 GFLOP product off that engine is the cost of TWO operand
+                # images per call, and the weight's is free here (round 5: the trunk's 81 products of 1-17 GFLOP ran on the
+                # small-product engine at 37 TFLOP/s, 9.5 ms of the cfg4 step; profiles/r05_cfg4_kernel_stats.csv)
+                self._image = None
+                if (w.is_cuda and not self.weight.requires_grad and cin % 16 == 0 and cin >= 64
+                        and os.environ.get('MOTIFS_RESNET_1X1', 'planes') != 'small'):          # (=small: the A/B arm)
+                    self._image = _hip.make_planes(d, True)
             elif k == 3 and self.stride == 1 and cin % 16 == 0:
                 d = _hip.conv3x3_pack_weight(_c(w))
             else:                                                            # im2col order: (ky*kw + kx)*C + c
@@ -69,7 +79,10 @@ class _Conv(nn.Module):
             if self.stride != 1:
                 x = x[:, ::self.stride, ::self.stride, :].contiguous()
                 B, H, W, C = x.shape
-            return _hip.gemm(x.view(-1, C), d, False, True).view(B, H, W, cout)
+            x2 = x.view(-1, C)
+            if getattr(self, '_image', None) is not None and x2.shape[0] >= 1024:
+                return _hip.gemm_planes(_hip.make_planes(x2, True), self._image).view(B, H, W, cout)
+            return _hip.gemm(x2, d, False, True).view(B, H, W, cout)
         if self.k == 3 and self.stride == 1 and C % 16 == 0:
             return _hip.conv3x3_nhwc(_c(x), d, None, 0)
         cols, Ho, Wo = _hip.im2col_nhwc(_c(x), self.k, self.k, self.stride, self.pad, ldo=d.shape[1])
