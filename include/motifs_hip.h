@@ -189,6 +189,10 @@ int mh_gemm_small_f32(int transA, int transB, int M, int N, int K, const float *
  * mh_debug_plconv_shape: A/B hook (-1 auto; round-3 loop: 0 256x128, 1 128x128, 2 256x64 block tiles; 4: the ring kernel's
  * 256x128, what auto selects for Cout >= 128). */
 size_t mh_act_planes_bytes(int B, int H, int W, int C);
+/* per-image maxima (fp32 bit patterns) of a [B][n] fp32 tensor, for mh_act_planes of a tensor whose producer did not report them.
+ * Round 5: mh_act_planes and mh_plconv3x3 (fp32 output) take up to 65535 images -- the 1536 7x7 RoI maps of the mask tower's 3x3
+ * conv (lib/get_union_boxes.py:35-37) and of the ResNet layer4 stacks (lib/resnet.py:126-133) run on the ring engine that way. */
+int mh_image_maxbits(const float *x, int B, long long n_per_image, unsigned *bits, void *stream);
 int mh_act_planes(const float *x_nhwc, const unsigned *maxbits, int B, int H, int W, int C, int pool, void *image,
                   void *stream);
 size_t mh_plconv_packed_bytes(int Cout, int Cin);

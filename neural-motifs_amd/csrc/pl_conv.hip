@@ -53,7 +53,8 @@ __global__ __launch_bounds__(256) void act_planes_kernel(const ActArgs p)
     const int G = p.C / kBK, Gb = G < 16 ? G : 16, ngrp = (G + Gb - 1) / Gb;
     const int ppb = 256 / Gb;                                             // pixels per block step (threads beyond ppb * Gb idle)
     const long long nblk_m = (Mo + ppb - 1) / ppb;
-    if (blockIdx.x == 0 && threadIdx.x < p.B) p.maxbits_out[threadIdx.x] = p.maxbits[threadIdx.x];
+    if (blockIdx.x == 0)
+        for (int i = threadIdx.x; i < p.B; i += 256) p.maxbits_out[i] = p.maxbits[i];
     for (long long blk = blockIdx.x; blk < nblk_m * ngrp; blk += gridDim.x) {
         const int g = (int)(blk % ngrp) * Gb + (int)(threadIdx.x % Gb);
         const long long m = (blk / ngrp) * ppb + threadIdx.x / Gb;
@@ -853,6 +854,7 @@ typedef Shape<256, 64, 2, 2> S256x64;
 // the ring shape that ships (shape 4).  Three more were built and measured in round 4 and removed again because they never won
 // (profiles/r04_ring_conv_sweep.jsonl: 256x256 on eight waves -- shape 3 there --, 256x64 and 128x128 with 64x64 wave tiles -- 5, 6)
 typedef Ring<4, 1, 2, 4, 3> CR256x128;     // shape 4: 4 waves, 64x128 wave tiles, 3 stages x 24 KB, two blocks per CU
+constexpr int kMaxImages = 65535;    // grid.y of image_absmax_kernel; activation images are addressed with 32-bit byte offsets anyway
 static int g_conv_shape = -1;       // mh_debug_plconv_shape
 static int g_conv_flags = 0;        // mh_debug_plconv_flags
 static int g_conv_splitk = 0;       // mh_debug_plconv_splitk: > 0 = every tile cut into that many K slices (measurement sweeps)
@@ -923,10 +925,23 @@ size_t mh_act_planes_bytes(int B, int H, int W, int C)
     return align_up(pl::act_cells_bytes((long long)B * H * W, C), 256) + align_up((size_t)B * 4, 256);
 }
 
+// largest |x| per image of a [B][n] fp32 tensor as fp32 bit patterns (what mh_act_planes wants of a tensor whose producer did not
+// report them: the mask tower's BatchNorm output, gradients)
+int mh_image_maxbits(const float *x, int B, long long n, unsigned *bits, void *stream)
+{
+    MH_REQUIRE(x && bits && B > 0 && B <= pl::kMaxImages && n > 0);
+    hipStream_t st = as_stream(stream);
+    hipError_t e = hipMemsetAsync(bits, 0, (size_t)B * sizeof(unsigned), st);
+    if (e != hipSuccess) { set_last_error("hipMemsetAsync(image maxima)", e); return (int)e; }
+    const unsigned gx = (unsigned)std::max<long long>(1, std::min<long long>(64, n / 4096));
+    hipLaunchKernelGGL(pl::image_absmax_kernel, dim3(gx, (unsigned)B), dim3(256), 0, st, x, n, bits);
+    return check_launch("pl::image_absmax_kernel");
+}
+
 // fp32 NHWC [B,H,W,C] (+ its per-image |x| maxima) -> activation image of [B,Ho,Wo,C]; pool = the 2x2/2 max-pool first
 int mh_act_planes(const float *x, const unsigned *maxbits, int B, int H, int W, int C, int pool, void *image, void *stream)
 {
-    MH_REQUIRE(x && maxbits && image && B > 0 && B <= 256 && H > 0 && W > 0 && C > 0 && C % pl::kBK == 0);
+    MH_REQUIRE(x && maxbits && image && B > 0 && B <= pl::kMaxImages && H > 0 && W > 0 && C > 0 && C % pl::kBK == 0);
     MH_REQUIRE(!pool || (H >= 2 && W >= 2));
     MH_REQUIRE(((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(image)) & 15) == 0);
     const int Ho = pool ? H / 2 : H, Wo = pool ? W / 2 : W;
@@ -984,7 +999,9 @@ static int plconv_impl(const void *in_image, const unsigned *in_true_maxbits, in
                        int Cout, const float *bias, int epilogue, float *out, void *out_image, unsigned *out_maxbits,
                        void *workspace, size_t ws_bytes, void *stream)
 {
-    MH_REQUIRE(in_image && packed && (out || out_image) && B > 0 && B <= 256 && H > 0 && W > 0);
+    // many small images (round 5: the 1536 7x7 RoI maps of the mask tower / the ResNet layer4 stacks): the fp32-output kernels
+    // look every row's image up in in_bits; only the image-output epilogue (scale words written by one block) is limited to 256
+    MH_REQUIRE(in_image && packed && (out || out_image) && B > 0 && B <= (out_image ? 256 : pl::kMaxImages) && H > 0 && W > 0);
     MH_REQUIRE(Cin > 0 && Cin % pl::kBK == 0 && Cout > 0 && Cout % 4 == 0);
     MH_REQUIRE(!out_image || (Cout % pl::kBK == 0 && in_true_maxbits));
     MH_REQUIRE(((reinterpret_cast<uintptr_t>(in_image) | reinterpret_cast<uintptr_t>(packed) | reinterpret_cast<uintptr_t>(out) |

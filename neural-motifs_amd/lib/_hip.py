@@ -23,7 +23,7 @@ SYMBOLS = (
     'mh_roi_align_fwd', 'mh_roi_align_bwd', 'mh_roi_align_bwd_det', 'mh_draw_union_boxes', 'mh_bbox_overlaps', 'mh_triplet_match',
     'mh_gemm_ws_bytes', 'mh_gemm_auto_splitk', 'mh_gemm_f32',
     'mh_planes_bytes', 'mh_make_planes', 'mh_make_planes_both', 'mh_gemm_planes_ws_bytes', 'mh_gemm_planes_auto_splitk', 'mh_gemm_planes',
-    'mh_act_planes_bytes', 'mh_act_planes', 'mh_plconv_packed_bytes', 'mh_plconv_pack_weight', 'mh_plconv3x3_ws_bytes',
+    'mh_act_planes_bytes', 'mh_act_planes', 'mh_image_maxbits', 'mh_plconv_packed_bytes', 'mh_plconv_pack_weight', 'mh_plconv3x3_ws_bytes',
     'mh_plconv3x3', 'mh_plconv3x3_to_image', 'mh_stem_to_image', 'mh_conv_first_nchw_max', 'mh_debug_plconv_shape', 'mh_debug_plconv_splitk', 'mh_debug_plconv_flags', 'mh_decoder_nms_commit_max_bytes',
     'mh_debug_pl_shape', 'mh_gemm_ws_bytes_v2', 'mh_gemm_auto_splitk_v2', 'mh_gemm_f32_v2',
     'mh_gemm_small_max_counters', 'mh_gemm_small_f32', 'mh_debug_small_plan',
@@ -489,6 +489,21 @@ def act_planes(x_nhwc, maxbits, pool=False):
     rc = L.mh_act_planes(f32(x_nhwc), i32(maxbits), B, H, W, C, c_int(int(pool)), ctypes.c_void_p(buf.data_ptr()), stream())
     _check(rc, 'mh_act_planes')
     return ActImage(buf, B, Ho, Wo, C)
+
+
+def image_maxbits(x_nhwc):
+    """int32 [B]: the largest |x| of every image of an NHWC tensor as fp32 bit patterns (input of act_planes)"""
+    B = x_nhwc.shape[0]
+    bits = torch.empty(B, dtype=torch.int32, device=x_nhwc.device)
+    _check(lib().mh_image_maxbits(f32(x_nhwc), B, c_ll(x_nhwc.numel() // B), i32(bits), stream()), 'mh_image_maxbits')
+    return bits
+
+
+def plconv_many_images_ok(B, H, W, cin, cout):
+    """can mh_plconv3x3 run a 3x3 conv over B small maps on the ring engine?  (Cout >= 128: the ring shapes; 32-bit image offsets)"""
+    M = B * H * W
+    return (cin % 16 == 0 and cout % 4 == 0 and cout >= 128 and B <= 65535 and M < (1 << 25)
+            and (M * cin * 4 + (2 * (W + 1) + 256) * 64) < 0x7ff00000 and M * cout * 4 < 0x7ff00000)
 
 
 def plconv_pack_weight(w, flip_transpose=False):

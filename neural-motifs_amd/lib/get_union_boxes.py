@@ -17,6 +17,7 @@ from config import BATCHNORM_MOMENTUM
 from lib.draw_rectangles.draw_rectangles import draw_union_boxes
 from lib.fpn.roi_align.functions.roi_align import RoIAlignFunction
 from lib import _hip
+from lib import hip_ops
 from lib.hip_ops import Conv2dNHWC, ReLU, EPI_NONE, EPI_RELU
 
 
@@ -76,8 +77,11 @@ class _TowerFn(torch.autograd.Function):
             bn1.num_batches_tracked += 1
             bn2.num_batches_tracked += 1
         z, arg = _hip.bn_pool_fwd(y0, mean1, invstd1, g1, be1)
-        wt4 = _hip.conv3x3_pack_weight(w4.contiguous(), False)
-        y1 = _hip.conv3x3_nhwc(z, wt4, b4, EPI_RELU)
+        ctx.maps = hip_ops._small_maps_on_planes(z, w4.shape[1], C1) and w4.shape[1] >= 128
+        if ctx.maps:                  # the 3x3 conv over the N 7x7 maps on the ring engine (lib/hip_ops.py: conv3x3_small_maps)
+            y1 = hip_ops.conv3x3_small_maps(z, w4, b4, EPI_RELU)
+        else:
+            y1 = _hip.conv3x3_nhwc(z, _hip.conv3x3_pack_weight(w4.contiguous(), False), b4, EPI_RELU)
         mean2, invstd2 = stats(y1.view(-1, C1), bn2)
         out = _hip.bn_residual_nchw(y1, mean2, invstd2, g2, be2, union_pools.contiguous())
         if TAPS is not None:
@@ -93,8 +97,10 @@ class _TowerFn(torch.autograd.Function):
         K0 = w0.shape[1] * w0.shape[2] * w0.shape[3]
         g_nhwc = _hip.nchw_to_nhwc_small(dout.contiguous())
         dx2, dg2, db2 = _hip.bn_bwd(y1, g_nhwc, None, mean2, invstd2, g2, True)          # through BN2 and conv.4's ReLU
-        wt4_t = _hip.conv3x3_pack_weight(w4.contiguous(), True)
-        dz = _hip.conv3x3_nhwc(dx2, wt4_t, None, EPI_NONE)
+        if ctx.maps and w4.shape[1] >= 128:
+            dz = hip_ops.conv3x3_small_maps(dx2, w4, None, EPI_NONE, flip_transpose=True)
+        else:
+            dz = _hip.conv3x3_nhwc(dx2, _hip.conv3x3_pack_weight(w4.contiguous(), True), None, EPI_NONE)
         dw4 = _hip.conv3x3_wgrad(z, dx2)                 # implicit GEMM over the pixels: no 0.7 GB patch matrix
         if dw4 is None:                                  # f32-MFMA build
             cols4, _, _ = _hip.im2col_nhwc(z, 3, 3, 1, 1)

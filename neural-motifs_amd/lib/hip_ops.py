@@ -484,6 +484,28 @@ class _ConvIm2colFn(torch.autograd.Function):
         return None, gw, gb, None, None, None, None
 
 
+# 3x3 convolutions over MANY SMALL maps (the 1536 7x7 RoI maps of the mask tower and of the ResNet layer4 stacks) on the ring
+# engine of the frozen trunk (round 5): per-map maxima (one small pass), the activation image, weights packed per call (they
+# train), mh_plconv3x3 with fp32 output.  The in-loop-split conv kernel (round 2) ran these at 220-285 TFLOP/s, the ring kernel
+# runs the same shapes at ~350.  Forward and input gradient (flip-transposed weights); the weight gradient stays on
+# conv3x3_wgrad.  MOTIFS_CONV3X3_MAPS=inloop: the round-2 kernels (A/B).
+_MAPS_ENGINE = os.environ.get('MOTIFS_CONV3X3_MAPS', 'planes')
+
+
+def _small_maps_on_planes(x_nhwc, cin, cout):
+    B, H, W, _ = x_nhwc.shape
+    return (_MAPS_ENGINE == 'planes' and x_nhwc.is_cuda and B >= 64 and H * W <= 1024 and B * H * W >= 8192
+            and _hip.plconv_many_images_ok(B, H, W, cin, cout))
+
+
+def conv3x3_small_maps(x_nhwc, weight, bias, epilogue, flip_transpose=False):
+    """epi(conv3x3(x, weight) + bias) (or, flip_transpose, the input-gradient convolution of that layer applied to x = dy) on the
+    plane / ring engine; x [B,H,W,C] fp32 NHWC, weight [Cout,Cin,3,3]"""
+    cout = weight.shape[1] if flip_transpose else weight.shape[0]
+    img = _hip.act_planes(x_nhwc, _hip.image_maxbits(x_nhwc))
+    return _hip.plconv3x3(img, _hip.plconv_pack_weight(_c(weight.detach()), flip_transpose), cout, bias, epilogue, None)
+
+
 class _Conv3x3Fn(torch.autograd.Function):
     """Trainable NHWC 3x3 conv with the fused bias + activation epilogue: forward = implicit GEMM; backward =
     activation mask (mh_act_bwd on the saved output), dgrad = the same conv kernel on flip-transposed weights,
@@ -492,8 +514,12 @@ class _Conv3x3Fn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x_nhwc, weight, bias, epilogue=EPI_NONE):
         x_nhwc = _c(x_nhwc)
-        wt = _hip.conv3x3_pack_weight(_c(weight), False)
-        y = _hip.conv3x3_nhwc(x_nhwc, wt, bias, epilogue)
+        ctx.maps = _small_maps_on_planes(x_nhwc, weight.shape[1], weight.shape[0]) and weight.shape[1] >= 128
+        if ctx.maps:
+            y = conv3x3_small_maps(x_nhwc, weight, bias, epilogue)
+        else:
+            wt = _hip.conv3x3_pack_weight(_c(weight), False)
+            y = _hip.conv3x3_nhwc(x_nhwc, wt, bias, epilogue)
         ctx.epilogue = epilogue
         ctx.save_for_backward(x_nhwc, weight, y if epilogue != EPI_NONE else None)
         return y
@@ -507,8 +533,11 @@ class _Conv3x3Fn(torch.autograd.Function):
         Cout, Cin = weight.shape[0], weight.shape[1]
         gx = gw = gb = None
         if ctx.needs_input_grad[0]:
-            wt_t = _hip.conv3x3_pack_weight(_c(weight), True)          # the dgrad conv's weights (roles swapped)
-            gx = _hip.conv3x3_nhwc(gy, wt_t, None, EPI_NONE)
+            if ctx.maps:
+                gx = conv3x3_small_maps(gy, weight, None, EPI_NONE, flip_transpose=True)
+            else:
+                wt_t = _hip.conv3x3_pack_weight(_c(weight), True)          # the dgrad conv's weights (roles swapped)
+                gx = _hip.conv3x3_nhwc(gy, wt_t, None, EPI_NONE)
         if ctx.needs_input_grad[1]:
             gwm = _hip.conv3x3_wgrad(x_nhwc, gy)                       # implicit GEMM over the pixels, no patch matrix
             if gwm is None:                                            # f32-MFMA build

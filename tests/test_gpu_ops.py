@@ -379,6 +379,40 @@ def test_conv3x3_dgrad_via_flipped_weights(hip):
     np.testing.assert_allclose(gx.permute(0, 3, 1, 2).cpu().numpy(), x.grad.float().numpy(), atol=1e-4)
 
 
+@pytest.mark.parametrize('B,H,W,Cin,Cout', [(300, 7, 7, 256, 512), (1536, 7, 7, 512, 512), (100, 14, 14, 128, 128), (1203, 7, 7, 128, 256)])
+def test_conv3x3_over_many_small_maps_on_the_ring_engine(hip, B, H, W, Cin, Cout):
+    """the mask tower's / ResNet layer4's 3x3 conv over hundreds of 7x7 maps on the plane / ring engine (mh_image_maxbits ->
+    mh_act_planes -> mh_plconv3x3 with up to 65535 images, per-map scales): forward with bias + ReLU and the input-gradient
+    convolution (flip-transposed weights) against float64, maps of very different magnitude included"""
+    from lib import hip_ops
+    g = torch.Generator().manual_seed(B + Cin)
+    x = torch.randn(B, H, W, Cin, generator=g) * (10.0 ** torch.randint(-3, 3, (B, 1, 1, 1), generator=g).float())
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) * (2.0 / (9 * Cin)) ** 0.5
+    bias = torch.randn(Cout, generator=g) * 0.1
+    assert hip_ops._small_maps_on_planes(x.cuda(), Cin, Cout)
+    y = hip_ops.conv3x3_small_maps(x.cuda(), w.cuda(), bias.cuda(), 1)
+    sel = torch.arange(0, B, max(1, B // 40))                      # float64 reference on a sample of the maps (CPU time)
+    ref = torch.relu(F.conv2d(x[sel].permute(0, 3, 1, 2).double(), w.double(), bias.double(), padding=1)).permute(0, 2, 3, 1)
+    scale = ref.abs().amax(dim=(1, 2, 3), keepdim=True).clamp(min=1e-30)
+    assert float(((y[sel.cuda()].cpu().double() - ref).abs() / scale).max()) < 2e-5          # per map: each has its own scale
+    gy = torch.randn(B, H, W, Cout, generator=g) * (10.0 ** torch.randint(-4, 2, (B, 1, 1, 1), generator=g).float())
+    gx = hip_ops.conv3x3_small_maps(gy.cuda(), w.cuda(), None, 0, flip_transpose=True)
+    gref = F.conv_transpose2d(gy[sel].permute(0, 3, 1, 2).double(), w.double(), padding=1).permute(0, 2, 3, 1)
+    gscale = gref.abs().amax(dim=(1, 2, 3), keepdim=True).clamp(min=1e-30)
+    assert tuple(gx.shape) == (B, H, W, Cin)
+    assert float(((gx[sel.cuda()].cpu().double() - gref).abs() / gscale).max()) < 2e-5
+    # the autograd node of the trainable layers takes this path and agrees with the in-loop kernels it replaces
+    if B * H * W <= 20000:
+        xs = x.cuda().requires_grad_(True)
+        ws = w.cuda().requires_grad_(True)
+        out = hip_ops._Conv3x3Fn.apply(xs, ws, None, 0)
+        out.backward(gy.cuda())
+        y2 = hip.conv3x3_nhwc(x.cuda(), hip.conv3x3_pack_weight(w.cuda(), False), None, 0)
+        assert float((out.detach() - y2).abs().max()) <= 2e-5 * float(y2.abs().max())
+        assert ws.grad is not None and torch.isfinite(ws.grad).all() and tuple(xs.grad.shape) == tuple(x.shape)
+        assert float((xs.grad - gx).abs().max()) == 0.0                # the node's input gradient IS the flip-transposed conv above
+
+
 @pytest.mark.parametrize('B,H,W,Cin,Cout', [(2, 9, 11, 16, 32), (3, 7, 7, 256, 512), (1, 37, 37, 64, 128),
                                             (2, 14, 14, 64, 64), (1, 20, 23, 128, 120), (5, 6, 5, 32, 8)])
 def test_conv3x3_weight_gradient_implicit_gemm(hip, B, H, W, Cin, Cout):
