@@ -463,8 +463,18 @@ def secondary(args, rank, world, dev):
             workload = ('SGDet MotifNet VGG16 train step (RPN + NMS + RoI head + per-class NMS -> <=64 detections/img, GT matching, '
                         'rel_assignments <=64 rows/img, context LSTMs, relation head; fwd+bwd+clip+SGD), batch %d/GPU, 592x592' % b)
 
+            # the frozen detector stage runs one batch ahead on its own thread / stream (RelModel.detect_ahead: the host's waits
+            # for proposal counts, kept detections and the sampled relations no longer leave the device idle); every timed
+            # step still contains one detector stage and one relation stage -- barrier() below drains the stage in flight, so
+            # the stage of timed step 0 is made in the warm-up and the one the last step starts is made inside the region.
+            # MOTIFS_DETECT_AHEAD=0: the in-line order (A/B); =N: N batches ahead
+            ahead = min(int(os.environ.get('MOTIFS_DETECT_AHEAD', '2')), len(blobs) - 1)
+            extra['detector_stage'] = '%d batch(es) ahead (worker thread + own HIP stream)' % ahead if ahead else 'in line'
+
             def step(i):
                 res = model[blobs[i % len(blobs)]]
+                for j in range(1, ahead + 1):                     # (a stage already in flight is not started twice)
+                    model.detect_ahead_blob(blobs[(i + j) % len(blobs)])
                 loss = F.cross_entropy(res.rm_obj_dists, res.rm_obj_labels) + F.cross_entropy(res.rel_dists, res.rel_labels[:, -1])
                 opt.zero_grad(set_to_none=True)
                 loss.backward()
@@ -478,13 +488,24 @@ def secondary(args, rank, world, dev):
                         'SGDet evaluation forward, 1 image per step, max_per_img 80 -> ALL ordered pairs (80*79 = 6320) through the '
                         'union-box relation head, VGG16, 592x592')
 
+            # evaluation: the detector stage of the next images is started before this image's relation stage is issued
+            # (RelModel.detect_ahead; MOTIFS_DETECT_AHEAD=0 = in line, =N: N images ahead)
+            # GT-box modes stay in line: their detector stage is the trunk alone, no waits (PredCls, r05_c15/16: 275 img/s in
+            # line, 292 one image ahead, 171 two ahead)
+            ahead = min(int(os.environ.get('MOTIFS_DETECT_AHEAD', '2')), len(blobs) - 1) if mode == 'sgdet' else 0
+            extra['detector_stage'] = '%d image(s) ahead (worker thread + own HIP stream)' % ahead if ahead else 'in line'
+
             def step(i):
                 with torch.no_grad():
+                    for j in range(1, ahead + 1):
+                        model.detect_ahead_blob(blobs[(i + j) % len(blobs)])
                     out = model[blobs[i % len(blobs)]]
                 extra['dets'], extra['rows'] = int(out[0].shape[0]), int(out[3].shape[0])
                 return out
 
     def barrier():
+        if hasattr(model, 'ahead_drain'):
+            model.ahead_drain()
         if world > 1:
             torch.distributed.barrier()
         torch.cuda.synchronize()

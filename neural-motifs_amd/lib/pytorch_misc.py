@@ -138,6 +138,42 @@ def h2d(x, device):
     return ring.stage(t.contiguous(), device)
 
 
+def with_next(iterable):
+    """(item, following item or None) pairs of an iterable: what a loop needs to start work on the next batch
+    (RelModel.detect_ahead_blob) while the current one is in flight"""
+    it = iter(iterable)
+    try:
+        cur = next(it)
+    except StopIteration:
+        return
+    for nxt in it:
+        yield cur, nxt
+        cur = nxt
+    yield cur, None
+
+
+def with_ahead(iterable, distance=1):
+    """(item, [items to start now]) pairs: a loop that keeps the detector stage of the next `distance` batches in flight
+    (RelModel.detect_ahead_blob) starts items 1..distance with the first item and item i+distance with item i afterwards"""
+    import collections
+    it = iter(iterable)
+    buf = collections.deque()
+    for x in it:
+        buf.append(x)
+        if len(buf) == distance + 1:
+            break
+    first, end = True, object()
+    while buf:
+        cur = buf.popleft()
+        if first:
+            start, first = list(buf), False
+        else:
+            nxt = next(it, end)
+            start = [] if nxt is end else [nxt]
+            buf.extend(start)
+        yield cur, start
+
+
 def quiet_gc():
     """Keep Python's cyclic collector out of the training step.  A full (generation-2) collection walks every tracked
     object of the process -- modules, parameters, the dataset's index arrays, ~10^6 objects here -- for ~100 ms, during

@@ -43,6 +43,14 @@ MODES = ('sgdet', 'sgcls', 'predcls')
 SGDET_CONTEXT_FIRST = os.environ.get('MOTIFS_SGDET_CONTEXT_FIRST', '0') == '1'
 
 
+class _AheadStage(object):
+    """the detector stage of one batch, started by RelModel.detect_ahead() and collected by the forward() of the same `x`"""
+    __slots__ = ('x', 'future')
+
+    def __init__(self, x, future):
+        self.x, self.future = x, future
+
+
 def _packing_plan(im_host):
     """host part of the LSTM packing order: per-image sort key offsets, and the time-major (TxB) gather of the image-sorted
     rois (reference :31-61, lib/pytorch_misc.py:365-384)"""
@@ -317,6 +325,8 @@ class RelModel(nn.Module):
         # trunk; 'force' = also on one stream / on the CPU (tests).  Measured in round 4 on one box, alternating, unprofiled
         # (profiles/r04_variance.jsonl): 18.75 ms per step with it, 18.80 without, both +-0.1 ms -- no gain, so it is off
         self.late_vr_backward = os.environ.get('MOTIFS_LATE_VR', '0')
+        # detector stage one batch ahead (detect_ahead): worker thread, its stream, the stages in flight keyed by id(x)
+        self._ahead_pool, self._ahead_tls, self._ahead = None, None, {}
 
         self.detector = ObjectDetector(
             classes=classes,
@@ -411,8 +421,10 @@ class RelModel(nn.Module):
         pooled = RoIAlignFunction(self.pooling_size, self.pooling_size, spatial_scale=1 / 16)(features, rois)
         return self.roi_fmap_obj(pooled if self.use_resnet else pooled.view(rois.size(0), -1))
 
-    def forward(self, x, im_sizes, image_offset, gt_boxes=None, gt_classes=None, gt_rels=None, proposals=None,
-                train_anchor_inds=None, return_fmap=False):
+    # ---- the detector stage: everything up to the sampled relation labels -------------------------------------------------
+    def _detect(self, x, im_sizes, image_offset, gt_boxes=None, gt_classes=None, gt_rels=None, proposals=None,
+                train_anchor_inds=None):
+        """boxes, labels, RoI logits and the feature map of a batch (reference :466-475)"""
         self.detector.sampler_rs = self.sampler_rs
         # a FusedClipSGD step deferred to its own stream (lib/optim.py: overlap_next_forward) may still be updating the trainable
         # parameters: the frozen detector stage runs beside it, everything after it waits
@@ -424,11 +436,134 @@ class RelModel(nn.Module):
         if x.is_cuda and not detector_trains:
             _hip.wait_param_update()
         if result.is_none():
-            return ValueError("heck")            # the reference returns (not raises) this, :474-475
-
+            return result, None
         im_inds = result.im_inds - image_offset
         if has_host(result.im_inds):
             set_host(im_inds, host_np(result.im_inds) - image_offset)
+        return result, im_inds
+
+    def _sample_relations(self, result, im_inds, image_offset, gt_boxes, gt_classes, gt_rels):
+        """SGDet training: relation rows sampled against the ground truth on the HOST (reference :480-487)"""
+        if self.training and result.rel_labels is None:
+            assert self.mode == 'sgdet'
+            # index / ground-truth tensors are passed as they are (no .detach(): a new tensor object would drop the host mirror)
+            result.rel_labels = rel_assignments(im_inds, result.rm_box_priors.detach(), result.rm_obj_labels.detach(),
+                                                gt_boxes, gt_classes, gt_rels, image_offset,
+                                                filter_non_overlap=True, num_sample_per_gt=1, rs=self.sampler_rs)
+
+    def detect_ahead(self, x, im_sizes, image_offset, gt_boxes=None, gt_classes=None, gt_rels=None, proposals=None,
+                     train_anchor_inds=None, return_fmap=False):
+        """Start the detector stage of a LATER forward(x, ...) now, on a worker thread and its own HIP stream.
+
+        Why: with a frozen detector (the relation drivers: reference models/train_rels.py:75-77) that stage of batch i+1 depends
+        on nothing batch i's step changes, and it is where the host has to WAIT for the device -- the proposal counts after the
+        RPN's NMS, the kept detections after the per-class NMS, the boxes that rel_assignments matches to the ground truth on
+        the host.  Issued in line, each wait finds the queue empty behind it: the SGDet step had the device idle for 9.6 of
+        its 41 ms (profiles/r04_cfg3_trace_gaps_final.txt).  Ahead, the waits of batch i+1 are served while the relation
+        stage / backward / optimizer of batch i are queued on the main stream.  Measured (gpurun r05_c16, b = 6): in line
+        160 img/s, one batch ahead 183 (the main thread still waits for the stage it has just asked for), two ahead 217-223,
+        three 214; a second worker 194-200 (two threads contending for the interpreter); SGDet evaluation 66 -> 77 img/s.
+
+        Call it with the arguments of the forward it belongs to, any time before that forward; the forward recognises its `x`
+        (same tensor object) and takes the stage.  Results are those of the in-line order (tests/test_gpu_sgdet.py); only
+        the interleaving of random draws between the two stages differs when the detector's dropout is active.  Refused
+        (returns False, the forward then runs the stage in line) when the detector has trainable parameters or the seeded host
+        mask stream of the parity tests is in use."""
+        if any(p.requires_grad for p in self.detector.parameters()) or rng_mod._host_rng is not None:
+            return False
+        if id(x) in self._ahead:
+            return True
+        if self._ahead_pool is None:
+            import sys
+            import threading
+            from concurrent.futures import ThreadPoolExecutor
+            # ONE worker: stages run in the order they were asked for, so the relation sampler's random stream
+            # (self.sampler_rs) is consumed in batch order, as in line.  MOTIFS_AHEAD_WORKERS=2 (measurements): two stages
+            # at a time, each worker on its own stream
+            self._ahead_pool = ThreadPoolExecutor(max_workers=max(1, int(os.environ.get('MOTIFS_AHEAD_WORKERS', '1'))),
+                                                  thread_name_prefix='detect_ahead')
+            self._ahead_tls = threading.local()
+            # the worker comes back from a device wait needing the interpreter lock the main thread holds while it enqueues:
+            # bound that hand-over (default 5 ms) well below the waits it is there to hide
+            sys.setswitchinterval(min(sys.getswitchinterval(), 2e-4))
+        args = (x, im_sizes, image_offset, gt_boxes, gt_classes, gt_rels, proposals, train_anchor_inds)
+        grad, training = torch.is_grad_enabled(), self.training
+        ready = None
+        if x.is_cuda:
+            ready = torch.cuda.Event()
+            ready.record(torch.cuda.current_stream(x.device))          # the inputs' uploads are ordered on the caller's stream
+
+        def run():
+            assert self.training == training, 'train() / eval() was switched between detect_ahead() and its forward()'
+            with torch.set_grad_enabled(grad):
+                if ready is None:
+                    result, im_inds = self._detect(*args)
+                    if im_inds is not None:
+                        self._sample_relations(result, im_inds, image_offset, gt_boxes, gt_classes, gt_rels)
+                    return result, im_inds, None
+                torch.cuda.set_device(x.device)
+                stream = getattr(self._ahead_tls, 'stream', None)      # one stream per worker thread
+                if stream is None:
+                    # default priority: measured (gpurun r05_c16, cfg3, two batches ahead) 223 img/s against 217 with a
+                    # high-priority stream (MOTIFS_AHEAD_PRIORITY=-1) -- the stage is two batches early, nothing waits for it
+                    prio = -1 if os.environ.get('MOTIFS_AHEAD_PRIORITY', '0') == '-1' else 0
+                    stream = self._ahead_tls.stream = torch.cuda.Stream(device=x.device, priority=prio)
+                with torch.cuda.stream(stream):
+                    stream.wait_event(ready)
+                    for t in args:
+                        if torch.is_tensor(t) and t.is_cuda:
+                            t.record_stream(stream)
+                    result, im_inds = self._detect(*args)
+                    if im_inds is not None:
+                        self._sample_relations(result, im_inds, image_offset, gt_boxes, gt_classes, gt_rels)
+                    done = torch.cuda.Event()
+                    done.record(stream)
+                return result, im_inds, done
+
+        self._ahead[id(x)] = _AheadStage(x, self._ahead_pool.submit(run))
+        return True
+
+    def detect_ahead_blob(self, batch):
+        """detect_ahead for a dataloader blob (the argument of `model[blob]`)"""
+        batch.scatter()
+        return self.detect_ahead(*batch[0])
+
+    def ahead_pending(self):
+        return len(self._ahead)
+
+    def ahead_drain(self):
+        """wait for every stage in flight (they stay collectable): the host-side work of those stages is over afterwards"""
+        for st in list(self._ahead.values()):
+            st.future.exception()
+
+    def ahead_discard(self):
+        """drop the stages that no forward will collect (a loop left early); their results are waited for, then released"""
+        self.ahead_drain()
+        self._ahead.clear()
+
+    def _take_ahead(self, x):
+        st = self._ahead.pop(id(x), None)
+        if st is None or st.x is not x:
+            return None
+        result, im_inds, done = st.future.result()         # re-raises what the stage raised
+        if done is not None:
+            main = torch.cuda.current_stream(x.device)
+            main.wait_event(done)
+            # the stage's tensors live in the worker stream's pool: tell the allocator that this stream reads them too
+            seen = [im_inds] + list(vars(result).values())
+            for t in seen:
+                if torch.is_tensor(t) and t.is_cuda:
+                    t.record_stream(main)
+        return result, im_inds
+
+    def forward(self, x, im_sizes, image_offset, gt_boxes=None, gt_classes=None, gt_rels=None, proposals=None,
+                train_anchor_inds=None, return_fmap=False):
+        ahead = self._take_ahead(x) if self._ahead else None
+        result, im_inds = ahead if ahead is not None else self._detect(x, im_sizes, image_offset, gt_boxes, gt_classes, gt_rels,
+                                                                        proposals, train_anchor_inds)
+        if result.is_none():
+            return ValueError("heck")            # the reference returns (not raises) this, :474-475
+
         boxes = result.rm_box_priors
         self.last_detector_obj_dists = result.rm_obj_dists.detach()   # the detector's logits of the kept boxes (the
         rois = torch.cat((im_inds[:, None].float(), boxes), 1)        # field is overwritten by the context's below)
@@ -457,12 +592,7 @@ class RelModel(nn.Module):
                 for t in (fmap, rois, im_inds, boxes, result.rm_obj_dists):
                     t.record_stream(side)
                 early_edge_rep = context_branch()
-        if self.training and result.rel_labels is None:
-            assert self.mode == 'sgdet'
-            # index / ground-truth tensors are passed as they are (no .detach(): a new tensor object would drop the host mirror)
-            result.rel_labels = rel_assignments(im_inds, boxes.detach(), result.rm_obj_labels.detach(),
-                                                gt_boxes, gt_classes, gt_rels, image_offset,
-                                                filter_non_overlap=True, num_sample_per_gt=1, rs=self.sampler_rs)
+        self._sample_relations(result, im_inds, image_offset, gt_boxes, gt_classes, gt_rels)
 
         rel_inds = self.get_rel_inds(result.rel_labels, im_inds, boxes)
         if self.training and getattr(self, 'rows_hook', None) is not None:

@@ -18,7 +18,7 @@ from tqdm import tqdm
 from config import ModelConfig, BOX_SCALE, IM_SCALE
 from dataloaders.visual_genome import VGDataLoader, VG
 from lib.evaluation.sg_eval import BasicSceneGraphEvaluator
-from lib.pytorch_misc import optimistic_restore
+from lib.pytorch_misc import optimistic_restore, with_ahead
 
 conf = ModelConfig()
 if conf.model == 'motifnet':
@@ -105,7 +105,13 @@ else:
     detector.eval()
     detector.eval_on_device = DEVICE_EVAL
     with torch.no_grad():
-        for val_b, batch in enumerate(tqdm(val_loader)):
+        # SGDet: the detector stage of the next images runs beside this image's relation stage (RelModel.detect_ahead; bench.py
+        # cfg5: 77 img/s against 66 in line; GT-box modes have no waits in that stage and stay in line).
+        # MOTIFS_DETECT_AHEAD=0: in line, =N: N images in flight
+        ahead = int(os.environ.get('MOTIFS_DETECT_AHEAD', '2')) if conf.mode == 'sgdet' else 0
+        for val_b, (batch, start) in enumerate(with_ahead(tqdm(val_loader), max(ahead, 1))):
+            for nb in (start if ahead else ()):
+                detector.detect_ahead_blob(nb)
             if DEVICE_EVAL:
                 val_batch_device(val_b, batch)
             else:

@@ -25,7 +25,7 @@ from dataloaders.visual_genome import VGDataLoader, VG
 from lib import dist as D
 from lib.evaluation.sg_eval import BasicSceneGraphEvaluator
 from lib.optim import FusedClipSGD
-from lib.pytorch_misc import restore_rel_checkpoint, clip_grad_norm, print_para, quiet_gc
+from lib.pytorch_misc import restore_rel_checkpoint, clip_grad_norm, print_para, quiet_gc, with_ahead
 
 conf = ModelConfig()
 if conf.model == 'motifnet':
@@ -89,8 +89,17 @@ detector.cuda()
 reducer = D.OverlappedGradReducer([p for p in detector.parameters() if p.requires_grad])   # inert at world 1
 
 
-def train_batch(b, verbose=False):
+# SGDet: the frozen detector stage of the next batches (RPN -> NMS -> RoI head -> per-class NMS -> GT matching: where the host
+# waits for the device) runs ahead on its own thread and stream (lib/rel_model.py: RelModel.detect_ahead; bench.py cfg3: 217-223 img/s
+# against 160 in line).  GT-box modes have no waits in their detector stage: in line.  MOTIFS_DETECT_AHEAD=0 turns it off, =N keeps
+# N batches in flight
+DETECT_AHEAD = int(os.environ.get('MOTIFS_DETECT_AHEAD', '2')) if conf.mode == 'sgdet' else 0
+
+
+def train_batch(b, verbose=False, start_ahead=()):
     result = detector[b]
+    for nb in start_ahead:
+        detector.detect_ahead_blob(nb)
     l_obj = F.cross_entropy(result.rm_obj_dists, result.rm_obj_labels)
     l_rel = F.cross_entropy(result.rel_dists, result.rel_labels[:, -1])
     if world > 1:      # global-mean loss semantics of the single-process reference
@@ -140,10 +149,10 @@ def train_epoch(epoch_num):
     # losses of the steps since the last print stay on the device (no per-step sync); every print interval they move to the
     # host in ONE copy and the device tensors are dropped (an epoch-long list of 512-byte blocks fragments the allocator)
     pending, frames, start = [], [], time.time()
-    for b, batch in enumerate(train_loader):
+    for b, (batch, start) in enumerate(with_ahead(train_loader, max(DETECT_AHEAD, 1))):
         if conf.max_iters and b >= conf.max_iters:
             break
-        pending.append(train_batch(batch, verbose=b % (conf.print_interval * 10) == 0))
+        pending.append(train_batch(batch, verbose=b % (conf.print_interval * 10) == 0, start_ahead=start if DETECT_AHEAD else ()))
         if b % conf.print_interval == 0 and b >= conf.print_interval:
             frames.append(_loss_frame(pending))
             pending = []
@@ -158,6 +167,7 @@ def train_epoch(epoch_num):
             start = time.time()
     if pending:
         frames.append(_loss_frame(pending))
+    detector.ahead_discard()                               # a stage started for a batch the loop did not reach (max_iters)
     _device_health()
     return pd.concat(frames, axis=1, ignore_index=True) if frames else pd.DataFrame()      # a loader that yields no batch
 
@@ -178,8 +188,11 @@ def val_epoch():
     detector.eval()
     evaluator = BasicSceneGraphEvaluator.all_modes()
     with torch.no_grad():
-        for val_b, batch in enumerate(val_loader):
+        for val_b, (batch, start) in enumerate(with_ahead(val_loader, max(DETECT_AHEAD, 1))):
+            for nb in (start if DETECT_AHEAD else ()):
+                detector.detect_ahead_blob(nb)
             val_batch((val_b * world + rank), batch, evaluator)
+    detector.ahead_discard()
     recalls = evaluator[conf.mode].result_dict[conf.mode + '_recall']
     if world > 1:                                            # every rank evaluated its own images: merge the lists
         gathered = [None] * world

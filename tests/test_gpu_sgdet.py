@@ -477,3 +477,98 @@ def test_cfg3_sgdet_train_step_b6(det_big):
     finally:
         model.eval()
         model.zero_grad(set_to_none=True)
+
+
+def test_detector_stage_one_batch_ahead_equals_the_in_line_order(det):
+    """RelModel.detect_ahead runs the frozen detector stage (RPN -> NMS -> RoI head -> per-class NMS -> GT matching and the
+    host-side relation sample) of the NEXT batch on a worker thread and its own HIP stream while the current step is in flight.
+    Four SGDet training steps issued that way must give the same sampled relation rows, the same first loss bit for bit and
+    parameters equal up to what two in-line runs differ by (detector dropout off as in bench.py's cfg3: with it on, only the interleaving of random
+    draws between the two stages would differ); a stage that raises must surface in the forward that collects it."""
+    from lib.optim import FusedClipSGD
+    ds, model, sd, make_blob = det
+    blobs = [make_blob(ds, [i], is_train=True) for i in range(3)]
+    frozen = [p for _, p in model.detector.named_parameters()]
+    was = [p.requires_grad for p in frozen]
+    try:
+        for p in frozen:
+            p.requires_grad = False
+        model.train()
+        for m in model.modules():
+            if m.__class__.__name__ == 'Dropout':
+                m.eval()
+
+        def run(ahead):
+            model.load_state_dict({k: v.clone() for k, v in sd.items()})
+            params = [p for p in model.parameters() if p.requires_grad]
+            opt = FusedClipSGD(params, lr=1e-2, momentum=0.9, weight_decay=1e-4)
+            model.sampler_rs = np.random.RandomState(11)
+            torch.manual_seed(77)
+            losses, rows = [], []
+            if ahead:
+                assert model.detect_ahead_blob(blobs[0])           # the first stage ahead too
+            for step in range(4):
+                if ahead:
+                    assert model.ahead_pending() == 1
+                res = model[blobs[step % 3]]
+                if ahead and step < 3:
+                    assert model.detect_ahead_blob(blobs[(step + 1) % 3])
+                loss = F.cross_entropy(res.rm_obj_dists, res.rm_obj_labels) + F.cross_entropy(res.rel_dists, res.rel_labels[:, -1])
+                opt.zero_grad(set_to_none=True)
+                loss.backward()
+                opt.step(max_norm=5.0)
+                losses.append(loss.detach())
+                rows.append(res.rel_labels.detach())
+            torch.cuda.synchronize()
+            assert model.ahead_pending() == 0
+            return ([float(l) for l in losses], [r.cpu().numpy() for r in rows],
+                    {n: p.detach().clone() for n, p in model.named_parameters() if p.requires_grad})
+
+        a, a2, b = run(False), run(False), run(True)
+        for ra, rb in zip(a[1], b[1]):
+            np.testing.assert_array_equal(ra, rb)
+        # losses: the first step's bit for bit; later ones see parameters that carry the atomics noise below
+        assert a[0][0] == b[0][0]
+        np.testing.assert_allclose(a[0], b[0], rtol=5e-6)
+        # Parameters: bit-identical except where torch's own backward adds with atomics (the gradient of
+        # emb_proj.index_select in lib/lstm/decoder_rnn.py is an index_add_: its summation order is not fixed run to run, and
+        # kernels of another stream on the device change it) -- those are held to fp32 summation noise and compared with what
+        # two IN-LINE runs differ by
+        def dist(p, q):
+            return {n: float((p[n] - q[n]).abs().max()) / max(float(p[n].abs().max()), 1e-30) for n in p}
+        d_self, d_ahead = dist(a[2], a2[2]), dist(a[2], b[2])
+        differ = sorted(n for n, v in d_ahead.items() if v > 0)
+        print('in-line vs in-line: %d tensors differ (max %.2e); in-line vs ahead: %d differ (max %.2e): %s' % (
+            sum(v > 0 for v in d_self.values()), max(d_self.values()), len(differ), max(d_ahead.values()), differ[:6]))
+        assert max(d_ahead.values()) <= max(1e-6, 10 * max(d_self.values())), differ
+        assert all(np.isfinite(a[0])) and sum(r.shape[0] for r in a[1]) >= 4
+
+        # a failing stage: the error is raised by the forward that takes the stage, and nothing stays in flight
+        boom = RuntimeError('stage failed')
+        orig = model.detector.forward
+
+        def failing(*args, **kw):
+            raise boom
+        model.detector.forward = failing
+        try:
+            assert model.detect_ahead_blob(blobs[1])
+            with pytest.raises(RuntimeError, match='stage failed'):
+                model[blobs[1]]
+        finally:
+            model.detector.forward = orig
+        assert model.ahead_pending() == 0
+        # refused with a trainable detector: the forward runs the stage in line
+        frozen[0].requires_grad = True
+        assert model.detect_ahead_blob(blobs[2]) is False and model.ahead_pending() == 0
+        frozen[0].requires_grad = False
+        # a stage nobody collects
+        assert model.detect_ahead_blob(blobs[2])
+        model.ahead_discard()
+        assert model.ahead_pending() == 0
+    finally:
+        for p, w in zip(frozen, was):
+            p.requires_grad = w
+        model.load_state_dict({k: v.clone() for k, v in sd.items()})
+        model.eval()
+        model.zero_grad(set_to_none=True)
+        model.sampler_rs = None

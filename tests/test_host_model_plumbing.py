@@ -740,3 +740,63 @@ def test_plain_lstm_decoder_cell_runs_on_the_highway_kernels(shim):
                 np.testing.assert_allclose(v.grad.numpy(), p[k].grad.numpy(), atol=5e-5 * max(1.0, float(p[k].grad.abs().max())), err_msg=k)
             np.testing.assert_allclose(dec.obj_embed.weight.grad.numpy(), p['obj_embed.weight'].grad.numpy(),
                                        atol=5e-5 * max(1.0, float(p['obj_embed.weight'].grad.abs().max())))
+
+
+def test_detector_stage_one_batch_ahead_on_the_cpu_shim(small_world):
+    """RelModel.detect_ahead (the detector stage of the next batch on a worker thread): the forward that is handed the same `x`
+    collects the stage and returns what the in-line order returns; stages are keyed by the tensor object, wait in submission
+    order, and a refused request (trainable detector, seeded host mask stream) leaves the forward to run the stage itself.
+    lib.pytorch_misc.with_next pairs every item with its follower."""
+    from lib import rng
+    from lib.pytorch_misc import with_next
+    assert list(with_next([])) == [] and list(with_next('a')) == [('a', None)]
+    assert list(with_next(iter(range(4)))) == [(0, 1), (1, 2), (2, 3), (3, None)]
+    from lib.pytorch_misc import with_ahead
+    assert list(with_ahead([], 2)) == [] and list(with_ahead('a', 2)) == [('a', [])]
+    assert list(with_ahead(iter(range(5)), 1)) == [(0, [1]), (1, [2]), (2, [3]), (3, [4]), (4, [])]
+    assert list(with_ahead(iter(range(5)), 2)) == [(0, [1, 2]), (1, [3]), (2, [4]), (3, []), (4, [])]
+    assert list(with_ahead(range(2), 3)) == [(0, [1]), (1, [])]
+    ds, model, make_blob = small_world
+    model.eval()
+    blobs = [make_blob(ds, [i], is_train=False) for i in range(3)]
+    with torch.no_grad():
+        plain = [model[b] for b in blobs]
+        assert model.ahead_pending() == 0
+        calls = []
+        orig = model.detector.forward
+
+        def counted(*a, **kw):
+            import threading
+            calls.append(threading.current_thread().name)
+            return orig(*a, **kw)
+        model.detector.forward = counted
+        try:
+            ahead = []
+            assert model.detect_ahead_blob(blobs[0]) and model.detect_ahead_blob(blobs[0])      # asked twice: one stage
+            for i, (b, nxt) in enumerate(with_next(blobs)):
+                if nxt is not None:
+                    assert model.detect_ahead_blob(nxt)
+                ahead.append(model[b])
+            assert model.ahead_pending() == 0
+            assert len(calls) == 3 and all(c.startswith('detect_ahead') for c in calls), calls
+            # grad mode travels with the request: the stage above ran under no_grad like its forward
+            rng.use_host_rng(5)
+            assert model.detect_ahead_blob(blobs[1]) is False            # the parity tests' host mask stream fixes the draw order
+            rng.use_host_rng(None)
+            p = next(model.detector.parameters())
+            p.requires_grad = True
+            assert model.detect_ahead_blob(blobs[1]) is False
+            p.requires_grad = False
+            assert model.ahead_pending() == 0
+            model[blobs[1]]
+            assert calls[-1] == 'MainThread' or not calls[-1].startswith('detect_ahead')
+            assert model.detect_ahead_blob(blobs[2])
+            model.ahead_discard()
+            assert model.ahead_pending() == 0
+        finally:
+            model.detector.forward = orig
+            rng.use_host_rng(None)
+    for a, b in zip(plain, ahead):
+        assert len(a) == len(b) == 5
+        for x, y in zip(a, b):
+            np.testing.assert_array_equal(np.asarray(x), np.asarray(y))
