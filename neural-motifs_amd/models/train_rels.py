@@ -94,6 +94,8 @@ reducer = D.OverlappedGradReducer([p for p in detector.parameters() if p.require
 # against 160 in line).  GT-box modes have no waits in their detector stage: in line.  MOTIFS_DETECT_AHEAD=0 turns it off, =N keeps
 # N batches in flight
 DETECT_AHEAD = int(os.environ.get('MOTIFS_DETECT_AHEAD', '2')) if conf.mode == 'sgdet' else 0
+if rank == 0:
+    print('detector stage: %s' % ('%d batch(es) ahead of the step' % DETECT_AHEAD if DETECT_AHEAD else 'in line'), flush=True)
 
 
 def train_batch(b, verbose=False, start_ahead=()):

@@ -147,3 +147,35 @@ def test_detector_driver_trains_and_validates():
     print(tail)
     assert r.returncode == 0, tail
     assert 'overall' in r.stdout and ('Average Precision' in r.stdout or 'No detections anywhere' in r.stdout)
+
+
+def test_relation_driver_trains_sgdet_from_a_detector_checkpoint(tmp_path):
+    """models/train_rels.py -m sgdet end to end on the GPU, as a subprocess, the way a user runs it: a detector checkpoint
+    (reference-format file name, `vgdet/vg-N.tar`; a random detector made confident like tests/test_gpu_sgdet.py does, so that it
+    detects something) -> 3 training batches with the frozen detector stage two batches ahead of the step, the loop left early by
+    -max_iters (stages in flight are discarded) -> the validation epoch (SGDet evaluation with the stage ahead) -> Recall@K"""
+    if not torch.cuda.is_available():
+        pytest.fail('needs a HIP device')
+    from lib.object_detector import ObjectDetector
+    from dataloaders.synthetic import SyntheticVG
+    torch.manual_seed(4)
+    ds = SyntheticVG(num_images=2, seed=1)
+    det = ObjectDetector(classes=ds.ind_to_classes, mode='refinerels')
+    with torch.no_grad():
+        det.score_fc.weight.mul_(30.0)
+        det.rpn_head.conv[2].weight.mul_(4.0)
+    os.makedirs(str(tmp_path / 'vgdet'))
+    ckpt = str(tmp_path / 'vgdet' / 'vg-0.tar')
+    torch.save({'epoch': 0, 'state_dict': det.state_dict()}, ckpt)
+    del det
+    env = dict(os.environ, PYTHONPATH=os.path.join(ROOT, 'neural-motifs_amd'), MOTIFS_DETECT_AHEAD='2')
+    cmd = [sys.executable, os.path.join(ROOT, 'neural-motifs_amd', 'models', 'train_rels.py'), '-m', 'sgdet', '-model', 'motifnet',
+           '-order', 'leftright', '-nl_obj', '1', '-nl_edge', '1', '-b', '2', '-nepoch', '1', '-max_iters', '3', '-val_size', '3',
+           '-synthetic', '14', '-p', '1', '-lr', '1e-3', '-hidden_dim', '128', '-pooling_dim', '4096', '-use_bias', '-clip', '5',
+           '-ngpu', '1', '-ckpt', ckpt]
+    r = subprocess.run(cmd, env=env, cwd=os.path.join(ROOT, 'neural-motifs_amd'), capture_output=True, text=True, timeout=900)
+    tail = (r.stdout + r.stderr)[-3000:]
+    print(tail)
+    assert r.returncode == 0, tail
+    assert 'detector stage: 2 batch(es) ahead' in r.stdout
+    assert 'overall' in r.stdout and 'R@100' in r.stdout
