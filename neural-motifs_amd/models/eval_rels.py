@@ -109,8 +109,8 @@ else:
         # cfg5: 77 img/s against 66 in line; GT-box modes have no waits in that stage and stay in line).
         # MOTIFS_DETECT_AHEAD=0: in line, =N: N images in flight
         ahead = int(os.environ.get('MOTIFS_DETECT_AHEAD', '2')) if conf.mode == 'sgdet' else 0
-        for val_b, (batch, start) in enumerate(with_ahead(tqdm(val_loader), max(ahead, 1))):
-            for nb in (start if ahead else ()):
+        for val_b, (batch, following) in enumerate(with_ahead(tqdm(val_loader), max(ahead, 1))):
+            for nb in (following if ahead else ()):
                 detector.detect_ahead_blob(nb)
             if DEVICE_EVAL:
                 val_batch_device(val_b, batch)

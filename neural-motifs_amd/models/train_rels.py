@@ -151,10 +151,10 @@ def train_epoch(epoch_num):
     # losses of the steps since the last print stay on the device (no per-step sync); every print interval they move to the
     # host in ONE copy and the device tensors are dropped (an epoch-long list of 512-byte blocks fragments the allocator)
     pending, frames, start = [], [], time.time()
-    for b, (batch, start) in enumerate(with_ahead(train_loader, max(DETECT_AHEAD, 1))):
+    for b, (batch, following) in enumerate(with_ahead(train_loader, max(DETECT_AHEAD, 1))):
         if conf.max_iters and b >= conf.max_iters:
             break
-        pending.append(train_batch(batch, verbose=b % (conf.print_interval * 10) == 0, start_ahead=start if DETECT_AHEAD else ()))
+        pending.append(train_batch(batch, verbose=b % (conf.print_interval * 10) == 0, start_ahead=following if DETECT_AHEAD else ()))
         if b % conf.print_interval == 0 and b >= conf.print_interval:
             frames.append(_loss_frame(pending))
             pending = []
@@ -190,8 +190,8 @@ def val_epoch():
     detector.eval()
     evaluator = BasicSceneGraphEvaluator.all_modes()
     with torch.no_grad():
-        for val_b, (batch, start) in enumerate(with_ahead(val_loader, max(DETECT_AHEAD, 1))):
-            for nb in (start if DETECT_AHEAD else ()):
+        for val_b, (batch, following) in enumerate(with_ahead(val_loader, max(DETECT_AHEAD, 1))):
+            for nb in (following if DETECT_AHEAD else ()):
                 detector.detect_ahead_blob(nb)
             val_batch((val_b * world + rank), batch, evaluator)
     detector.ahead_discard()

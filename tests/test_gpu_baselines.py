@@ -149,7 +149,7 @@ def test_detector_driver_trains_and_validates():
     assert 'overall' in r.stdout and ('Average Precision' in r.stdout or 'No detections anywhere' in r.stdout)
 
 
-def test_relation_driver_trains_sgdet_from_a_detector_checkpoint(tmp_path):
+def test_relation_drivers_train_and_evaluate_sgdet_from_a_detector_checkpoint(tmp_path):
     """models/train_rels.py -m sgdet end to end on the GPU, as a subprocess, the way a user runs it: a detector checkpoint
     (reference-format file name, `vgdet/vg-N.tar`; a random detector made confident like tests/test_gpu_sgdet.py does, so that it
     detects something) -> 3 training batches with the frozen detector stage two batches ahead of the step, the loop left early by
@@ -172,10 +172,21 @@ def test_relation_driver_trains_sgdet_from_a_detector_checkpoint(tmp_path):
     cmd = [sys.executable, os.path.join(ROOT, 'neural-motifs_amd', 'models', 'train_rels.py'), '-m', 'sgdet', '-model', 'motifnet',
            '-order', 'leftright', '-nl_obj', '1', '-nl_edge', '1', '-b', '2', '-nepoch', '1', '-max_iters', '3', '-val_size', '3',
            '-synthetic', '14', '-p', '1', '-lr', '1e-3', '-hidden_dim', '128', '-pooling_dim', '4096', '-use_bias', '-clip', '5',
-           '-ngpu', '1', '-ckpt', ckpt]
+           '-ngpu', '1', '-ckpt', ckpt, '-save_dir', str(tmp_path / 'rel')]
     r = subprocess.run(cmd, env=env, cwd=os.path.join(ROOT, 'neural-motifs_amd'), capture_output=True, text=True, timeout=900)
     tail = (r.stdout + r.stderr)[-3000:]
     print(tail)
     assert r.returncode == 0, tail
     assert 'detector stage: 2 batch(es) ahead' in r.stdout
     assert 'overall' in r.stdout and 'R@100' in r.stdout
+    # ... and models/eval_rels.py on the relation checkpoint it wrote (one image per step, the detector stage of the next two ahead)
+    rel = str(tmp_path / 'rel' / 'vgrel-0.tar')
+    assert os.path.exists(rel)
+    cmd = [sys.executable, os.path.join(ROOT, 'neural-motifs_amd', 'models', 'eval_rels.py'), '-m', 'sgdet', '-model', 'motifnet',
+           '-order', 'leftright', '-nl_obj', '1', '-nl_edge', '1', '-b', '1', '-val_size', '4', '-synthetic', '14',
+           '-hidden_dim', '128', '-pooling_dim', '4096', '-use_bias', '-ngpu', '1', '-ckpt', rel]
+    r = subprocess.run(cmd, env=env, cwd=os.path.join(ROOT, 'neural-motifs_amd'), capture_output=True, text=True, timeout=900)
+    tail = (r.stdout + r.stderr)[-3000:]
+    print(tail)
+    assert r.returncode == 0, tail
+    assert 'R@100' in r.stdout
