@@ -53,6 +53,7 @@ for p in (ROOT, os.path.join(ROOT, 'neural-motifs_amd')):
 
 PEAK_FP32_MFMA_TFLOPS = 157.3          # /opt/skills/guides/MI355X_MICROARCH.md chip table (f32-input MFMA)
 PEAK_BF16_MFMA_TFLOPS = 2500.0         # same table, dense bf16 MFMA
+GEMM_TRAFFIC_SUMMARY = 'profiles/r05_gemm_traffic_summary.json'   # tools/r05/gemm_traffic_summary.py (the step's big products on plane images)
 TRAFFIC_SUMMARY = 'profiles/r04_conv_traffic_summary.json'   # tools/r04/traffic_summary.py (ring trunk, shipped schedule)
 PEAK_HBM_TBS = 8.0                     # same table, HBM3E
 # every product is an fp32 product (operands, accumulation and results fp32, 1e-4 parity against the fp32 oracle); the matrix cores
@@ -71,8 +72,8 @@ class KernelMeter(object):
 
     sampling = True          # class-wide: False on the steps that are not sampled (METER_EVERY)
 
-    def __init__(self, hip, name, work_of, obj=None):
-        self.hip, self.name, self.work_of = hip if obj is None else obj, name, work_of
+    def __init__(self, hip, name, work_of, obj=None, tag_of=None):
+        self.hip, self.name, self.work_of, self.tag_of = hip if obj is None else obj, name, work_of, tag_of
         self.orig = getattr(self.hip, name)
         self.records, self.enabled = [], False
         setattr(self.hip, name, self)
@@ -85,16 +86,19 @@ class KernelMeter(object):
         y = self.orig(*args, **kwargs)
         e.record()
         w = self.work_of(args, kwargs, y)
-        self.records.append((s, e) + (tuple(w) if isinstance(w, tuple) else (w, 0.0)))
+        self.records.append((s, e) + (tuple(w) if isinstance(w, tuple) else (w, 0.0)) + (self.tag_of(args, kwargs) if self.tag_of else None,))
         return y
 
-    def summary(self):
+    def summary(self, tag=None):
+        """totals of the recorded calls; tag: only the calls `tag_of` labelled so (the plane conv serves the trunk AND, since round
+        5, the 3x3 convs over many small RoI maps: two rows of the report)"""
         torch.cuda.synchronize()
-        ms = sum(s.elapsed_time(e) for s, e, _, _ in self.records)
-        flops = sum(r[2] for r in self.records)
-        nbytes = sum(r[3] for r in self.records)
-        n = max(len(self.records), 1)
-        return dict(launches=len(self.records), avg_ms=ms / n, total_ms=ms, flops_per_launch=flops / n, flops=flops,
+        records = self.records if tag is None else [r for r in self.records if r[4] == tag]
+        ms = sum(r[0].elapsed_time(r[1]) for r in records)
+        flops = sum(r[2] for r in records)
+        nbytes = sum(r[3] for r in records)
+        n = max(len(records), 1)
+        return dict(launches=len(records), avg_ms=ms / n, total_ms=ms, flops_per_launch=flops / n, flops=flops,
                     bytes=nbytes, tflops=(flops / (ms * 1e-3) / 1e12) if ms > 0 else 0.0,
                     gbps=(nbytes / (ms * 1e-3) / 1e9) if ms > 0 else 0.0)
 
@@ -150,7 +154,8 @@ def _make_planes_bytes(args, kwargs, y):
 def install_meters(_hip):
     from lib.optim import FusedClipSGD
     m = dict(
-        plconv=KernelMeter(_hip, 'plconv3x3', _plconv_flops), conv=KernelMeter(_hip, 'conv3x3_nhwc', _conv_flops),
+        plconv=KernelMeter(_hip, 'plconv3x3', _plconv_flops, tag_of=lambda a, k: 'maps' if a[0].B >= 64 else 'trunk'),
+        conv=KernelMeter(_hip, 'conv3x3_nhwc', _conv_flops),
         plconv_img=KernelMeter(_hip, 'plconv3x3_to_image', lambda a, k, y: 2.0 * a[0].B * a[0].H * a[0].W * a[0].C * a[3] * 9),
         stem=KernelMeter(_hip, 'stem_to_image', lambda a, k, y: (0.0, 4.0 * a[0].numel() + float(y.buf.numel()))),
         gemm_planes=KernelMeter(_hip, 'gemm_planes', _gemm_planes_flops), gemm=KernelMeter(_hip, 'gemm', _gemm_flops),
@@ -853,8 +858,10 @@ def main():
     # what a first N > 1 run needs to be readable (lib/dist.py: scaling_diagnostics): gathered through the process group
     diag = D.scaling_diagnostics(reducer, dev, 1e3 * dt_local / args.steps)
     if rank == 0:
-        plc, c2 = merge(meters['plconv'].summary(), meters['plconv_img'].summary()), meters['conv'].summary()
-        conv = merge(plc, c2)
+        # the plane conv's calls: the trunk's (<= 6 images) and the 3x3 convs over many small RoI maps (hip_ops.conv3x3_small_maps)
+        plc, c2 = merge(meters['plconv'].summary('trunk'), meters['plconv_img'].summary()), meters['conv'].summary()
+        cmaps = meters['plconv'].summary('maps')
+        conv = merge(plc, cmaps, c2)
         gpl, gg, gi = meters['gemm_planes'].summary(), meters['gemm'].summary(), meters['gemm_inloop'].summary()
         gm = merge(gpl, gg, gi)
         _hip.check_faults()
@@ -870,13 +877,17 @@ def main():
                 how = 'fp32 products as 3 f16 MFMAs (f16x3: two-term f16 split of row-scaled operands, fp32 accumulate): peak = %.0f/3' % PEAK_BF16_MFMA_TFLOPS
         else:
             peak, how = PEAK_FP32_MFMA_TFLOPS, 'v_mfma_f32_32x32x2_f32'
-        traffic = None
+        traffic = gemm_traffic = None
         tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), TRAFFIC_SUMMARY)
         if os.path.exists(tpath) and _hip.lib().mh_split_f16():   # collected on the f16x3 build, on exactly these 14 launches
             with open(tpath) as f:
                 traffic = json.load(f)
             if traffic.get('launches') * msteps != plc['launches']:
                 traffic = None                               # another launch mix: the offline figure does not apply
+        gpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), GEMM_TRAFFIC_SUMMARY)
+        if os.path.exists(gpath) and _hip.lib().mh_split_f16():
+            with open(gpath) as f:
+                gemm_traffic = json.load(f)
         line = {
             'metric': 'images/sec MotifNet-SGCls fwd+bwd' + (' (shipped recipe: nl_edge 4)' if args.config == 'recipe' else ''),
             'value': world * BATCH * args.steps / dt, 'unit': 'img/s',
@@ -887,8 +898,8 @@ def main():
             'config': {'workload': 'SGCls MotifNet VGG16 train step (fwd+bwd+clip+SGD), order=leftright, nl_obj=2, '
                                    'nl_edge=%d, hidden 512, batch 6/GPU, 20 GT boxes/img, <=256 rel rows/img, 592x592' % model_kw['nl_edge'],
                        'global_batch': world * BATCH, 'parallelism': 'dp%d' % world, 'final_loss': float(loss.item())},
-            'roofline': {'bound': 'mfma', 'kernel': 'pl::conv3x3_ring_kernel (implicit GEMM on pre-split plane images, LDS-DMA ring K loop: 11 VGG trunk layers; '
-                                                    'conv1_2 on pl::conv3x3_kernel) + conv3x3_nhwc_kernel (union tower fwd / dgrad); ' + how,
+            'roofline': {'bound': 'mfma', 'kernel': 'pl::conv3x3_ring_kernel (implicit GEMM on pre-split plane images, LDS-DMA ring K loop: 11 VGG trunk layers '
+                                                    '+ the union tower\'s conv over 1536 7x7 maps, fwd / dgrad; conv1_2 on pl::conv3x3_kernel); ' + how,
                          'achieved': conv['tflops'], 'peak': peak, 'unit': 'TFLOP/s',
                          'frac': conv['tflops'] / peak, 'traffic': traffic['bytes_per_launch'] if traffic else None,
                          'traffic_unit': 'bytes per launch (L2 fabric side: HBM + Infinity-Cache)',
@@ -901,7 +912,9 @@ def main():
                          'launches': conv['launches'], 'avg_launch_ms': conv['avg_ms'],
                          'flops_per_launch': conv['flops_per_launch'],
                          'trunk_only': {'tflops': plc['tflops'], 'frac': plc['tflops'] / peak, 'ms_per_step': plc['total_ms'] / msteps,
-                                        'launches': plc['launches']}},
+                                        'launches': plc['launches']},
+                         'small_maps': {'tflops': cmaps['tflops'], 'frac': cmaps['tflops'] / peak, 'ms_per_step': cmaps['total_ms'] / msteps,
+                                        'launches': cmaps['launches'], 'what': 'the plane conv over many small RoI maps (mask tower fwd / dgrad)'}},
         }
         line['roofline_gemm'] = {
             'bound': 'mfma', 'kernel': 'every matrix product of the step: pl::gemm_ring_kernel / pl::gemm_kernel on ready plane images (mh_gemm_planes: fc6/fc7 '
@@ -912,7 +925,14 @@ def main():
             'flops_per_step': gm['flops_per_launch'] * gm['launches'] / msteps,
             'products_on_images': {'tflops': gpl['tflops'], 'frac': gpl['tflops'] / peak, 'ms_per_step': gpl['total_ms'] / msteps,
                                    'launches': gpl['launches']},
-            'note': 'HIP-event time of the calls; some run concurrently with the other HIP stream (context branch)'}
+            'note': 'HIP-event time of the calls; some run concurrently with the other HIP stream (context branch)',
+            # fabric-side bytes of the big products (the 16 launches of products_on_images are these five shapes, forward and backward)
+            'traffic': gemm_traffic['bytes_per_launch'] if gemm_traffic else None,
+            'traffic_unit': 'bytes per launch (L2 fabric side: HBM + Infinity-Cache), mean over the five big product shapes of the step',
+            'traffic_algorithmic': gemm_traffic['algorithmic_bytes_per_launch'] if gemm_traffic else None,
+            'traffic_source': GEMM_TRAFFIC_SUMMARY + ' (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over one launch per shape -- fc6 forward / '
+                              'input gradient / weight gradient at 1536 rows, the 120-row object fc6, fc7 -- with the shipped library, tools/traffic_run.sh gemm, '
+                              'gpurun r05_c19; replayed offline: a PMC pass over the whole step does not finish)'}
         # which kernel class takes more of the step by HIP-event time (the verdict of round 2 noted that GEMM-class work exceeds
         # the conv's: both rooflines are reported, this names the larger one)
         line['dominant_by_time'] = {'class': 'gemm' if gm['total_ms'] > conv['total_ms'] else 'conv3x3',
@@ -921,7 +941,7 @@ def main():
         # are repeated in the headline object
         line['roofline_conv'] = line['roofline']
         if line['dominant_by_time']['class'] == 'gemm':
-            line['roofline'] = dict(line['roofline_gemm'], traffic=None, avg_launch_ms=gm['avg_ms'], flops_per_launch=gm['flops_per_launch'])
+            line['roofline'] = dict(line['roofline_gemm'], avg_launch_ms=gm['avg_ms'], flops_per_launch=gm['flops_per_launch'])
         line['roofline'] = dict(line['roofline'], dominant_class=line['dominant_by_time']['class'],
                                 frac_conv3x3=conv['tflops'] / peak, frac_gemm=gm['tflops'] / peak, frac_trunk_only=plc['tflops'] / peak)
         opt_ms = sum(a.elapsed_time(b) for a, b in opt_events) / max(len(opt_events), 1) if opt_events else None
