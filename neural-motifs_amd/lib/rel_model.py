@@ -523,6 +523,12 @@ class RelModel(nn.Module):
         self._ahead[id(x)] = _AheadStage(x, self._ahead_pool.submit(run))
         return True
 
+    def __getstate__(self):
+        # copy.deepcopy / pickle of the module: the worker pool and the stages in flight belong to THIS object
+        state = self.__dict__.copy()
+        state['_ahead_pool'], state['_ahead_tls'], state['_ahead'] = None, None, {}
+        return state
+
     def detect_ahead_blob(self, batch):
         """detect_ahead for a dataloader blob (the argument of `model[blob]`)"""
         batch.scatter()

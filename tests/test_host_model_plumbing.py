@@ -796,6 +796,10 @@ def test_detector_stage_one_batch_ahead_on_the_cpu_shim(small_world):
         finally:
             model.detector.forward = orig
             rng.use_host_rng(None)
+    import copy
+    twin = copy.deepcopy(model)                    # the worker pool (thread locks) stays with the original
+    assert model._ahead_pool is not None and twin._ahead_pool is None and twin.ahead_pending() == 0
+    del twin
     for a, b in zip(plain, ahead):
         assert len(a) == len(b) == 5
         for x, y in zip(a, b):
