@@ -601,6 +601,10 @@ def main():
         raise SystemExit('bench.py needs a HIP device (no CPU fallback for the hot path)')
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
+    if world > 1 and os.environ.get('OMP_NUM_THREADS') == '1':
+        # torch.distributed.run gives every rank ONE host thread unless told otherwise; building the model (the block-orthogonal
+        # LSTM initialisation is 12 QR factorisations of 4424^2 / 4808^2 matrices) then takes 45 s per rank instead of 12
+        torch.set_num_threads(max(1, min(16, (os.cpu_count() or 16) // world)))
 
     from dataloaders.synthetic import SyntheticVG, make_blob
     from lib import _hip
