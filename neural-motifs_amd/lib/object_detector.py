@@ -90,6 +90,14 @@ class ResNetCompress(nn.Sequential):
 
     def forward(self, fmap):                     # logical NCHW, channels_last memory
         from lib import _hip as H
+        if torch.is_grad_enabled() and (fmap.requires_grad or any(p.requires_grad for p in self.parameters())):
+            # detector pre-training: the same three layers through autograd (product with fused bias + ReLU, train-mode BN)
+            from lib.hip_ops import linear
+            x = fmap.permute(0, 2, 3, 1).contiguous()
+            B, Hh, Ww, C = x.shape
+            conv, bn = self[0], self[2]
+            y = linear(x.view(-1, C), conv.weight.view(conv.weight.shape[0], C), conv.bias, relu=True).view(B, Hh, Ww, -1)
+            return bn(y).permute(0, 3, 1, 2)
         with torch.no_grad():
             x = fmap.permute(0, 2, 3, 1).contiguous()
             B, Hh, Ww, C = x.shape

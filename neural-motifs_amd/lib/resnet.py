@@ -11,12 +11,17 @@ reference's state dicts load.  Everything runs NHWC on the HIP kernels of libmot
   BatchNorm            -> mh_bn_stats (batch statistics + running-stat update in train mode, exactly like the
                           reference, which calls detector.train() with frozen weights: train_rels.py:101) fused with
                           the residual add and the ReLU in mh_bn_apply_nhwc; the stem's BN is fused with its 3x3/2 max-pool
-The trunk is forward-only (models/train_rels.py freezes the detector); its backward belongs to detector pre-training
-(SURVEY.md §8f)."""
+models/train_rels.py freezes the detector: that path is forward-only (no_grad, fused BN + pool, cached weight images).  With
+trainable parameters (detector pre-training, SURVEY.md §8f: models/train_detector.py -resnet) the same blocks run through the
+autograd Functions of lib/hip_ops.py -- no kernel of their own: a strided 1x1 conv is the product on the subsampled rows, a
+strided 3x3 conv is the stride-1 conv subsampled (identical arithmetic at the kept pixels; two layers of the trunk), the 7x7/2
+stem is im2col + the product (its input is the image: no input gradient), BN + ReLU + max-pool of the stem is mh_bn_pool_fwd
+with mh_bn_bwd's pooled form behind it (_StemPoolFn)."""
 import os
 
 import torch
 import torch.nn as nn
+import torch.nn.functional as F
 
 from lib import _hip
 from lib.hip_ops import _c, _Conv3x3Fn, linear, EPI_NONE, EPI_RELU
@@ -67,13 +72,26 @@ class _Conv(nn.Module):
         B, H, W, C = x.shape
         cout = self.weight.shape[0]
         if torch.is_grad_enabled() and (x.requires_grad or self.weight.requires_grad):
-            # autograd path for the relation model's trainable layer4 copies --
-            # stride-1 1x1 (GEMM) and 3x3 (implicit GEMM) only, which is all layer4 at 7x7 needs
-            if self.k == 1 and self.stride == 1:
+            # autograd path: the relation model's trainable layer4 copies (stride-1 1x1 / 3x3) and, for detector pre-training,
+            # the trunk's strided layers
+            s = self.stride
+            if self.k == 1:
+                if s != 1:
+                    x = x[:, ::s, ::s, :].contiguous()
+                    B, H, W, C = x.shape
                 return linear(x.reshape(-1, C), self.weight.view(cout, C)).view(B, H, W, cout)
-            if self.k == 3 and self.stride == 1 and C % 16 == 0:
-                return _Conv3x3Fn.apply(x, self.weight, None, EPI_NONE)
-            raise NotImplementedError('trainable ResNet conv: only stride-1 1x1 / 3x3 (layer4 of the relation model)')
+            if self.k == 3 and self.pad == 1 and C % 16 == 0:
+                y = _Conv3x3Fn.apply(x, self.weight, None, EPI_NONE)
+                # stride s, pad 1: output (i, j) reads the window centred on input (s i, s j) = the stride-1 output there
+                return y if s == 1 else y[:, ::s, ::s, :].contiguous()
+            if x.requires_grad:
+                raise NotImplementedError('trainable ResNet conv %dx%d/%d with an input gradient (only the stem, whose input is '
+                                          'the image, takes the im2col path)' % (self.k, self.k, s))
+            K = self.k * self.k * C
+            ld = (K + 3) // 4 * 4
+            cols, Ho, Wo = _hip.im2col_nhwc(_c(x), self.k, self.k, s, self.pad, ldo=ld)       # pad columns are zero
+            wm = F.pad(self.weight.permute(0, 2, 3, 1).reshape(cout, K), (0, ld - K))         # im2col order (ky*kw + kx)*C + c
+            return linear(cols, wm).view(B, Ho, Wo, cout)
         d = self._derived()
         if self.k == 1:
             if self.stride != 1:
@@ -110,6 +128,27 @@ class _BNFn(torch.autograd.Function):
             g = _hip.act_bwd(g, y, EPI_RELU)
         dx, dgamma, dbeta = _hip.bn_bwd(x, g, None, mean, invstd, gamma, False)
         return dx, dgamma, dbeta, (g if ctx.has_res else None), None, None, None
+
+
+class _StemPoolFn(torch.autograd.Function):
+    """relu(maxpool3x3/2(BN(x))) of the stem in train mode (== maxpool(relu(BN(x))), lib/object_detector.py:121-124) on
+    mh_bn_pool_fwd; backward: the ReLU mask on the saved output, then mh_bn_bwd in its pooled form (gradient gathered through
+    the saved arg-max, through the batch statistics, dgamma, dbeta) -- the kernels of the union-box mask tower"""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, mean, invstd):
+        x = _c(x)
+        y, argmax = _hip.bn_pool_fwd(x, mean, invstd, gamma.detach(), beta.detach())
+        y = torch.relu_(y)
+        ctx.save_for_backward(x, gamma.detach(), mean, invstd, argmax, y)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        x, gamma, mean, invstd, argmax, y = ctx.saved_tensors
+        g = _hip.act_bwd(_c(g), y, EPI_RELU)
+        dx, dgamma, dbeta = _hip.bn_bwd(x, g, argmax, mean, invstd, gamma, False)
+        return dx, dgamma, dbeta, None, None
 
 
 class _BN(nn.Module):
@@ -184,11 +223,25 @@ class ResNet101Trunk(nn.Module):
             layers.append(Bottleneck(self.inplanes, planes))
         return nn.Sequential(*layers)
 
+    def stem(self, x):
+        """conv1 -> bn1 -> relu -> maxpool of a [B,3,S,S] image with autograd (trainable trunk) -> NHWC [B,S/4,S/4,64]"""
+        if not self.training:
+            raise NotImplementedError('BatchNorm backward is built for train mode (batch statistics) only')
+        y = self.conv1(_hip.nchw_to_nhwc(_c(x)))
+        if y.shape[1] % 2 or y.shape[2] % 2:
+            raise ValueError('the fused BN + 3x3/2 max-pool needs an even stem output (image side % 4 == 0)')
+        mean, invstd = self.bn1.stats(y.detach())
+        return _StemPoolFn.apply(y, self.bn1.weight, self.bn1.bias, mean, invstd)
+
     def forward(self, x):
         """[B,3,S,S] NCHW image -> c4 [B,1024,S/16,S/16] (channels_last memory), lib/object_detector.py:119-127"""
         if any(p.requires_grad for p in self.parameters()) and torch.is_grad_enabled():
-            raise NotImplementedError('ResNet trunk backward is not built (detector pre-training path, SURVEY.md §8f); '
-                                      'freeze the detector as models/train_rels.py does')
+            # detector pre-training (models/train_detector.py -resnet): the same blocks through their autograd Functions
+            y = self.stem(x)
+            for layer in (self.layer1, self.layer2, self.layer3):
+                for block in layer:
+                    y = block(y)
+            return y.permute(0, 3, 1, 2)
         with torch.no_grad():
             y = self.conv1(_hip.nchw_to_nhwc(_c(x)))
             if y.shape[1] % 2 or y.shape[2] % 2:

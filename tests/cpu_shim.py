@@ -158,12 +158,29 @@ def install():
         return torch.relu(y) if relu else y
 
     def bn_pool_fwd(x, mean, invstd, gamma, beta):
+        # arg-max as the kernel stores it: window position ky * 3 + kx of the 3x3 / 2 / pad 1 window, first maximum wins
+        N, H, W, C = x.shape
         y = ((x - mean) * invstd * gamma + beta).permute(0, 3, 1, 2)
-        z = F.max_pool2d(y, 3, 2, 1).permute(0, 2, 3, 1).contiguous()
-        return z, torch.zeros(z.shape, dtype=torch.uint8)
+        z, flat = F.max_pool2d(y, 3, 2, 1, return_indices=True)               # flat = iy * W + ix in the input plane
+        oy = torch.arange(H // 2).view(1, 1, -1, 1)
+        ox = torch.arange(W // 2).view(1, 1, 1, -1)
+        arg = (torch.div(flat, W, rounding_mode='floor') - (2 * oy - 1)) * 3 + (flat % W - (2 * ox - 1))
+        return z.permute(0, 2, 3, 1).contiguous(), arg.permute(0, 2, 3, 1).contiguous().to(torch.uint8)
 
     def bn_bwd(x, g, argmax, mean, invstd, gamma, relu_mask):
-        assert argmax is None and not relu_mask, 'shim: dense BatchNorm backward only'
+        assert not relu_mask, 'shim: BatchNorm backward without the producer-ReLU mask only'
+        if argmax is not None:
+            # pooled form: g belongs to the 3x3 / 2 max-pool's output; route it to the arg-max positions first
+            N, H, W, C = x.shape
+            a = argmax.long()
+            oy = torch.arange(H // 2).view(1, -1, 1, 1)
+            ox = torch.arange(W // 2).view(1, 1, -1, 1)
+            iy, ix = 2 * oy - 1 + torch.div(a, 3, rounding_mode='floor'), 2 * ox - 1 + a % 3
+            n = torch.arange(N).view(-1, 1, 1, 1).expand_as(a)
+            c = torch.arange(C).view(1, 1, 1, -1).expand_as(a)
+            dense = torch.zeros(N * H * W * C, dtype=torch.float64)
+            dense.index_add_(0, (((n * H + iy) * W + ix) * C + c).reshape(-1), g.reshape(-1).double())
+            g = dense.view(N, H, W, C)
         C = x.shape[-1]
         x2, g2 = x.reshape(-1, C).double(), g.reshape(-1, C).double()
         M = x2.shape[0]

@@ -134,14 +134,16 @@ def test_message_passing_baseline_on_the_gpu():
     assert len(tup) == 5 and tup[3].shape[1] == 2 and tup[4].shape[1] == 51
 
 
-def test_detector_driver_trains_and_validates():
+@pytest.mark.parametrize('trunk', ['vgg', 'resnet'])
+def test_detector_driver_trains_and_validates(trunk):
     """models/train_detector.py end to end on the GPU: 2 training batches, then the validation epoch (eval forward with
-    the freshly updated weights -> detections -> box mAP -> scheduler) -- as a subprocess, the way a user runs it"""
+    the freshly updated weights -> detections -> box mAP -> scheduler) -- as a subprocess, the way a user runs it; with the
+    VGG16 trunk and (since round 5: lib/resnet.py trains) with `-resnet`"""
     if not torch.cuda.is_available():
         pytest.fail('needs a HIP device')
     env = dict(os.environ, PYTHONPATH=os.path.join(ROOT, 'neural-motifs_amd'))
     cmd = [sys.executable, os.path.join(ROOT, 'neural-motifs_amd', 'models', 'train_detector.py'), '-b', '2', '-nepoch', '1',
-           '-max_iters', '2', '-val_size', '4', '-synthetic', '12', '-p', '1', '-lr', '1e-3']
+           '-max_iters', '2', '-val_size', '4', '-synthetic', '12', '-p', '1', '-lr', '1e-3'] + (['-resnet'] if trunk == 'resnet' else [])
     r = subprocess.run(cmd, env=env, cwd=os.path.join(ROOT, 'neural-motifs_amd'), capture_output=True, text=True, timeout=900)
     tail = (r.stdout + r.stderr)[-3000:]
     print(tail)

@@ -422,3 +422,16 @@ def test_resnet101_trunk_at_the_stated_size_against_the_float64_floor():
     assert e_prod <= max(1e-4, 2.0 * e_o32), 'product %.3e of scale from the float64 evaluation, fp32 oracle %.3e' % (e_prod, e_o32)
     for k in ('features.bn1.running_mean', 'features.layer2.3.bn2.running_var', 'features.layer3.22.bn3.running_var'):
         rel_close(det.state_dict()[k].cpu().numpy(), sd32['detector.' + k].numpy(), rtol=1e-4, what=k, own_scale=True)
+
+
+def test_trainable_resnet_trunk_gradients():
+    """detector pre-training with the ResNet-101 trunk (reference models/train_detector.py with lib/object_detector.py:615-620;
+    round 4 raised NotImplementedError here): the stem (7x7/2 conv as im2col + product, BN + ReLU + 3x3/2 max-pool with
+    mh_bn_bwd's pooled form behind it), bottlenecks with strided 3x3 / projection convs, the compress head -- outputs, parameter
+    gradients and input gradients of every piece against the float64 oracle; then the whole chain conv1 .. layer3 + compress,
+    where the yardstick is the fp32 oracle's own distance from float64 (tests/parity_util.py)"""
+    if not torch.cuda.is_available():
+        pytest.fail('needs a HIP device')
+    from parity_util import assert_resnet_piece_gradients, assert_resnet_trunk_gradients
+    assert assert_resnet_piece_gradients('cuda', 'resnet pieces') >= 40
+    assert assert_resnet_trunk_gradients('cuda', 'resnet trunk + compress') == 30 * 9 + 3 * 3 + 3 + 4

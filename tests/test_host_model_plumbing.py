@@ -804,3 +804,12 @@ def test_detector_stage_one_batch_ahead_on_the_cpu_shim(small_world):
         assert len(a) == len(b) == 5
         for x, y in zip(a, b):
             np.testing.assert_array_equal(np.asarray(x), np.asarray(y))
+
+
+def test_trainable_resnet_trunk_plumbing_on_the_cpu_shim(shim):
+    """detector pre-training with the ResNet-101 trunk: conv1 (im2col + product) .. layer3 (strided 1x1 / 3x3 convs through the
+    stride-1 Functions, train-mode BatchNorm, the stem's fused BN + max-pool with mh_bn_bwd's pooled form behind it) + the
+    compress head -- every parameter gets the oracle's gradient (autograd plumbing; the kernels are the shim's here)"""
+    from parity_util import assert_resnet_piece_gradients, assert_resnet_trunk_gradients
+    assert assert_resnet_piece_gradients('cpu', 'resnet pieces (cpu shim)') >= 40
+    assert assert_resnet_trunk_gradients('cpu', 'resnet trunk + compress (cpu shim)') == 30 * 9 + 3 * 3 + 3 + 4
