@@ -338,6 +338,23 @@ def test_conv_traffic_summary_matches_the_committed_counter_files():
         assert all(r['read_ratio'] >= 1.0 and r['write_ratio'] >= 0.999 for r in committed['per_layer'])
     import bench
     assert os.path.samefile(bench.TRAFFIC_SUMMARY, prof('r04_conv_traffic_summary.json'))
+    # round 5: the step's big matrix products on plane images (tools/traffic_run.sh gemm -> tools/r05/gemm_traffic_summary.py):
+    # what bench.py reports as roofline.traffic when the products are the class that takes more of the step
+    spec5 = importlib.util.spec_from_file_location('gemm_traffic_summary_r05', os.path.join(root, 'tools', 'r05', 'gemm_traffic_summary.py'))
+    mod5 = importlib.util.module_from_spec(spec5)
+    spec5.loader.exec_module(mod5)
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        mod5.main(prof('r05_gemm_traffic_launches.jsonl'), prof('r05_gemm_traffic_fetch_size.csv'), prof('r05_gemm_traffic_write_size.csv'))
+    with open(prof('r05_gemm_traffic_summary.json')) as f:
+        committed = json.load(f)
+    assert json.loads(buf.getvalue()) == committed
+    assert committed['launches'] == 5 and abs(committed['fetch_correction'] - 2.0) < 1e-3 and abs(committed['write_correction'] - 1.0) < 1e-3
+    rows = {r['name']: r for r in committed['per_launch']}
+    assert all(r['read_bytes'] >= r['read_bytes_algorithmic'] and r['write_bytes'] >= 0.999 * r['write_bytes_algorithmic'] for r in rows.values())
+    assert 4.0 < rows['fc6_fwd_M1536']['read_ratio'] < 4.2 and rows['fc6_fwd_M1536']['k_slices'] == 5
+    assert 2.5 < committed['ratio'] < 3.5
+    assert os.path.samefile(bench.GEMM_TRAFFIC_SUMMARY, prof('r05_gemm_traffic_summary.json'))
 
 def test_resnet_relation_model_matches_the_oracle(shim):
     """BASELINE cfg4's model, RelModel(use_resnet=True), with the documented repair
