@@ -149,6 +149,12 @@ int mh_gemm_planes(int M, int N, int K, const void *A_image, const void *B_image
  * ring loop: 3 256x256 on eight waves, 4 256x128);
  * the round-2 in-loop-split kernel (fp32 operands split inside the K loop) kept for comparison runs. */
 void mh_debug_pl_shape(int shape);
+/* tile order of the plane GEMMs: 1 (default) = XCD-banded (K slices on their own XCDs, bands of the tile space otherwise:
+ * csrc/pl_gemm.hip gemm_item), 0 = the round-3 patch numbering (A/B and traffic runs; MH_GEMM_ORDER=0 does the same per process) */
+void mh_debug_pl_order(int order);
+/* host-side replay of the kernels' block -> (tile, K slice) mapping for the launch mh_gemm_planes(M, N, K, splitk) would make:
+ * out[10] = {grid_x, grid_y, tm, tn, z, valid, tiles_m, tiles_n, splitk, order} (no device needed; tests/test_gemm_order.py) */
+int mh_debug_pl_item(int M, int N, int K, int splitk, long long block, int *out);
 size_t mh_gemm_ws_bytes_v2(int M, int N, int K, int splitk);
 int mh_gemm_auto_splitk_v2(int M, int N, int K);
 int mh_gemm_f32_v2(int transA, int transB, int M, int N, int K, const float *A, int lda,

@@ -49,7 +49,7 @@ def compile_flags(src):
     packed = os.environ.get('MH_PACKED_F32')
     if packed == '0' or (packed != '1' and src not in PACKED_OK):
         cmd += ['-Xclang', '-target-feature', '-Xclang', '-packed-fp32-ops']
-    for knob in ('MH_MINW', 'MH_CONV_TAP_MAJOR', 'MH_BAR_SLEEP', 'MH_F16_VALU'):
+    for knob in ('MH_MINW', 'MH_CONV_TAP_MAJOR', 'MH_BAR_SLEEP', 'MH_F16_VALU', 'MH_ATOMIC_ALWAYS'):
         if os.environ.get(knob):
             cmd += ['-D%s=%s' % (knob, os.environ[knob])]
     return cmd
@@ -63,7 +63,7 @@ def build(force=False, verbose=False, out_dir=None):
     os.makedirs(out_dir, exist_ok=True)
     so = os.path.join(out_dir, os.path.basename(SO))
     hdrs = [os.path.join(HERE, h) for h in HEADERS]
-    objs = []
+    objs, jobs = [], []
     for src in SOURCES:
         s = os.path.join(HERE, src)
         o = os.path.join(out_dir, src.replace('.hip', '.o'))
@@ -73,7 +73,13 @@ def build(force=False, verbose=False, out_dir=None):
             if verbose:
                 cmd += ['-Rpass-analysis=kernel-resource-usage']
                 print(' '.join(cmd))
-            subprocess.check_call(cmd)
+            jobs.append(cmd)
+    # the translation units are independent: up to MH_JOBS (default 4) hipcc processes at a time
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(max_workers=max(1, int(os.environ.get('MH_JOBS', '4')))) as pool:
+        for rc in pool.map(lambda c: subprocess.call(c), jobs):
+            if rc:
+                raise subprocess.CalledProcessError(rc, 'hipcc')
     if force or _stale(so, objs):
         cmd = [HIPCC, '--offload-arch=' + ARCH, '-shared', '-fPIC', '-o', so] + objs
         if verbose:

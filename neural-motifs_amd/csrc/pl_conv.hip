@@ -338,7 +338,7 @@ __global__ __launch_bounds__(kThreads, (S::bm * S::bn <= 128 * 128) ? 3 : 2) voi
             unsigned m = bits;                       // one row = the 32 lanes of a half-wave: reduce, one atomic per row
 #pragma unroll
             for (int o = 16; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o));
-            if ((lane & 31) == 0 && m) atomicMax(p.out_bits + row / HW, m);
+            if ((lane & 31) == 0 && m && may_raise(p.out_bits + row / HW, m)) atomicMax(p.out_bits + row / HW, m);
         }
     };
     if (!IMG) {
@@ -704,7 +704,7 @@ __global__ __launch_bounds__(256) void reduce_kernel(const float *__restrict__ p
         C[idx] = v;
         const int b = (int)((row0 + row) / HW);
         if (b != cur) {
-            if (cur >= 0 && vmax && out_bits) atomicMax(out_bits + cur, vmax);
+            if (cur >= 0 && vmax && out_bits && may_raise(out_bits + cur, vmax)) atomicMax(out_bits + cur, vmax);
             cur = b;
             vmax = 0;
         }
@@ -741,7 +741,7 @@ __global__ __launch_bounds__(256) void reduce_planes_kernel(const float *__restr
         }
         const int b = (int)((row0 + r) / HW);
         if (b != cur) {
-            if (cur >= 0 && vmax && out_bits) atomicMax(out_bits + cur, vmax);
+            if (cur >= 0 && vmax && out_bits && may_raise(out_bits + cur, vmax)) atomicMax(out_bits + cur, vmax);
             cur = b;
             vmax = 0;
         }
@@ -800,7 +800,7 @@ __global__ __launch_bounds__(256) void stem_kernel(const float *__restrict__ in,
         if (pix >= M) continue;
         const int x = (int)(pix % W), y = (int)((pix / W) % H), b = (int)(pix / ((long long)W * H));
         if (b != cur) {
-            if (cur >= 0 && vmax && out_bits) atomicMax(out_bits + cur, vmax);
+            if (cur >= 0 && vmax && out_bits && may_raise(out_bits + cur, vmax)) atomicMax(out_bits + cur, vmax);
             cur = b;
             vmax = 0;
             e = row_exponent(bound_bits(b));

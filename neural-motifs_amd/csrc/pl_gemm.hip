@@ -8,6 +8,7 @@
 // LSTM input projections, post_lstm, rel_compress and their dgrad/wgrad): reference lib/rel_model.py:366-373,403-414,
 // lib/object_detector.py:129-138 (cuBLAS there).
 #include <algorithm>
+#include <cmath>
 #include <cstdlib>
 
 #include "mfma_tile.h"     // launch_row_exponents / launch_splitk_reduce / makespan_units (gemm.hip)
@@ -191,7 +192,46 @@ struct GemmArgs {
     int splitk, kc_per_split;
     float *partial;                // [splitk][M][N] when splitk > 1
     int tiles_m, tiles_n, patch_h, patch_w;
+    // round 6, XCD-banded order (1-D grid): 0 = the round-3 numbering on a (tiles, splitk) grid; 1 = every XCD owns whole K slices
+    // (slice z on XCD z % 8); 2 = 8 / splitk XCDs share a slice and each owns a band of its tile space (band_n: along N)
+    int order, bands, band_n;
 };
+
+// Which (tile, K slice) a block works on.  Blocks are handed to the XCDs round-robin by their linear id (block b on XCD b % 8,
+// MI355X_MICROARCH.md) and every XCD has its own L2, so what the blocks an XCD runs AT THE SAME TIME have in common decides
+// how often an operand panel crosses the fabric.  Round 3-5 gave XCD x a contiguous chunk of the patch-major tile numbering
+// in EVERY K slice: ~12 tiles x 2-3 slices at a time, i.e. 12 panels per 12 tiles and slice -- the fc6 forward pulled 4.1x its
+// operands through the fabric, its input gradient 5.7x (profiles/r05_gemm_traffic_summary.json).  Now the slices are spread
+// over the XCDs first (an XCD streams its own K range of both operands: nothing is fetched twice across XCDs), and what is
+// left of the XCDs per slice divides the tile space into bands along its longer side; inside its region an XCD walks
+// patch_h x patch_w patches sized to what it runs at once (near-square in bytes: patch_h * bm ~ patch_w * bn).
+__host__ __device__ __forceinline__ bool gemm_item(const GemmArgs &p, int bx, int by, int &tm, int &tn, int &z)
+{
+    if (p.order == 0) {
+        const int t = xcd_remap(bx, p.tiles_m * p.tiles_n);
+        patch_tile(t, p.tiles_m, p.tiles_n, p.patch_h, p.patch_w, tm, tn);
+        z = by;
+        return true;
+    }
+    const int xcd = bx & 7, idx = bx >> 3;
+    if (p.order == 1) {
+        const int tiles = p.tiles_m * p.tiles_n;
+        const int zl = idx / tiles;
+        z = xcd + 8 * zl;
+        if (z >= p.splitk) return false;
+        patch_tile(idx - zl * tiles, p.tiles_m, p.tiles_n, p.patch_h, p.patch_w, tm, tn);
+        return true;
+    }
+    const int b = xcd % p.bands;
+    z = xcd / p.bands;
+    const int along = p.band_n ? p.tiles_n : p.tiles_m;
+    const int lo = (int)((long long)b * along / p.bands), hi = (int)((long long)(b + 1) * along / p.bands);
+    const int rm = p.band_n ? p.tiles_m : hi - lo, rn = p.band_n ? hi - lo : p.tiles_n;
+    if (z >= p.splitk || idx >= rm * rn) return false;
+    patch_tile(idx, rm, rn, p.patch_h < rm ? p.patch_h : rm, p.patch_w < rn ? p.patch_w : rn, tm, tn);
+    if (p.band_n) tn += lo; else tm += lo;
+    return true;
+}
 
 __device__ __forceinline__ float epi(float v, int epilogue)
 {
@@ -207,11 +247,9 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_kernel(const GemmArgs p)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     int wm, wn;
     wave_origin<S>(wave, wm, wn);
-    const int t = xcd_remap(blockIdx.x, p.tiles_m * p.tiles_n);
-    int tm, tn;
-    patch_tile(t, p.tiles_m, p.tiles_n, p.patch_h, p.patch_w, tm, tn);
+    int tm, tn, z;
+    if (!gemm_item(p, (int)blockIdx.x, (int)blockIdx.y, tm, tn, z)) return;
     const int m0 = tm * S::bm, n0 = tn * S::bn;
-    const int z = blockIdx.y;
     const int kt_begin = z * p.kc_per_split, kt_end = min(p.Kc, kt_begin + p.kc_per_split);
 
     const Src sa = make_src(p.A + (size_t)m0 * kCell), sb = make_src(p.B + (size_t)n0 * kCell);
@@ -288,11 +326,9 @@ __global__ __launch_bounds__(R::threads, (R::threads == 512 || R::sm * R::sn <= 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     int wm0, wn0;
     rwave_origin<R>(wave, wm0, wn0);
-    const int t = xcd_remap(blockIdx.x, p.tiles_m * p.tiles_n);
-    int tm, tn;
-    patch_tile(t, p.tiles_m, p.tiles_n, p.patch_h, p.patch_w, tm, tn);
+    int tm, tn, z;
+    if (!gemm_item(p, (int)blockIdx.x, (int)blockIdx.y, tm, tn, z)) return;
     const int m0 = tm * R::bm, n0 = tn * R::bn;
-    const int z = blockIdx.y;
     const int kt_begin = z * p.kc_per_split, kt_end = min(p.Kc, kt_begin + p.kc_per_split);
 
     const Src sa = make_src(p.A + (size_t)m0 * kCell), sb = make_src(p.B + (size_t)n0 * kCell);
@@ -387,6 +423,30 @@ struct Plan {
     int bm, bn, splitk;
 };
 static int g_force_shape = -1;      // mh_debug_pl_shape: A/B runs
+// tile order (gemm_item): 1 = XCD-banded (round 6), 0 = round-3 patch numbering; MH_GEMM_ORDER / mh_debug_pl_order for A/B runs
+static int g_order = [] { const char *e = getenv("MH_GEMM_ORDER"); return (e && e[0] == '0') ? 0 : 1; }();
+
+struct Order {
+    int order, bands, band_n, per_xcd;      // per_xcd: work items of the busiest XCD (grid = 8 * per_xcd blocks)
+};
+// how the (tiles_m x tiles_n x splitk) work items are dealt to the 8 XCDs (gemm_item)
+static Order plan_order(int tiles_m, int tiles_n, int bm, int bn, int splitk)
+{
+    Order o = {0, 1, 1, 0};
+    if (!g_order) return o;
+    const int tiles = tiles_m * tiles_n;
+    if (splitk >= 8) { o.order = 1; o.per_xcd = ceil_div(splitk, 8) * tiles; return o; }
+    if (8 % splitk) return o;                                 // 3, 5, 6, 7 slices: the planner does not pick them when banding
+    const int bands = 8 / splitk;
+    const bool n_longer = (long long)tiles_n * bn >= (long long)tiles_m * bm;
+    int band_n = n_longer ? 1 : 0;
+    if ((band_n ? tiles_n : tiles_m) < bands) band_n ^= 1;
+    const int along = band_n ? tiles_n : tiles_m;
+    if (along < bands) return o;                              // too few tiles to give every XCD a band
+    o.order = 2; o.bands = bands; o.band_n = band_n;
+    o.per_xcd = ceil_div(along, bands) * (band_n ? tiles_m : tiles_n);
+    return o;
+}
 
 static Plan plan_gemm(int M, int N, int K, int want_splitk)
 {
@@ -417,12 +477,16 @@ static Plan plan_gemm(int M, int N, int K, int want_splitk)
         set_resident_slots_override(256 * per_cu[s]);
         auto consider = [&](int sk) {
             const double t_partial = (sk > 1) ? ((double)M * N * 8.0 * sk) / 4.0e12 + 4e-6 : 0.0;
-            const double cost = makespan_units(tiles * sk) * t1 / sk + t_partial;
+            // banded orders: the XCD with the most work items sets the pace (8 * per_xcd blocks' worth of rounds)
+            const Order o = plan_order(ceil_div(M, bms[s]), ceil_div(N, bns[s]), bms[s], bns[s], sk);
+            const long long blocks = o.order ? 8LL * o.per_xcd : tiles * sk;
+            const double cost = makespan_units(blocks) * t1 / sk + t_partial;
             if (cost < best_cost * 0.97) { best_cost = cost; best = {s, bms[s], bns[s], sk}; }
         };
         if (want_splitk > 0) { consider(std::max(1, std::min(std::min(want_splitk, 64), ktiles))); set_resident_slots_override(0); continue; }
         for (int sk : cand) {
             if (sk > 1 && ktiles / sk < 8) break;
+            if (g_order && sk < 8 && 8 % sk) continue;          // banded order: 1, 2, 4 slices share the XCDs evenly, >= 8 own them
             consider(sk);
         }
     }
@@ -440,9 +504,9 @@ static inline unsigned *image_maxbits(void *image, long long rows, long long K)
     return reinterpret_cast<unsigned *>(reinterpret_cast<char *>(image) + align_up(cells_bytes(rows, K), 256));
 }
 
-static int launch_gemm(const GemmArgs &p0, const Plan &pl, hipStream_t st)
+// tile counts, order and patch of a launch; returns the grid
+static dim3 plan_launch(GemmArgs &p, const Plan &pl)
 {
-    GemmArgs p = p0;
     p.tiles_m = ceil_div(p.M, pl.bm);
     p.tiles_n = ceil_div(p.N, pl.bn);
     int ph = 8, pw = 8;       // ~64 tiles per patch = what one XCD runs at a time (patch_tile)
@@ -450,7 +514,29 @@ static int launch_gemm(const GemmArgs &p0, const Plan &pl, hipStream_t st)
     else if (p.tiles_n < 8) { pw = p.tiles_n; ph = std::min(p.tiles_m, std::max(1, 64 / pw)); }
     p.patch_h = std::max(ph, 1);
     p.patch_w = std::max(pw, 1);
-    const dim3 grid((unsigned)(p.tiles_m * p.tiles_n), (unsigned)p.splitk);
+    const Order o = plan_order(p.tiles_m, p.tiles_n, pl.bm, pl.bn, p.splitk);
+    p.order = o.order; p.bands = o.bands; p.band_n = o.band_n;
+    dim3 grid((unsigned)(p.tiles_m * p.tiles_n), (unsigned)p.splitk);
+    if (o.order) {
+        // the region an XCD walks, and the patch of tiles it runs at once: conc blocks, near-square in operand bytes
+        const int along = o.band_n ? p.tiles_n : p.tiles_m;
+        const int rm = (o.order == 2 && !o.band_n) ? ceil_div(along, o.bands) : p.tiles_m;
+        const int rn = (o.order == 2 && o.band_n) ? ceil_div(along, o.bands) : p.tiles_n;
+        const int conc = (pl.shape == 3) ? 32 : 64;
+        int h = std::max(1, (int)std::lround(std::sqrt((double)conc * pl.bn / pl.bm)));
+        h = std::min(h, rm);
+        int w = std::min(rn, std::max(1, conc / h));
+        if (w == rn) h = std::min(rm, std::max(h, conc / w));      // a narrow region: taller patches
+        p.patch_h = h; p.patch_w = w;
+        grid = dim3((unsigned)(8 * o.per_xcd), 1);
+    }
+    return grid;
+}
+
+static int launch_gemm(const GemmArgs &p0, const Plan &pl, hipStream_t st)
+{
+    GemmArgs p = p0;
+    const dim3 grid = plan_launch(p, pl);
     if (pl.shape == 3) launch<gemm_ring_kernel<R256x256>>(grid, ring_gemm_lds<R256x256>(), st, p, 0, R256x256::threads);
     else if (pl.shape == 4) launch<gemm_ring_kernel<R256x128>>(grid, ring_gemm_lds<R256x128>(), st, p, 0, R256x128::threads);
     else if (pl.shape == 0) launch<gemm_kernel<S256x128>>(grid, S256x128::lds_bytes, st, p);
@@ -479,6 +565,27 @@ using namespace mh;
 extern "C" {
 
 void mh_debug_pl_shape(int shape) { pl::g_force_shape = shape; }
+void mh_debug_pl_order(int order) { pl::g_order = order ? 1 : 0; }
+
+// the work item of block `block` of the launch mh_gemm_planes(M, N, K, splitk) would make, computed on the host with the
+// kernels' own mapping (tests/test_gemm_order.py: every (tile, slice) exactly once).  out = {grid_x, grid_y, tm, tn, z, valid,
+// tiles_m, tiles_n, splitk, order}; returns MH_EINVAL for a block outside the grid.
+int mh_debug_pl_item(int M, int N, int K, int splitk, long long block, int *out)
+{
+    MH_REQUIRE(M > 0 && N > 0 && K > 0 && out && block >= 0);
+    const pl::Plan pln = pl::plan_gemm(M, N, K, splitk);
+    pl::GemmArgs p = {};
+    p.M = M; p.N = N; p.Kc = ceil_div(K, pl::kBK);
+    p.kc_per_split = ceil_div(p.Kc, pln.splitk);
+    p.splitk = ceil_div(p.Kc, p.kc_per_split);
+    const dim3 grid = pl::plan_launch(p, pln);
+    MH_REQUIRE(block < (long long)grid.x * grid.y);
+    int tm = -1, tn = -1, z = -1;
+    const bool ok = pl::gemm_item(p, (int)(block % grid.x), (int)(block / grid.x), tm, tn, z);
+    out[0] = (int)grid.x; out[1] = (int)grid.y; out[2] = tm; out[3] = tn; out[4] = z; out[5] = ok ? 1 : 0;
+    out[6] = p.tiles_m; out[7] = p.tiles_n; out[8] = p.splitk; out[9] = p.order;
+    return MH_OK;
+}
 
 size_t mh_planes_bytes(long long rows, long long K)
 {

@@ -243,7 +243,7 @@ __device__ __forceinline__ void acc_foreach(const Acc<S> &acc, int wm, int wn, i
 
 // XCD-aware remap of a linear block id: consecutive ids go round-robin over the 8 XCDs, so give each XCD a contiguous
 // chunk of the tile numbering (neighbouring tiles share operand panels -> that XCD's L2)
-__device__ __forceinline__ int xcd_remap(int bid, int nblocks)
+__host__ __device__ __forceinline__ int xcd_remap(int bid, int nblocks)
 {
     constexpr int kXcd = 8;
     const int q = nblocks / kXcd, r = nblocks % kXcd;
@@ -252,29 +252,44 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblocks)
     return start + idx;
 }
 // patch-major numbering of a tiles_m x tiles_n tile space (ph x pw tile patches, row-major inside a patch)
-__device__ __forceinline__ void patch_tile(int t, int tiles_m, int tiles_n, int ph, int pw, int &tm, int &tn)
+__host__ __device__ __forceinline__ void patch_tile(int t, int tiles_m, int tiles_n, int ph, int pw, int &tm, int &tn)
 {
     const int band = t / (ph * tiles_n);
     int rem = t - band * (ph * tiles_n);
-    const int bh = min(ph, tiles_m - band * ph);
+    const int bh = ph < tiles_m - band * ph ? ph : tiles_m - band * ph;
     const int npw = (tiles_n + pw - 1) / pw;
-    const int j = min(rem / (bh * pw), npw - 1);
+    const int j = rem / (bh * pw) < npw - 1 ? rem / (bh * pw) : npw - 1;
     rem -= j * (bh * pw);
-    const int w = min(pw, tiles_n - j * pw);
+    const int w = pw < tiles_n - j * pw ? pw : tiles_n - j * pw;
     tm = band * ph + rem / w;
     tn = j * pw + rem % w;
 }
 
 // largest |x| (fp32 bits) of a wave's lanes -> ONE atomicMax when all lanes share `key` (the usual case); lanes with
 // differing keys fall back to their own atomics.  Every lane of the wave must call it.
+//
+// Round 6: the atomic is issued only when it can raise the word.  A layer's tiles all aim at the same B words (one per image,
+// and the tiles of one image run at the same time): conv1_2 sent 65 k atomicMax at six addresses per launch, conv2_x 16 k --
+// same-address atomics are served one after the other by one L2 channel (~11-13 ns each, MI355X_MICROARCH.md "fanin"), and a
+// wave does not retire before its own has been served.  A maximum converges after the first few tiles, so a relaxed
+// agent-scope load (L2-served, never a stale L1 line) in front of the atomic removes nearly all of them; a load that is behind
+// the word's latest value only costs an atomic that was not needed (the word never decreases).
+__device__ __forceinline__ bool may_raise(const unsigned *word, unsigned v)
+{
+#ifdef MH_ATOMIC_ALWAYS       // A/B build knob (csrc/build.py): rounds 3-5, every wave sends its atomic
+    return true;
+#else
+    return v > __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
+}
 __device__ __forceinline__ void wave_atomic_max(unsigned *words, int key, unsigned v)
 {
     const int key0 = __shfl(key, 0);
     if (__all(key == key0)) {
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) v = max(v, (unsigned)__shfl_xor((int)v, o));
-        if ((threadIdx.x & 63) == 0 && v) atomicMax(words + key0, v);
-    } else if (v) {
+        if ((threadIdx.x & 63) == 0 && v && may_raise(words + key0, v)) atomicMax(words + key0, v);
+    } else if (v && may_raise(words + key, v)) {
         atomicMax(words + key, v);
     }
 }

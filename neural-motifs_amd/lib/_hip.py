@@ -25,7 +25,7 @@ SYMBOLS = (
     'mh_planes_bytes', 'mh_make_planes', 'mh_make_planes_both', 'mh_gemm_planes_ws_bytes', 'mh_gemm_planes_auto_splitk', 'mh_gemm_planes',
     'mh_act_planes_bytes', 'mh_act_planes', 'mh_image_maxbits', 'mh_plconv_packed_bytes', 'mh_plconv_pack_weight', 'mh_plconv3x3_ws_bytes',
     'mh_plconv3x3', 'mh_plconv3x3_to_image', 'mh_stem_to_image', 'mh_conv_first_nchw_max', 'mh_debug_plconv_shape', 'mh_debug_plconv_splitk', 'mh_debug_plconv_flags', 'mh_decoder_nms_commit_max_bytes',
-    'mh_debug_pl_shape', 'mh_gemm_ws_bytes_v2', 'mh_gemm_auto_splitk_v2', 'mh_gemm_f32_v2',
+    'mh_debug_pl_shape', 'mh_debug_pl_order', 'mh_debug_pl_item', 'mh_gemm_ws_bytes_v2', 'mh_gemm_auto_splitk_v2', 'mh_gemm_f32_v2',
     'mh_gemm_small_max_counters', 'mh_gemm_small_f32', 'mh_debug_small_plan',
     'mh_conv3x3_packed_floats', 'mh_conv3x3_pack_weight', 'mh_conv3x3_ws_bytes', 'mh_conv3x3_schedule', 'mh_conv3x3_nhwc',
     'mh_conv3x3_wgrad_ws_bytes', 'mh_conv3x3_wgrad', 'mh_conv_first_nchw', 'mh_maxpool2x2_nhwc',

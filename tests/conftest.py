@@ -29,3 +29,13 @@ def load_golden(name):
 @pytest.fixture
 def golden():
     return load_golden
+
+
+@pytest.fixture(scope='session')
+def so_path():
+    """libmotifs_hip.so, (re)built in-tree if a source is newer (hipcc cross-compiles without a GPU)"""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location('mh_build', os.path.join(PKG, 'csrc', 'build.py'))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod.build()

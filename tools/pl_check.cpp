@@ -537,6 +537,36 @@ static void ring_speed(const char *name, int M, int N, int K, int iters)
     set_shape(-1);
 }
 
+// --order-ab: the planner's own launch of each big product of the step under the round-3 tile numbering (order 0) and the
+// XCD-banded order (1), alternating, on ready images
+static shape_fn set_order;
+static void order_ab(const char *name, int M, int N, int K, int iters)
+{
+    Dev dA((size_t)M * K * 4), dB((size_t)N * K * 4), dC((size_t)M * N * 4), ia(pbytes(M, K)), ib(pbytes(N, K));
+    fill_dev(dA.f(), (size_t)M * K, 1); fill_dev(dB.f(), (size_t)N * K, 2);
+    mkplanes(dA.f(), 1, M, K, K, ia.p, nullptr);
+    mkplanes(dB.f(), 1, N, K, K, ib.p, nullptr);
+    const double flops = 2.0 * M * N * (double)K;
+    for (int rep = 0; rep < 2; ++rep)
+        for (int order : {0, 1}) {
+            set_order(order);
+            for (int shape : {-1, 3, 4}) {
+                if (rep == 1 && shape >= 0) continue;
+                set_shape(shape);
+                for (int sk : {0, 1, 2, 4, 8}) {
+                    if (sk > 1 && K / 16 / sk < 8) continue;
+                    if (rep == 1 && sk != 0) continue;
+                    Dev ws(wspl(M, N, K, sk));
+                    const float ms = time_ms(iters, [&] { gemmpl(M, N, K, ia.p, ib.p, dC.f(), N, nullptr, 0, 0, sk, ws.p, ws.n, nullptr); });
+                    printf("{\"check\": \"order ab\", \"case\": \"%s\", \"M\": %d, \"N\": %d, \"K\": %d, \"order\": %d, \"shape\": %d, \"splitk\": %d, \"ms\": %.4f, \"tflops\": %.1f}\n",
+                           name, M, N, K, order, shape, sk, ms, flops / ms * 1e-9);
+                    fflush(stdout);
+                }
+            }
+        }
+    set_order(1); set_shape(-1);
+}
+
 int main(int argc, char **argv)
 {
     if (argc < 2) { printf("usage: pl_check <libmotifs_hip.so> [--quick] [--speed-only]\n"); return 1; }
@@ -638,6 +668,17 @@ int main(int argc, char **argv)
             conv_speed("conv5_1", 6, 37, 37, 512, 512, 1, 5);
         }
         return badc ? 1 : 0;
+    }
+    if (argc > 2 && !strcmp(argv[2], "--order-ab")) {
+        set_order = (shape_fn)dlsym(h, "mh_debug_pl_order");
+        if (!set_order) { printf("missing mh_debug_pl_order\n"); return 2; }
+        order_ab("fc6 forward", 1536, 4096, 25088, 5);
+        order_ab("fc6 input gradient", 1536, 25088, 4096, 5);
+        order_ab("fc6 weight gradient", 4096, 25088, 1536, 5);
+        order_ab("fc7 forward", 1536, 4096, 4096, 10);
+        order_ab("fc7 weight gradient", 4096, 4096, 1536, 10);
+        order_ab("4096^3", 4096, 4096, 4096, 5);
+        return 0;
     }
     int bad = 0;
     if (argc > 2 && !strcmp(argv[2], "--ring")) {
