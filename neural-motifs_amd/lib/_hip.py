@@ -7,6 +7,7 @@ tensor, the call raises.  Build the library with ``python neural-motifs_amd/csrc
 (or ``__graft_entry__.build()``).
 """
 import ctypes
+import threading
 import os
 
 import torch
@@ -120,12 +121,50 @@ def set_pending_param_update(event):
 
 
 def wait_param_update():
-    """make the current stream wait for a deferred optimizer step, if one is in flight (no host synchronisation)"""
+    """make the current stream wait for a deferred optimizer step, if one is in flight (no host synchronisation).  The event is
+    consumed only by the thread that runs the step: a helper thread (RelModel.detect_ahead's worker) orders ITS stream behind
+    the update but leaves the event for the main stream, whose relation stage reads the trainable weights."""
     global _pending_param_update
     ev = _pending_param_update
     if ev is not None:
         torch.cuda.current_stream().wait_event(ev)
-        _pending_param_update = None
+        if threading.current_thread() is threading.main_thread():
+            _pending_param_update = None
+
+
+# ---- values cached across calls that are BUILT by kernels on one stream and READ from others (the weight plane images of
+# hip_ops / resnet, packed conv weights): the detector stage may run on a worker thread with its own stream
+# (RelModel.detect_ahead) while the main stream runs the same frozen layers, and a cache entry is made by whichever of the two
+# touches it first.  `cache_lock` keeps the two threads from building an entry twice; `built_here()` marks an entry with an
+# event on the building stream and `use_built()` makes any OTHER stream wait for it once before its kernels read the entry
+# (ADVICE r05: eval_rels started two ahead stages before the first in-line batch, with cold caches).
+cache_lock = threading.RLock()
+
+
+class _Built(object):
+    __slots__ = ('event', 'stream', 'synced')
+
+
+def built_here(device):
+    """marker of a cache entry whose build kernels were just enqueued on the current stream of `device` (None off the GPU)"""
+    if getattr(device, 'type', None) != 'cuda':
+        return None
+    b = _Built()
+    b.stream = torch.cuda.current_stream(device)
+    b.event = torch.cuda.Event()
+    b.event.record(b.stream)
+    b.synced = set()
+    return b
+
+
+def use_built(b):
+    """the current stream is about to read the cache entry marked `b`: order it behind the entry's build"""
+    if b is None:
+        return
+    cur = torch.cuda.current_stream(b.stream.device)
+    if cur != b.stream and cur.cuda_stream not in b.synced:
+        cur.wait_event(b.event)
+        b.synced.add(cur.cuda_stream)
 
 
 def version_of(p):

@@ -62,20 +62,24 @@ def _weight_image(weight, transposed, want_both=False):
     -- the backward of this step will ask for the other one."""
     key = id(weight)
     ver = _hip.version_of(weight)
-    hit = _weight_images.get(key)
-    if hit is None or hit[0] != ver:
-        if hit is None:
-            weakref.finalize(weight, _weight_images.pop, key, None)      # the images die with their parameter
-        hit = [ver, None, None]
-        _weight_images[key] = hit
-    idx = 2 if transposed else 1
-    if hit[idx] is None:
-        w2 = _rows2d(weight.detach())
-        if want_both and hit[1] is None and hit[2] is None:
-            hit[1], hit[2] = _hip.make_planes_both(w2)
-        else:
-            hit[idx] = _hip.make_planes(w2, k_contiguous=not transposed)
-    return hit[idx]
+    with _hip.cache_lock:                  # entries are shared with the detect-ahead worker thread and its stream (_hip.built_here)
+        hit = _weight_images.get(key)
+        if hit is None or hit[0] != ver:
+            if hit is None:
+                weakref.finalize(weight, _weight_images.pop, key, None)      # the images die with their parameter
+            hit = [ver, None, None, None, None]                              # version, image, transposed image, their build marks
+            _weight_images[key] = hit
+        idx = 2 if transposed else 1
+        if hit[idx] is None:
+            w2 = _rows2d(weight.detach())
+            if want_both and hit[1] is None and hit[2] is None:
+                hit[1], hit[2] = _hip.make_planes_both(w2)
+                hit[3] = hit[4] = _hip.built_here(weight.device)
+            else:
+                hit[idx] = _hip.make_planes(w2, k_contiguous=not transposed)
+                hit[idx + 2] = _hip.built_here(weight.device)
+        _hip.use_built(hit[idx + 2])
+        return hit[idx]
 
 
 def drop_weight_images():
@@ -291,21 +295,28 @@ class Conv3x3(nn.Module):
         self._packed_key = None
         self._plane = None
         self._plane_key = None
+        self._packed_built = self._plane_built = None      # _hip.built_here marks of the two cached copies
 
     def plane_weight(self):
         """packed plane image of the weights for the plane-engine conv (csrc/pl_conv.hip), cached per parameter value"""
         key = (_hip.version_of(self.weight), self.weight.device)
-        if self._plane_key != key:
-            self._plane = _hip.plconv_pack_weight(_c(self.weight.detach()), False)
-            self._plane_key = key
-        return self._plane
+        with _hip.cache_lock:
+            if self._plane_key != key:
+                self._plane = _hip.plconv_pack_weight(_c(self.weight.detach()), False)
+                self._plane_built = _hip.built_here(self.weight.device)
+                self._plane_key = key
+            _hip.use_built(self._plane_built)
+            return self._plane
 
     def packed_weight(self, flip_transpose=False):
         key = (_hip.version_of(self.weight), flip_transpose, self.weight.device)
-        if self._packed_key != key:
-            self._packed = _hip.conv3x3_pack_weight(_c(self.weight.detach()), flip_transpose)
-            self._packed_key = key
-        return self._packed
+        with _hip.cache_lock:
+            if self._packed_key != key:
+                self._packed = _hip.conv3x3_pack_weight(_c(self.weight.detach()), flip_transpose)
+                self._packed_built = _hip.built_here(self.weight.device)
+                self._packed_key = key
+            _hip.use_built(self._packed_built)
+            return self._packed
 
     def forward_nhwc(self, x_nhwc, epilogue=EPI_RELU):
         if self.in_channels % 16 != 0:

@@ -423,8 +423,10 @@ class RelModel(nn.Module):
 
     # ---- the detector stage: everything up to the sampled relation labels -------------------------------------------------
     def _detect(self, x, im_sizes, image_offset, gt_boxes=None, gt_classes=None, gt_rels=None, proposals=None,
-                train_anchor_inds=None):
-        """boxes, labels, RoI logits and the feature map of a batch (reference :466-475)"""
+                train_anchor_inds=None, ahead=False):
+        """boxes, labels, RoI logits and the feature map of a batch (reference :466-475).  ahead: the call is a detect_ahead stage
+        on the worker thread -- the detector is frozen there, so the stage needs no ordering against a deferred optimizer step;
+        the forward that collects it waits on the MAIN stream (forward(): _hip.wait_param_update after _take_ahead)"""
         self.detector.sampler_rs = self.sampler_rs
         # a FusedClipSGD step deferred to its own stream (lib/optim.py: overlap_next_forward) may still be updating the trainable
         # parameters: the frozen detector stage runs beside it, everything after it waits
@@ -433,7 +435,7 @@ class RelModel(nn.Module):
             _hip.wait_param_update()
         result = self.detector(x, im_sizes, image_offset, gt_boxes, gt_classes, gt_rels, proposals,
                                train_anchor_inds, return_fmap=True)
-        if x.is_cuda and not detector_trains:
+        if x.is_cuda and not detector_trains and not ahead:
             _hip.wait_param_update()
         if result.is_none():
             return result, None
@@ -497,7 +499,7 @@ class RelModel(nn.Module):
             assert self.training == training, 'train() / eval() was switched between detect_ahead() and its forward()'
             with torch.set_grad_enabled(grad):
                 if ready is None:
-                    result, im_inds = self._detect(*args)
+                    result, im_inds = self._detect(*args, ahead=True)
                     if im_inds is not None:
                         self._sample_relations(result, im_inds, image_offset, gt_boxes, gt_classes, gt_rels)
                     return result, im_inds, None
@@ -513,7 +515,7 @@ class RelModel(nn.Module):
                     for t in args:
                         if torch.is_tensor(t) and t.is_cuda:
                             t.record_stream(stream)
-                    result, im_inds = self._detect(*args)
+                    result, im_inds = self._detect(*args, ahead=True)
                     if im_inds is not None:
                         self._sample_relations(result, im_inds, image_offset, gt_boxes, gt_classes, gt_rels)
                     done = torch.cuda.Event()
@@ -565,6 +567,10 @@ class RelModel(nn.Module):
     def forward(self, x, im_sizes, image_offset, gt_boxes=None, gt_classes=None, gt_rels=None, proposals=None,
                 train_anchor_inds=None, return_fmap=False):
         ahead = self._take_ahead(x) if self._ahead else None
+        if ahead is not None and x.is_cuda:
+            # the stage ran on the worker's stream: the wait for a deferred optimizer step (the relation stage below reads the
+            # trainable weights) belongs to THIS stream and was not taken there
+            _hip.wait_param_update()
         result, im_inds = ahead if ahead is not None else self._detect(x, im_sizes, image_offset, gt_boxes, gt_classes, gt_rels,
                                                                         proposals, train_anchor_inds)
         if result.is_none():

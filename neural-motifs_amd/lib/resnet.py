@@ -45,6 +45,10 @@ class _Conv(nn.Module):
     def _derived(self):
         """weight matrix / packed weights for the kernel in use, rebuilt only when the parameter changes"""
         key = _hip.version_of(self.weight)
+        with _hip.cache_lock:               # shared with the detect-ahead worker thread / stream (_hip.built_here)
+            return self._derived_locked(key)
+
+    def _derived_locked(self, key):
         if self._cache[0] != key:
             w = self.weight.detach()
             cout, cin, k = w.shape[0], w.shape[1], self.k
@@ -65,7 +69,9 @@ class _Conv(nn.Module):
                 ld = (K + 3) // 4 * 4
                 d = w.new_zeros(cout, ld)
                 d[:, :K] = w.permute(0, 2, 3, 1).reshape(cout, K)
+            self._built = _hip.built_here(w.device)
             self._cache = (key, d)
+        _hip.use_built(getattr(self, '_built', None))
         return self._cache[1]
 
     def forward(self, x):                       # x NHWC
