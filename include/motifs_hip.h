@@ -217,6 +217,13 @@ int mh_conv_first_nchw_max(const float *in_nchw, int B, int Cin, int H, int W, c
 int mh_plconv3x3_to_image(const void *in_image, const unsigned *in_true_maxbits, int B, int H, int W, int Cin,
                           const void *packed, int Cout, const float *bias, int epilogue, void *out_image,
                           unsigned *out_maxbits, void *workspace, size_t ws_bytes, void *stream);
+/* the same conv through the 2x2 / 2 max-pool that follows it (H, W even): out_image = activation image of the POOLED output
+ * [B, H/2, W/2, Cout], mh_act_planes_bytes(B, H / 2, W / 2, Cout) bytes; the pool happens in the kernel's epilogue (tile rows in
+ * pool order), bit-identical to mh_plconv3x3 followed by mh_act_planes(pool = 1).  Replaces the nn.MaxPool2d modules of
+ * vgg16.features behind conv1_2 / conv2_2 / conv3_3 / conv4_3 (reference lib/object_detector.py:110-118, :623-626). */
+int mh_plconv3x3_pool_to_image(const void *in_image, const unsigned *in_true_maxbits, int B, int H, int W, int Cin, const void *packed,
+                               int Cout, const float *bias, int epilogue, void *out_image, unsigned *out_maxbits, void *workspace,
+                               size_t ws_bytes, void *stream);
 int mh_stem_to_image(const float *in_nchw, int B, int Cin, int H, int W, const float *w, int Cout, const float *bias,
                      int epilogue, void *out_image, unsigned *out_maxbits, void *stream);
 

@@ -178,6 +178,7 @@ struct ConvArgs {
     int tail_tiles, tail_slices, tail_ktiles;
     long long tail_row0;
     float *partial, *partial_tail;
+    int *counters;             // ring kernels: arrival counters of the sliced tiles [body_tiles + tail_tiles], zero on entry, left zero
     int debug_flags;           // measurement only (mh_debug_plconv_flags): bit 1 = the ring kernel returns without its epilogue (no output):
                                // what the K loop alone costs (gpurun r04_c5)
 };
@@ -402,24 +403,50 @@ __global__ __launch_bounds__(kThreads, (S::bm * S::bn <= 128 * 128) ? 3 : 2) voi
 
 // ------------------------------------------------------------------------------------------------- the ring conv kernel
 // Round 4: the same implicit GEMM on the ring loop of pl_ring.h (LDS-DMA staging: no staging registers, no ds_write;
-// register double-buffered fragments; one barrier per k-tile with NS - 2 tiles in flight).  Images, scales, schedules and both
-// epilogues are those of conv3x3_kernel above; what changes is how a k-tile reaches LDS:
+// register double-buffered fragments; one barrier per k-tile with NS - 2 tiles in flight).  Images and scales are those of
+// conv3x3_kernel above; what changes is how a k-tile reaches LDS:
 //   * a lane owns R::na rows of the A tile (one per DMA piece) and keeps their 9-bit tap masks; for the k-tile of tap t a
 //     row whose tap leaves the image is fetched out of range (the DMA writes zeros), selected per piece with one v_cndmask;
-//   * the (A offset, B offset, tap bit) entry of a k-tile comes from the same per-block table in LDS, read one issue ahead;
-//     padding steps of the unrolled ring (and steps past a K slice's end) carry tap bit 0: A = zeros, acc += 0 * B.
+//   * padding steps of the unrolled ring (and steps past a K slice's end) carry tap bit 0: A = zeros, acc += 0 * B.
+// Round 6:
+//   * MODE 2 -- the 2x2 / 2 max-pool that follows the layer happens in the epilogue and the POOLED output leaves as the next
+//     layer's activation image (conv1_2, conv2_2, conv3_3, conv4_3 wrote 1 GB of fp32 per step for a converter pass to read
+//     back).  The rows of a tile are the pixels in POOL ORDER: row q = 4 * (pooled pixel) + 2 * dx + dy, so the four pixels of
+//     a pooling window are four consecutive rows = four neighbouring lanes of one accumulator register (two DPP row maxima),
+//     no window straddles a tile, and the pooled pixels of a tile are consecutive in the pooled image.  The order costs
+//     nothing in the K loop: a lane's DMA source offset is free (dma_probe), a tap is still one scalar offset for the whole
+//     tile.  max commutes with the (monotone) epilogue, so the maximum is taken on the raw accumulators and a lane then
+//     finishes a QUARTER of its registers: bit-identical to pooling afterwards.
+//   * K slices are added up INSIDE the launch: every slice leaves its raw accumulators in the workspace in register order
+//     (1 KiB per store instruction), takes a ticket on the tile's arrival counter (agent-scope release in front of it), and the
+//     block that draws the last ticket acquires, adds the slices in slice order (the result does not depend on the arrival
+//     order) and runs the tile's ordinary epilogue.  No reduce launch, no second epilogue code path, and the schedule may cut
+//     a launch that fills half the chip (conv5: 132 tiles) into slices without paying for a second pass.
 constexpr int kRingStageOff = 8192;   // LDS offset of the ring kernel's image staging (exponent tables of up to 512 + 256 rows in front)
 template <class R>
-constexpr int ring_conv_lds_bytes(bool img)
+constexpr int ring_conv_lds_bytes(int mode)
 {
-    const int epi = kRingStageOff + R::waves * (img ? 2 * 32 * 80 : 32 * 36 * 4);      // wave-private staging patches of the epilogue
+    const int epi = kRingStageOff + R::waves * (mode == 1 ? 2 * 32 * 80 : (mode == 2 ? 2 * 8 * 80 : 32 * 36 * 4));      // wave-private staging patches
     return epi > R::lds_bytes ? epi : R::lds_bytes;
 }
+// floats one (tile, slice) leaves in the workspace: the block's accumulators in register order
+template <class R>
+constexpr size_t ring_partial_floats() { return (size_t)R::bm * R::bn; }
 
-template <class R, bool IMG>
+__device__ __forceinline__ float quad_max(float v)
+{
+    // maximum over the four lanes of a quad (DPP quad_perm [1,0,3,2], then [2,3,0,1]): every lane of the quad gets it
+    float t = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, false));
+    v = fmaxf(v, t);
+    t = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, false));
+    return fmaxf(v, t);
+}
+
+template <class R, int MODE>      // MODE 0: fp32 NHWC output, 1: activation image, 2: 2x2-pooled activation image
 __global__ __launch_bounds__(R::threads, (R::threads == 512 || R::sm * R::sn <= 8) ? 2 : 1) void conv3x3_ring_kernel(const ConvArgs p)
 {
     extern __shared__ __attribute__((aligned(1024))) char lds[];
+    constexpr bool IMG = MODE != 0, POOL = MODE == 2;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     int wm, wn;
     rwave_origin<R>(wave, wm, wn);
@@ -441,27 +468,46 @@ __global__ __launch_bounds__(R::threads, (R::threads == 512 || R::sm * R::sn <= 
     const long long m0 = (long long)(t / p.tiles_n) * R::bm;
     const int n0 = (t % p.tiles_n) * R::bn;
     const long long HW = (long long)p.H * p.W, Mtot = (long long)p.B * HW;
+    const unsigned uW = (unsigned)p.W, uHW = (unsigned)HW;                 // B*H*W < 2^25 (host-checked image size)
+    const unsigned uWo = uW >> 1, uHoWo = uHW >> 2;
     const int G = p.Cin / kBK;
     const int total_kt = 9 * G;
     const int kt_begin = slice * kt_per_slice, kt_end = min(total_kt, kt_begin + kt_per_slice);
 
+    // tile row -> (image, y, x) and the linear pixel index its cells are addressed by
+    auto locate = [&](unsigned q, unsigned &py, unsigned &px) -> unsigned {
+        if (!POOL) {
+            const unsigned rem = q % uHW;
+            py = rem / uW; px = rem - py * uW;
+            return q;
+        }
+        const unsigned quad = q >> 2, b = quad / uHoWo, rem = quad - b * uHoWo, yo = rem / uWo, xo = rem - yo * uWo;
+        py = 2 * yo + (q & 1); px = 2 * xo + ((q >> 1) & 1);
+        return (b * (unsigned)p.H + py) * uW + px;
+    };
+    // A is addressed relative to one halo (W + 1 pixels) before the tile's first pixel (the smallest pixel index of the tile in
+    // either order): every tap of every valid pixel has a non-negative offset
     const int halo = p.W + 1;
-    const Src sa = make_src(p.in + (m0 - halo) * (long long)kCell), sb = make_src(p.wt + (size_t)n0 * kCell);
+    unsigned py0, px0;
+    const unsigned pix0 = locate((unsigned)min(m0, Mtot - 1), py0, px0);
+    const Src sa = make_src(p.in + ((long long)pix0 - halo) * (long long)kCell), sb = make_src(p.wt + (size_t)n0 * kCell);
     DmaPlan<R> dp;
     plan_dma<R>(dp, [&](int) { return true; }, [&](int r) { return n0 + r < p.Cout; }, wave, lane);
     unsigned a_taps[R::na];
 #pragma unroll
     for (int j = 0; j < R::na; ++j) {
-        const long long pix = m0 + dma_row<R>(j, wave, lane);
-        const bool ok = pix < Mtot;
-        const int rem = (int)((ok ? pix : 0) % HW), py = rem / p.W, px = rem % p.W;
+        const int row = dma_row<R>(j, wave, lane);
+        const bool ok = m0 + row < Mtot;
+        unsigned py, px;
+        const unsigned pix = locate(ok ? (unsigned)(m0 + row) : (unsigned)m0, py, px);
         unsigned mask = 0;
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
             const int dy = tap / 3 - 1, dx = tap % 3 - 1;
-            if (ok && (unsigned)(py + dy) < (unsigned)p.H && (unsigned)(px + dx) < (unsigned)p.W) mask |= 1u << tap;
+            if (ok && (unsigned)((int)py + dy) < (unsigned)p.H && (unsigned)((int)px + dx) < (unsigned)p.W) mask |= 1u << tap;
         }
         a_taps[j] = mask;
+        if (POOL) dp.va[j] = (pix - pix0) * (unsigned)kCell + 16u * (unsigned)((lane & 3) ^ swz(row));
     }
     FragPlan fp;
     rplan_frags<R>(fp, wm, wn, lane);
@@ -507,19 +553,62 @@ __global__ __launch_bounds__(R::threads, (R::threads == 512 || R::sm * R::sn <= 
         return;
     }
 
+    // ---- K slices: leave the raw accumulators, take a ticket; the last block of the tile adds all slices (in slice order) and goes on
+    if (nslices > 1) {
+        const int t_local = is_tail ? t - p.body_tiles : t, region_tiles = is_tail ? p.tail_tiles : p.body_tiles;
+        float *region = is_tail ? p.partial_tail : p.partial;
+        const size_t tile_floats = ring_partial_floats<R>(), wave_floats = tile_floats / R::waves;
+        float *mine = region + ((size_t)slice * region_tiles + t_local) * tile_floats + (size_t)wave * wave_floats;
+#pragma unroll
+        for (int sm = 0; sm < R::sm; ++sm)
+#pragma unroll
+            for (int sn = 0; sn < R::sn; ++sn)
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    *reinterpret_cast<float4 *>(mine + ((size_t)((sm * R::sn + sn) * 4 + q) * 64 + lane) * 4) =
+                        make_float4(acc.v[sm][sn][4 * q], acc.v[sm][sn][4 * q + 1], acc.v[sm][sn][4 * q + 2], acc.v[sm][sn][4 * q + 3]);
+        int *ticket = reinterpret_cast<int *>(lds);
+        int *counter = p.counters + (is_tail ? p.body_tiles : 0) + t_local;
+        __syncthreads();
+        if (tid == 0) {
+            // plain stores -> barrier -> one agent-scope release -> drained -> relaxed ticket (MI355X_MICROARCH.md, valid producer form)
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const int got = __hip_atomic_fetch_add(counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (got == nslices - 1) {
+                __hip_atomic_store(counter, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // re-armed for the next launch
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            }
+            *ticket = got;
+        }
+        __syncthreads();
+        if (*ticket != nslices - 1) return;
+        racc_zero<R>(acc);
+        for (int z = 0; z < nslices; ++z) {
+            const float *src = region + ((size_t)z * region_tiles + t_local) * tile_floats + (size_t)wave * wave_floats;
+#pragma unroll
+            for (int sm = 0; sm < R::sm; ++sm)
+#pragma unroll
+                for (int sn = 0; sn < R::sn; ++sn)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const float4 v = *reinterpret_cast<const float4 *>(src + ((size_t)((sm * R::sn + sn) * 4 + q) * 64 + lane) * 4);
+                        acc.v[sm][sn][4 * q] += v.x; acc.v[sm][sn][4 * q + 1] += v.y; acc.v[sm][sn][4 * q + 2] += v.z; acc.v[sm][sn][4 * q + 3] += v.w;
+                    }
+        }
+        __syncthreads();                        // the ticket word is part of the tables below
+    }
+
     // ---- epilogue.  The MFMAs ran with the operand roles SWAPPED (rmma: weights as the matrix-core A operand, pixels as B), so
     // accumulator (sm, sn) of lane (j = lane & 31, g = lane >> 5) holds, in registers 4 q .. 4 q + 3, FOUR CONSECUTIVE CHANNELS
-    //     channel = wn + 32 sn + 8 q + 4 g + (0..3)     of pixel     wm + 32 sm + j
-    // -- 16 contiguous bytes of an NHWC row, or a quarter of a plane-image cell.  Round 3's epilogue had one channel of 16
-    // rows per lane: 128 four-byte global stores per lane and tile (fp32) or a shuffle + ds_write_b32 per ELEMENT (image), and
-    // measured as long as the whole K loop on the shallow layers (gpurun r04_c5: conv2_1 186 TF/s with it, 392 without).
-    // Now each 32 x 32 accumulator goes through a wave-private LDS patch (4 ds_write_b128 / 8 ds_write_b64 per lane) and leaves
-    // as four 16-byte stores per lane covering whole 128-byte lines.
+    //     channel = wn + 32 sn + 8 q + 4 g + (0..3)     of tile row     wm + 32 sm + j
+    // -- 16 contiguous bytes of an NHWC row, or a quarter of a plane-image cell.  Each 32 x 32 accumulator goes through a
+    // wave-private LDS patch and leaves as 16-byte stores covering whole 128-byte lines (fp32) or runs of 64-byte cells (image).
     float *chan_f = reinterpret_cast<float *>(lds);             // bias[bn]
     int *chan_e = reinterpret_cast<int *>(lds) + R::bn;         // weight exponent per channel [bn]
     for (int i = tid; i < R::bn; i += R::threads) {
         const bool ok = n0 + i < p.Cout;
-        chan_f[i] = (ok && p.bias && nslices == 1) ? p.bias[n0 + i] : 0.f;
+        chan_f[i] = (ok && p.bias) ? p.bias[n0 + i] : 0.f;
         chan_e[i] = ok ? row_exponent(p.wt_bits[n0 + i]) : 0;
     }
     float bmax = 0.f;
@@ -542,45 +631,9 @@ __global__ __launch_bounds__(R::threads, (R::threads == 512 || R::sm * R::sn <= 
     __syncthreads();
     static_assert((2 * R::bn + 16) * 4 <= kRingStageOff, "channel tables must fit in front of the staging patches");
     const int j = lane & 31, g = lane >> 5;
-    const unsigned uHW = (unsigned)HW;                                      // B*H*W < 2^25 (host-checked image size)
-    if (nslices > 1) {
-        // partial sums of this K slice (fp32, scales removed): rows numbered from the first row of the block's region
-        const long long region_row0 = is_tail ? p.tail_row0 : 0, region_rows = is_tail ? Mtot - p.tail_row0 : p.tail_row0;
-        float *dst = (is_tail ? p.partial_tail : p.partial) + (size_t)slice * region_rows * p.Cout;
-        float *stg = reinterpret_cast<float *>(lds + kRingStageOff) + wave * (32 * 36);
-#pragma unroll
-        for (int sm = 0; sm < R::sm; ++sm) {
-            const long long row = m0 + wm + 32 * sm + j;
-            const int ea = row < Mtot ? row_exponent(p.in_bits[(unsigned)row / uHW]) : 0;
-#pragma unroll
-            for (int sn = 0; sn < R::sn; ++sn) {
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int c = wn + 32 * sn + 8 * q + 4 * g;
-                    const int4 eb = *reinterpret_cast<const int4 *>(chan_e + c);
-                    float4 v;
-                    v.x = __builtin_ldexpf(acc.v[sm][sn][4 * q + 0], -(ea + eb.x));
-                    v.y = __builtin_ldexpf(acc.v[sm][sn][4 * q + 1], -(ea + eb.y));
-                    v.z = __builtin_ldexpf(acc.v[sm][sn][4 * q + 2], -(ea + eb.z));
-                    v.w = __builtin_ldexpf(acc.v[sm][sn][4 * q + 3], -(ea + eb.w));
-                    *reinterpret_cast<float4 *>(stg + j * 36 + 8 * q + 4 * g) = v;
-                }
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int rr = 8 * i + (lane >> 3), c4 = 4 * (lane & 7);
-                    const long long orow = m0 + wm + 32 * sm + rr;
-                    const int col = n0 + wn + 32 * sn + c4;
-                    const float4 v = *reinterpret_cast<const float4 *>(stg + rr * 36 + c4);
-                    if (orow < Mtot && col < p.Cout) *reinterpret_cast<float4 *>(dst + (size_t)(orow - region_row0) * p.Cout + col) = v;
-                }
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        }
-        return;
-    }
     unsigned vmax[R::sm];
     int img_of[R::sm];
-    if (!IMG) {
+    if (MODE == 0) {
         float *stg = reinterpret_cast<float *>(lds + kRingStageOff) + wave * (32 * 36);      // [32 pixels][32 channels + 4 pad]
 #pragma unroll
         for (int sm = 0; sm < R::sm; ++sm) {
@@ -621,7 +674,7 @@ __global__ __launch_bounds__(R::threads, (R::threads == 512 || R::sm * R::sn <= 
             }
             vmax[sm] = vm;
         }
-    } else {
+    } else if (MODE == 1) {
         // image output: a lane's four channels are 8 bytes of the cell's h1 half and 8 bytes of its h2 half; the wave assembles the
         // 2 chunks x 32 pixels of a 32 x 32 accumulator in an LDS patch with an 80-byte cell pitch (ds_write_b64 two-way instead of
         // eight-way conflicts) and copies the cells out as 1 KiB runs (the 64-byte cells of consecutive pixels are adjacent)
@@ -669,6 +722,64 @@ __global__ __launch_bounds__(R::threads, (R::threads == 512 || R::sm * R::sn <= 
                     const u32x4 cellv = *reinterpret_cast<const u32x4 *>(stg + (cc * 32 + rr) * kPitch + 16 * c16);
                     if (orow < Mtot && chunk * kBK < p.Cout)
                         *reinterpret_cast<u32x4 *>(p.out_cells + ((size_t)chunk * Mtot + orow) * kCell + 16 * c16) = cellv;
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            vmax[sm] = vm;
+        }
+    } else {
+        // pooled image output (see the header): quad maxima of the raw accumulators, then lane (j, g) finishes register quad
+        // q = j & 3 of pooled pixel j >> 2 -- channels 32 sn + 8 (j & 3) + 4 g + (0..3) -- so every lane scales, clamps and splits
+        // four values per accumulator instead of sixteen; 2 chunks x 8 pooled pixels of cells per accumulator leave as ONE 16-byte
+        // store per lane (two 512-byte runs)
+        constexpr int kPitch = 80;
+        char *stg = lds + kRingStageOff + wave * (2 * 8 * kPitch);
+        const long long chunk0 = (n0 + wn) / kBK, Mo = Mtot >> 2;
+        const int within = j & 3, pl = j >> 2;
+#pragma unroll
+        for (int sm = 0; sm < R::sm; ++sm) {
+            const long long row = m0 + wm + 32 * sm + j;
+            const bool rok = row < Mtot;                                   // H and W are even: a window is inside or outside as a whole
+            const int b = rok ? (int)((unsigned)(row >> 2) / uHoWo) : 0;
+            const int ea = rok ? row_exponent(p.in_bits[b]) : 0;
+            const int eo = rok ? row_exponent(bound_bits(b)) : 0;
+            img_of[sm] = b;
+            unsigned vm = 0;
+#pragma unroll
+            for (int sn = 0; sn < R::sn; ++sn) {
+                float x[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float m0q = quad_max(acc.v[sm][sn][i]), m1q = quad_max(acc.v[sm][sn][4 + i]);
+                    const float m2q = quad_max(acc.v[sm][sn][8 + i]), m3q = quad_max(acc.v[sm][sn][12 + i]);
+                    x[i] = (within & 2) ? ((within & 1) ? m3q : m2q) : ((within & 1) ? m1q : m0q);
+                }
+                const int c = wn + 32 * sn + 8 * within + 4 * g;
+                const int4 eb = *reinterpret_cast<const int4 *>(chan_e + c);
+                const float4 bs = *reinterpret_cast<const float4 *>(chan_f + c);
+                float v0 = conv_epi(__builtin_ldexpf(x[0], -(ea + eb.x)) + bs.x, p.epilogue);
+                float v1 = conv_epi(__builtin_ldexpf(x[1], -(ea + eb.y)) + bs.y, p.epilogue);
+                float v2 = conv_epi(__builtin_ldexpf(x[2], -(ea + eb.z)) + bs.z, p.epilogue);
+                float v3 = conv_epi(__builtin_ldexpf(x[3], -(ea + eb.w)) + bs.w, p.epilogue);
+                if (!rok) v0 = v1 = v2 = v3 = 0.f;
+                if (n0 + c + 0 >= p.Cout) v0 = 0.f;
+                if (n0 + c + 1 >= p.Cout) v1 = 0.f;
+                if (n0 + c + 2 >= p.Cout) v2 = 0.f;
+                if (n0 + c + 3 >= p.Cout) v3 = 0.f;
+                vm = max(vm, max(max(__float_as_uint(v0) & 0x7fffffffu, __float_as_uint(v1) & 0x7fffffffu),
+                                 max(__float_as_uint(v2) & 0x7fffffffu, __float_as_uint(v3) & 0x7fffffffu)));
+                unsigned a1, a2, b1, b2;
+                split2(v0, v1, eo, a1, a2);
+                split2(v2, v3, eo, b1, b2);
+                char *cell = stg + ((within >> 1) * 8 + pl) * kPitch + 16 * (within & 1) + 8 * g;
+                *reinterpret_cast<u32x2 *>(cell) = (u32x2){a1, b1};
+                *reinterpret_cast<u32x2 *>(cell + 32) = (u32x2){a2, b2};
+                {
+                    const int cc = lane >> 5, pp = (lane >> 2) & 7, c16 = lane & 3;
+                    const long long orow = ((m0 + wm + 32 * sm) >> 2) + pp, chunk = chunk0 + 2 * sn + cc;
+                    const u32x4 cellv = *reinterpret_cast<const u32x4 *>(stg + (cc * 8 + pp) * kPitch + 16 * c16);
+                    if (orow < Mo && chunk * kBK < p.Cout)
+                        *reinterpret_cast<u32x4 *>(p.out_cells + ((size_t)chunk * Mo + orow) * kCell + 16 * c16) = cellv;
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -851,9 +962,12 @@ __global__ __launch_bounds__(256) void image_absmax_kernel(const float *__restri
 typedef Shape<256, 128, 4, 2> S256x128;
 typedef Shape<128, 128, 2, 2> S128x128;
 typedef Shape<256, 64, 2, 2> S256x64;
-// the ring shape that ships (shape 4).  Three more were built and measured in round 4 and removed again because they never won
-// (profiles/r04_ring_conv_sweep.jsonl: 256x256 on eight waves -- shape 3 there --, 256x64 and 128x128 with 64x64 wave tiles -- 5, 6)
+// the ring shapes: 4 ships since round 4 for Cout >= 128; 5 / 6 are the 64-channel tiles of conv1_2 (round 6: with the pooled
+// image epilogue the layer's time is its K loop, which round 4 measured at 355 TF/s on this tile against 228 for the round-3 loop
+// with its fp32 epilogue; profiles/r04_conv_no_epilogue.jsonl)
 typedef Ring<4, 1, 2, 4, 3> CR256x128;     // shape 4: 4 waves, 64x128 wave tiles, 3 stages x 24 KB, two blocks per CU
+typedef Ring<4, 1, 2, 2, 4> CR256x64;      // shape 5: 4 waves, 64x64 wave tiles, 4 stages x 20 KB, two blocks per CU
+typedef Ring<4, 1, 2, 2, 3> CR256x64s3;    // shape 6: the same with 3 stages
 constexpr int kMaxImages = 65535;    // grid.y of image_absmax_kernel; activation images are addressed with 32-bit byte offsets anyway
 static int g_conv_shape = -1;       // mh_debug_plconv_shape
 static int g_conv_flags = 0;        // mh_debug_plconv_flags
@@ -884,28 +998,71 @@ static Sched schedule(long long M, int Cin, int Cout)
     // 331 / 324, conv4_2 393 / 378 vs 329 / 324, conv5_1 223 / 217 vs 211 / 210; Cout 64 (conv1_2: 36 k-tiles per tile, the
     // block count per CU decides) stays on the round-3 256x64 loop, whole tiles (228 vs 203 with the tail cut into slices)
     static const bool ring_off = [] { const char *e = getenv("MH_PL_RING"); return e && e[0] == '0'; }();      // A/B: MH_PL_RING=0 = round-3 loop
-    s.shape = (g_conv_shape >= 0) ? g_conv_shape : (Cout <= 64 ? 2 : (env_shape >= 0 ? env_shape : (ring_off ? 1 : 4)));
-    if (Cout <= 64 || s.shape == 3 || s.shape > 4) s.shape = (Cout <= 64) ? 2 : 4;          // 64 output channels: the 64-wide round-3 tiles
-    static const int bms[5] = {256, 128, 256, 256, 256}, bns[5] = {128, 128, 64, 256, 128};
+    static const int env64 = [] { const char *e = getenv("MH_PLCONV_SHAPE64"); return e ? atoi(e) : -1; }();      // 2 | 5 | 6 (A/B)
+    const int narrow = (env64 == 2 || env64 == 5 || env64 == 6) ? env64 : (ring_off ? 2 : 5);
+    if (Cout <= 64) s.shape = (g_conv_shape == 2 || g_conv_shape == 5 || g_conv_shape == 6) ? g_conv_shape : narrow;
+    else {
+        s.shape = (g_conv_shape >= 0) ? g_conv_shape : (env_shape >= 0 ? env_shape : (ring_off ? 1 : 4));
+        if (s.shape == 2 || s.shape == 3 || s.shape > 4) s.shape = 4;
+    }
+    static const int bms[7] = {256, 128, 256, 256, 256, 256, 256}, bns[7] = {128, 128, 64, 256, 128, 64, 64};
     s.bm = bms[s.shape];
     s.bn = bns[s.shape];
     s.pl = plan_conv_tiles(M, Cin, Cout, s.bm, s.bn);
     const long long tiles = (long long)s.pl.tiles_m * s.pl.tiles_n;
     const int slots = resident_slots();
     const long long rounds = tiles / slots;
-    const bool whole = (rounds == 0) ? tiles > slots / 4 : (rounds > 3 || s.shape == 2);
+    const bool ring = s.shape >= 4;
+    bool whole = (rounds == 0) ? tiles > slots / 4 : (rounds > 3 || s.shape == 2);
+    if (ring && rounds == 0) {
+        // the ring kernels add their K slices up inside the launch (round 6): a launch that leaves CUs idle or alone with one block
+        // is cut until the blocks fill the resident slots (conv5: 132 tiles -> 3 slices of 11 / 11 / 10 chunks; MH_PLCONV_ONE_ROUND=n
+        // forces n slices, 1 = whole tiles as in round 5)
+        static const int env_sk = [] { const char *e = getenv("MH_PLCONV_ONE_ROUND"); return e ? atoi(e) : 0; }();
+        const int chunks = Cin / kBK;
+        int sk = env_sk > 0 ? env_sk : (int)std::max<long long>(1, slots / std::max<long long>(tiles, 1));
+        sk = std::max(1, std::min(sk, chunks / 4));                    // >= 4 chunks (36 k-tiles) per slice
+        s.pl.splitk = sk; s.pl.body_mtiles = s.pl.tiles_m; s.pl.tail_slices = 1;
+        whole = false;
+    }
     if (whole) { s.pl.splitk = 1; s.pl.body_mtiles = s.pl.tiles_m; s.pl.tail_slices = 1; }
     if (g_conv_splitk > 0) { s.pl.splitk = std::min(g_conv_splitk, 9 * (Cin / kBK)); s.pl.body_mtiles = s.pl.tiles_m; s.pl.tail_slices = 1; }
     return s;
 }
-static void partial_bytes(const Sched &sc, long long M, int Cin, int Cout, size_t &body, size_t &tail)
+// the launch's K slicing as the kernels see it (ring shapes slice at whole 16-channel chunks = 9 k-tiles)
+struct Slicing {
+    int ktiles_per_split, splitk, tail_ktiles, tail_slices, body_tiles, tail_tiles;
+    long long tail_row0;
+};
+static Slicing slicing_of(const Sched &sc, long long M, int Cin)
 {
+    Slicing z;
     const int total_kt = 9 * (Cin / kBK);
-    const long long row0 = std::min<long long>(M, (long long)sc.pl.body_mtiles * sc.bm);
-    const int s0 = ceil_div(total_kt, ceil_div(total_kt, sc.pl.splitk));
-    body = (s0 > 1) ? align_up((size_t)s0 * row0 * Cout * sizeof(float), 256) : 0;
-    const int tk = ceil_div(total_kt, sc.pl.tail_slices), ts = ceil_div(total_kt, tk);
-    tail = (ts > 1 && row0 < M) ? align_up((size_t)ts * (M - row0) * Cout * sizeof(float), 256) : 0;
+    const int kgran = (sc.shape >= 3) ? 9 : 1;
+    z.ktiles_per_split = ceil_div(ceil_div(total_kt, sc.pl.splitk), kgran) * kgran;
+    z.splitk = ceil_div(total_kt, z.ktiles_per_split);
+    z.tail_ktiles = ceil_div(ceil_div(total_kt, sc.pl.tail_slices), kgran) * kgran;
+    z.tail_slices = ceil_div(total_kt, z.tail_ktiles);
+    z.body_tiles = sc.pl.body_mtiles * sc.pl.tiles_n;
+    z.tail_tiles = (sc.pl.tiles_m - sc.pl.body_mtiles) * sc.pl.tiles_n;
+    z.tail_row0 = std::min<long long>(M, (long long)sc.pl.body_mtiles * sc.bm);
+    if (z.tail_tiles == 0) z.tail_slices = 1;
+    return z;
+}
+// workspace: partial sums of the body region | of the tail region | (ring shapes) the tiles' arrival counters
+static void partial_bytes(const Sched &sc, long long M, int Cin, int Cout, size_t &body, size_t &tail, size_t &counters)
+{
+    const Slicing z = slicing_of(sc, M, Cin);
+    if (sc.shape >= 4) {        // ring kernels: whole tiles of raw accumulators per slice (register order), reduced inside the launch
+        const size_t tile = (size_t)sc.bm * sc.bn * sizeof(float);
+        body = (z.splitk > 1) ? align_up((size_t)z.splitk * z.body_tiles * tile, 256) : 0;
+        tail = (z.tail_slices > 1 && z.tail_tiles > 0) ? align_up((size_t)z.tail_slices * z.tail_tiles * tile, 256) : 0;
+        counters = (body + tail) ? align_up((size_t)(z.body_tiles + z.tail_tiles) * sizeof(int), 256) : 0;
+        return;
+    }
+    counters = 0;
+    body = (z.splitk > 1) ? align_up((size_t)z.splitk * z.tail_row0 * Cout * sizeof(float), 256) : 0;
+    tail = (z.tail_slices > 1 && z.tail_row0 < M) ? align_up((size_t)z.tail_slices * (M - z.tail_row0) * Cout * sizeof(float), 256) : 0;
 }
 
 }  // namespace pl
@@ -990,13 +1147,13 @@ size_t mh_plconv3x3_ws_bytes(int B, int H, int W, int Cin, int Cout)
     const long long M = (long long)B * H * W;
     if (M <= 0 || Cin <= 0 || Cout <= 0 || Cin % pl::kBK) return 0;
     const pl::Sched sc = pl::schedule(M, Cin, Cout);
-    size_t body, tail;
-    pl::partial_bytes(sc, M, Cin, Cout, body, tail);
-    return body + tail;
+    size_t body, tail, counters;
+    pl::partial_bytes(sc, M, Cin, Cout, body, tail, counters);
+    return body + tail + counters;
 }
 
 static int plconv_impl(const void *in_image, const unsigned *in_true_maxbits, int B, int H, int W, int Cin, const void *packed,
-                       int Cout, const float *bias, int epilogue, float *out, void *out_image, unsigned *out_maxbits,
+                       int Cout, const float *bias, int epilogue, float *out, void *out_image, int pool, unsigned *out_maxbits,
                        void *workspace, size_t ws_bytes, void *stream)
 {
     // many small images (round 5: the 1536 7x7 RoI maps of the mask tower / the ResNet layer4 stacks): the fp32-output kernels
@@ -1004,10 +1161,13 @@ static int plconv_impl(const void *in_image, const unsigned *in_true_maxbits, in
     MH_REQUIRE(in_image && packed && (out || out_image) && B > 0 && B <= (out_image ? 256 : pl::kMaxImages) && H > 0 && W > 0);
     MH_REQUIRE(Cin > 0 && Cin % pl::kBK == 0 && Cout > 0 && Cout % 4 == 0);
     MH_REQUIRE(!out_image || (Cout % pl::kBK == 0 && in_true_maxbits));
+    MH_REQUIRE(!pool || (out_image && H % 2 == 0 && W % 2 == 0));
     MH_REQUIRE(((reinterpret_cast<uintptr_t>(in_image) | reinterpret_cast<uintptr_t>(packed) | reinterpret_cast<uintptr_t>(out) |
                  reinterpret_cast<uintptr_t>(out_image)) & 15) == 0);
     const long long M = (long long)B * H * W;
-    MH_REQUIRE(pl::act_cells_bytes(M, Cin) + (size_t)(2 * (W + 1) + 256) * pl::kCell < (size_t)0x7ff00000u &&
+    // 32-bit offsets from a tile's first pixel: the tile, two halos, and in pool order the image rows a tile's 64 windows span
+    const long long span = pool ? 2LL * W * (64 / std::max(W / 2, 1) + 2) : 256;
+    MH_REQUIRE(M < (1LL << 25) && pl::act_cells_bytes(M, Cin) + (size_t)(2 * (W + 1) + span) * pl::kCell < (size_t)0x7ff00000u &&
                pl::wt_cells_bytes(Cout, Cin) < (size_t)0x7ff00000u);
     pl::ConvArgs p;
     p.in = reinterpret_cast<const char *>(in_image);
@@ -1020,26 +1180,23 @@ static int plconv_impl(const void *in_image, const unsigned *in_true_maxbits, in
     p.Cout = Cout; p.bias = bias; p.epilogue = epilogue; p.out = out; p.out_bits = out_maxbits;
     p.debug_flags = pl::g_conv_flags;
     p.out_cells = reinterpret_cast<char *>(out_image);
-    p.out_scale_bits = out_image ? reinterpret_cast<unsigned *>(p.out_cells + align_up(pl::act_cells_bytes(M, Cout), 256)) : nullptr;
+    p.out_scale_bits = out_image ? reinterpret_cast<unsigned *>(p.out_cells + align_up(pl::act_cells_bytes(pool ? M / 4 : M, Cout), 256)) : nullptr;
     pl::Sched sc = pl::schedule(M, Cin, Cout);
-    size_t body_bytes, tail_bytes;
-    pl::partial_bytes(sc, M, Cin, Cout, body_bytes, tail_bytes);
-    if (body_bytes + tail_bytes > 0 && (workspace == nullptr || ws_bytes < body_bytes + tail_bytes)) {
+    if (pool && sc.shape < 4) sc = [&] { const int keep = pl::g_conv_shape; pl::g_conv_shape = Cout <= 64 ? 5 : 4; pl::Sched r = pl::schedule(M, Cin, Cout); pl::g_conv_shape = keep; return r; }();   // the pooled epilogue exists on the ring kernels only
+    size_t body_bytes, tail_bytes, counter_bytes;
+    pl::partial_bytes(sc, M, Cin, Cout, body_bytes, tail_bytes, counter_bytes);
+    if (body_bytes + tail_bytes > 0 && (workspace == nullptr || ws_bytes < body_bytes + tail_bytes + counter_bytes)) {
         sc.pl.splitk = 1; sc.pl.body_mtiles = sc.pl.tiles_m; sc.pl.tail_slices = 1;     // no room for partial sums: whole tiles only
-        body_bytes = tail_bytes = 0;
+        body_bytes = tail_bytes = counter_bytes = 0;
     }
     const int total_kt = 9 * (Cin / pl::kBK);
+    const pl::Slicing z = pl::slicing_of(sc, M, Cin);
     p.tiles_m = sc.pl.tiles_m; p.tiles_n = sc.pl.tiles_n;
-    p.body_tiles = sc.pl.body_mtiles * sc.pl.tiles_n;
-    const int kgran = (sc.shape >= 3) ? 9 : 1;          // ring shapes: K slices of whole 16-channel chunks (9 k-tiles)
-    p.ktiles_per_split = ceil_div(ceil_div(total_kt, sc.pl.splitk), kgran) * kgran;
-    p.splitk = ceil_div(total_kt, p.ktiles_per_split);
-    p.tail_tiles = (sc.pl.tiles_m - sc.pl.body_mtiles) * sc.pl.tiles_n;
-    p.tail_ktiles = ceil_div(ceil_div(total_kt, sc.pl.tail_slices), kgran) * kgran;
-    p.tail_slices = ceil_div(total_kt, p.tail_ktiles);
-    p.tail_row0 = std::min<long long>(M, (long long)sc.pl.body_mtiles * sc.bm);
+    p.body_tiles = z.body_tiles; p.ktiles_per_split = z.ktiles_per_split; p.splitk = z.splitk;
+    p.tail_tiles = z.tail_tiles; p.tail_ktiles = z.tail_ktiles; p.tail_slices = z.tail_slices; p.tail_row0 = z.tail_row0;
     p.partial = reinterpret_cast<float *>(workspace);
     p.partial_tail = reinterpret_cast<float *>(reinterpret_cast<char *>(workspace) + body_bytes);
+    p.counters = reinterpret_cast<int *>(reinterpret_cast<char *>(workspace) + body_bytes + tail_bytes);
     const long long nblocks = (long long)p.tail_tiles * p.tail_slices + (long long)p.body_tiles * p.splitk;
     MH_REQUIRE(nblocks > 0 && nblocks < (1LL << 31));
     hipStream_t st = as_stream(stream);
@@ -1047,13 +1204,21 @@ static int plconv_impl(const void *in_image, const unsigned *in_true_maxbits, in
     constexpr size_t kTabMax = 1024 * 16;                          // the per-k-tile offset table lives in LDS (16 B per k-tile)
     MH_REQUIRE(total_kt <= 1024);
     const size_t tab_bytes = (size_t)total_kt * 16;
+    if (sc.shape >= 4 && counter_bytes) {
+        // arrival counters of the sliced tiles: zero on entry (the last block of a tile re-arms its counter, but the workspace is
+        // the caller's scratch: nothing promises it is still zero)
+        hipError_t e = hipMemsetAsync(p.counters, 0, counter_bytes, st);
+        if (e != hipSuccess) { set_last_error("hipMemsetAsync(conv arrival counters)", e); return (int)e; }
+    }
     auto ring = [&](auto tag) {
         typedef decltype(tag) R;
-        if (out_image) pl::launch<pl::conv3x3_ring_kernel<R, true>>(grid, pl::ring_conv_lds_bytes<R>(true), st, p, 0, R::threads);
-        else pl::launch<pl::conv3x3_ring_kernel<R, false>>(grid, pl::ring_conv_lds_bytes<R>(false), st, p, 0, R::threads);
+        if (pool) pl::launch<pl::conv3x3_ring_kernel<R, 2>>(grid, pl::ring_conv_lds_bytes<R>(2), st, p, 0, R::threads);
+        else if (out_image) pl::launch<pl::conv3x3_ring_kernel<R, 1>>(grid, pl::ring_conv_lds_bytes<R>(1), st, p, 0, R::threads);
+        else pl::launch<pl::conv3x3_ring_kernel<R, 0>>(grid, pl::ring_conv_lds_bytes<R>(0), st, p, 0, R::threads);
     };
-    if (sc.shape == 4) ring(pl::CR256x128());
-    else
+    if (sc.shape == 4) { ring(pl::CR256x128()); return check_launch("pl::conv3x3_ring_kernel"); }
+    if (sc.shape == 5) { ring(pl::CR256x64()); return check_launch("pl::conv3x3_ring_kernel"); }
+    if (sc.shape == 6) { ring(pl::CR256x64s3()); return check_launch("pl::conv3x3_ring_kernel"); }
     if (out_image) {
         if (sc.shape == 0) pl::launch<pl::conv3x3_kernel<pl::S256x128, true>>(grid, pl::conv_lds_bytes<pl::S256x128>() + tab_bytes, st, p, pl::conv_lds_bytes<pl::S256x128>() + kTabMax);
         else if (sc.shape == 1) pl::launch<pl::conv3x3_kernel<pl::S128x128, true>>(grid, pl::conv_lds_bytes<pl::S128x128>() + tab_bytes, st, p, pl::conv_lds_bytes<pl::S128x128>() + kTabMax);
@@ -1065,6 +1230,7 @@ static int plconv_impl(const void *in_image, const unsigned *in_true_maxbits, in
     }
     int rc = check_launch("pl::conv3x3_kernel");
     if (rc) return rc;
+    // the round-3 loop (MH_PL_RING=0 and the A/B shapes) adds its K slices up in a second launch
     const long long HW = (long long)H * W;
     auto reduce = [&](const float *part, int slices, long long rows, long long row0) {
         if (out_image) {
@@ -1089,7 +1255,7 @@ int mh_plconv3x3(const void *in_image, int B, int H, int W, int Cin, const void 
                  int epilogue, float *out, unsigned *out_maxbits, void *workspace, size_t ws_bytes, void *stream)
 {
     MH_REQUIRE(out);
-    return plconv_impl(in_image, nullptr, B, H, W, Cin, packed, Cout, bias, epilogue, out, nullptr, out_maxbits, workspace, ws_bytes, stream);
+    return plconv_impl(in_image, nullptr, B, H, W, Cin, packed, Cout, bias, epilogue, out, nullptr, 0, out_maxbits, workspace, ws_bytes, stream);
 }
 
 // the same conv whose output leaves the kernel AS the next layer's activation image (mh_act_planes_bytes(B, H, W, Cout)): no
@@ -1100,7 +1266,20 @@ int mh_plconv3x3_to_image(const void *in_image, const unsigned *in_true_maxbits,
                           size_t ws_bytes, void *stream)
 {
     MH_REQUIRE(out_image && in_true_maxbits);
-    return plconv_impl(in_image, in_true_maxbits, B, H, W, Cin, packed, Cout, bias, epilogue, nullptr, out_image, out_maxbits, workspace,
+    return plconv_impl(in_image, in_true_maxbits, B, H, W, Cin, packed, Cout, bias, epilogue, nullptr, out_image, 0, out_maxbits, workspace,
+                       ws_bytes, stream);
+}
+
+// ... and through the 2x2 / 2 max-pool that follows the layer (H, W even): out_image = the activation image of the POOLED output
+// [B, H/2, W/2, Cout] (mh_act_planes_bytes(B, H / 2, W / 2, Cout)), bit-identical to mh_plconv3x3 + mh_act_planes(pool = 1) on a
+// monotone epilogue (none / ReLU / ReLU6).  Replaces the fp32 tensor and the converter pass of conv1_2, conv2_2, conv3_3, conv4_3
+// (reference lib/object_detector.py:110-118: the MaxPool2d modules of vgg16.features).
+int mh_plconv3x3_pool_to_image(const void *in_image, const unsigned *in_true_maxbits, int B, int H, int W, int Cin, const void *packed,
+                               int Cout, const float *bias, int epilogue, void *out_image, unsigned *out_maxbits, void *workspace,
+                               size_t ws_bytes, void *stream)
+{
+    MH_REQUIRE(out_image && in_true_maxbits);
+    return plconv_impl(in_image, in_true_maxbits, B, H, W, Cin, packed, Cout, bias, epilogue, nullptr, out_image, 1, out_maxbits, workspace,
                        ws_bytes, stream);
 }
 

@@ -452,7 +452,9 @@ static Plan plan_gemm(int M, int N, int K, int want_splitk)
 {
     static const int bms[5] = {256, 128, 256, 256, 256}, bns[5] = {128, 128, 64, 256, 128};
     // fp32-equivalent FLOP/s one CU sustains with a full complement of blocks of the shape (measured: DESIGN.md 5)
-    static const double rate[5] = {365e12 / 256, 370e12 / 256, 300e12 / 256, 450e12 / 256, 430e12 / 256};
+    // (round 6, gpurun r06_c1: the fc6 input gradient 1536 x 25088 x 4096 ran at 350-357 TF/s on the 128x128 round-3 tiles this
+    // table used to pick and at 394-402 on the 256x128 ring tiles: the round-3 rates were optimistic by ~7 %)
+    static const double rate[5] = {340e12 / 256, 345e12 / 256, 300e12 / 256, 450e12 / 256, 430e12 / 256};
     static const int per_cu[5] = {2, 2, 2, 1, 2};          // resident blocks per CU the makespan model assumes
     const int ktiles = ceil_div(K, kBK);
     Plan best = {1, 128, 128, 1};

@@ -25,7 +25,7 @@ SYMBOLS = (
     'mh_gemm_ws_bytes', 'mh_gemm_auto_splitk', 'mh_gemm_f32',
     'mh_planes_bytes', 'mh_make_planes', 'mh_make_planes_both', 'mh_gemm_planes_ws_bytes', 'mh_gemm_planes_auto_splitk', 'mh_gemm_planes',
     'mh_act_planes_bytes', 'mh_act_planes', 'mh_image_maxbits', 'mh_plconv_packed_bytes', 'mh_plconv_pack_weight', 'mh_plconv3x3_ws_bytes',
-    'mh_plconv3x3', 'mh_plconv3x3_to_image', 'mh_stem_to_image', 'mh_conv_first_nchw_max', 'mh_debug_plconv_shape', 'mh_debug_plconv_splitk', 'mh_debug_plconv_flags', 'mh_decoder_nms_commit_max_bytes',
+    'mh_plconv3x3', 'mh_plconv3x3_to_image', 'mh_plconv3x3_pool_to_image', 'mh_stem_to_image', 'mh_conv_first_nchw_max', 'mh_debug_plconv_shape', 'mh_debug_plconv_splitk', 'mh_debug_plconv_flags', 'mh_decoder_nms_commit_max_bytes',
     'mh_debug_pl_shape', 'mh_debug_pl_order', 'mh_debug_pl_item', 'mh_gemm_ws_bytes_v2', 'mh_gemm_auto_splitk_v2', 'mh_gemm_f32_v2',
     'mh_gemm_small_max_counters', 'mh_gemm_small_f32', 'mh_debug_small_plan',
     'mh_conv3x3_packed_floats', 'mh_conv3x3_pack_weight', 'mh_conv3x3_ws_bytes', 'mh_conv3x3_schedule', 'mh_conv3x3_nhwc',
@@ -581,6 +581,22 @@ def plconv3x3_to_image(img, in_true_maxbits, packed, cout, bias, epilogue, out_m
                                  i32(out_maxbits), ptr(ws), c_size_t(ws.numel() if ws is not None else 0), stream())
     _check(rc, 'mh_plconv3x3_to_image')
     return ActImage(buf, img.B, img.H, img.W, cout)
+
+
+def plconv3x3_pool_to_image(img, in_true_maxbits, packed, cout, bias, epilogue, out_maxbits):
+    """the same conv through the 2x2 / 2 max-pool behind it: the ActImage of the POOLED output [B, H/2, W/2, cout], pooled in the
+    kernel's epilogue (no fp32 tensor, no converter pass); H and W even"""
+    L = lib()
+    if img.H % 2 or img.W % 2:
+        raise HipKernelError('plconv3x3_pool_to_image needs even map sizes, got %d x %d' % (img.H, img.W))
+    buf = torch.empty(L.mh_act_planes_bytes(img.B, img.H // 2, img.W // 2, cout), dtype=torch.uint8, device=img.buf.device)
+    wsb = L.mh_plconv3x3_ws_bytes(img.B, img.H, img.W, img.C, cout)
+    ws = workspace(wsb, buf.device, 'conv') if wsb else None
+    rc = L.mh_plconv3x3_pool_to_image(ctypes.c_void_p(img.buf.data_ptr()), i32(in_true_maxbits), img.B, img.H, img.W, img.C,
+                                      ctypes.c_void_p(packed.data_ptr()), cout, f32(bias), c_int(epilogue), ctypes.c_void_p(buf.data_ptr()),
+                                      i32(out_maxbits), ptr(ws), c_size_t(ws.numel() if ws is not None else 0), stream())
+    _check(rc, 'mh_plconv3x3_pool_to_image')
+    return ActImage(buf, img.B, img.H // 2, img.W // 2, cout)
 
 
 def stem_to_image(x, w, bias, epilogue, out_maxbits):

@@ -406,8 +406,10 @@ class VGG16Features(nn.Sequential):
             first = mods[0]
             direct = os.environ.get('MOTIFS_TRUNK_DIRECT', '1') != '0' and B <= 32
             # a layer that is NOT followed by a pool hands its output to the next one as a plane image straight from its
-            # epilogue (no fp32 tensor, no converter); a layer in front of a pool (and the last one) writes fp32 NHWC and the
-            # pool happens inside the converter of the next layer's input
+            # epilogue (no fp32 tensor, no converter).  A layer in front of a pool does the same THROUGH the pool since round 6
+            # (_hip.plconv3x3_pool_to_image: tile rows in pool order, the window maximum taken in the epilogue; even map sizes --
+            # MOTIFS_TRUNK_POOL=converter restores the fp32 output + pooling converter); the last layer writes fp32 NHWC
+            fused_pool = direct and os.environ.get('MOTIFS_TRUNK_POOL', 'epilogue') != 'converter'
             def pool_follows(idx):
                 return idx + 2 < len(mods) and isinstance(mods[idx + 2], MaxPool2x2)
             is_last = lambda idx: idx + 2 >= len(mods)
@@ -426,6 +428,11 @@ class VGG16Features(nn.Sequential):
                     if direct and not pool_follows(i) and not is_last(i):
                         img, y = _hip.plconv3x3_to_image(img, mb[layer], m.plane_weight(), m.out_channels, m.bias.detach(), EPI_RELU,
                                                          mb[layer + 1]), None
+                    elif (fused_pool and pool_follows(i) and i + 3 < len(mods) and img.H % 2 == 0 and img.W % 2 == 0
+                          and m.out_channels % 16 == 0):
+                        img, y = _hip.plconv3x3_pool_to_image(img, mb[layer], m.plane_weight(), m.out_channels, m.bias.detach(),
+                                                              EPI_RELU, mb[layer + 1]), None
+                        i += 1                  # the MaxPool2x2 module behind the ReLU has been applied
                     else:
                         y = _hip.plconv3x3(img, m.plane_weight(), m.out_channels, m.bias.detach(), EPI_RELU, mb[layer + 1])
                         img = None

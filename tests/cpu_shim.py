@@ -116,6 +116,10 @@ def install():
         y = plconv3x3(img, packed, cout, bias, epilogue, out_maxbits)
         return _hip.ActImage(y, y.shape[0], y.shape[1], y.shape[2], y.shape[3])
 
+    def plconv3x3_pool_to_image(img, in_true_maxbits, packed, cout, bias, epilogue, out_maxbits):
+        y = maxpool2x2_nhwc(plconv3x3(img, packed, cout, bias, epilogue, out_maxbits))
+        return _hip.ActImage(y, y.shape[0], y.shape[1], y.shape[2], y.shape[3])
+
     def stem_to_image(x, w, bias, epilogue, out_maxbits):
         y = conv_first_nchw_max(x, w, bias, epilogue, out_maxbits)
         return _hip.ActImage(y, y.shape[0], y.shape[1], y.shape[2], y.shape[3])

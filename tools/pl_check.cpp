@@ -371,7 +371,7 @@ static int conv_case(const char *name, int B, int H, int W, int Cin, int Cout, i
 typedef int (*plconv_img_fn)(const void *, const unsigned *, int, int, int, int, const void *, int, const float *, int, void *, unsigned *, void *, size_t, void *);
 typedef int (*stem_img_fn)(const float *, int, int, int, int, const float *, int, const float *, int, void *, unsigned *, void *);
 typedef int (*stem_max_fn)(const float *, int, int, int, int, const float *, int, const float *, int, float *, unsigned *, void *);
-static plconv_img_fn plconv_img;
+static plconv_img_fn plconv_img, plconv_pool;
 static stem_img_fn stem_img;
 static stem_max_fn stem_max;
 
@@ -449,7 +449,74 @@ static int chain_case(const char *name, int B, int H, int W, int C0, int C1, int
     return bad;
 }
 
-static bool g_sweep_quick = false;
+// pooled-image epilogue (round 6): the image mh_plconv3x3_pool_to_image writes must be, cell for cell, the 2x2 maximum of the image
+// mh_plconv3x3_to_image writes for the same launch shape (same K order, same per-image scale from the same bound, the split is a
+// monotone function of the value): bitwise.  True maxima and scale words must be equal too.
+static int pool_case(const char *name, int B, int H, int W, int Cin, int Cout, int splitk, unsigned seed)
+{
+    if (!plconv_pool) { printf("{\"check\": \"conv pooled image\", \"error\": \"no mh_plconv3x3_pool_to_image\"}\n"); return 1; }
+    std::mt19937 rng(seed);
+    std::normal_distribution<float> nrm(0.f, 1.f);
+    const size_t M = (size_t)B * H * W, Mo = M / 4;
+    std::vector<float> x(M * Cin), w((size_t)Cout * Cin * 9), bias(Cout);
+    for (size_t i = 0; i < x.size(); ++i) { const float v = nrm(rng) * (1.f + 3.f * ((i / ((size_t)H * W * Cin)) % 3)); x[i] = v > 0 ? v : 0.f; }
+    for (auto &v : w) v = nrm(rng) * 0.05f;
+    for (auto &v : bias) v = nrm(rng) * 0.1f;
+    std::vector<unsigned> mb(B, 0);
+    for (int b = 0; b < B; ++b)
+        for (size_t i = 0; i < (size_t)H * W * Cin; ++i) mb[b] = std::max(mb[b], fbits(x[(size_t)b * H * W * Cin + i]));
+    Dev dx(x.size() * 4), dw(w.size() * 4), db(Cout * 4), dmb(B * 4), dm1(B * 4), dm2(B * 4);
+    HIP_OK(hipMemcpy(dx.p, x.data(), x.size() * 4, hipMemcpyHostToDevice));
+    HIP_OK(hipMemcpy(dw.p, w.data(), w.size() * 4, hipMemcpyHostToDevice));
+    HIP_OK(hipMemcpy(db.p, bias.data(), Cout * 4, hipMemcpyHostToDevice));
+    HIP_OK(hipMemcpy(dmb.p, mb.data(), B * 4, hipMemcpyHostToDevice));
+    Dev img(act_bytes(B, H, W, Cin)), pk(plpacked_bytes(Cout, Cin)), i1(act_bytes(B, H, W, Cout)), i2(act_bytes(B, H / 2, W / 2, Cout));
+    int rc = act_planes(dx.f(), (const unsigned *)dmb.p, B, H, W, Cin, 0, img.p, nullptr);
+    rc |= plpack(dw.f(), Cout, Cin, 0, pk.p, nullptr);
+    int bad = 0;
+    for (int shape : {Cout <= 64 ? 5 : 4, Cout <= 64 ? 6 : -1}) {
+        set_conv_shape(shape); set_conv_splitk(splitk);
+        Dev ws3(plconv_ws(B, H, W, Cin, Cout));
+        HIP_OK(hipMemset(dm1.p, 0, B * 4)); HIP_OK(hipMemset(dm2.p, 0, B * 4));
+        HIP_OK(hipMemset(i1.p, 0xee, i1.n)); HIP_OK(hipMemset(i2.p, 0xee, i2.n));
+        int r2 = plconv_img(img.p, (const unsigned *)dmb.p, B, H, W, Cin, pk.p, Cout, db.f(), 1, i1.p, (unsigned *)dm1.p, ws3.p, ws3.n, nullptr);
+        r2 |= plconv_pool(img.p, (const unsigned *)dmb.p, B, H, W, Cin, pk.p, Cout, db.f(), 1, i2.p, (unsigned *)dm2.p, ws3.p, ws3.n, nullptr);
+        HIP_OK(hipDeviceSynchronize());
+        std::vector<unsigned char> h1(i1.n), h2(i2.n);
+        std::vector<unsigned> m1(B), m2(B);
+        HIP_OK(hipMemcpy(h1.data(), i1.p, i1.n, hipMemcpyDeviceToHost)); HIP_OK(hipMemcpy(h2.data(), i2.p, i2.n, hipMemcpyDeviceToHost));
+        HIP_OK(hipMemcpy(m1.data(), dm1.p, B * 4, hipMemcpyDeviceToHost)); HIP_OK(hipMemcpy(m2.data(), dm2.p, B * 4, hipMemcpyDeviceToHost));
+        auto half = [](const unsigned char *p) { unsigned short u; memcpy(&u, p, 2); const int e = (u >> 10) & 31, m = u & 1023; float v = e ? std::ldexp(1.f + m / 1024.f, e - 15) : std::ldexp(m / 1024.f, -14); return (u & 0x8000) ? -v : v; };
+        auto cell = [&](const std::vector<unsigned char> &im, size_t Mtot, size_t pix, int c) { return im.data() + ((size_t)(c / 16) * Mtot + pix) * 64 + 2 * (c % 16); };
+        long long wrong = 0;
+        for (int b = 0; b < B; ++b) for (int yo = 0; yo < H / 2; ++yo) for (int xo = 0; xo < W / 2; ++xo) for (int c = 0; c < Cout; ++c) {
+            double best = -1e300; const unsigned char *bp = nullptr;
+            for (int dy = 0; dy < 2; ++dy) for (int dxx = 0; dxx < 2; ++dxx) {
+                const unsigned char *q = cell(h1, M, ((size_t)b * H + 2 * yo + dy) * W + 2 * xo + dxx, c);
+                const double v = (double)half(q) + (double)half(q + 32);
+                if (v > best) { best = v; bp = q; }
+            }
+            const unsigned char *q2 = cell(h2, Mo, ((size_t)b * (H / 2) + yo) * (W / 2) + xo, c);
+            wrong += (memcmp(bp, q2, 2) != 0) || (memcmp(bp + 32, q2 + 32, 2) != 0);
+        }
+        const size_t c1 = ((size_t)(Cout / 16) * M * 64 + 255) / 256 * 256, c2 = ((size_t)(Cout / 16) * Mo * 64 + 255) / 256 * 256;
+        const int scale_diff = memcmp(h1.data() + c1, h2.data() + c2, (size_t)B * 4) != 0;
+        int mdiff = 0;
+        for (int b = 0; b < B; ++b) mdiff += m1[b] != m2[b];
+        const bool ok = (rc | r2) == 0 && wrong == 0 && !scale_diff && mdiff == 0;
+        bad += !ok;
+        printf("{\"check\": \"conv pooled image\", \"case\": \"%s\", \"B\": %d, \"H\": %d, \"W\": %d, \"Cin\": %d, \"Cout\": %d, \"shape\": %d, \"splitk\": %d, \"rc\": %d, "
+               "\"cells_wrong\": %lld, \"scales_differ\": %d, \"maxima_differ\": %d, \"ok\": %s}\n", name, B, H, W, Cin, Cout, shape, splitk, rc | r2, wrong, scale_diff, mdiff,
+               ok ? "true" : "false");
+        if (rc | r2) printf("{\"error\": \"%s\"}\n", last_err());
+        fflush(stdout);
+        if (Cout > 64) break;
+    }
+    set_conv_shape(-1); set_conv_splitk(0);
+    return bad;
+}
+
+static bool g_sweep_quick = false, g_sweep_ring_only = false;
 // shape x split-K sweep of one layer (the planner's choice is the row with splitk 0)
 static void conv_sweep(const char *name, int B, int H, int W, int Cin, int Cout, int iters)
 {
@@ -462,17 +529,22 @@ static void conv_sweep(const char *name, int B, int H, int W, int Cin, int Cout,
     Dev img(act_bytes(B, H, W, Cin)), pk(plpacked_bytes(Cout, Cin)), oimg(act_bytes(B, H, W, Cout));
     plpack(dw.f(), Cout, Cin, 0, pk.p, nullptr);
     act_planes(dx.f(), (const unsigned *)dmb.p, B, H, W, Cin, 0, img.p, nullptr);
-    for (int shape = 0; shape <= 4; ++shape) {
+    for (int shape = 0; shape <= 6; ++shape) {
         if (shape == 3 || (shape == 2 && Cout > 64)) continue;
-        if (Cout <= 64 && shape != 2) continue;
+        if (Cout <= 64 ? (shape != 2 && shape < 5) : shape > 4) continue;
+        if (g_sweep_ring_only && shape < 4 && Cout > 64) continue;
         for (int sk : {0, 1, 2, 3, 4, 6}) {
             if (g_sweep_quick && sk != 0 && sk != 1 && !(H <= 74 && (sk == 2 || sk == 3 || sk == 4))) continue;
             set_conv_shape(shape); set_conv_splitk(sk);
             Dev ws3(plconv_ws(B, H, W, Cin, Cout));
             const float ms = time_ms(iters, [&] { plconv(img.p, B, H, W, Cin, pk.p, Cout, db.f(), 1, dout.f(), (unsigned *)dmbo.p, ws3.p, ws3.n, nullptr); });
             const float msi = time_ms(iters, [&] { plconv_img(img.p, (const unsigned *)dmb.p, B, H, W, Cin, pk.p, Cout, db.f(), 1, oimg.p, (unsigned *)dmbo.p, ws3.p, ws3.n, nullptr); });
-            printf("{\"check\": \"conv sweep\", \"case\": \"%s\", \"shape\": %d, \"splitk\": %d, \"ms\": %.4f, \"tflops\": %.1f, \"ms_image_out\": %.4f, \"tflops_image_out\": %.1f}\n",
-                   name, shape, sk, ms, flops / ms * 1e-9, msi, flops / msi * 1e-9);
+            float msp = 0.f;      // output through the 2x2 pool as the next layer's image (ring shapes, even maps)
+            if (plconv_pool && shape >= 4 && H % 2 == 0 && W % 2 == 0)
+                msp = time_ms(iters, [&] { plconv_pool(img.p, (const unsigned *)dmb.p, B, H, W, Cin, pk.p, Cout, db.f(), 1, oimg.p, (unsigned *)dmbo.p, ws3.p, ws3.n, nullptr); });
+            printf("{\"check\": \"conv sweep\", \"case\": \"%s\", \"shape\": %d, \"splitk\": %d, \"ms\": %.4f, \"tflops\": %.1f, \"ms_image_out\": %.4f, \"tflops_image_out\": %.1f, "
+                   "\"ms_pooled_image_out\": %.4f, \"tflops_pooled_image_out\": %.1f}\n",
+                   name, shape, sk, ms, flops / ms * 1e-9, msi, flops / msi * 1e-9, msp, msp > 0 ? flops / msp * 1e-9 : 0.0);
             fflush(stdout);
         }
     }
@@ -588,7 +660,7 @@ int main(int argc, char **argv)
     set_conv_shape = (shape_fn)dlsym(h, "mh_debug_plconv_shape");
     set_conv_splitk = (shape_fn)dlsym(h, "mh_debug_plconv_splitk");
     set_conv_flags = (shape_fn)dlsym(h, "mh_debug_plconv_flags");
-    plconv_img = (plconv_img_fn)dlsym(h, "mh_plconv3x3_to_image"); stem_img = (stem_img_fn)dlsym(h, "mh_stem_to_image"); stem_max = (stem_max_fn)dlsym(h, "mh_conv_first_nchw_max");
+    plconv_img = (plconv_img_fn)dlsym(h, "mh_plconv3x3_to_image"); plconv_pool = (plconv_img_fn)dlsym(h, "mh_plconv3x3_pool_to_image"); stem_img = (stem_img_fn)dlsym(h, "mh_stem_to_image"); stem_max = (stem_max_fn)dlsym(h, "mh_conv_first_nchw_max");
     if (!act_bytes || !plpacked_bytes || !v2packed_floats || !plconv_ws || !v2conv_ws || !act_planes || !plpack || !plconv || !v2pack || !v2conv || !set_conv_shape || !plconv_img || !stem_img || !stem_max) { printf("missing conv symbol\n"); return 2; }
     if (argc > 2 && !strcmp(argv[2], "--conv-replay")) {
         // the 12 trunk launches of one bench step (b = 6, 592x592), each once: the target of the rocprofv3 --pmc FETCH_SIZE /
@@ -631,6 +703,27 @@ int main(int argc, char **argv)
         set_conv_flags(0);
         return 0;
     }
+    if (argc > 2 && !strcmp(argv[2], "--conv-r06")) {
+        // round 6: the ring shapes only -- 64-channel tiles (5, 6) next to the round-3 loop (2) on conv1_2, pooled image output,
+        // K slices added up inside the launch (conv5: 1 .. 6 slices), with and without the epilogue (debug flag 2)
+        g_sweep_ring_only = true;
+        for (int fl : {0, 2}) {
+            set_conv_flags(fl);
+            printf("{\"debug_flags\": %d}\n", fl);
+            g_sweep_quick = fl != 0;
+            conv_sweep("conv1_2", 6, 592, 592, 64, 64, 5);
+            conv_sweep("conv2_1", 6, 296, 296, 64, 128, 5);
+            conv_sweep("conv2_2", 6, 296, 296, 128, 128, 5);
+            conv_sweep("conv3_1", 6, 148, 148, 128, 256, 5);
+            conv_sweep("conv3_3", 6, 148, 148, 256, 256, 5);
+            conv_sweep("conv4_1", 6, 74, 74, 256, 512, 5);
+            conv_sweep("conv4_3", 6, 74, 74, 512, 512, 5);
+            g_sweep_quick = false;
+            conv_sweep("conv5_1", 6, 37, 37, 512, 512, 10);
+        }
+        set_conv_flags(0);
+        return 0;
+    }
     if (argc > 2 && !strcmp(argv[2], "--conv-sweep")) {
         g_sweep_quick = argc > 3 && !strcmp(argv[3], "--quick");
         conv_sweep("conv1_2", 6, 592, 592, 64, 64, 5);
@@ -656,6 +749,12 @@ int main(int argc, char **argv)
         badc += chain_case("stem", 3, 24, 31, 64, 64, 128, true, 43);
         badc += chain_case("conv5-like (split-K)", 6, 37, 37, 512, 512, 512, false, 44);
         badc += chain_case("conv4-like (tail slices)", 6, 74, 74, 256, 512, 256, false, 45);
+        badc += pool_case("small", 3, 20, 20, 32, 64, 0, 51);
+        badc += pool_case("ragged windows", 2, 26, 18, 64, 128, 0, 52);
+        badc += pool_case("three images per tile", 5, 6, 10, 16, 256, 0, 53);
+        badc += pool_case("conv4_3-like (tail slices)", 6, 74, 74, 256, 512, 0, 54);
+        badc += pool_case("K slices added up in the launch", 3, 36, 36, 256, 128, 3, 55);
+        badc += pool_case("conv1_2-like", 1, 120, 136, 64, 64, 0, 56);
         printf("{\"check\": \"conv summary\", \"failed\": %d}\n", badc);
         if (argc > 3 && !strcmp(argv[3], "--speed")) {
             conv_speed("conv1_2", 6, 592, 592, 64, 64, 0, 5);
