@@ -170,6 +170,10 @@ __global__ __launch_bounds__(kThreads, MH_MINW) void gemm_kernel(const GemmArgs 
         // agent-scope release-increment publishes them (the grid barrier of lstm.hip uses the same idiom across XCDs);
         // the block that draws the last ticket acquires and owns the tile.
         __shared__ int s_last;
+        // every wave drains its own partial-sum stores first: the s_barrier of __syncthreads() does not wait for the other waves'
+        // global stores (no s_waitcnt vmcnt(0) in front of it at workgroup scope), so thread 0's release could overtake them
+        // (found live in the conv kernel's copy of this idiom, gpurun r06_c2)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (tid == 0) {
             const int old = __hip_atomic_fetch_add(p.counters + t, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);

@@ -421,9 +421,12 @@ __device__ __forceinline__ void grid_barrier(unsigned *counters, int slot, unsig
     unsigned *counter = counters + slot;
     unsigned *broken = counters + kBrokenWord;    // sticky: set by the first block that times out
     target += fc.inflate;
+    // every wave drains its own global stores first: the s_barrier of __syncthreads() does not wait for the other waves' stores
+    // (round 6: the same idiom without this wait added up stale partial sums in the conv kernel, gpurun r06_c2)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (threadIdx.x == 0) {
-        // release: the block's stores (all waves: ordered before by __syncthreads) become visible at agent scope
+        // release: the block's stores (all waves: drained and ordered before by the barrier) become visible at agent scope
         __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
         bool done = false;
         for (int spin = 0; spin < (1 << 18) && !done; ++spin) {

@@ -178,6 +178,7 @@ struct ConvArgs {
     int tail_tiles, tail_slices, tail_ktiles;
     long long tail_row0;
     float *partial, *partial_tail;
+    int stagger, first_round;  // ring kernels: see "Stagger" in conv3x3_ring_kernel (0 = off)
     int *counters;             // ring kernels: arrival counters of the sliced tiles [body_tiles + tail_tiles], zero on entry, left zero
     int debug_flags;           // measurement only (mh_debug_plconv_flags): bit 1 = the ring kernel returns without its epilogue (no output):
                                // what the K loop alone costs (gpurun r04_c5)
@@ -465,6 +466,20 @@ __global__ __launch_bounds__(R::threads, (R::threads == 512 || R::sm * R::sn <= 
         kt_per_slice = p.ktiles_per_split;
         nslices = p.splitk;
     }
+    // Stagger (round 6).  Two blocks share a CU; they start together, run their K loops together (sharing the matrix pipe) and
+    // then run their epilogues together (matrix pipe idle): a round costs 2 k + e.  If one of the two starts e later, its K loop
+    // runs beside the other's epilogue and the round costs 2 k -- and the offset is inherited by the blocks that follow them
+    // (a block starts when its predecessor in the slot ends), so it has to be paid once per launch: the blocks of the FIRST
+    // round whose wave sits in an odd wave slot of its SIMD (the second block of the CU) sleep p.stagger x 8128 cycles.
+    if (p.stagger > 0 && (int)blockIdx.x < p.first_round) {
+        int *flag = reinterpret_cast<int *>(lds);
+        if (tid == 0) *flag = (int)(__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (3 << 11)) & 1u);      // HW_REG_HW_ID (4), wave_id bits [3:0]
+        __syncthreads();
+        const bool second = *flag != 0;
+        __syncthreads();
+        if (second)
+            for (int i = 0; i < p.stagger; ++i) __builtin_amdgcn_s_sleep(127);
+    }
     const long long m0 = (long long)(t / p.tiles_n) * R::bm;
     const int n0 = (t % p.tiles_n) * R::bn;
     const long long HW = (long long)p.H * p.W, Mtot = (long long)p.B * HW;
@@ -569,9 +584,13 @@ __global__ __launch_bounds__(R::threads, (R::threads == 512 || R::sm * R::sn <= 
                         make_float4(acc.v[sm][sn][4 * q], acc.v[sm][sn][4 * q + 1], acc.v[sm][sn][4 * q + 2], acc.v[sm][sn][4 * q + 3]);
         int *ticket = reinterpret_cast<int *>(lds);
         int *counter = p.counters + (is_tail ? p.body_tiles : 0) + t_local;
+        // every wave drains ITS stores before the barrier: hipcc puts no s_waitcnt vmcnt(0) in front of the s_barrier of
+        // __syncthreads() (workgroup scope, non-tgsplit), so without this the other three waves' stores are still in flight
+        // when wave 0 publishes the ticket (gpurun r06_c2: the last block added up stale partial sums)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (tid == 0) {
-            // plain stores -> barrier -> one agent-scope release -> drained -> relaxed ticket (MI355X_MICROARCH.md, valid producer form)
+            // drained stores -> barrier -> one agent-scope release -> drained -> relaxed ticket (MI355X_MICROARCH.md, valid producer form)
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             const int got = __hip_atomic_fetch_add(counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1178,7 +1197,9 @@ static int plconv_impl(const void *in_image, const unsigned *in_true_maxbits, in
     p.wt_bits = reinterpret_cast<const unsigned *>(p.wt + align_up(pl::wt_cells_bytes(Cout, Cin), 256));
     p.wnorm = reinterpret_cast<const float *>(reinterpret_cast<const char *>(p.wt_bits) + align_up((size_t)Cout * 4, 256));
     p.Cout = Cout; p.bias = bias; p.epilogue = epilogue; p.out = out; p.out_bits = out_maxbits;
-    p.debug_flags = pl::g_conv_flags;
+    p.debug_flags = pl::g_conv_flags & 0xff;
+    p.stagger = (pl::g_conv_flags >> 8) & 0xffff;      // measurement: mh_debug_plconv_flags(flags | sleeps << 8)
+    p.first_round = resident_slots();
     p.out_cells = reinterpret_cast<char *>(out_image);
     p.out_scale_bits = out_image ? reinterpret_cast<unsigned *>(p.out_cells + align_up(pl::act_cells_bytes(pool ? M / 4 : M, Cout), 256)) : nullptr;
     pl::Sched sc = pl::schedule(M, Cin, Cout);

@@ -707,7 +707,7 @@ int main(int argc, char **argv)
         // round 6: the ring shapes only -- 64-channel tiles (5, 6) next to the round-3 loop (2) on conv1_2, pooled image output,
         // K slices added up inside the launch (conv5: 1 .. 6 slices), with and without the epilogue (debug flag 2)
         g_sweep_ring_only = true;
-        for (int fl : {0, 2}) {
+        for (int fl : {0, 2, 0x200, 0x400, 0x800, 0}) {       // 0x100 x n: first-round stagger of n x 8128 cycles (see the kernel)
             set_conv_flags(fl);
             printf("{\"debug_flags\": %d}\n", fl);
             g_sweep_quick = fl != 0;
@@ -718,7 +718,7 @@ int main(int argc, char **argv)
             conv_sweep("conv3_3", 6, 148, 148, 256, 256, 5);
             conv_sweep("conv4_1", 6, 74, 74, 256, 512, 5);
             conv_sweep("conv4_3", 6, 74, 74, 512, 512, 5);
-            g_sweep_quick = false;
+            g_sweep_quick = fl != 0 && fl != 2;
             conv_sweep("conv5_1", 6, 37, 37, 512, 512, 10);
         }
         set_conv_flags(0);
