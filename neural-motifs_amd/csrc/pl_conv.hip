@@ -178,7 +178,6 @@ struct ConvArgs {
     int tail_tiles, tail_slices, tail_ktiles;
     long long tail_row0;
     float *partial, *partial_tail;
-    int stagger, first_round;  // ring kernels: see "Stagger" in conv3x3_ring_kernel (0 = off)
     int *counters;             // ring kernels: arrival counters of the sliced tiles [body_tiles + tail_tiles], zero on entry, left zero
     int debug_flags;           // measurement only (mh_debug_plconv_flags): bit 1 = the ring kernel returns without its epilogue (no output):
                                // what the K loop alone costs (gpurun r04_c5)
@@ -466,20 +465,6 @@ __global__ __launch_bounds__(R::threads, (R::threads == 512 || R::sm * R::sn <= 
         kt_per_slice = p.ktiles_per_split;
         nslices = p.splitk;
     }
-    // Stagger (round 6).  Two blocks share a CU; they start together, run their K loops together (sharing the matrix pipe) and
-    // then run their epilogues together (matrix pipe idle): a round costs 2 k + e.  If one of the two starts e later, its K loop
-    // runs beside the other's epilogue and the round costs 2 k -- and the offset is inherited by the blocks that follow them
-    // (a block starts when its predecessor in the slot ends), so it has to be paid once per launch: the blocks of the FIRST
-    // round whose wave sits in an odd wave slot of its SIMD (the second block of the CU) sleep p.stagger x 8128 cycles.
-    if (p.stagger > 0 && (int)blockIdx.x < p.first_round) {
-        int *flag = reinterpret_cast<int *>(lds);
-        if (tid == 0) *flag = (int)(__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (3 << 11)) & 1u);      // HW_REG_HW_ID (4), wave_id bits [3:0]
-        __syncthreads();
-        const bool second = *flag != 0;
-        __syncthreads();
-        if (second)
-            for (int i = 0; i < p.stagger; ++i) __builtin_amdgcn_s_sleep(127);
-    }
     const long long m0 = (long long)(t / p.tiles_n) * R::bm;
     const int n0 = (t % p.tiles_n) * R::bn;
     const long long HW = (long long)p.H * p.W, Mtot = (long long)p.B * HW;
@@ -646,7 +631,9 @@ __global__ __launch_bounds__(R::threads, (R::threads == 512 || R::sm * R::sn <= 
         bmax = __uint_as_float(mm);
     }
     auto bound_bits = [&](int b) { return __float_as_uint(__uint_as_float(p.in_true_bits[b]) * p.wnorm[0] + bmax); };
-    if (IMG && blockIdx.x == 0 && tid < p.B) p.out_scale_bits[tid] = bound_bits(tid);
+    // the scale words of the output image: written by the block that finishes tile 0 (with K slices that is the tile's LAST block,
+    // whichever it is -- block 0 may have left after its partial sums)
+    if (IMG && t == 0 && tid < p.B) p.out_scale_bits[tid] = bound_bits(tid);
     __syncthreads();
     static_assert((2 * R::bn + 16) * 4 <= kRingStageOff, "channel tables must fit in front of the staging patches");
     const int j = lane & 31, g = lane >> 5;
@@ -700,13 +687,22 @@ __global__ __launch_bounds__(R::threads, (R::threads == 512 || R::sm * R::sn <= 
         constexpr int kPitch = 80;
         char *stg = lds + kRingStageOff + wave * (2 * 32 * kPitch);
         const long long chunk0 = (n0 + wn) / kBK;
+        // Round 6: the value is formed directly at the OUTPUT image's scale -- xs = clamp(acc 2^(eo - ea - eb) + bias 2^eo), the same
+        // bits as (clamp(acc 2^-(ea + eb) + bias)) 2^eo because a power-of-two factor commutes with the rounding of the sum -- which
+        // drops the second ldexp of every element, and rows / channels outside the layer need no masks: their accumulators and
+        // bias entries are zero and their rows' factor 2^eo is replaced by 0.  The epilogue's cost is its VALU instruction count
+        // (gpurun r06_c3: 0.085 / 0.05 / 0.027 ms per 2054 tiles for this / the fp32 / the pooled epilogue at ~330 / 200 / 110
+        // instructions per accumulator).
+        const float lo = (p.epilogue == MH_EPI_NONE) ? -__builtin_inff() : 0.f, hi6 = (p.epilogue == MH_EPI_RELU6) ? 6.f : __builtin_inff();
 #pragma unroll
         for (int sm = 0; sm < R::sm; ++sm) {
             const long long row = m0 + wm + 32 * sm + j;
             const bool rok = row < Mtot;
             const int b = rok ? (int)((unsigned)row / uHW) : 0;
-            const int ea = rok ? row_exponent(p.in_bits[b]) : 0;
             const int eo = rok ? row_exponent(bound_bits(b)) : 0;
+            const int ek = eo - (rok ? row_exponent(p.in_bits[b]) : 0);
+            const float so = rok ? __builtin_ldexpf(1.f, eo) : 0.f;
+            const float hi = (p.epilogue == MH_EPI_RELU6) ? hi6 * so : hi6;
             img_of[sm] = b;
             unsigned vm = 0;
 #pragma unroll
@@ -716,20 +712,15 @@ __global__ __launch_bounds__(R::threads, (R::threads == 512 || R::sm * R::sn <= 
                     const int c = wn + 32 * sn + 8 * q + 4 * g;
                     const int4 eb = *reinterpret_cast<const int4 *>(chan_e + c);
                     const float4 bs = *reinterpret_cast<const float4 *>(chan_f + c);
-                    float v0 = conv_epi(__builtin_ldexpf(acc.v[sm][sn][4 * q + 0], -(ea + eb.x)) + bs.x, p.epilogue);
-                    float v1 = conv_epi(__builtin_ldexpf(acc.v[sm][sn][4 * q + 1], -(ea + eb.y)) + bs.y, p.epilogue);
-                    float v2 = conv_epi(__builtin_ldexpf(acc.v[sm][sn][4 * q + 2], -(ea + eb.z)) + bs.z, p.epilogue);
-                    float v3 = conv_epi(__builtin_ldexpf(acc.v[sm][sn][4 * q + 3], -(ea + eb.w)) + bs.w, p.epilogue);
-                    if (!rok) v0 = v1 = v2 = v3 = 0.f;
-                    if (n0 + c + 0 >= p.Cout) v0 = 0.f;
-                    if (n0 + c + 1 >= p.Cout) v1 = 0.f;
-                    if (n0 + c + 2 >= p.Cout) v2 = 0.f;
-                    if (n0 + c + 3 >= p.Cout) v3 = 0.f;
-                    vm = max(vm, max(max(__float_as_uint(v0) & 0x7fffffffu, __float_as_uint(v1) & 0x7fffffffu),
-                                     max(__float_as_uint(v2) & 0x7fffffffu, __float_as_uint(v3) & 0x7fffffffu)));
+                    const float x0 = __builtin_amdgcn_fmed3f(__builtin_fmaf(bs.x, so, __builtin_ldexpf(acc.v[sm][sn][4 * q + 0], ek - eb.x)), lo, hi);
+                    const float x1 = __builtin_amdgcn_fmed3f(__builtin_fmaf(bs.y, so, __builtin_ldexpf(acc.v[sm][sn][4 * q + 1], ek - eb.y)), lo, hi);
+                    const float x2 = __builtin_amdgcn_fmed3f(__builtin_fmaf(bs.z, so, __builtin_ldexpf(acc.v[sm][sn][4 * q + 2], ek - eb.z)), lo, hi);
+                    const float x3 = __builtin_amdgcn_fmed3f(__builtin_fmaf(bs.w, so, __builtin_ldexpf(acc.v[sm][sn][4 * q + 3], ek - eb.w)), lo, hi);
+                    vm = max(vm, max(max(__float_as_uint(x0) & 0x7fffffffu, __float_as_uint(x1) & 0x7fffffffu),
+                                     max(__float_as_uint(x2) & 0x7fffffffu, __float_as_uint(x3) & 0x7fffffffu)));
                     unsigned a1, a2, b1, b2;
-                    split2(v0, v1, eo, a1, a2);
-                    split2(v2, v3, eo, b1, b2);
+                    split2_scaled(x0, x1, a1, a2);
+                    split2_scaled(x2, x3, b1, b2);
                     char *cell = stg + ((q >> 1) * 32 + j) * kPitch + 16 * (q & 1) + 8 * g;
                     *reinterpret_cast<u32x2 *>(cell) = (u32x2){a1, b1};
                     *reinterpret_cast<u32x2 *>(cell + 32) = (u32x2){a2, b2};
@@ -744,7 +735,8 @@ __global__ __launch_bounds__(R::threads, (R::threads == 512 || R::sm * R::sn <= 
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
-            vmax[sm] = vm;
+            // the true maximum of the layer's output: the largest scaled value, scale taken off (exact)
+            vmax[sm] = __float_as_uint(__builtin_ldexpf(__uint_as_float(vm), -eo));
         }
     } else {
         // pooled image output (see the header): quad maxima of the raw accumulators, then lane (j, g) finishes register quad
@@ -755,13 +747,16 @@ __global__ __launch_bounds__(R::threads, (R::threads == 512 || R::sm * R::sn <= 
         char *stg = lds + kRingStageOff + wave * (2 * 8 * kPitch);
         const long long chunk0 = (n0 + wn) / kBK, Mo = Mtot >> 2;
         const int within = j & 3, pl = j >> 2;
+        const float lo = (p.epilogue == MH_EPI_NONE) ? -__builtin_inff() : 0.f, hi6 = (p.epilogue == MH_EPI_RELU6) ? 6.f : __builtin_inff();
 #pragma unroll
         for (int sm = 0; sm < R::sm; ++sm) {
             const long long row = m0 + wm + 32 * sm + j;
             const bool rok = row < Mtot;                                   // H and W are even: a window is inside or outside as a whole
             const int b = rok ? (int)((unsigned)(row >> 2) / uHoWo) : 0;
-            const int ea = rok ? row_exponent(p.in_bits[b]) : 0;
             const int eo = rok ? row_exponent(bound_bits(b)) : 0;
+            const int ek = eo - (rok ? row_exponent(p.in_bits[b]) : 0);
+            const float so = rok ? __builtin_ldexpf(1.f, eo) : 0.f;
+            const float hi = (p.epilogue == MH_EPI_RELU6) ? hi6 * so : hi6;
             img_of[sm] = b;
             unsigned vm = 0;
 #pragma unroll
@@ -776,20 +771,15 @@ __global__ __launch_bounds__(R::threads, (R::threads == 512 || R::sm * R::sn <= 
                 const int c = wn + 32 * sn + 8 * within + 4 * g;
                 const int4 eb = *reinterpret_cast<const int4 *>(chan_e + c);
                 const float4 bs = *reinterpret_cast<const float4 *>(chan_f + c);
-                float v0 = conv_epi(__builtin_ldexpf(x[0], -(ea + eb.x)) + bs.x, p.epilogue);
-                float v1 = conv_epi(__builtin_ldexpf(x[1], -(ea + eb.y)) + bs.y, p.epilogue);
-                float v2 = conv_epi(__builtin_ldexpf(x[2], -(ea + eb.z)) + bs.z, p.epilogue);
-                float v3 = conv_epi(__builtin_ldexpf(x[3], -(ea + eb.w)) + bs.w, p.epilogue);
-                if (!rok) v0 = v1 = v2 = v3 = 0.f;
-                if (n0 + c + 0 >= p.Cout) v0 = 0.f;
-                if (n0 + c + 1 >= p.Cout) v1 = 0.f;
-                if (n0 + c + 2 >= p.Cout) v2 = 0.f;
-                if (n0 + c + 3 >= p.Cout) v3 = 0.f;
-                vm = max(vm, max(max(__float_as_uint(v0) & 0x7fffffffu, __float_as_uint(v1) & 0x7fffffffu),
-                                 max(__float_as_uint(v2) & 0x7fffffffu, __float_as_uint(v3) & 0x7fffffffu)));
+                const float x0 = __builtin_amdgcn_fmed3f(__builtin_fmaf(bs.x, so, __builtin_ldexpf(x[0], ek - eb.x)), lo, hi);
+                const float x1 = __builtin_amdgcn_fmed3f(__builtin_fmaf(bs.y, so, __builtin_ldexpf(x[1], ek - eb.y)), lo, hi);
+                const float x2 = __builtin_amdgcn_fmed3f(__builtin_fmaf(bs.z, so, __builtin_ldexpf(x[2], ek - eb.z)), lo, hi);
+                const float x3 = __builtin_amdgcn_fmed3f(__builtin_fmaf(bs.w, so, __builtin_ldexpf(x[3], ek - eb.w)), lo, hi);
+                vm = max(vm, max(max(__float_as_uint(x0) & 0x7fffffffu, __float_as_uint(x1) & 0x7fffffffu),
+                                 max(__float_as_uint(x2) & 0x7fffffffu, __float_as_uint(x3) & 0x7fffffffu)));
                 unsigned a1, a2, b1, b2;
-                split2(v0, v1, eo, a1, a2);
-                split2(v2, v3, eo, b1, b2);
+                split2_scaled(x0, x1, a1, a2);
+                split2_scaled(x2, x3, b1, b2);
                 char *cell = stg + ((within >> 1) * 8 + pl) * kPitch + 16 * (within & 1) + 8 * g;
                 *reinterpret_cast<u32x2 *>(cell) = (u32x2){a1, b1};
                 *reinterpret_cast<u32x2 *>(cell + 32) = (u32x2){a2, b2};
@@ -802,7 +792,7 @@ __global__ __launch_bounds__(R::threads, (R::threads == 512 || R::sm * R::sn <= 
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
-            vmax[sm] = vm;
+            vmax[sm] = __float_as_uint(__builtin_ldexpf(__uint_as_float(vm), -eo));
         }
     }
     if (p.out_bits) {
@@ -1197,9 +1187,7 @@ static int plconv_impl(const void *in_image, const unsigned *in_true_maxbits, in
     p.wt_bits = reinterpret_cast<const unsigned *>(p.wt + align_up(pl::wt_cells_bytes(Cout, Cin), 256));
     p.wnorm = reinterpret_cast<const float *>(reinterpret_cast<const char *>(p.wt_bits) + align_up((size_t)Cout * 4, 256));
     p.Cout = Cout; p.bias = bias; p.epilogue = epilogue; p.out = out; p.out_bits = out_maxbits;
-    p.debug_flags = pl::g_conv_flags & 0xff;
-    p.stagger = (pl::g_conv_flags >> 8) & 0xffff;      // measurement: mh_debug_plconv_flags(flags | sleeps << 8)
-    p.first_round = resident_slots();
+    p.debug_flags = pl::g_conv_flags;
     p.out_cells = reinterpret_cast<char *>(out_image);
     p.out_scale_bits = out_image ? reinterpret_cast<unsigned *>(p.out_cells + align_up(pl::act_cells_bytes(pool ? M / 4 : M, Cout), 256)) : nullptr;
     pl::Sched sc = pl::schedule(M, Cin, Cout);

@@ -67,6 +67,16 @@ __device__ __forceinline__ void split2(float x0, float x1, int e, unsigned &p1, 
     p2 = __builtin_bit_cast(unsigned, __builtin_convertvector(r, f16x2));
 }
 
+// the same for a pair that is already scaled
+__device__ __forceinline__ void split2_scaled(float xs0, float xs1, unsigned &p1, unsigned &p2)
+{
+    const f32x2 xs = {xs0, xs1};
+    const f16x2 h1 = __builtin_convertvector(xs, f16x2);
+    const f32x2 r = xs - __builtin_convertvector(h1, f32x2);     // exact
+    p1 = __builtin_bit_cast(unsigned, h1);
+    p2 = __builtin_bit_cast(unsigned, __builtin_convertvector(r, f16x2));
+}
+
 struct Src {
     __amdgpu_buffer_rsrc_t rsrc;
 };
