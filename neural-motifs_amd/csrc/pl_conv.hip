@@ -954,7 +954,200 @@ __global__ __launch_bounds__(256) void stem_kernel(const float *__restrict__ in,
     if (out_bits) wave_atomic_max(out_bits, cur < 0 ? 0 : cur, cur < 0 ? 0u : vmax);
 }
 
-// (Round 5 built a second form of this kernel -- weights as SGPR operands from a packed table read with s_load_dwordx16, inputs
+// Round 6: the same layer on the matrix cores.  The VALU kernel above spends 0.40-0.43 ms on 1.2 GFLOP per image -- 1728 FMAs per
+// pixel behind one LDS weight read per four of them -- against a 0.11 ms write floor.  As a product it is [pixels] x [27 -> 32] x
+// [64]: two 16-k tiles, 24 MFMAs per wave and 256-pixel tile.  A block builds the im2col rows of its tile IN LDS (thread = pixel:
+// 27 cached loads, scaled by the image's exponent and split into the two f16 planes: ~200 VALU instructions instead of 1728), the
+// weights' plane tile is built once per block, the accumulators come out transposed (rmma's operand order) and leave through the
+// image epilogue of the ring conv kernel (value formed at the output scale, cells assembled in a wave-private LDS patch, 1 KiB
+// stores).  fp32 evaluation as everywhere (f16x3); scale words and true maxima as the VALU kernel writes them.
+struct StemArgs {
+    const float *in;            // [B][Cin][H][W]
+    int B, Cin, H, W;
+    const float *w;             // [64][Cin][3][3]
+    const float *bias;
+    int epilogue;
+    const unsigned *in_bits;    // [B] largest |pixel| per image
+    char *out_cells;            // [4][B*H*W][64]
+    unsigned *scale_bits, *out_bits;
+};
+constexpr int kStemA = 2 * 256 * kCell, kStemB = 2 * 64 * kCell, kStemPatch = 2 * 32 * 80;
+constexpr int kStemLds = kStemA + kStemB + 1024 + 4 * kStemPatch;       // A tile | B tile | bias[64], eb[64], reduction words | patches
+
+__global__ __launch_bounds__(256, 2) void stem_mfma_kernel(const StemArgs p)
+{
+    extern __shared__ __attribute__((aligned(1024))) char lds[];
+    char *At = lds, *Bt = lds + kStemA;
+    float *bias_l = reinterpret_cast<float *>(lds + kStemA + kStemB);
+    int *eb_l = reinterpret_cast<int *>(bias_l) + 64;
+    float *red = bias_l + 128;                                            // [0..63] sum |w_n|, [64..127] |bias_n|
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int K = 9 * p.Cin;                                              // <= 27 (host-checked), padded to 32
+    // ---- weights: thread (n = tid & 63, part = tid >> 6) writes 16-byte chunk `part` (plane part >> 1, k half part & 1) of both k-chunks
+    {
+        const int n = tid & 63, part = tid >> 6;
+        const float *wr = p.w + (size_t)n * K;                            // w[n][ci][tap]: k = ci * 9 + tap is the row's memory order
+        float wv[32];
+        unsigned m = 0;
+        float sum = 0.f;
+#pragma unroll
+        for (int k = 0; k < 32; ++k) {
+            wv[k] = k < K ? wr[k] : 0.f;
+            m = max(m, __float_as_uint(wv[k]) & 0x7fffffffu);
+            sum += fabsf(wv[k]);
+        }
+        const int e = row_exponent(m);
+        if (part == 0) {
+            eb_l[n] = e;
+            bias_l[n] = p.bias ? p.bias[n] : 0.f;
+            red[n] = sum;
+            red[64 + n] = p.bias ? fabsf(p.bias[n]) : 0.f;
+        }
+#pragma unroll
+        for (int kc = 0; kc < 2; ++kc) {
+            unsigned d[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int k = 16 * kc + 8 * (part & 1) + 2 * i;
+                unsigned h1, h2;
+                split2(wv[k], wv[k + 1], e, h1, h2);
+                d[i] = (part >> 1) ? h2 : h1;
+            }
+            *reinterpret_cast<u32x4 *>(Bt + kc * (64 * kCell) + lds_chunk(n, part)) = (u32x4){d[0], d[1], d[2], d[3]};
+        }
+    }
+    __syncthreads();
+    float wnorm = 0.f, bmax = 0.f;
+    for (int n = 0; n < 64; ++n) { wnorm = fmaxf(wnorm, red[n]); bmax = fmaxf(bmax, red[64 + n]); }
+    wnorm *= 1.0001f;                                                     // a hair above the rounded sum (as weight_norm_kernel)
+    auto bound_bits = [&](int b) { return __float_as_uint(__uint_as_float(p.in_bits[b]) * wnorm + bmax); };
+    if (blockIdx.x == 0 && tid < p.B) p.scale_bits[tid] = bound_bits(tid);
+    const unsigned uW = (unsigned)p.W, uHW = (unsigned)(p.H * p.W);
+    const long long M = (long long)p.B * p.H * p.W;
+    const long long ntiles = (M + 255) / 256;
+    const int j = lane & 31, g = lane >> 5;
+    const int wm0 = wave * 64;
+    unsigned fa[2], fb[2];                                                // fragment offsets [plane], as rplan_frags
+#pragma unroll
+    for (int pl_ = 0; pl_ < 2; ++pl_) { fa[pl_] = lds_chunk(wm0 + j, 2 * pl_ + g); fb[pl_] = lds_chunk(j, 2 * pl_ + g); }
+    char *stg = lds + kStemA + kStemB + 1024 + wave * kStemPatch;
+    const float lo = (p.epilogue == MH_EPI_NONE) ? -__builtin_inff() : 0.f, hi6 = (p.epilogue == MH_EPI_RELU6) ? 6.f : __builtin_inff();
+    int cur = -1;
+    unsigned vmax = 0;                                                    // running true maximum of image `cur` (this lane)
+    for (long long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const long long m0 = tile * 256;
+        // ---- im2col row of pixel m0 + tid, scaled by its image's exponent, split into the two planes
+        {
+            const long long m = m0 + tid;
+            const bool ok = m < M;
+            const unsigned b = ok ? (unsigned)m / uHW : 0, rem = ok ? (unsigned)m - b * uHW : 0, y = rem / uW, x = rem - y * uW;
+            const int ea = row_exponent(p.in_bits[b]);
+            const float *img = p.in + (size_t)b * p.Cin * uHW;
+            unsigned h1p[16], h2p[16];
+#pragma unroll
+            for (int kp = 0; kp < 16; ++kp) {
+                float v[2];
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int k = 2 * kp + u;
+                    const int ci = k / 9, tap = k - 9 * ci, dy = tap / 3 - 1, dx = tap - 3 * (tap / 3) - 1;
+                    const int yy = (int)y + dy, xx = (int)x + dx;
+                    v[u] = (ok && k < K && (unsigned)yy < (unsigned)p.H && (unsigned)xx < uW) ? img[(size_t)ci * uHW + (unsigned)yy * uW + (unsigned)xx] : 0.f;
+                }
+                split2(v[0], v[1], ea, h1p[kp], h2p[kp]);
+            }
+#pragma unroll
+            for (int kc = 0; kc < 2; ++kc)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const unsigned *src = (c >> 1) ? h2p : h1p;
+                    const int q0 = 8 * kc + 4 * (c & 1);
+                    *reinterpret_cast<u32x4 *>(At + kc * (256 * kCell) + lds_chunk(tid, c)) = (u32x4){src[q0], src[q0 + 1], src[q0 + 2], src[q0 + 3]};
+                }
+        }
+        __syncthreads();
+        // ---- 2 k-tiles x 3 terms x (2 x 2) accumulators, operand roles swapped as in rmma (transposed accumulators)
+        f32x16 acc[2][2];
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[a][c][r] = 0.f;
+#pragma unroll
+        for (int kc = 0; kc < 2; ++kc) {
+            f16x8 a[2][2], bq[2][2];
+#pragma unroll
+            for (int sm = 0; sm < 2; ++sm)
+#pragma unroll
+                for (int pl_ = 0; pl_ < 2; ++pl_) a[sm][pl_] = *reinterpret_cast<const f16x8 *>(At + kc * (256 * kCell) + fa[pl_] + 2048 * sm);
+#pragma unroll
+            for (int sn = 0; sn < 2; ++sn)
+#pragma unroll
+                for (int pl_ = 0; pl_ < 2; ++pl_) bq[sn][pl_] = *reinterpret_cast<const f16x8 *>(Bt + kc * (64 * kCell) + fb[pl_] + 2048 * sn);
+            constexpr int kTermA[3] = {1, 0, 0}, kTermB[3] = {0, 1, 0};
+#pragma unroll
+            for (int t = 0; t < 3; ++t)
+#pragma unroll
+                for (int sm = 0; sm < 2; ++sm)
+#pragma unroll
+                    for (int sn = 0; sn < 2; ++sn)
+                        acc[sm][sn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bq[sn][kTermB[t]], a[sm][kTermA[t]], acc[sm][sn], 0, 0, 0);
+        }
+        __syncthreads();                                                  // the A tile is free for the next tile's rows
+        // ---- image epilogue (conv3x3_ring_kernel, MODE 1): lane (j, g), registers 4 q .. 4 q + 3 = channels 32 sn + 8 q + 4 g + (0..3)
+        // of pixel wm0 + 32 sm + j
+#pragma unroll
+        for (int sm = 0; sm < 2; ++sm) {
+            const long long row = m0 + wm0 + 32 * sm + j;
+            const bool rok = row < M;
+            const int b = rok ? (int)((unsigned)row / uHW) : 0;
+            const int eo = rok ? row_exponent(bound_bits(b)) : 0;
+            const int ek = eo - (rok ? row_exponent(p.in_bits[b]) : 0);
+            const float so = rok ? __builtin_ldexpf(1.f, eo) : 0.f;
+            const float hi = (p.epilogue == MH_EPI_RELU6) ? hi6 * so : hi6;
+            if (rok && b != cur) {
+                if (cur >= 0 && vmax && p.out_bits && may_raise(p.out_bits + cur, vmax)) atomicMax(p.out_bits + cur, vmax);
+                cur = b;
+                vmax = 0;
+            }
+            unsigned vm = 0;
+#pragma unroll
+            for (int sn = 0; sn < 2; ++sn) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int c = 32 * sn + 8 * q + 4 * g;
+                    const int4 eb = *reinterpret_cast<const int4 *>(eb_l + c);
+                    const float4 bs = *reinterpret_cast<const float4 *>(bias_l + c);
+                    const float x0 = __builtin_amdgcn_fmed3f(__builtin_fmaf(bs.x, so, __builtin_ldexpf(acc[sm][sn][4 * q + 0], ek - eb.x)), lo, hi);
+                    const float x1 = __builtin_amdgcn_fmed3f(__builtin_fmaf(bs.y, so, __builtin_ldexpf(acc[sm][sn][4 * q + 1], ek - eb.y)), lo, hi);
+                    const float x2 = __builtin_amdgcn_fmed3f(__builtin_fmaf(bs.z, so, __builtin_ldexpf(acc[sm][sn][4 * q + 2], ek - eb.z)), lo, hi);
+                    const float x3 = __builtin_amdgcn_fmed3f(__builtin_fmaf(bs.w, so, __builtin_ldexpf(acc[sm][sn][4 * q + 3], ek - eb.w)), lo, hi);
+                    vm = max(vm, max(max(__float_as_uint(x0) & 0x7fffffffu, __float_as_uint(x1) & 0x7fffffffu),
+                                     max(__float_as_uint(x2) & 0x7fffffffu, __float_as_uint(x3) & 0x7fffffffu)));
+                    unsigned a1, a2, b1, b2;
+                    split2_scaled(x0, x1, a1, a2);
+                    split2_scaled(x2, x3, b1, b2);
+                    char *cell = stg + ((q >> 1) * 32 + j) * 80 + 16 * (q & 1) + 8 * g;
+                    *reinterpret_cast<u32x2 *>(cell) = (u32x2){a1, b1};
+                    *reinterpret_cast<u32x2 *>(cell + 32) = (u32x2){a2, b2};
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int cc = i >> 1, rr = 16 * (i & 1) + (lane >> 2), c16 = lane & 3;
+                    const long long orow = m0 + wm0 + 32 * sm + rr;
+                    const u32x4 cellv = *reinterpret_cast<const u32x4 *>(stg + (cc * 32 + rr) * 80 + 16 * c16);
+                    if (orow < M) *reinterpret_cast<u32x4 *>(p.out_cells + ((size_t)(2 * sn + cc) * M + orow) * kCell + 16 * c16) = cellv;
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (rok) vmax = max(vmax, __float_as_uint(__builtin_ldexpf(__uint_as_float(vm), -eo)));
+        }
+    }
+    if (p.out_bits) wave_atomic_max(p.out_bits, cur, cur < 0 ? 0u : vmax);      // (a lane that never saw a pixel carries no value: its key is not used)
+}
+
+// (Round 5 built a second form of the VALU kernel -- weights as SGPR operands from a packed table read with s_load_dwordx16, inputs
 // in a per-thread LDS column, v_pk_fma_f32 with an SGPR pair, no LDS weight reads: bit-identical output -- and measured it in the
 // step against this one on the same boxes: 0.51 / 0.54 ms (two / one pixel per thread) against 0.42-0.43 ms.  Removed;
 // profiles/r05_bench_c5_*.json, r05_bench_c6_*.json.)
@@ -1312,6 +1505,16 @@ int mh_stem_to_image(const float *in_nchw, int B, int Cin, int H, int W, const f
     hipLaunchKernelGGL(pl::image_absmax_kernel, dim3(64, (unsigned)B), dim3(256), 0, st, in_nchw, (long long)Cin * H * W, in_bits);
     int rc = check_launch("pl::image_absmax_kernel");
     if (rc) return rc;
+    // 64 output channels from <= 3 input channels (VGG's conv1_1): the matrix-core form (round 6); MH_STEM=valu keeps the VALU kernel (A/B)
+    static const bool valu_only = [] { const char *e = getenv("MH_STEM"); return e && e[0] == 'v'; }();
+    if (Cout == 64 && Cin <= 3 && M < (1LL << 31) && !valu_only) {
+        pl::StemArgs p;
+        p.in = in_nchw; p.B = B; p.Cin = Cin; p.H = H; p.W = W; p.w = w; p.bias = bias; p.epilogue = epilogue; p.in_bits = in_bits;
+        p.out_cells = cells; p.scale_bits = scale; p.out_bits = out_maxbits;
+        const long long ntiles = (M + 255) / 256;
+        pl::launch<pl::stem_mfma_kernel>(dim3((unsigned)std::min<long long>(ntiles, 256 * 2 * 4)), (size_t)pl::kStemLds, st, p);
+        return check_launch("pl::stem_mfma_kernel");
+    }
     const long long nblk = ((M + 255) / 256) * (Cout / pl::kBK);
     hipLaunchKernelGGL(pl::stem_kernel, dim3((unsigned)std::min<long long>(nblk, 256 * 16)), dim3(256), lds, st, in_nchw, B, Cin, H, W, w, Cout,
                        bias, epilogue, in_bits, cells, scale, out_maxbits);

@@ -413,6 +413,58 @@ def test_conv3x3_over_many_small_maps_on_the_ring_engine(hip, B, H, W, Cin, Cout
         assert float((xs.grad - gx).abs().max()) == 0.0                # the node's input gradient IS the flip-transposed conv above
 
 
+def _decode_act_image(img):
+    """ActImage (csrc/pl_conv.hip: cells [C/16][B*H*W][h1[16] | h2[16]] f16, per-image scale words behind them) -> float64
+    [B,H,W,C]: value = (h1 + h2) 2^-e, exact"""
+    B, H, W, C = img.B, img.H, img.W, img.C
+    M, G = B * H * W, C // 16
+    raw = img.buf.cpu().numpy()
+    cells = raw[:G * M * 64].view(np.float16).reshape(G, M, 2, 16).astype(np.float64)
+    off = (G * M * 64 + 255) // 256 * 256
+    bits = raw[off:off + 4 * B].view(np.uint32)
+    biased = (bits >> 23) & 0xff
+    e = np.where((biased == 0) | (biased == 255), 0, 14 - (biased.astype(np.int64) - 127))
+    val = (cells[:, :, 0, :] + cells[:, :, 1, :]).transpose(1, 0, 2).reshape(B, H * W, C)
+    return torch.from_numpy(val * (2.0 ** -e.astype(np.float64))[:, None, None]).reshape(B, H, W, C)
+
+
+@pytest.mark.parametrize('B,H,W,Cin,Cout', [(3, 20, 20, 32, 64), (2, 26, 18, 64, 128), (5, 6, 10, 16, 256), (1, 120, 136, 64, 64),
+                                            (3, 36, 36, 256, 128), (6, 74, 74, 256, 512)])
+def test_conv3x3_pooled_image_epilogue(hip, B, H, W, Cin, Cout):
+    """mh_plconv3x3_pool_to_image (round 6: tile rows in pool order, the 2x2 window maximum taken in the epilogue, the POOLED
+    output written as the next layer's activation image; K slices added up inside the launch where the planner cuts) against
+    (a) float64 conv + ReLU + max-pool, (b) mh_plconv3x3 + torch max-pool (same arithmetic: fp32 rounding apart), (c) the max-pool
+    of the image mh_plconv3x3_to_image writes -- cell for cell when every tile of the launch is sliced alike; true maxima reported
+    for the next layer equal the un-pooled layer's.  Covers 64-channel tiles (conv1_2's ring shape), windows that wrap image rows
+    inside a tile, several images per tile, the conv4_3 shape with its sliced tail tiles."""
+    g = torch.Generator().manual_seed(B * H + Cout)
+    x = torch.relu(torch.randn(B, H, W, Cin, generator=g)) * torch.tensor([1.0, 5.0, 0.2, 9.0, 1.0, 3.0])[:B].view(B, 1, 1, 1)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) * (2.0 / (9 * Cin)) ** 0.5
+    bias = torch.randn(Cout, generator=g) * 0.1
+    xd, wd, bd = x.cuda(), w.cuda(), bias.cuda()
+    mb_in = hip.image_maxbits(xd)
+    img = hip.act_planes(xd, mb_in)
+    pk = hip.plconv_pack_weight(wd, False)
+    mb0, mb1, mb2 = (torch.zeros(B, dtype=torch.int32, device='cuda') for _ in range(3))
+    y = hip.plconv3x3(img, pk, Cout, bd, 1, mb0)
+    im1 = hip.plconv3x3_to_image(img, mb_in, pk, Cout, bd, 1, mb1)
+    im2 = hip.plconv3x3_pool_to_image(img, mb_in, pk, Cout, bd, 1, mb2)
+    assert (im2.B, im2.H, im2.W, im2.C) == (B, H // 2, W // 2, Cout)
+    pooled = _decode_act_image(im2)
+    ref = F.max_pool2d(torch.relu(F.conv2d(x.permute(0, 3, 1, 2).double(), w.double(), bias.double(), padding=1)), 2, 2).permute(0, 2, 3, 1)
+    scale = ref.abs().amax(dim=(1, 2, 3), keepdim=True).clamp(min=1e-30)
+    err = ((pooled - ref).abs() / scale)
+    assert float(err.max()) < 4e-5 and float((err ** 2).mean().sqrt()) < 3e-6, (float(err.max()), float((err ** 2).mean().sqrt()))
+    y_pool = F.max_pool2d(y.permute(0, 3, 1, 2), 2, 2).permute(0, 2, 3, 1).cpu().double()
+    assert float(((pooled - y_pool).abs() / scale).max()) < 4e-5
+    assert torch.equal(mb1.cpu(), mb2.cpu()) and torch.equal(mb0.cpu(), mb2.cpu())          # true per-image maxima (fp32 bits)
+    pool_of_image = F.max_pool2d(_decode_act_image(im1).permute(0, 3, 1, 2), 2, 2).permute(0, 2, 3, 1)
+    if B * H * W * (Cout // 64) < 256 * 512 * 2:       # fewer tiles than one round of resident blocks: every tile is sliced alike
+        assert torch.equal(pooled, pool_of_image)
+    else:                                              # tail tiles are sliced, body tiles are not; the two orders put other pixels there
+        assert float(((pooled - pool_of_image).abs() / scale).max()) < 2e-6
+
+
 @pytest.mark.parametrize('B,H,W,Cin,Cout', [(2, 9, 11, 16, 32), (3, 7, 7, 256, 512), (1, 37, 37, 64, 128),
                                             (2, 14, 14, 64, 64), (1, 20, 23, 128, 120), (5, 6, 5, 32, 8)])
 def test_conv3x3_weight_gradient_implicit_gemm(hip, B, H, W, Cin, Cout):

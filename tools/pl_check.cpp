@@ -487,6 +487,7 @@ static int pool_case(const char *name, int B, int H, int W, int Cin, int Cout, i
         HIP_OK(hipMemcpy(h1.data(), i1.p, i1.n, hipMemcpyDeviceToHost)); HIP_OK(hipMemcpy(h2.data(), i2.p, i2.n, hipMemcpyDeviceToHost));
         HIP_OK(hipMemcpy(m1.data(), dm1.p, B * 4, hipMemcpyDeviceToHost)); HIP_OK(hipMemcpy(m2.data(), dm2.p, B * 4, hipMemcpyDeviceToHost));
         auto half = [](const unsigned char *p) { unsigned short u; memcpy(&u, p, 2); const int e = (u >> 10) & 31, m = u & 1023; float v = e ? std::ldexp(1.f + m / 1024.f, e - 15) : std::ldexp(m / 1024.f, -14); return (u & 0x8000) ? -v : v; };
+        const bool tails = splitk == 0 && (long long)((M + 255) / 256) * ((Cout + (Cout <= 64 ? 63 : 127)) / (Cout <= 64 ? 64 : 128)) > 512;
         auto cell = [&](const std::vector<unsigned char> &im, size_t Mtot, size_t pix, int c) { return im.data() + ((size_t)(c / 16) * Mtot + pix) * 64 + 2 * (c % 16); };
         long long wrong = 0;
         for (int b = 0; b < B; ++b) for (int yo = 0; yo < H / 2; ++yo) for (int xo = 0; xo < W / 2; ++xo) for (int c = 0; c < Cout; ++c) {
@@ -497,7 +498,11 @@ static int pool_case(const char *name, int B, int H, int W, int Cin, int Cout, i
                 if (v > best) { best = v; bp = q; }
             }
             const unsigned char *q2 = cell(h2, Mo, ((size_t)b * (H / 2) + yo) * (W / 2) + xo, c);
-            wrong += (memcmp(bp, q2, 2) != 0) || (memcmp(bp + 32, q2 + 32, 2) != 0);
+            const bool differ = (memcmp(bp, q2, 2) != 0) || (memcmp(bp + 32, q2 + 32, 2) != 0);
+            // a launch with sliced TAIL tiles: the two row orders put different pixels into the tail, whose sums are added up in
+            // another order -- those cells may differ in the last bits of the two-term value (<= 2^-20 of the scaled range)
+            if (differ && tails) { const double v2 = (double)half(q2) + (double)half(q2 + 32); wrong += std::fabs(v2 - best) > 32768.0 * 1e-6; }
+            else wrong += differ;
         }
         const size_t c1 = ((size_t)(Cout / 16) * M * 64 + 255) / 256 * 256, c2 = ((size_t)(Cout / 16) * Mo * 64 + 255) / 256 * 256;
         const int scale_diff = memcmp(h1.data() + c1, h2.data() + c2, (size_t)B * 4) != 0;
