@@ -157,6 +157,8 @@ def install_meters(_hip):
         plconv=KernelMeter(_hip, 'plconv3x3', _plconv_flops, tag_of=lambda a, k: 'maps' if a[0].B >= 64 else 'trunk'),
         conv=KernelMeter(_hip, 'conv3x3_nhwc', _conv_flops),
         plconv_img=KernelMeter(_hip, 'plconv3x3_to_image', lambda a, k, y: 2.0 * a[0].B * a[0].H * a[0].W * a[0].C * a[3] * 9),
+        # round 6: the layers in front of a pool write the POOLED image from their epilogue (same algorithmic flops: the full-resolution conv)
+        plconv_pool=KernelMeter(_hip, 'plconv3x3_pool_to_image', lambda a, k, y: 2.0 * a[0].B * a[0].H * a[0].W * a[0].C * a[3] * 9),
         stem=KernelMeter(_hip, 'stem_to_image', lambda a, k, y: (0.0, 4.0 * a[0].numel() + float(y.buf.numel()))),
         gemm_planes=KernelMeter(_hip, 'gemm_planes', _gemm_planes_flops), gemm=KernelMeter(_hip, 'gemm', _gemm_flops),
         gemm_inloop=KernelMeter(_hip, 'gemm_inloop', _gemm_flops),
@@ -548,7 +550,7 @@ def secondary(args, rank, world, dev):
         _hip.check_faults()
         split = _hip.lib().mh_mfma_split()
         peak = PEAK_BF16_MFMA_TFLOPS / split if split else PEAK_FP32_MFMA_TFLOPS
-        c = merge(meters['plconv'].summary(), meters['plconv_img'].summary(), meters['conv'].summary())
+        c = merge(meters['plconv'].summary(), meters['plconv_img'].summary(), meters['plconv_pool'].summary(), meters['conv'].summary())
         g = merge(meters['gemm_planes'].summary(), meters['gemm'].summary(), meters['gemm_inloop'].summary())
         dom, dom_name = (g, 'gemm_kernel (relation-head / RoI-head / 1x1-conv GEMMs)') if g['total_ms'] >= c['total_ms'] else \
             (c, 'conv3x3_nhwc_kernel (implicit GEMM)')
@@ -863,7 +865,7 @@ def main():
     diag = D.scaling_diagnostics(reducer, dev, 1e3 * dt_local / args.steps)
     if rank == 0:
         # the plane conv's calls: the trunk's (<= 6 images) and the 3x3 convs over many small RoI maps (hip_ops.conv3x3_small_maps)
-        plc, c2 = merge(meters['plconv'].summary('trunk'), meters['plconv_img'].summary()), meters['conv'].summary()
+        plc, c2 = merge(meters['plconv'].summary('trunk'), meters['plconv_img'].summary(), meters['plconv_pool'].summary()), meters['conv'].summary()
         cmaps = meters['plconv'].summary('maps')
         conv = merge(plc, cmaps, c2)
         gpl, gg, gi = meters['gemm_planes'].summary(), meters['gemm'].summary(), meters['gemm_inloop'].summary()
@@ -902,8 +904,9 @@ def main():
             'config': {'workload': 'SGCls MotifNet VGG16 train step (fwd+bwd+clip+SGD), order=leftright, nl_obj=2, '
                                    'nl_edge=%d, hidden 512, batch 6/GPU, 20 GT boxes/img, <=256 rel rows/img, 592x592' % model_kw['nl_edge'],
                        'global_batch': world * BATCH, 'parallelism': 'dp%d' % world, 'final_loss': float(loss.item())},
-            'roofline': {'bound': 'mfma', 'kernel': 'pl::conv3x3_ring_kernel (implicit GEMM on pre-split plane images, LDS-DMA ring K loop: 11 VGG trunk layers '
-                                                    '+ the union tower\'s conv over 1536 7x7 maps, fwd / dgrad; conv1_2 on pl::conv3x3_kernel); ' + how,
+            'roofline': {'bound': 'mfma', 'kernel': 'pl::conv3x3_ring_kernel (implicit GEMM on pre-split plane images, LDS-DMA ring K loop: the 12 VGG trunk layers '
+                                                    'conv1_2 .. conv5_3 -- image / pooled-image / fp32 epilogues, K slices added up in the launch -- '
+                                                    '+ the union tower\'s conv over 1536 7x7 maps, fwd / dgrad); ' + how,
                          'achieved': conv['tflops'], 'peak': peak, 'unit': 'TFLOP/s',
                          'frac': conv['tflops'] / peak, 'traffic': traffic['bytes_per_launch'] if traffic else None,
                          'traffic_unit': 'bytes per launch (L2 fabric side: HBM + Infinity-Cache)',

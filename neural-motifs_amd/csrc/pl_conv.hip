@@ -972,7 +972,8 @@ struct StemArgs {
     unsigned *scale_bits, *out_bits;
 };
 constexpr int kStemA = 2 * 256 * kCell, kStemB = 2 * 64 * kCell, kStemPatch = 2 * 32 * 80;
-constexpr int kStemLds = kStemA + kStemB + 1024 + 4 * kStemPatch;       // A tile | B tile | bias[64], eb[64], reduction words | patches
+constexpr int kStemTab = 1280;      // bias[64] | eb[64] | reduction words [128] | per-image input / output exponents [32 + 32]
+constexpr int kStemLds = kStemA + kStemB + kStemTab + 4 * kStemPatch;       // A tile | B tile | bias[64], eb[64], reduction words, per-image exponents | patches
 
 __global__ __launch_bounds__(256, 2) void stem_mfma_kernel(const StemArgs p)
 {
@@ -1025,37 +1026,49 @@ __global__ __launch_bounds__(256, 2) void stem_mfma_kernel(const StemArgs p)
     const unsigned uW = (unsigned)p.W, uHW = (unsigned)(p.H * p.W);
     const long long M = (long long)p.B * p.H * p.W;
     const long long ntiles = (M + 255) / 256;
+    // per-image exponents in LDS (B <= 32): input scale, output scale -- looked up per row below instead of a dependent global load
+    int *ea_l = reinterpret_cast<int *>(red) + 128, *eo_l = ea_l + 32;
+    if (tid < 32) {
+        const bool in = tid < p.B;
+        ea_l[tid] = in ? row_exponent(p.in_bits[tid]) : 0;
+        eo_l[tid] = in ? row_exponent(bound_bits(tid)) : 0;
+    }
+    __syncthreads();
     const int j = lane & 31, g = lane >> 5;
     const int wm0 = wave * 64;
     unsigned fa[2], fb[2];                                                // fragment offsets [plane], as rplan_frags
 #pragma unroll
     for (int pl_ = 0; pl_ < 2; ++pl_) { fa[pl_] = lds_chunk(wm0 + j, 2 * pl_ + g); fb[pl_] = lds_chunk(j, 2 * pl_ + g); }
-    char *stg = lds + kStemA + kStemB + 1024 + wave * kStemPatch;
+    char *stg = lds + kStemA + kStemB + kStemTab + wave * kStemPatch;
     const float lo = (p.epilogue == MH_EPI_NONE) ? -__builtin_inff() : 0.f, hi6 = (p.epilogue == MH_EPI_RELU6) ? 6.f : __builtin_inff();
     int cur = -1;
     unsigned vmax = 0;                                                    // running true maximum of image `cur` (this lane)
+    // the 27 (padded: 32) taps of pixel m0 + tid, raw: loaded one tile AHEAD (the loads of tile t + 1 fly under the MFMAs and the
+    // epilogue of tile t; the first version waited for them at the top of every tile: 21 us per tile and block, gpurun r06_c6)
+    float raw[32];
+    int raw_b = 0;
+    auto fetch = [&](long long tile) {
+        const long long m = tile * 256 + tid;
+        const bool ok = tile < ntiles && m < M;
+        const unsigned b = ok ? (unsigned)m / uHW : 0, rem = ok ? (unsigned)m - b * uHW : 0, y = rem / uW, x = rem - y * uW;
+        const float *img = p.in + (size_t)b * p.Cin * uHW;
+        raw_b = (int)b;
+#pragma unroll
+        for (int k = 0; k < 32; ++k) {
+            const int ci = k / 9, tap = k - 9 * ci, dy = tap / 3 - 1, dx = tap - 3 * (tap / 3) - 1;
+            const int yy = (int)y + dy, xx = (int)x + dx;
+            raw[k] = (ok && k < K && (unsigned)yy < (unsigned)p.H && (unsigned)xx < uW) ? img[(size_t)ci * uHW + (unsigned)yy * uW + (unsigned)xx] : 0.f;
+        }
+    };
+    fetch(blockIdx.x);
     for (long long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const long long m0 = tile * 256;
         // ---- im2col row of pixel m0 + tid, scaled by its image's exponent, split into the two planes
         {
-            const long long m = m0 + tid;
-            const bool ok = m < M;
-            const unsigned b = ok ? (unsigned)m / uHW : 0, rem = ok ? (unsigned)m - b * uHW : 0, y = rem / uW, x = rem - y * uW;
-            const int ea = row_exponent(p.in_bits[b]);
-            const float *img = p.in + (size_t)b * p.Cin * uHW;
+            const int ea = ea_l[raw_b];
             unsigned h1p[16], h2p[16];
 #pragma unroll
-            for (int kp = 0; kp < 16; ++kp) {
-                float v[2];
-#pragma unroll
-                for (int u = 0; u < 2; ++u) {
-                    const int k = 2 * kp + u;
-                    const int ci = k / 9, tap = k - 9 * ci, dy = tap / 3 - 1, dx = tap - 3 * (tap / 3) - 1;
-                    const int yy = (int)y + dy, xx = (int)x + dx;
-                    v[u] = (ok && k < K && (unsigned)yy < (unsigned)p.H && (unsigned)xx < uW) ? img[(size_t)ci * uHW + (unsigned)yy * uW + (unsigned)xx] : 0.f;
-                }
-                split2(v[0], v[1], ea, h1p[kp], h2p[kp]);
-            }
+            for (int kp = 0; kp < 16; ++kp) split2(raw[2 * kp], raw[2 * kp + 1], ea, h1p[kp], h2p[kp]);
 #pragma unroll
             for (int kc = 0; kc < 2; ++kc)
 #pragma unroll
@@ -1066,6 +1079,7 @@ __global__ __launch_bounds__(256, 2) void stem_mfma_kernel(const StemArgs p)
                 }
         }
         __syncthreads();
+        fetch(tile + gridDim.x);
         // ---- 2 k-tiles x 3 terms x (2 x 2) accumulators, operand roles swapped as in rmma (transposed accumulators)
         f32x16 acc[2][2];
 #pragma unroll
@@ -1102,8 +1116,8 @@ __global__ __launch_bounds__(256, 2) void stem_mfma_kernel(const StemArgs p)
             const long long row = m0 + wm0 + 32 * sm + j;
             const bool rok = row < M;
             const int b = rok ? (int)((unsigned)row / uHW) : 0;
-            const int eo = rok ? row_exponent(bound_bits(b)) : 0;
-            const int ek = eo - (rok ? row_exponent(p.in_bits[b]) : 0);
+            const int eo = rok ? eo_l[b] : 0;
+            const int ek = eo - (rok ? ea_l[b] : 0);
             const float so = rok ? __builtin_ldexpf(1.f, eo) : 0.f;
             const float hi = (p.epilogue == MH_EPI_RELU6) ? hi6 * so : hi6;
             if (rok && b != cur) {

@@ -670,14 +670,15 @@ int main(int argc, char **argv)
     if (argc > 2 && !strcmp(argv[2], "--conv-replay")) {
         // the 12 trunk launches of one bench step (b = 6, 592x592), each once: the target of the rocprofv3 --pmc FETCH_SIZE /
         // WRITE_SIZE passes behind bench.py's roofline.traffic (tools/r03/traffic.sh); prints the algorithmic bytes per launch
-        struct L { const char *name; int H, Cin, Cout, pool; } layers[] = {
-            {"conv1_2", 592, 64, 64, 0}, {"conv2_1", 296, 64, 128, 1}, {"conv2_2", 296, 128, 128, 0}, {"conv3_1", 148, 128, 256, 1},
-            {"conv3_2", 148, 256, 256, 0}, {"conv3_3", 148, 256, 256, 0}, {"conv4_1", 74, 256, 512, 1}, {"conv4_2", 74, 512, 512, 0},
-            {"conv4_3", 74, 512, 512, 0}, {"conv5_1", 37, 512, 512, 1}, {"conv5_2", 37, 512, 512, 0}, {"conv5_3", 37, 512, 512, 0}};
+        // round 6: every layer with the epilogue the step uses -- 1 = output as the next layer's image, 2 = through the 2x2 pool as the
+        // next layer's image, 0 = fp32 NHWC (the last layer); the input image of a layer is made by the converter here
+        struct L { const char *name; int H, Cin, Cout, mode; } layers[] = {
+            {"conv1_2", 592, 64, 64, 2}, {"conv2_1", 296, 64, 128, 1}, {"conv2_2", 296, 128, 128, 2}, {"conv3_1", 148, 128, 256, 1},
+            {"conv3_2", 148, 256, 256, 1}, {"conv3_3", 148, 256, 256, 2}, {"conv4_1", 74, 256, 512, 1}, {"conv4_2", 74, 512, 512, 1},
+            {"conv4_3", 74, 512, 512, 2}, {"conv5_1", 37, 512, 512, 1}, {"conv5_2", 37, 512, 512, 1}, {"conv5_3", 37, 512, 512, 0}};
         const int B = 6;
         for (const L &l : layers) {
-            const int Hi = l.pool ? 2 * l.H : l.H;
-            const size_t nx = (size_t)B * Hi * Hi * l.Cin;
+            const size_t nx = (size_t)B * l.H * l.H * l.Cin;
             Dev dx(nx * 4), dw((size_t)l.Cout * l.Cin * 9 * 4), db(l.Cout * 4), dmb(B * 4), dmbo(B * 4), dout((size_t)B * l.H * l.H * l.Cout * 4);
             fill_dev(dx.f(), nx, 3); fill_dev(dw.f(), (size_t)l.Cout * l.Cin * 9, 5); fill_dev(db.f(), l.Cout, 6);
             std::vector<unsigned> mb(B, fbits(6.0f));
@@ -685,12 +686,16 @@ int main(int argc, char **argv)
             HIP_OK(hipMemset(dmbo.p, 0, B * 4));
             Dev img(act_bytes(B, l.H, l.H, l.Cin)), pk(plpacked_bytes(l.Cout, l.Cin)), ws3(plconv_ws(B, l.H, l.H, l.Cin, l.Cout));
             plpack(dw.f(), l.Cout, l.Cin, 0, pk.p, nullptr);
-            act_planes(dx.f(), (const unsigned *)dmb.p, B, Hi, Hi, l.Cin, l.pool, img.p, nullptr);
-            plconv(img.p, B, l.H, l.H, l.Cin, pk.p, l.Cout, db.f(), 1, dout.f(), (unsigned *)dmbo.p, ws3.p, ws3.n, nullptr);
+            act_planes(dx.f(), (const unsigned *)dmb.p, B, l.H, l.H, l.Cin, 0, img.p, nullptr);
+            int rc;
+            if (l.mode == 0) rc = plconv(img.p, B, l.H, l.H, l.Cin, pk.p, l.Cout, db.f(), 1, dout.f(), (unsigned *)dmbo.p, ws3.p, ws3.n, nullptr);
+            else if (l.mode == 1) rc = plconv_img(img.p, (const unsigned *)dmb.p, B, l.H, l.H, l.Cin, pk.p, l.Cout, db.f(), 1, dout.p, (unsigned *)dmbo.p, ws3.p, ws3.n, nullptr);
+            else rc = plconv_pool(img.p, (const unsigned *)dmb.p, B, l.H, l.H, l.Cin, pk.p, l.Cout, db.f(), 1, dout.p, (unsigned *)dmbo.p, ws3.p, ws3.n, nullptr);
             HIP_OK(hipDeviceSynchronize());
             const double M = (double)B * l.H * l.H;
-            printf("{\"layer\": \"%s\", \"H\": %d, \"Cin\": %d, \"Cout\": %d, \"algorithmic_read_bytes\": %.0f, \"algorithmic_write_bytes\": %.0f, \"flops\": %.0f}\n",
-                   l.name, l.H, l.Cin, l.Cout, 4.0 * (M * l.Cin + 9.0 * l.Cin * l.Cout), 4.0 * M * l.Cout, 2.0 * 9 * l.Cin * l.Cout * M);
+            printf("{\"layer\": \"%s\", \"H\": %d, \"Cin\": %d, \"Cout\": %d, \"epilogue\": \"%s\", \"rc\": %d, \"algorithmic_read_bytes\": %.0f, \"algorithmic_write_bytes\": %.0f, \"flops\": %.0f}\n",
+                   l.name, l.H, l.Cin, l.Cout, l.mode == 0 ? "fp32" : (l.mode == 1 ? "image" : "pooled image"), rc, 4.0 * (M * l.Cin + 9.0 * l.Cin * l.Cout),
+                   4.0 * M * l.Cout / (l.mode == 2 ? 4 : 1), 2.0 * 9 * l.Cin * l.Cout * M);
         }
         return 0;
     }
@@ -706,6 +711,16 @@ int main(int argc, char **argv)
             conv_sweep("conv3_2", 6, 148, 148, 256, 256, 5);
         }
         set_conv_flags(0);
+        return 0;
+    }
+    if (argc > 2 && !strcmp(argv[2], "--stem")) {
+        // conv1_1 -> image at the bench size (b = 6, 592 x 592): MH_STEM=valu in the environment selects the VALU kernel
+        const int B = 6, H = 592, W = 592, C0 = 64;
+        const size_t M = (size_t)B * H * W;
+        Dev dx(M * 3 * 4), dw((size_t)C0 * 27 * 4), db(C0 * 4), mb(64 * 4), img(act_bytes(B, H, W, C0));
+        fill_dev(dx.f(), M * 3, 3); fill_dev(dw.f(), (size_t)C0 * 27, 5); fill_dev(db.f(), C0, 6);
+        const float ms = time_ms(20, [&] { HIP_OK(hipMemsetAsync(mb.p, 0, 64 * 4, nullptr)); stem_img(dx.f(), B, 3, H, W, dw.f(), C0, db.f(), 1, img.p, (unsigned *)mb.p, nullptr); });
+        printf("{\"check\": \"stem speed\", \"variant\": \"%s\", \"ms\": %.4f, \"image_GBps\": %.0f}\n", getenv("MH_STEM") ? getenv("MH_STEM") : "mfma", ms, M * C0 * 4.0 / ms * 1e-6);
         return 0;
     }
     if (argc > 2 && !strcmp(argv[2], "--conv-r06")) {
