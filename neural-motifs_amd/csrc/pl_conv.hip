@@ -1525,8 +1525,10 @@ int mh_stem_to_image(const float *in_nchw, int B, int Cin, int H, int W, const f
         pl::StemArgs p;
         p.in = in_nchw; p.B = B; p.Cin = Cin; p.H = H; p.W = W; p.w = w; p.bias = bias; p.epilogue = epilogue; p.in_bits = in_bits;
         p.out_cells = cells; p.scale_bits = scale; p.out_bits = out_maxbits;
+        // two blocks per CU = what is resident: every block walks ~16 tiles (gpurun r06_c8: 0.30 ms against 0.50-0.59 with 4-8 blocks per CU queued)
+        static const int blocks_per_cu = [] { const char *e = getenv("MH_STEM_BLOCKS"); return e ? std::max(1, atoi(e)) : 2; }();
         const long long ntiles = (M + 255) / 256;
-        pl::launch<pl::stem_mfma_kernel>(dim3((unsigned)std::min<long long>(ntiles, 256 * 2 * 4)), (size_t)pl::kStemLds, st, p);
+        pl::launch<pl::stem_mfma_kernel>(dim3((unsigned)std::min<long long>(ntiles, 256LL * blocks_per_cu)), (size_t)pl::kStemLds, st, p);
         return check_launch("pl::stem_mfma_kernel");
     }
     const long long nblk = ((M + 255) / 256) * (Cout / pl::kBK);
