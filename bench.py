@@ -284,6 +284,19 @@ def cpu_baseline(ds, model_sd, iters=3, eval_images=3, budget_s=150.0):
                                        eval_images, ', '.join('%.2f' % t for t in etimes[1:]))})
 
 
+def rank_command(args, argv):
+    """(command line, environment) of the N ranks `python bench.py --gpus N` starts under torch.distributed.run: one process per
+    GPU, standalone c10d rendezvous on 127.0.0.1."""
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')      # dmabuf IPC: RCCL's cross-process buffer sharing needs it on this driver
+    env.setdefault('OMP_NUM_THREADS', str(max(1, (os.cpu_count() or 8) // max(args.gpus, 1))))
+    # --standalone: the c10d rendezvous binds a free port ITSELF (no bind-close-rebind window in which another process could
+    # take a port picked here, ADVICE r04); --local-addr: the container's hostname may not resolve
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--standalone', '--local-addr', '127.0.0.1', '--nnodes=1',
+           '--nproc-per-node', str(args.gpus), os.path.abspath(__file__)] + list(argv)
+    return cmd, env
+
+
 def launch_ranks(args, argv):
     """`python bench.py --gpus N` without torchrun's environment: start N ranks of this file under torch.distributed.run
     (one process per GPU, standalone c10d rendezvous on 127.0.0.1) and pass rank 0's JSON line through.  Returns the exit code."""
@@ -293,14 +306,139 @@ def launch_ranks(args, argv):
         if n_dev < args.gpus:
             raise SystemExit('bench.py --gpus %d: only %d HIP device(s) visible -- refusing to run a smaller job under that name'
                              % (args.gpus, n_dev))
-    env = dict(os.environ)
-    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')      # dmabuf IPC: RCCL's cross-process buffer sharing needs it on this driver
-    env.setdefault('OMP_NUM_THREADS', str(max(1, (os.cpu_count() or 8) // max(args.gpus, 1))))
-    # --standalone: the c10d rendezvous binds a free port ITSELF (no bind-close-rebind window in which another process could
-    # take a port picked here); --local-addr: the container's hostname may not resolve
-    cmd = [sys.executable, '-m', 'torch.distributed.run', '--standalone', '--local-addr', '127.0.0.1', '--nnodes=1',
-           '--nproc-per-node', str(args.gpus), os.path.abspath(__file__)] + list(argv)
+    cmd, env = rank_command(args, argv)
     return subprocess.call(cmd, env=env)
+
+
+# ---------------------------------------------------------------------------------------------------------------- --dry
+# `python bench.py --gpus 8 --dry` -- everything of the first N-GPU run that does NOT need N GPUs, on any box (VERDICT r05 #7):
+#   * the N rank command lines and their environment, exactly as launch_ranks() would start them (rank_command);
+#   * the REAL trainable-parameter list of the benched model (built once by the parent, shapes only) handed to N gloo ranks on the
+#     CPU: every rank runs lib.dist.OverlappedGradReducer's own planning code on it (buckets, <= 64 MB collective units, the row
+#     ranges of fc6) and the plans are compared ACROSS the ranks through the process group;
+#   * the step's collectives at their real sizes, in the reducer's launch order, asynchronously like the reducer issues them,
+#     on a reused <= 64 MB scratch buffer (a different order or size on any rank deadlocks or fails HERE, not on the 8-GPU node),
+#     with the sums checked; lib.dist.scaling_diagnostics (its all_gather_object) over the same group;
+#   * the learning-rate rule (models/train_rels.py:192: 1e-3 x world x batch) and the per-rank host-thread budget: N ranks x
+#     (main thread + the detect-ahead worker of the SGDet configurations) against the node's cores, OMP threads per rank.
+# One JSON line from rank 0; exit code != 0 when a check fails.  No scaling number comes out of this -- SCALE_rNN.json does that.
+_INIT_FNS = ('uniform_', 'normal_', 'trunc_normal_', 'constant_', 'ones_', 'zeros_', 'eye_', 'dirac_', 'xavier_uniform_',
+             'xavier_normal_', 'kaiming_uniform_', 'kaiming_normal_', 'orthogonal_', 'sparse_')
+
+
+def trainable_parameter_list(config):
+    """[(name, shape, requires_grad)] of the benched model: the constructor runs with torch.nn.init's functions stubbed (the
+    block-orthogonal LSTM initialisation and three 411 MB fc6 draws are most of its 50 s; shapes do not depend on values)"""
+    import torch.nn.init as I
+    from dataloaders.synthetic import SyntheticVG
+    from lib.rel_model import RelModel
+    saved = {n: getattr(I, n) for n in _INIT_FNS if hasattr(I, n)}
+    for n in saved:
+        setattr(I, n, lambda t, *a, **k: t)
+    try:
+        ds = SyntheticVG(num_images=2, seed=1, n_boxes=N_BOXES, n_rels=N_RELS)
+        kw = dict(MODEL_KW, nl_edge=4) if config == 'recipe' else MODEL_KW
+        mode = 'sgdet' if config in ('cfg3', 'cfg5') else 'sgcls'
+        model = RelModel(classes=ds.ind_to_classes, rel_classes=ds.ind_to_predicates, mode=mode, num_gpus=1, **kw)
+    finally:
+        for n, f in saved.items():
+            setattr(I, n, f)
+    for _, p in model.detector.named_parameters():           # models/train_rels.py:50-52
+        p.requires_grad = False
+    return [(n, list(p.shape), bool(p.requires_grad)) for n, p in model.named_parameters()]
+
+
+def dry_parent(args, argv):
+    import subprocess
+    import tempfile
+    real_cmd, env = rank_command(args, [a for a in argv if a != '--dry'])
+    plist = trainable_parameter_list(args.config)
+    with tempfile.NamedTemporaryFile('w', suffix='.json', delete=False) as f:
+        json.dump({'params': plist, 'real_cmd': real_cmd,
+                   'env': {k: env[k] for k in ('HSA_ENABLE_IPC_MODE_LEGACY', 'OMP_NUM_THREADS')}}, f)
+        path = f.name
+    try:
+        cmd, env = rank_command(args, argv)
+        env['MOTIFS_DRY_PLAN'] = path
+        env['HIP_VISIBLE_DEVICES'] = ''                       # the rehearsal is a CPU job wherever it runs
+        return subprocess.call(cmd, env=env)
+    finally:
+        os.unlink(path)
+
+
+def dry_rank(args):
+    import hashlib
+    import torch.distributed as dist
+    from lib import dist as D
+    rank, world, local_rank = D.init_from_env(backend='gloo')
+    if world != args.gpus or (world > 1 and dist.get_world_size() != args.gpus):
+        raise SystemExit('--dry: asked for %d ranks, the process group has %d' % (args.gpus, world))
+    plan = json.load(open(os.environ['MOTIFS_DRY_PLAN']))
+    names, params = [], []
+    for name, shape, rg in plan['params']:
+        if rg:
+            names.append(name)
+            params.append(torch.nn.Parameter(torch.empty(shape, device='meta')))
+    reducer = D.OverlappedGradReducer(params, force=True)      # the product's planning code on the real shapes
+    name_of = {id(p): n for n, p in zip(names, params)}
+    layout = [[name_of[id(p)] for p in b] for b in reducer.buckets]
+    digest = hashlib.sha256(json.dumps([layout, reducer.units]).encode()).hexdigest()
+    seen = [None] * world
+    if world > 1:
+        dist.all_gather_object(seen, digest)
+    else:
+        seen = [digest]
+    plan_identical = all(d == seen[0] for d in seen)
+    # the collectives of one backward at their real sizes, in launch order, in flight together like the reducer's
+    biggest = max(hi - lo for _, lo, hi in reducer.units)
+    scratch = [torch.empty(biggest) for _ in range(2)]
+    t0 = time.time()
+    ok = True
+    work = []
+    for u, (_, lo, hi) in enumerate(reducer.units):
+        buf = scratch[u % 2][:hi - lo]
+        if len(work) >= 2:                                      # two scratch buffers: wait for the unit that used this one
+            w, b, n = work.pop(0)
+            w.wait()
+            ok = ok and bool((b[:8] == n).all()) and bool((b[-8:] == n).all())
+        buf.fill_(float(rank + 1))
+        expect = float(world * (world + 1) // 2)
+        if world > 1:
+            work.append((dist.all_reduce(buf, op=dist.ReduceOp.SUM, async_op=True), buf, expect))
+        else:
+            expect = 1.0
+        reducer.launch_log.append(u)
+    for w, b, n in work:
+        w.wait()
+        ok = ok and bool((b[:8] == n).all()) and bool((b[-8:] == n).all())
+    t_coll = time.time() - t0
+    diag = D.scaling_diagnostics(reducer, 'cpu', 0.0)
+    cores = os.cpu_count() or 1
+    sgdet = args.config in ('cfg3', 'cfg5')
+    per_rank = 1 + (1 if sgdet else 0)                          # main thread + RelModel.detect_ahead's worker (SGDet only)
+    omp = int(os.environ.get('OMP_NUM_THREADS', '1'))
+    threads = {'cores': cores, 'ranks': world, 'python_threads_per_rank': per_rank, 'omp_threads_per_rank': omp,
+               'ok': world * per_rank <= cores and world * omp <= max(cores, world)}
+    grad_bytes = sum(p.numel() for p in params) * 4
+    checks = {'plan_identical_across_ranks': plan_identical, 'collectives_ok': ok,
+              'collective_order_identical': bool(diag['collective_order_identical']),
+              'distinct_ranks_seen': diag['distinct_devices'] == world, 'host_threads_ok': threads['ok'],
+              'units_cover_gradients': sum(hi - lo for _, lo, hi in reducer.units) * 4 == grad_bytes,
+              'unit_bytes_le_split': all((hi - lo) * 4 <= reducer.split_bytes or len(reducer.buckets[bi]) > 1
+                                         for bi, lo, hi in reducer.units)}
+    if rank == 0:
+        print(json.dumps({'dry': True, 'n_gpus': world, 'config': args.config, 'backend': 'gloo (CPU rehearsal; RCCL on the GPU node)',
+                          'rank_command': plan['real_cmd'], 'rank_env': plan['env'],
+                          'trainable_parameters': len(params), 'gradient_mb': round(grad_bytes / 2.0 ** 20, 1),
+                          'collective_units': len(reducer.units), 'bucket_mb': reducer.bucket_mb, 'plan_sha256': digest[:16],
+                          'rehearsal_s': round(t_coll, 2), 'lr': 1e-3 * world * BATCH, 'lr_rule': 'models/train_rels.py:192',
+                          'host_threads': threads, 'checks': checks, 'ok': all(checks.values()),
+                          'note': 'no scaling number: nothing here ran on a GPU'}), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if not all(checks.values()):
+        raise SystemExit('--dry: failed checks: %s' % [k for k, v in checks.items() if not v])
 
 
 def launch_selftest(args):
@@ -589,8 +727,15 @@ def main():
     ap.add_argument('--h2d-steps', type=int, default=8, help='steps of the second, H2D-inclusive timing (0 = skip)')
     ap.add_argument('--gemm-shapes', default='', help='after the timed region: one more cfg2 step with every matrix-product call '
                     'logged (binding, M, N, K, transposes, HIP-event time, stream) as JSON lines into this file')
+    ap.add_argument('--dry', action='store_true', help='rehearse the N-rank launch on the CPU (gloo): rank command lines, the real '
+                    'parameter list through the gradient reducer\'s planning code on every rank, the collectives at their real sizes and '
+                    'order, host-thread budget; one JSON line, no GPU needed, no scaling number produced')
     args = ap.parse_args()
 
+    if args.dry:
+        if 'WORLD_SIZE' not in os.environ:
+            raise SystemExit(dry_parent(args, sys.argv[1:]))
+        return dry_rank(args)
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
         raise SystemExit(launch_ranks(args, sys.argv[1:]))       # not started by torchrun: start the ranks ourselves
     if args.launch_selftest:

@@ -11,6 +11,8 @@
 //             ReLU mask.
 // HBM-bound: a few passes over [n*14*14, 256] / [n*7*7, 512].
 #include <algorithm>
+#include <cstdlib>
+#include <string>
 
 #include "common.h"
 
@@ -453,6 +455,278 @@ __global__ __launch_bounds__(256) void tower_conv1_wgrad_reduce_kernel(const flo
 }
 constexpr int kT1PairsPerBlock = 3;
 
+// ---- Round 6: the same layer on the matrix cores -------------------------------------------------------------------------------
+// The direct kernels above are VALU-bound at the fp32 FMA rate: 7.5 G FMA per cfg2 step = 0.31-0.36 ms forward, 0.42-0.46 ms
+// weight gradient (profiles/r06_bench_n1_kernel_stats_c9.csv) for 15 GFLOP each.  As products they are
+//   forward          y[p][c]   = sum_k' A[p][k'] w[c][k']      p = 301056 output pixels, c = 256, k' = 7 kernel rows x 16
+//   weight gradient  dw[k'][c] = sum_p  A[p][k'] dy[p][c]
+// with k' = 16 ky + (2 kx + ci): one kernel row of the NHWC mask is 14 CONTIGUOUS floats of the padded copy, padded here to one
+// 16-deep k-tile (the two extra columns meet zero weights / are never written out).  No column matrix and no LDS operand tiles:
+// every lane builds its MFMA fragments straight from global memory --
+//   forward: lane (pixel j, half g) of a 32-pixel tile reads floats 8 g .. 8 g + 7 of the seven window rows (two 16-byte loads),
+//     scales by 2^14 (masks lie in [0, 1]) and splits into the two f16 planes (f16x3, as everywhere: pl_tile.h split2); the
+//     weights' fragments of the wave's 64 channels (per-channel exponent, two planes, 7 k-tiles) live in 112 VGPRs for the whole
+//     launch.  42 MFMAs per wave and 32-pixel tile; the accumulators come out transposed (a lane's register quad = four
+//     consecutive channels of one pixel), take bias + ReLU, and leave through a wave-private LDS patch as 256-byte runs.
+//     Bound by the 308 MB of y it writes.
+//   weight gradient: the contraction runs over pixels, so a k-tile is ONE OUTPUT ROW (14 pixels, padded to 16 with zero
+//     gradients): lane (tap row j, half g) reads the mask value under its tap for pixels 8 g .. 8 g + 7 (stride-4 floats), lane
+//     (channel j, half g) the 8 gradients of its channel (stride C0: 128-byte runs across the wave).  The gradients have no
+//     a-priori scale, so this product is bf16x6 (mfma_tile.h: three bf16 terms per fp32 value, six MFMAs, no maxima pass).  A wave
+//     owns 64 channels x all 112 (128) tap rows = 128 accumulator registers; a block owns a contiguous range of output rows and
+//     writes ONE partial [99][C0] (bias gradient = exact fp32 sums of the raw gradients, row 98) that the existing fixed-order
+//     reduce kernel adds up.  48 MFMAs per wave and output row.
+// MH_TOWER_CONV1=valu keeps the direct kernels (A/B).
+namespace t1 {
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4_u __attribute__((ext_vector_type(4), aligned(8)));      // a window row starts on an 8-byte boundary (33 x 2 floats per padded row)
+typedef float f32x2_u __attribute__((ext_vector_type(2), aligned(8)));
+
+constexpr int kKy = kT1K;                      // 7 k-tiles (kernel rows)
+constexpr int kMaskExp = 14;                   // masks lie in [0, 1]: scaled by 2^14 they fit f16 with the usual headroom
+
+__device__ __forceinline__ void split2_f16(float x0, float x1, int e, unsigned &p1, unsigned &p2)
+{
+    const f32x2 xs = {__builtin_ldexpf(x0, e), __builtin_ldexpf(x1, e)};
+    const f16x2 h1 = __builtin_convertvector(xs, f16x2);
+    const f32x2 r = xs - __builtin_convertvector(h1, f32x2);     // exact
+    p1 = __builtin_bit_cast(unsigned, h1);
+    p2 = __builtin_bit_cast(unsigned, __builtin_convertvector(r, f16x2));
+}
+__device__ __forceinline__ unsigned pack_bf16(float lo16, float hi16)
+{
+    const f32x2 v = {lo16, hi16};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
+}
+__device__ __forceinline__ void split3_bf16(float x0, float x1, unsigned &p1, unsigned &p2, unsigned &p3)
+{
+    p1 = pack_bf16(x0, x1);
+    const float r0 = x0 - __builtin_bit_cast(float, p1 << 16);               // exact
+    const float r1 = x1 - __builtin_bit_cast(float, p1 & 0xffff0000u);
+    p2 = pack_bf16(r0, r1);
+    const float s0 = r0 - __builtin_bit_cast(float, p2 << 16);               // exact
+    const float s1 = r1 - __builtin_bit_cast(float, p2 & 0xffff0000u);
+    p3 = pack_bf16(s0, s1);
+}
+__device__ __forceinline__ int exponent_of(unsigned absmax_bits)            // pl_tile.h row_exponent
+{
+    const int biased = (int)(absmax_bits >> 23) & 0xff;
+    if (biased == 0 || biased == 0xff) return 0;
+    return 14 - (biased - 127);
+}
+
+constexpr int kFwdPatchRow = 64 + 4;           // floats per pixel row of the wave's output patch (+4: bank spread)
+constexpr int kFwdPatch = 32 * kFwdPatchRow * 4;       // bytes
+constexpr int kFwdLds = 4 * kFwdPatch + 256 * 8;       // four patches | bias[256], exponent[256]
+
+// grid (pixel-tile walkers, C0 / 256), block 256: wave w = channels 64 w .. 64 w + 63 of the block's group
+__global__ __launch_bounds__(256) void tower_conv1_mfma_fwd_kernel(const float *__restrict__ xp, long long N, int Sp, int Ho, int Wo,
+                                                                   const float *__restrict__ wk, const float *__restrict__ bias,
+                                                                   int C0, float *__restrict__ y)
+{
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int j = lane & 31, g = lane >> 5;
+    const int cg = (int)blockIdx.y * 256;
+    float *patch = reinterpret_cast<float *>(lds + wave * kFwdPatch);
+    float *bias_l = reinterpret_cast<float *>(lds + 4 * kFwdPatch);
+    int *eb_l = reinterpret_cast<int *>(bias_l + 256);
+    // ---- weights of the wave's 64 channels -> per-channel exponent, two f16 planes, fragments in registers
+    unsigned bq[2][kKy][2][4];                                             // [n-block][ky][plane][4 dwords = 8 k]
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb) {
+        const int c = cg + 64 * wave + 32 * nb + j;
+        float wv[kKy][8];
+        unsigned m = 0;
+#pragma unroll
+        for (int ky = 0; ky < kKy; ++ky)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int t = 8 * g + i;                                   // column of the padded kernel row
+                wv[ky][i] = t < kT1Row ? wk[(size_t)(ky * kT1Row + t) * C0 + c] : 0.f;
+                m = max(m, __float_as_uint(wv[ky][i]) & 0x7fffffffu);
+            }
+        m = max(m, (unsigned)__shfl_xor((int)m, 32));                      // both halves of the channel's row
+        const int e = exponent_of(m);
+        if (g == 0) {
+            eb_l[64 * wave + 32 * nb + j] = e;
+            bias_l[64 * wave + 32 * nb + j] = bias ? bias[c] : 0.f;
+        }
+#pragma unroll
+        for (int ky = 0; ky < kKy; ++ky)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) split2_f16(wv[ky][2 * i], wv[ky][2 * i + 1], e, bq[nb][ky][0][i], bq[nb][ky][1][i]);
+    }
+    __syncthreads();
+    const long long M = N * Ho * Wo;
+    const long long ntiles = (M + 31) / 32;
+    const int HW = Ho * Wo;
+    for (long long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const long long p = tile * 32 + j;
+        const bool ok = p < M;
+        const long long pc = ok ? p : M - 1;
+        const long long n = pc / HW;
+        const int rem = (int)(pc - n * HW), oy = rem / Wo, ox = rem - oy * Wo;
+        const float *win = xp + (((size_t)n * Sp + (size_t)oy * kT1Stride) * Sp + (size_t)ox * kT1Stride) * kT1C + 8 * g;
+        f32x16 acc[2];
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[nb][r] = 0.f;
+        f32x4_u v0[kKy];
+        f32x2_u v1[kKy], v2[kKy];
+#pragma unroll
+        for (int ky = 0; ky < kKy; ++ky) {                                 // floats 8 g .. 8 g + 7 of the window row (14 are real)
+            const float *row = win + (size_t)ky * Sp * kT1C;
+            v0[ky] = *reinterpret_cast<const f32x4_u *>(row);
+            v1[ky] = *reinterpret_cast<const f32x2_u *>(row + 4);
+            v2[ky] = g == 0 ? *reinterpret_cast<const f32x2_u *>(row + 6) : (f32x2_u){0.f, 0.f};
+        }
+#pragma unroll
+        for (int ky = 0; ky < kKy; ++ky) {
+            unsigned a[2][4];
+            split2_f16(v0[ky].x, v0[ky].y, kMaskExp, a[0][0], a[1][0]);
+            split2_f16(v0[ky].z, v0[ky].w, kMaskExp, a[0][1], a[1][1]);
+            split2_f16(v1[ky].x, v1[ky].y, kMaskExp, a[0][2], a[1][2]);
+            split2_f16(v2[ky].x, v2[ky].y, kMaskExp, a[0][3], a[1][3]);
+            const f16x8 a1 = __builtin_bit_cast(f16x8, (u32x4){a[0][0], a[0][1], a[0][2], a[0][3]});
+            const f16x8 a2 = __builtin_bit_cast(f16x8, (u32x4){a[1][0], a[1][1], a[1][2], a[1][3]});
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb) {
+                const f16x8 b1 = __builtin_bit_cast(f16x8, (u32x4){bq[nb][ky][0][0], bq[nb][ky][0][1], bq[nb][ky][0][2], bq[nb][ky][0][3]});
+                const f16x8 b2 = __builtin_bit_cast(f16x8, (u32x4){bq[nb][ky][1][0], bq[nb][ky][1][1], bq[nb][ky][1][2], bq[nb][ky][1][3]});
+                // weights first: rows of the result = channels, columns = pixels (transposed accumulators, pl_conv.hip rmma)
+                acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b1, a2, acc[nb], 0, 0, 0);
+                acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b2, a1, acc[nb], 0, 0, 0);
+                acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b1, a1, acc[nb], 0, 0, 0);
+            }
+        }
+        // ---- epilogue: lane (j, g), registers 4 q .. 4 q + 3 = channels 32 nb + 8 q + 4 g + (0..3) of pixel j
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int c = 32 * nb + 8 * q + 4 * g;
+                const int4 eb = *reinterpret_cast<const int4 *>(eb_l + 64 * wave + c);
+                const float4 bs = *reinterpret_cast<const float4 *>(bias_l + 64 * wave + c);
+                float4 o;
+                o.x = fmaxf(__builtin_ldexpf(acc[nb][4 * q + 0], -kMaskExp - eb.x) + bs.x, 0.f);
+                o.y = fmaxf(__builtin_ldexpf(acc[nb][4 * q + 1], -kMaskExp - eb.y) + bs.y, 0.f);
+                o.z = fmaxf(__builtin_ldexpf(acc[nb][4 * q + 2], -kMaskExp - eb.z) + bs.z, 0.f);
+                o.w = fmaxf(__builtin_ldexpf(acc[nb][4 * q + 3], -kMaskExp - eb.w) + bs.w, 0.f);
+                *reinterpret_cast<float4 *>(patch + j * kFwdPatchRow + c) = o;
+            }
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int px = 4 * it + (lane >> 4), ch = 4 * (lane & 15);
+            const float4 o = *reinterpret_cast<const float4 *>(patch + px * kFwdPatchRow + ch);
+            const long long po = tile * 32 + px;
+            if (po < M) *reinterpret_cast<float4 *>(y + (size_t)po * C0 + cg + 64 * wave + ch) = o;
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// grid (row-range blocks, C0 / 256), block 256: wave w = channels 64 w .. 64 w + 63; partial[blockIdx.x][99][C0]
+__global__ __launch_bounds__(256) void tower_conv1_mfma_wgrad_kernel(const float *__restrict__ xp, long long N, int Sp, int Ho, int Wo,
+                                                                     const float *__restrict__ dy, int C0, int rows_per_block,
+                                                                     float *__restrict__ partial)
+{
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int j = lane & 31, g = lane >> 5;
+    const int c0 = (int)blockIdx.y * 256 + 64 * wave;
+    const long long rows = N * Ho;
+    const long long r0 = (long long)blockIdx.x * rows_per_block, r1 = min(rows, r0 + rows_per_block);
+    // tap row 32 mb + j of the padded k' order: kernel row ky = 2 mb + (j >> 4), column t = j & 15 (14 real)
+    int tap_off[4];
+    bool tap_ok[4];
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb) {
+        const int ky = 2 * mb + (j >> 4), t = j & 15;
+        tap_ok[mb] = ky < kKy && t < kT1Row;
+        tap_off[mb] = tap_ok[mb] ? (ky * Sp * kT1C + t) : 0;
+    }
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mb][nb][r] = 0.f;
+    float bsum[2] = {0.f, 0.f};
+    float av[4][8], dv[2][8];                                              // the raw values of the NEXT output row
+    auto fetch = [&](long long row) {
+        const bool rok = row < r1;
+        const long long rc = rok ? row : r1 - 1;
+        const long long n = rc / Ho;
+        const int oy = (int)(rc - n * Ho);
+        const float *xrow = xp + ((size_t)n * Sp + (size_t)oy * kT1Stride) * Sp * kT1C + (size_t)(8 * g) * kT1Stride * kT1C;
+        const float *drow = dy + ((size_t)rc * Wo + 8 * g) * C0 + c0 + j;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const bool pok = rok && 8 * g + i < Wo;                        // pixels 14, 15 of the padded row carry nothing
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb) av[mb][i] = (pok && tap_ok[mb]) ? xrow[tap_off[mb] + i * kT1Stride * kT1C] : 0.f;
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb) dv[nb][i] = pok ? drow[(size_t)i * C0 + 32 * nb] : 0.f;
+        }
+    };
+    if (r0 < r1) fetch(r0);
+    for (long long row = r0; row < r1; ++row) {
+        unsigned a[4][3][4], d[2][3][4];
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) split3_bf16(av[mb][2 * i], av[mb][2 * i + 1], a[mb][0][i], a[mb][1][i], a[mb][2][i]);
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) split3_bf16(dv[nb][2 * i], dv[nb][2 * i + 1], d[nb][0][i], d[nb][1][i], d[nb][2][i]);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) bsum[nb] += dv[nb][i];
+        }
+        fetch(row + 1);                                                    // flies under the 48 MFMAs below
+        constexpr int kTa[6] = {2, 0, 1, 1, 0, 0}, kTd[6] = {0, 2, 1, 0, 1, 0};   // b3 d1, b1 d3, b2 d2, b2 d1, b1 d2, b1 d1
+#pragma unroll
+        for (int t = 0; t < 6; ++t)
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+                for (int nb = 0; nb < 2; ++nb) {
+                    const bf16x8 fa = __builtin_bit_cast(bf16x8, (u32x4){a[mb][kTa[t]][0], a[mb][kTa[t]][1], a[mb][kTa[t]][2], a[mb][kTa[t]][3]});
+                    const bf16x8 fd = __builtin_bit_cast(bf16x8, (u32x4){d[nb][kTd[t]][0], d[nb][kTd[t]][1], d[nb][kTd[t]][2], d[nb][kTd[t]][3]});
+                    acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fd, acc[mb][nb], 0, 0, 0);
+                }
+    }
+    // ---- partial[b][k][c]: lane (channel j, g), register r of block mb = tap row 32 mb + 8 (r / 4) + 4 g + r % 4
+    float *out = partial + (size_t)blockIdx.x * (kT1Taps + 1) * C0 + c0 + j;
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int kp = 32 * mb + 8 * (r >> 2) + 4 * g + (r & 3);
+            const int ky = kp >> 4, t = kp & 15;
+            if (ky < kKy && t < kT1Row) {
+#pragma unroll
+                for (int nb = 0; nb < 2; ++nb) out[(size_t)(ky * kT1Row + t) * C0 + 32 * nb] = acc[mb][nb][r];
+            }
+        }
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb) {
+        const float s = bsum[nb] + __shfl_xor(bsum[nb], 32);
+        if (g == 0) out[(size_t)kT1Taps * C0 + 32 * nb] = s;
+    }
+}
+constexpr int kWgradBlocks = 256;              // one row range per CU
+}  // namespace t1
+
 static int grid_for(long long total) { return (int)std::min<long long>((total + 255) / 256, 256 * 16); }
 
 }  // namespace mh
@@ -578,7 +852,12 @@ int mh_bn_bwd(const float *x, const float *g, const unsigned char *argmax, long 
     return check_launch("bn_bwd_apply_kernel");
 }
 
-// ---- the tower's first convolution, direct: see tower_conv1_fwd_kernel ----
+// ---- the tower's first convolution: matrix cores (t1::, round 6) unless MH_TOWER_CONV1=valu (the direct kernels) ----
+static bool tower_conv1_on_mfma()
+{
+    static const bool on = [] { const char *e = getenv("MH_TOWER_CONV1"); return !(e && std::string(e) == "valu"); }();
+    return on;
+}
 static int check_t1(long long N, int S, int C0)
 {
     MH_REQUIRE(N > 0 && N <= 0x7fffffffLL / 4 && S >= kT1K - 2 * kT1Pad && S <= 4096 && C0 > 0 && C0 % 256 == 0 && C0 <= 256 * 65535);
@@ -597,7 +876,8 @@ size_t mh_tower_conv1_padded_bytes(long long N, int S)
 size_t mh_tower_conv1_wgrad_ws_bytes(long long N, int C0)
 {
     if (N <= 0 || C0 <= 0) return 0;
-    const size_t nblk = (size_t)ceil_div(N, (long long)kT1PairsPerBlock);
+    // the direct kernel: one partial per 3 pairs; the matrix-core kernel: one per row range, at most t1::kWgradBlocks
+    const size_t nblk = std::max<size_t>((size_t)ceil_div(N, (long long)kT1PairsPerBlock), (size_t)std::min<long long>(t1::kWgradBlocks, N * kT1MaxW));
     return align_up(nblk * (kT1Taps + 1) * (size_t)C0 * sizeof(float), 256);
 }
 int mh_tower_conv1_pad(const float *rects_nhwc, long long N, int S, float *padded, void *stream)
@@ -617,6 +897,13 @@ int mh_tower_conv1_fwd(const float *padded, long long N, int S, const float *w_k
     if (rc) return rc;
     MH_REQUIRE(padded && w_kc && y_nhwc);
     const int Ho = mh_tower_conv1_out_size(S);
+    if (tower_conv1_on_mfma()) {
+        MH_REQUIRE(((reinterpret_cast<uintptr_t>(padded) | reinterpret_cast<uintptr_t>(y_nhwc)) & 15) == 0);
+        const long long ntiles = (N * Ho * Ho + 31) / 32;
+        hipLaunchKernelGGL(t1::tower_conv1_mfma_fwd_kernel, dim3((unsigned)std::min<long long>(ntiles, 256 * 8), (unsigned)(C0 / 256)), dim3(256),
+                           (size_t)t1::kFwdLds, as_stream(stream), padded, N, S + 2 * kT1Pad, Ho, Ho, w_kc, bias, C0, y_nhwc);
+        return check_launch("tower_conv1_mfma_fwd_kernel");
+    }
     hipLaunchKernelGGL(tower_conv1_fwd_kernel, dim3((unsigned)N, (unsigned)(C0 / 256)), dim3(256), 0, as_stream(stream), padded,
                        S + 2 * kT1Pad, Ho, Ho, w_kc, bias, C0, y_nhwc);
     return check_launch("tower_conv1_fwd_kernel");
@@ -629,8 +916,19 @@ int mh_tower_conv1_wgrad(const float *padded, const float *dy_nhwc, long long N,
     MH_REQUIRE(padded && dy_nhwc && dw_kc && workspace && ws_bytes >= mh_tower_conv1_wgrad_ws_bytes(N, C0));
     hipStream_t st = as_stream(stream);
     const int Ho = mh_tower_conv1_out_size(S);
-    const int nblk = (int)ceil_div(N, (long long)kT1PairsPerBlock);
     float *partial = reinterpret_cast<float *>(workspace);
+    if (tower_conv1_on_mfma()) {
+        const long long rows = N * Ho;
+        const int per = (int)ceil_div(rows, (long long)t1::kWgradBlocks), nb = (int)ceil_div(rows, (long long)per);
+        hipLaunchKernelGGL(t1::tower_conv1_mfma_wgrad_kernel, dim3((unsigned)nb, (unsigned)(C0 / 256)), dim3(256), 0, st, padded, N,
+                           S + 2 * kT1Pad, Ho, Ho, dy_nhwc, C0, per, partial);
+        rc = check_launch("tower_conv1_mfma_wgrad_kernel");
+        if (rc) return rc;
+        const int rows_c0 = (kT1Taps + 1) * C0;
+        hipLaunchKernelGGL(tower_conv1_wgrad_reduce_kernel, dim3(ceil_div(rows_c0, 256)), dim3(256), 0, st, partial, nb, rows_c0, dw_kc);
+        return check_launch("tower_conv1_wgrad_reduce_kernel");
+    }
+    const int nblk = (int)ceil_div(N, (long long)kT1PairsPerBlock);
     hipLaunchKernelGGL(tower_conv1_wgrad_kernel, dim3((unsigned)nblk, (unsigned)(C0 / 256)), dim3(256), 0, st, padded, S + 2 * kT1Pad, Ho,
                        Ho, dy_nhwc, N, C0, kT1PairsPerBlock, partial);
     rc = check_launch("tower_conv1_wgrad_kernel");

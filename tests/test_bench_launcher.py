@@ -46,3 +46,23 @@ def test_missing_devices_fail_loudly():
                          stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120, text=True)
     assert out.returncode != 0 and 'HIP device(s) visible' in (out.stderr + out.stdout)
     assert not [l for l in out.stdout.split('\n') if l.startswith('{')]
+
+
+def test_dry_rehearsal_of_the_rank_launch():
+    """`bench.py --gpus N --dry`: the rank command line, the REAL parameter list through the reducer's planning code on every rank
+    (plans compared through the process group), the step's 25 collectives at their real sizes and order over gloo, host threads.
+    N = 2 here (the 8-rank rehearsal is the same code: `python bench.py --gpus 8 --dry`, 36 s on 8 cores)."""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--dry'], env=_env(),
+                         stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600, text=True)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.split('\n') if l.startswith('{')]
+    assert len(lines) == 1, out.stdout
+    d = json.loads(lines[0])
+    assert d['dry'] and d['ok'] and d['n_gpus'] == 2 and all(d['checks'].values()), d['checks']
+    cmd = d['rank_command']
+    assert cmd[1:3] == ['-m', 'torch.distributed.run'] and '--dry' not in cmd and cmd[cmd.index('--nproc-per-node') + 1] == '2'
+    assert d['rank_env']['HSA_ENABLE_IPC_MODE_LEGACY'] == '0'
+    # the plan of the real cfg2 parameter list: fc6 (411 MB) of the two trainable heads in <= 64 MB row ranges, nothing larger
+    assert d['collective_units'] == len(d['bucket_mb']) >= 20 and max(d['bucket_mb']) <= 64.0
+    assert abs(sum(d['bucket_mb']) - d['gradient_mb']) < 0.5 and d['gradient_mb'] > 1000
+    assert d['lr'] == 1e-3 * 2 * 6
