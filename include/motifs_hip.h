@@ -445,8 +445,12 @@ int mh_bn_bwd(const float *x, const float *g, const unsigned char *argmax, long 
               float *dgamma, float *dbeta, void *workspace, size_t ws_bytes, void *stream);
 
 /* The tower's FIRST convolution, direct (replaces nn.Conv2d(2, dim/2, kernel_size=7, stride=2, padding=3) + ReLU of
- * /root/reference lib/get_union_boxes.py:31-32 on the [N,S,S,2] NHWC masks of draw_union_boxes, S = 27): thread = output
- * channel with its 98 weights in registers, mask values through the scalar cache, exact fp32 FMAs; no column matrix.
+ * /root/reference lib/get_union_boxes.py:31-32 on the [N,S,S,2] NHWC masks of draw_union_boxes, S = 27); no column matrix.
+ * Round 6: on the matrix cores -- every lane builds its MFMA fragments straight from the padded masks (a kernel row = 14
+ * contiguous floats = one 16-deep k-tile); forward f16x3 (masks scaled by 2^14, per-channel weight exponents), weight gradient
+ * bf16x6 with one output row per k-tile; fp32 products as everywhere.  MH_TOWER_CONV1=valu (environment, read per
+ * call) selects round 4's kernels: thread = output channel with its 98 weights in registers, mask values through the scalar
+ * cache, exact fp32 FMAs.
  *   mh_tower_conv1_out_size      : output height = width for mask size S (27 -> 14)
  *   mh_tower_conv1_padded_bytes  : bytes of the zero-padded mask copy [N, S+6, S+6, 2] (kept for the weight gradient)
  *   mh_tower_conv1_pad           : rects [N,S,S,2] -> padded

@@ -661,8 +661,10 @@ __global__ __launch_bounds__(256) void tower_conv1_mfma_wgrad_kernel(const float
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[mb][nb][r] = 0.f;
     float bsum[2] = {0.f, 0.f};
-    float av[4][8], dv[2][8];                                              // the raw values of the NEXT output row
-    auto fetch = [&](long long row) {
+    // the raw values of the next TWO output rows (one wave per SIMD: with one row in flight an iteration took 3 us, the latency of
+    // its 48 loads, against 0.7 us of MFMAs -- gpurun r06_c10: 256 us for 84 rows per block)
+    float av[2][4][8], dv[2][2][8];
+    auto fetch = [&](float (&a_)[4][8], float (&d_)[2][8], long long row) {
         const bool rok = row < r1;
         const long long rc = rok ? row : r1 - 1;
         const long long n = rc / Ho;
@@ -673,26 +675,25 @@ __global__ __launch_bounds__(256) void tower_conv1_mfma_wgrad_kernel(const float
         for (int i = 0; i < 8; ++i) {
             const bool pok = rok && 8 * g + i < Wo;                        // pixels 14, 15 of the padded row carry nothing
 #pragma unroll
-            for (int mb = 0; mb < 4; ++mb) av[mb][i] = (pok && tap_ok[mb]) ? xrow[tap_off[mb] + i * kT1Stride * kT1C] : 0.f;
+            for (int mb = 0; mb < 4; ++mb) a_[mb][i] = (pok && tap_ok[mb]) ? xrow[tap_off[mb] + i * kT1Stride * kT1C] : 0.f;
 #pragma unroll
-            for (int nb = 0; nb < 2; ++nb) dv[nb][i] = pok ? drow[(size_t)i * C0 + 32 * nb] : 0.f;
+            for (int nb = 0; nb < 2; ++nb) d_[nb][i] = pok ? drow[(size_t)i * C0 + 32 * nb] : 0.f;
         }
     };
-    if (r0 < r1) fetch(r0);
-    for (long long row = r0; row < r1; ++row) {
+    auto step = [&](float (&a_)[4][8], float (&d_)[2][8], long long next_row) {
         unsigned a[4][3][4], d[2][3][4];
 #pragma unroll
         for (int mb = 0; mb < 4; ++mb)
 #pragma unroll
-            for (int i = 0; i < 4; ++i) split3_bf16(av[mb][2 * i], av[mb][2 * i + 1], a[mb][0][i], a[mb][1][i], a[mb][2][i]);
+            for (int i = 0; i < 4; ++i) split3_bf16(a_[mb][2 * i], a_[mb][2 * i + 1], a[mb][0][i], a[mb][1][i], a[mb][2][i]);
 #pragma unroll
         for (int nb = 0; nb < 2; ++nb) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) split3_bf16(dv[nb][2 * i], dv[nb][2 * i + 1], d[nb][0][i], d[nb][1][i], d[nb][2][i]);
+            for (int i = 0; i < 4; ++i) split3_bf16(d_[nb][2 * i], d_[nb][2 * i + 1], d[nb][0][i], d[nb][1][i], d[nb][2][i]);
 #pragma unroll
-            for (int i = 0; i < 8; ++i) bsum[nb] += dv[nb][i];
+            for (int i = 0; i < 8; ++i) bsum[nb] += d_[nb][i];
         }
-        fetch(row + 1);                                                    // flies under the 48 MFMAs below
+        fetch(a_, d_, next_row);                                           // flies under this row's and the next row's MFMAs
         constexpr int kTa[6] = {2, 0, 1, 1, 0, 0}, kTd[6] = {0, 2, 1, 0, 1, 0};   // b3 d1, b1 d3, b2 d2, b2 d1, b1 d2, b1 d1
 #pragma unroll
         for (int t = 0; t < 6; ++t)
@@ -704,6 +705,14 @@ __global__ __launch_bounds__(256) void tower_conv1_mfma_wgrad_kernel(const float
                     const bf16x8 fd = __builtin_bit_cast(bf16x8, (u32x4){d[nb][kTd[t]][0], d[nb][kTd[t]][1], d[nb][kTd[t]][2], d[nb][kTd[t]][3]});
                     acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fd, acc[mb][nb], 0, 0, 0);
                 }
+    };
+    if (r0 < r1) {
+        fetch(av[0], dv[0], r0);
+        fetch(av[1], dv[1], r0 + 1);
+    }
+    for (long long row = r0; row < r1; row += 2) {
+        step(av[0], dv[0], row + 2);
+        if (row + 1 < r1) step(av[1], dv[1], row + 3);
     }
     // ---- partial[b][k][c]: lane (channel j, g), register r of block mb = tap row 32 mb + 8 (r / 4) + 4 g + r % 4
     float *out = partial + (size_t)blockIdx.x * (kT1Taps + 1) * C0 + c0 + j;
@@ -855,8 +864,8 @@ int mh_bn_bwd(const float *x, const float *g, const unsigned char *argmax, long 
 // ---- the tower's first convolution: matrix cores (t1::, round 6) unless MH_TOWER_CONV1=valu (the direct kernels) ----
 static bool tower_conv1_on_mfma()
 {
-    static const bool on = [] { const char *e = getenv("MH_TOWER_CONV1"); return !(e && std::string(e) == "valu"); }();
-    return on;
+    const char *e = getenv("MH_TOWER_CONV1");          // read per call: the tests run both forms in one process
+    return !(e && std::string(e) == "valu");
 }
 static int check_t1(long long N, int S, int C0)
 {

@@ -35,9 +35,11 @@ class _MaxPoolNHWC(nn.MaxPool2d):
         return y.permute(0, 2, 3, 1)
 
 
-# the tower's first convolution: 'direct' = csrc/tower.hip tower_conv1_* (mask values through the scalar cache, exact fp32 FMAs, no
-# column matrix; shapes the kernels do not cover fall through to the other path), 'gemm' = im2col + the in-loop-split GEMM of
-# rounds 1-3.  MOTIFS_TOWER_CONV1=gemm for A/B runs (gpurun r04_c21: 17.12 vs 17.26 ms per cfg2 step, p50 16.67 vs 16.98).
+# the tower's first convolution: 'direct' = csrc/tower.hip, no column matrix -- since round 6 on the matrix cores (t1::tower_conv1_mfma_*:
+# MFMA fragments built straight from the zero-padded masks, f16x3 forward, bf16x6 weight gradient; MH_TOWER_CONV1=valu = the round-4
+# kernels, mask values through the scalar cache and exact fp32 FMAs; shapes the kernels do not cover fall through to the other path),
+# 'gemm' = im2col + the small-product engine.  MOTIFS_TOWER_CONV1=gemm for A/B runs.  gpurun r06_c10, same box, alternating:
+# 415.0 / 418.5 img/s (14.46 / 14.34 ms per cfg2 step) on the matrix cores against 408.1 / 407.2 (14.70 / 14.74) on the VALU kernels.
 TOWER_CONV1 = os.environ.get('MOTIFS_TOWER_CONV1', 'direct')
 
 

@@ -52,6 +52,30 @@ def grad_close(got, ref, what='', rtol=1e-4, max_flipped_rows=0):
     assert err.max() <= 5e-2 * mag, what
 
 
+def unforced_report(tag, named_grads, forced, unforced):
+    """the gradient comparison AGAIN with the oracle's OWN ReLU / max-pool decisions, printed beside the
+    asserted, forced one (never asserted: a unit within rounding of a kink that the two sides decide differently moves a whole
+    row of a gradient by its full contribution -- that is the kink, not an arithmetic error; how rare and how close to the kink
+    those units are IS asserted, by assert_genuine_kinks).  named_grads: [(name, product grad ndarray)]; forced / unforced:
+    {name: oracle grad ndarray}.  Returns (worst forced, worst unforced) as fractions of each tensor's own maximum."""
+    worst_f, worst_u, rows = 0.0, 0.0, []
+    for name, got in named_grads:
+        got = np.asarray(got, dtype=np.float64)
+        out = []
+        for ref in (forced[name], unforced[name]):
+            ref = np.asarray(ref, dtype=np.float64)
+            mag = float(np.abs(ref).max()) if ref.size else 0.0
+            out.append(float(np.abs(got - ref).max()) / mag if mag > 0.0 else 0.0)
+        worst_f, worst_u = max(worst_f, out[0]), max(worst_u, out[1])
+        rows.append((name, out[0], out[1]))
+    print('%s: error of every trainable gradient as a fraction of its own maximum -- oracle with the product\'s kink decisions '
+          '(asserted above) | oracle with its OWN decisions (printed only)' % tag)
+    for name, f, u in rows:
+        print('  %-44s forced %.2e | un-forced %.2e%s' % (name[-44:], f, u, '   <- differs' if u > 2.0 * max(f, 1e-7) else ''))
+    print('%s: worst of %d gradients: forced %.2e, un-forced %.2e of own max' % (tag, len(rows), worst_f, worst_u))
+    return worst_f, worst_u
+
+
 class ProductMasks(object):
     """Context manager: captures the product's ReLU masks (forward hooks on the Linear / ReLU modules; the fused tower
     reports through lib.get_union_boxes.TAPS) during the forward passes run inside it.  .force = {site name: CPU tensor}

@@ -143,7 +143,7 @@ def test_cfg2_sgcls_train_step_b6_1536_rows():
     from dataloaders.synthetic import make_blob
     from lib import rng
     from oracle import model as OM
-    from parity_util import ProductMasks, assert_genuine_kinks, grad_close, oracle_forced
+    from parity_util import ProductMasks, assert_genuine_kinks, grad_close, oracle_forced, unforced_report
     ds, model, sd_init = build('sgcls', 1234 + 200, 6)
     sd = calibrated(sd_init)
     model.cuda().train()
@@ -184,6 +184,13 @@ def test_cfg2_sgcls_train_step_b6_1536_rows():
         grad_close(p.grad.cpu().numpy(), params[name].grad.numpy(), what='cfg2 grad ' + name[-24:])
         checked += 1
     assert checked >= 30
+    # the same gradients against the oracle with its OWN kink decisions: printed beside the forced figures, not asserted
+    params_u = {k: v.clone().requires_grad_(k in trainable) for k, v in sd.items()}
+    out_u = OM.relmodel_forward(params_u, dict(MODEL_KW, mode='sgcls'), a[0], a[1], 0, a[3], a[4], True, OM.HostRNG(77),
+                                rel_labels=res.rel_labels.cpu())
+    (F.cross_entropy(out_u['rm_obj_dists'], out_u['rm_obj_labels']) + F.cross_entropy(out_u['rel_dists'], out_u['rel_labels'][:, -1])).backward()
+    unforced_report('cfg2', [(n, p.grad.cpu().numpy()) for n, p in model.named_parameters() if p.requires_grad],
+                    {n: params[n].grad.numpy() for n in trainable}, {n: params_u[n].grad.numpy() for n in trainable})
 
     # the same step at the reference's own initialisation (forward only): O(1e2) relation logits, relative bound
     model.load_state_dict({k: v.clone() for k, v in sd_init.items()})
@@ -273,7 +280,7 @@ def test_cfg4_resnet_sgcls_train_step_b6_1536_rows():
     from lib import rng
     from lib.rel_model import RelModel
     from oracle import model as OM
-    from parity_util import ProductMasks, assert_genuine_kinks, grad_close, oracle_forced, rel_close
+    from parity_util import ProductMasks, assert_genuine_kinks, grad_close, oracle_forced, rel_close, unforced_report
     seed = 1234 + 400
     torch.manual_seed(seed)
     np.random.seed(seed)
@@ -348,6 +355,15 @@ def test_cfg4_resnet_sgcls_train_step_b6_1536_rows():
         grad_close(p.grad.cpu().numpy(), osd[name].grad.numpy(), what='cfg4 grad ' + name[-30:])
         checked += 1
     assert checked >= 80                                   # 2 x 30 layer4 tensors + context + tower + tail
+    # the same gradients against the oracle with its OWN kink decisions: printed beside the forced figures, not asserted
+    osd_u = {k: v.clone().requires_grad_(k in trainable) for k, v in sd.items()}
+    ref_u = OM.relmodel_forward(osd_u, dict(cfg, use_resnet=True, use_vision=True), x, im_sizes, off, gt_boxes, gt_classes, True,
+                                OM.HostRNG(41), rel_labels=res.rel_labels.cpu(), det_override=det)
+    (F.cross_entropy(ref_u['rm_obj_dists'], ref_u['rm_obj_labels']) + F.cross_entropy(ref_u['rel_dists'], ref_u['rel_labels'][:, -1])).backward()
+    names_u = [n for n in sorted(trainable) if n != 'union_boxes.conv.6.bias']
+    pg = dict(model.named_parameters())
+    unforced_report('cfg4', [(n, pg[n].grad.cpu().numpy()) for n in names_u], {n: osd[n].grad.numpy() for n in names_u},
+                    {n: osd_u[n].grad.numpy() for n in names_u})
     # running statistics after ONE training step: momentum 0.01 (the reference's own Bottleneck), unbiased variance
     msd = model.state_dict()
     for stack in ('roi_fmap', 'roi_fmap_obj'):
