@@ -53,7 +53,7 @@ for p in (ROOT, os.path.join(ROOT, 'neural-motifs_amd')):
 
 PEAK_FP32_MFMA_TFLOPS = 157.3          # /opt/skills/guides/MI355X_MICROARCH.md chip table (f32-input MFMA)
 PEAK_BF16_MFMA_TFLOPS = 2500.0         # same table, dense bf16 MFMA
-GEMM_TRAFFIC_SUMMARY = 'profiles/r05_gemm_traffic_summary.json'   # tools/r05/gemm_traffic_summary.py (the step's big products on plane images)
+GEMM_TRAFFIC_SUMMARY = 'profiles/r06_gemm_traffic_summary.json'   # tools/r05/gemm_traffic_summary.py (the step's big products on plane images, XCD-banded order)
 TRAFFIC_SUMMARY = 'profiles/r04_conv_traffic_summary.json'   # tools/r04/traffic_summary.py (ring trunk, shipped schedule)
 PEAK_HBM_TBS = 8.0                     # same table, HBM3E
 # every product is an fp32 product (operands, accumulation and results fp32, 1e-4 parity against the fp32 oracle); the matrix cores
@@ -900,6 +900,7 @@ def main():
             e = torch.cuda.Event(enable_timing=True)
             e.record()
             return e
+        model.stream_marks = []
         for i in range(args.h2d_steps):
             marks.append([_ev(), None, None, None, None])
             blob = blobs[i % len(blobs)]
@@ -918,9 +919,14 @@ def main():
         torch.cuda.synchronize()
         seg = [[a.elapsed_time(b) for a, b in zip(m[:-1], m[1:])] for m in marks[1:]]
         n = max(len(seg), 1)
+        waits = [a.elapsed_time(b) for a, b in model.stream_marks[1:]]
+        model.stream_marks = None
         segments = {'detector_stage_ms': sum(x[0] for x in seg) / n, 'rest_of_forward_ms': sum(x[1] for x in seg) / n,
                     'backward_ms': sum(x[2] for x in seg) / n, 'optimizer_ms': sum(x[3] for x in seg) / n, 'steps': len(seg),
-                    'what': 'HIP events on the main stream, unprofiled, meters off; the detector stage = frozen trunk + RoI head of the GT boxes'}
+                    'main_waits_for_context_ms': (sum(waits) / len(waits)) if waits else None,
+                    'what': 'HIP events on the main stream, unprofiled, meters off; the detector stage = frozen trunk + RoI head of the GT boxes; '
+                            'main_waits_for_context_ms = part of rest_of_forward in which the main stream (union-box branch done) waits for '
+                            'the context branch on the other stream'}
     if world > 1:
         torch.distributed.barrier()
 
@@ -1084,7 +1090,7 @@ def main():
             'traffic_algorithmic': gemm_traffic['algorithmic_bytes_per_launch'] if gemm_traffic else None,
             'traffic_source': GEMM_TRAFFIC_SUMMARY + ' (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over one launch per shape -- fc6 forward / '
                               'input gradient / weight gradient at 1536 rows, the 120-row object fc6, fc7 -- with the shipped library, tools/traffic_run.sh gemm, '
-                              'gpurun r05_c19; replayed offline: a PMC pass over the whole step does not finish)'}
+                              'gpurun r06_c1 (XCD-banded tile order; round 5: 3.09x); replayed offline: a PMC pass over the whole step does not finish)'}
         # which kernel class takes more of the step by HIP-event time (the verdict of round 2 noted that GEMM-class work exceeds
         # the conv's: both rooflines are reported, this names the larger one)
         line['dominant_by_time'] = {'class': 'gemm' if gm['total_ms'] > conv['total_ms'] else 'conv3x3',

@@ -625,7 +625,15 @@ class RelModel(nn.Module):
             else:
                 vr = self.visual_rep(fmap, rois, rel_inds[:, 1:])
                 edge_rep = early_edge_rep
+            marks = getattr(self, 'stream_marks', None)      # measurement hook (bench.py): how long the main stream waits here
+            if marks is not None:
+                e0 = torch.cuda.Event(enable_timing=True)
+                e0.record(main)
             main.wait_stream(side)
+            if marks is not None:
+                e1 = torch.cuda.Event(enable_timing=True)
+                e1.record(main)
+                marks.append((e0, e1))
             for t in (edge_rep, result.obj_fmap, result.rm_obj_dists, result.obj_preds):
                 if torch.is_tensor(t):
                     t.record_stream(main)

@@ -354,7 +354,21 @@ def test_conv_traffic_summary_matches_the_committed_counter_files():
     assert all(r['read_bytes'] >= r['read_bytes_algorithmic'] and r['write_bytes'] >= 0.999 * r['write_bytes_algorithmic'] for r in rows.values())
     assert 4.0 < rows['fc6_fwd_M1536']['read_ratio'] < 4.2 and rows['fc6_fwd_M1536']['k_slices'] == 5
     assert 2.5 < committed['ratio'] < 3.5
-    assert os.path.samefile(bench.GEMM_TRAFFIC_SUMMARY, prof('r05_gemm_traffic_summary.json'))
+    # round 6: the XCD-banded tile order (gpurun r06_c1, same box, same launches as the MH_GEMM_ORDER=0 passes beside it)
+    for tag, suffix, label in (('new', '', 'r06_c1, XCD-banded tile order'), ('old', '_order0', "r06_c1, MH_GEMM_ORDER=0: round 5's tile order")):
+        buf = io.StringIO()
+        with contextlib.redirect_stdout(buf):
+            mod5.main(prof('r06_gemm_traffic_launches.jsonl'), prof('r06_gemm_traffic_fetch_size_%s.csv' % tag),
+                      prof('r06_gemm_traffic_write_size_%s.csv' % tag), label)
+        with open(prof('r06_gemm_traffic_summary%s.json' % suffix)) as f:
+            c6 = json.load(f)
+        assert json.loads(buf.getvalue()) == c6 and c6['launches'] == 5
+        r6 = {r['name']: r for r in c6['per_launch']}
+        if tag == 'new':
+            assert 2.0 < c6['ratio'] < 2.5 and r6['fc6_fwd_M1536']['read_ratio'] < 2.0          # 3.0 -> 2.24; fc6 forward 4.1 -> 1.8
+        else:
+            assert 2.8 < c6['ratio'] < 3.3 and r6['fc6_fwd_M1536']['read_ratio'] > 3.8
+    assert os.path.samefile(bench.GEMM_TRAFFIC_SUMMARY, prof('r06_gemm_traffic_summary.json'))
 
 def test_resnet_relation_model_matches_the_oracle(shim):
     """BASELINE cfg4's model, RelModel(use_resnet=True), with the documented repair

@@ -2,7 +2,7 @@
 """Compact timeline of ONE training step from a rocprofv3 kernel trace: every launch as (start ms from the step's start, duration us,
 queue, kernel), plus per-queue busy time and, per kernel name, launches / total us.  A step ends with `multi_sgd_kernel`.
 
-    python tools/r04/step_timeline.py <kernel_trace.csv> [--step -2] > profiles/r04_step_timeline.txt
+    python tools/r04/step_timeline.py <kernel_trace.csv> [--step -2] [--all] > profiles/r04_step_timeline.txt
 """
 import csv
 import re
@@ -43,6 +43,11 @@ def main():
     print('\nper kernel (queue, name): launches, total us')
     for (q, n), (c, t) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:60]:
         print('  q%s %-80s %4d %9.1f' % (q, n, c, t / 1e3))
+    if '--all' in sys.argv:          # round 6: every launch, nothing folded (the glue between the kernels: which torch ops, in which order)
+        print('\nevery launch (start ms, duration us, queue, kernel)')
+        for a, b, n, q in seg:
+            print('  %8.3f %8.1f  q%s  %s' % ((a - t0) / 1e6, (b - a) / 1e3, q, re.sub(r'\(.*', '', n).replace('void ', '')[:150]))
+        return
     print('\ntimeline (start ms, duration us, queue, kernel); launches shorter than 20 us are folded into runs')
     run = None
     for a, b, n, q in seg:

@@ -38,7 +38,7 @@ def calls(rows):
     return out
 
 
-def main(launch_path, fetch_path, write_path):
+def main(launch_path, fetch_path, write_path, tag='r05_c19'):
     launches = [json.loads(l) for l in open(launch_path)]
     fetch, write = calls(rows_of(fetch_path)), calls(rows_of(write_path))
     assert len(fetch) == len(write) == len(launches), (len(fetch), len(write), len(launches))
@@ -60,10 +60,10 @@ def main(launch_path, fetch_path, write_path):
     print(json.dumps({
         'what': 'fabric-side (L2 miss) bytes of the step\'s big matrix products on plane images, one launch per shape (fc6 forward / '
                 'input gradient / weight gradient at 1536 rows, the 120-row object fc6, fc7); rocprofv3 --pmc FETCH_SIZE and --pmc '
-                'WRITE_SIZE in separate passes (tools/traffic_run.sh gemm, gpurun r05_c19)',
+                'WRITE_SIZE in separate passes (tools/traffic_run.sh gemm, gpurun %s)' % tag,
         'fetch_correction': round(k_rd, 4), 'write_correction': round(k_wr, 4), 'launches': n,
         'bytes_per_launch': tot / n, 'algorithmic_bytes_per_launch': alg / n, 'ratio': tot / alg, 'per_launch': rows}, indent=1))
 
 
 if __name__ == '__main__':
-    main(*sys.argv[1:4])
+    main(*sys.argv[1:5])
