@@ -194,3 +194,46 @@ def test_detection_rows_and_dataset_ground_truth():
     np.testing.assert_allclose(dets[:5, 1:5], gt.xywh[0], atol=1e-3)
     stats = DM.evaluate_bbox(gt, dets, range(4))
     assert 0.9 < stats[1] <= 1.0
+
+
+def test_hand_computed_three_images_two_categories():
+    """a 3-image, 2-category fixture whose twelve COCO statistics are derived by hand below from the published
+    protocol (cocoeval.py: greedy matching in score order per IoU threshold, non-ignored ground truth first, a matched ground
+    truth is skipped by later detections, unmatched detections outside the area range are ignored; precision made monotone from
+    the right and sampled at 101 recall points, 0 where the recall is never reached; categories without a non-ignored ground
+    truth are left out of the mean).
+
+    ground truth   img0: A cat1 100x100 (large), B cat2 30x30 (small)    img1: C cat1 60x60 (medium)    img2: D cat2 50x50 (medium)
+    cat1 detections  d1 .9 img0 = A;  d2 .8 img1 = C shifted 6 px (IoU 3240/3960 = .818: a hit up to .80);  d3 .7 img2 50x50, no
+                     cat1 ground truth there;  d4 .6 img1 = C exactly
+    cat2 detections  e1 .95 img2 = D;  e2 .5 img0 = B shifted 5 px (IoU 750/1050 = .714: a hit up to .70)"""
+    gt = DM.FauxCoco([[1, 2], [1], [2]],
+                     [[[0, 0, 99, 99], [200, 200, 229, 229]], [[50, 50, 109, 109]], [[0, 0, 49, 49]]], num_classes=3, first_ann_id=1)
+    dets = [xyxy_to_det(0, [0, 0, 99, 99], 0.9, 1), xyxy_to_det(1, [56, 50, 115, 109], 0.8, 1), xyxy_to_det(2, [10, 10, 59, 59], 0.7, 1),
+            xyxy_to_det(1, [50, 50, 109, 109], 0.6, 1),
+            xyxy_to_det(2, [0, 0, 49, 49], 0.95, 2), xyxy_to_det(0, [205, 200, 234, 229], 0.5, 2)]
+    np.testing.assert_allclose(DM.box_iou_xywh([[56, 50, 60, 60]], [[50, 50, 60, 60]], [False]), [[3240.0 / 3960.0]])
+    np.testing.assert_allclose(DM.box_iou_xywh([[205, 200, 30, 30]], [[200, 200, 30, 30]], [False]), [[750.0 / 1050.0]])
+    s = DM.evaluate_bbox(gt, dets)
+    half = 51.0 / 101.0            # precision 1 up to recall .5 (51 of the 101 points), recall never above .5
+    # cat1, thresholds .50-.80 (7): d1 TP, d2 TP, d3 FP, d4 FP (C is taken) -> precision 1 up to recall 1: AP 1
+    #       thresholds .85-.95 (3): d1 TP (r .5, p 1), d2 FP, d3 FP, d4 TP (r 1, p 2/4) -> 51 points at 1, 50 at .5: 76/101
+    ap1 = (7 * 1.0 + 3 * (76.0 / 101.0)) / 10
+    # cat2, thresholds .50-.70 (5): e1 TP, e2 TP: AP 1;  .75-.95 (5): e1 TP, e2 FP, recall stops at .5: 51/101
+    ap2 = (5 * 1.0 + 5 * half) / 10
+    want = {
+        'AP': (ap1 + ap2) / 2, 'AP50': 1.0, 'AP75': (1.0 + half) / 2,
+        # small (B only; cat1 has no small ground truth and drops out): e1 sits on D (ignored) and is ignored; e2 hits B up to .70,
+        # above that it is an unmatched small detection = FP with no TP at all -> 0
+        'APs': 0.5,
+        # medium (C, D): cat1 -- d1 on A (ignored) is ignored, d3 50x50 is a medium FP; .50-.80: d2 TP first -> 1;
+        # .85-.95: d2 FP, d3 FP, d4 TP -> precision 1/3 at every recall -> (7 + 3/3) / 10 = .8;  cat2 -- e1 TP, e2 ignored -> 1
+        'APm': (0.8 + 1.0) / 2,
+        # large (A): d1 TP; d2 / d4 on C (ignored) or unmatched-and-medium are ignored, d3 medium is ignored; cat2 drops out
+        'APl': 1.0,
+        # one detection per image and category: cat1 keeps d1, d2, d3 -> recall 1 up to .80, .5 above: .85; cat2 keeps both: .75
+        'AR1': (0.85 + 0.75) / 2,
+        'AR10': (1.0 + 0.75) / 2, 'AR100': (1.0 + 0.75) / 2,     # d4 recovers C above .80
+        'ARs': 0.5, 'ARm': 1.0, 'ARl': 1.0}
+    for name, got in zip(DM.STAT_NAMES, s):
+        assert abs(got - want[name]) < 1e-9, (name, got, want[name])

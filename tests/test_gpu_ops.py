@@ -563,13 +563,14 @@ def test_mask_tower_first_convolution_in_its_three_forms_agree(hip, monkeypatch)
     direct VALU kernels and on im2col + GEMM.  The forms round differently, so a unit within rounding of a kink (the two ReLUs,
     the max-pool) may be decided differently: such a unit moves gradients by its whole contribution (a conv.4 flip moves EVERY
     gradient upstream of it: gpurun r06_c11, one flip of 2.4 M units = 5.5e-3 of conv.4.weight's gradient at 96 pairs) -- that is
-    the kink, not arithmetic.  The kink decisions of every form are captured (lib.get_union_boxes.TAPS): at most 4 of the 7.2 M
-    may differ between two forms, and the gradients are compared on a draw where none does."""
+    the kink, not arithmetic; at 96 pairs = 7.2 M kink units every draw has 1-4 such units between ANY two forms, r06_c12).  The
+    kink decisions of every form are captured (lib.get_union_boxes.TAPS): at most 4 may differ between two forms, and the
+    gradients are compared on a draw where none does (6 pairs = 0.45 M units: most draws)."""
     import lib.get_union_boxes as GUB
     from parity_util import grad_close
-    N = 96
+    N = 6
     forms = (('gemm', 'gemm', 'valu'), ('valu', 'direct', 'valu'), ('mfma', 'direct', 'mfma'))
-    for seed in (5, 6, 7, 8, 9):
+    for seed in range(5, 17):
         torch.manual_seed(seed)
         tower = GUB.UnionBoxesAndFeats(pooling_size=7, stride=16, dim=512).cuda().train()
         rects = torch.rand(N, 27, 27, 2).cuda()
@@ -596,7 +597,7 @@ def test_mask_tower_first_convolution_in_its_three_forms_agree(hip, monkeypatch)
         if max(flips.values()) == 0:
             break
     else:
-        raise AssertionError('no draw without a differing kink decision in 5 seeds')
+        raise AssertionError('no draw without a differing kink decision in 12 seeds')
     names = ['output'] + [n for n, _ in tower.named_parameters()]
     for form in ('valu', 'mfma'):
         for name, a, d in zip(names, res['gemm'], res[form]):
