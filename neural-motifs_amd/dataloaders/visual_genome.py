@@ -4,9 +4,10 @@ Visual Genome dataset + loader with the reference's entry points (dataloaders/vi
 
 On-disk formats: `VG-SGG.h5` (split mask, boxes_1024 in (xc,yc,w,h), labels, img_to_first/last
 box / rel, relationships, predicates), `VG-SGG-dicts.json`, `image_data.json`, the JPEGs.  The HDF5 container is read
-with h5py when it is importable; the same arrays saved with `numpy.savez` (`*.npz`) are accepted everywhere a `.h5` is,
-so the logic is testable -- and pinned against the reference's own `load_graphs` / `load_info` / `VG.__getitem__` -- in
-an environment without h5py (tests/test_vg_loader.py, goldens from tests/golden/make_golden.py).
+with h5py when it is importable and with dataloaders/h5lite.py (pure Python, round 6) otherwise; the same arrays saved with
+`numpy.savez` (`*.npz`) are accepted everywhere a `.h5` is.  The logic is pinned against the reference's own `load_graphs` /
+`load_info` / `VG.__getitem__` (tests/test_vg_loader.py, goldens from tests/golden/make_golden.py), the container format
+against files written by the real HDF5 library (tests/test_h5lite.py, tests/golden/make_vg_h5.py).
 
 When the VG files are absent (this build / benchmark environment) `VG.splits` serves the synthetic VG-shaped dataset
 (dataloaders/synthetic.py) with the same entry dict and attributes; the drivers do not change.
@@ -28,14 +29,16 @@ from lib.fpn.box_intersections_cpu.bbox import bbox_overlaps
 
 
 def _open_arrays(path):
-    """mapping name -> array-like supporting [:] and fancy indexing: an h5py.File, or a numpy .npz with the same keys"""
+    """mapping name -> array-like supporting [:] and fancy indexing: an h5py.File when h5py is importable, else the pure-Python
+    reader of dataloaders/h5lite.py (the HDF5 subset VG-SGG.h5 and the proposal file use, pinned against files written by the
+    real library: tests/test_h5lite.py); a numpy .npz with the same keys is accepted everywhere a .h5 is"""
     if str(path).endswith('.npz'):
         return np.load(path)
     try:
         import h5py
     except ImportError:
-        raise ImportError('reading %s needs h5py (not installed here); convert it once with '
-                          'numpy.savez(path.npz, **{k: f[k][:] for k in f}) and pass the .npz' % path)
+        from dataloaders import h5lite
+        return h5lite.File(path, 'r')
     return h5py.File(path, 'r')
 
 
