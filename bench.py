@@ -54,7 +54,7 @@ for p in (ROOT, os.path.join(ROOT, 'neural-motifs_amd')):
 PEAK_FP32_MFMA_TFLOPS = 157.3          # /opt/skills/guides/MI355X_MICROARCH.md chip table (f32-input MFMA)
 PEAK_BF16_MFMA_TFLOPS = 2500.0         # same table, dense bf16 MFMA
 GEMM_TRAFFIC_SUMMARY = 'profiles/r06_gemm_traffic_summary.json'   # tools/r05/gemm_traffic_summary.py (the step's big products on plane images, XCD-banded order)
-TRAFFIC_SUMMARY = 'profiles/r04_conv_traffic_summary.json'   # tools/r04/traffic_summary.py (ring trunk, shipped schedule)
+TRAFFIC_SUMMARY = 'profiles/r06_conv_traffic_summary.json'   # tools/r04/traffic_summary.py (ring trunk with the step's image / pooled-image epilogues, round 6)
 PEAK_HBM_TBS = 8.0                     # same table, HBM3E
 # every product is an fp32 product (operands, accumulation and results fp32, 1e-4 parity against the fp32 oracle); the matrix cores
 # evaluate it from 16-bit terms: big products as f16x3 (two f16 terms of row-scaled operands, 3 MFMAs), small ones as bf16x6
@@ -1063,7 +1063,8 @@ def main():
                          'traffic_unit': 'bytes per launch (L2 fabric side: HBM + Infinity-Cache)',
                          'traffic_algorithmic': traffic['algorithmic_bytes_per_launch'] if traffic else None,
                          'traffic_source': TRAFFIC_SUMMARY + ' (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over one '
-                                           'launch per trunk layer of this step with the shipped library, tools/r04/traffic.sh; replayed offline: a '
+                                           'launch per trunk layer of this step with the shipped library and the step\'s epilogues (image / pooled image / fp32, '
+                                           'conv5 in K slices added up in the launch), tools/r04/traffic.sh, gpurun r06_c13; replayed offline: a '
                                            'PMC pass over the whole step does not finish); covers the 12 plane-trunk launches',
                          'frac_of_f32_mfma_peak': conv['tflops'] / PEAK_FP32_MFMA_TFLOPS,
                          'frac_of_bf16x6_peak': conv['tflops'] / (PEAK_BF16_MFMA_TFLOPS / 6.0),

@@ -1171,7 +1171,16 @@ __global__ __launch_bounds__(256) void image_absmax_kernel(const float *__restri
 {
     const float *p = x + (size_t)blockIdx.y * n;
     unsigned m = 0;
-    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) m = max(m, __float_as_uint(p[i]) & 0x7fffffffu);
+    if ((n & 3) == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0) {       // 16-byte loads (round 6: 4-byte loads ran at 1.4-2.2 TB/s, r06_c9)
+        const u32x4 *q = reinterpret_cast<const u32x4 *>(p);
+        const long long n4 = n >> 2;
+        for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+            const u32x4 v = q[i];
+            m = max(max(m, v.x & 0x7fffffffu), max(max(v.y & 0x7fffffffu, v.z & 0x7fffffffu), v.w & 0x7fffffffu));
+        }
+    } else {
+        for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) m = max(m, __float_as_uint(p[i]) & 0x7fffffffu);
+    }
     wave_atomic_max(bits, (int)blockIdx.y, m);
 }
 

@@ -677,6 +677,9 @@ int main(int argc, char **argv)
             {"conv3_2", 148, 256, 256, 1}, {"conv3_3", 148, 256, 256, 2}, {"conv4_1", 74, 256, 512, 1}, {"conv4_2", 74, 512, 512, 1},
             {"conv4_3", 74, 512, 512, 2}, {"conv5_1", 37, 512, 512, 1}, {"conv5_2", 37, 512, 512, 1}, {"conv5_3", 37, 512, 512, 0}};
         const int B = 6;
+        // --conv-replay N: every layer N times back to back (the counter passes then take the LAST launch of each layer: warm
+        // caches and clocks, as in the step, instead of the first launch after an idle gap)
+        const int reps = argc > 3 ? std::max(1, atoi(argv[3])) : 1;
         for (const L &l : layers) {
             const size_t nx = (size_t)B * l.H * l.H * l.Cin;
             Dev dx(nx * 4), dw((size_t)l.Cout * l.Cin * 9 * 4), db(l.Cout * 4), dmb(B * 4), dmbo(B * 4), dout((size_t)B * l.H * l.H * l.Cout * 4);
@@ -687,10 +690,12 @@ int main(int argc, char **argv)
             Dev img(act_bytes(B, l.H, l.H, l.Cin)), pk(plpacked_bytes(l.Cout, l.Cin)), ws3(plconv_ws(B, l.H, l.H, l.Cin, l.Cout));
             plpack(dw.f(), l.Cout, l.Cin, 0, pk.p, nullptr);
             act_planes(dx.f(), (const unsigned *)dmb.p, B, l.H, l.H, l.Cin, 0, img.p, nullptr);
-            int rc;
-            if (l.mode == 0) rc = plconv(img.p, B, l.H, l.H, l.Cin, pk.p, l.Cout, db.f(), 1, dout.f(), (unsigned *)dmbo.p, ws3.p, ws3.n, nullptr);
-            else if (l.mode == 1) rc = plconv_img(img.p, (const unsigned *)dmb.p, B, l.H, l.H, l.Cin, pk.p, l.Cout, db.f(), 1, dout.p, (unsigned *)dmbo.p, ws3.p, ws3.n, nullptr);
-            else rc = plconv_pool(img.p, (const unsigned *)dmb.p, B, l.H, l.H, l.Cin, pk.p, l.Cout, db.f(), 1, dout.p, (unsigned *)dmbo.p, ws3.p, ws3.n, nullptr);
+            int rc = 0;
+            for (int rep = 0; rep < reps; ++rep) {
+                if (l.mode == 0) rc = plconv(img.p, B, l.H, l.H, l.Cin, pk.p, l.Cout, db.f(), 1, dout.f(), (unsigned *)dmbo.p, ws3.p, ws3.n, nullptr);
+                else if (l.mode == 1) rc = plconv_img(img.p, (const unsigned *)dmb.p, B, l.H, l.H, l.Cin, pk.p, l.Cout, db.f(), 1, dout.p, (unsigned *)dmbo.p, ws3.p, ws3.n, nullptr);
+                else rc = plconv_pool(img.p, (const unsigned *)dmb.p, B, l.H, l.H, l.Cin, pk.p, l.Cout, db.f(), 1, dout.p, (unsigned *)dmbo.p, ws3.p, ws3.n, nullptr);
+            }
             HIP_OK(hipDeviceSynchronize());
             const double M = (double)B * l.H * l.H;
             printf("{\"layer\": \"%s\", \"H\": %d, \"Cin\": %d, \"Cout\": %d, \"epilogue\": \"%s\", \"rc\": %d, \"algorithmic_read_bytes\": %.0f, \"algorithmic_write_bytes\": %.0f, \"flops\": %.0f}\n",

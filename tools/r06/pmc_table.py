@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Per-layer PMC table of the trunk's convolution launches: joins the counter passes of tools/r04/pmc.sh
-over `pl_check --conv-replay` (one launch per trunk layer of the cfg2 step, each with the epilogue the step uses) with the replay's
+over `pl_check --conv-replay [N]` (the trunk layers of the cfg2 step, each with the epilogue the step uses, N launches per layer: the
+last one is tabulated) with the replay's
 launch list.
 
     python tools/r06/pmc_table.py <dir with set1.csv set2.csv set3.csv> <replay.jsonl> > profiles/r06_pmc_ring_table.txt
@@ -32,7 +33,9 @@ def main(d, replay):
     layers = [json.loads(l) for l in open(replay) if l.startswith('{"layer"')]
     pat = r'conv3x3_ring_kernel|pl::conv3x3_kernel'
     sets = [launches('%s/set%d.csv' % (d, i), pat) for i in (1, 2, 3)]
-    assert all(len(s) == len(layers) for s in sets), ([len(s) for s in sets], len(layers))
+    reps = len(sets[0]) // len(layers)                  # pl_check --conv-replay N: N launches per layer, the last one (warm) is tabulated
+    assert reps >= 1 and all(len(s) == reps * len(layers) for s in sets), ([len(s) for s in sets], len(layers))
+    sets = [s[reps - 1::reps] for s in sets]
     print(__doc__.split('\n\n')[2].replace('\n', '\n# ').join(['# ', '']))
     print('%-9s %-13s %-26s %7s %7s %6s %9s %7s %7s %7s %7s %9s %9s' % (
         'layer', 'epilogue', 'kernel', 'us', 'TF/s', 'GHz', 'pipe busy', 'VALU/M', 'SALU/M', 'LDS/M', 'VMEM/M', 'wait_any', 'LDS confl'))
