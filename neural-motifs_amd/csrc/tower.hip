@@ -648,37 +648,42 @@ __global__ __launch_bounds__(256) void tower_conv1_mfma_fwd_kernel(const float *
     }
 }
 
-// grid (row-range blocks, C0 / 256), block 256: wave w = channels 64 w .. 64 w + 63; partial[blockIdx.x][99][C0]
-__global__ __launch_bounds__(256) void tower_conv1_mfma_wgrad_kernel(const float *__restrict__ xp, long long N, int Sp, int Ho, int Wo,
-                                                                     const float *__restrict__ dy, int C0, int rows_per_block,
-                                                                     float *__restrict__ partial)
+// grid (row-range blocks, C0 / (128 NB)), block 256: wave w = channels 32 NB w .. of the block's group; partial[blockIdx.x][99][C0].
+// NB = n-blocks (32 channels) per wave: 2 ships (64 channels per wave, 128 accumulator registers); NB = 1 (MH_TOWER_WGRAD_NB=1: half
+// the accumulators, two blocks per CU) measured no faster (202 against 196 us per call, r06_c16).
+template <int NB>
+__global__ __launch_bounds__(256, 2) void tower_conv1_mfma_wgrad_kernel(const float *__restrict__ xp, long long N, int Sp, int Ho, int Wo,
+                                                                                      const float *__restrict__ dy, int C0, int rows_per_block,
+                                                                                      float *__restrict__ partial)
 {
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int j = lane & 31, g = lane >> 5;
-    const int c0 = (int)blockIdx.y * 256 + 64 * wave;
+    const int c0 = (int)blockIdx.y * (128 * NB) + 32 * NB * wave;
     const long long rows = N * Ho;
     const long long r0 = (long long)blockIdx.x * rows_per_block, r1 = min(rows, r0 + rows_per_block);
     // tap row 32 mb + j of the padded k' order: kernel row ky = 2 mb + (j >> 4), column t = j & 15 (14 real)
-    int tap_off[4];
-    bool tap_ok[4];
-#pragma unroll
-    for (int mb = 0; mb < 4; ++mb) {
-        const int ky = 2 * mb + (j >> 4), t = j & 15;
-        tap_ok[mb] = ky < kKy && t < kT1Row;
-        tap_off[mb] = tap_ok[mb] ? (ky * Sp * kT1C + t) : 0;
-    }
-    f32x16 acc[4][2];
+    const int my_ky = 2 * wave + (j >> 4), my_t = j & 15;                     // the tap block this wave fetches for the block: mb = wave
+    const bool my_tap_ok = my_ky < kKy && my_t < kT1Row;
+    const int my_tap_off = my_tap_ok ? (my_ky * Sp * kT1C + my_t) : 0;
+    f32x16 acc[4][NB];
 #pragma unroll
     for (int mb = 0; mb < 4; ++mb)
 #pragma unroll
-        for (int nb = 0; nb < 2; ++nb)
+        for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[mb][nb][r] = 0.f;
-    float bsum[2] = {0.f, 0.f};
-    // the raw values of the next TWO output rows (one wave per SIMD: with one row in flight an iteration took 3 us, the latency of
-    // its 48 loads, against 0.7 us of MFMAs -- gpurun r06_c10: 256 us for 84 rows per block)
-    float av[2][4][8], dv[2][2][8];
-    auto fetch = [&](float (&a_)[4][8], float (&d_)[2][8], long long row) {
+    float bsum[NB];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) bsum[nb] = 0.f;
+    // The mask fragments are the same for every wave of the block: wave w fetches and splits tap block w ONLY and hands its three
+    // bf16 planes to the others through LDS (two buffers, one barrier per output row).  With every wave fetching all four tap
+    // blocks itself the kernel was bound by its 32 + 8 NB gather loads per row, not by the MFMAs (256 / 273 us at NB = 2 / 1,
+    // r06_c10 / r06_c15).
+    __shared__ u32x4 a_lds[2][4][3][64];
+    float av[8], dv[NB][8];                                                // the raw values of the NEXT output row (tap block `wave`)
+    // (two rows in flight were measured on this form as well, r06_c16: 240 / 206 us per call at NB = 2 / 1 against 196 / 202 --
+    // the second row's registers cost more than its latency cover gives)
+    auto fetch = [&](long long row) {
         const bool rok = row < r1;
         const long long rc = rok ? row : r1 - 1;
         const long long n = rc / Ho;
@@ -688,45 +693,47 @@ __global__ __launch_bounds__(256) void tower_conv1_mfma_wgrad_kernel(const float
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const bool pok = rok && 8 * g + i < Wo;                        // pixels 14, 15 of the padded row carry nothing
+            av[i] = (pok && my_tap_ok) ? xrow[my_tap_off + i * kT1Stride * kT1C] : 0.f;
 #pragma unroll
-            for (int mb = 0; mb < 4; ++mb) a_[mb][i] = (pok && tap_ok[mb]) ? xrow[tap_off[mb] + i * kT1Stride * kT1C] : 0.f;
-#pragma unroll
-            for (int nb = 0; nb < 2; ++nb) d_[nb][i] = pok ? drow[(size_t)i * C0 + 32 * nb] : 0.f;
+            for (int nb = 0; nb < NB; ++nb) dv[nb][i] = pok ? drow[(size_t)i * C0 + 32 * nb] : 0.f;
         }
     };
-    auto step = [&](float (&a_)[4][8], float (&d_)[2][8], long long next_row) {
-        unsigned a[4][3][4], d[2][3][4];
+    if (r0 < r1) fetch(r0);
+    int buf = 0;
+    for (long long row = r0; row < r1; ++row, buf ^= 1) {
+        unsigned d[NB][3][4];
+        {
+            unsigned mine[3][4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) split3_bf16(av[2 * i], av[2 * i + 1], mine[0][i], mine[1][i], mine[2][i]);
+#pragma unroll
+            for (int pl_ = 0; pl_ < 3; ++pl_) a_lds[buf][wave][pl_][lane] = (u32x4){mine[pl_][0], mine[pl_][1], mine[pl_][2], mine[pl_][3]};
+        }
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) split3_bf16(dv[nb][2 * i], dv[nb][2 * i + 1], d[nb][0][i], d[nb][1][i], d[nb][2][i]);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) bsum[nb] += dv[nb][i];
+        }
+        __syncthreads();
+        fetch(row + 1);                                                    // flies under the MFMAs below
+        u32x4 a[4][3];
 #pragma unroll
         for (int mb = 0; mb < 4; ++mb)
 #pragma unroll
-            for (int i = 0; i < 4; ++i) split3_bf16(a_[mb][2 * i], a_[mb][2 * i + 1], a[mb][0][i], a[mb][1][i], a[mb][2][i]);
-#pragma unroll
-        for (int nb = 0; nb < 2; ++nb) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) split3_bf16(d_[nb][2 * i], d_[nb][2 * i + 1], d[nb][0][i], d[nb][1][i], d[nb][2][i]);
-#pragma unroll
-            for (int i = 0; i < 8; ++i) bsum[nb] += d_[nb][i];
-        }
-        fetch(a_, d_, next_row);                                           // flies under this row's and the next row's MFMAs
+            for (int pl_ = 0; pl_ < 3; ++pl_) a[mb][pl_] = a_lds[buf][mb][pl_][lane];
         constexpr int kTa[6] = {2, 0, 1, 1, 0, 0}, kTd[6] = {0, 2, 1, 0, 1, 0};   // b3 d1, b1 d3, b2 d2, b2 d1, b1 d2, b1 d1
 #pragma unroll
         for (int t = 0; t < 6; ++t)
 #pragma unroll
             for (int mb = 0; mb < 4; ++mb)
 #pragma unroll
-                for (int nb = 0; nb < 2; ++nb) {
-                    const bf16x8 fa = __builtin_bit_cast(bf16x8, (u32x4){a[mb][kTa[t]][0], a[mb][kTa[t]][1], a[mb][kTa[t]][2], a[mb][kTa[t]][3]});
+                for (int nb = 0; nb < NB; ++nb) {
+                    const bf16x8 fa = __builtin_bit_cast(bf16x8, a[mb][kTa[t]]);
                     const bf16x8 fd = __builtin_bit_cast(bf16x8, (u32x4){d[nb][kTd[t]][0], d[nb][kTd[t]][1], d[nb][kTd[t]][2], d[nb][kTd[t]][3]});
                     acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fd, acc[mb][nb], 0, 0, 0);
                 }
-    };
-    if (r0 < r1) {
-        fetch(av[0], dv[0], r0);
-        fetch(av[1], dv[1], r0 + 1);
-    }
-    for (long long row = r0; row < r1; row += 2) {
-        step(av[0], dv[0], row + 2);
-        if (row + 1 < r1) step(av[1], dv[1], row + 3);
     }
     // ---- partial[b][k][c]: lane (channel j, g), register r of block mb = tap row 32 mb + 8 (r / 4) + 4 g + r % 4
     float *out = partial + (size_t)blockIdx.x * (kT1Taps + 1) * C0 + c0 + j;
@@ -738,16 +745,16 @@ __global__ __launch_bounds__(256) void tower_conv1_mfma_wgrad_kernel(const float
             const int ky = kp >> 4, t = kp & 15;
             if (ky < kKy && t < kT1Row) {
 #pragma unroll
-                for (int nb = 0; nb < 2; ++nb) out[(size_t)(ky * kT1Row + t) * C0 + 32 * nb] = acc[mb][nb][r];
+                for (int nb = 0; nb < NB; ++nb) out[(size_t)(ky * kT1Row + t) * C0 + 32 * nb] = acc[mb][nb][r];
             }
         }
 #pragma unroll
-    for (int nb = 0; nb < 2; ++nb) {
+    for (int nb = 0; nb < NB; ++nb) {
         const float s = bsum[nb] + __shfl_xor(bsum[nb], 32);
         if (g == 0) out[(size_t)kT1Taps * C0 + 32 * nb] = s;
     }
 }
-constexpr int kWgradBlocks = 256;              // one row range per CU
+constexpr int kWgradBlocks = 512;              // at most two row ranges per CU (the workspace bound); MH_TOWER_WGRAD_BLOCKS picks fewer
 }  // namespace t1
 
 static int grid_for(long long total) { return (int)std::min<long long>((total + 255) / 256, 256 * 16); }
@@ -942,9 +949,15 @@ int mh_tower_conv1_wgrad(const float *padded, const float *dy_nhwc, long long N,
     float *partial = reinterpret_cast<float *>(workspace);
     if (tower_conv1_on_mfma()) {
         const long long rows = N * Ho;
-        const int per = (int)ceil_div(rows, (long long)t1::kWgradBlocks), nb = (int)ceil_div(rows, (long long)per);
-        hipLaunchKernelGGL(t1::tower_conv1_mfma_wgrad_kernel, dim3((unsigned)nb, (unsigned)(C0 / 256)), dim3(256), 0, st, padded, N,
-                           S + 2 * kT1Pad, Ho, Ho, dy_nhwc, C0, per, partial);
+        static const int want = [] { const char *e = getenv("MH_TOWER_WGRAD_BLOCKS"); const int v = e ? atoi(e) : 0; return (v >= 1 && v <= t1::kWgradBlocks) ? v : 256; }();
+        const int per = (int)ceil_div(rows, (long long)want), nb = (int)ceil_div(rows, (long long)per);
+        static const bool wide = [] { const char *e = getenv("MH_TOWER_WGRAD_NB"); return !(e && atoi(e) == 1); }();     // default 64 channels per wave, one block per CU (=1: 32 channels, two blocks per CU)
+        if (wide)
+            hipLaunchKernelGGL(t1::tower_conv1_mfma_wgrad_kernel<2>, dim3((unsigned)nb, (unsigned)(C0 / 256)), dim3(256), 0, st, padded, N,
+                               S + 2 * kT1Pad, Ho, Ho, dy_nhwc, C0, per, partial);
+        else
+            hipLaunchKernelGGL(t1::tower_conv1_mfma_wgrad_kernel<1>, dim3((unsigned)nb, (unsigned)(C0 / 128)), dim3(256), 0, st, padded, N,
+                               S + 2 * kT1Pad, Ho, Ho, dy_nhwc, C0, per, partial);
         rc = check_launch("tower_conv1_mfma_wgrad_kernel");
         if (rc) return rc;
         const int rows_c0 = (kT1Taps + 1) * C0;

@@ -680,6 +680,7 @@ int main(int argc, char **argv)
         // --conv-replay N: every layer N times back to back (the counter passes then take the LAST launch of each layer: warm
         // caches and clocks, as in the step, instead of the first launch after an idle gap)
         const int reps = argc > 3 ? std::max(1, atoi(argv[3])) : 1;
+        if (argc > 4) set_conv_splitk(atoi(argv[4]));          // measurement: every tile in that many K slices (1 = whole tiles, no tail slicing)
         for (const L &l : layers) {
             const size_t nx = (size_t)B * l.H * l.H * l.Cin;
             Dev dx(nx * 4), dw((size_t)l.Cout * l.Cin * 9 * 4), db(l.Cout * 4), dmb(B * 4), dmbo(B * 4), dout((size_t)B * l.H * l.H * l.Cout * 4);
