@@ -132,6 +132,13 @@ def test_rccl_reducer_beside_the_two_compute_streams_of_the_real_backward():
                 exact += int(err == 0.0)
             assert exact >= len(plain[3]) // 2, 'only %d of %d gradients are bitwise equal' % (exact, len(plain[3]))
         assert red.stats['in_place_bytes'] > 0                           # fc6 / fc7 weight gradients were born inside the buckets
+        # the N > 1-only producer path ran HERE: the relation head's fc6 gradient (411 MB) was written range by
+        # range into its bucket (lib/hip_ops.py: _wgrad_planes) and every range reduced as its own collective, in unit order
+        fc6 = model.roi_fmap[1][0].weight
+        rows = red.segments(fc6)
+        assert rows is not None and len(rows) >= 6 and all((r1 - r0) * fc6.shape[1] * 4 <= red.split_bytes for r0, r1 in rows)
+        assert red.launch_log == list(range(len(red.units))) and len(red.units) > len(red.buckets)
+        assert red.stats['in_place_bytes'] >= 3 * 2 * fc6.numel() * 4       # both trainable fc6 copies, three trials
         red.remove()
     finally:
         dist.destroy_process_group()
