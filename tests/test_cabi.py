@@ -182,3 +182,14 @@ def test_latency_critical_kernels_keep_their_load_structure(tmp_path):
     for name in ('tower_conv1_fwd_kernel', 'tower_conv1_wgrad_kernel'):
         m = re.search(r'\.amdhsa_kernel \w*%s\w*\n(.*?)\.end_amdhsa_kernel' % name, asm, flags=re.S)
         assert m and re.search(r'\.amdhsa_private_segment_fixed_size 0\b', m.group(1)), name + ' spills to scratch'
+    # round 6, the same layer on the matrix cores: 7 k-tiles x 2 channel blocks x 3 f16 terms per 32-pixel tile in the forward kernel
+    # (its weight fragments stay in registers: no scratch), 4 tap blocks x 2 channel blocks x 6 bf16 terms per output row in the
+    # weight gradient; the window rows arrive as 16-byte / 8-byte loads, not as 14 scalar ones
+    fwd = _kernel_body(asm, 'tower_conv1_mfma_fwd_kernel')
+    assert len(re.findall(r'\bv_mfma_f32_32x32x16_f16\b', fwd)) == 42 and len(re.findall(r'\bglobal_load_dwordx4\b', fwd)) >= 7
+    assert 'v_cvt_pk_f16_f32' in fwd and not re.search(r'\bv_cvt_pkrtz', fwd)            # round-to-nearest split
+    wg = _kernel_body(asm, 'tower_conv1_mfma_wgrad_kernelILi2E')
+    assert len(re.findall(r'\bv_mfma_f32_32x32x16_bf16\b', wg)) == 48 and 'ds_read_b128' in wg and 's_barrier' in wg
+    for name in ('tower_conv1_mfma_fwd_kernel', 'tower_conv1_mfma_wgrad_kernelILi2E', 'tower_conv1_mfma_wgrad_kernelILi1E'):
+        m = re.search(r'\.amdhsa_kernel \w*%s\w*\n(.*?)\.end_amdhsa_kernel' % name, asm, flags=re.S)
+        assert m and re.search(r'\.amdhsa_private_segment_fixed_size 0\b', m.group(1)), name + ' spills to scratch'
