@@ -99,6 +99,23 @@ int mh_roi_align_bwd_det(const float *grad_out, int B, int C, int H, int W, int 
 int mh_draw_union_boxes(const float *box_pairs, int n, int P, float offset, int channels_last,
                         float *out, void *stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Relation tail (round 6): prod[r] = subj[i1[r]] * obj[i2[r]] (* vis[r]) -- replaces the two row gathers and the two
+ * multiplies of /root/reference lib/rel_model.py:500-512 (`subj_rep[rel_inds[:, 1]] * obj_rep[rel_inds[:, 2]]`, then `* vr`)
+ * and, in the backward pass, their four multiplies, two sort-based index-add chains and two select-backward fills.
+ *   edge [n][2][D] fp32: subject (side 0) and object (side 1) representation of every box; i1 / i2 [R] int64; vis [R][D] or NULL
+ *   forward : out [R][D]
+ *   backward: d_vis [R][D] = grad_out * (subj * obj)   (NULL iff vis is NULL);
+ *             d_edge [n][2][D]: side 0 of box i = sum over the rows r with i1[r] == i of (grad_out[r] * vis[r]) * obj[i2[r]],
+ *             side 1 over the rows with i2[r] == i of (grad_out[r] * vis[r]) * subj[i1[r]].  The rows of a box are given by the
+ *             caller: order [2][R] (side-major row lists) and ptr [2][n+1] (offsets INTO order, both sides in one index space:
+ *             ptr[1][*] >= R); sums run in list order -- deterministic, no atomics.  D % 4 == 0, pointers 16-byte aligned.
+ * ------------------------------------------------------------------------------------------- */
+int mh_pair_product_fwd(const float *edge, int n, int D, const long long *i1, const long long *i2, int R, const float *vis,
+                        float *out, void *stream);
+int mh_pair_product_bwd(const float *edge, int n, int D, const long long *i1, const long long *i2, int R, const float *vis,
+                        const float *grad_out, const int *order, const int *ptr, float *d_edge, float *d_vis, void *stream);
+
 /* fp32 pairwise IoU, torch semantics of lib/fpn/box_utils.py:85-131: out[a,b] */
 int mh_bbox_overlaps(const float *boxes_a, int na, const float *boxes_b, int nb, float *out,
                      void *stream);

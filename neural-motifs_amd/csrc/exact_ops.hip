@@ -711,6 +711,67 @@ __global__ __launch_bounds__(256) void decoder_nms_commit_kernel(const float *__
     }
 }
 
+// ---- relation tail: prod[r] = subj[i1[r]] * obj[i2[r]] (* vis[r]) and its backward (lib/rel_model.py:500-512 of the reference:
+// `subj_rep[rel_inds[:, 1]] * obj_rep[rel_inds[:, 2]]`, then `* vr`) -----------------------------------------------------------
+// The framework evaluates this as two row gathers and two multiplies, and its backward as four multiplies, two sort-based
+// index-add chains (~10 launches each) and two select-backward fills: ~30 launches of 2-20 us on the main stream between the end
+// of the forward pass and the first product of the backward pass (profiles/r06_step_launches_c13.txt).  Here: one launch forward,
+// two backward; the sums over the rows that share a subject / an object run over a list the HOST made from the pair indices it
+// sampled itself (stable order: deterministic, no atomics).
+// edge [n][2][D]: subject / object representation of every box; i1 / i2 [R]; out [R][D].
+__global__ __launch_bounds__(256) void pair_product_fwd_kernel(const float4 *__restrict__ edge, const long long *__restrict__ i1,
+                                                               const long long *__restrict__ i2, const float4 *__restrict__ vis,
+                                                               int D4, float4 *__restrict__ out)
+{
+    const int r = blockIdx.x;
+    const float4 *s = edge + (size_t)i1[r] * 2 * D4, *o = edge + ((size_t)i2[r] * 2 + 1) * D4;
+    for (int c = threadIdx.x; c < D4; c += 256) {
+        const float4 a = s[c], b = o[c];
+        float4 p = make_float4(a.x * b.x, a.y * b.y, a.z * b.z, a.w * b.w);           // (subj * obj) * vis: the reference's order
+        if (vis) {
+            const float4 v = vis[(size_t)r * D4 + c];
+            p = make_float4(p.x * v.x, p.y * v.y, p.z * v.z, p.w * v.w);
+        }
+        out[(size_t)r * D4 + c] = p;
+    }
+}
+// d_vis[r] = g[r] * (subj[i1[r]] * obj[i2[r]])
+__global__ __launch_bounds__(256) void pair_product_dvis_kernel(const float4 *__restrict__ edge, const long long *__restrict__ i1,
+                                                                const long long *__restrict__ i2, const float4 *__restrict__ g,
+                                                                int D4, float4 *__restrict__ dvis)
+{
+    const int r = blockIdx.x;
+    const float4 *s = edge + (size_t)i1[r] * 2 * D4, *o = edge + ((size_t)i2[r] * 2 + 1) * D4;
+    for (int c = threadIdx.x; c < D4; c += 256) {
+        const float4 a = s[c], b = o[c], gv = g[(size_t)r * D4 + c];
+        dvis[(size_t)r * D4 + c] = make_float4(gv.x * (a.x * b.x), gv.y * (a.y * b.y), gv.z * (a.z * b.z), gv.w * (a.w * b.w));
+    }
+}
+// d_edge[i][side] = sum over the rows r of segment (side, i), in list order, of (g[r] * vis[r]) * partner(r):
+// partner = obj[i2[r]] for side 0 (the rows whose subject is i), subj[i1[r]] for side 1.  grid (n, 2, column chunks)
+__global__ __launch_bounds__(256) void pair_product_dedge_kernel(const float4 *__restrict__ edge, const long long *__restrict__ i1,
+                                                                 const long long *__restrict__ i2, const float4 *__restrict__ vis,
+                                                                 const float4 *__restrict__ g, const int *__restrict__ order,
+                                                                 const int *__restrict__ ptr, int n, int D4, float4 *__restrict__ dedge)
+{
+    const int i = blockIdx.x, side = blockIdx.y, c = blockIdx.z * 256 + threadIdx.x;
+    if (c >= D4) return;
+    const int k0 = ptr[side * (n + 1) + i], k1 = ptr[side * (n + 1) + i + 1];
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int k = k0; k < k1; ++k) {
+        const int r = order[k];
+        const float4 *partner = side == 0 ? edge + ((size_t)i2[r] * 2 + 1) * D4 : edge + (size_t)i1[r] * 2 * D4;
+        float4 gv = g[(size_t)r * D4 + c];
+        if (vis) {
+            const float4 v = vis[(size_t)r * D4 + c];
+            gv = make_float4(gv.x * v.x, gv.y * v.y, gv.z * v.z, gv.w * v.w);
+        }
+        const float4 pv = partner[c];
+        acc.x += gv.x * pv.x; acc.y += gv.y * pv.y; acc.z += gv.z * pv.z; acc.w += gv.w * pv.w;
+    }
+    dedge[((size_t)i * 2 + side) * D4 + c] = acc;
+}
+
 }  // namespace mh
 
 using namespace mh;
@@ -912,6 +973,40 @@ int mh_bbox_overlaps(const float *boxes_a, int na, const float *boxes_b, int nb,
                        reinterpret_cast<const float4 *>(boxes_a), na, reinterpret_cast<const float4 *>(boxes_b), nb,
                        out);
     return check_launch("bbox_overlaps_kernel");
+}
+
+int mh_pair_product_fwd(const float *edge, int n, int D, const long long *i1, const long long *i2, int R, const float *vis, float *out,
+                        void *stream)
+{
+    MH_REQUIRE(n >= 0 && R >= 0 && D > 0 && D % 4 == 0);
+    if (R == 0) return MH_OK;
+    MH_REQUIRE(edge && i1 && i2 && out && n > 0);
+    MH_REQUIRE(((reinterpret_cast<uintptr_t>(edge) | reinterpret_cast<uintptr_t>(vis) | reinterpret_cast<uintptr_t>(out)) & 15) == 0);
+    hipLaunchKernelGGL(pair_product_fwd_kernel, dim3((unsigned)R), dim3(256), 0, as_stream(stream), reinterpret_cast<const float4 *>(edge),
+                       i1, i2, reinterpret_cast<const float4 *>(vis), D / 4, reinterpret_cast<float4 *>(out));
+    return check_launch("pair_product_fwd_kernel");
+}
+
+int mh_pair_product_bwd(const float *edge, int n, int D, const long long *i1, const long long *i2, int R, const float *vis,
+                        const float *grad_out, const int *order, const int *ptr, float *d_edge, float *d_vis, void *stream)
+{
+    MH_REQUIRE(n > 0 && R >= 0 && D > 0 && D % 4 == 0 && edge && d_edge && ptr && (vis == nullptr) == (d_vis == nullptr));
+    MH_REQUIRE(R == 0 || (i1 && i2 && grad_out && order));
+    MH_REQUIRE(((reinterpret_cast<uintptr_t>(edge) | reinterpret_cast<uintptr_t>(vis) | reinterpret_cast<uintptr_t>(grad_out) |
+                 reinterpret_cast<uintptr_t>(d_edge) | reinterpret_cast<uintptr_t>(d_vis)) & 15) == 0);
+    MH_REQUIRE(n <= 0x7fffffff / 2 && (D / 4 + 255) / 256 <= 65535);
+    hipStream_t st = as_stream(stream);
+    const int D4 = D / 4;
+    if (d_vis && R > 0) {
+        hipLaunchKernelGGL(pair_product_dvis_kernel, dim3((unsigned)R), dim3(256), 0, st, reinterpret_cast<const float4 *>(edge), i1, i2,
+                           reinterpret_cast<const float4 *>(grad_out), D4, reinterpret_cast<float4 *>(d_vis));
+        int rc = check_launch("pair_product_dvis_kernel");
+        if (rc) return rc;
+    }
+    hipLaunchKernelGGL(pair_product_dedge_kernel, dim3((unsigned)n, 2, (unsigned)((D4 + 255) / 256)), dim3(256), 0, st,
+                       reinterpret_cast<const float4 *>(edge), i1, i2, reinterpret_cast<const float4 *>(vis),
+                       reinterpret_cast<const float4 *>(grad_out), order, ptr, n, D4, reinterpret_cast<float4 *>(d_edge));
+    return check_launch("pair_product_dedge_kernel");
 }
 
 }  // extern "C"

@@ -22,6 +22,7 @@ SYMBOLS = (
     'mh_version', 'mh_mfma_split', 'mh_split_rne', 'mh_split_f16', 'mh_last_error',
     'mh_nms_ws_bytes', 'mh_nms', 'mh_nms_batched_ws_bytes', 'mh_nms_batched',
     'mh_roi_align_fwd', 'mh_roi_align_bwd', 'mh_roi_align_bwd_det', 'mh_draw_union_boxes', 'mh_bbox_overlaps', 'mh_triplet_match',
+    'mh_pair_product_fwd', 'mh_pair_product_bwd',
     'mh_gemm_ws_bytes', 'mh_gemm_auto_splitk', 'mh_gemm_f32',
     'mh_planes_bytes', 'mh_make_planes', 'mh_make_planes_both', 'mh_gemm_planes_ws_bytes', 'mh_gemm_planes_auto_splitk', 'mh_gemm_planes',
     'mh_act_planes_bytes', 'mh_act_planes', 'mh_image_maxbits', 'mh_plconv_packed_bytes', 'mh_plconv_pack_weight', 'mh_plconv3x3_ws_bytes',
@@ -439,6 +440,32 @@ def draw_union_boxes(box_pairs, P, offset=0.0, channels_last=False):
                                    stream())
     _check(rc, 'mh_draw_union_boxes')
     return out
+
+
+def _i64(t):
+    if t is not None and t.dtype != torch.int64:
+        raise HipKernelError('expected int64, got %s' % t.dtype)
+    return ptr(t)
+
+
+def pair_product_fwd(edge, i1, i2, vis=None):
+    """edge [n,2,D] (subject / object representation of every box), i1 / i2 [R] int64, vis [R,D] or None ->
+    edge[i1, 0] * edge[i2, 1] (* vis), one launch (csrc/exact_ops.hip: pair_product_fwd_kernel)"""
+    n, D, R = edge.shape[0], edge.shape[2], i1.shape[0]
+    out = torch.empty(R, D, dtype=torch.float32, device=edge.device)
+    _check(lib().mh_pair_product_fwd(f32(edge), n, D, _i64(i1), _i64(i2), R, f32(vis), f32(out), stream()), 'mh_pair_product_fwd')
+    return out
+
+
+def pair_product_bwd(edge, i1, i2, vis, grad_out, order, ptr_):
+    """-> (d_edge [n,2,D], d_vis [R,D] or None); order [2,R] / ptr_ [2,n+1] int32: the rows of every box per side (host-made,
+    see lib/rel_model.py: _PairProductFn), summed in list order"""
+    n, D, R = edge.shape[0], edge.shape[2], i1.shape[0]
+    d_edge = torch.empty_like(edge)
+    d_vis = torch.empty(R, D, dtype=torch.float32, device=edge.device) if vis is not None else None
+    _check(lib().mh_pair_product_bwd(f32(edge), n, D, _i64(i1), _i64(i2), R, f32(vis), f32(grad_out), i32(order), i32(ptr_), f32(d_edge),
+                                     f32(d_vis), stream()), 'mh_pair_product_bwd')
+    return d_edge, d_vis
 
 
 def bbox_overlaps(a, b):

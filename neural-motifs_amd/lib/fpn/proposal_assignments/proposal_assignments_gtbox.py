@@ -9,7 +9,7 @@ import numpy as np
 import torch
 
 from config import RELS_PER_IMG, REL_FG_FRACTION
-from lib.pytorch_misc import enumerate_by_image, host_np, h2d
+from lib.pytorch_misc import enumerate_by_image, host_np, h2d, set_host
 
 
 def proposal_assignments_gtbox(rois, gt_boxes, gt_classes, gt_rels, image_offset, fg_thresh=0.5, rs=None):
@@ -48,4 +48,5 @@ def proposal_assignments_gtbox(rois, gt_boxes, gt_classes, gt_rels, image_offset
     key = rel_labels[:, 0] * (n ** 2) + rel_labels[:, 1] * n + rel_labels[:, 2]
     rel_labels = rel_labels[np.argsort(key, kind='stable')]
     labels = gt_classes[:, 1].contiguous()
-    return rois, labels, h2d(rel_labels, dev)
+    rel_labels = np.ascontiguousarray(rel_labels, dtype=np.int64)
+    return rois, labels, set_host(h2d(rel_labels, dev), rel_labels)      # (mirror: the union-box geometry is computed on the host from it)

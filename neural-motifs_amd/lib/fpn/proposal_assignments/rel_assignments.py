@@ -13,7 +13,7 @@ import torch
 
 from config import REL_FG_FRACTION
 from lib.fpn.box_intersections_cpu.bbox import bbox_overlaps
-from lib.pytorch_misc import h2d, host_np
+from lib.pytorch_misc import h2d, host_np, set_host
 
 RELS_PER_IMG_SGDET = 64
 
@@ -92,4 +92,5 @@ def rel_assignments(im_inds, rpn_rois, roi_gtlabels, gt_boxes, gt_classes, gt_re
         rows = rows[np.lexsort((rows[:, 1], rows[:, 0]))]
         out.append(np.column_stack((np.full(rows.shape[0], im, dtype=np.int64), rows)))
         seen += n
-    return h2d(np.concatenate(out, 0), dev)
+    rows_all = np.ascontiguousarray(np.concatenate(out, 0), dtype=np.int64)
+    return set_host(h2d(rows_all, dev), rows_all)

@@ -9,6 +9,7 @@ State-dict keys are the reference's: conv.{0,2,4,6}.*
 """
 import os
 
+import numpy as np
 import torch
 from torch import nn
 from torch.nn import functional as F
@@ -17,6 +18,7 @@ from config import BATCHNORM_MOMENTUM
 from lib.draw_rectangles.draw_rectangles import draw_union_boxes
 from lib.fpn.roi_align.functions.roi_align import RoIAlignFunction
 from lib import _hip
+from lib.pytorch_misc import h2d, has_host, host_np
 from lib import hip_ops
 from lib.hip_ops import Conv2dNHWC, ReLU, EPI_NONE, EPI_RELU
 
@@ -41,6 +43,8 @@ class _MaxPoolNHWC(nn.MaxPool2d):
 # 'gemm' = im2col + the small-product engine.  MOTIFS_TOWER_CONV1=gemm for A/B runs.  gpurun r06_c10, same box, alternating:
 # 415.0 / 418.5 img/s (14.46 / 14.34 ms per cfg2 step) on the matrix cores against 408.1 / 407.2 (14.70 / 14.74) on the VALU kernels.
 TOWER_CONV1 = os.environ.get('MOTIFS_TOWER_CONV1', 'direct')
+# union rectangles / pair boxes computed on the host when boxes and pair list carry their host mirrors (round 6); =0: on the device (A/B)
+HOST_GEOMETRY = os.environ.get('MOTIFS_HOST_GEOMETRY', '1') != '0'
 
 
 # test hook (tests/parity_util.py): a dict here receives the tower's ReLU masks and pool arg-max table of the next forward,
@@ -145,7 +149,11 @@ class UnionBoxesAndFeats(nn.Module):
         union_pools = union_boxes(fmap, rois, union_inds, pooling_size=self.pooling_size, stride=self.stride)
         if not self.use_feats:
             return union_pools.detach()
-        pair_rois = torch.cat((rois[:, 1:][union_inds[:, 0]], rois[:, 1:][union_inds[:, 1]]), 1).detach()
+        if HOST_GEOMETRY and rois.is_cuda and has_host(rois) and has_host(union_inds):
+            r, u = host_np(rois), host_np(union_inds)                  # GT-box modes: the pairs' boxes gathered on the host, one upload
+            pair_rois = h2d(np.ascontiguousarray(np.concatenate((r[u[:, 0], 1:], r[u[:, 1], 1:]), 1), dtype=np.float32), rois.device)
+        else:
+            pair_rois = torch.cat((rois[:, 1:][union_inds[:, 0]], rois[:, 1:][union_inds[:, 1]]), 1).detach()
         rects = draw_union_boxes(pair_rois, self.pooling_size * 4 - 1, offset=-0.5, channels_last=True)   # [N,27,27,2]
         if not self.concat and rects.is_cuda:
             c = self.conv
@@ -160,6 +168,15 @@ class UnionBoxesAndFeats(nn.Module):
 def union_boxes(fmap, rois, union_inds, pooling_size=14, stride=16):
     """RoIAlign over the union rectangle of each pair (reference :72-93)"""
     assert union_inds.size(1) == 2
+    if HOST_GEOMETRY and rois.is_cuda and has_host(rois) and has_host(union_inds):
+        # boxes and pair list came from the host (GT-box modes; the sampled relations of a training step): the union rectangles are
+        # min / max of fp32 values -- exact on either side -- computed in numpy and uploaded once (was ~10 launches on the main stream
+        # in front of the RoIAlign, profiles/r06_step_launches_c13.txt)
+        r, u = host_np(rois), host_np(union_inds)
+        a, b = r[u[:, 0]], r[u[:, 1]]
+        union_np = np.ascontiguousarray(np.concatenate((a[:, :1], np.minimum(a[:, 1:3], b[:, 1:3]), np.maximum(a[:, 3:5], b[:, 3:5])), 1),
+                                        dtype=np.float32)
+        return RoIAlignFunction(pooling_size, pooling_size, spatial_scale=1 / stride)(fmap, h2d(union_np, rois.device))
     im_inds = rois[:, 0][union_inds[:, 0]]
     union_rois = torch.cat((
         im_inds[:, None],

@@ -51,6 +51,59 @@ class _AheadStage(object):
         self.x, self.future = x, future
 
 
+_HOST_GEOMETRY = os.environ.get('MOTIFS_HOST_GEOMETRY', '1') != '0'
+# the relation tail's gather-gather-multiply(-multiply) as one autograd node over csrc/exact_ops.hip pair_product_* (round 6);
+# MOTIFS_PAIR_PRODUCT=0: the framework's index / multiply ops (A/B)
+_PAIR_PRODUCT = os.environ.get('MOTIFS_PAIR_PRODUCT', '1') != '0'
+
+
+def _pair_lists(i1, i2, n):
+    """which rows have box i as their subject (side 0) / object (side 1): order [2, R] (stable: ascending row) and ptr [2, n + 1]
+    (offsets into the flattened order array), int32, from the HOST copies of the pair indices"""
+    R = i1.shape[0]
+    order = np.empty((2, R), dtype=np.int32)
+    ptr = np.empty((2, n + 1), dtype=np.int32)
+    for side, idx in enumerate((i1, i2)):
+        order[side] = np.argsort(idx, kind='stable').astype(np.int32)
+        ptr[side] = side * R + np.searchsorted(idx[order[side]], np.arange(n + 1)).astype(np.int32)
+    return order, ptr
+
+
+class _PairProductFn(torch.autograd.Function):
+    """prod[r] = edge[i1[r], 0] * edge[i2[r], 1] * vis[r] (reference lib/rel_model.py:500-512) -- one launch forward, two backward;
+    the backward's sums over the rows that share a box run over lists made on the host from the mirror of the pair indices
+    (deterministic order, no atomics, no device sort)."""
+
+    @staticmethod
+    def forward(ctx, edge, vis, rel_inds):
+        i1, i2 = rel_inds[:, 1].contiguous(), rel_inds[:, 2].contiguous()
+        edge_c = edge.contiguous()
+        vis_c = vis.contiguous() if vis is not None else None
+        out = _hip.pair_product_fwd(edge_c, i1, i2, vis_c)
+        host = host_np(rel_inds)
+        order, ptr = _pair_lists(host[:, 1], host[:, 2], edge.shape[0])
+        lists = h2d(np.concatenate((order.reshape(-1), ptr.reshape(-1))), edge.device)
+        ctx.n_rows = i1.shape[0]
+        ctx.has_vis = vis is not None
+        ctx.save_for_backward(edge_c, vis_c, i1, i2, lists)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        edge, vis, i1, i2, lists = ctx.saved_tensors
+        R = ctx.n_rows
+        d_edge, d_vis = _hip.pair_product_bwd(edge, i1, i2, vis, g.contiguous(), lists[:2 * R], lists[2 * R:])
+        return d_edge, (d_vis if ctx.has_vis else None), None
+
+
+def _cols_from(t, c0):
+    """t[:, c0:] with its host mirror (a slice is a new tensor object: the mirror would be lost)"""
+    out = t[:, c0:]
+    if has_host(t):
+        set_host(out, host_np(t)[:, c0:])
+    return out
+
+
 def _packing_plan(im_host):
     """host part of the LSTM packing order: per-image sort key offsets, and the time-major (TxB) gather of the image-sorted
     rois (reference :31-61, lib/pytorch_misc.py:365-384)"""
@@ -396,7 +449,10 @@ class RelModel(nn.Module):
         """candidate (image, subject, object) rows: the sampled labels in training, every ordered pair of distinct
         boxes of an image in eval (overlapping ones only for sgdet)"""
         if self.training:
-            return rel_labels[:, :3].detach().clone()
+            out = rel_labels[:, :3].detach().clone()
+            if has_host(rel_labels):
+                set_host(out, host_np(rel_labels)[:, :3])
+            return out
         if not self.require_overlap and has_host(im_inds):
             # GT-box evaluation: every ordered pair of distinct boxes of an image, enumerated on the host from the
             # mirrored image indices in the order nonzero() gives (row-major) -- no device->host synchronisation
@@ -406,7 +462,8 @@ class RelModel(nn.Module):
             ij = np.column_stack(np.nonzero(cand)).astype(np.int64)
             if ij.shape[0] == 0:
                 ij = np.zeros((1, 2), dtype=np.int64)
-            return h2d(np.column_stack((im[ij[:, 0]].astype(np.int64), ij)), im_inds.device)
+            cand_np = np.ascontiguousarray(np.column_stack((im[ij[:, 0]].astype(np.int64), ij)))
+            return set_host(h2d(cand_np, im_inds.device), cand_np)
         rel_cands = im_inds[:, None] == im_inds[None]
         rel_cands.fill_diagonal_(False)
         if self.require_overlap:
@@ -578,7 +635,13 @@ class RelModel(nn.Module):
 
         boxes = result.rm_box_priors
         self.last_detector_obj_dists = result.rm_obj_dists.detach()   # the detector's logits of the kept boxes (the
-        rois = torch.cat((im_inds[:, None].float(), boxes), 1)        # field is overwritten by the context's below)
+        if _HOST_GEOMETRY and x.is_cuda and has_host(im_inds) and has_host(boxes) and not boxes.requires_grad:
+            # GT-box modes: [image, x1, y1, x2, y2] assembled on the host from the two mirrors -- one upload instead of a cast + a
+            # concatenation, and the union-box geometry below (lib/get_union_boxes.py) needs no launch at all
+            rois_np = np.ascontiguousarray(np.column_stack((host_np(im_inds).astype(np.float32), host_np(boxes).astype(np.float32))))
+            rois = set_host(h2d(rois_np, boxes.device), rois_np)
+        else:
+            rois = torch.cat((im_inds[:, None].float(), boxes), 1)    # field is overwritten by the context's below)
         fmap = result.fmap.detach()
 
         def context_branch():
@@ -617,13 +680,13 @@ class RelModel(nn.Module):
             late = self._late_ok(fmap) and self.late_vr_backward in ('auto', '1', 'force')
             if early_edge_rep is None:
                 side.wait_stream(main)                               # fmap / rois / labels are ready
-                vr = self.visual_rep(fmap, rois, rel_inds[:, 1:])     # big kernels first: the GPU is busy while
+                vr = self.visual_rep(fmap, rois, _cols_from(rel_inds, 1))     # big kernels first: the GPU is busy while
                 with torch.cuda.stream(side):                         # the host enqueues the small ones
                     for t in (fmap, rois, im_inds, boxes, result.rm_obj_dists):
                         t.record_stream(side)
                     edge_rep = context_branch()
             else:
-                vr = self.visual_rep(fmap, rois, rel_inds[:, 1:])
+                vr = self.visual_rep(fmap, rois, _cols_from(rel_inds, 1))
                 edge_rep = early_edge_rep
             marks = getattr(self, 'stream_marks', None)      # measurement hook (bench.py): how long the main stream waits here
             if marks is not None:
@@ -642,18 +705,22 @@ class RelModel(nn.Module):
         else:
             edge_rep = context_branch()
             if self.use_vision and self.late_vr_backward == 'force' and self._late_ok(fmap):
-                vr_inner = self.visual_rep(fmap, rois, rel_inds[:, 1:])
+                vr_inner = self.visual_rep(fmap, rois, _cols_from(rel_inds, 1))
                 vr = _LateBackward.apply(vr_inner.detach().requires_grad_(True), [vr_inner]) if vr_inner.requires_grad else vr_inner
-        subj_rep, obj_rep = edge_rep[:, 0], edge_rep[:, 1]
-        prod_rep = subj_rep[rel_inds[:, 1]] * obj_rep[rel_inds[:, 2]]
-
-        if self.use_vision:
-            if vr is None:
-                vr = self.visual_rep(fmap, rois, rel_inds[:, 1:])
-            if self.limit_vision:
-                prod_rep = torch.cat((prod_rep[:, :2048] * vr[:, :2048], prod_rep[:, 2048:]), 1)
-            else:
-                prod_rep = prod_rep * vr
+        if self.use_vision and vr is None:
+            vr = self.visual_rep(fmap, rois, _cols_from(rel_inds, 1))
+        fused = (_PAIR_PRODUCT and x.is_cuda and has_host(rel_inds) and edge_rep.dtype == torch.float32 and self.pooling_dim % 4 == 0
+                 and not (self.use_vision and self.limit_vision))
+        if fused:
+            prod_rep = _PairProductFn.apply(edge_rep, vr if self.use_vision else None, rel_inds)
+        else:
+            subj_rep, obj_rep = edge_rep[:, 0], edge_rep[:, 1]
+            prod_rep = subj_rep[rel_inds[:, 1]] * obj_rep[rel_inds[:, 2]]
+            if self.use_vision:
+                if self.limit_vision:
+                    prod_rep = torch.cat((prod_rep[:, :2048] * vr[:, :2048], prod_rep[:, 2048:]), 1)
+                else:
+                    prod_rep = prod_rep * vr
         if self.use_tanh:
             prod_rep = torch.tanh(prod_rep)
 

@@ -604,6 +604,45 @@ def test_mask_tower_first_convolution_in_its_three_forms_agree(hip, monkeypatch)
             grad_close(d.cpu().numpy(), a.cpu().numpy(), what='tower %s %s' % (form, name), rtol=1e-4)
 
 
+@pytest.mark.parametrize('n,R,D,with_vis', [(120, 1536, 4096, True), (7, 33, 64, True), (5, 1, 8, False), (40, 300, 512, False)])
+def test_pair_product_forward_and_backward(hip, n, R, D, with_vis):
+    """csrc/exact_ops.hip pair_product_*: the relation tail's subj[i1] * obj[i2] (* vis) as one autograd node (lib/rel_model.py:
+    _PairProductFn) against the framework's gather / multiply ops -- forward bit for bit (same multiplication order, no
+    contraction), gradients against the same graph in float64; boxes without a row on a side get exact zeros."""
+    from lib.pytorch_misc import set_host
+    from lib.rel_model import _PairProductFn
+    g = torch.Generator().manual_seed(n * 1000 + R)
+    edge = torch.randn(n, 2, D, generator=g)
+    vis = torch.randn(R, D, generator=g) if with_vis else None
+    rel = torch.stack((torch.zeros(R, dtype=torch.int64), torch.randint(0, max(n - 2, 1), (R,), generator=g),
+                       torch.randint(1, n, (R,), generator=g)), 1)             # box n-1 is never a subject, box 0 never an object
+    gout = torch.randn(R, D, generator=g)
+    e_d = edge.cuda().requires_grad_(True)
+    v_d = vis.cuda().requires_grad_(True) if with_vis else None
+    rel_d = set_host(rel.cuda(), rel.numpy())
+    out = _PairProductFn.apply(e_d, v_d, rel_d)
+    ref32 = edge[rel[:, 1], 0] * edge[rel[:, 2], 1]
+    if with_vis:
+        ref32 = ref32 * vis
+    assert torch.equal(out.detach().cpu(), ref32)
+    out.backward(gout.cuda())
+    e64 = edge.double().requires_grad_(True)
+    v64 = vis.double().requires_grad_(True) if with_vis else None
+    ref = e64[rel[:, 1], 0] * e64[rel[:, 2], 1]
+    if with_vis:
+        ref = ref * v64
+    ref.backward(gout.double())
+    scale = float(e64.grad.abs().max())
+    np.testing.assert_allclose(e_d.grad.cpu().numpy(), e64.grad.numpy(), atol=2e-6 * scale)
+    assert float(e_d.grad[n - 1, 0].abs().max()) == 0.0 and float(e_d.grad[0, 1].abs().max()) == 0.0
+    if with_vis:
+        np.testing.assert_allclose(v_d.grad.cpu().numpy(), v64.grad.numpy(), atol=2e-6 * float(v64.grad.abs().max()))
+    # twice the same call: deterministic
+    e2 = edge.cuda().requires_grad_(True)
+    _PairProductFn.apply(e2, v_d.detach() if with_vis else None, rel_d).backward(gout.cuda())
+    assert torch.equal(e2.grad, e_d.grad)
+
+
 # ----------------------------------------------------------------------------------------------- LSTM
 def _lstm_problem(lengths, in_size, H, nl, seed, p=0.0):
     from oracle import lstm as OL

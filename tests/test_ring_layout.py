@@ -24,12 +24,13 @@ GEMM = open(os.path.join(ROOT, 'neural-motifs_amd', 'csrc', 'pl_gemm.hip')).read
 CONV = open(os.path.join(ROOT, 'neural-motifs_amd', 'csrc', 'pl_conv.hip')).read()
 
 # (WM, WN, SM, SN, NS) of the typedefs that ship
-SHAPES = [tuple(int(x) for x in m) for m in re.findall(r'typedef Ring<(\d+), (\d+), (\d+), (\d+), (\d+)> C?R\d+x\d+;', GEMM + CONV)]
+SHAPES = [tuple(int(x) for x in m) for m in re.findall(r'typedef Ring<(\d+), (\d+), (\d+), (\d+), (\d+)> C?R\d+x\d+(?:s\d)?;', GEMM + CONV)]
 B64_WRITE_GROUPS = [list(range(16 * g, 16 * g + 16)) for g in range(4)]
 
 
 def test_sources_say_what_the_model_assumes():
-    assert sorted(set(SHAPES)) == [(4, 1, 2, 4, 3), (4, 2, 2, 4, 4)]
+    # round 6: the 64-channel ring tiles of conv1_2 (Ring<4, 1, 2, 2, 4> ships, <4, 1, 2, 2, 3> is its three-stage A/B arm)
+    assert sorted(set(SHAPES)) == [(4, 1, 2, 2, 3), (4, 1, 2, 2, 4), (4, 1, 2, 4, 3), (4, 2, 2, 4, 4)]
     assert 'return 16 * (j * R::waves + wave) + (lane >> 2);' in RING                               # dma_row
     assert 'row * kCell + 16 * ((lane & 3) ^ swz(row))' in RING                                     # source offset of a lane
     assert 'stage + (j * R::waves + wave) * 1024' in RING and 'stage + R::a_bytes + (j * R::waves + wave) * 1024' in RING
