@@ -888,6 +888,13 @@ static bool tower_conv1_on_mfma()
     const char *e = getenv("MH_TOWER_CONV1");          // read per call: the tests run both forms in one process
     return !(e && std::string(e) == "valu");
 }
+// pixel-tile walkers of the forward kernel: every block first builds the weight fragments of its 256 channels (56 strided loads
+// and 28 splits per lane), so few long-lived blocks (two per CU) beat many short ones; MH_TOWER_FWD_BLOCKS for A/B
+static long long tower_fwd_blocks()
+{
+    static const int v = [] { const char *e = getenv("MH_TOWER_FWD_BLOCKS"); const int x = e ? atoi(e) : 0; return x > 0 ? x : 512; }();
+    return v;
+}
 static int check_t1(long long N, int S, int C0)
 {
     MH_REQUIRE(N > 0 && N <= 0x7fffffffLL / 4 && S >= kT1K - 2 * kT1Pad && S <= 4096 && C0 > 0 && C0 % 256 == 0 && C0 <= 256 * 65535);
@@ -930,7 +937,7 @@ int mh_tower_conv1_fwd(const float *padded, long long N, int S, const float *w_k
     if (tower_conv1_on_mfma()) {
         MH_REQUIRE(((reinterpret_cast<uintptr_t>(padded) | reinterpret_cast<uintptr_t>(y_nhwc)) & 15) == 0);
         const long long ntiles = (N * Ho * Ho + 31) / 32;
-        hipLaunchKernelGGL(t1::tower_conv1_mfma_fwd_kernel, dim3((unsigned)std::min<long long>(ntiles, 256 * 8), (unsigned)(C0 / 256)), dim3(256),
+        hipLaunchKernelGGL(t1::tower_conv1_mfma_fwd_kernel, dim3((unsigned)std::min<long long>(ntiles, tower_fwd_blocks()), (unsigned)(C0 / 256)), dim3(256),
                            (size_t)t1::kFwdLds, as_stream(stream), padded, N, S + 2 * kT1Pad, Ho, Ho, w_kc, bias, C0, y_nhwc);
         return check_launch("tower_conv1_mfma_fwd_kernel");
     }
