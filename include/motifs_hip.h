@@ -116,6 +116,15 @@ int mh_pair_product_fwd(const float *edge, int n, int D, const long long *i1, co
 int mh_pair_product_bwd(const float *edge, int n, int D, const long long *i1, const long long *i2, int R, const float *vis,
                         const float *grad_out, const int *order, const int *ptr, float *d_edge, float *d_vis, void *stream);
 
+/* Relation tail (round 6): out[r] = logits[r] + table[labels[i1[r]] * num_objs + labels[i2[r]]] -- the FrequencyBias term of
+ * /root/reference lib/rel_model.py:528-531 (`self.freq_bias.index_with_labels(torch.stack((obj_preds[rel_inds[:, 1]],
+ * obj_preds[rel_inds[:, 2]]), 1))`, lib/sparse_targets.py:39-45) in one launch; keys [R] (int64, out) = the table rows used.
+ * mh_freq_bias_bwd: d_table [table_rows][P] = sum of grad_out rows per key, in ascending row order (deterministic: the first row of
+ * a key gathers the rows of its key; no device sort, no atomics); d_table is cleared by the call.  R <= 8192. */
+int mh_freq_bias_add(const float *logits, const float *table, const long long *labels, const long long *i1, const long long *i2, int R,
+                     int P, int num_objs, float *out, long long *keys, void *stream);
+int mh_freq_bias_bwd(const float *grad_out, const long long *keys, int R, int P, long long table_rows, float *d_table, void *stream);
+
 /* fp32 pairwise IoU, torch semantics of lib/fpn/box_utils.py:85-131: out[a,b] */
 int mh_bbox_overlaps(const float *boxes_a, int na, const float *boxes_b, int nb, float *out,
                      void *stream);

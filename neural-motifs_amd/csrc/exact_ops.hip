@@ -772,6 +772,59 @@ __global__ __launch_bounds__(256) void pair_product_dedge_kernel(const float4 *_
     dedge[((size_t)i * 2 + side) * D4 + c] = acc;
 }
 
+// ---- relation tail: rel_dists + FrequencyBias[subject class, object class] (reference lib/rel_model.py:528-531,
+// lib/sparse_targets.py:39-45) ---------------------------------------------------------------------------------------------------
+// Forward: key[r] = labels[i1[r]] * num_objs + labels[i2[r]]; out[r] = logits[r] + table[key[r]] -- one launch instead of two label
+// gathers, a stack, the key arithmetic, the embedding gather and the add.  Backward of the table: the framework sorts the keys on the
+// device and segments the rows (8 launches, ~85 us at 1536 rows).  Here: one block per row l; it is the LEADER of its key when no
+// earlier row has the same key, and then sums the gradient rows of its key in ascending row order -- deterministic, no sort, no
+// atomics.  d_table must be zero on entry (the entry point clears it).
+constexpr int kFbMaxRows = 8192;       // rows per call the leader kernel handles (keys staged through LDS in pieces of 1024)
+__global__ __launch_bounds__(256) void freq_bias_add_kernel(const float *__restrict__ logits, const float *__restrict__ table,
+                                                            const long long *__restrict__ labels, const long long *__restrict__ i1,
+                                                            const long long *__restrict__ i2, int R, int P, int num_objs,
+                                                            float *__restrict__ out, long long *__restrict__ keys)
+{
+    const long long total = (long long)R * P;
+    for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+        const int r = (int)(idx / P), p = (int)(idx - (long long)r * P);
+        const long long key = labels[i1[r]] * num_objs + labels[i2[r]];
+        if (p == 0) keys[r] = key;
+        out[idx] = logits[idx] + table[key * P + p];
+    }
+}
+__global__ __launch_bounds__(64) void freq_bias_bwd_kernel(const float *__restrict__ grad, const long long *__restrict__ keys, int R, int P,
+                                                           float *__restrict__ d_table)
+{
+    __shared__ int rows[kFbMaxRows];
+    __shared__ int nrows;
+    const int l = blockIdx.x, lane = threadIdx.x;
+    const long long key = keys[l];
+    // leader test: does an earlier row carry the same key?
+    int earlier = 0;
+    for (int r = lane; r < l; r += 64) earlier |= (keys[r] == key) ? 1 : 0;
+    if (__any(earlier)) return;
+    // the rows of this key at or after l, ascending (one wave: ballot + prefix keeps the order)
+    if (lane == 0) nrows = 0;
+    __syncthreads();
+    for (int r0 = l; r0 < R; r0 += 64) {
+        const int r = r0 + lane;
+        const bool hit = r < R && keys[r] == key;
+        const unsigned long long m = __ballot(hit);
+        const int base = nrows;
+        if (hit) rows[base + __popcll(m & ((1ull << lane) - 1ull))] = r;
+        __syncthreads();
+        if (lane == 0) nrows = base + __popcll(m);
+        __syncthreads();
+    }
+    const int n = nrows;
+    for (int p = lane; p < P; p += 64) {
+        float acc = 0.f;
+        for (int k = 0; k < n; ++k) acc += grad[(size_t)rows[k] * P + p];
+        d_table[(size_t)key * P + p] = acc;
+    }
+}
+
 }  // namespace mh
 
 using namespace mh;
@@ -1007,6 +1060,30 @@ int mh_pair_product_bwd(const float *edge, int n, int D, const long long *i1, co
                        reinterpret_cast<const float4 *>(edge), i1, i2, reinterpret_cast<const float4 *>(vis),
                        reinterpret_cast<const float4 *>(grad_out), order, ptr, n, D4, reinterpret_cast<float4 *>(d_edge));
     return check_launch("pair_product_dedge_kernel");
+}
+
+int mh_freq_bias_add(const float *logits, const float *table, const long long *labels, const long long *i1, const long long *i2, int R,
+                     int P, int num_objs, float *out, long long *keys, void *stream)
+{
+    MH_REQUIRE(R >= 0 && P > 0 && num_objs > 0);
+    if (R == 0) return MH_OK;
+    MH_REQUIRE(logits && table && labels && i1 && i2 && out && keys);
+    const long long total = (long long)R * P;
+    hipLaunchKernelGGL(freq_bias_add_kernel, dim3((unsigned)std::min<long long>((total + 255) / 256, 256 * 8)), dim3(256), 0, as_stream(stream),
+                       logits, table, labels, i1, i2, R, P, num_objs, out, keys);
+    return check_launch("freq_bias_add_kernel");
+}
+
+int mh_freq_bias_bwd(const float *grad_out, const long long *keys, int R, int P, long long table_rows, float *d_table, void *stream)
+{
+    MH_REQUIRE(R >= 0 && R <= kFbMaxRows && P > 0 && table_rows > 0 && d_table);
+    hipStream_t st = as_stream(stream);
+    hipError_t e = hipMemsetAsync(d_table, 0, (size_t)table_rows * P * sizeof(float), st);
+    if (e != hipSuccess) { set_last_error("hipMemsetAsync(frequency-bias gradient)", e); return (int)e; }
+    if (R == 0) return MH_OK;
+    MH_REQUIRE(grad_out && keys);
+    hipLaunchKernelGGL(freq_bias_bwd_kernel, dim3((unsigned)R), dim3(64), 0, st, grad_out, keys, R, P, d_table);
+    return check_launch("freq_bias_bwd_kernel");
 }
 
 }  // extern "C"

@@ -22,7 +22,7 @@ SYMBOLS = (
     'mh_version', 'mh_mfma_split', 'mh_split_rne', 'mh_split_f16', 'mh_last_error',
     'mh_nms_ws_bytes', 'mh_nms', 'mh_nms_batched_ws_bytes', 'mh_nms_batched',
     'mh_roi_align_fwd', 'mh_roi_align_bwd', 'mh_roi_align_bwd_det', 'mh_draw_union_boxes', 'mh_bbox_overlaps', 'mh_triplet_match',
-    'mh_pair_product_fwd', 'mh_pair_product_bwd',
+    'mh_pair_product_fwd', 'mh_pair_product_bwd', 'mh_freq_bias_add', 'mh_freq_bias_bwd',
     'mh_gemm_ws_bytes', 'mh_gemm_auto_splitk', 'mh_gemm_f32',
     'mh_planes_bytes', 'mh_make_planes', 'mh_make_planes_both', 'mh_gemm_planes_ws_bytes', 'mh_gemm_planes_auto_splitk', 'mh_gemm_planes',
     'mh_act_planes_bytes', 'mh_act_planes', 'mh_image_maxbits', 'mh_plconv_packed_bytes', 'mh_plconv_pack_weight', 'mh_plconv3x3_ws_bytes',
@@ -466,6 +466,27 @@ def pair_product_bwd(edge, i1, i2, vis, grad_out, order, ptr_):
     _check(lib().mh_pair_product_bwd(f32(edge), n, D, _i64(i1), _i64(i2), R, f32(vis), f32(grad_out), i32(order), i32(ptr_), f32(d_edge),
                                      f32(d_vis), stream()), 'mh_pair_product_bwd')
     return d_edge, d_vis
+
+
+FREQ_BIAS_MAX_ROWS = 8192
+
+
+def freq_bias_add(logits, table, labels, i1, i2, num_objs):
+    """logits [R,P] + table[labels[i1] * num_objs + labels[i2]] -> (out [R,P], keys [R] int64)"""
+    R, P = logits.shape
+    out = torch.empty_like(logits)
+    keys = torch.empty(R, dtype=torch.int64, device=logits.device)
+    _check(lib().mh_freq_bias_add(f32(logits), f32(table), _i64(labels), _i64(i1), _i64(i2), R, P, int(num_objs), f32(out), _i64(keys),
+                                  stream()), 'mh_freq_bias_add')
+    return out, keys
+
+
+def freq_bias_bwd(grad_out, keys, table_rows):
+    """-> d_table [table_rows, P]: the gradient rows of every key summed in ascending row order"""
+    R, P = grad_out.shape
+    d_table = torch.empty(table_rows, P, dtype=torch.float32, device=grad_out.device)
+    _check(lib().mh_freq_bias_bwd(f32(grad_out), _i64(keys), R, P, c_ll(table_rows), f32(d_table), stream()), 'mh_freq_bias_bwd')
+    return d_table
 
 
 def bbox_overlaps(a, b):

@@ -69,6 +69,26 @@ def _pair_lists(i1, i2, n):
     return order, ptr
 
 
+class _FreqBiasAddFn(torch.autograd.Function):
+    """rel_dists + FrequencyBias[obj_preds[i1], obj_preds[i2]] (reference lib/rel_model.py:528-531) as one node: one launch forward
+    (was two label gathers, a stack, the key arithmetic, the embedding gather and the add), and the table's gradient from a
+    leader-per-key kernel in ascending row order instead of the framework's device sort (csrc/exact_ops.hip: freq_bias_*)."""
+
+    @staticmethod
+    def forward(ctx, logits, table, obj_preds, rel_inds, num_objs):
+        i1, i2 = rel_inds[:, 1].contiguous(), rel_inds[:, 2].contiguous()
+        out, keys = _hip.freq_bias_add(logits.contiguous(), table, obj_preds.contiguous(), i1, i2, num_objs)
+        ctx.table_rows = table.shape[0]
+        ctx.save_for_backward(keys)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        keys, = ctx.saved_tensors
+        d_table = _hip.freq_bias_bwd(g.contiguous(), keys, ctx.table_rows) if ctx.needs_input_grad[1] else None
+        return g, d_table, None, None, None
+
+
 class _PairProductFn(torch.autograd.Function):
     """prod[r] = edge[i1[r], 0] * edge[i2[r], 1] * vis[r] (reference lib/rel_model.py:500-512) -- one launch forward, two backward;
     the backward's sums over the rows that share a box run over lists made on the host from the mirror of the pair indices
@@ -80,9 +100,11 @@ class _PairProductFn(torch.autograd.Function):
         edge_c = edge.contiguous()
         vis_c = vis.contiguous() if vis is not None else None
         out = _hip.pair_product_fwd(edge_c, i1, i2, vis_c)
-        host = host_np(rel_inds)
-        order, ptr = _pair_lists(host[:, 1], host[:, 2], edge.shape[0])
-        lists = h2d(np.concatenate((order.reshape(-1), ptr.reshape(-1))), edge.device)
+        lists = None
+        if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:      # (an evaluation forward has no use for the row lists)
+            host = host_np(rel_inds)
+            order, ptr = _pair_lists(host[:, 1], host[:, 2], edge.shape[0])
+            lists = h2d(np.concatenate((order.reshape(-1), ptr.reshape(-1))), edge.device)
         ctx.n_rows = i1.shape[0]
         ctx.has_vis = vis is not None
         ctx.save_for_backward(edge_c, vis_c, i1, i2, lists)
@@ -726,8 +748,13 @@ class RelModel(nn.Module):
 
         result.rel_dists = self.rel_compress(prod_rep)
         if self.use_bias:
-            result.rel_dists = result.rel_dists + self.freq_bias.index_with_labels(torch.stack((
-                result.obj_preds[rel_inds[:, 1]], result.obj_preds[rel_inds[:, 2]]), 1))
+            fb = self.freq_bias.obj_baseline.weight
+            if (_PAIR_PRODUCT and x.is_cuda and result.rel_dists.dtype == torch.float32 and result.obj_preds.dtype == torch.int64
+                    and fb.is_contiguous() and 0 < rel_inds.shape[0] <= _hip.FREQ_BIAS_MAX_ROWS):
+                result.rel_dists = _FreqBiasAddFn.apply(result.rel_dists, fb, result.obj_preds, rel_inds, self.freq_bias.num_objs)
+            else:
+                result.rel_dists = result.rel_dists + self.freq_bias.index_with_labels(torch.stack((
+                    result.obj_preds[rel_inds[:, 1]], result.obj_preds[rel_inds[:, 2]]), 1))
         if self.training:
             return result
 

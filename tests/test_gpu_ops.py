@@ -643,6 +643,38 @@ def test_pair_product_forward_and_backward(hip, n, R, D, with_vis):
     assert torch.equal(e2.grad, e_d.grad)
 
 
+@pytest.mark.parametrize('n,R', [(120, 1536), (9, 40), (3, 1), (80, 6320)])
+def test_frequency_bias_add_forward_and_table_gradient(hip, n, R):
+    """csrc/exact_ops.hip freq_bias_*: rel_dists + FrequencyBias[obj_preds[i1], obj_preds[i2]] as one node (lib/rel_model.py:
+    _FreqBiasAddFn) against the framework's gather / embedding ops -- forward bit for bit; the table's gradient (rows of a key summed
+    in ascending row order by the key's first row) against the same graph in float64, zero everywhere else, bitwise reproducible;
+    few classes so that many rows share a key."""
+    from lib.rel_model import _FreqBiasAddFn
+    g = torch.Generator().manual_seed(n + R)
+    C, P = 151, 51
+    table = torch.randn(C * C, P, generator=g)
+    logits = torch.randn(R, P, generator=g)
+    preds = torch.randint(1, 6 if R > 8 else C, (n,), generator=g)
+    rel = torch.stack((torch.zeros(R, dtype=torch.int64), torch.randint(0, n, (R,), generator=g), torch.randint(0, n, (R,), generator=g)), 1)
+    gout = torch.randn(R, P, generator=g)
+    t_d = table.cuda().requires_grad_(True)
+    l_d = logits.cuda().requires_grad_(True)
+    out = _FreqBiasAddFn.apply(l_d, t_d, preds.cuda(), rel.cuda(), C)
+    keys = preds[rel[:, 1]] * C + preds[rel[:, 2]]
+    assert torch.equal(out.detach().cpu(), logits + table[keys])
+    out.backward(gout.cuda())
+    assert torch.equal(l_d.grad.cpu(), gout)
+    ref = torch.zeros(C * C, P, dtype=torch.float64).index_add_(0, keys, gout.double())
+    got = t_d.grad.cpu()
+    np.testing.assert_allclose(got.numpy(), ref.numpy(), atol=2e-6 * float(ref.abs().max()))
+    untouched = torch.ones(C * C, dtype=torch.bool)
+    untouched[keys] = False
+    assert float(got[untouched].abs().max()) == 0.0
+    t2 = table.cuda().requires_grad_(True)
+    _FreqBiasAddFn.apply(logits.cuda(), t2, preds.cuda(), rel.cuda(), C).backward(gout.cuda())
+    assert torch.equal(t2.grad, t_d.grad)
+
+
 # ----------------------------------------------------------------------------------------------- LSTM
 def _lstm_problem(lengths, in_size, H, nl, seed, p=0.0):
     from oracle import lstm as OL
