@@ -31,6 +31,10 @@ extern "C" {
 #define MH_EPI_NONE 0
 #define MH_EPI_RELU 1
 #define MH_EPI_RELU6 2
+/* OR-ed into `epilogue` of mh_plconv3x3 / _to_image / _pool_to_image (round 6): the first 64 KiB of `workspace` (the arrival
+ * counters of the sliced tiles) were zero when the buffer was first handed to the library and have only been used by these calls
+ * since (every launch leaves them zero): the call skips its memset. */
+#define MH_EPI_WS_ZEROED 0x100
 
 int mh_version(void);
 /* how the fp32 matrix products of mh_gemm_* / mh_conv3x3_* are evaluated (MFMAs per fp32 product): always 3, with

@@ -1367,6 +1367,11 @@ int mh_plconv_pack_weight(const float *w, int Cout, int Cin, int flip_transpose,
     return check_launch("pl::pack_weight_kernel");
 }
 
+// Workspace of a sliced launch: [arrival counters | partial sums of the body | of the tail].  The counters sit FIRST, in a fixed
+// reserve, so that launches of different layers (whose partial-sum regions differ) never write over them: every launch leaves its
+// counters zero (the block that finishes a tile re-arms it), so a caller that hands in a buffer zeroed ONCE (MH_EPI_WS_ZEROED in
+// `epilogue`) needs no memset per launch -- 14 of them per cfg2 step on the main stream (profiles/r06_step_launches_c21.txt).
+static constexpr size_t kCounterReserve = 64 << 10;
 size_t mh_plconv3x3_ws_bytes(int B, int H, int W, int Cin, int Cout)
 {
     const long long M = (long long)B * H * W;
@@ -1374,13 +1379,15 @@ size_t mh_plconv3x3_ws_bytes(int B, int H, int W, int Cin, int Cout)
     const pl::Sched sc = pl::schedule(M, Cin, Cout);
     size_t body, tail, counters;
     pl::partial_bytes(sc, M, Cin, Cout, body, tail, counters);
-    return body + tail + counters;
+    return body + tail + (counters ? std::max(counters, kCounterReserve) : 0);
 }
 
 static int plconv_impl(const void *in_image, const unsigned *in_true_maxbits, int B, int H, int W, int Cin, const void *packed,
                        int Cout, const float *bias, int epilogue, float *out, void *out_image, int pool, unsigned *out_maxbits,
                        void *workspace, size_t ws_bytes, void *stream)
 {
+    const bool ws_zeroed = (epilogue & MH_EPI_WS_ZEROED) != 0;
+    epilogue &= ~MH_EPI_WS_ZEROED;
     // many small images (round 5: the 1536 7x7 RoI maps of the mask tower / the ResNet layer4 stacks): the fp32-output kernels
     // look every row's image up in in_bits; only the image-output epilogue (scale words written by one block) is limited to 256
     MH_REQUIRE(in_image && packed && (out || out_image) && B > 0 && B <= (out_image ? 256 : pl::kMaxImages) && H > 0 && W > 0);
@@ -1410,7 +1417,8 @@ static int plconv_impl(const void *in_image, const unsigned *in_true_maxbits, in
     if (pool && sc.shape < 4) sc = [&] { const int keep = pl::g_conv_shape; pl::g_conv_shape = Cout <= 64 ? 5 : 4; pl::Sched r = pl::schedule(M, Cin, Cout); pl::g_conv_shape = keep; return r; }();   // the pooled epilogue exists on the ring kernels only
     size_t body_bytes, tail_bytes, counter_bytes;
     pl::partial_bytes(sc, M, Cin, Cout, body_bytes, tail_bytes, counter_bytes);
-    if (body_bytes + tail_bytes > 0 && (workspace == nullptr || ws_bytes < body_bytes + tail_bytes + counter_bytes)) {
+    const size_t counter_room = counter_bytes ? std::max(counter_bytes, kCounterReserve) : 0;
+    if (body_bytes + tail_bytes > 0 && (workspace == nullptr || ws_bytes < body_bytes + tail_bytes + counter_room)) {
         sc.pl.splitk = 1; sc.pl.body_mtiles = sc.pl.tiles_m; sc.pl.tail_slices = 1;     // no room for partial sums: whole tiles only
         body_bytes = tail_bytes = counter_bytes = 0;
     }
@@ -1419,9 +1427,10 @@ static int plconv_impl(const void *in_image, const unsigned *in_true_maxbits, in
     p.tiles_m = sc.pl.tiles_m; p.tiles_n = sc.pl.tiles_n;
     p.body_tiles = z.body_tiles; p.ktiles_per_split = z.ktiles_per_split; p.splitk = z.splitk;
     p.tail_tiles = z.tail_tiles; p.tail_ktiles = z.tail_ktiles; p.tail_slices = z.tail_slices; p.tail_row0 = z.tail_row0;
-    p.partial = reinterpret_cast<float *>(workspace);
-    p.partial_tail = reinterpret_cast<float *>(reinterpret_cast<char *>(workspace) + body_bytes);
-    p.counters = reinterpret_cast<int *>(reinterpret_cast<char *>(workspace) + body_bytes + tail_bytes);
+    const size_t counter_off = counter_bytes ? std::max(counter_bytes, kCounterReserve) : 0;       // counters first (see mh_plconv3x3_ws_bytes)
+    p.counters = reinterpret_cast<int *>(workspace);
+    p.partial = reinterpret_cast<float *>(reinterpret_cast<char *>(workspace) + counter_off);
+    p.partial_tail = reinterpret_cast<float *>(reinterpret_cast<char *>(workspace) + counter_off + body_bytes);
     const long long nblocks = (long long)p.tail_tiles * p.tail_slices + (long long)p.body_tiles * p.splitk;
     MH_REQUIRE(nblocks > 0 && nblocks < (1LL << 31));
     hipStream_t st = as_stream(stream);
@@ -1429,9 +1438,9 @@ static int plconv_impl(const void *in_image, const unsigned *in_true_maxbits, in
     constexpr size_t kTabMax = 1024 * 16;                          // the per-k-tile offset table lives in LDS (16 B per k-tile)
     MH_REQUIRE(total_kt <= 1024);
     const size_t tab_bytes = (size_t)total_kt * 16;
-    if (sc.shape >= 4 && counter_bytes) {
+    if (sc.shape >= 4 && counter_bytes && !(ws_zeroed && counter_bytes <= kCounterReserve)) {
         // arrival counters of the sliced tiles: zero on entry (the last block of a tile re-arms its counter, but the workspace is
-        // the caller's scratch: nothing promises it is still zero)
+        // the caller's scratch: nothing promises it is still zero -- unless the caller says so, MH_EPI_WS_ZEROED)
         hipError_t e = hipMemsetAsync(p.counters, 0, counter_bytes, st);
         if (e != hipSuccess) { set_last_error("hipMemsetAsync(conv arrival counters)", e); return (int)e; }
     }

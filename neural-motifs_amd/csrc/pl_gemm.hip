@@ -127,6 +127,14 @@ __global__ __launch_bounds__(256) void planes_both_kernel(const PlaneJob rows_jo
     planes_tile(cols_job, tj * cols_job.tiles_k + ti, lds);
 }
 
+__global__ __launch_bounds__(256) void zero_two_kernel(unsigned *__restrict__ a, long long na, unsigned *__restrict__ b, long long nb)
+{
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < na || i < nb; i += (long long)gridDim.x * 256) {
+        if (i < na) a[i] = 0u;
+        if (i < nb) b[i] = 0u;
+    }
+}
+
 // row AND column |x| maxima of X [R][C] in one pass (both arrays zero on entry): block = 64 rows x 256 columns; a wave owns
 // rows w, w + 4, ... (one shuffle reduction + one atomicMax per row), column maxima are combined over the four waves in LDS
 __global__ __launch_bounds__(256) void absmax_both_kernel(const float *__restrict__ X, long long R, long long C, long long ld, int vec,
@@ -624,9 +632,12 @@ int mh_make_planes_both(const float *X, long long R, long long C, long long ld, 
     MH_REQUIRE(pl::cells_bytes(R, C) < (size_t)0x7ff00000u && pl::cells_bytes(C, R) < (size_t)0x7ff00000u);
     hipStream_t st = as_stream(stream);
     unsigned *rb = pl::image_maxbits(img_rows, R, C), *cb = pl::image_maxbits(img_cols, C, R);
-    hipError_t e = hipMemsetAsync(rb, 0, (size_t)R * 4, st);
-    if (e == hipSuccess) e = hipMemsetAsync(cb, 0, (size_t)C * 4, st);
-    if (e != hipSuccess) { set_last_error("hipMemsetAsync(plane maxima)", e); return (int)e; }
+    // both sets of maxima cleared by ONE launch (they live in two buffers: two memsets were two launches in front of every pair of images)
+    hipLaunchKernelGGL(pl::zero_two_kernel, dim3((unsigned)std::min<long long>(ceil_div(std::max(R, C), 256LL), 1024)), dim3(256), 0, st, rb, R, cb, C);
+    {
+        int rc0 = check_launch("pl::zero_two_kernel");
+        if (rc0) return rc0;
+    }
     const int vec = ((reinterpret_cast<uintptr_t>(X) & 15) == 0 && ld % 4 == 0) ? 1 : 0;
     MH_REQUIRE(ceil_div(R, 64LL) <= 65535);
     hipLaunchKernelGGL(pl::absmax_both_kernel, dim3((unsigned)ceil_div(C, 256LL), (unsigned)ceil_div(R, 64LL)), dim3(256), 0, st, X, R, C,

@@ -216,6 +216,11 @@ def workspace(nbytes, device, tag='default'):
     return buf
 
 
+# include/motifs_hip.h MH_EPI_WS_ZEROED: the workspace's counter words are zero on entry and stay zero (MOTIFS_PLCONV_WS_ZEROED=0: the
+# library clears them per launch, the A/B arm)
+EPI_WS_ZEROED = 0x100 if os.environ.get('MOTIFS_PLCONV_WS_ZEROED', '1') != '0' else 0
+
+
 def zeroed_workspace(nbytes, device, tag):
     """like workspace(), but zero-filled when it is (re)allocated: for kernels that need zeroed scratch on entry and leave it
     zeroed (the split-K arrival counters of mh_gemm_small_f32) -- no memset per call"""
@@ -609,9 +614,9 @@ def plconv3x3(img, packed, cout, bias, epilogue, out_maxbits=None):
     L = lib()
     out = torch.empty(img.B, img.H, img.W, cout, dtype=torch.float32, device=img.buf.device)
     wsb = L.mh_plconv3x3_ws_bytes(img.B, img.H, img.W, img.C, cout)
-    ws = workspace(wsb, out.device, 'conv') if wsb else None
+    ws = zeroed_workspace(wsb, out.device, 'plconv') if wsb else None        # counters first, zero once: no memset per launch (MH_EPI_WS_ZEROED)
     rc = L.mh_plconv3x3(ctypes.c_void_p(img.buf.data_ptr()), img.B, img.H, img.W, img.C, ctypes.c_void_p(packed.data_ptr()), cout,
-                        f32(bias), c_int(epilogue), f32(out), i32(out_maxbits), ptr(ws),
+                        f32(bias), c_int(epilogue | EPI_WS_ZEROED), f32(out), i32(out_maxbits), ptr(ws),
                         c_size_t(ws.numel() if ws is not None else 0), stream())
     _check(rc, 'mh_plconv3x3')
     return out
@@ -623,9 +628,9 @@ def plconv3x3_to_image(img, in_true_maxbits, packed, cout, bias, epilogue, out_m
     L = lib()
     buf = torch.empty(L.mh_act_planes_bytes(img.B, img.H, img.W, cout), dtype=torch.uint8, device=img.buf.device)
     wsb = L.mh_plconv3x3_ws_bytes(img.B, img.H, img.W, img.C, cout)
-    ws = workspace(wsb, buf.device, 'conv') if wsb else None
+    ws = zeroed_workspace(wsb, buf.device, 'plconv') if wsb else None
     rc = L.mh_plconv3x3_to_image(ctypes.c_void_p(img.buf.data_ptr()), i32(in_true_maxbits), img.B, img.H, img.W, img.C,
-                                 ctypes.c_void_p(packed.data_ptr()), cout, f32(bias), c_int(epilogue), ctypes.c_void_p(buf.data_ptr()),
+                                 ctypes.c_void_p(packed.data_ptr()), cout, f32(bias), c_int(epilogue | EPI_WS_ZEROED), ctypes.c_void_p(buf.data_ptr()),
                                  i32(out_maxbits), ptr(ws), c_size_t(ws.numel() if ws is not None else 0), stream())
     _check(rc, 'mh_plconv3x3_to_image')
     return ActImage(buf, img.B, img.H, img.W, cout)
@@ -639,9 +644,9 @@ def plconv3x3_pool_to_image(img, in_true_maxbits, packed, cout, bias, epilogue, 
         raise HipKernelError('plconv3x3_pool_to_image needs even map sizes, got %d x %d' % (img.H, img.W))
     buf = torch.empty(L.mh_act_planes_bytes(img.B, img.H // 2, img.W // 2, cout), dtype=torch.uint8, device=img.buf.device)
     wsb = L.mh_plconv3x3_ws_bytes(img.B, img.H, img.W, img.C, cout)
-    ws = workspace(wsb, buf.device, 'conv') if wsb else None
+    ws = zeroed_workspace(wsb, buf.device, 'plconv') if wsb else None
     rc = L.mh_plconv3x3_pool_to_image(ctypes.c_void_p(img.buf.data_ptr()), i32(in_true_maxbits), img.B, img.H, img.W, img.C,
-                                      ctypes.c_void_p(packed.data_ptr()), cout, f32(bias), c_int(epilogue), ctypes.c_void_p(buf.data_ptr()),
+                                      ctypes.c_void_p(packed.data_ptr()), cout, f32(bias), c_int(epilogue | EPI_WS_ZEROED), ctypes.c_void_p(buf.data_ptr()),
                                       i32(out_maxbits), ptr(ws), c_size_t(ws.numel() if ws is not None else 0), stream())
     _check(rc, 'mh_plconv3x3_pool_to_image')
     return ActImage(buf, img.B, img.H // 2, img.W // 2, cout)
