@@ -80,8 +80,11 @@ class _TowerFn(torch.autograd.Function):
             return bn.running_mean, torch.rsqrt(bn.running_var + bn.eps)
         mean1, invstd1 = stats(y0.view(-1, C0), bn1)
         if training:
-            bn1.num_batches_tracked += 1
-            bn2.num_batches_tracked += 1
+            if bn1.num_batches_tracked.is_cuda:
+                torch._foreach_add_([bn1.num_batches_tracked, bn2.num_batches_tracked], 1)       # one launch for both counters
+            else:
+                bn1.num_batches_tracked += 1
+                bn2.num_batches_tracked += 1
         z, arg = _hip.bn_pool_fwd(y0, mean1, invstd1, g1, be1)
         ctx.maps = hip_ops._small_maps_on_planes(z, w4.shape[1], C1) and w4.shape[1] >= 128
         if ctx.maps:                  # the 3x3 conv over the N 7x7 maps on the ring engine (lib/hip_ops.py: conv3x3_small_maps)

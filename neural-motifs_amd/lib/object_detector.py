@@ -23,7 +23,7 @@ from lib.fpn.proposal_assignments.proposal_assignments_det import proposal_assig
 from lib.fpn.roi_align.functions.roi_align import RoIAlignFunction
 from lib.hip_ops import (AlphaDropout, Conv3x3, Dropout, FCStack, Linear, ReLU, VGG16Features, EPI_NONE, EPI_RELU6, _is_nhwc,
                          _Conv3x3Fn, linear)
-from lib.pytorch_misc import enumerate_by_image, gather_nd, has_host, host_np, set_host
+from lib.pytorch_misc import enumerate_by_image, gather_nd, h2d, has_host, host_np, set_host
 
 
 class Result(object):
@@ -187,12 +187,17 @@ class ObjectDetector(nn.Module):
     def gt_boxes(self, fmap, im_sizes, image_offset, gt_boxes=None, gt_classes=None, gt_rels=None,
                  train_anchor_inds=None, proposals=None):
         assert gt_boxes is not None
-        im_inds = gt_classes[:, 0] - image_offset
-        rois = torch.cat((im_inds.float()[:, None], gt_boxes), 1)
         mirrored = has_host(gt_classes) and has_host(gt_boxes)
         if mirrored:        # GT arrays of a Blob carry their host values: the sampler / packing order need no D2H copy
-            set_host(rois, np.column_stack(((host_np(gt_classes)[:, 0] - image_offset).astype(np.float32),
-                                            host_np(gt_boxes).astype(np.float32))))
+            rois_np = np.ascontiguousarray(np.column_stack(((host_np(gt_classes)[:, 0] - image_offset).astype(np.float32),
+                                                            host_np(gt_boxes).astype(np.float32))))
+            if gt_boxes.is_cuda and not gt_boxes.requires_grad:
+                rois = set_host(h2d(rois_np, gt_boxes.device), rois_np)       # one upload instead of subtract + cast + concatenate (round 6)
+            else:
+                rois = set_host(torch.cat(((gt_classes[:, 0] - image_offset).float()[:, None], gt_boxes), 1), rois_np)
+        else:
+            im_inds = gt_classes[:, 0] - image_offset
+            rois = torch.cat((im_inds.float()[:, None], gt_boxes), 1)
         if gt_rels is not None and self.training:
             rois, labels, rel_labels = proposal_assignments_gtbox(
                 rois, gt_boxes, gt_classes, gt_rels, image_offset, fg_thresh=0.5, rs=getattr(self, 'sampler_rs', None))
@@ -254,9 +259,13 @@ class ObjectDetector(nn.Module):
             else:
                 rm_obj_labels = None
         else:
-            im_inds = rois[:, 0].long().contiguous() + image_offset
-            if has_host(rois):
-                set_host(im_inds, host_np(rois)[:, 0].astype(np.int64) + image_offset)
+            if has_host(rois) and rois.is_cuda:
+                im_np = np.ascontiguousarray(host_np(rois)[:, 0].astype(np.int64) + image_offset)
+                im_inds = set_host(h2d(im_np, rois.device), im_np)           # (was cast + copy + add on the device)
+            else:
+                im_inds = rois[:, 0].long().contiguous() + image_offset
+                if has_host(rois):
+                    set_host(im_inds, host_np(rois)[:, 0].astype(np.int64) + image_offset)
             nms_scores = nms_preds = nms_boxes_assign = nms_boxes = None
             box_priors = rois[:, 1:]
             if has_host(rois):

@@ -11,7 +11,7 @@ def test_cited_profile_files_exist():
     for md in ('DESIGN.md', 'BASELINE.md', 'README.md', 'INTEGRATION.md', os.path.join('profiles', 'README.md'),
                os.path.join('tools', 'README.md')):
         txt = open(os.path.join(ROOT, md)).read()
-        for m in re.finditer(r'`((?:profiles/)?r0[12345]_[A-Za-z0-9_.*\-]+\.(?:json|jsonl|csv|txt))`', txt):
+        for m in re.finditer(r'`((?:profiles/)?r0[123456]_[A-Za-z0-9_.*\-]+\.(?:json|jsonl|csv|txt))`', txt):
             name = m.group(1).replace('1..5', '*')                      # "set1..5.csv" = the five counter-set files
             path = name if name.startswith('profiles/') else os.path.join('profiles', name)
             if not glob.glob(os.path.join(ROOT, path)):
