@@ -844,3 +844,46 @@ def test_trainable_resnet_trunk_plumbing_on_the_cpu_shim(shim):
     from parity_util import assert_resnet_piece_gradients, assert_resnet_trunk_gradients
     assert assert_resnet_piece_gradients('cpu', 'resnet pieces (cpu shim)') >= 40
     assert assert_resnet_trunk_gradients('cpu', 'resnet trunk + compress (cpu shim)') == 30 * 9 + 3 * 3 + 3 + 4
+
+
+def test_pair_lists_and_host_union_geometry_equal_the_device_arithmetic(shim):
+    """round 6, host side of the relation tail: (a) lib.rel_model._pair_lists -- for every box and side the rows that name it, in
+    ascending row order, with offsets into ONE flattened list -- against a brute-force scan; (b) the union rectangles / pair boxes
+    lib.get_union_boxes computes in numpy from the host mirrors are the values the device expressions give (min / max / gather of
+    fp32: exact), and the samplers attach the mirror of what they upload."""
+    from lib.rel_model import _pair_lists, _cols_from
+    from lib.pytorch_misc import set_host, has_host, host_np
+    rs = np.random.RandomState(3)
+    for n, R in ((5, 1), (7, 40), (120, 1536)):
+        i1, i2 = rs.randint(0, max(n - 1, 1), R), rs.randint(0, n, R)
+        order, ptr = _pair_lists(i1, i2, n)
+        assert order.dtype == np.int32 and ptr.dtype == np.int32 and order.shape == (2, R) and ptr.shape == (2, n + 1)
+        flat = order.reshape(-1)
+        for side, idx in enumerate((i1, i2)):
+            for box in range(n):
+                rows = flat[ptr[side, box]:ptr[side, box + 1]]
+                assert rows.tolist() == np.nonzero(idx == box)[0].tolist()          # the rows of this box, ascending
+            assert ptr[side, 0] == side * R and ptr[side, n] == side * R + R
+    # (b) geometry
+    rois = np.concatenate((rs.randint(0, 3, (20, 1)).astype(np.float32), (rs.rand(20, 4) * 500).astype(np.float32)), 1)
+    rois[:, 3:] += rois[:, 1:3]
+    pairs = rs.randint(0, 20, (64, 2)).astype(np.int64)
+    rt, pt = torch.from_numpy(rois), torch.from_numpy(pairs)
+    dev_union = torch.cat((rt[:, 0][pt[:, 0]][:, None], torch.min(rt[:, 1:3][pt[:, 0]], rt[:, 1:3][pt[:, 1]]),
+                           torch.max(rt[:, 3:5][pt[:, 0]], rt[:, 3:5][pt[:, 1]])), 1)
+    a, b = rois[pairs[:, 0]], rois[pairs[:, 1]]
+    host_union = np.concatenate((a[:, :1], np.minimum(a[:, 1:3], b[:, 1:3]), np.maximum(a[:, 3:5], b[:, 3:5])), 1)
+    np.testing.assert_array_equal(dev_union.numpy(), host_union)
+    np.testing.assert_array_equal(torch.cat((rt[:, 1:][pt[:, 0]], rt[:, 1:][pt[:, 1]]), 1).numpy(), np.concatenate((a[:, 1:], b[:, 1:]), 1))
+    t = set_host(torch.arange(12).view(4, 3), np.arange(12).reshape(4, 3))
+    c = _cols_from(t, 1)
+    assert has_host(c) and np.array_equal(host_np(c), c.numpy())
+    # the GT-box sampler hands out what it uploaded
+    from dataloaders.synthetic import SyntheticVG, make_blob
+    from lib.fpn.proposal_assignments.proposal_assignments_gtbox import proposal_assignments_gtbox
+    ds = SyntheticVG(num_images=2, seed=4, n_boxes=[4, 5], n_rels=4, im_size=96)
+    blob = make_blob(ds, [0, 1], is_train=True)
+    x, im_sizes, off, gt_boxes, gt_classes, gt_rels = blob[0][:6]
+    rois_t = torch.cat((gt_classes[:, 0].float()[:, None], gt_boxes), 1)
+    _, _, rel_labels = proposal_assignments_gtbox(rois_t, gt_boxes, gt_classes, gt_rels, 0, fg_thresh=0.5, rs=np.random.RandomState(0))
+    assert has_host(rel_labels) and np.array_equal(host_np(rel_labels), rel_labels.numpy())
