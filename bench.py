@@ -192,7 +192,7 @@ def hbm_rows(meters, steps, opt_ms=None, opt_bytes=None):
                           'frac': summ['gbps'] / (PEAK_HBM_TBS * 1e3), 'launches_per_step': summ['launches'] / steps,
                           'ms_per_step': summ['total_ms'] / steps, 'bytes_per_step': summ['bytes'] / steps}
     row('roi_align_fwd', meters['roi'].summary(), 'RoIAlign 7x7 forward (objects + union boxes): output bytes + feature map once')
-    row('stem_to_image', meters['stem'].summary(), 'conv1_1 (3 -> 64 channels, VALU) writing its output as a plane image: NCHW input + image bytes')
+    row('stem_to_image', meters['stem'].summary(), 'conv1_1 (3 -> 64 channels, on the matrix cores since round 6: im2col rows built in LDS, K = 27 -> 32) writing its output as a plane image: NCHW input + image bytes')
     row('act_planes', meters['act'].summary(), 'fp32 NHWC -> plane image (2x2 pool fused where the trunk has one): bytes in + bytes out')
     row('make_planes', merge(meters['planes'].summary(), meters['planes_both'].summary()),
         'GEMM operand preparation (row maxima + split, both orientations from one read where both are needed): read once + images written')
