@@ -1,5 +1,6 @@
 #!/bin/bash
 # GPU call 28 (round 6): do the +1 ms steps of a young process go away when the GPU is loaded for a few hundred ms before the warm-up?
+# (the --preheat-ms option of bench.py existed for this call only: it changed nothing and was removed again)
 set -u
 OUT=gpurun_out/r06_c28; mkdir -p $OUT
 show() { python - "$1" "$2" <<'PY'

@@ -1,5 +1,6 @@
 #!/bin/bash
 # GPU call 29 (round 6): allocator activity during the timed steps (are the +1 ms steps of a young process device allocations?)
+# (MOTIFS_BENCH_ALLOC_TRACE existed in bench.py for this call only: no device allocation happens in the timed steps; removed again)
 set -u
 OUT=gpurun_out/r06_c29; mkdir -p $OUT
 MOTIFS_BENCH_ALLOC_TRACE=1 timeout 200 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --h2d-steps 0 > $OUT/trace.json 2> $OUT/trace.err
