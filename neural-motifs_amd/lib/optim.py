@@ -45,8 +45,14 @@ class FusedClipSGD(torch.optim.Optimizer):
         # hence the sparse events.  MOTIFS_MAX_AHEAD: -1 = unbounded, 0 = synchronise every step.
         # Round 5 re-measured the bound on the lighter step (gpurun r05_c6, one box, first 12 / last 8 of 20 timed steps after 5
         # warm-up steps): bound 8: 16.5-16.7 / 16.0 ms -- while the host is still racing ahead about every second step takes 17+ ms;
-        # bound 4: 16.17 / 16.01; bound 2: 16.16 / 16.00 (365.8-368.2 -> 372.5 / 372.7 img/s).  Default 4.
-        self.max_ahead = int(os.environ.get('MOTIFS_MAX_AHEAD', '4'))
+        # bound 4: 16.17 / 16.01; bound 2: 16.16 / 16.00 (365.8-368.2 -> 372.5 / 372.7 img/s).
+        # Round 6 (gpurun r06_c23, c28-c31): the slow steps are a cluster of four or five +1.2 ms steps around step 9-13 of a PROCESS --
+        # while the host is still gaining on the GPU -- whatever is metered, with or without matrix-core load in front of the
+        # warm-up, with no device allocation in sight; bounds 2 / 3 / 4 / 8 all show it, bound 1 does not (three of three runs:
+        # 437.7 / 438.2 / 433.3 img/s against 429.5 / 432.8 / 433.5 at bound 4 over 20 timed steps after 5 warm-up steps), and the
+        # steady state is the same or better (60 steps: 438.7 / 438.8 against 437.7 / 436.5; recipe 409-414 against 390-402;
+        # cfg3 / cfg4 equal).  The host needs 7-8 ms to enqueue a 13.7 ms step, so one step of lead keeps the GPU fed.  Default 1.
+        self.max_ahead = int(os.environ.get('MOTIFS_MAX_AHEAD', '1'))
         self._done_events = []
         self._table = None
         self._table_key = None
