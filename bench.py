@@ -788,11 +788,17 @@ def main():
     if world > 1:
         model.rows_hook = roww.start          # the row-count all-reduce starts inside the forward pass, asynchronously
 
+    ahead = {}
+
     def step(i, upload=False):
         blob = blobs[i % len(blobs)]
-        if upload:                           # the reference's per-step scatter (train_rels.py:137, blob.py:155-180): 25 MB of
+        if upload == 'inline':               # the reference's per-step scatter (train_rels.py:137, blob.py:155-180): 25 MB of
             blob = copy.copy(host_blobs[i % len(host_blobs)])      # page-locked batch -> HBM, asynchronous, ordered on the stream
             blob.scatter()
+        elif upload:                         # the shipped loop (models/train_rels.py): the NEXT batch's copies start on the copy stream
+            blob = ahead.pop(i, None) or copy.copy(host_blobs[i % len(host_blobs)])      # while this step runs (Blob.prefetch)
+            blob.scatter()
+            ahead[i + 1] = copy.copy(host_blobs[(i + 1) % len(host_blobs)]).prefetch()
         res = model[blob]
         l_obj = F.cross_entropy(res.rm_obj_dists, res.rm_obj_labels)
         l_rel = F.cross_entropy(res.rel_dists, res.rel_labels[:, -1])
@@ -869,9 +875,25 @@ def main():
         dth = float(dth.item())
         nbytes = sum(getattr(host_blobs[0], n).numel() * getattr(host_blobs[0], n).element_size()
                      for n in ('imgs', 'gt_boxes', 'gt_classes', 'gt_rels'))
+        # ... and the reference's placement of the copy: on the compute stream, in front of the step's first kernel
+        ahead.clear()
+        for i in range(2):
+            step(i, upload='inline')
+        barrier()
+        t1b = time.time()
+        for i in range(args.h2d_steps):
+            step(2 + i, upload='inline')
+        barrier()
+        dti = torch.tensor([time.time() - t1b], dtype=torch.float64, device=dev)
+        if world > 1:
+            torch.distributed.all_reduce(dti, op=torch.distributed.ReduceOp.MAX)
+        dti = float(dti.item())
         h2d = {'value': world * BATCH * args.h2d_steps / dth, 'unit': 'img/s', 'ms_per_step': 1e3 * dth / args.h2d_steps,
                'steps': args.h2d_steps, 'bytes_per_step': nbytes,
-               'what': 'same step with the batch uploaded (pinned host -> HBM, async on the main stream) inside every step, unmetered'}
+               'what': 'same step with a batch uploaded in every step (pinned host -> HBM), unmetered: the NEXT batch\'s copies run on a copy '
+                       'stream while the step computes (Blob.prefetch, what models/train_rels.py does)',
+               'inline': {'value': world * BATCH * args.h2d_steps / dti, 'ms_per_step': 1e3 * dti / args.h2d_steps,
+                          'what': 'the same with the copies on the compute stream in front of the step (the reference\'s placement, round 5\'s figure)'}}
 
     # third timing, meters off, inputs resident: what the headline would be without the sampled HIP-event pairs
     unmetered = None

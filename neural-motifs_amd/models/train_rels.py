@@ -98,10 +98,13 @@ if rank == 0:
     print('detector stage: %s' % ('%d batch(es) ahead of the step' % DETECT_AHEAD if DETECT_AHEAD else 'in line'), flush=True)
 
 
-def train_batch(b, verbose=False, start_ahead=()):
+def train_batch(b, verbose=False, start_ahead=(), upload_ahead=()):
     result = detector[b]
     for nb in start_ahead:
         detector.detect_ahead_blob(nb)
+    for nb in upload_ahead:          # the next batch's host -> HBM copies start now, on the copy stream (dataloaders/blob.py: Blob.prefetch)
+        if hasattr(nb, 'prefetch'):
+            nb.prefetch()
     l_obj = F.cross_entropy(result.rm_obj_dists, result.rm_obj_labels)
     l_rel = F.cross_entropy(result.rel_dists, result.rel_labels[:, -1])
     if world > 1:      # global-mean loss semantics of the single-process reference
@@ -154,7 +157,8 @@ def train_epoch(epoch_num):
     for b, (batch, following) in enumerate(with_ahead(train_loader, max(DETECT_AHEAD, 1))):
         if conf.max_iters and b >= conf.max_iters:
             break
-        pending.append(train_batch(batch, verbose=b % (conf.print_interval * 10) == 0, start_ahead=following if DETECT_AHEAD else ()))
+        pending.append(train_batch(batch, verbose=b % (conf.print_interval * 10) == 0, start_ahead=following if DETECT_AHEAD else (),
+                                   upload_ahead=() if DETECT_AHEAD else following))
         if b % conf.print_interval == 0 and b >= conf.print_interval:
             frames.append(_loss_frame(pending))
             pending = []

@@ -435,3 +435,40 @@ def test_trainable_resnet_trunk_gradients():
     from parity_util import assert_resnet_piece_gradients, assert_resnet_trunk_gradients
     assert assert_resnet_piece_gradients('cuda', 'resnet pieces') >= 40
     assert assert_resnet_trunk_gradients('cuda', 'resnet trunk + compress') == 30 * 9 + 3 * 3 + 3 + 4
+
+
+def test_prefetched_batch_equals_the_scattered_one_and_its_step_equals_the_in_line_step():
+    """dataloaders/blob.py Blob.prefetch (round 6): the batch's host -> HBM copies on the copy stream one step ahead; scatter() then only
+    waits for their event.  The tensors (and the host mirrors of the GT arrays) are those of an in-line scatter, a forward on the
+    prefetched batch is bit for bit the forward on the scattered one, and a batch that is not page-locked or already on the device
+    is left alone."""
+    import copy
+    from dataloaders.synthetic import SyntheticVG, make_blob
+    from lib.pytorch_misc import has_host, host_np
+    from lib.rel_model import RelModel
+    torch.manual_seed(2)
+    ds = SyntheticVG(num_images=4, seed=11, n_boxes=6, n_rels=8, im_size=224)
+    model = RelModel(classes=ds.ind_to_classes, rel_classes=ds.ind_to_predicates, mode='sgcls', num_gpus=1, hidden_dim=128,
+                     pooling_dim=4096, nl_obj=1, nl_edge=1, order='leftright', rec_dropout=0.0, use_bias=True, use_tanh=False,
+                     limit_vision=False, pass_in_obj_feats_to_decoder=False, pass_in_obj_feats_to_edge=False).cuda().eval()
+    host = make_blob(ds, [0], is_train=False).pin_memory()             # (evaluation decodes one image at a time)
+    a, b = copy.copy(host), copy.copy(host)
+    a.scatter()
+    assert b.prefetch() is b and b._prefetch_event is not None
+    x = torch.randn(2048, 2048, device='cuda') @ torch.randn(2048, 2048, device='cuda')         # the compute stream is busy meanwhile
+    b.scatter()
+    assert b._prefetch_event is None
+    for name in ('imgs', 'gt_boxes', 'gt_classes', 'gt_rels'):
+        ta, tb = getattr(a, name), getattr(b, name)
+        assert tb.is_cuda and torch.equal(ta, tb), name
+        if name != 'imgs':
+            assert has_host(tb) and np.array_equal(host_np(ta), host_np(tb))
+    with torch.no_grad():
+        ra, rb = model[a], model[b]
+    for u, v in zip(ra, rb):
+        np.testing.assert_array_equal(np.asarray(u), np.asarray(v))
+    c = make_blob(ds, [2], is_train=False)                     # pageable: prefetch leaves it alone, scatter uploads it
+    assert c.prefetch() is c and getattr(c, '_prefetch_event', None) is None and not c.imgs.is_cuda
+    c.scatter()
+    assert c.imgs.is_cuda and c.prefetch() is c and getattr(c, '_prefetch_event', None) is None
+    del x
