@@ -14,8 +14,10 @@ process group of another size, is an error, never a silent smaller run.
 
 Step-time distribution: every timed step is bracketed by HIP events on the main stream and by host timestamps;
 `ms_per_step` stays the wall-clock mean the driver expects, `step_ms` carries p50 / p90 / max / the per-step list.
-`h2d_inclusive` re-times a few steps with the batch uploaded from page-locked host memory INSIDE each step (what
-models/train_rels.py:137 + dataloaders/blob.py:155-180 do per step); `value` itself is quoted with inputs resident in HBM.
+`h2d_inclusive` re-times a few steps with a batch uploaded from page-locked host memory in EVERY step (what
+models/train_rels.py:137 + dataloaders/blob.py:155-180 do per step): the next batch's copies run on a copy stream while the
+step computes (Blob.prefetch, the shipped training loop), `h2d_inclusive.inline` = the copies on the compute stream in front
+of the step (the reference's placement); `value` itself is quoted with inputs resident in HBM.
 
 Extra objects in the line:
   roofline     -- the dominant kernel class, the 3x3 convolutions as implicit GEMMs on the matrix cores (12 trunk layers on
