@@ -83,3 +83,19 @@ def test_what_is_not_covered_fails_loudly(tmp_path):
         h5lite.File(str(q))
     with pytest.raises(ValueError):
         h5lite.File(os.path.join(GOLDEN, FIXTURES[0]), 'w')
+
+
+def test_the_rest_of_the_covered_format_reads_back_exactly():
+    """tests/golden/h5lite_types.h5 (same generator, real library): nested groups, a big-endian and a 64-bit float type, a 3-D and a
+    scalar dataset, chunks without filters, the fletcher32 checksum, a compact dataset"""
+    from dataloaders import h5lite
+    exp = np.load(os.path.join(GOLDEN, 'h5lite_types_expected.npz'))
+    with h5lite.File(os.path.join(GOLDEN, 'h5lite_types.h5')) as f:
+        assert f.keys() == ['checksummed', 'compact', 'grp', 'plain_chunks', 'scalar']
+        assert f['grp'].keys() == ['f64', 'sub'] and f['grp/sub'].keys() == ['i16_be', 'u8'] and 'grp/sub/u8' in f and 'grp/nope' not in f
+        for k in exp.files:
+            d = f[k.replace('__', '/')]
+            got = d[()] if d.shape == () else d[:]
+            assert d.shape == exp[k].shape and np.array_equal(np.asarray(got), exp[k]), k
+        assert f['grp/sub/i16_be'].dtype == np.dtype('>i2') and f['grp/sub/i16_be'][:].dtype == np.dtype('int16')      # values come back in native order
+        assert f['grp']['sub']['u8'].shape == (4, 3, 2)
