@@ -887,3 +887,32 @@ def test_pair_lists_and_host_union_geometry_equal_the_device_arithmetic(shim):
     rois_t = torch.cat((gt_classes[:, 0].float()[:, None], gt_boxes), 1)
     _, _, rel_labels = proposal_assignments_gtbox(rois_t, gt_boxes, gt_classes, gt_rels, 0, fg_thresh=0.5, rs=np.random.RandomState(0))
     assert has_host(rel_labels) and np.array_equal(host_np(rel_labels), rel_labels.numpy())
+
+
+def test_leader_per_key_sum_is_an_ordered_index_add():
+    """the algorithm of csrc/exact_ops.hip freq_bias_bwd_kernel replayed on the host: row l is the leader of its key when no earlier row
+    has the key; the leader adds the gradient rows of its key in ascending row order (the wave's ballot + prefix keeps that order) --
+    every key gets exactly one writer, the result is index_add with a fixed summation order"""
+    rs = np.random.RandomState(5)
+    for R, nkeys in ((1, 1), (40, 5), (1536, 37), (300, 300)):
+        keys = rs.randint(0, nkeys, R)
+        g = rs.randn(R, 51).astype(np.float32)
+        table = np.zeros((nkeys, 51), np.float32)
+        writers = np.zeros(nkeys, int)
+        for l in range(R):
+            if (keys[:l] == keys[l]).any():
+                continue                                            # an earlier row leads this key
+            rows = []
+            for r0 in range(l, R, 64):                              # the wave walks the rows 64 at a time
+                lanes = np.arange(r0, min(r0 + 64, R))
+                hit = keys[lanes] == keys[l]
+                rows += lanes[hit].tolist()                         # ballot + popcount prefix = ascending lane order
+            acc = np.zeros(51, np.float32)
+            for r in rows:
+                acc = acc + g[r]
+            table[keys[l]] = acc
+            writers[keys[l]] += 1
+        assert (writers[np.unique(keys)] == 1).all() and writers.sum() == len(np.unique(keys))
+        ref = np.zeros((nkeys, 51), np.float64)
+        np.add.at(ref, keys, g.astype(np.float64))
+        np.testing.assert_allclose(table, ref, atol=1e-5)
