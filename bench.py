@@ -757,6 +757,7 @@ def main():
 
     from dataloaders.synthetic import SyntheticVG, make_blob
     from lib import _hip
+    from lib.losses import relation_losses
     from lib.optim import FusedClipSGD
     from lib.rel_model import RelModel
 
@@ -802,13 +803,8 @@ def main():
             blob.scatter()
             ahead[i + 1] = copy.copy(host_blobs[(i + 1) % len(host_blobs)]).prefetch()
         res = model[blob]
-        l_obj = F.cross_entropy(res.rm_obj_dists, res.rm_obj_labels)
-        l_rel = F.cross_entropy(res.rel_dists, res.rel_labels[:, -1])
-        if world > 1:
-            w = roww.get()
-            loss = l_obj * w[0] + l_rel * w[1]
-        else:
-            loss = l_obj + l_rel
+        ls = relation_losses(res)            # [class loss, relation loss]: models/train_rels.py:140-141 as one node (lib/losses.py)
+        loss = (ls * roww.get()).sum() if world > 1 else ls.sum()
         opt.zero_grad(set_to_none=True)
         reducer.prepare()
         loss.backward()                  # N > 1: each 32 MB gradient bucket is all-reduced (RCCL) as soon as it is complete
@@ -929,7 +925,7 @@ def main():
             marks.append([_ev(), None, None, None, None])
             blob = blobs[i % len(blobs)]
             res = model[blob]
-            loss_i = F.cross_entropy(res.rm_obj_dists, res.rm_obj_labels) + F.cross_entropy(res.rel_dists, res.rel_labels[:, -1])
+            loss_i = relation_losses(res).sum()
             marks[-1][2] = _ev()
             opt.zero_grad(set_to_none=True)
             reducer.prepare()

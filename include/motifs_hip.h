@@ -129,6 +129,18 @@ int mh_freq_bias_add(const float *logits, const float *table, const long long *l
                      int P, int num_objs, float *out, long long *keys, void *stream);
 int mh_freq_bias_bwd(const float *grad_out, const long long *keys, int R, int P, long long table_rows, float *d_table, void *stream);
 
+/* The training script's two cross-entropy losses (round 6; /root/reference models/train_rels.py:140-141:
+ * `F.cross_entropy(result.rm_obj_dists, result.rm_obj_labels)`, `F.cross_entropy(result.rel_dists, result.rel_labels[:, -1])`) in
+ * two launches, their backward in one.  logits_x [Rx][Cx] fp32 contiguous; label of row r at labels_x[r * stride_x] (int64,
+ * 0 <= label < Cx).  Forward: lse [Ra + Rb] (log-sum-exp per row, kept for the backward pass), rowloss [Ra + Rb] (scratch),
+ * losses [2] = the two means (summed in a fixed order).  Backward: grad_x[r][c] = (exp(x - lse_r) - [c == label_r]) * upstream[x] / Rx,
+ * upstream [2] on the device; a NULL grad pointer skips that side. */
+int mh_ce_pair_fwd(const float *logits_a, const long long *labels_a, long long stride_a, int Ra, int Ca, const float *logits_b,
+                   const long long *labels_b, long long stride_b, int Rb, int Cb, float *lse, float *rowloss, float *losses, void *stream);
+int mh_ce_pair_bwd(const float *logits_a, const long long *labels_a, long long stride_a, int Ra, int Ca, const float *logits_b,
+                   const long long *labels_b, long long stride_b, int Rb, int Cb, const float *lse, const float *upstream, float *grad_a,
+                   float *grad_b, void *stream);
+
 /* fp32 pairwise IoU, torch semantics of lib/fpn/box_utils.py:85-131: out[a,b] */
 int mh_bbox_overlaps(const float *boxes_a, int na, const float *boxes_b, int nb, float *out,
                      void *stream);

@@ -825,6 +825,75 @@ __global__ __launch_bounds__(64) void freq_bias_bwd_kernel(const float *__restri
     }
 }
 
+// ---- the training script's two losses (reference models/train_rels.py:140-141: F.cross_entropy(result.rm_obj_dists, result.rm_obj_labels)
+// and F.cross_entropy(result.rel_dists, result.rel_labels[:, -1])) as ONE node ---------------------------------------------------------
+// The framework evaluates each as log_softmax + nll_loss (+ their two backward kernels and fills): ~25 launches of a few microseconds on
+// the main stream between the relation tail and the first product of the backward pass.  Here: one wave per row (row maximum,
+// sum of exponentials, log-sum-exp kept for the backward pass, row loss), a one-block ordered sum for the two means, and one backward
+// launch: grad[r][c] = (exp(x - lse_r) - [c == label_r]) * upstream / rows.
+__device__ __forceinline__ float wave_max_f(float v) { for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o)); return v; }
+__device__ __forceinline__ float wave_sum_f(float v) { for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o); return v; }
+struct CeSide {
+    const float *logits;        // [R][C]
+    const long long *labels;    // element r at labels[r * label_stride]
+    long long label_stride;
+    int R, C;
+};
+__global__ __launch_bounds__(256) void ce_pair_rows_kernel(CeSide a, CeSide b, float *__restrict__ lse, float *__restrict__ rowloss)
+{
+    const int row = (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= a.R + b.R) return;
+    const CeSide &s = row < a.R ? a : b;
+    const int r = row < a.R ? row : row - a.R;
+    const float *x = s.logits + (size_t)r * s.C;
+    float m = -__builtin_inff();
+    for (int c = lane; c < s.C; c += 64) m = fmaxf(m, x[c]);
+    m = wave_max_f(m);
+    float sum = 0.f;
+    for (int c = lane; c < s.C; c += 64) sum += expf(x[c] - m);
+    sum = wave_sum_f(sum);
+    if (lane == 0) {
+        const float l = m + logf(sum);
+        lse[row] = l;
+        rowloss[row] = l - x[s.labels[(size_t)r * s.label_stride]];
+    }
+}
+// losses[0] = mean of the first Ra row losses, losses[1] = mean of the next Rb: one block, fixed order (deterministic)
+__global__ __launch_bounds__(256) void ce_pair_mean_kernel(const float *__restrict__ rowloss, int Ra, int Rb, float *__restrict__ losses)
+{
+    __shared__ float red[256];
+    for (int side = 0; side < 2; ++side) {
+        const float *p = rowloss + (side ? Ra : 0);
+        const int n = side ? Rb : Ra;
+        float acc = 0.f;
+        for (int i = threadIdx.x; i < n; i += 256) acc += p[i];
+        red[threadIdx.x] = acc;
+        __syncthreads();
+        for (int o = 128; o > 0; o >>= 1) {
+            if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) losses[side] = n > 0 ? red[0] / (float)n : 0.f;
+        __syncthreads();
+    }
+}
+__global__ __launch_bounds__(256) void ce_pair_bwd_kernel(CeSide a, CeSide b, const float *__restrict__ lse, const float *__restrict__ upstream,
+                                                          float *__restrict__ grad_a, float *__restrict__ grad_b)
+{
+    const int row = (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= a.R + b.R) return;
+    const bool first = row < a.R;
+    const CeSide &s = first ? a : b;
+    const int r = first ? row : row - a.R;
+    float *g = (first ? grad_a : grad_b);
+    if (!g) return;
+    const float scale = upstream[first ? 0 : 1] / (float)s.R;
+    const float *x = s.logits + (size_t)r * s.C;
+    const float l = lse[row];
+    const int label = (int)s.labels[(size_t)r * s.label_stride];
+    for (int c = lane; c < s.C; c += 64) g[(size_t)r * s.C + c] = (expf(x[c] - l) - (c == label ? 1.f : 0.f)) * scale;
+}
+
 }  // namespace mh
 
 using namespace mh;
@@ -1084,6 +1153,31 @@ int mh_freq_bias_bwd(const float *grad_out, const long long *keys, int R, int P,
     MH_REQUIRE(grad_out && keys);
     hipLaunchKernelGGL(freq_bias_bwd_kernel, dim3((unsigned)R), dim3(64), 0, st, grad_out, keys, R, P, d_table);
     return check_launch("freq_bias_bwd_kernel");
+}
+
+int mh_ce_pair_fwd(const float *logits_a, const long long *labels_a, long long stride_a, int Ra, int Ca, const float *logits_b,
+                   const long long *labels_b, long long stride_b, int Rb, int Cb, float *lse, float *rowloss, float *losses, void *stream)
+{
+    MH_REQUIRE(Ra > 0 && Rb > 0 && Ca > 0 && Cb > 0 && stride_a > 0 && stride_b > 0);
+    MH_REQUIRE(logits_a && labels_a && logits_b && labels_b && lse && rowloss && losses);
+    const CeSide a{logits_a, labels_a, stride_a, Ra, Ca}, b{logits_b, labels_b, stride_b, Rb, Cb};
+    hipStream_t st = as_stream(stream);
+    hipLaunchKernelGGL(ce_pair_rows_kernel, dim3((unsigned)((Ra + Rb + 3) / 4)), dim3(256), 0, st, a, b, lse, rowloss);
+    int rc = check_launch("ce_pair_rows_kernel");
+    if (rc) return rc;
+    hipLaunchKernelGGL(ce_pair_mean_kernel, dim3(1), dim3(256), 0, st, rowloss, Ra, Rb, losses);
+    return check_launch("ce_pair_mean_kernel");
+}
+
+int mh_ce_pair_bwd(const float *logits_a, const long long *labels_a, long long stride_a, int Ra, int Ca, const float *logits_b,
+                   const long long *labels_b, long long stride_b, int Rb, int Cb, const float *lse, const float *upstream, float *grad_a,
+                   float *grad_b, void *stream)
+{
+    MH_REQUIRE(Ra > 0 && Rb > 0 && Ca > 0 && Cb > 0 && stride_a > 0 && stride_b > 0);
+    MH_REQUIRE(logits_a && labels_a && logits_b && labels_b && lse && upstream && (grad_a || grad_b));
+    const CeSide a{logits_a, labels_a, stride_a, Ra, Ca}, b{logits_b, labels_b, stride_b, Rb, Cb};
+    hipLaunchKernelGGL(ce_pair_bwd_kernel, dim3((unsigned)((Ra + Rb + 3) / 4)), dim3(256), 0, as_stream(stream), a, b, lse, upstream, grad_a, grad_b);
+    return check_launch("ce_pair_bwd_kernel");
 }
 
 }  // extern "C"

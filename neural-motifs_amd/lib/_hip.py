@@ -22,7 +22,7 @@ SYMBOLS = (
     'mh_version', 'mh_mfma_split', 'mh_split_rne', 'mh_split_f16', 'mh_last_error',
     'mh_nms_ws_bytes', 'mh_nms', 'mh_nms_batched_ws_bytes', 'mh_nms_batched',
     'mh_roi_align_fwd', 'mh_roi_align_bwd', 'mh_roi_align_bwd_det', 'mh_draw_union_boxes', 'mh_bbox_overlaps', 'mh_triplet_match',
-    'mh_pair_product_fwd', 'mh_pair_product_bwd', 'mh_freq_bias_add', 'mh_freq_bias_bwd',
+    'mh_pair_product_fwd', 'mh_pair_product_bwd', 'mh_freq_bias_add', 'mh_freq_bias_bwd', 'mh_ce_pair_fwd', 'mh_ce_pair_bwd',
     'mh_gemm_ws_bytes', 'mh_gemm_auto_splitk', 'mh_gemm_f32',
     'mh_planes_bytes', 'mh_make_planes', 'mh_make_planes_both', 'mh_gemm_planes_ws_bytes', 'mh_gemm_planes_auto_splitk', 'mh_gemm_planes',
     'mh_act_planes_bytes', 'mh_act_planes', 'mh_image_maxbits', 'mh_plconv_packed_bytes', 'mh_plconv_pack_weight', 'mh_plconv3x3_ws_bytes',
@@ -492,6 +492,44 @@ def freq_bias_bwd(grad_out, keys, table_rows):
     d_table = torch.empty(table_rows, P, dtype=torch.float32, device=grad_out.device)
     _check(lib().mh_freq_bias_bwd(f32(grad_out), _i64(keys), R, P, c_ll(table_rows), f32(d_table), stream()), 'mh_freq_bias_bwd')
     return d_table
+
+
+def _labels_arg(labels):
+    """(pointer, element stride) of a 1-D int64 label view (e.g. rel_labels[:, -1]: stride 4)"""
+    if labels.dtype != torch.int64 or labels.dim() != 1 or not labels.is_cuda:
+        raise HipKernelError('labels: expected a 1-D int64 CUDA (HIP) tensor')
+    stride = labels.stride(0) if labels.numel() > 1 else 1
+    if stride < 1:
+        raise HipKernelError('labels: expected a positive element stride')
+    return ctypes.c_void_p(labels.data_ptr()), c_ll(stride)          # a strided view is fine: the kernels index labels[r * stride]
+
+
+def ce_pair_fwd(logits_a, labels_a, logits_b, labels_b):
+    """the two mean cross-entropy losses -> (losses [2], lse [Ra + Rb])"""
+    Ra, Ca = logits_a.shape
+    Rb, Cb = logits_b.shape
+    dev = logits_a.device
+    lse = torch.empty(Ra + Rb, dtype=torch.float32, device=dev)
+    rowloss = torch.empty(Ra + Rb, dtype=torch.float32, device=dev)
+    losses = torch.empty(2, dtype=torch.float32, device=dev)
+    pa, sa = _labels_arg(labels_a)
+    pb, sb = _labels_arg(labels_b)
+    _check(lib().mh_ce_pair_fwd(f32(logits_a), pa, sa, Ra, Ca, f32(logits_b), pb, sb, Rb, Cb, f32(lse), f32(rowloss), f32(losses), stream()),
+           'mh_ce_pair_fwd')
+    return losses, lse
+
+
+def ce_pair_bwd(logits_a, labels_a, logits_b, labels_b, lse, upstream, need_a=True, need_b=True):
+    """-> (grad_a, grad_b) of the two mean losses; upstream [2] fp32 on the device"""
+    Ra, Ca = logits_a.shape
+    Rb, Cb = logits_b.shape
+    ga = torch.empty_like(logits_a) if need_a else None
+    gb = torch.empty_like(logits_b) if need_b else None
+    pa, sa = _labels_arg(labels_a)
+    pb, sb = _labels_arg(labels_b)
+    _check(lib().mh_ce_pair_bwd(f32(logits_a), pa, sa, Ra, Ca, f32(logits_b), pb, sb, Rb, Cb, f32(lse), f32(upstream), f32(ga), f32(gb), stream()),
+           'mh_ce_pair_bwd')
+    return ga, gb
 
 
 def bbox_overlaps(a, b):

@@ -25,6 +25,7 @@ from dataloaders.visual_genome import VGDataLoader, VG
 from lib import dist as D
 from lib.evaluation.sg_eval import BasicSceneGraphEvaluator
 from lib.optim import FusedClipSGD
+from lib.losses import relation_losses
 from lib.pytorch_misc import restore_rel_checkpoint, clip_grad_norm, print_para, quiet_gc, with_ahead
 
 conf = ModelConfig()
@@ -105,13 +106,12 @@ def train_batch(b, verbose=False, start_ahead=(), upload_ahead=()):
     for nb in upload_ahead:          # the next batch's host -> HBM copies start now, on the copy stream (dataloaders/blob.py: Blob.prefetch)
         if hasattr(nb, 'prefetch'):
             nb.prefetch()
-    l_obj = F.cross_entropy(result.rm_obj_dists, result.rm_obj_labels)
-    l_rel = F.cross_entropy(result.rel_dists, result.rel_labels[:, -1])
+    ls = relation_losses(result)          # [class_loss, rel_loss] (reference :140-141) as one autograd node: lib/losses.py
     if world > 1:      # global-mean loss semantics of the single-process reference
-        w = D.global_row_weights([result.rm_obj_labels.shape[0], result.rel_labels.shape[0]], l_obj.device)
-        loss = l_obj * w[0] + l_rel * w[1]
+        w = D.global_row_weights([result.rm_obj_labels.shape[0], result.rel_labels.shape[0]], ls.device)
+        loss = (ls * w).sum()
     else:
-        loss = l_obj + l_rel
+        loss = ls.sum()
     optimizer.zero_grad(set_to_none=True)
     reducer.prepare()
     loss.backward()          # world > 1: gradient buckets are all-reduced (RCCL) while backward is still running
@@ -127,7 +127,7 @@ def train_batch(b, verbose=False, start_ahead=(), upload_ahead=()):
     # the three losses stay on the device: reading them here (the reference's `.data[0]`, :150) would drain the GPU queue
     # every step and serialise the host's launch work of the next step with this step's kernels; train_epoch reads a whole
     # print interval at once
-    return torch.stack((l_obj.detach(), l_rel.detach(), (l_obj + l_rel).detach()))
+    return torch.cat((ls.detach(), ls.detach().sum()[None]))        # [class_loss, rel_loss, total]
 
 
 LOSS_KEYS = ('class_loss', 'rel_loss', 'total')

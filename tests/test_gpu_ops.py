@@ -675,6 +675,35 @@ def test_frequency_bias_add_forward_and_table_gradient(hip, n, R):
     assert torch.equal(t2.grad, t_d.grad)
 
 
+@pytest.mark.parametrize('Ra,Ca,Rb,Cb', [(120, 151, 1536, 51), (3, 5, 1, 2), (257, 1000, 64, 7)])
+def test_cross_entropy_pair_forward_and_backward(hip, Ra, Ca, Rb, Cb):
+    """csrc/exact_ops.hip ce_pair_* / lib/losses.py: the relation driver's two mean cross-entropy losses as one node against
+    F.cross_entropy in float64 (losses, both logit gradients with unequal upstream weights), the strided label view of
+    rel_labels[:, -1], bitwise reproducible; MOTIFS_FUSED_LOSS=0 and CPU tensors take the framework's functions."""
+    from lib.losses import _CrossEntropyPairFn
+    g = torch.Generator().manual_seed(Ra + Rb)
+    a = (torch.randn(Ra, Ca, generator=g) * 3).requires_grad_(True)
+    b = (torch.randn(Rb, Cb, generator=g) * 5).requires_grad_(True)
+    la = torch.randint(0, Ca, (Ra,), generator=g)
+    lb4 = torch.randint(0, Cb, (Rb, 4), generator=g)
+    w = torch.tensor([0.7, 1.9])
+    a_d, b_d = a.detach().cuda().requires_grad_(True), b.detach().cuda().requires_grad_(True)
+    lb_d = lb4.cuda()[:, -1]
+    assert Rb == 1 or lb_d.stride(0) == 4
+    ls = _CrossEntropyPairFn.apply(a_d, la.cuda(), b_d, lb_d)
+    (ls * w.cuda()).sum().backward()
+    ref = torch.stack((F.cross_entropy(a.double(), la), F.cross_entropy(b.double(), lb4[:, -1])))
+    (ref * w.double()).sum().backward()
+    # (a loss is lse - x[label]: fp32 cancellation bounds it absolutely, at the logits' scale, not relatively)
+    np.testing.assert_allclose(ls.detach().cpu().numpy(), ref.detach().numpy(), rtol=2e-6, atol=2e-7 * max(1.0, float(a.abs().max()), float(b.abs().max())))
+    np.testing.assert_allclose(a_d.grad.cpu().numpy(), a.grad.numpy(), atol=2e-7 * max(1.0, float(a.grad.abs().max()) * 1e3))
+    np.testing.assert_allclose(b_d.grad.cpu().numpy(), b.grad.numpy(), atol=2e-7 * max(1.0, float(b.grad.abs().max()) * 1e3))
+    a2, b2 = a.detach().cuda().requires_grad_(True), b.detach().cuda().requires_grad_(True)
+    ls2 = _CrossEntropyPairFn.apply(a2, la.cuda(), b2, lb_d)
+    (ls2 * w.cuda()).sum().backward()
+    assert torch.equal(ls2, ls) and torch.equal(a2.grad, a_d.grad) and torch.equal(b2.grad, b_d.grad)
+
+
 # ----------------------------------------------------------------------------------------------- LSTM
 def _lstm_problem(lengths, in_size, H, nl, seed, p=0.0):
     from oracle import lstm as OL
