@@ -78,6 +78,7 @@ def lib():
 def _check(rc, what):
     if rc != 0:
         msg = lib().mh_last_error()
+        drop_zeroed_workspaces()
         raise HipKernelError('%s failed with status %d: %s' % (what, rc, msg.decode() if msg else ''))
 
 
@@ -87,6 +88,7 @@ def check_faults():
     have COMPLETED -- call it after a natural sync point (loss.item(), the eval tuple's D2H copy, optimizer step)."""
     n = lib().mh_fault_pending()
     if n:
+        drop_zeroed_workspaces()
         raise HipKernelError('a persistent LSTM launch timed out in its grid barrier on %d device(s): the results of '
                              'this step are invalid (outputs were NaN-poisoned); call lib().mh_fault_clear() to re-arm' % n)
 
@@ -230,7 +232,20 @@ def zeroed_workspace(nbytes, device, tag):
     if buf is None or buf.numel() < nbytes:
         buf = torch.zeros(nbytes, dtype=torch.uint8, device=device)
         _ws_cache[key] = buf
+        _zeroed_keys.add(key)
     return buf
+
+
+_zeroed_keys = set()
+
+
+def drop_zeroed_workspaces():
+    """Forget every zero-on-allocation workspace: the next call allocates a fresh zeroed one.  Called when a launch reports an
+    error or a persistent kernel a fault -- a product that stopped half-way leaves arrival counters non-zero, and every later
+    product on that stream would skip or repeat its reduction."""
+    for key in list(_zeroed_keys):
+        _ws_cache.pop(key, None)
+    _zeroed_keys.clear()
 
 
 c_int = ctypes.c_int

@@ -191,20 +191,21 @@ class DecoderRNN(torch.nn.Module):
     def _projections(self, sequence_tensor):
         D = self.inputs_dim
         w_in, b_in, w_state, b_state = self._cell_params()
-        self._cell = (w_state, b_state)        # (a tuple: a Parameter assigned to a module attribute would register under that name)
         enc_proj = linear(sequence_tensor, w_in[:, :D], b_in)          # [N,6H]
         emb_proj = linear(self.obj_embed.weight, w_in[:, D:], None)                         # [152,6H]
-        return enc_proj, emb_proj
+        # the cell's state parameters travel with the call (with use_highway=False they are non-leaf concatenations: kept on
+        # the module they would hold the step's graph between steps and break copy.deepcopy of the model)
+        return enc_proj, emb_proj, (w_state, b_state)
 
-    def _greedy_feedback(self, enc_proj, emb_proj, batch_sizes, labels, dropout_mask):
+    def _greedy_feedback(self, enc_proj, emb_proj, cell, batch_sizes, labels, dropout_mask):
         """Sequential no-grad pass that resolves which label index is fed back at every row
         (train: the GT label, or the step's non-bg arg-max where the label is 0; eval: the arg-max)."""
         H = self.hidden_size
         if enc_proj.is_cuda and _hip.hwcell_seq_supported(H, int(batch_sizes[0])):
             with torch.no_grad():                     # one persistent launch (mh_decoder_greedy)
                 h_all, logits, fed, commits = _hip.decoder_greedy(
-                    enc_proj.contiguous(), emb_proj.contiguous(), batch_sizes, self._cell[0].detach().contiguous(),
-                    self._cell[1].detach(), dropout_mask, self.out.weight.contiguous(), self.out.bias,
+                    enc_proj.contiguous(), emb_proj.contiguous(), batch_sizes, cell[0].detach().contiguous(),
+                    cell[1].detach(), dropout_mask, self.out.weight.contiguous(), self.out.bias,
                     None if labels is None else labels.contiguous())
             self._greedy_states = (h_all, logits)
             return fed, commits
@@ -214,7 +215,7 @@ class DecoderRNN(torch.nn.Module):
             h_prev = c_prev = enc_proj.new_zeros(B, H)
             prev = torch.zeros(B, dtype=torch.long, device=enc_proj.device)      # 'start'
             fed, commits = [], []
-            w_state, b_state = self._cell[0].detach().contiguous(), self._cell[1].detach()
+            w_state, b_state = cell[0].detach().contiguous(), cell[1].detach()
             for s, e, n in _step_bounds(batch_sizes):
                 fed.append(prev[:n])
                 pre_i = enc_proj[s:e] + emb_proj.index_select(0, prev[:n])
@@ -245,7 +246,7 @@ class DecoderRNN(torch.nn.Module):
         if self.recurrent_dropout_probability > 0.0:
             m = get_dropout_mask(self.recurrent_dropout_probability, (B, self.hidden_size), sequence_tensor.device)
             dropout_mask = m if self.training else None            # reference :126-130 applies it in train only
-        enc_proj, emb_proj = self._projections(sequence_tensor)
+        enc_proj, emb_proj, cell = self._projections(sequence_tensor)
 
         if self.training:
             if labels is None:
@@ -253,7 +254,7 @@ class DecoderRNN(torch.nn.Module):
             if labels_have_background is None:                      # unknown on the host: ask the device (synchronises)
                 labels_have_background = bool((labels == 0).any())
             if labels_have_background:
-                fed, commits = self._greedy_feedback(enc_proj.detach(), emb_proj.detach(), batch_sizes, labels,
+                fed, commits = self._greedy_feedback(enc_proj.detach(), emb_proj.detach(), cell, batch_sizes, labels,
                                                      dropout_mask)
             else:
                 # prev label of row r at step t is the label of the same sequence at step t-1
@@ -263,7 +264,7 @@ class DecoderRNN(torch.nn.Module):
         else:
             for n in batch_sizes:
                 assert n == 1, 'eval decodes one image at a time (reference :215)'
-            fed, commits = self._greedy_feedback(enc_proj.detach(), emb_proj.detach(), batch_sizes, None, None)
+            fed, commits = self._greedy_feedback(enc_proj.detach(), emb_proj.detach(), cell, batch_sizes, None, None)
             if getattr(self, '_greedy_states', None) is not None and not torch.is_grad_enabled():
                 # the fused launch already produced the states and the class logits of every row: no second pass
                 out_dists = self._greedy_states[1]
@@ -272,8 +273,9 @@ class DecoderRNN(torch.nn.Module):
                     commits = self._nms_commitments(out_dists, boxes_for_nms)
                 return out_dists, commits
 
+        self._greedy_states = None
         pre_i_all = enc_proj + emb_proj.index_select(0, fed)
-        h_all = _DecoderRecurrenceFn.apply(pre_i_all, self._cell[0], self._cell[1],
+        h_all = _DecoderRecurrenceFn.apply(pre_i_all, cell[0], cell[1],
                                            dropout_mask, batch_sizes)
         out_dists = self.out(h_all)
 

@@ -351,6 +351,7 @@ class LinearizedContext(nn.Module):
             edge_ctx = self.edge_ctx(torch.cat((obj_fmaps, obj_ctx), 1) if self.pass_in_obj_feats_to_edge else obj_ctx,
                                      obj_dists=obj_dists2.detach(), im_inds=im_inds, obj_preds=obj_preds,
                                      box_priors=box_priors)
+        self._order_cache = None          # the batch's tensors are not kept on the module between forwards
         return obj_dists2, obj_preds, edge_ctx
 
 

@@ -771,6 +771,11 @@ def test_plain_lstm_decoder_cell_runs_on_the_highway_kernels(shim):
                 np.testing.assert_allclose(v.grad.numpy(), p[k].grad.numpy(), atol=5e-5 * max(1.0, float(p[k].grad.abs().max())), err_msg=k)
             np.testing.assert_allclose(dec.obj_embed.weight.grad.numpy(), p['obj_embed.weight'].grad.numpy(),
                                        atol=5e-5 * max(1.0, float(p['obj_embed.weight'].grad.abs().max())))
+        # nothing of the step stays on the module: the padded cell parameters are non-leaf tensors (a kept one would hold the
+        # step's graph and make copy.deepcopy raise), the greedy pass's states belong to the call
+        import copy
+        assert not [k for k, v in vars(dec).items() if torch.is_tensor(v) or (isinstance(v, tuple) and any(map(torch.is_tensor, v)))]
+        copy.deepcopy(dec)
 
 
 def test_detector_stage_one_batch_ahead_on_the_cpu_shim(small_world):
@@ -916,3 +921,25 @@ def test_leader_per_key_sum_is_an_ordered_index_add():
         ref = np.zeros((nkeys, 51), np.float64)
         np.add.at(ref, keys, g.astype(np.float64))
         np.testing.assert_allclose(table, ref, atol=1e-5)
+
+
+def test_a_failed_launch_forgets_the_zero_on_allocation_workspaces(shim, monkeypatch):
+    """the arrival counters of the small-product engine and the ring conv live in workspaces zeroed only when allocated; a launch
+    that reports an error (or a persistent kernel's fault) may have left them non-zero, so the binding drops them and the next
+    call gets a fresh zeroed buffer (csrc/gemm.hip ticket counters)"""
+    from lib import _hip
+    w = _hip.zeroed_workspace(1024, 'cpu', 'unit-test')
+    assert w is _hip.zeroed_workspace(512, 'cpu', 'unit-test') and int(w.sum()) == 0
+    w[3] = 7                                                    # a product that stopped half-way
+    plain = _hip.workspace(256, torch.device('cpu'), 'unit-test-plain') if hasattr(_hip, 'workspace') else None
+
+    class _L(object):
+        def mh_last_error(self):
+            return b'injected'
+    monkeypatch.setattr(_hip, 'lib', lambda: _L())
+    with pytest.raises(_hip.HipKernelError, match='injected'):
+        _hip._check(1, 'unit test')
+    w2 = _hip.zeroed_workspace(1024, 'cpu', 'unit-test')
+    assert w2 is not w and int(w2.sum()) == 0
+    if plain is not None:                                       # ordinary workspaces stay
+        assert plain is _hip.workspace(256, torch.device('cpu'), 'unit-test-plain')
