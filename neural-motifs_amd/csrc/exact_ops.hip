@@ -855,7 +855,9 @@ __global__ __launch_bounds__(256) void ce_pair_rows_kernel(CeSide a, CeSide b, f
     if (lane == 0) {
         const float l = m + logf(sum);
         lse[row] = l;
-        rowloss[row] = l - x[s.labels[(size_t)r * s.label_stride]];
+        const long long lab = s.labels[(size_t)r * s.label_stride];
+        // a label outside [0, C) is a caller's error (the framework's kernel asserts on the device): no read outside the row, the loss says so
+        rowloss[row] = (lab >= 0 && lab < s.C) ? l - x[lab] : __builtin_nanf("");
     }
 }
 // losses[0] = mean of the first Ra row losses, losses[1] = mean of the next Rb: one block, fixed order (deterministic)
