@@ -702,6 +702,11 @@ def test_cross_entropy_pair_forward_and_backward(hip, Ra, Ca, Rb, Cb):
     ls2 = _CrossEntropyPairFn.apply(a2, la.cuda(), b2, lb_d)
     (ls2 * w.cuda()).sum().backward()
     assert torch.equal(ls2, ls) and torch.equal(a2.grad, a_d.grad) and torch.equal(b2.grad, b_d.grad)
+    # a label outside the row: the loss of that side is NaN (no read outside the logits), the other side's is untouched
+    bad = la.clone()
+    bad[0] = Ca
+    ls3 = _CrossEntropyPairFn.apply(a.detach().cuda(), bad.cuda(), b.detach().cuda(), lb_d)
+    assert bool(torch.isnan(ls3[0])) and torch.equal(ls3[1], ls[1])
 
 
 # ----------------------------------------------------------------------------------------------- LSTM
