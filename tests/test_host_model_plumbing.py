@@ -943,3 +943,25 @@ def test_a_failed_launch_forgets_the_zero_on_allocation_workspaces(shim, monkeyp
     assert w2 is not w and int(w2.sum()) == 0
     if plain is not None:                                       # ordinary workspaces stay
         assert plain is _hip.workspace(256, torch.device('cpu'), 'unit-test-plain')
+
+
+def test_relation_losses_on_cpu_tensors_are_the_frameworks_cross_entropies(shim):
+    """lib/losses.py: the fused node serves fp32 CUDA logits with int64 labels only; everything else (CPU tensors here) is the
+    stack of the two F.cross_entropy calls of the reference's script (models/train_rels.py:140-141), the relation label being the
+    LAST column of rel_labels -- values and both gradients"""
+    from collections import namedtuple
+    import torch.nn.functional as F
+    from lib import losses
+    R = namedtuple('R', 'rm_obj_dists rm_obj_labels rel_dists rel_labels')
+    g = torch.Generator().manual_seed(3)
+    a = torch.randn(7, 151, generator=g, requires_grad=True)
+    b = torch.randn(11, 51, generator=g, requires_grad=True)
+    la = torch.randint(0, 151, (7,), generator=g)
+    lb = torch.randint(0, 51, (11, 4), generator=g)
+    ls = losses.relation_losses(R(a, la, b, lb))
+    assert tuple(ls.shape) == (2,)
+    (ls * torch.tensor([0.25, 2.0])).sum().backward()
+    a2, b2 = a.detach().clone().requires_grad_(True), b.detach().clone().requires_grad_(True)
+    (0.25 * F.cross_entropy(a2, la) + 2.0 * F.cross_entropy(b2, lb[:, -1])).backward()
+    assert torch.equal(ls.detach(), torch.stack((F.cross_entropy(a2, la), F.cross_entropy(b2, lb[:, -1]))).detach())
+    assert torch.equal(a.grad, a2.grad) and torch.equal(b.grad, b2.grad)
