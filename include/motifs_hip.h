@@ -134,7 +134,9 @@ int mh_freq_bias_bwd(const float *grad_out, const long long *keys, int R, int P,
  * two launches, their backward in one.  logits_x [Rx][Cx] fp32 contiguous; label of row r at labels_x[r * stride_x] (int64,
  * 0 <= label < Cx).  Forward: lse [Ra + Rb] (log-sum-exp per row, kept for the backward pass), rowloss [Ra + Rb] (scratch),
  * losses [2] = the two means (summed in a fixed order).  Backward: grad_x[r][c] = (exp(x - lse_r) - [c == label_r]) * upstream[x] / Rx,
- * upstream [2] on the device; a NULL grad pointer skips that side. */
+ * upstream [2] on the device; a NULL grad pointer skips that side.  A label outside [0, Cx) is the caller's error: nothing is read
+ * outside the row and that side's loss is NaN (the framework's kernel asserts on the device; ignore_index is not implemented -- the
+ * reference's labels never use it). */
 int mh_ce_pair_fwd(const float *logits_a, const long long *labels_a, long long stride_a, int Ra, int Ca, const float *logits_b,
                    const long long *labels_b, long long stride_b, int Rb, int Cb, float *lse, float *rowloss, float *losses, void *stream);
 int mh_ce_pair_bwd(const float *logits_a, const long long *labels_a, long long stride_a, int Ra, int Ca, const float *logits_b,
